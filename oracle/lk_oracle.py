@@ -1,0 +1,403 @@
+"""
+CPU oracle for the LensKit hot path -- TEST INFRASTRUCTURE ONLY.
+
+Python face of ``oracle/lk_oracle.c`` (the C restatement of the reference's Rust
+accelerator) plus NumPy/SciPy restatements of the reference's *Python* half of
+the path (matrix preparation, initialisation, Gramian, fold-in, item-kNN
+normalisation).  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module; the product package ``lkpy_amd``
+never does.
+
+Pinning status (details in oracle/README.md):
+
+* item-kNN build + scoring: PINNED by the reference's golden vector
+  ``tests/models/item-item-preds.csv`` (committed as
+  ``tests/golden/item-item-preds.csv``) and the closed-form checks of
+  ``tests/models/test_knn_item_item.py:106-162``.
+* top-N: PINNED by the Rust unit tests ``src/accel/indirect/heap.rs:105-162`` and
+  the properties of ``tests/accel/test_argsort.py:60-211``.
+* implicit-ALS factors: **parity unpinned at bit level** -- the reference holds no
+  golden factors and the arithmetic inside LAPACK
+  ``sposv`` (SciPy's bundled OpenBLAS) and ndarray's ``dot`` is third-party.  The
+  oracle calls the *same* ``sposv`` function pointer the reference resolves
+  (``src/accel/als/solve.rs:47-59``), and is checked against the behavioural
+  tests of ``tests/models/test_als_implicit.py``.
+
+All ``file:line`` citations are relative to ``/root/reference``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import scipy.sparse as sps
+import scipy.sparse.linalg as spla
+from scipy.linalg import cho_factor, cho_solve
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_f32p = ctypes.POINTER(ctypes.c_float)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build():
+    "Compile the C restatement (gcc + OpenMP)."
+    subprocess.check_call(["make", "-s", "-C", str(_HERE)])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = _HERE / "liblkoracle.so"
+        if not so.exists():
+            build()
+        _LIB = ctypes.CDLL(str(so))
+        _LIB.lko_num_threads.restype = ctypes.c_int
+        _LIB.lko_argtopn.restype = ctypes.c_int64
+        _LIB.lko_free.argtypes = [ctypes.c_void_p]
+    return _LIB
+
+
+def num_threads() -> int:
+    return int(lib().lko_num_threads())
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _sposv_pointer() -> int:
+    """
+    Resolve LAPACK ``sposv`` exactly as the reference does: the Cython capsule
+    ``scipy.linalg.cython_lapack.__pyx_capi__["sposv"]`` (``src/accel/cython.rs:16-46``,
+    ``src/accel/als/solve.rs:47-59``).
+    """
+    import scipy.linalg.cython_lapack as cl
+
+    cap = cl.__pyx_capi__["sposv"]
+    ctypes.pythonapi.PyCapsule_GetName.restype = ctypes.c_char_p
+    ctypes.pythonapi.PyCapsule_GetName.argtypes = [ctypes.py_object]
+    ctypes.pythonapi.PyCapsule_GetPointer.restype = ctypes.c_void_p
+    ctypes.pythonapi.PyCapsule_GetPointer.argtypes = [ctypes.py_object, ctypes.c_char_p]
+    name = ctypes.pythonapi.PyCapsule_GetName(cap)
+    return ctypes.pythonapi.PyCapsule_GetPointer(cap, name)
+
+
+# --------------------------------------------------------------------------
+# implicit ALS
+# --------------------------------------------------------------------------
+
+
+def implicit_otor(other: np.ndarray, reg: float) -> np.ndarray:
+    "``_implicit_otor`` (src/lenskit/als/_implicit.py:177-184): OtO + reg*I via NumPy."
+    nf = other.shape[1]
+    regmat = np.eye(nf, dtype=other.dtype)
+    regmat *= reg
+    OtO = other.T @ other
+    OtO += regmat
+    return OtO
+
+
+def als_half_epoch(
+    matrix: sps.csr_array, this: np.ndarray, other: np.ndarray, otor: np.ndarray, n_threads=0
+) -> float:
+    """
+    ``train_implicit_matrix`` (src/accel/als/implicit.rs:35-125): one half-epoch;
+    ``this`` is updated IN PLACE, returns sqrt(sum ||delta row||^2) (f32).
+    """
+    assert this.dtype == np.float32 and this.flags.c_contiguous and this.flags.writeable
+    other = np.ascontiguousarray(other, dtype=np.float32)
+    otor = np.ascontiguousarray(otor, dtype=np.float32)
+    n_rows, k = this.shape
+    assert matrix.shape[0] == n_rows and other.shape == (matrix.shape[1], k)
+    indptr = np.ascontiguousarray(matrix.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(matrix.indices, dtype=np.int32)
+    values = np.ascontiguousarray(matrix.data, dtype=np.float32)
+    frob = ctypes.c_float(0.0)
+    rc = lib().lko_als_implicit_half_epoch(
+        ctypes.c_void_p(_sposv_pointer()),
+        _p(indptr, _i64p),
+        _p(indices, _i32p),
+        _p(values, _f32p),
+        ctypes.c_int64(n_rows),
+        ctypes.c_int(k),
+        _p(this, _f32p),
+        _p(other, _f32p),
+        _p(otor, _f32p),
+        ctypes.c_int(n_threads),
+        ctypes.byref(frob),
+    )
+    if rc != 0:
+        # implicit.rs:79 -> RuntimeError("ALS solve error: ...")
+        raise RuntimeError(f"ALS solve error: LAPACK info {rc}")
+    return float(frob.value)
+
+
+def als_initial_params(rng: np.random.Generator, nrows: int, ncols: int) -> np.ndarray:
+    "``ImplicitMFTrainer.initial_params`` (src/lenskit/als/_implicit.py:152-155)."
+    mat = rng.standard_normal((nrows, ncols), dtype=np.float32) * 0.01
+    mat *= mat
+    return mat
+
+
+def als_prepare_matrix(rmat: sps.coo_array, weight: float = 40.0) -> sps.coo_array:
+    "``ImplicitMFTrainer.prepare_matrix`` (src/lenskit/als/_implicit.py:141-149)."
+    vals = np.require(rmat.data, dtype=np.float32) * weight
+    return sps.coo_array((vals, (rmat.row, rmat.col)), shape=rmat.shape)
+
+
+class ALSState:
+    "What the reference leaves on the scorer after training."
+
+    def __init__(self):
+        self.user_embeddings = None
+        self.item_embeddings = None
+        self.OtOr = None
+        self.deltas = []
+
+
+def als_train(
+    rmat: sps.coo_array,
+    k: int,
+    epochs: int,
+    rng,
+    reg: float | tuple[float, float] = 0.1,
+    weight: float = 40.0,
+    n_threads: int = 0,
+    callback=None,
+) -> ALSState:
+    """
+    ``ALSTrainerBase.__init__`` + ``train_epoch`` loop + ``finalize``
+    (src/lenskit/als/_common.py:209-256,287-301; _implicit.py:135-175):
+    item matrix initialised FIRST, then the user matrix, from the same generator;
+    epoch = user half with the previous Q, then item half with the new P;
+    OtOr recomputed before each half with that half's own regulariser.
+
+    ``rmat``: users x items interaction matrix (values 1 or ratings), COO.
+    ``rng``: seed / SeedSequence / Generator, as ``np.random.default_rng`` takes
+    (``src/lenskit/random.py:181-185``).
+    """
+    ureg, ireg = (reg, reg) if np.isscalar(reg) else reg
+    rng = np.random.default_rng(rng)
+    ui = als_prepare_matrix(rmat, weight)
+    ui_csr = sps.csr_array(ui)  # SparseRowArray.from_scipy(ui_rates)   (_common.py:218)
+    iu_csr = sps.csr_array(ui.T)  # SparseRowArray.from_scipy(ui_rates.T) (_common.py:219)
+    ui_csr.sort_indices()
+    iu_csr.sort_indices()
+    n_users, n_items = ui_csr.shape
+    st = ALSState()
+    st.item_embeddings = als_initial_params(rng, n_items, k)  # items first (_common.py:291-294)
+    st.user_embeddings = als_initial_params(rng, n_users, k)
+    for ep in range(epochs):
+        otor = implicit_otor(st.item_embeddings, ureg)
+        du = als_half_epoch(ui_csr, st.user_embeddings, st.item_embeddings, otor, n_threads)
+        otor = implicit_otor(st.user_embeddings, ireg)
+        di = als_half_epoch(iu_csr, st.item_embeddings, st.user_embeddings, otor, n_threads)
+        st.deltas.append((du, di))
+        st.OtOr = implicit_otor(st.item_embeddings, ureg)  # _save_user_otor (_implicit.py:171-175)
+        if callback is not None:
+            callback(ep, st)
+    st.OtOr = implicit_otor(st.item_embeddings, ureg)
+    return st
+
+
+def als_fold_in(items: np.ndarray, ratings: np.ndarray, i_embeds: np.ndarray, OtOr: np.ndarray):
+    """
+    ``ImplicitMFScorer._train_new_row`` (src/lenskit/als/_implicit.py:101-130) with
+    ``solve_cholesky`` (src/lenskit/math/solve.py:17-41).
+    """
+    ratings = np.asarray(ratings, dtype=i_embeds.dtype)
+    M = i_embeds[items, :]
+    MMT = (M.T * ratings) @ M
+    A = OtOr + MMT
+    y = i_embeds.T[:, items] @ (ratings + 1.0)
+    L, low = cho_factor(A)
+    return np.require(cho_solve((L, low), y), dtype=A.dtype)
+
+
+def score_dense(q: np.ndarray, u: np.ndarray) -> np.ndarray:
+    "Scores in a fixed k-ordered f32 fmaf chain (see lk_oracle.c lko_score_dense)."
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    u = np.ascontiguousarray(u, dtype=np.float32)
+    out = np.empty(q.shape[0], dtype=np.float32)
+    lib().lko_score_dense(
+        _p(q, _f32p), ctypes.c_int64(q.shape[0]), ctypes.c_int(q.shape[1]), _p(u, _f32p),
+        _p(out, _f32p)
+    )
+    return out
+
+
+# --------------------------------------------------------------------------
+# top-N
+# --------------------------------------------------------------------------
+
+
+def argtopn(scores: np.ndarray, n: int, valid: np.ndarray | None = None) -> np.ndarray:
+    """
+    ``argtopn`` (src/accel/data/sorting.rs:132-172) with the indirect min-heap of
+    src/accel/indirect/heap.rs.  NaN (and invalid) scores are skipped; result is
+    sorted by score descending.  ``n <= 0`` returns an empty array, like the Rust.
+    """
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    ln = len(scores)
+    if n <= 0 or ln == 0:
+        return np.empty(0, dtype=np.int32)
+    out = np.empty(min(n, ln), dtype=np.int32)
+    vp = None
+    if valid is not None:
+        valid = np.ascontiguousarray(valid, dtype=np.uint8)
+        vp = _p(valid, _u8p)
+    m = lib().lko_argtopn(
+        _p(scores, _f32p), vp, ctypes.c_int64(ln), ctypes.c_int64(n), _p(out, _i32p)
+    )
+    return out[:m]
+
+
+def argsort_descending(scores: np.ndarray) -> np.ndarray:
+    """
+    ``argsort_descending`` (src/accel/data/sorting.rs:69-103): NaN dropped, sorted by
+    score descending.  The reference sort is unstable (tie order unspecified); the
+    oracle breaks ties by lower index.
+    """
+    scores = np.asarray(scores, dtype=np.float32)
+    idx = np.flatnonzero(~np.isnan(scores)).astype(np.int32)
+    order = np.argsort(-scores[idx], kind="stable")
+    return idx[order]
+
+
+# --------------------------------------------------------------------------
+# item-kNN
+# --------------------------------------------------------------------------
+
+
+def iknn_prepare(rmat: sps.coo_array, explicit: bool = True):
+    """
+    ``ItemKNNScorer.train`` preparation (src/lenskit/knn/item.py:142-156,202-228):
+    item-mean centring (explicit only) and per-item L2 normalisation with SciPy,
+    call for call; returns (ui_csr, iu_csr, item_means | None, all_zero_flag).
+    """
+    rmat = sps.coo_array(rmat).astype(np.float32)
+    means = None
+    all_zero = False
+    if explicit:
+        rmat = rmat.tocsc()
+        counts = np.diff(rmat.indptr)
+        sums = rmat.sum(axis=0)
+        means = np.zeros(sums.shape, dtype=np.float32)
+        np.divide(sums, counts, out=means, where=counts > 0)
+        rmat.data = rmat.data - np.repeat(means, counts)
+        all_zero = bool(np.allclose(rmat.data, 0.0))
+    norms = spla.norm(rmat, 2, axis=0)
+    cmat = rmat / np.maximum(norms, np.finfo("f4").smallest_normal)
+    cmat = cmat.astype(np.float32)
+    ui = sps.csr_array(cmat.tocsr())
+    iu = sps.csr_array(cmat.T.tocsr())
+    ui.sort_indices()
+    iu.sort_indices()
+    return ui, iu, (None if means is None else np.asarray(means)), all_zero
+
+
+def iknn_build(
+    ui: sps.csr_array, iu: sps.csr_array, min_sim: float = 1.0e-6, save_nbrs=None, n_threads=0
+) -> sps.csr_array:
+    """
+    ``compute_similarities`` (src/accel/knn/item_train.rs:33-152): returns the
+    similarity matrix as CSR with int64 offsets, rows sorted by column.
+    """
+    n_users, n_items = ui.shape
+    assert iu.shape == (n_items, n_users)
+    uip = np.ascontiguousarray(ui.indptr, dtype=np.int64)
+    uii = np.ascontiguousarray(ui.indices, dtype=np.int32)
+    uiv = np.ascontiguousarray(ui.data, dtype=np.float32)
+    iup = np.ascontiguousarray(iu.indptr, dtype=np.int64)
+    iui = np.ascontiguousarray(iu.indices, dtype=np.int32)
+    iuv = np.ascontiguousarray(iu.data, dtype=np.float32)
+    out_ptr = np.empty(n_items + 1, dtype=np.int64)
+    oi = _i32p()
+    ov = _f32p()
+    lib().lko_iknn_build(
+        _p(uip, _i64p), _p(uii, _i32p), _p(uiv, _f32p),
+        _p(iup, _i64p), _p(iui, _i32p), _p(iuv, _f32p),
+        ctypes.c_int64(n_users), ctypes.c_int64(n_items),
+        ctypes.c_float(np.float32(min_sim)),  # cast to f32 at the boundary (item_train.rs:37)
+        ctypes.c_int64(-1 if save_nbrs is None else int(save_nbrs)),
+        ctypes.c_int(n_threads),
+        _p(out_ptr, _i64p), ctypes.byref(oi), ctypes.byref(ov),
+    )  # fmt: skip
+    nnz = int(out_ptr[-1])
+    idx = np.ctypeslib.as_array(oi, shape=(max(nnz, 1),))[:nnz].copy()
+    val = np.ctypeslib.as_array(ov, shape=(max(nnz, 1),))[:nnz].copy()
+    lib().lko_free(oi)
+    lib().lko_free(ov)
+    return sps.csr_array((val, idx, out_ptr), shape=(n_items, n_items))
+
+
+def iknn_score(
+    sims: sps.csr_array,
+    ref_items: np.ndarray,
+    ref_rates: np.ndarray | None,
+    tgt_items: np.ndarray,
+    max_nbrs: int,
+    min_nbrs: int,
+):
+    """
+    ``score_explicit`` (``ref_rates`` given) / ``score_implicit`` (``None``)
+    (src/accel/knn/item_score.rs:23-111).  Negative ``ref_items``/``tgt_items`` are
+    nulls.  Returns (scores f32 with NaN for null, counts i32 with -1 for null).
+    """
+    n_items = sims.shape[0]
+    sp = np.ascontiguousarray(sims.indptr, dtype=np.int64)
+    si = np.ascontiguousarray(sims.indices, dtype=np.int32)
+    sv = np.ascontiguousarray(sims.data, dtype=np.float32)
+    ri = np.ascontiguousarray(ref_items, dtype=np.int32)
+    explicit = ref_rates is not None
+    rr = np.ascontiguousarray(ref_rates if explicit else np.zeros(len(ri)), dtype=np.float32)
+    ti = np.ascontiguousarray(tgt_items, dtype=np.int32)
+    scores = np.empty(len(ti), dtype=np.float32)
+    valid = np.empty(len(ti), dtype=np.uint8)
+    counts = np.empty(len(ti), dtype=np.int32)
+    rc = lib().lko_iknn_score(
+        _p(sp, _i64p), _p(si, _i32p), _p(sv, _f32p), ctypes.c_int64(n_items),
+        _p(ri, _i32p), _p(rr, _f32p), ctypes.c_int64(len(ri)),
+        _p(ti, _i32p), ctypes.c_int64(len(ti)),
+        ctypes.c_int(max_nbrs), ctypes.c_int(min_nbrs), ctypes.c_int(1 if explicit else 0),
+        _p(scores, _f32p), _p(valid, _u8p), _p(counts, _i32p),
+    )  # fmt: skip
+    if rc:
+        raise ValueError("similarity is null")  # accum.rs:146-151
+    scores[valid == 0] = np.nan
+    return scores, counts
+
+
+# --------------------------------------------------------------------------
+# fixtures
+# --------------------------------------------------------------------------
+
+
+def load_ml_small(path=None):
+    """
+    The ml-latest-small fixture as the reference's ``ml_ds`` sees it
+    (``src/lenskit/testing/_movielens.py:46-103``): items = every movies.csv id,
+    sorted (``src/lenskit/data/_builder.py:345-346``); users = sorted rating user ids;
+    interactions sorted by (user, item).  Returns a dict with ``user_ids``,
+    ``item_ids`` (vocabularies) and ``rmat`` (users x items COO of ratings, f32).
+    """
+    if path is None:
+        path = _HERE.parent / "tests" / "golden" / "ml_small.npz"
+    z = np.load(path)
+    user_ids = np.unique(z["user_id"])
+    item_ids = np.unique(z["all_item_ids"])
+    rows = np.searchsorted(user_ids, z["user_id"]).astype(np.int32)
+    cols = np.searchsorted(item_ids, z["item_id"]).astype(np.int32)
+    order = np.lexsort((cols, rows))
+    rmat = sps.coo_array(
+        (z["rating"][order].astype(np.float32), (rows[order], cols[order])),
+        shape=(len(user_ids), len(item_ids)),
+    )
+    return {"user_ids": user_ids, "item_ids": item_ids, "rmat": rmat}
