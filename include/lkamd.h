@@ -1,0 +1,215 @@
+/*
+ * lkamd.h -- C ABI of the MI355X (gfx950) backend for LensKit's hot path.
+ *
+ * Every entry point replaces one function of the reference's native module
+ * `lenskit._accel` (Rust/PyO3) or the NumPy call next to it; the reference
+ * interface each one stands in for is cited as file:line relative to the
+ * lenskit/lkpy checkout.  Plain pointers and sizes only: no torch / Arrow /
+ * Python types cross this boundary.  INTEGRATION.md shows the binding a
+ * LensKit maintainer would add on the reference side.
+ *
+ * Conventions
+ *  - `d_` pointers are DEVICE pointers (HBM); `h_` pointers are HOST pointers.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *    device entry points are asynchronous on that stream unless stated.
+ *  - Return value: 0 on success, negative LK_E_* code on failure;
+ *    lk_last_error() returns a thread-local message for the last failure.
+ *  - CSR: `indptr` has n_rows+1 entries, int32 or int64 (`indptr_is_64`);
+ *    `indices` int32; `values` float32.  This is the layout of the
+ *    reference's SparseRowArray (src/lenskit/data/matrix.py:318-539; Rust view
+ *    src/accel/sparse/csr.rs:44-223): Arrow List<Struct{index:i32,value:f32}>
+ *    (int32 offsets) or LargeList (int64 offsets).
+ *  - Factor matrices are row-major float32 with an explicit leading dimension
+ *    `ld` (floats).  The kernels require ld == lk_padded_dim(k) and the pad
+ *    columns [k, ld) to be zero; lk_pad_rows / lk_unpad_rows convert.
+ */
+#ifndef LKAMD_H
+#define LKAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LK_OK 0
+#define LK_E_INVALID (-1)   /* bad argument (shape, k, null pointer) */
+#define LK_E_HIP (-2)       /* HIP runtime error */
+#define LK_E_NOT_SPD (-3)   /* ALS normal matrix not positive definite
+                               (reference: RuntimeError("ALS solve error: ..."),
+                               src/accel/als/implicit.rs:79, solve.rs:99-105) */
+#define LK_E_NAN_SIM (-4)   /* NaN similarity (reference: ValueError("similarity is
+                               null"), src/accel/knn/accum.rs:146-151) */
+#define LK_E_NOMEM (-5)
+#define LK_E_CANCELLED (-6) /* cooperative cancel (AccelTask.cancel(),
+                               src/accel/tasks/mod.rs:88-95) */
+
+#define LK_SOLVER_CHOLESKY 0 /* exact SPD solve: the reference's method (LAPACK sposv) */
+#define LK_SOLVER_CG 1       /* tolerance-terminated conjugate gradient */
+#define LK_SOLVER_AUTO 2     /* Cholesky for k <= 64, CG above */
+
+const char *lk_last_error(void);
+const char *lk_version(void);
+/* Number of visible HIP devices (0 when there is no GPU / no driver). */
+int lk_device_count(void);
+
+/* Padded embedding width used on the device for `k` features:
+ * the next of {16, 32, 64, 128, 256}; 0 if k is unsupported (k < 1 or k > 256). */
+int32_t lk_padded_dim(int32_t k);
+
+/* Copy an [n x k] row-major matrix (leading dimension ld_src) into an
+ * [n x ld_dst] one, zero-filling columns [k, ld_dst); and the inverse. */
+int lk_pad_rows(const float *d_src, int64_t n, int32_t k, int32_t ld_src, float *d_dst,
+                int32_t ld_dst, void *stream);
+int lk_unpad_rows(const float *d_src, int64_t n, int32_t k, int32_t ld_src, float *d_dst,
+                  int32_t ld_dst, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Gramian:  out = M^T M + reg * I          (k x k, row-major, ld_out floats)
+ * Replaces `_implicit_otor` (src/lenskit/als/_implicit.py:177-184), a NumPy
+ * sgemm in the reference.  `d_ws` must hold lk_gramian_workspace_bytes(k).
+ * Deterministic (fixed reduction order); the result is exactly symmetric.
+ * ---------------------------------------------------------------------- */
+size_t lk_gramian_workspace_bytes(int32_t k);
+int lk_gramian(const float *d_m, int64_t n, int32_t k, int32_t ld, float reg, float *d_out,
+               int32_t ld_out, void *d_ws, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Implicit-feedback ALS half-epoch.
+ * Replaces `lenskit._accel.als.train_implicit_matrix(matrix, this, other, otor)`
+ * (src/lenskit/_accel/als.pyi:11-16; src/accel/als/implicit.rs:35-125 with
+ * src/accel/als/solve.rs:65-107):  for every CSR row r
+ *     A = otor + sum_j v_j q_j q_j^T,  y = sum_j (v_j + 1) q_j,  x = A^-1 y,
+ *     this[r] <- x        (empty row: this[r] <- 0, contributes 0 to the delta)
+ * and *d_out_frob = sqrt(sum_r ||x - this_old[r]||^2)  (float32, on device).
+ *
+ * A plan (row schedule: longest-first order, split of very long rows into
+ * chunks, workspace layout) is built ONCE per matrix from the HOST copy of
+ * indptr and reused for every epoch.
+ * ---------------------------------------------------------------------- */
+typedef struct lk_als_plan lk_als_plan;
+
+int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int indptr_is_64, int64_t n_rows,
+                       int32_t k, int32_t solver);
+void lk_als_plan_destroy(lk_als_plan *plan);
+/* Device workspace the half-epoch needs (bytes); allocate once, reuse. */
+size_t lk_als_plan_workspace_bytes(const lk_als_plan *plan);
+/* Effective solver of the plan (LK_SOLVER_CHOLESKY or LK_SOLVER_CG). */
+int32_t lk_als_plan_solver(const lk_als_plan *plan);
+
+/* CG controls (ignored by the Cholesky solver): stop when ||r|| <= tol*||y|| or
+ * after max_iter iterations (<=0: k iterations).  Defaults 1e-7 / k. */
+int lk_als_plan_set_cg(lk_als_plan *plan, float tol, int32_t max_iter);
+
+int lk_als_implicit_half_epoch(const lk_als_plan *plan, const void *d_indptr,
+                               const int32_t *d_indices, const float *d_values, int64_t n_rows,
+                               int64_t n_cols, int32_t k, float *d_this, int32_t ld_this,
+                               const float *d_other, int32_t ld_other, const float *d_otor,
+                               int32_t ld_otor, void *d_ws, float *d_out_frob, void *stream);
+/* Synchronise `stream` and translate the device status word of the last
+ * half-epoch into a return code (LK_E_NOT_SPD with the offending row in
+ * lk_last_error()).  Call before trusting `this`. */
+int lk_als_check_status(const lk_als_plan *plan, void *d_ws, void *stream);
+
+/* Host-pointer convenience form with the reference's exact argument list
+ * (this: [n_rows x k] updated in place, other: [n_cols x k], otor: [k x k], all
+ * C-contiguous host float32).  Allocates, copies, runs, copies back; blocking. */
+int lk_als_implicit_half_epoch_host(const void *h_indptr, int indptr_is_64,
+                                    const int32_t *h_indices, const float *h_values,
+                                    int64_t n_rows, int64_t n_cols, int32_t k, float *h_this,
+                                    const float *h_other, const float *h_otor, int32_t solver,
+                                    float *h_out_frob);
+
+/* ------------------------------------------------------------------------
+ * Item-item similarity build.
+ * Replaces `lenskit._accel.knn.compute_similarities(ui, iu, shape, min_sim,
+ * save_nbrs)` (src/lenskit/_accel/knn.pyi:8-14; src/accel/knn/item_train.rs:33-152
+ * + src/accel/sparse/consumer.rs:24-142): for each item i,
+ *     dots[j] = sum over users u of i (ascending u) of a_ui * a_uj   (j != i)
+ * accumulated in f32 as round(a_ui*a_uj) then add -- the reference's order and
+ * rounding, so values are bit-identical -- keep dots[j] >= min_sim, optional
+ * per-row top-`save_nbrs` (by similarity, ties by first encounter), rows sorted
+ * by column.  Output CSR has int64 offsets (LargeList).
+ *
+ * Two-phase because the output size is data dependent:
+ *   lk_iknn_build_count  -> fills d_out_indptr (n_items+1, int64, exclusive scan)
+ *                           and returns the total through *h_total_nnz (blocking);
+ *   lk_iknn_build_fill   -> writes d_out_indices / d_out_values.
+ * ---------------------------------------------------------------------- */
+typedef struct lk_iknn_plan lk_iknn_plan;
+int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr, const void *h_iu_indptr,
+                        int indptr_is_64, int64_t n_users, int64_t n_items);
+void lk_iknn_plan_destroy(lk_iknn_plan *plan);
+size_t lk_iknn_plan_workspace_bytes(const lk_iknn_plan *plan);
+
+int lk_iknn_build_count(const lk_iknn_plan *plan, const void *d_ui_indptr,
+                        const int32_t *d_ui_indices, const float *d_ui_values,
+                        const void *d_iu_indptr, const int32_t *d_iu_indices,
+                        const float *d_iu_values, float min_sim, int64_t save_nbrs, void *d_ws,
+                        int64_t *d_out_indptr, int64_t *h_total_nnz, void *stream);
+int lk_iknn_build_fill(const lk_iknn_plan *plan, const void *d_ui_indptr,
+                       const int32_t *d_ui_indices, const float *d_ui_values,
+                       const void *d_iu_indptr, const int32_t *d_iu_indices,
+                       const float *d_iu_values, float min_sim, int64_t save_nbrs, void *d_ws,
+                       const int64_t *d_out_indptr, int32_t *d_out_indices, float *d_out_values,
+                       void *stream);
+
+/* ------------------------------------------------------------------------
+ * Item-kNN scoring for a BATCH of queries.
+ * Replaces `_accel.knn.score_explicit` / `score_implicit`
+ * (src/lenskit/_accel/knn.pyi:15-29; src/accel/knn/item_score.rs:23-111,
+ * src/accel/knn/accum.rs:16-239), which score ONE query per call.
+ *   query q has reference (history) items ref_items[ref_ptr[q]..ref_ptr[q+1]) with
+ *   centred ratings ref_rates (NULL => implicit) and targets
+ *   tgt_items[tgt_ptr[q]..tgt_ptr[q+1]); negative item numbers are nulls.
+ *   score_t = sum_{top max_nbrs by sim} s*v / sum s  (explicit)  or  sum s (implicit);
+ *   fewer than min_nbrs contributors => NaN.  out_counts = contributors kept
+ *   (-1 for a null target).
+ * ---------------------------------------------------------------------- */
+size_t lk_iknn_score_workspace_bytes(int64_t n_items, int64_t n_queries);
+int lk_iknn_score_batch(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
+                        const float *d_sim_values, int64_t n_items, int64_t n_queries,
+                        const int64_t *d_ref_ptr, const int32_t *d_ref_items,
+                        const float *d_ref_rates, const int64_t *d_tgt_ptr,
+                        const int32_t *d_tgt_items, int32_t max_nbrs, int32_t min_nbrs,
+                        void *d_ws, float *d_out_scores, int32_t *d_out_counts, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Dense scoring with fused top-K.
+ * Replaces, for a batch of users, `ALSBase.__call__` scoring
+ * (src/lenskit/als/_common.py:159-170: scores = Q u) followed by
+ * `TopNRanker` -> `ItemList.top_n` -> `_accel.data.argtopn`
+ * (src/lenskit/basic/topn.py:45-69, src/lenskit/data/_items.py:942-998,
+ * src/accel/data/sorting.rs:132-172).
+ *   scores[b][i] = fma-chain over f = 0..k-1 of U[b][f]*Q[i][f]  (f32 MFMA: exact,
+ *   k-ordered) for every item i not listed in the exclusion CSR row b
+ *   (candidate selector: training items minus the query's items,
+ *   src/lenskit/basic/candidates.py:77-94); NaN scores are skipped;
+ *   out_idx[b][0..n) = indices of the n largest scores, descending, ties by
+ *   lower index; out_score likewise; rows with fewer than n candidates are
+ *   padded with index -1 / score NaN.
+ * ---------------------------------------------------------------------- */
+size_t lk_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t n);
+int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_users, const float *d_items,
+                  int32_t ld_items, int64_t n_items, int32_t k, int32_t n,
+                  const int64_t *d_excl_ptr, const int32_t *d_excl_items, void *d_ws,
+                  int32_t *d_out_idx, float *d_out_score, void *stream);
+
+/* Plain top-N over score vectors already in HBM (one row per query), the
+ * direct stand-in for `_accel.data.argtopn(scores, n)`. */
+int lk_argtopn(const float *d_scores, int64_t n_rows, int64_t row_len, int32_t n, void *d_ws,
+               int32_t *d_out_idx, void *stream);
+
+/* Batched fold-in (new-user embedding) -- `ImplicitMFScorer.new_user_embedding`
+ * / `_train_new_row` (src/lenskit/als/_implicit.py:77-130): same algebra as one
+ * ALS row with OtOr = Q^T Q + user_reg I; histories given as a CSR over items. */
+int lk_als_fold_in(const lk_als_plan *plan, const void *d_hist_ptr, const int32_t *d_hist_items,
+                   const float *d_hist_values, int64_t n_queries, int64_t n_items, int32_t k,
+                   float *d_out_users, int32_t ld_out, const float *d_items, int32_t ld_items,
+                   const float *d_otor, int32_t ld_otor, void *d_ws, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LKAMD_H */

@@ -1,0 +1,196 @@
+"""
+Device-side plumbing: torch tensors as HBM buffers, the current torch stream as the
+HIP stream, thin typed wrappers over the C ABI (``include/lkamd.h``).
+
+Nothing in here computes: every arithmetic step is a hand-written HIP kernel behind
+``lkpy_amd/_lkamd.so``.  PyTorch only owns memory, streams and (elsewhere) the RCCL
+process group.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _native
+from ._native import check
+
+
+def device(dev=None) -> torch.device:
+    _native.require_gpu()
+    if dev is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        raise _native.BackendUnavailable(f"lkpy_amd runs on a HIP device only (got {dev})")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def _ptr(t) -> ctypes.c_void_p:
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def padded_dim(k: int) -> int:
+    kp = _native.load().lk_padded_dim(int(k))
+    if kp == 0:
+        raise ValueError(f"unsupported embedding size {k} (supported: 1..256)")
+    return kp
+
+
+def to_device_padded(mat: np.ndarray, dev) -> torch.Tensor:
+    "Host [n x k] float32 -> device [n x KP] with zero pad columns."
+    mat = np.ascontiguousarray(mat, dtype=np.float32)
+    n, k = mat.shape
+    kp = padded_dim(k)
+    src = torch.from_numpy(mat).to(dev)
+    if kp == k:
+        return src.contiguous()
+    dst = torch.empty((n, kp), dtype=torch.float32, device=dev)
+    check(_native.load().lk_pad_rows(_ptr(src), n, k, k, _ptr(dst), kp, _stream()), "lk_pad_rows")
+    return dst
+
+
+def to_host_unpadded(mat: torch.Tensor, k: int) -> np.ndarray:
+    "Device [n x KP] -> host [n x k] float32."
+    n, kp = mat.shape
+    if kp == k:
+        return mat.cpu().numpy()
+    dst = torch.empty((n, k), dtype=torch.float32, device=mat.device)
+    check(
+        _native.load().lk_unpad_rows(_ptr(mat), n, k, kp, _ptr(dst), k, _stream()),
+        "lk_unpad_rows",
+    )
+    return dst.cpu().numpy()
+
+
+@dataclass
+class DeviceCSR:
+    "CSR in HBM: the SparseRowArray layout (offsets i32/i64, indices i32, values f32)."
+
+    indptr: torch.Tensor
+    indices: torch.Tensor
+    values: torch.Tensor
+    shape: tuple[int, int]
+    h_indptr: np.ndarray  # host copy of the offsets (plans are built from it)
+
+    @property
+    def nnz(self) -> int:
+        return int(self.indices.shape[0])
+
+    @property
+    def is64(self) -> bool:
+        return self.indptr.dtype == torch.int64
+
+    @classmethod
+    def from_arrays(cls, indptr, indices, values, shape, dev) -> "DeviceCSR":
+        indptr = np.ascontiguousarray(indptr)
+        if indptr.dtype not in (np.int32, np.int64):
+            indptr = indptr.astype(np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        return cls(
+            torch.from_numpy(indptr).to(dev),
+            torch.from_numpy(indices).to(dev),
+            torch.from_numpy(values).to(dev),
+            (int(shape[0]), int(shape[1])),
+            indptr,
+        )
+
+    @classmethod
+    def from_scipy(cls, mat, dev) -> "DeviceCSR":
+        mat = mat.tocsr()
+        mat.sort_indices()
+        return cls.from_arrays(mat.indptr, mat.indices, mat.data, mat.shape, dev)
+
+
+class Gramian:
+    "``M^T M + reg I`` (lk_gramian) with a reusable workspace."
+
+    def __init__(self, k: int, dev):
+        self.k = int(k)
+        self.kp = padded_dim(k)
+        lib = _native.load()
+        self.ws = torch.empty(lib.lk_gramian_workspace_bytes(self.k), dtype=torch.uint8, device=dev)
+        self.dev = dev
+
+    def __call__(self, m: torch.Tensor, reg: float, out: torch.Tensor | None = None):
+        n, ld = m.shape
+        assert ld == self.kp and m.dtype == torch.float32 and m.is_contiguous()
+        if out is None:
+            out = torch.empty((self.k, self.k), dtype=torch.float32, device=self.dev)
+        check(
+            _native.load().lk_gramian(
+                _ptr(m), n, self.k, ld, float(reg), _ptr(out), out.stride(0), _ptr(self.ws),
+                _stream()
+            ),
+            "lk_gramian",
+        )  # fmt: skip
+        return out
+
+
+class ALSPlan:
+    "Row schedule + workspace of one CSR orientation (lk_als_plan)."
+
+    def __init__(self, csr: DeviceCSR, k: int, solver: int = _native.SOLVER_AUTO):
+        lib = _native.require_gpu()
+        self.csr = csr
+        self.k = int(k)
+        self.kp = padded_dim(k)
+        self._h = ctypes.c_void_p(0)
+        hp = csr.h_indptr
+        check(
+            lib.lk_als_plan_create(
+                ctypes.byref(self._h), hp.ctypes.data_as(ctypes.c_void_p),
+                1 if hp.dtype == np.int64 else 0, csr.shape[0], self.k, int(solver)
+            ),
+            "lk_als_plan_create",
+        )  # fmt: skip
+        dev = csr.indices.device
+        self.ws = torch.empty(lib.lk_als_plan_workspace_bytes(self._h), dtype=torch.uint8,
+                              device=dev)
+        self.frob = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.solver = int(lib.lk_als_plan_solver(self._h))
+
+    def set_cg(self, tol: float, max_iter: int = 0):
+        check(_native.load().lk_als_plan_set_cg(self._h, float(tol), int(max_iter)))
+
+    def half_epoch(self, this: torch.Tensor, other: torch.Tensor, otor: torch.Tensor):
+        """
+        One ALS half-epoch on the current stream; ``this`` ([rows x KP]) is updated in
+        place.  Asynchronous: returns the device scalar holding sqrt(sum ||delta||^2).
+        """
+        csr = self.csr
+        assert this.shape == (csr.shape[0], self.kp) and other.shape == (csr.shape[1], self.kp)
+        assert this.is_contiguous() and other.is_contiguous() and otor.is_contiguous()
+        check(
+            _native.load().lk_als_implicit_half_epoch(
+                self._h, _ptr(csr.indptr), _ptr(csr.indices), _ptr(csr.values),
+                csr.shape[0], csr.shape[1], self.k, _ptr(this), self.kp, _ptr(other), self.kp,
+                _ptr(otor), otor.stride(0), _ptr(self.ws), _ptr(self.frob), _stream()
+            ),
+            "lk_als_implicit_half_epoch",
+        )  # fmt: skip
+        return self.frob
+
+    def check_status(self):
+        "Synchronise and raise RuntimeError('ALS solve error: ...') on a failed solve."
+        check(_native.load().lk_als_check_status(self._h, _ptr(self.ws), _stream()))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _native.load().lk_als_plan_destroy(self._h)
+                self._h = ctypes.c_void_p(0)
+        except Exception:
+            pass

@@ -1,0 +1,131 @@
+"""
+ctypes binding of the C ABI declared in ``include/lkamd.h`` (``lkpy_amd/_lkamd.so``).
+
+The product path has NO CPU fallback: if the HIP library is missing or there is no
+GPU, the calls raise (:class:`BackendUnavailable`).  Loading the library and listing
+its symbols works without a GPU (used by the CPU-only tests).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import re
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "_lkamd.so"
+HEADER_PATH = _PKG.parent / "include" / "lkamd.h"
+
+LK_OK = 0
+LK_E_INVALID = -1
+LK_E_HIP = -2
+LK_E_NOT_SPD = -3
+LK_E_NAN_SIM = -4
+LK_E_NOMEM = -5
+LK_E_CANCELLED = -6
+
+SOLVER_CHOLESKY = 0
+SOLVER_CG = 1
+SOLVER_AUTO = 2
+
+
+class BackendUnavailable(RuntimeError):
+    "The HIP extension or the GPU is missing; there is deliberately no CPU fallback."
+
+
+_lib = None
+
+
+def _declare(lib):
+    vp = c_void_p
+    sigs = {
+        "lk_last_error": (c_char_p, []),
+        "lk_version": (c_char_p, []),
+        "lk_device_count": (c_int, []),
+        "lk_padded_dim": (c_int32, [c_int32]),
+        "lk_pad_rows": (c_int, [vp, c_int64, c_int32, c_int32, vp, c_int32, vp]),
+        "lk_unpad_rows": (c_int, [vp, c_int64, c_int32, c_int32, vp, c_int32, vp]),
+        "lk_gramian_workspace_bytes": (c_size_t, [c_int32]),
+        "lk_gramian": (c_int, [vp, c_int64, c_int32, c_int32, c_float, vp, c_int32, vp, vp]),
+        "lk_als_plan_create": (c_int, [POINTER(vp), vp, c_int, c_int64, c_int32, c_int32]),
+        "lk_als_plan_destroy": (None, [vp]),
+        "lk_als_plan_workspace_bytes": (c_size_t, [vp]),
+        "lk_als_plan_solver": (c_int32, [vp]),
+        "lk_als_plan_set_cg": (c_int, [vp, c_float, c_int32]),
+        "lk_als_implicit_half_epoch": (
+            c_int,
+            [vp, vp, vp, vp, c_int64, c_int64, c_int32, vp, c_int32, vp, c_int32, vp, c_int32, vp,
+             vp, vp],
+        ),
+        "lk_als_check_status": (c_int, [vp, vp, vp]),
+        "lk_als_implicit_half_epoch_host": (
+            c_int,
+            [vp, c_int, vp, vp, c_int64, c_int64, c_int32, vp, vp, vp, c_int32, vp],
+        ),
+    }  # fmt: skip
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sigs
+
+
+def load(build_if_missing: bool = False):
+    "Load ``_lkamd.so``; raises :class:`BackendUnavailable` if it is not built."
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        if build_if_missing:
+            from .csrc.build import build
+
+            build()
+        else:
+            raise BackendUnavailable(
+                f"{LIB_PATH} not found: build it with `python -m lkpy_amd.csrc.build` "
+                "(or __graft_entry__.build()); lkpy_amd has no CPU fallback"
+            )
+    try:
+        lib = ctypes.CDLL(str(LIB_PATH))
+    except OSError as e:  # pragma: no cover
+        raise BackendUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    _declare(lib)
+    _lib = lib
+    return lib
+
+
+def declared_symbols() -> list[str]:
+    "Every function ``include/lkamd.h`` declares (used by the export test)."
+    text = HEADER_PATH.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lk_[a-z0-9_]+)\s*\(", text)))
+
+
+def last_error() -> str:
+    return load().lk_last_error().decode()
+
+
+def check(rc: int, what: str = "lkamd call"):
+    "Map a C-ABI return code to the exception the reference raises for it."
+    if rc == LK_OK:
+        return
+    msg = last_error()
+    if rc == LK_E_NOT_SPD:
+        # src/accel/als/implicit.rs:79 -> RuntimeError("ALS solve error: ...")
+        raise RuntimeError(msg)
+    if rc == LK_E_NAN_SIM:
+        raise ValueError("similarity is null")  # src/accel/knn/accum.rs:146-151
+    if rc == LK_E_INVALID:
+        raise ValueError(f"{what}: {msg}")
+    if rc == LK_E_CANCELLED:
+        raise KeyboardInterrupt(msg)
+    raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+
+def require_gpu():
+    "Raise unless the library is loaded and a HIP device is visible."
+    lib = load()
+    if lib.lk_device_count() < 1:
+        raise BackendUnavailable("no HIP device visible; lkpy_amd has no CPU fallback")
+    return lib

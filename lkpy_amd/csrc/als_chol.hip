@@ -1,0 +1,724 @@
+// als_chol.hip -- implicit-ALS half-epoch, exact (Cholesky) solver, gfx950.
+//
+// Stands in for `train_implicit_matrix` / `ImplicitTrainTask::invoke` /
+// `train_row_solve` (src/accel/als/implicit.rs:35-125) and `POSV::solve`
+// (src/accel/als/solve.rs:65-107).  Per CSR row r with columns c_j, values v_j:
+//     A = OtOr + sum_j v_j q_j q_j^T      y = sum_j (v_j + 1) q_j      x = A^-1 y
+//     this[r] <- x;   delta_r = ||x - this_old[r]||^2   (empty row: zeros, delta 0)
+//
+// Work decomposition: ONE WAVE PER ROW (4 independent waves per workgroup, no
+// workgroup barriers).  Rows are visited longest-first (plan order); rows longer
+// than LK_ALS_LONG_ROW are pre-reduced by a chunk kernel (one wave per chunk of
+// <= LK_ALS_CHUNK entries) into partial slabs that the solving wave sums in
+// chunk order, so the result is independent of scheduling (bit-reproducible).
+//
+// Normal-matrix build (the flop carrier, 2*k^2 per CSR entry): f32 MFMA
+// v_mfma_f32_16x16x4_f32, K = 4 CSR entries per instruction, upper tiles only
+// (A is symmetric): NT(NT+1)/2 MFMAs per 4 entries instead of NT^2.  Features
+// are handled in "primed" order p = t*16 + s <-> f = s*NT + t so that a lane's NT
+// features of a factor row are one contiguous vector load and 16 lanes fetch the
+// whole row of `other` in one coalesced request (the gather is per CSR entry:
+// 4*k contiguous bytes).  The CSR (indices, values) stream is read coalesced, 64
+// entries per wave-load, and broadcast with ds_bpermute.
+//
+// Solve: the accumulator tiles are transposed through a wave-private LDS region
+// so that lane R holds row R of A' (primed order == a symmetric permutation of A,
+// which leaves the solution unchanged); an in-register right-looking Cholesky
+// with v_readlane broadcasts (no LDS traffic in the O(k^3) loop), forward
+// substitution in registers, back substitution against L^T staged in LDS.
+//
+// Roofline: f32 MFMA bound for k = 64 (nnz*(2k^2+2k) +
+// rows*(k^3/3 + 2k^2) flop per half-epoch); HBM traffic is the CSR stream plus
+// the (L2/MALL-resident) gathered factor rows.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+#define LK_ALS_CHUNK 1024     // CSR entries per chunk of a long row
+#define LK_ALS_LONG_ROW 2048  // rows longer than this are chunked
+
+struct lk_als_plan {
+    int64_t n_rows = 0;
+    int32_t k = 0, KP = 0, NT = 0, solver = 0;
+    int32_t is64 = 0;  // width of the CSR offsets the plan was built from
+    int64_t n_chunks = 0;
+    int64_t n_long = 0;
+    // device-side schedule
+    int32_t *d_order = nullptr;      // [n_rows] rows, longest first
+    int32_t *d_row_slab = nullptr;   // [n_rows] first slab of the row or -1
+    int32_t *d_chunk_row = nullptr;  // [n_chunks]
+    int64_t *d_chunk_beg = nullptr;  // [n_chunks] CSR entry range
+    int32_t *d_chunk_len = nullptr;
+    // workspace layout (byte offsets)
+    size_t off_status = 0, off_otor = 0, off_delta = 0, off_partial = 0, off_slabs = 0,
+           ws_bytes = 0;
+    float cg_tol = 1e-7f;
+    int32_t cg_max_iter = 0;
+};
+
+namespace lk {
+
+__host__ __device__ constexpr int als_tiles(int NT) { return NT * (NT + 1) / 2; }
+// packed index of upper tile (ti <= tj)
+__host__ __device__ constexpr int tidx(int ti, int tj) { return tj * (tj + 1) / 2 + ti; }
+
+template <int NT>
+struct Gram {
+    f32x4 t[als_tiles(NT)];
+    float y[NT];
+};
+
+template <int NT>
+__device__ __forceinline__ void load_q(const float *p, float (&q)[NT])
+{
+    if constexpr (NT == 1) {
+        q[0] = *p;
+    } else if constexpr (NT == 2) {
+        f32x2 t = *reinterpret_cast<const f32x2 *>(p);
+        q[0] = t.x;
+        q[1] = t.y;
+    } else {
+        static_assert(NT == 4, "Cholesky path supports NT in {1,2,4}");
+        f32x4 t = *reinterpret_cast<const f32x4 *>(p);
+        q[0] = t.x;
+        q[1] = t.y;
+        q[2] = t.z;
+        q[3] = t.w;
+    }
+}
+
+// Accumulate CSR entries [beg, end) of one row into G (A tiles and y).
+template <int NT>
+__device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__restrict__ cols,
+                                                const float *__restrict__ vals, int64_t beg,
+                                                int64_t end, const float *__restrict__ other,
+                                                int ld)
+{
+    const int lane = lane_id();
+    const int sub = lane & 15, slot = lane >> 4;
+    constexpr int PF = 4;  // gathered groups (of 4 entries) in flight per wave
+
+    for (int64_t base = beg; base < end; base += 64) {
+        const int64_t e = base + lane;
+        const bool ok = e < end;
+        const int mycol = ok ? cols[e] : 0;
+        const float myval = ok ? vals[e] : 0.f;
+        const int nb = (end - base) < 64 ? (int)(end - base) : 64;
+        const int ngroups = (nb + 3) >> 2;
+
+        float qn[PF][NT];
+        float vn[PF];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int s = p * 4 + slot;
+            const int col = __shfl(mycol, s, 64);
+            vn[p] = __shfl(myval, s, 64);
+            if (p < ngroups) {
+                load_q<NT>(other + (int64_t)col * ld + sub * NT, qn[p]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) qn[p][t] = 0.f;
+            }
+        }
+        for (int g0 = 0; g0 < ngroups; g0 += PF) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int g = g0 + p;
+                float q[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) q[t] = qn[p][t];
+                const float v = vn[p];
+                // refill this ring slot with group g + PF
+                {
+                    const int gn = g + PF;
+                    const int s = (gn * 4 + slot) & 63;
+                    const int col = __shfl(mycol, s, 64);
+                    vn[p] = __shfl(myval, s, 64);
+                    if (gn < ngroups) load_q<NT>(other + (int64_t)col * ld + sub * NT, qn[p]);
+                }
+                if (g < ngroups) {
+                    // entries past the row end carry (col 0, v 0): kill their q so that
+                    // neither A (v*q*q) nor y ((v+1)*q) sees them
+                    const bool live = (g * 4 + slot) < nb;
+                    float a[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        q[t] = live ? q[t] : 0.f;
+                        a[t] = q[t] * v;  // `mtl = mt * vals` (implicit.rs:110-111)
+                    }
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                        for (int ti = 0; ti <= tj; ++ti)
+                            G.t[tidx(ti, tj)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                a[ti], q[tj], G.t[tidx(ti, tj)], 0, 0, 0);
+                    const float v1 = v + 1.0f;  // `vals += 1.0` (implicit.rs:116)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) G.y[t] = fmaf(q[t], v1, G.y[t]);
+                }
+            }
+        }
+    }
+}
+
+// slab layout: [(NTILES*4 + NT)][64] floats, register-major / lane-minor
+template <int NT>
+__host__ __device__ constexpr int slab_floats()
+{
+    return (als_tiles(NT) * 4 + NT) * 64;
+}
+
+template <int NT>
+__device__ __forceinline__ void slab_store(const Gram<NT> &G, float *__restrict__ slab)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int e = 0; e < als_tiles(NT); ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(e * 4 + r) * 64 + lane] = G.t[e][r];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) slab[(als_tiles(NT) * 4 + t) * 64 + lane] = G.y[t];
+}
+
+template <int NT>
+__device__ __forceinline__ void slab_add(Gram<NT> &G, const float *__restrict__ slab)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int e = 0; e < als_tiles(NT); ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) G.t[e][r] += slab[(e * 4 + r) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) G.y[t] += slab[(als_tiles(NT) * 4 + t) * 64 + lane];
+}
+
+// ---- chunk kernel: one wave per chunk of a long row ------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void als_chunk_kernel(
+    const int32_t *__restrict__ indices, const float *__restrict__ values,
+    const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_len,
+    int64_t n_chunks, const float *__restrict__ other, int ld, float *__restrict__ slabs)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t c = (int64_t)blockIdx.x * 4 + wave;
+    if (c >= n_chunks) return;
+    Gram<NT> G;
+#pragma unroll
+    for (int e = 0; e < als_tiles(NT); ++e) G.t[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) G.y[t] = 0.f;
+    const int64_t beg = chunk_beg[c];
+    gram_accumulate<NT>(G, indices, values, beg, beg + chunk_len[c], other, ld);
+    slab_store<NT>(G, slabs + (size_t)c * slab_floats<NT>());
+}
+
+// ---- solve: lane R owns row R of the (primed) normal matrix -----------------
+// a[c] (c <= R valid), b = rhs; lds: KP*(KP+1) floats, wave private.
+// Returns false when a pivot is not positive (matrix not SPD).
+template <int KP>
+__device__ __forceinline__ bool chol_solve(float (&a)[KP], float &b, float *__restrict__ lds)
+{
+    const int lane = lane_id();
+    constexpr int LD = KP + 1;
+    bool ok = true;
+    float dinv = 0.f;  // lane j keeps 1 / L_jj
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const float ajj = bcast(a[j], j);
+        ok = ok && (ajj > 0.f);
+        const float d = sqrtf(ajj);
+        const float rinv = 1.0f / d;
+        const float lj = (lane == j) ? d : a[j] * rinv;  // column j of L (lanes >= j)
+        a[j] = lj;
+        dinv = (lane == j) ? rinv : dinv;
+        if (lane < KP) lds[j * LD + lane] = lj;  // L^T row j
+#pragma unroll
+        for (int c = j + 1; c < KP; ++c) {
+            const float lcj = bcast(lj, c);
+            a[c] = fmaf(-lj, lcj, a[c]);  // a_ic -= L_ij * L_cj   (i = lane >= c)
+        }
+    }
+    // forward: L z = y
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const float zj = bcast(b * dinv, j);
+        b = (lane == j) ? zj : ((lane > j) ? fmaf(-a[j], zj, b) : b);
+    }
+    // backward: L^T x = z ; L[j][i] = lds[i*LD + j]
+#pragma unroll
+    for (int j = KP - 1; j >= 0; --j) {
+        const float xj = bcast(b * dinv, j);
+        const float lji = (lane < KP) ? lds[lane * LD + j] : 0.f;
+        b = (lane == j) ? xj : ((lane < j) ? fmaf(-lji, xj, b) : b);
+    }
+    return ok;
+}
+
+template <int NT, bool IS64>
+__global__ __launch_bounds__(256) void als_solve_kernel(
+    const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_rows,
+    const int32_t *__restrict__ row_slab, const float *__restrict__ other, int ld_other,
+    float *__restrict__ this_, int ld_this, const float *__restrict__ otor_p,
+    const float *__restrict__ slabs, float *__restrict__ row_delta, int *__restrict__ status,
+    int k)
+{
+    constexpr int KP = NT * 16;
+    constexpr int LDT = KP + 4;  // transposition buffer stride (16-byte aligned rows)
+    __shared__ __attribute__((aligned(16))) float lds_all[4][KP * LDT];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int sub = lane & 15, slot = lane >> 4;
+    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    if (t >= n_rows) return;
+    const int row = order[t];
+    const int64_t beg = indptr[row], end = indptr[row + 1];
+    float *lds = lds_all[wave];
+
+    // feature owned by this lane in the lane==row phase
+    const int my_f = (lane & 15) * NT + (lane >> 4);
+    const bool my_valid = (lane < KP) && (my_f < k);
+    float *xrow = this_ + (int64_t)row * ld_this;
+
+    if (end == beg) {  // implicit.rs:98-101
+        if (lane < KP) xrow[lane] = 0.f;
+        if (lane == 0) row_delta[row] = 0.f;
+        return;
+    }
+
+    Gram<NT> G;
+    // start from OtOr (primed, padded with identity on the pad features)
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int ti = 0; ti <= tj; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                G.t[tidx(ti, tj)][r] = otor_p[(ti * 16 + slot * 4 + r) * KP + tj * 16 + sub];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) G.y[tt] = 0.f;
+
+    const int first_slab = row_slab[row];
+    if (first_slab >= 0) {
+        const int64_t n = end - beg;
+        const int ns = (int)((n + LK_ALS_CHUNK - 1) / LK_ALS_CHUNK);
+        for (int s = 0; s < ns; ++s)
+            slab_add<NT>(G, slabs + (size_t)(first_slab + s) * slab_floats<NT>());
+    } else {
+        gram_accumulate<NT>(G, indices, values, beg, end, other, ld_other);
+    }
+
+    // y: combine the 4 entry slots -> every lane has the full y for feature (t, sub)
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        G.y[tt] += __shfl_xor(G.y[tt], 16, 64);
+        G.y[tt] += __shfl_xor(G.y[tt], 32, 64);
+    }
+    // tile (ti,tj): lane holds D[i = slot*4+r][j = sub] = A'[ti*16+i][tj*16+j]
+    //             = A'[row' = tj*16+sub][col' = ti*16 + slot*4 + r]  (symmetry)
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int ti = 0; ti <= tj; ++ti)
+            *reinterpret_cast<f32x4 *>(&lds[(tj * 16 + sub) * LDT + ti * 16 + slot * 4]) =
+                G.t[tidx(ti, tj)];
+
+    float a[KP];
+    float b = 0.f;
+    if (lane < KP) {
+#pragma unroll
+        for (int c4 = 0; c4 < KP / 4; ++c4) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(&lds[lane * LDT + c4 * 4]);
+            a[c4 * 4 + 0] = v.x;
+            a[c4 * 4 + 1] = v.y;
+            a[c4 * 4 + 2] = v.z;
+            a[c4 * 4 + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < KP; ++c) a[c] = 0.f;
+    }
+    // rhs for primed row `lane`: tile lane>>4, sub lane&15 -> G.y[lane>>4] of this lane
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) b = (slot == tt) ? G.y[tt] : b;
+    if (lane >= KP) b = 0.f;
+
+    const float old = my_valid ? xrow[my_f] : 0.f;
+    const bool ok = chol_solve<KP>(a, b, lds);
+    if (!ok && lane == 0) atomicCAS(status, 0, row + 1);
+
+    float d = 0.f;
+    if (my_valid) {
+        xrow[my_f] = b;
+        d = b - old;
+    }
+    const float d2 = wave_sum(d * d);
+    if (lane == 0) row_delta[row] = d2;
+}
+
+// OtOr [k x k] -> primed [KP x KP] with identity on the pad features.
+template <int NT>
+__global__ void als_prep_otor_kernel(const float *__restrict__ otor, int ld_otor, int k,
+                                     float *__restrict__ otor_p)
+{
+    constexpr int KP = NT * 16;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= KP * KP) return;
+    int pr = idx / KP, pc = idx % KP;
+    int fr = (pr & 15) * NT + (pr >> 4), fc = (pc & 15) * NT + (pc >> 4);
+    float v;
+    if (fr < k && fc < k)
+        v = otor[fr * ld_otor + fc];
+    else
+        v = (pr == pc) ? 1.0f : 0.0f;
+    otor_p[idx] = v;
+}
+
+// deterministic two-stage sum of row deltas -> sqrt
+__global__ void delta_partial_kernel(const float *__restrict__ row_delta, int64_t n,
+                                     float *__restrict__ partial)
+{
+    __shared__ float sm[256];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    int64_t b = (int64_t)blockIdx.x * per, e = b + per;
+    if (e > n) e = n;
+    float s = 0.f;
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) s += row_delta[i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
+__global__ void delta_final_kernel(const float *__restrict__ partial, int n,
+                                   float *__restrict__ out)
+{
+    __shared__ float sm[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sqrtf(sm[0]);
+}
+
+constexpr int DELTA_BLOCKS = 256;
+
+template <int NT, bool IS64>
+static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *indices,
+                       const float *values, int64_t n_rows, int k, float *this_, int ld_this,
+                       const float *other, int ld_other, const float *otor, int ld_otor,
+                       char *ws, float *out_frob, hipStream_t st)
+{
+    constexpr int KP = NT * 16;
+    int *status = reinterpret_cast<int *>(ws + p->off_status);
+    float *otor_p = reinterpret_cast<float *>(ws + p->off_otor);
+    float *row_delta = reinterpret_cast<float *>(ws + p->off_delta);
+    float *partial = reinterpret_cast<float *>(ws + p->off_partial);
+    float *slabs = reinterpret_cast<float *>(ws + p->off_slabs);
+
+    LK_HIP_CHECK(hipMemsetAsync(status, 0, 64, st));
+    hipLaunchKernelGGL(als_prep_otor_kernel<NT>, dim3((KP * KP + 255) / 256), dim3(256), 0, st,
+                       otor, ld_otor, k, otor_p);
+    if (p->n_chunks > 0) {
+        hipLaunchKernelGGL(als_chunk_kernel<NT>, dim3((unsigned)((p->n_chunks + 3) / 4)),
+                           dim3(256), 0, st, indices, values, p->d_chunk_beg, p->d_chunk_len,
+                           p->n_chunks, other, ld_other, slabs);
+    }
+    if (n_rows > 0) {
+        using IT = typename IndPtr<IS64>::type;
+        hipLaunchKernelGGL((als_solve_kernel<NT, IS64>), dim3((unsigned)((n_rows + 3) / 4)),
+                           dim3(256), 0, st, static_cast<const IT *>(indptr), indices, values,
+                           p->d_order, n_rows, p->d_row_slab, other, ld_other, this_, ld_this,
+                           otor_p, slabs, row_delta, status, k);
+    }
+    hipLaunchKernelGGL(delta_partial_kernel, dim3(DELTA_BLOCKS), dim3(256), 0, st, row_delta,
+                       n_rows, partial);
+    hipLaunchKernelGGL(delta_final_kernel, dim3(1), dim3(256), 0, st, partial, DELTA_BLOCKS,
+                       out_frob);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+int als_cg_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
+                      const float *values, int64_t n_rows, int k, float *this_, int ld_this,
+                      const float *other, int ld_other, const float *otor, int ld_otor, char *ws,
+                      float *out_frob, hipStream_t st);
+
+}  // namespace lk
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+
+extern "C" int32_t lk_padded_dim(int32_t k)
+{
+    if (k < 1) return 0;
+    if (k <= 16) return 16;
+    if (k <= 32) return 32;
+    if (k <= 64) return 64;
+    if (k <= 128) return 128;
+    if (k <= 256) return 256;
+    return 0;
+}
+
+template <typename T>
+static int upload(T **dst, const std::vector<T> &src)
+{
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(dst), bytes));
+    if (!src.empty())
+        LK_HIP_CHECK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return LK_OK;
+}
+
+extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int indptr_is_64,
+                                  int64_t n_rows, int32_t k, int32_t solver)
+{
+    LK_REQUIRE(out != nullptr && h_indptr != nullptr, "lk_als_plan_create: null pointer");
+    LK_REQUIRE(n_rows >= 0 && n_rows < (int64_t)INT32_MAX, "lk_als_plan_create: bad n_rows");
+    int KP = lk_padded_dim(k);
+    LK_REQUIRE(KP > 0, "lk_als_plan_create: unsupported embedding size k=%d (1..256)", k);
+    if (solver == LK_SOLVER_AUTO) solver = (KP <= 64) ? LK_SOLVER_CHOLESKY : LK_SOLVER_CG;
+    LK_REQUIRE(solver == LK_SOLVER_CHOLESKY || solver == LK_SOLVER_CG,
+               "lk_als_plan_create: unknown solver %d", solver);
+    LK_REQUIRE(!(solver == LK_SOLVER_CHOLESKY && KP > 64),
+               "lk_als_plan_create: the Cholesky solver supports k <= 64 (got %d); use CG", k);
+
+    auto *p = new lk_als_plan();
+    p->n_rows = n_rows;
+    p->k = k;
+    p->KP = KP;
+    p->NT = KP / 16;
+    p->solver = solver;
+    p->is64 = indptr_is_64 ? 1 : 0;
+    p->cg_max_iter = 0;
+
+    auto len = [&](int64_t r) -> int64_t {
+        if (indptr_is_64) {
+            const int64_t *ip = static_cast<const int64_t *>(h_indptr);
+            return ip[r + 1] - ip[r];
+        }
+        const int32_t *ip = static_cast<const int32_t *>(h_indptr);
+        return (int64_t)ip[r + 1] - ip[r];
+    };
+    auto start = [&](int64_t r) -> int64_t {
+        return indptr_is_64 ? static_cast<const int64_t *>(h_indptr)[r]
+                            : (int64_t) static_cast<const int32_t *>(h_indptr)[r];
+    };
+
+    std::vector<int32_t> order((size_t)n_rows);
+    for (int64_t r = 0; r < n_rows; ++r) order[(size_t)r] = (int32_t)r;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int32_t x, int32_t y) { return len(x) > len(y); });
+
+    std::vector<int32_t> row_slab((size_t)n_rows, -1);
+    std::vector<int32_t> chunk_row;
+    std::vector<int64_t> chunk_beg;
+    std::vector<int32_t> chunk_len;
+    if (solver == LK_SOLVER_CHOLESKY) {
+        for (int64_t r = 0; r < n_rows; ++r) {
+            int64_t n = len(r);
+            if (n > LK_ALS_LONG_ROW) {
+                row_slab[(size_t)r] = (int32_t)chunk_row.size();
+                for (int64_t o = 0; o < n; o += LK_ALS_CHUNK) {
+                    chunk_row.push_back((int32_t)r);
+                    chunk_beg.push_back(start(r) + o);
+                    chunk_len.push_back((int32_t)std::min<int64_t>(LK_ALS_CHUNK, n - o));
+                }
+                p->n_long++;
+            }
+        }
+    }
+    p->n_chunks = (int64_t)chunk_row.size();
+
+    int rc;
+    if ((rc = upload(&p->d_order, order)) != LK_OK || (rc = upload(&p->d_row_slab, row_slab)) ||
+        (rc = upload(&p->d_chunk_row, chunk_row)) || (rc = upload(&p->d_chunk_beg, chunk_beg)) ||
+        (rc = upload(&p->d_chunk_len, chunk_len))) {
+        lk_als_plan_destroy(p);
+        return rc;
+    }
+
+    size_t off = 0;
+    p->off_status = off;
+    off += 256;
+    p->off_otor = off;
+    off += lk::align_up((size_t)KP * KP * sizeof(float), 256);
+    p->off_delta = off;
+    off += lk::align_up((size_t)std::max<int64_t>(n_rows, 1) * sizeof(float), 256);
+    p->off_partial = off;
+    off += lk::align_up((size_t)lk::DELTA_BLOCKS * sizeof(float), 256);
+    p->off_slabs = off;
+    size_t slab_f = (size_t)(lk::als_tiles(p->NT) * 4 + p->NT) * 64;
+    off += lk::align_up((size_t)std::max<int64_t>(p->n_chunks, 1) * slab_f * sizeof(float), 256);
+    p->ws_bytes = off;
+    *out = p;
+    return LK_OK;
+}
+
+extern "C" void lk_als_plan_destroy(lk_als_plan *p)
+{
+    if (!p) return;
+    if (p->d_order) (void)hipFree(p->d_order);
+    if (p->d_row_slab) (void)hipFree(p->d_row_slab);
+    if (p->d_chunk_row) (void)hipFree(p->d_chunk_row);
+    if (p->d_chunk_beg) (void)hipFree(p->d_chunk_beg);
+    if (p->d_chunk_len) (void)hipFree(p->d_chunk_len);
+    delete p;
+}
+
+extern "C" size_t lk_als_plan_workspace_bytes(const lk_als_plan *p) { return p ? p->ws_bytes : 0; }
+extern "C" int32_t lk_als_plan_solver(const lk_als_plan *p) { return p ? p->solver : -1; }
+
+extern "C" int lk_als_plan_set_cg(lk_als_plan *p, float tol, int32_t max_iter)
+{
+    LK_REQUIRE(p != nullptr, "lk_als_plan_set_cg: null plan");
+    LK_REQUIRE(tol > 0.f, "lk_als_plan_set_cg: tol must be positive");
+    p->cg_tol = tol;
+    p->cg_max_iter = max_iter;
+    return LK_OK;
+}
+
+extern "C" int lk_als_implicit_half_epoch(const lk_als_plan *plan, const void *d_indptr,
+                                          const int32_t *d_indices, const float *d_values,
+                                          int64_t n_rows, int64_t n_cols, int32_t k,
+                                          float *d_this, int32_t ld_this, const float *d_other,
+                                          int32_t ld_other, const float *d_otor, int32_t ld_otor,
+                                          void *d_ws, float *d_out_frob, void *stream)
+{
+    LK_REQUIRE(plan != nullptr, "lk_als_implicit_half_epoch: null plan");
+    LK_REQUIRE(n_rows == plan->n_rows && k == plan->k,
+               "lk_als_implicit_half_epoch: plan built for %lld rows, k=%d; got %lld rows, k=%d",
+               (long long)plan->n_rows, plan->k, (long long)n_rows, k);
+    LK_REQUIRE(ld_this == plan->KP && ld_other == plan->KP,
+               "lk_als_implicit_half_epoch: factor leading dimensions (%d, %d) must equal "
+               "lk_padded_dim(k)=%d",
+               ld_this, ld_other, plan->KP);
+    LK_REQUIRE(ld_otor >= k, "lk_als_implicit_half_epoch: ld_otor < k");
+    LK_REQUIRE(d_indptr && d_this && d_otor && d_ws && d_out_frob,
+               "lk_als_implicit_half_epoch: null pointer");
+    LK_REQUIRE(n_cols >= 0 && (n_cols == 0 || d_other), "lk_als_implicit_half_epoch: null other");
+    hipStream_t st = lk::as_stream(stream);
+    char *ws = static_cast<char *>(d_ws);
+    if (plan->solver == LK_SOLVER_CG)
+        return lk::als_cg_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows, k,
+                                     d_this, ld_this, d_other, ld_other, d_otor, ld_otor, ws,
+                                     d_out_frob, st);
+#define LK_CHOL_CASE(NT)                                                                        \
+    return plan->is64 ? lk::launch_chol<NT, true>(plan, d_indptr, d_indices, d_values, n_rows, \
+                                                  k, d_this, ld_this, d_other, ld_other,       \
+                                                  d_otor, ld_otor, ws, d_out_frob, st)         \
+                      : lk::launch_chol<NT, false>(plan, d_indptr, d_indices, d_values,        \
+                                                   n_rows, k, d_this, ld_this, d_other,        \
+                                                   ld_other, d_otor, ld_otor, ws, d_out_frob,  \
+                                                   st)
+    switch (plan->NT) {
+        case 1: LK_CHOL_CASE(1);
+        case 2: LK_CHOL_CASE(2);
+        case 4: LK_CHOL_CASE(4);
+    }
+#undef LK_CHOL_CASE
+    lk::set_error("lk_als_implicit_half_epoch: no Cholesky kernel for padded k=%d", plan->KP);
+    return LK_E_INVALID;
+}
+
+extern "C" int lk_als_check_status(const lk_als_plan *plan, void *d_ws, void *stream)
+{
+    LK_REQUIRE(plan && d_ws, "lk_als_check_status: null pointer");
+    int status[2] = {0, 0};
+    LK_HIP_CHECK(hipMemcpyAsync(status, static_cast<char *>(d_ws) + plan->off_status,
+                                sizeof(status), hipMemcpyDeviceToHost, lk::as_stream(stream)));
+    LK_HIP_CHECK(hipStreamSynchronize(lk::as_stream(stream)));
+    if (status[0] != 0) {
+        // reference: RuntimeError("ALS solve error: ...") (src/accel/als/implicit.rs:79)
+        lk::set_error("ALS solve error: normal matrix of row %d is not positive definite",
+                      status[0] - 1);
+        return LK_E_NOT_SPD;
+    }
+    return LK_OK;
+}
+
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes)
+    {
+        LK_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
+        return LK_OK;
+    }
+};
+}  // namespace
+
+extern "C" int lk_als_implicit_half_epoch_host(const void *h_indptr, int indptr_is_64,
+                                               const int32_t *h_indices, const float *h_values,
+                                               int64_t n_rows, int64_t n_cols, int32_t k,
+                                               float *h_this, const float *h_other,
+                                               const float *h_otor, int32_t solver,
+                                               float *h_out_frob)
+{
+    LK_REQUIRE(h_indptr && h_this && h_otor && h_out_frob, "half_epoch_host: null pointer");
+    const int KP = lk_padded_dim(k);
+    LK_REQUIRE(KP > 0, "half_epoch_host: unsupported k=%d", k);
+    lk_als_plan *plan = nullptr;
+    int rc = lk_als_plan_create(&plan, h_indptr, indptr_is_64, n_rows, k, solver);
+    if (rc != LK_OK) return rc;
+    const int64_t nnz = indptr_is_64 ? static_cast<const int64_t *>(h_indptr)[n_rows]
+                                     : static_cast<const int32_t *>(h_indptr)[n_rows];
+    const size_t ipb = (size_t)(n_rows + 1) * (indptr_is_64 ? 8 : 4);
+    DevBuf ip, idx, val, th, thp, ot, otp, oo, ws, fr;
+    auto fail = [&](int c) {
+        lk_als_plan_destroy(plan);
+        return c;
+    };
+    if ((rc = ip.alloc(ipb)) || (rc = idx.alloc((size_t)nnz * 4)) ||
+        (rc = val.alloc((size_t)nnz * 4)) || (rc = th.alloc((size_t)n_rows * k * 4)) ||
+        (rc = thp.alloc((size_t)n_rows * KP * 4)) || (rc = ot.alloc((size_t)n_cols * k * 4)) ||
+        (rc = otp.alloc((size_t)n_cols * KP * 4)) || (rc = oo.alloc((size_t)k * k * 4)) ||
+        (rc = ws.alloc(lk_als_plan_workspace_bytes(plan))) || (rc = fr.alloc(4)))
+        return fail(rc);
+#define LK_H(expr)                                                              \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) {                                                 \
+            lk::set_error("%s failed: %s", #expr, hipGetErrorString(_e));       \
+            return fail(LK_E_HIP);                                              \
+        }                                                                       \
+    } while (0)
+    LK_H(hipMemcpy(ip.p, h_indptr, ipb, hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        LK_H(hipMemcpy(idx.p, h_indices, (size_t)nnz * 4, hipMemcpyHostToDevice));
+        LK_H(hipMemcpy(val.p, h_values, (size_t)nnz * 4, hipMemcpyHostToDevice));
+    }
+    if (n_rows > 0) LK_H(hipMemcpy(th.p, h_this, (size_t)n_rows * k * 4, hipMemcpyHostToDevice));
+    if (n_cols > 0) LK_H(hipMemcpy(ot.p, h_other, (size_t)n_cols * k * 4, hipMemcpyHostToDevice));
+    LK_H(hipMemcpy(oo.p, h_otor, (size_t)k * k * 4, hipMemcpyHostToDevice));
+    if ((rc = lk_pad_rows((const float *)th.p, n_rows, k, k, (float *)thp.p, KP, nullptr)) ||
+        (rc = lk_pad_rows((const float *)ot.p, n_cols, k, k, (float *)otp.p, KP, nullptr)))
+        return fail(rc);
+    rc = lk_als_implicit_half_epoch(plan, ip.p, (const int32_t *)idx.p, (const float *)val.p,
+                                    n_rows, n_cols, k, (float *)thp.p, KP, (const float *)otp.p,
+                                    KP, (const float *)oo.p, k, ws.p, (float *)fr.p, nullptr);
+    if (rc != LK_OK) return fail(rc);
+    if ((rc = lk_als_check_status(plan, ws.p, nullptr)) != LK_OK) return fail(rc);
+    if ((rc = lk_unpad_rows((const float *)thp.p, n_rows, k, KP, (float *)th.p, k, nullptr)))
+        return fail(rc);
+    LK_H(hipDeviceSynchronize());
+    if (n_rows > 0) LK_H(hipMemcpy(h_this, th.p, (size_t)n_rows * k * 4, hipMemcpyDeviceToHost));
+    LK_H(hipMemcpy(h_out_frob, fr.p, 4, hipMemcpyDeviceToHost));
+#undef LK_H
+    lk_als_plan_destroy(plan);
+    return LK_OK;
+}

@@ -1,0 +1,224 @@
+// gramian.hip -- out = M^T M + reg*I on gfx950 (f32 MFMA, deterministic).
+//
+// Stands in for `_implicit_otor` (src/lenskit/als/_implicit.py:177-184), which is a
+// NumPy sgemm in the reference.  M is [n x ld] row-major with ld = padded k and
+// zero pad columns.
+//
+// Layout / mapping
+//   The k features are handled in "primed" order: feature f = s*NT + t  <->
+//   primed index p = t*16 + s  (t = 16-wide tile, s = lane & 15), so that one
+//   lane loads its NT features of a row as ONE contiguous NT-float vector and a
+//   16-lane group covers the whole row with a single coalesced request.
+//   v_mfma_f32_16x16x4_f32: A[i = lane&15][kk = lane>>4], B[kk][j = lane&15];
+//   kk indexes 4 consecutive rows of M.  Tile (ti,tj) accumulates
+//   D[i][j] += sum_rows M[row][f(ti,i)] * M[row][f(tj,j)].
+//   Only upper tiles (ti <= tj) are computed; they are dealt round-robin to the 4
+//   waves of a block, every wave streams the block's row slab (L1-served for
+//   waves 1..3).  Each block writes one partial [KP x KP] slab; a second kernel
+//   sums the slabs in block order (fixed order => bit-reproducible), adds reg*I,
+//   un-permutes and mirrors, so the result is exactly symmetric.
+//
+// Roofline: HBM-bound, algorithmic bytes = n*k*4 (one read of M).
+#include "common.h"
+
+namespace lk {
+
+constexpr int GRAM_WAVES = 4;
+
+__host__ __device__ constexpr int gram_tiles(int NT) { return NT * (NT + 1) / 2; }
+
+// e-th upper tile, column-major packed: e = tj*(tj+1)/2 + ti
+__host__ __device__ constexpr int tile_tj(int e)
+{
+    int tj = 0;
+    while ((tj + 1) * (tj + 2) / 2 <= e) ++tj;
+    return tj;
+}
+__host__ __device__ constexpr int tile_ti(int e) { return e - tile_tj(e) * (tile_tj(e) + 1) / 2; }
+
+template <int NT>
+struct QVec {
+    float v[NT];
+};
+
+template <int NT>
+__device__ __forceinline__ QVec<NT> load_qvec(const float *p)
+{
+    QVec<NT> q;
+    if constexpr (NT == 1) {
+        q.v[0] = *p;
+    } else if constexpr (NT == 2) {
+        f32x2 t = *reinterpret_cast<const f32x2 *>(p);
+        q.v[0] = t.x;
+        q.v[1] = t.y;
+    } else {
+#pragma unroll
+        for (int c = 0; c < NT / 4; ++c) {
+            f32x4 t = *reinterpret_cast<const f32x4 *>(p + 4 * c);
+            q.v[4 * c + 0] = t.x;
+            q.v[4 * c + 1] = t.y;
+            q.v[4 * c + 2] = t.z;
+            q.v[4 * c + 3] = t.w;
+        }
+    }
+    return q;
+}
+
+template <int NT, int W>
+__device__ __forceinline__ void gram_wave(const float *__restrict__ m, int64_t row_beg,
+                                          int64_t row_end, int ld, float *__restrict__ slab)
+{
+    constexpr int NTILES = gram_tiles(NT);
+    constexpr int NLOC = (NTILES - W + GRAM_WAVES - 1) / GRAM_WAVES;  // tiles of this wave
+    constexpr int KP = NT * 16;
+    const int lane = lane_id();
+    const int sub = lane & 15, slot = lane >> 4;
+
+    f32x4 acc[NLOC > 0 ? NLOC : 1];
+#pragma unroll
+    for (int l = 0; l < NLOC; ++l) acc[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int PF = (NT >= 8) ? 2 : 4;  // groups in flight
+    QVec<NT> qn[PF];
+    const int64_t ngroups = (row_end - row_beg + 3) >> 2;
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        int64_t r = row_beg + (int64_t)p * 4 + slot;
+        if (r < row_end)
+            qn[p] = load_qvec<NT>(m + r * ld + sub * NT);
+        else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) qn[p].v[t] = 0.f;
+        }
+    }
+    for (int64_t g0 = 0; g0 < ngroups; g0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            QVec<NT> q = qn[p];
+            int64_t rn = row_beg + (g0 + p + PF) * 4 + slot;
+            if (rn < row_end)
+                qn[p] = load_qvec<NT>(m + rn * ld + sub * NT);
+            else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) qn[p].v[t] = 0.f;
+            }
+#pragma unroll
+            for (int l = 0; l < NLOC; ++l) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int e = l * GRAM_WAVES + W;
+                const int ti = tile_ti(e), tj = tile_tj(e);
+                acc[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.v[ti], q.v[tj], acc[l], 0, 0, 0);
+            }
+        }
+    }
+    // D[i = slot*4 + r][j = sub]  ->  slab[(ti*16 + i) * KP + tj*16 + j]
+#pragma unroll
+    for (int l = 0; l < NLOC; ++l) {
+        const int e = l * GRAM_WAVES + W;
+        const int ti = tile_ti(e), tj = tile_tj(e);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            slab[(ti * 16 + slot * 4 + r) * KP + tj * 16 + sub] = acc[l][r];
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void gramian_partial_kernel(const float *__restrict__ m,
+                                                              int64_t n, int ld,
+                                                              int64_t rows_per_block,
+                                                              float *__restrict__ ws)
+{
+    constexpr int KP = NT * 16;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int64_t row_beg = (int64_t)blockIdx.x * rows_per_block;
+    int64_t row_end = row_beg + rows_per_block;
+    if (row_end > n) row_end = n;
+    if (row_beg > n) row_beg = n;
+    float *slab = ws + (size_t)blockIdx.x * KP * KP;
+    switch (wave) {
+        case 0: gram_wave<NT, 0>(m, row_beg, row_end, ld, slab); break;
+        case 1: gram_wave<NT, 1>(m, row_beg, row_end, ld, slab); break;
+        case 2: gram_wave<NT, 2>(m, row_beg, row_end, ld, slab); break;
+        default: gram_wave<NT, 3>(m, row_beg, row_end, ld, slab); break;
+    }
+}
+
+// One thread per primed upper-tile element; sums the slabs in block order.
+template <int NT>
+__global__ void gramian_finish_kernel(const float *__restrict__ ws, int nblocks, int k, float reg,
+                                      float *__restrict__ out, int ld_out)
+{
+    constexpr int KP = NT * 16;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= KP * KP) return;
+    int pr = idx / KP, pc = idx % KP;
+    int ti = pr >> 4, tj = pc >> 4;
+    if (ti > tj) return;  // lower tiles are never written by the partial kernel
+    int fr = (pr & 15) * NT + ti, fc = (pc & 15) * NT + tj;
+    if (fr >= k || fc >= k) return;
+    // within a diagonal tile both (fr,fc) and (fc,fr) are present and equal up to
+    // operand order (a*b == b*a exactly), so taking fr <= fc is enough.
+    if (ti == tj && fr > fc) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += ws[(size_t)b * KP * KP + idx];
+    if (fr == fc) s += reg;
+    out[fr * ld_out + fc] = s;
+    out[fc * ld_out + fr] = s;
+}
+
+static int gram_blocks(int64_t n, int KP)
+{
+    // enough blocks to fill 256 CUs, fewer slabs for wide k (slab = KP*KP*4 bytes)
+    int64_t maxb = (KP >= 256) ? 128 : (KP >= 128 ? 256 : 512);
+    int64_t b = (n + 63) / 64;  // at least 64 rows (16 groups) per block
+    if (b > maxb) b = maxb;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <int NT>
+static int launch_gramian(const float *m, int64_t n, int k, int ld, float reg, float *out,
+                          int ld_out, float *ws, hipStream_t st)
+{
+    constexpr int KP = NT * 16;
+    int nb = gram_blocks(n, KP);
+    int64_t rpb = ((n + nb - 1) / nb + 3) / 4 * 4;
+    if (rpb < 4) rpb = 4;
+    hipLaunchKernelGGL(gramian_partial_kernel<NT>, dim3(nb), dim3(256), 0, st, m, n, ld, rpb, ws);
+    int nth = KP * KP;
+    hipLaunchKernelGGL(gramian_finish_kernel<NT>, dim3((nth + 255) / 256), dim3(256), 0, st, ws,
+                       nb, k, reg, out, ld_out);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+}  // namespace lk
+
+extern "C" size_t lk_gramian_workspace_bytes(int32_t k)
+{
+    int KP = lk_padded_dim(k);
+    if (KP == 0) return 0;
+    return (size_t)512 * KP * KP * sizeof(float);
+}
+
+extern "C" int lk_gramian(const float *d_m, int64_t n, int32_t k, int32_t ld, float reg,
+                          float *d_out, int32_t ld_out, void *d_ws, void *stream)
+{
+    int KP = lk_padded_dim(k);
+    LK_REQUIRE(KP > 0, "lk_gramian: unsupported k=%d", k);
+    LK_REQUIRE(ld == KP, "lk_gramian: ld=%d must equal lk_padded_dim(k)=%d", ld, KP);
+    LK_REQUIRE(ld_out >= k, "lk_gramian: ld_out=%d < k=%d", ld_out, k);
+    LK_REQUIRE(d_m && d_out && d_ws, "lk_gramian: null pointer");
+    LK_REQUIRE(n >= 0, "lk_gramian: negative n");
+    hipStream_t st = lk::as_stream(stream);
+    float *ws = static_cast<float *>(d_ws);
+    switch (KP) {
+        case 16: return lk::launch_gramian<1>(d_m, n, k, ld, reg, d_out, ld_out, ws, st);
+        case 32: return lk::launch_gramian<2>(d_m, n, k, ld, reg, d_out, ld_out, ws, st);
+        case 64: return lk::launch_gramian<4>(d_m, n, k, ld, reg, d_out, ld_out, ws, st);
+        case 128: return lk::launch_gramian<8>(d_m, n, k, ld, reg, d_out, ld_out, ws, st);
+        case 256: return lk::launch_gramian<16>(d_m, n, k, ld, reg, d_out, ld_out, ws, st);
+    }
+    return LK_E_INVALID;
+}

@@ -34,10 +34,17 @@
 typedef void (*lko_sposv_fn)(const char *uplo, const int *n, const int *nrhs, float *a,
                              const int *lda, float *b, const int *ldb, int *info);
 
+/* Thread cap: every row solve calls OpenBLAS' sposv concurrently, and SciPy's
+ * bundled OpenBLAS has a fixed pool of per-thread work buffers (built for 64
+ * threads); more concurrent callers than that crash it.  The reference itself
+ * defaults to min(ncpus, 8) worker threads (src/lenskit/schemas/settings.py:182-185). */
+#define LKO_MAX_THREADS 32
+
 int lko_num_threads(void)
 {
 #ifdef _OPENMP
-    return omp_get_max_threads();
+    int n = omp_get_max_threads();
+    return n > LKO_MAX_THREADS ? LKO_MAX_THREADS : n;
 #else
     return 1;
 #endif
@@ -130,7 +137,10 @@ int lko_als_implicit_half_epoch(void *sposv_ptr, const int64_t *indptr, const in
     double total = 0.0; /* partials are f32 like the reference; the cross-thread
                            combine order is free in the reference (rayon) */
 #ifdef _OPENMP
-    if (n_threads <= 0) n_threads = omp_get_max_threads();
+    if (n_threads <= 0 || n_threads > LKO_MAX_THREADS) {
+        int cap = lko_num_threads();
+        n_threads = (n_threads <= 0 || n_threads > cap) ? cap : n_threads;
+    }
 #else
     n_threads = 1;
 #endif
@@ -256,6 +266,7 @@ int lko_iknn_build(const int64_t *ui_ptr, const int32_t *ui_idx, const float *ui
     (void)n_users;
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
+    if (n_threads > 256) n_threads = 256;
 #else
     n_threads = 1;
 #endif

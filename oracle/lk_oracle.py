@@ -139,6 +139,30 @@ def als_half_epoch(
     return float(frob.value)
 
 
+def als_half_epoch_f64(matrix: sps.csr_array, other: np.ndarray, reg: float) -> np.ndarray:
+    """
+    REFEREE, not the reference: the same half-epoch in float64 (Gramian, normal
+    matrices and solves), i.e. the exact answer both float32 implementations (the
+    reference's sposv path and the HIP kernels) approximate.  The reference's own
+    float32 result deviates from it by cond(A)*eps ~ 1e-4..5e-3 on ml-latest-small,
+    which is the noise floor of any float32-vs-float32 comparison there.
+    """
+    o64 = np.asarray(other, dtype=np.float64)
+    k = o64.shape[1]
+    otor = o64.T @ o64 + reg * np.eye(k)
+    out = np.zeros((matrix.shape[0], k), dtype=np.float64)
+    indptr, indices, data = matrix.indptr, matrix.indices, matrix.data
+    for r in range(matrix.shape[0]):
+        s, e = indptr[r], indptr[r + 1]
+        if e == s:
+            continue
+        M = o64[indices[s:e]]
+        v = data[s:e].astype(np.float64)
+        A = otor + (M.T * v) @ M
+        out[r] = np.linalg.solve(A, M.T @ (v + 1.0))
+    return out
+
+
 def als_initial_params(rng: np.random.Generator, nrows: int, ncols: int) -> np.ndarray:
     "``ImplicitMFTrainer.initial_params`` (src/lenskit/als/_implicit.py:152-155)."
     mat = rng.standard_normal((nrows, ncols), dtype=np.float32) * 0.01
