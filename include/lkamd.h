@@ -107,6 +107,14 @@ int lk_als_implicit_half_epoch(const lk_als_plan *plan, const void *d_indptr,
                                int64_t n_cols, int32_t k, float *d_this, int32_t ld_this,
                                const float *d_other, int32_t ld_other, const float *d_otor,
                                int32_t ld_otor, void *d_ws, float *d_out_frob, void *stream);
+/* Optional per-kernel timing with HIP events recorded on the launch stream
+ * (bench.py's roofline leg).  get_timing waits for the recorded events, returns the
+ * summed durations (ms) of the chunk kernel and of the solve kernel over the
+ * *n_launches half-epochs recorded since the last call (at most 128), and resets. */
+int lk_als_plan_enable_timing(lk_als_plan *plan, int enable);
+int lk_als_plan_get_timing(lk_als_plan *plan, double *ms_chunk, double *ms_solve,
+                           int32_t *n_launches);
+
 /* Synchronise `stream` and translate the device status word of the last
  * half-epoch into a return code (LK_E_NOT_SPD with the offending row in
  * lk_last_error()).  Call before trusting `this`. */

@@ -1,0 +1,217 @@
+"""
+Device-resident implicit-ALS training engine (one process per GPU).
+
+Mirrors the epoch structure of ``ALSTrainerBase`` / ``ImplicitMFTrainer``
+(src/lenskit/als/_common.py:209-256, src/lenskit/als/_implicit.py:135-175):
+
+    epoch = user half (OtOr = Q^T Q + user_reg I, previous Q)
+          + item half (OtOr = P^T P + item_reg I, NEW P)
+
+but keeps both CSR orientations and both factor matrices in HBM across epochs, so a
+training run crosses PCIe once in and once out.
+
+Row layout.  Users and items are RELABELLED once at set-up: rows are sorted by length
+(longest first) and dealt round-robin to the ``world`` ranks; rank r owns the
+contiguous block ``[r*rpr, (r+1)*rpr)`` of the relabelled matrix (padded with empty
+rows).  This gives every rank the same row count and nearly the same nnz, lets the
+half-epoch kernel write straight into the rank's slice of the replicated factor
+matrix, makes the exchange a single in-place ``all_gather_into_tensor`` (RCCL picks
+the xGMI full-mesh all-gather), and packs the factor rows of popular items together
+(better L2 hit rate for the gathers).  Host-visible factors are un-permuted on
+download, so callers never see the relabelling.
+
+Collectives per epoch (world > 1): all-gather of the freshly solved P slice, k x k
+all-reduce of the slice Gramians, the same for Q, and a scalar all-reduce of the
+squared deltas.  No collective at world == 1.
+
+The arithmetic lives behind a small backend object so the sharding / exchange logic
+can be exercised on CPU (gloo) in tests with the oracle standing in for the kernels;
+the product backend is :class:`HipBackend` and there is no fallback.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sps
+import torch
+import torch.distributed as dist
+
+from . import _native
+
+
+def deal_rows(lengths: np.ndarray, world: int):
+    """
+    Relabelling of rows for ``world`` ranks: returns (new_of_old, old_of_new, rpr) with
+    ``rpr`` rows per rank; new index = rank*rpr + j for the j-th row dealt to ``rank``.
+    Slots beyond the real rows (padding) have old_of_new == -1.
+    """
+    n = len(lengths)
+    order = np.argsort(-lengths.astype(np.int64), kind="stable")
+    rpr = (n + world - 1) // world
+    j, r = np.divmod(np.arange(n), world)
+    # serpentine dealing keeps the per-rank nnz closer than plain round-robin
+    r = np.where(j % 2 == 0, r, world - 1 - r)
+    new_pos = r * rpr + j
+    new_of_old = np.empty(n, dtype=np.int64)
+    new_of_old[order] = new_pos
+    old_of_new = np.full(world * rpr, -1, dtype=np.int64)
+    old_of_new[new_pos] = order
+    return new_of_old, old_of_new, rpr
+
+
+def _relabel_csr(mat: sps.csr_array, row_new_of_old, n_rows_new, col_new_of_old, n_cols_new):
+    "Apply the row/column relabelling; returns CSR with sorted column indices."
+    coo = mat.tocoo()
+    out = sps.csr_array(
+        (coo.data, (row_new_of_old[coo.row], col_new_of_old[coo.col])),
+        shape=(n_rows_new, n_cols_new),
+    )
+    out.sort_indices()
+    return out
+
+
+class HipBackend:
+    "The product backend: hand-written HIP kernels through the C ABI."
+
+    def __init__(self, k: int, dev, solver=_native.SOLVER_AUTO):
+        from . import _device as D
+
+        self.D = D
+        self.k = k
+        self.dev = D.device(dev)
+        self.kp = D.padded_dim(k)
+        self.solver = solver
+        self._gram = D.Gramian(k, self.dev)
+
+    def make_plan(self, local_csr: sps.csr_array):
+        csr = self.D.DeviceCSR.from_scipy(local_csr, self.dev)
+        return self.D.ALSPlan(csr, self.k, self.solver)
+
+    def upload(self, mat: np.ndarray) -> torch.Tensor:
+        return self.D.to_device_padded(mat, self.dev)
+
+    def download(self, mat: torch.Tensor) -> np.ndarray:
+        return self.D.to_host_unpadded(mat, self.k)
+
+    def gramian(self, rows: torch.Tensor, reg: float) -> torch.Tensor:
+        return self._gram(rows, reg)
+
+    def half_epoch(self, plan, this_slice, other_full, otor) -> torch.Tensor:
+        "-> device scalar sqrt(sum ||delta||^2) of the slice"
+        return plan.half_epoch(this_slice, other_full, otor)
+
+    def check(self, plan):
+        plan.check_status()
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.dev)
+
+
+class ImplicitALSEngine:
+    def __init__(
+        self,
+        ui: sps.csr_array,
+        k: int,
+        user_reg: float,
+        item_reg: float,
+        user_init: np.ndarray,
+        item_init: np.ndarray,
+        backend,
+        group=None,
+    ):
+        self.k = int(k)
+        self.backend = backend
+        self.user_reg, self.item_reg = float(user_reg), float(item_reg)
+        self.group = group
+        self.world = dist.get_world_size(group) if (group is not None or _dist_on()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        n_users, n_items = ui.shape
+        ui = sps.csr_array(ui)
+        self.n_users, self.n_items = n_users, n_items
+
+        ulen = np.diff(ui.indptr)
+        ilen = np.bincount(ui.indices, minlength=n_items)
+        self.u_new, self.u_old, self.u_rpr = deal_rows(ulen, self.world)
+        self.i_new, self.i_old, self.i_rpr = deal_rows(ilen, self.world)
+        nu, ni = self.world * self.u_rpr, self.world * self.i_rpr
+
+        ui_new = _relabel_csr(ui, self.u_new, nu, self.i_new, ni)
+        iu_new = sps.csr_array(ui_new.T)
+        iu_new.sort_indices()
+        r = self.rank
+        self.u_lo, self.u_hi = r * self.u_rpr, (r + 1) * self.u_rpr
+        self.i_lo, self.i_hi = r * self.i_rpr, (r + 1) * self.i_rpr
+        self.u_plan = backend.make_plan(ui_new[self.u_lo : self.u_hi])
+        self.i_plan = backend.make_plan(iu_new[self.i_lo : self.i_hi])
+        self.local_nnz = (int(ui_new.indptr[self.u_hi] - ui_new.indptr[self.u_lo]),
+                          int(iu_new.indptr[self.i_hi] - iu_new.indptr[self.i_lo]))  # fmt: skip
+
+        P = np.zeros((nu, self.k), dtype=np.float32)
+        Q = np.zeros((ni, self.k), dtype=np.float32)
+        P[self.u_new] = user_init
+        Q[self.i_new] = item_init
+        self.P = backend.upload(P)
+        self.Q = backend.upload(Q)
+        # Gramian of the initial Q (user half of epoch 1 needs it); padding rows are 0
+        self._qtq = self._gramian(self.Q, self.i_lo, self.i_hi, self.user_reg)
+        self.epochs_trained = 0
+
+    # -- collectives ---------------------------------------------------------
+    def _gramian(self, full: torch.Tensor, lo: int, hi: int, reg: float) -> torch.Tensor:
+        "M^T M + reg I from slice Gramians (k x k all-reduce when sharded)."
+        if self.world == 1:
+            return self.backend.gramian(full, reg)
+        g = self.backend.gramian(full[lo:hi], reg if self.rank == 0 else 0.0)
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+        return g
+
+    def _exchange(self, full: torch.Tensor, lo: int, hi: int):
+        if self.world > 1:
+            dist.all_gather_into_tensor(full, full[lo:hi], group=self.group)
+
+    # -- training ------------------------------------------------------------
+    def train_epoch(self):
+        "One epoch; returns device tensors (|dP|, |dQ|) -- no host sync inside."
+        b = self.backend
+        # user half: previous Q (src/lenskit/als/_common.py:251)
+        du = b.half_epoch(self.u_plan, self.P[self.u_lo : self.u_hi], self.Q, self._qtq)
+        du = self._delta(du)
+        self._exchange(self.P, self.u_lo, self.u_hi)
+        ptp = self._gramian(self.P, self.u_lo, self.u_hi, self.item_reg)
+        # item half: NEW P (_common.py:253)
+        di = b.half_epoch(self.i_plan, self.Q[self.i_lo : self.i_hi], self.P, ptp)
+        di = self._delta(di)
+        self._exchange(self.Q, self.i_lo, self.i_hi)
+        # Q^T Q + user_reg I: next epoch's user half AND the scorer's _OtOr
+        # (_save_user_otor, src/lenskit/als/_implicit.py:171-175)
+        self._qtq = self._gramian(self.Q, self.i_lo, self.i_hi, self.user_reg)
+        self.epochs_trained += 1
+        return du, di
+
+    def _delta(self, d: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return d.clone()
+        sq = d * d
+        dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
+        return sq.sqrt()
+
+    def check(self):
+        "Synchronise; raise RuntimeError('ALS solve error: ...') if a solve failed."
+        self.backend.check(self.u_plan)
+        self.backend.check(self.i_plan)
+
+    # -- results (host, original labelling) ------------------------------------
+    def user_embeddings(self) -> np.ndarray:
+        return self.backend.download(self.P)[self.u_new]
+
+    def item_embeddings(self) -> np.ndarray:
+        return self.backend.download(self.Q)[self.i_new]
+
+    def otor(self) -> np.ndarray:
+        "Q^T Q + user_reg I (k x k) -- the scorer's ``_OtOr``."
+        g = self._qtq
+        return g.cpu().numpy() if isinstance(g, torch.Tensor) else np.asarray(g)
+
+
+def _dist_on() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1

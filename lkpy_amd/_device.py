@@ -183,6 +183,19 @@ class ALSPlan:
         )  # fmt: skip
         return self.frob
 
+    def enable_timing(self, enable: bool = True):
+        check(_native.load().lk_als_plan_enable_timing(self._h, 1 if enable else 0))
+
+    def get_timing(self):
+        "-> (ms in the chunk kernel, ms in the solve kernel, half-epochs recorded); resets."
+        a, b, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int32(0)
+        check(
+            _native.load().lk_als_plan_get_timing(
+                self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)
+            )
+        )
+        return a.value, b.value, n.value
+
     def check_status(self):
         "Synchronise and raise RuntimeError('ALS solve error: ...') on a failed solve."
         check(_native.load().lk_als_check_status(self._h, _ptr(self.ws), _stream()))

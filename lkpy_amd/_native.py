@@ -59,6 +59,10 @@ def _declare(lib):
              vp, vp],
         ),
         "lk_als_check_status": (c_int, [vp, vp, vp]),
+        "lk_als_plan_enable_timing": (c_int, [vp, c_int]),
+        "lk_als_plan_get_timing": (
+            c_int, [vp, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int32)]
+        ),
         "lk_als_implicit_half_epoch_host": (
             c_int,
             [vp, c_int, vp, vp, c_int64, c_int64, c_int32, vp, vp, vp, c_int32, vp],

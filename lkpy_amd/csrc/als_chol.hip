@@ -55,6 +55,12 @@ struct lk_als_plan {
            ws_bytes = 0;
     float cg_tol = 1e-7f;
     int32_t cg_max_iter = 0;
+    // optional per-kernel timing (HIP events on the launch stream): ring of
+    // (start, mid, stop) triples -- start..mid = chunk kernel, mid..stop = solve kernel
+    static constexpr int TIMING_RING = 128;
+    bool timing = false;
+    mutable int timing_n = 0;
+    mutable hipEvent_t ev[TIMING_RING][3] = {};
 };
 
 namespace lk {
@@ -428,17 +434,24 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
     LK_HIP_CHECK(hipMemsetAsync(status, 0, 64, st));
     hipLaunchKernelGGL(als_prep_otor_kernel<NT>, dim3((KP * KP + 255) / 256), dim3(256), 0, st,
                        otor, ld_otor, k, otor_p);
+    const bool tm = p->timing && p->timing_n < lk_als_plan::TIMING_RING;
+    if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][0], st));
     if (p->n_chunks > 0) {
         hipLaunchKernelGGL(als_chunk_kernel<NT>, dim3((unsigned)((p->n_chunks + 3) / 4)),
                            dim3(256), 0, st, indices, values, p->d_chunk_beg, p->d_chunk_len,
                            p->n_chunks, other, ld_other, slabs);
     }
+    if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
     if (n_rows > 0) {
         using IT = typename IndPtr<IS64>::type;
         hipLaunchKernelGGL((als_solve_kernel<NT, IS64>), dim3((unsigned)((n_rows + 3) / 4)),
                            dim3(256), 0, st, static_cast<const IT *>(indptr), indices, values,
                            p->d_order, n_rows, p->d_row_slab, other, ld_other, this_, ld_this,
                            otor_p, slabs, row_delta, status, k);
+    }
+    if (tm) {
+        LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][2], st));
+        p->timing_n++;
     }
     hipLaunchKernelGGL(delta_partial_kernel, dim3(DELTA_BLOCKS), dim3(256), 0, st, row_delta,
                        n_rows, partial);
@@ -565,9 +578,43 @@ extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int i
     return LK_OK;
 }
 
+extern "C" int lk_als_plan_enable_timing(lk_als_plan *p, int enable)
+{
+    LK_REQUIRE(p != nullptr, "lk_als_plan_enable_timing: null plan");
+    if (enable && !p->ev[0][0]) {
+        for (int i = 0; i < lk_als_plan::TIMING_RING; ++i)
+            for (int j = 0; j < 3; ++j) LK_HIP_CHECK(hipEventCreate(&p->ev[i][j]));
+    }
+    p->timing = enable != 0;
+    p->timing_n = 0;
+    return LK_OK;
+}
+
+extern "C" int lk_als_plan_get_timing(lk_als_plan *p, double *ms_chunk, double *ms_solve,
+                                      int32_t *n_launches)
+{
+    LK_REQUIRE(p && ms_chunk && ms_solve && n_launches, "lk_als_plan_get_timing: null pointer");
+    *ms_chunk = 0.0;
+    *ms_solve = 0.0;
+    *n_launches = p->timing_n;
+    for (int i = 0; i < p->timing_n; ++i) {
+        float a = 0.f, b = 0.f;
+        LK_HIP_CHECK(hipEventSynchronize(p->ev[i][2]));
+        LK_HIP_CHECK(hipEventElapsedTime(&a, p->ev[i][0], p->ev[i][1]));
+        LK_HIP_CHECK(hipEventElapsedTime(&b, p->ev[i][1], p->ev[i][2]));
+        *ms_chunk += a;
+        *ms_solve += b;
+    }
+    p->timing_n = 0;
+    return LK_OK;
+}
+
 extern "C" void lk_als_plan_destroy(lk_als_plan *p)
 {
     if (!p) return;
+    if (p->ev[0][0])
+        for (int i = 0; i < lk_als_plan::TIMING_RING; ++i)
+            for (int j = 0; j < 3; ++j) (void)hipEventDestroy(p->ev[i][j]);
     if (p->d_order) (void)hipFree(p->d_order);
     if (p->d_row_slab) (void)hipFree(p->d_row_slab);
     if (p->d_chunk_row) (void)hipFree(p->d_chunk_row);
