@@ -31,6 +31,7 @@
 // rows*(k^3/3 + 2k^2) flop per half-epoch); HBM traffic is the CSR stream plus
 // the (L2/MALL-resident) gathered factor rows.
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -95,76 +96,108 @@ __device__ __forceinline__ void load_q(const float *p, float (&q)[NT])
 }
 
 // Accumulate CSR entries [beg, end) of one row into G (A tiles and y).
+//
+// Software pipeline: entries are taken in batches of 64 (one coalesced load of
+// indices + values per wave, fetched ONE BATCH AHEAD), each batch is 16 groups of
+// 4 entries (= one K=4 MFMA step).  The gathered factor rows live in an 8-slot
+// register ring: the gather for group g+8 is issued as soon as group g has been
+// consumed -- across batch boundaries too -- so ~8 x 320 MFMA cycles of work cover
+// every gather and the wave never drains its memory queue inside a row.
+template <int NT>
+struct GatherRing {
+    static constexpr int RING = 8;
+    float q[RING][NT];
+    float v[RING];
+};
+
+template <int NT>
+__device__ __forceinline__ void ring_issue(GatherRing<NT> &R, const int slot_idx, const int g,
+                                           const int col_reg, const float val_reg,
+                                           const float *__restrict__ other)
+{
+    constexpr int KP = NT * 16;
+    const int lane = lane_id();
+    const int s = (g * 4 + (lane >> 4)) & 63;
+    const int col = __shfl(col_reg, s, 64);
+    R.v[slot_idx] = __shfl(val_reg, s, 64);
+    load_q<NT>(other + (int64_t)col * KP + (lane & 15) * NT, R.q[slot_idx]);
+}
+
+template <int NT>
+__device__ __forceinline__ void ring_consume(Gram<NT> &G, const GatherRing<NT> &R,
+                                             const int slot_idx, const int g, const int nb)
+{
+    const int lane = lane_id();
+    // entries past the row end carry (col 0, v 0): kill their q so that neither
+    // A (v*q*q) nor y ((v+1)*q) sees them
+    const bool live = (g * 4 + (lane >> 4)) < nb;
+    const float v = R.v[slot_idx];
+    float q[NT], a[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        q[t] = live ? R.q[slot_idx][t] : 0.f;
+        a[t] = q[t] * v;  // `mtl = mt * vals` (implicit.rs:110-111)
+    }
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int ti = 0; ti <= tj; ++ti)
+            G.t[tidx(ti, tj)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], q[tj],
+                                                                     G.t[tidx(ti, tj)], 0, 0, 0);
+    const float v1 = v + 1.0f;  // `vals += 1.0` (implicit.rs:116)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) G.y[t] = fmaf(q[t], v1, G.y[t]);
+}
+
 template <int NT>
 __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__restrict__ cols,
                                                 const float *__restrict__ vals, int64_t beg,
                                                 int64_t end, const float *__restrict__ other,
-                                                int ld)
+                                                int /*ld == 16*NT*/)
 {
     const int lane = lane_id();
-    const int sub = lane & 15, slot = lane >> 4;
-    constexpr int PF = 4;  // gathered groups (of 4 entries) in flight per wave
+    constexpr int RING = GatherRing<NT>::RING;
+    GatherRing<NT> R;
 
+    // batch 0 indices/values
+    int cur_col = 0, nxt_col = 0;
+    float cur_val = 0.f, nxt_val = 0.f;
+    if (beg + lane < end) {
+        cur_col = cols[beg + lane];
+        cur_val = vals[beg + lane];
+    }
+    {
+        const int nb0 = (end - beg) < 64 ? (int)(end - beg) : 64;
+        const int ng0 = (nb0 + 3) >> 2;
+#pragma unroll
+        for (int g = 0; g < RING; ++g)
+            if (g < ng0) ring_issue<NT>(R, g, g, cur_col, cur_val, other);
+    }
     for (int64_t base = beg; base < end; base += 64) {
-        const int64_t e = base + lane;
-        const bool ok = e < end;
-        const int mycol = ok ? cols[e] : 0;
-        const float myval = ok ? vals[e] : 0.f;
         const int nb = (end - base) < 64 ? (int)(end - base) : 64;
         const int ngroups = (nb + 3) >> 2;
-
-        float qn[PF][NT];
-        float vn[PF];
+        const int64_t nbase = base + 64;
+        const int nnb = nbase < end ? ((end - nbase) < 64 ? (int)(end - nbase) : 64) : 0;
+        const int nngroups = (nnb + 3) >> 2;
+        nxt_col = 0;
+        nxt_val = 0.f;
+        if (nbase + lane < end) {
+            nxt_col = cols[nbase + lane];
+            nxt_val = vals[nbase + lane];
+        }
 #pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const int s = p * 4 + slot;
-            const int col = __shfl(mycol, s, 64);
-            vn[p] = __shfl(myval, s, 64);
-            if (p < ngroups) {
-                load_q<NT>(other + (int64_t)col * ld + sub * NT, qn[p]);
+        for (int g = 0; g < 16; ++g) {
+            if (g < ngroups) ring_consume<NT>(G, R, g % RING, g, nb);
+            if (g < 16 - RING) {
+                if (g + RING < ngroups)
+                    ring_issue<NT>(R, g % RING, g + RING, cur_col, cur_val, other);
             } else {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) qn[p][t] = 0.f;
+                if (g + RING - 16 < nngroups)
+                    ring_issue<NT>(R, g % RING, g + RING - 16, nxt_col, nxt_val, other);
             }
         }
-        for (int g0 = 0; g0 < ngroups; g0 += PF) {
-#pragma unroll
-            for (int p = 0; p < PF; ++p) {
-                const int g = g0 + p;
-                float q[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) q[t] = qn[p][t];
-                const float v = vn[p];
-                // refill this ring slot with group g + PF
-                {
-                    const int gn = g + PF;
-                    const int s = (gn * 4 + slot) & 63;
-                    const int col = __shfl(mycol, s, 64);
-                    vn[p] = __shfl(myval, s, 64);
-                    if (gn < ngroups) load_q<NT>(other + (int64_t)col * ld + sub * NT, qn[p]);
-                }
-                if (g < ngroups) {
-                    // entries past the row end carry (col 0, v 0): kill their q so that
-                    // neither A (v*q*q) nor y ((v+1)*q) sees them
-                    const bool live = (g * 4 + slot) < nb;
-                    float a[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        q[t] = live ? q[t] : 0.f;
-                        a[t] = q[t] * v;  // `mtl = mt * vals` (implicit.rs:110-111)
-                    }
-#pragma unroll
-                    for (int tj = 0; tj < NT; ++tj)
-#pragma unroll
-                        for (int ti = 0; ti <= tj; ++ti)
-                            G.t[tidx(ti, tj)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                a[ti], q[tj], G.t[tidx(ti, tj)], 0, 0, 0);
-                    const float v1 = v + 1.0f;  // `vals += 1.0` (implicit.rs:116)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) G.y[t] = fmaf(q[t], v1, G.y[t]);
-                }
-            }
-        }
+        cur_col = nxt_col;
+        cur_val = nxt_val;
     }
 }
 
@@ -220,45 +253,173 @@ __global__ __launch_bounds__(256) void als_chunk_kernel(
 }
 
 // ---- solve: lane R owns row R of the (primed) normal matrix -----------------
-// a[c] (c <= R valid), b = rhs; lds: KP*(KP+1) floats, wave private.
-// Returns false when a pivot is not positive (matrix not SPD).
+//
+// Right-looking Cholesky with the matrix rows in registers (lane i: a[c] = A'[i][c]).
+// Step j: pivot broadcast (v_readlane), rinv = rsq(pivot), column j of L
+// (strictly lower: zero on and above the diagonal, so later updates need no lane
+// masks) is written to a packed LDS image; the NEXT pivot's update uses a
+// v_readlane fast path, the bulk of the trailing update reads L_cj back as
+// wave-uniform ds_read_b128 broadcasts (4 multipliers per LDS instruction), which
+// keeps the O(k^3/3) loop at one v_fma per element.  Forward substitution runs on
+// the register rows, back substitution on the LDS image (column access).
+//
+// Packed strictly-lower image: column j holds rows c in [c0(j), KP), c0 = (j+1)&~3
+// (16-byte aligned segments); off(j) = 4*KP*m - 8m^2 + 4m + r*(KP - 4m), j = 4m + r.
 template <int KP>
-__device__ __forceinline__ bool chol_solve(float (&a)[KP], float &b, float *__restrict__ lds)
+struct LPack {
+    __host__ __device__ static constexpr int c0(int j) { return (j + 1) & ~3; }
+    __host__ __device__ static constexpr int off(int j)
+    {
+        const int m = j >> 2, r = j & 3;
+        return 4 * KP * m - 8 * m * m + 4 * m + r * (KP - 4 * m);
+    }
+    static constexpr int SIZE = KP * KP / 2 + KP;
+};
+
+// Row storage: KP floats as KP/2 register PAIRS so the trailing update can use
+// v_pk_fma_f32 (two FMAs per VALU issue).  AT(a, c) is element c.
+#define AT(a, c) ((a)[(c) >> 1][(c) & 1])
+
+// One pipelined factorisation step (J compile-time): with column J of L in `lj`,
+// (1) finish column J+1 through the v_readlane fast path and start ITS pivot chain
+// (readlane -> rsq -> scale -> LDS write) while (2) the bulk of step J's trailing
+// update (c >= J+2) streams its multipliers back from LDS.  The two are independent,
+// so the v_pk_fma stream covers the pivot latency.
+template <int KP, int J>
+__device__ __forceinline__ void chol_step(f32x2 (&a)[KP / 2], float &lj, float &dinv,
+                                          float &minpiv, float *__restrict__ lds)
 {
+    using P = LPack<KP>;
     const int lane = lane_id();
-    constexpr int LD = KP + 1;
-    bool ok = true;
-    float dinv = 0.f;  // lane j keeps 1 / L_jj
+    const float ln = bcast(lj, J + 1);
+    AT(a, J + 1) = fmaf(-lj, ln, AT(a, J + 1));
+    const float ajj = bcast(AT(a, J + 1), J + 1);
+    minpiv = fminf(minpiv, ajj);
+    const float rinv = __builtin_amdgcn_rsqf(ajj);
+    dinv = (lane == J + 1) ? rinv : dinv;
+    const float lnext = (lane > J + 1) ? AT(a, J + 1) * rinv : 0.f;
+    AT(a, J + 1) = lnext;
+    if constexpr (J + 2 < KP) {
+        if (lane >= P::c0(J + 1)) lds[P::off(J + 1) + lane - P::c0(J + 1)] = lnext;
+    }
+    // multipliers L_cJ, c >= J+2, as wave-uniform ds_read_b128 broadcasts; the reads run
+    // LOOKAHEAD groups ahead of the FMAs that use them
+    constexpr int C0 = (J + 2) & ~3;
+    constexpr int NG = (KP - C0) / 4;
+    constexpr int LOOKAHEAD = 4;
+    if constexpr (NG > 0) {
+        const float *col = lds + P::off(J) - P::c0(J);
+        const f32x2 nl = f32x2{-lj, -lj};
+        f32x4 lq[NG];
 #pragma unroll
-    for (int j = 0; j < KP; ++j) {
-        const float ajj = bcast(a[j], j);
-        ok = ok && (ajj > 0.f);
-        const float d = sqrtf(ajj);
-        const float rinv = 1.0f / d;
-        const float lj = (lane == j) ? d : a[j] * rinv;  // column j of L (lanes >= j)
-        a[j] = lj;
-        dinv = (lane == j) ? rinv : dinv;
-        if (lane < KP) lds[j * LD + lane] = lj;  // L^T row j
+        for (int g = 0; g < NG && g < LOOKAHEAD; ++g)
+            lq[g] = *reinterpret_cast<const f32x4 *>(col + C0 + 4 * g);
 #pragma unroll
-        for (int c = j + 1; c < KP; ++c) {
-            const float lcj = bcast(lj, c);
-            a[c] = fmaf(-lj, lcj, a[c]);  // a_ic -= L_ij * L_cj   (i = lane >= c)
+        for (int g = 0; g < NG; ++g) {
+            if (g + LOOKAHEAD < NG)
+                lq[g + LOOKAHEAD] =
+                    *reinterpret_cast<const f32x4 *>(col + C0 + 4 * (g + LOOKAHEAD));
+            const int c4 = C0 + 4 * g;
+            // a_ic -= L_iJ * L_cJ for c = c4 .. c4+3, c >= J+2
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = c4 + 2 * h;
+                const f32x2 m = f32x2{lq[g][2 * h], lq[g][2 * h + 1]};
+                if (c >= J + 2)
+                    a[c >> 1] = __builtin_elementwise_fma(nl, m, a[c >> 1]);
+                else if (c + 1 >= J + 2)
+                    AT(a, c + 1) = fmaf(-lj, m[1], AT(a, c + 1));
+            }
+            // pin the updates here: without it the compiler sinks every FMA chain down to
+            // the step that first reads a[c] (a left-looking schedule that keeps all
+            // multipliers alive and spills hundreds of registers)
+            asm volatile("" : "+v"(a[c4 >> 1]), "+v"(a[(c4 >> 1) + 1]));
         }
     }
-    // forward: L z = y
+    lj = lnext;
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KP, int... Js>
+__device__ __forceinline__ void chol_steps(f32x2 (&a)[KP / 2], float &lj, float &dinv,
+                                           float &minpiv, float *__restrict__ lds,
+                                           std::integer_sequence<int, Js...>)
+{
+    (chol_step<KP, Js>(a, lj, dinv, minpiv, lds), ...);
+}
+
+// a: row `lane` of A' (entries c <= lane valid, anything above), b = rhs.  On return
+// b = solution for primed row `lane`; returns the smallest pivot seen (<= 0 or a
+// non-finite solution => not SPD).
+template <int KP>
+__device__ __forceinline__ float chol_solve(f32x2 (&a)[KP / 2], float &b,
+                                            float *__restrict__ lds)
+{
+    using P = LPack<KP>;
+    const int lane = lane_id();
+    float minpiv = 3.0e38f;
+    float dinv = 0.f;  // lane j keeps 1 / L_jj
+
+    // column 0
+    float lj;
+    {
+        const float ajj = bcast(AT(a, 0), 0);
+        minpiv = fminf(minpiv, ajj);
+        const float rinv = __builtin_amdgcn_rsqf(ajj);
+        dinv = (lane == 0) ? rinv : dinv;
+        lj = (lane > 0) ? AT(a, 0) * rinv : 0.f;  // strictly-lower column 0
+        AT(a, 0) = lj;
+        lds[P::off(0) + lane - P::c0(0)] = lj;
+    }
+    chol_steps<KP>(a, lj, dinv, minpiv, lds, std::make_integer_sequence<int, KP - 1>{});
+    // forward: L z = y.  a[j] is zero for lanes <= j, so no masks: lane i only
+    // receives the terms j < i; z_i = b_i * dinv_i.
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
         const float zj = bcast(b * dinv, j);
-        b = (lane == j) ? zj : ((lane > j) ? fmaf(-a[j], zj, b) : b);
+        b = fmaf(-AT(a, j), zj, b);
     }
-    // backward: L^T x = z ; L[j][i] = lds[i*LD + j]
+    b *= dinv;
+    // backward: L^T x = z.  Lane i needs L[j][i] (j > i) = column i of the LDS image,
+    // read four rows at a time (ds_read_b128; rows <= i inside the column are stored
+    // zeros, rows below c0(i) are outside it).
+    const int my_c0 = (lane + 1) & ~3;
+    const float *mycol = lds + P::off(lane) - my_c0;
 #pragma unroll
-    for (int j = KP - 1; j >= 0; --j) {
-        const float xj = bcast(b * dinv, j);
-        const float lji = (lane < KP) ? lds[lane * LD + j] : 0.f;
-        b = (lane == j) ? xj : ((lane < j) ? fmaf(-lji, xj, b) : b);
+    for (int j4 = KP / 4 - 1; j4 >= 0; --j4) {
+        f32x4 l4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lane < KP - 1 && 4 * j4 >= my_c0) l4 = *reinterpret_cast<const f32x4 *>(mycol + 4 * j4);
+#pragma unroll
+        for (int u = 3; u >= 0; --u) {
+            const int j = 4 * j4 + u;
+            if (j >= 1) {
+                const float xj = bcast(b * dinv, j);
+                b = fmaf(-l4[u], xj, b);
+            }
+        }
     }
-    return ok;
+    b *= dinv;
+    return minpiv;
+}
+
+// transposition buffer: row R' (tile row tr = R' >> 4) keeps its (tr+1)*16 lower
+// entries; stride inside tile row tr is (tr+1)*16 + 4 floats (16-byte aligned).
+template <int NT>
+struct TPack {
+    __host__ __device__ static constexpr int stride(int tr) { return (tr + 1) * 16 + 4; }
+    __host__ __device__ static constexpr int base(int tr)
+    {
+        int b = 0;
+        for (int t = 0; t < tr; ++t) b += 16 * stride(t);
+        return b;
+    }
+    static constexpr int SIZE = base(NT);
+};
+
+template <int NT>
+__host__ __device__ constexpr int solve_lds_floats()
+{
+    return TPack<NT>::SIZE > LPack<NT * 16>::SIZE ? TPack<NT>::SIZE : LPack<NT * 16>::SIZE;
 }
 
 template <int NT, bool IS64>
@@ -271,8 +432,7 @@ __global__ __launch_bounds__(256) void als_solve_kernel(
     int k)
 {
     constexpr int KP = NT * 16;
-    constexpr int LDT = KP + 4;  // transposition buffer stride (16-byte aligned rows)
-    __shared__ __attribute__((aligned(16))) float lds_all[4][KP * LDT];
+    __shared__ __attribute__((aligned(16))) float lds_all[4][solve_lds_floats<NT>()];
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
@@ -328,23 +488,26 @@ __global__ __launch_bounds__(256) void als_solve_kernel(
     for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
         for (int ti = 0; ti <= tj; ++ti)
-            *reinterpret_cast<f32x4 *>(&lds[(tj * 16 + sub) * LDT + ti * 16 + slot * 4]) =
+            *reinterpret_cast<f32x4 *>(
+                &lds[TPack<NT>::base(tj) + sub * TPack<NT>::stride(tj) + ti * 16 + slot * 4]) =
                 G.t[tidx(ti, tj)];
 
-    float a[KP];
+    f32x2 a[KP / 2];
     float b = 0.f;
-    if (lane < KP) {
+    {
+        // lane = primed row: tile row slot (= lane >> 4), row-in-tile sub
+        int rowoff = 0;
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr)
+            rowoff = (slot == tr) ? TPack<NT>::base(tr) + sub * TPack<NT>::stride(tr) : rowoff;
 #pragma unroll
         for (int c4 = 0; c4 < KP / 4; ++c4) {
-            f32x4 v = *reinterpret_cast<const f32x4 *>(&lds[lane * LDT + c4 * 4]);
-            a[c4 * 4 + 0] = v.x;
-            a[c4 * 4 + 1] = v.y;
-            a[c4 * 4 + 2] = v.z;
-            a[c4 * 4 + 3] = v.w;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (lane < KP && (c4 >> 2) <= slot)
+                v = *reinterpret_cast<const f32x4 *>(&lds[rowoff + c4 * 4]);
+            a[c4 * 2 + 0] = f32x2{v.x, v.y};
+            a[c4 * 2 + 1] = f32x2{v.z, v.w};
         }
-    } else {
-#pragma unroll
-        for (int c = 0; c < KP; ++c) a[c] = 0.f;
     }
     // rhs for primed row `lane`: tile lane>>4, sub lane&15 -> G.y[lane>>4] of this lane
 #pragma unroll
@@ -352,8 +515,10 @@ __global__ __launch_bounds__(256) void als_solve_kernel(
     if (lane >= KP) b = 0.f;
 
     const float old = my_valid ? xrow[my_f] : 0.f;
-    const bool ok = chol_solve<KP>(a, b, lds);
-    if (!ok && lane == 0) atomicCAS(status, 0, row + 1);
+    const float minpiv = chol_solve<KP>(a, b, lds);
+    // not SPD: a non-positive pivot, or NaN/Inf anywhere in the solution
+    const bool bad = !(minpiv > 0.f) || (my_valid && !(fabsf(b) <= 3.0e38f));
+    if (__any(bad) && lane == 0) atomicCAS(status, 0, row + 1);
 
     float d = 0.f;
     if (my_valid) {

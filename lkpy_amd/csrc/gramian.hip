@@ -104,8 +104,6 @@ __device__ __forceinline__ void gram_wave(const float *__restrict__ m, int64_t r
             }
 #pragma unroll
             for (int l = 0; l < NLOC; ++l) {
-                constexpr int dummy = 0;
-                (void)dummy;
                 const int e = l * GRAM_WAVES + W;
                 const int ti = tile_ti(e), tj = tile_tj(e);
                 acc[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.v[ti], q.v[tj], acc[l], 0, 0, 0);
@@ -144,24 +142,42 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float *__res
     }
 }
 
-// One thread per primed upper-tile element; sums the slabs in block order.
+// Sum the slabs (fixed order => bit-reproducible), add reg*I, un-permute, mirror.
+// One workgroup per 64 consecutive primed elements (one coalesced 256-byte segment of
+// every slab); wave w sums slabs w, w+4, ...; the four partial sums are combined in
+// wave order.
 template <int NT>
-__global__ void gramian_finish_kernel(const float *__restrict__ ws, int nblocks, int k, float reg,
-                                      float *__restrict__ out, int ld_out)
+__global__ __launch_bounds__(256) void gramian_finish_kernel(const float *__restrict__ ws,
+                                                             int nblocks, int k, float reg,
+                                                             float *__restrict__ out, int ld_out)
 {
     constexpr int KP = NT * 16;
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= KP * KP) return;
-    int pr = idx / KP, pc = idx % KP;
-    int ti = pr >> 4, tj = pc >> 4;
-    if (ti > tj) return;  // lower tiles are never written by the partial kernel
-    int fr = (pr & 15) * NT + ti, fc = (pc & 15) * NT + tj;
-    if (fr >= k || fc >= k) return;
-    // within a diagonal tile both (fr,fc) and (fc,fr) are present and equal up to
-    // operand order (a*b == b*a exactly), so taking fr <= fc is enough.
-    if (ti == tj && fr > fc) return;
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + lane;
+    const int pr = idx / KP, pc = idx % KP;
+    const int ti = pr >> 4, tj = pc >> 4;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += ws[(size_t)b * KP * KP + idx];
+    if (ti <= tj) {  // lower tiles are never written by the partial kernel
+        const float *src = ws + idx;
+        float s0 = 0.f, s1 = 0.f;
+        int b = wave;
+        for (; b + 4 < nblocks; b += 8) {
+            s0 += src[(size_t)b * KP * KP];
+            s1 += src[(size_t)(b + 4) * KP * KP];
+        }
+        if (b < nblocks) s0 += src[(size_t)b * KP * KP];
+        s = s0 + s1;
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave != 0 || ti > tj) return;
+    s = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    const int fr = (pr & 15) * NT + ti, fc = (pc & 15) * NT + tj;
+    if (fr >= k || fc >= k) return;
+    // within a diagonal tile both (fr,fc) and (fc,fr) are present and bitwise equal
+    // (a*b == b*a, same accumulation order), so taking fr <= fc is enough.
+    if (ti == tj && fr > fc) return;
     if (fr == fc) s += reg;
     out[fr * ld_out + fc] = s;
     out[fc * ld_out + fr] = s;
@@ -170,7 +186,7 @@ __global__ void gramian_finish_kernel(const float *__restrict__ ws, int nblocks,
 static int gram_blocks(int64_t n, int KP)
 {
     // enough blocks to fill 256 CUs, fewer slabs for wide k (slab = KP*KP*4 bytes)
-    int64_t maxb = (KP >= 256) ? 128 : (KP >= 128 ? 256 : 512);
+    int64_t maxb = (KP >= 256) ? 128 : 256;
     int64_t b = (n + 63) / 64;  // at least 64 rows (16 groups) per block
     if (b > maxb) b = maxb;
     if (b < 1) b = 1;
@@ -186,9 +202,8 @@ static int launch_gramian(const float *m, int64_t n, int k, int ld, float reg, f
     int64_t rpb = ((n + nb - 1) / nb + 3) / 4 * 4;
     if (rpb < 4) rpb = 4;
     hipLaunchKernelGGL(gramian_partial_kernel<NT>, dim3(nb), dim3(256), 0, st, m, n, ld, rpb, ws);
-    int nth = KP * KP;
-    hipLaunchKernelGGL(gramian_finish_kernel<NT>, dim3((nth + 255) / 256), dim3(256), 0, st, ws,
-                       nb, k, reg, out, ld_out);
+    hipLaunchKernelGGL(gramian_finish_kernel<NT>, dim3(KP * KP / 64), dim3(256), 0, st, ws, nb, k,
+                       reg, out, ld_out);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }
