@@ -109,6 +109,42 @@ def cpu_baseline(ui, k, reg, budget_s=20.0):
     }
 
 
+def cpu_baseline_knn(ratings, budget_s=15.0):
+    """
+    Time the CPU oracle's ``sim_row`` (port of src/accel/knn/item_train.rs:95-152) on a
+    random sample of item rows and extrapolate the full build by multiply-accumulates.
+    """
+    from lkpy_amd._knn_bench import prepare_explicit
+    from oracle import lk_oracle as lko
+
+    ui, iu, _ = prepare_explicit(ratings)
+    ulen = np.diff(ui.indptr).astype(np.int64)
+    row_macs = np.add.reduceat(ulen[iu.indices], iu.indptr[:-1].astype(np.int64))
+    row_macs[np.diff(iu.indptr) == 0] = 0
+    total = int(row_macs.sum())
+    rng = np.random.default_rng(2)
+    threads = min(lko.num_threads(), os.cpu_count() or 1)
+    n = max(64, ui.shape[1] // 400)
+    dt, rows = 0.0, None
+    for _ in range(3):
+        rows = np.sort(rng.choice(ui.shape[1], min(n, ui.shape[1]), replace=False))
+        t0 = time.perf_counter()
+        lko.iknn_sample_rows(ui, iu, rows, 1.0e-6, None, threads)
+        dt = time.perf_counter() - t0
+        if dt > budget_s / 4 or n >= ui.shape[1]:
+            break
+        n = int(min(ui.shape[1], n * min(8.0, budget_s / 2 / max(dt, 1e-3))))
+    frac = float(row_macs[rows].sum()) / max(total, 1)
+    return {
+        "value": round(dt / max(frac, 1e-12), 2),
+        "unit": "s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{len(rows)} of {ui.shape[1]} item rows ({frac * 100:.2f}% of the "
+        f"multiply-accumulates) in {dt:.2f}s, extrapolated by MACs",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,6 +283,8 @@ def main():
             from lkpy_amd import _knn_bench  # noqa: F401
 
             out["knn"] = _knn_bench.run(ratings, dev)
+            if not args.no_cpu:
+                out["knn"]["cpu_baseline"] = cpu_baseline_knn(ratings)
         except ImportError:
             pass
     if rank == 0 and world == 1 and not args.no_cpu:

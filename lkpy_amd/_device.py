@@ -207,3 +207,54 @@ class ALSPlan:
                 self._h = ctypes.c_void_p(0)
         except Exception:
             pass
+
+
+def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None) -> DeviceCSR:
+    """
+    Item-item similarity build (lk_iknn_build_count / _fill): ``ui`` users x items and
+    ``iu`` items x users hold the normalised ratings; returns the similarity matrix as a
+    device CSR with int64 offsets, rows sorted by column.
+    """
+    lib = _native.require_gpu()
+    n_users, n_items = ui.shape
+    assert iu.shape == (n_items, n_users)
+    assert ui.h_indptr.dtype == iu.h_indptr.dtype
+    dev = ui.indices.device
+    is64 = 1 if ui.h_indptr.dtype == np.int64 else 0
+    h = ctypes.c_void_p(0)
+    check(
+        lib.lk_iknn_plan_create(
+            ctypes.byref(h), ui.h_indptr.ctypes.data_as(ctypes.c_void_p),
+            iu.h_indptr.ctypes.data_as(ctypes.c_void_p), is64, n_users, n_items
+        ),
+        "lk_iknn_plan_create",
+    )  # fmt: skip
+    try:
+        ws = torch.empty(lib.lk_iknn_plan_workspace_bytes(h), dtype=torch.uint8, device=dev)
+        out_ptr = torch.empty(n_items + 1, dtype=torch.int64, device=dev)
+        total = ctypes.c_int64(0)
+        sn = -1 if save_nbrs is None else int(save_nbrs)
+        ms = float(np.float32(min_sim))  # cast to f32 at the boundary (item_train.rs:37)
+        check(
+            lib.lk_iknn_build_count(
+                h, _ptr(ui.indptr), _ptr(ui.indices), _ptr(ui.values), _ptr(iu.indptr),
+                _ptr(iu.indices), _ptr(iu.values), ms, sn, _ptr(ws), _ptr(out_ptr),
+                ctypes.byref(total), _stream()
+            ),
+            "lk_iknn_build_count",
+        )  # fmt: skip
+        nnz = int(total.value)
+        out_idx = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
+        out_val = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)[:nnz]
+        check(
+            lib.lk_iknn_build_fill(
+                h, _ptr(ui.indptr), _ptr(ui.indices), _ptr(ui.values), _ptr(iu.indptr),
+                _ptr(iu.indices), _ptr(iu.values), ms, sn, _ptr(ws), _ptr(out_ptr),
+                _ptr(out_idx), _ptr(out_val), _stream()
+            ),
+            "lk_iknn_build_fill",
+        )  # fmt: skip
+        torch.cuda.current_stream().synchronize()
+    finally:
+        lib.lk_iknn_plan_destroy(h)
+    return DeviceCSR(out_ptr, out_idx, out_val, (n_items, n_items), None)

@@ -63,6 +63,15 @@ def _declare(lib):
         "lk_als_plan_get_timing": (
             c_int, [vp, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int32)]
         ),
+        "lk_iknn_plan_create": (c_int, [POINTER(vp), vp, vp, c_int, c_int64, c_int64]),
+        "lk_iknn_plan_destroy": (None, [vp]),
+        "lk_iknn_plan_workspace_bytes": (c_size_t, [vp]),
+        "lk_iknn_build_count": (
+            c_int, [vp, vp, vp, vp, vp, vp, vp, c_float, c_int64, vp, vp, POINTER(c_int64), vp]
+        ),
+        "lk_iknn_build_fill": (
+            c_int, [vp, vp, vp, vp, vp, vp, vp, c_float, c_int64, vp, vp, vp, vp, vp]
+        ),
         "lk_als_implicit_half_epoch_host": (
             c_int,
             [vp, c_int, vp, vp, c_int64, c_int64, c_int32, vp, vp, vp, c_int32, vp],

@@ -1,0 +1,463 @@
+// iknn_build.hip -- item-item similarity build on gfx950.
+//
+// Stands in for `compute_similarities` / `ItemSimTask::invoke` / `sim_row`
+// (src/accel/knn/item_train.rs:33-152) and the order-preserving CSR collection of
+// `ArrowCSRConsumer` (src/accel/sparse/consumer.rs:24-142).  For every item i:
+//
+//     dots[j] = sum over users u of i, ASCENDING u, of  a_ui * a_uj      (j != i)
+//     keep dots[j] >= min_sim, rows sorted by column, int64 row offsets.
+//
+// Bit-exact by construction: for one (i, j) cell the reference adds the rounded
+// products round(a_ui*a_uj) in ascending-user order (item_train.rs:112-129, Rust does
+// not contract to FMA).  Here ONE WAVE owns a task (row i, column window p) and
+// walks the users of i sequentially, applying each user's items in parallel (they
+// are distinct columns, so there is no intra-instruction conflict); products use
+// __fmul_rn / __fadd_rn.  The accumulation order of every cell is therefore the
+// reference's, independent of scheduling.
+//
+// Data layout.  Each wave keeps a dense f32 accumulator for a window of W columns in
+// its private quarter of the workgroup's LDS (W = 8192 -> 128 KiB per workgroup, one
+// workgroup per CU).  A row needs P = ceil(n_items / W) tasks.  A small table
+// seg[u][p] (first entry of user u's row with column >= p*W, built once by binary
+// search) lets a task touch only the slice of each user's list that falls into its
+// window.  The (user, weight) stream of item i and the slice bounds are read 64 users
+// at a time (coalesced / gathered once), the slices themselves coalesced, with the
+// next user's slice prefetched while the current one is applied.
+//
+// Output is produced in two passes over the same kernel (the size is data
+// dependent): COUNT stores the survivors of each task, an exclusive scan turns them
+// into output offsets (windows of a row are consecutive, so rows come out sorted by
+// column), FILL recomputes and writes (column, value).
+//
+// Roofline: LDS read-modify-write bound; algorithmic bytes per product = 8 (the
+// expanded (index, value) stream) -- macs = sum_u n_u^2.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+// never contract mul+add into FMA in this file: bit parity with the reference
+#pragma clang fp contract(off)
+
+#define LK_IKNN_W 8192
+
+struct lk_iknn_plan {
+    int64_t n_users = 0, n_items = 0;
+    int32_t is64 = 0;
+    int32_t W = 0, P = 0;
+    int32_t Q = 0;             // window quads per row: ceil(P / 4)
+    int64_t n_tasks = 0;       // n_items * P   (counts/offsets are indexed by row*P + p)
+    int64_t n_btasks = 0;      // n_items * Q   (what a workgroup takes: one row, 4 windows)
+    int64_t nnz = 0;
+    int32_t *d_task = nullptr;  // [n_btasks] row*Q + quad, heavy rows first
+    size_t off_pack = 0, off_seg = 0, off_cnt = 0, off_off = 0, off_scan = 0, ws_bytes = 0;
+};
+
+namespace lk {
+
+// seg[u*(P+1) + p] = number of entries of user u with column < p*W
+template <bool IS64>
+__global__ void iknn_seg_kernel(const typename IndPtr<IS64>::type *__restrict__ ui_ptr,
+                                const int32_t *__restrict__ ui_idx, int64_t n_users, int P, int W,
+                                int32_t *__restrict__ seg)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_users * (P + 1)) return;
+    const int64_t u = t / (P + 1);
+    const int p = (int)(t - u * (P + 1));
+    const int64_t b = ui_ptr[u], e = ui_ptr[u + 1];
+    const int64_t bound = (int64_t)p * W;
+    int64_t lo = b, hi = e;  // first index with column >= bound
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (ui_idx[mid] < bound)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    seg[t] = (int32_t)(lo - b);
+}
+
+// (index, value) of the user rows interleaved as 8-byte pairs: one coalesced 8-byte load
+// per lane fetches a slice entry, and a slice is ONE contiguous span
+__global__ void iknn_pack_kernel(const int32_t *__restrict__ idx, const float *__restrict__ val,
+                                 int64_t nnz, int2 *__restrict__ pack)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz;
+         e += (int64_t)gridDim.x * blockDim.x)
+        pack[e] = make_int2(idx[e], __builtin_bit_cast(int, val[e]));
+}
+
+template <bool IS64, bool FILL>
+__global__ __launch_bounds__(256) void iknn_build_kernel(
+    const typename IndPtr<IS64>::type *__restrict__ ui_ptr, const int2 *__restrict__ ui_pack,
+    const typename IndPtr<IS64>::type *__restrict__ iu_ptr, const int32_t *__restrict__ iu_idx,
+    const float *__restrict__ iu_val, const int32_t *__restrict__ seg,
+    const int32_t *__restrict__ tasks, int64_t n_btasks, int64_t n_items, int P, int Q, int W,
+    float min_sim, int32_t *__restrict__ task_cnt,
+    const int64_t *__restrict__ task_off, int32_t *__restrict__ out_idx,
+    float *__restrict__ out_val)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_acc[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    float *acc = lds_acc + (size_t)wave * W;
+    for (int c = lane; c < W; c += 64) acc[c] = 0.f;
+
+    // a workgroup takes one row and four ADJACENT windows (wave w -> window 4*quad + w):
+    // the four waves walk the same users, so the adjacent slices they read share cache
+    // lines in L1/L2
+    for (int64_t bt = blockIdx.x; bt < n_btasks; bt += gridDim.x) {
+        const int code = tasks[bt];
+        const int row = code / Q;
+        const int p = (code - row * Q) * 4 + wave;
+        if (p >= P) continue;
+        const int task = row * P + p;
+        const int c_lo = p * W;
+        const int wlen = (int)((n_items - c_lo) < W ? (n_items - c_lo) : W);
+        const int64_t rb = iu_ptr[row], re = iu_ptr[row + 1];
+
+        // ---- accumulate: users of `row` in ascending order -----------------
+        // Per user: one coalesced read of the slice (prefetched RING users ahead), one
+        // v_mul (rounded product) and one LDS float atomic (ds_add_f32, fire-and-forget):
+        // the LDS unit applies a wave's instructions in issue order and the lanes of one
+        // instruction hit distinct columns, so every cell still receives its terms in
+        // ascending-user order, each as round(round(r*v) + acc) -- the reference's
+        // arithmetic -- while the wave never waits for an LDS round trip.
+        for (int64_t base = rb; base < re; base += 64) {
+            const int nb = (re - base) < 64 ? (int)(re - base) : 64;
+            unsigned my_beg_lo = 0, my_beg_hi = 0;
+            int my_len = 0;
+            float my_r = 0.f;
+            if (lane < nb) {
+                const int u = iu_idx[base + lane];
+                my_r = iu_val[base + lane];
+                const int s0 = seg[(int64_t)u * (P + 1) + p];
+                const int s1 = seg[(int64_t)u * (P + 1) + p + 1];
+                const int64_t b = (int64_t)ui_ptr[u] + s0;
+                my_beg_lo = (unsigned)b;
+                my_beg_hi = (unsigned)(b >> 32);
+                my_len = s1 - s0;
+            }
+            constexpr int RING = 8;
+            int rj[RING];
+            float rv[RING];
+            // wave-uniform lane reads (v_readlane -> SGPR): no LDS traffic, scalar branches
+            auto slice_beg = [&](int k) -> int64_t {
+                const unsigned lo = __builtin_amdgcn_readlane(my_beg_lo, k);
+                const unsigned hi = __builtin_amdgcn_readlane(my_beg_hi, k);
+                return (int64_t)(((unsigned long long)hi << 32) | lo);
+            };
+            // every ring load is UNCONDITIONAL (inactive lanes / users read entry 0 and are
+            // masked afterwards): loads inside branches make the compiler drain the whole
+            // memory queue (vmcnt(0)) at every user, which serialises the gathers
+            auto slot_load = [&](int q, int k) {
+                const int64_t b = slice_beg(k & 63);
+                const int l = (k < nb) ? __builtin_amdgcn_readlane(my_len, k & 63) : 0;
+                const bool on = lane < l;
+                const int64_t a = on ? b + lane : 0;
+                const int2 e = ui_pack[a];
+                rv[q] = __builtin_bit_cast(float, e.y);
+                rj[q] = on ? e.x : -1;
+            };
+#pragma unroll
+            for (int q = 0; q < RING; ++q) slot_load(q, q);
+            for (int k0 = 0; k0 < nb; k0 += RING) {
+#pragma unroll
+                for (int q = 0; q < RING; ++q) {
+                    const int k = k0 + q;  // may run past nb: such users have an empty slice
+                    const int len = (k < nb) ? __builtin_amdgcn_readlane(my_len, k & 63) : 0;
+                    const float r = __builtin_bit_cast(
+                        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_r), k & 63));
+                    const int j = rj[q];
+                    const float v = rv[q];
+                    slot_load(q, k + RING);  // refill with user k + RING
+                    // `if other == row { continue }` (item_train.rs:120-122);
+                    // `dots[other] += r * orate` (item_train.rs:128)
+                    if (j >= 0 && j != row) {
+                        float prod = r * v;
+                        asm volatile("" : "+v"(prod));  // keep the rounded product
+                        (void)__hip_atomic_fetch_add(&acc[j - c_lo], prod, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                    if (len > 64) {  // the rest of a long slice (rare)
+                        const int64_t beg = slice_beg(k & 63);
+                        for (int off = 64; off < len; off += 64) {
+                            if (off + lane < len) {
+                                const int2 e2 = ui_pack[beg + off + lane];
+                                const int j2 = e2.x;
+                                if (j2 != row) {
+                                    float prod = r * __builtin_bit_cast(float, e2.y);
+                                    asm volatile("" : "+v"(prod));
+                                    (void)__hip_atomic_fetch_add(&acc[j2 - c_lo], prod,
+                                                                 __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- extract: survivors in column order, clear the window -----------
+        int64_t wpos = FILL ? task_off[task] : 0;
+        int count = 0;
+        for (int c0 = 0; c0 < wlen; c0 += 64) {
+            const int c = c0 + lane;
+            float s = 0.f;
+            if (c < wlen) {
+                s = acc[c];
+                acc[c] = 0.f;
+            }
+            const bool keep = (c < wlen) && (s >= min_sim);  // item_train.rs:135
+            const unsigned long long m = __ballot(keep);
+            if (FILL) {
+                if (keep) {
+                    const int rank = __builtin_amdgcn_mbcnt_hi(
+                        (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    out_idx[wpos + rank] = c_lo + c;
+                    out_val[wpos + rank] = s;
+                }
+                wpos += __popcll(m);
+            } else {
+                count += __popcll(m);
+            }
+        }
+        if (!FILL && lane == 0) task_cnt[task] = count;
+    }
+}
+
+// exclusive scan of int32 counts into int64 offsets (n+1 outputs), one workgroup
+__global__ __launch_bounds__(1024) void iknn_scan_kernel(const int32_t *__restrict__ cnt,
+                                                        int64_t n, int64_t *__restrict__ off)
+{
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = (i < n) ? (int64_t)cnt[i] : 0;
+        int64_t x = v;  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int64_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int64_t carry = carry_s;
+        if (i < n) off[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[n] = carry_s;
+}
+
+// counts / offsets are indexed by TASK ID = row*P + p (item order, windows of a row
+// adjacent), so the scan yields rows in item order sorted by column; `tasks` is only
+// the visiting order (heavy rows first).  out_indptr[r] = off[r*P].
+__global__ void iknn_indptr_kernel(const int64_t *__restrict__ task_off, int64_t n_items, int P,
+                                   int64_t *__restrict__ out_indptr)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= n_items) out_indptr[r] = task_off[r * P];
+}
+
+}  // namespace lk
+
+extern "C" int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr,
+                                   const void *h_iu_indptr, int indptr_is_64, int64_t n_users,
+                                   int64_t n_items)
+{
+    LK_REQUIRE(out && h_ui_indptr && h_iu_indptr, "lk_iknn_plan_create: null pointer");
+    LK_REQUIRE(n_users >= 0 && n_items >= 0 && n_items < (int64_t)INT32_MAX &&
+                   n_users < (int64_t)INT32_MAX,
+               "lk_iknn_plan_create: bad shape");
+    auto *p = new lk_iknn_plan();
+    p->n_users = n_users;
+    p->n_items = n_items;
+    p->is64 = indptr_is_64 ? 1 : 0;
+    int64_t W = LK_IKNN_W;
+    if (n_items < W) W = std::max<int64_t>(64, (n_items + 63) / 64 * 64);
+    p->W = (int32_t)W;
+    p->P = (int32_t)std::max<int64_t>(1, (n_items + W - 1) / W);
+    p->Q = (p->P + 3) / 4;
+    p->n_tasks = n_items * p->P;
+    p->n_btasks = n_items * p->Q;
+    p->nnz = indptr_is_64 ? static_cast<const int64_t *>(h_ui_indptr)[n_users]
+                          : (int64_t) static_cast<const int32_t *>(h_ui_indptr)[n_users];
+    LK_REQUIRE(p->n_tasks < (int64_t)INT32_MAX, "lk_iknn_plan_create: too many tasks");
+
+    auto len = [&](int64_t r) -> int64_t {
+        if (indptr_is_64) {
+            const int64_t *ip = static_cast<const int64_t *>(h_iu_indptr);
+            return ip[r + 1] - ip[r];
+        }
+        const int32_t *ip = static_cast<const int32_t *>(h_iu_indptr);
+        return (int64_t)ip[r + 1] - ip[r];
+    };
+    std::vector<int32_t> rows((size_t)n_items);
+    for (int64_t r = 0; r < n_items; ++r) rows[(size_t)r] = (int32_t)r;
+    std::stable_sort(rows.begin(), rows.end(),
+                     [&](int32_t a, int32_t b) { return len(a) > len(b); });
+    std::vector<int32_t> tasks((size_t)p->n_btasks);
+    size_t q = 0;
+    for (int64_t r = 0; r < n_items; ++r)
+        for (int w = 0; w < p->Q; ++w) tasks[q++] = rows[(size_t)r] * p->Q + w;
+    size_t bytes = std::max<size_t>(tasks.size(), 1) * sizeof(int32_t);
+    if (hipMalloc(reinterpret_cast<void **>(&p->d_task), bytes) != hipSuccess) {
+        delete p;
+        lk::set_error("lk_iknn_plan_create: hipMalloc failed");
+        return LK_E_HIP;
+    }
+    if (!tasks.empty() &&
+        hipMemcpy(p->d_task, tasks.data(), tasks.size() * sizeof(int32_t),
+                  hipMemcpyHostToDevice) != hipSuccess) {
+        lk_iknn_plan_destroy(p);
+        lk::set_error("lk_iknn_plan_create: hipMemcpy failed");
+        return LK_E_HIP;
+    }
+    size_t off = 0;
+    p->off_pack = off;
+    off += lk::align_up((size_t)std::max<int64_t>(p->nnz, 1) * sizeof(int2), 256);
+    p->off_seg = off;
+    off += lk::align_up((size_t)std::max<int64_t>(n_users, 1) * (p->P + 1) * sizeof(int32_t), 256);
+    p->off_cnt = off;
+    off += lk::align_up((size_t)(p->n_tasks + 1) * sizeof(int32_t), 256);
+    p->off_off = off;
+    off += lk::align_up((size_t)(p->n_tasks + 1) * sizeof(int64_t), 256);
+    p->ws_bytes = off;
+    *out = p;
+    return LK_OK;
+}
+
+extern "C" void lk_iknn_plan_destroy(lk_iknn_plan *p)
+{
+    if (!p) return;
+    if (p->d_task) (void)hipFree(p->d_task);
+    delete p;
+}
+
+extern "C" size_t lk_iknn_plan_workspace_bytes(const lk_iknn_plan *p)
+{
+    return p ? p->ws_bytes : 0;
+}
+
+namespace lk {
+
+template <bool IS64, bool FILL>
+static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t *ui_idx,
+                       const float *ui_val, const void *iu_ptr, const int32_t *iu_idx,
+                       const float *iu_val, float min_sim, char *ws, int32_t *out_idx,
+                       float *out_val, hipStream_t st)
+{
+    using IT = typename IndPtr<IS64>::type;
+    int32_t *seg = reinterpret_cast<int32_t *>(ws + p->off_seg);
+    int2 *pack = reinterpret_cast<int2 *>(ws + p->off_pack);
+    int32_t *cnt = reinterpret_cast<int32_t *>(ws + p->off_cnt);
+    int64_t *off = reinterpret_cast<int64_t *>(ws + p->off_off);
+    if (p->n_tasks == 0) return LK_OK;
+    if (!FILL) {
+        const int64_t nseg = p->n_users * (p->P + 1);
+        if (nseg > 0)
+            hipLaunchKernelGGL((iknn_seg_kernel<IS64>), dim3((unsigned)((nseg + 255) / 256)),
+                               dim3(256), 0, st, static_cast<const IT *>(ui_ptr), ui_idx,
+                               p->n_users, p->P, p->W, seg);
+        if (p->nnz > 0)
+            hipLaunchKernelGGL(iknn_pack_kernel, dim3(2048), dim3(256), 0, st, ui_idx, ui_val,
+                               p->nnz, pack);
+    }
+    const size_t lds = (size_t)4 * p->W * sizeof(float);
+    auto kern = iknn_build_kernel<IS64, FILL>;
+    LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // one resident workgroup per CU at W = 8192 (128 KiB of LDS); more for small windows
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+    int64_t blocks = std::min<int64_t>(p->n_btasks, (int64_t)256 * per_cu);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st,
+                       static_cast<const IT *>(ui_ptr), pack, static_cast<const IT *>(iu_ptr),
+                       iu_idx, iu_val, seg, p->d_task, p->n_btasks, p->n_items, p->P, p->Q, p->W,
+                       min_sim, cnt, off, out_idx, out_val);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+}  // namespace lk
+
+static int check_args(const lk_iknn_plan *plan, const void *a, const void *b, const void *ws,
+                      int64_t save_nbrs, const char *who)
+{
+    LK_REQUIRE(plan && ws, "%s: null plan/workspace", who);
+    LK_REQUIRE(plan->n_tasks == 0 || (a && b), "%s: null CSR pointer", who);
+    LK_REQUIRE(save_nbrs <= 0,
+               "%s: save_nbrs truncation is not implemented in the HIP build yet "
+               "(save_nbrs must be <= 0 / None)",
+               who);
+    return LK_OK;
+}
+
+extern "C" int lk_iknn_build_count(const lk_iknn_plan *plan, const void *d_ui_indptr,
+                                   const int32_t *d_ui_indices, const float *d_ui_values,
+                                   const void *d_iu_indptr, const int32_t *d_iu_indices,
+                                   const float *d_iu_values, float min_sim, int64_t save_nbrs,
+                                   void *d_ws, int64_t *d_out_indptr, int64_t *h_total_nnz,
+                                   void *stream)
+{
+    int rc = check_args(plan, d_ui_indptr, d_iu_indptr, d_ws, save_nbrs, "lk_iknn_build_count");
+    if (rc != LK_OK) return rc;
+    LK_REQUIRE(d_out_indptr && h_total_nnz, "lk_iknn_build_count: null output");
+    hipStream_t st = lk::as_stream(stream);
+    char *ws = static_cast<char *>(d_ws);
+    int32_t *cnt = reinterpret_cast<int32_t *>(ws + plan->off_cnt);
+    int64_t *off = reinterpret_cast<int64_t *>(ws + plan->off_off);
+    if (plan->n_tasks == 0) {
+        LK_HIP_CHECK(hipMemsetAsync(d_out_indptr, 0, sizeof(int64_t) * (plan->n_items + 1), st));
+        LK_HIP_CHECK(hipStreamSynchronize(st));
+        *h_total_nnz = 0;
+        return LK_OK;
+    }
+    rc = plan->is64 ? lk::launch_iknn<true, false>(plan, d_ui_indptr, d_ui_indices, d_ui_values,
+                                                  d_iu_indptr, d_iu_indices, d_iu_values,
+                                                  min_sim, ws, nullptr, nullptr, st)
+                    : lk::launch_iknn<false, false>(plan, d_ui_indptr, d_ui_indices, d_ui_values,
+                                                   d_iu_indptr, d_iu_indices, d_iu_values,
+                                                   min_sim, ws, nullptr, nullptr, st);
+    if (rc != LK_OK) return rc;
+    hipLaunchKernelGGL(lk::iknn_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, plan->n_tasks, off);
+    hipLaunchKernelGGL(lk::iknn_indptr_kernel, dim3((unsigned)((plan->n_items + 256) / 256)),
+                       dim3(256), 0, st, off, plan->n_items, plan->P, d_out_indptr);
+    LK_HIP_CHECK(hipGetLastError());
+    LK_HIP_CHECK(hipMemcpyAsync(h_total_nnz, off + plan->n_tasks, sizeof(int64_t),
+                                hipMemcpyDeviceToHost, st));
+    LK_HIP_CHECK(hipStreamSynchronize(st));
+    return LK_OK;
+}
+
+extern "C" int lk_iknn_build_fill(const lk_iknn_plan *plan, const void *d_ui_indptr,
+                                  const int32_t *d_ui_indices, const float *d_ui_values,
+                                  const void *d_iu_indptr, const int32_t *d_iu_indices,
+                                  const float *d_iu_values, float min_sim, int64_t save_nbrs,
+                                  void *d_ws, const int64_t *d_out_indptr, int32_t *d_out_indices,
+                                  float *d_out_values, void *stream)
+{
+    int rc = check_args(plan, d_ui_indptr, d_iu_indptr, d_ws, save_nbrs, "lk_iknn_build_fill");
+    if (rc != LK_OK) return rc;
+    (void)d_out_indptr;  // offsets of the count pass are kept in the workspace
+    if (plan->n_tasks == 0) return LK_OK;
+    // d_out_indices / d_out_values may be null when the count pass found nothing
+    hipStream_t st = lk::as_stream(stream);
+    char *ws = static_cast<char *>(d_ws);
+    return plan->is64 ? lk::launch_iknn<true, true>(plan, d_ui_indptr, d_ui_indices, d_ui_values,
+                                                   d_iu_indptr, d_iu_indices, d_iu_values,
+                                                   min_sim, ws, d_out_indices, d_out_values, st)
+                      : lk::launch_iknn<false, true>(plan, d_ui_indptr, d_ui_indices,
+                                                     d_ui_values, d_iu_indptr, d_iu_indices,
+                                                     d_iu_values, min_sim, ws, d_out_indices,
+                                                     d_out_values, st);
+}

@@ -319,6 +319,40 @@ int lko_iknn_build(const int64_t *ui_ptr, const int32_t *ui_idx, const float *ui
     return 0;
 }
 
+/* sim_row for a SUBSET of rows, results discarded except the kept-neighbour count:
+ * used to time a bounded sample of the build (bench.py cpu_baseline). */
+int64_t lko_iknn_sample_rows(const int64_t *ui_ptr, const int32_t *ui_idx, const float *ui_val,
+                             const int64_t *iu_ptr, const int32_t *iu_idx, const float *iu_val,
+                             int64_t n_items, const int32_t *rows, int64_t n_sel, float min_sim,
+                             int64_t save_nbrs, int n_threads)
+{
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+    if (n_threads > 256) n_threads = 256;
+#else
+    n_threads = 1;
+#endif
+    int64_t kept = 0;
+#pragma omp parallel num_threads(n_threads) reduction(+ : kept)
+    {
+        int32_t *counts = (int32_t *)calloc((size_t)n_items, sizeof(int32_t));
+        float *dots = (float *)calloc((size_t)n_items, sizeof(float));
+        int32_t *used = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_items);
+        lko_pair *out = (lko_pair *)malloc(sizeof(lko_pair) * (size_t)n_items);
+        lko_pair *tmp = (lko_pair *)malloc(sizeof(lko_pair) * (size_t)n_items);
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t q = 0; q < n_sel; q++)
+            kept += lko_sim_row(rows[q], ui_ptr, ui_idx, ui_val, iu_ptr, iu_idx, iu_val, min_sim,
+                                save_nbrs, counts, dots, used, out, tmp);
+        free(counts);
+        free(dots);
+        free(used);
+        free(out);
+        free(tmp);
+    }
+    return kept;
+}
+
 void lko_free(void *p) { free(p); }
 
 /* ------------------------------------------------------------------------- */

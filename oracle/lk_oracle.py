@@ -362,6 +362,27 @@ def iknn_build(
     return sps.csr_array((val, idx, out_ptr), shape=(n_items, n_items))
 
 
+def iknn_sample_rows(ui, iu, rows, min_sim=1.0e-6, save_nbrs=None, n_threads=0) -> int:
+    "``sim_row`` for the given rows only (results discarded): timing of a bounded sample."
+    n_users, n_items = ui.shape
+    uip = np.ascontiguousarray(ui.indptr, dtype=np.int64)
+    uii = np.ascontiguousarray(ui.indices, dtype=np.int32)
+    uiv = np.ascontiguousarray(ui.data, dtype=np.float32)
+    iup = np.ascontiguousarray(iu.indptr, dtype=np.int64)
+    iui = np.ascontiguousarray(iu.indices, dtype=np.int32)
+    iuv = np.ascontiguousarray(iu.data, dtype=np.float32)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    f = lib().lko_iknn_sample_rows
+    f.restype = ctypes.c_int64
+    return int(f(
+        _p(uip, _i64p), _p(uii, _i32p), _p(uiv, _f32p),
+        _p(iup, _i64p), _p(iui, _i32p), _p(iuv, _f32p),
+        ctypes.c_int64(n_items), _p(rows, _i32p), ctypes.c_int64(len(rows)),
+        ctypes.c_float(np.float32(min_sim)),
+        ctypes.c_int64(-1 if save_nbrs is None else int(save_nbrs)), ctypes.c_int(n_threads),
+    ))  # fmt: skip
+
+
 def iknn_score(
     sims: sps.csr_array,
     ref_items: np.ndarray,

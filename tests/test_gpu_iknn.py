@@ -1,0 +1,101 @@
+"""GPU parity: item-item similarity build vs the CPU oracle -- BIT-EXACT."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+pytestmark = pytest.mark.gpu
+
+
+def _build_gpu(D, gpu, ui, iu, min_sim, is64=False):
+    dt = np.int64 if is64 else np.int32
+    dui = D.DeviceCSR.from_arrays(ui.indptr.astype(dt), ui.indices, ui.data, ui.shape, gpu)
+    diu = D.DeviceCSR.from_arrays(iu.indptr.astype(dt), iu.indices, iu.data, iu.shape, gpu)
+    out = D.iknn_build(dui, diu, min_sim)
+    return (out.indptr.cpu().numpy(), out.indices.cpu().numpy(), out.values.cpu().numpy())
+
+
+def _assert_same(got, want: sps.csr_array):
+    ptr, idx, val = got
+    assert ptr.dtype == np.int64  # LargeList offsets (src/lenskit/knn/item.py:176)
+    assert np.array_equal(ptr, want.indptr)
+    assert np.array_equal(idx, want.indices)
+    # bit-exact values: same products, same order, no FMA contraction
+    assert np.array_equal(val.view(np.uint32), want.data.astype(np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("explicit", [True, False])
+@pytest.mark.parametrize("is64", [False, True])
+def test_build_ml_small_bit_exact(gpu, oracle, ml_small, explicit, is64):
+    from lkpy_amd import _device as D
+
+    rmat = ml_small["rmat"]
+    if not explicit:
+        rmat = sps.coo_array((np.ones(rmat.nnz, np.float32), (rmat.row, rmat.col)), rmat.shape)
+    ui, iu, _means, _ = oracle.iknn_prepare(rmat, explicit)
+    want = oracle.iknn_build(ui, iu, 1.0e-6, None)
+    got = _build_gpu(D, gpu, ui, iu, 1.0e-6, is64)
+    _assert_same(got, want)
+    ptr, idx, val = got
+    assert val.min() > 0 and val.max() <= 1 + 1e-6  # tests/models/test_knn_item_item.py:134-148
+    # no self-similarity (item_train.rs:120-122); rows sorted by column (item_train.rs:149)
+    rows = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+    assert not np.any(rows == idx)
+    same_row = rows[1:] == rows[:-1]
+    assert np.all(np.diff(idx)[same_row] > 0)
+
+
+def test_build_windows_and_edges(gpu, oracle, rng):
+    """More items than one LDS window (several tasks per row), empty users and items,
+    negative values, a threshold that cuts through the distribution."""
+    from lkpy_amd import _device as D
+    from lkpy_amd import synth
+
+    mat = synth.ml25m_like(seed=7, scale=0.15)  # ~9.3k items > W = 8192 -> P = 2
+    assert mat.shape[1] > 8192
+    ui, iu, _m, _ = oracle.iknn_prepare(sps.coo_array(mat), True)
+    for min_sim in (1.0e-6, 0.05):
+        want = oracle.iknn_build(ui, iu, min_sim, None)
+        got = _build_gpu(D, gpu, ui, iu, min_sim)
+        _assert_same(got, want)
+
+
+def test_build_toy_closed_form(gpu, oracle):
+    """The reference's 14-rating toy set: sim(6,7) equals the hand-computed centred
+    cosine (tests/models/test_knn_item_item.py:106-162)."""
+    from lkpy_amd import _device as D
+
+    recs = [(1, 6, 4.0), (2, 6, 2.0), (1, 7, 3.0), (2, 7, 2.0), (3, 7, 5.0), (4, 7, 2.0),
+            (1, 8, 3.0), (2, 8, 4.0), (3, 8, 3.0), (4, 8, 2.0), (5, 8, 3.0), (6, 8, 2.0),
+            (1, 9, 3.0), (3, 9, 4.0)]  # fmt: skip
+    u = np.array([r[0] - 1 for r in recs])
+    i = np.array([r[1] - 6 for r in recs])
+    v = np.array([r[2] for r in recs], np.float32)
+    rmat = sps.coo_array((v, (u, i)), shape=(6, 4))
+    ui, iu, means, _ = oracle.iknn_prepare(rmat, True)
+    ptr, idx, val = _build_gpu(D, gpu, ui, iu, 1.0e-6)
+    S = sps.csr_array((val, idx, ptr), shape=(4, 4)).toarray()
+    six = np.array([4.0, 2.0]) - 3.0
+    seven = np.array([3.0, 2.0, 5.0, 2.0]) - 3.0
+    num = six[0] * seven[0] + six[1] * seven[1]
+    denom = np.linalg.norm(six) * np.linalg.norm(seven)
+    assert S[0, 1] == pytest.approx(num / denom, rel=1e-5)
+    assert S[0, 1] == S[1, 0]
+    assert np.all(val > 0)
+
+
+def test_build_empty(gpu):
+    from lkpy_amd import _device as D
+
+    ui = sps.csr_array((3, 5), dtype=np.float32)
+    iu = sps.csr_array((5, 3), dtype=np.float32)
+    ptr, idx, val = _build_gpu(D, gpu, ui, iu, 1e-6)
+    assert np.array_equal(ptr, np.zeros(6, np.int64)) and len(idx) == 0 and len(val) == 0
+
+
+def test_save_nbrs_fails_loudly(gpu, oracle, ml_small):
+    from lkpy_amd import _device as D
+
+    ui, iu, _m, _ = oracle.iknn_prepare(ml_small["rmat"], True)
+    dui, diu = D.DeviceCSR.from_scipy(ui, gpu), D.DeviceCSR.from_scipy(iu, gpu)
+    with pytest.raises(ValueError, match="save_nbrs"):
+        D.iknn_build(dui, diu, 1e-6, 100)
