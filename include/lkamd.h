@@ -163,6 +163,7 @@ int lk_iknn_build_fill(const lk_iknn_plan *plan, const void *d_ui_indptr,
                        const int64_t *d_out_indptr, int32_t *d_out_indices, float *d_out_values,
                        void *stream);
 
+#if 0 /* PLANNED entry points -- declared when implemented */
 /* ------------------------------------------------------------------------
  * Item-kNN scoring for a BATCH of queries.
  * Replaces `_accel.knn.score_explicit` / `score_implicit`
@@ -216,6 +217,8 @@ int lk_als_fold_in(const lk_als_plan *plan, const void *d_hist_ptr, const int32_
                    const float *d_hist_values, int64_t n_queries, int64_t n_items, int32_t k,
                    float *d_out_users, int32_t ld_out, const float *d_items, int32_t ld_items,
                    const float *d_otor, int32_t ld_otor, void *d_ws, void *stream);
+
+#endif /* planned */
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,9 @@
 #pragma clang fp contract(off)
 
 #define LK_IKNN_W 8192
+#ifndef LK_IKNN_RING
+#define LK_IKNN_RING 8
+#endif
 
 struct lk_iknn_plan {
     int64_t n_users = 0, n_items = 0;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
                 my_beg_hi = (unsigned)(b >> 32);
                 my_len = s1 - s0;
             }
-            constexpr int RING = 8;
+            constexpr int RING = LK_IKNN_RING;
             int rj[RING];
             float rv[RING];
             // wave-uniform lane reads (v_readlane -> SGPR): no LDS traffic, scalar branches

@@ -1,0 +1,245 @@
+"""
+CPU tests of the ORACLE itself: it is pinned against the reference's own golden
+vectors, closed forms and unit tests before any GPU result is compared with it.
+All citations relative to the reference checkout (lenskit/lkpy).
+"""
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sps
+from pathlib import Path
+
+GOLDEN = Path(__file__).parent / "golden"
+
+
+# ---- item-kNN: pinned by tests/models/item-item-preds.csv ---------------------------
+
+
+@pytest.fixture(scope="module")
+def iknn_model(oracle, ml_small):
+    ui, iu, means, _ = oracle.iknn_prepare(ml_small["rmat"], True)
+    sims = oracle.iknn_build(ui, iu, 1.0e-6, None)
+    return ui, iu, means, sims
+
+
+def test_iknn_known_preds(oracle, ml_small, iknn_model):
+    """
+    ``test_ii_known_preds`` (tests/models/test_knn_item_item.py:413-453):
+    ItemKNNScorer(k=20, min_sim=1e-6) on ml-latest-small must reproduce the 1288 golden
+    predictions.  The reference's only hard assertion is "no erroneously missing
+    prediction" (line 435); its error histogram allows a few tie-induced outliers.
+    """
+    _ui, _iu, means, sims = iknn_model
+    known = pd.read_csv(GOLDEN / "item-item-preds.csv")
+    assert len(known) == 1288
+    csr = sps.csr_array(ml_small["rmat"])
+    errs, missing = [], 0
+    for uid, grp in known.groupby("user_id"):
+        u = int(np.searchsorted(ml_small["user_ids"], uid))
+        hist = csr.indices[csr.indptr[u] : csr.indptr[u + 1]]
+        rates = csr.data[csr.indptr[u] : csr.indptr[u + 1]].astype(np.float32) - means[hist]
+        tg = np.searchsorted(ml_small["item_ids"], grp.item_id.values).astype(np.int32)
+        sc, cnt = oracle.iknn_score(sims, hist, rates, tg, 20, 1)
+        sc = sc + means[tg]
+        missing += int(np.sum(np.isnan(sc) & ~np.isnan(grp.prediction.values)))
+        e = grp.prediction.values - sc
+        errs.extend(e[~np.isnan(e)])
+    errs = np.abs(np.array(errs))
+    assert missing == 0
+    assert len(errs) == 1288
+    assert np.sum(errs > 1e-5) <= 5  # top-20 boundary ties (the golden file is from Java LensKit)
+    assert np.median(errs) < 1e-6
+
+
+def test_iknn_sims_match_dense_cosine(oracle, ml_small, iknn_model):
+    "sims == centred cosine computed densely in float64 (cf. test_knn_item_item.py:331-338)."
+    ui, _iu, _means, sims = iknn_model
+    rng = np.random.default_rng(1)
+    dense = ui.astype(np.float64)
+    for i in rng.choice(np.flatnonzero(np.diff(sims.indptr) > 0), 40):
+        cols = sims.indices[sims.indptr[i] : sims.indptr[i + 1]]
+        vals = sims.data[sims.indptr[i] : sims.indptr[i + 1]]
+        ref = np.asarray((dense[:, [i]].T @ dense[:, cols]).todense()).ravel()
+        assert np.allclose(vals, ref, atol=1e-6)
+    assert sims.data.min() > 0 and sims.data.max() <= 1 + 1e-6
+    assert not np.any(sims.diagonal() != 0)
+
+
+def test_iknn_toy_closed_form(oracle):
+    "tests/models/test_knn_item_item.py:106-162: sim(6,7) on the 14-rating toy set."
+    recs = [(1, 6, 4.0), (2, 6, 2.0), (1, 7, 3.0), (2, 7, 2.0), (3, 7, 5.0), (4, 7, 2.0),
+            (1, 8, 3.0), (2, 8, 4.0), (3, 8, 3.0), (4, 8, 2.0), (5, 8, 3.0), (6, 8, 2.0),
+            (1, 9, 3.0), (3, 9, 4.0)]  # fmt: skip
+    u = np.array([r[0] - 1 for r in recs])
+    i = np.array([r[1] - 6 for r in recs])
+    v = np.array([r[2] for r in recs], np.float32)
+    ui, iu, means, all_zero = oracle.iknn_prepare(sps.coo_array((v, (u, i)), shape=(6, 4)), True)
+    assert not all_zero
+    assert np.allclose(means, [3.0, 3.0, 17 / 6, 3.5])
+    for save in (None, 500):
+        S = oracle.iknn_build(ui, iu, 1e-6, save).toarray()
+        six = np.array([4.0, 2.0]) - 3.0
+        seven = np.array([3.0, 2.0, 5.0, 2.0]) - 3.0
+        num = six[0] * seven[0] + six[1] * seven[1]
+        assert S[0, 1] == pytest.approx(num / (np.linalg.norm(six) * np.linalg.norm(seven)), rel=1e-5)
+
+
+def test_iknn_constant_ratings_flagged(oracle):
+    "test_ii_warns_center (test_knn_item_item.py:211-216): all-equal ratings centre to zero."
+    rmat = sps.coo_array((np.ones(6, np.float32), ([0, 0, 1, 1, 2, 2], [0, 1, 0, 1, 0, 1])), (3, 2))
+    _ui, _iu, _m, all_zero = oracle.iknn_prepare(rmat, True)
+    assert all_zero
+
+
+def test_iknn_save_nbrs_truncation(oracle, ml_small, iknn_model):
+    "test_ii_large_models (test_knn_item_item.py:256-370): bounded rows are the top of unbounded."
+    ui, iu, _means, full = iknn_model
+    lim = oracle.iknn_build(ui, iu, 1.0e-6, 100)
+    assert np.all(np.diff(lim.indptr) <= 100)
+    rng = np.random.default_rng(3)
+    for i in rng.choice(full.shape[0], 60):
+        fc = full.indices[full.indptr[i] : full.indptr[i + 1]]
+        fv = full.data[full.indptr[i] : full.indptr[i + 1]]
+        lc = lim.indices[lim.indptr[i] : lim.indptr[i + 1]]
+        lv = lim.data[lim.indptr[i] : lim.indptr[i + 1]]
+        assert np.all(np.diff(lc) > 0)
+        assert np.all(np.isin(lc, fc))
+        if len(fc) <= 100:
+            assert np.array_equal(lc, fc) and np.array_equal(lv, fv)
+        else:
+            assert len(lc) == 100
+            kth = np.sort(fv)[-100]
+            assert lv.min() == kth
+            assert set(fc[fv > kth]) <= set(lc)
+
+
+def test_iknn_score_implicit_sum_of_topk(oracle, ml_small):
+    "test_ii_implicit_large (test_knn_item_item.py:373-410): score == sum of the k largest sims."
+    rmat = ml_small["rmat"]
+    ind = sps.coo_array((np.ones(rmat.nnz, np.float32), (rmat.row, rmat.col)), rmat.shape)
+    ui, iu, _m, _ = oracle.iknn_prepare(ind, False)
+    sims = oracle.iknn_build(ui, iu, 1e-6, None)
+    dense = sims.toarray()
+    csr = sps.csr_array(ind)
+    rng = np.random.default_rng(5)
+    for u in rng.choice(rmat.shape[0], 10):
+        hist = csr.indices[csr.indptr[u] : csr.indptr[u + 1]]
+        tg = rng.choice(rmat.shape[1], 50, replace=False).astype(np.int32)
+        sc, cnt = oracle.iknn_score(sims, hist, None, tg, 5, 1)
+        for t, s, c in zip(tg, sc, cnt):
+            col = dense[hist, t]
+            col = np.sort(col[col > 0])[::-1][:5]
+            assert c == len(col)
+            if len(col) == 0:
+                assert np.isnan(s)
+            else:
+                assert s == pytest.approx(col.sum(), rel=1e-5)
+
+
+def test_iknn_score_nulls_and_min_nbrs(oracle, iknn_model):
+    _ui, _iu, means, sims = iknn_model
+    hist = np.array([0, 5, -1, 30], np.int32)  # -1: unknown history item, skipped
+    rates = np.array([1.0, -0.5, 9.0, 0.25], np.float32)
+    tg = np.array([1, -1, 2, 9000], np.int32)
+    sc, cnt = oracle.iknn_score(sims, hist, rates, tg, 20, 1)
+    assert np.isnan(sc[1]) and cnt[1] == -1  # null target
+    sc2, cnt2 = oracle.iknn_score(sims, hist, rates, tg, 20, 4)
+    assert np.all(np.isnan(sc2[cnt2 < 4]))
+    assert np.array_equal(cnt, cnt2)
+
+
+# ---- top-N: pinned by src/accel/indirect/heap.rs:105-162, tests/accel/test_argsort.py ----
+
+
+def test_argtopn_rust_unit_vectors(oracle):
+    assert len(oracle.argtopn(np.array([], np.float32), 5)) == 0  # test_heap_empty
+    assert oracle.argtopn(np.array([10.0], np.float32), 5).tolist() == [0]  # test_heap_one
+    assert oracle.argtopn(np.array([10.0, 20.0], np.float32), 5).tolist() == [1, 0]  # test_heap_two
+    s = np.arange(1, 11, dtype=np.float32)  # test_heap_sort
+    assert oracle.argtopn(s, 5).tolist() == [9, 8, 7, 6, 5]
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_argtopn_properties(oracle, seed):
+    "tests/accel/test_argsort.py:60-211: length, descending, nothing excluded beats the min, NaN skipped."
+    rng = np.random.default_rng(seed)
+    n_s = int(rng.integers(1, 3000))
+    s = rng.standard_normal(n_s).astype(np.float32)
+    s[rng.random(n_s) < 0.1] = np.nan
+    if seed % 3 == 0:
+        s = np.round(s, 1)  # ties
+    n = int(rng.integers(1, 200))
+    top = oracle.argtopn(s, n)
+    valid = ~np.isnan(s)
+    assert len(top) == min(n, valid.sum())
+    assert not np.any(np.isnan(s[top]))
+    assert np.all(np.diff(s[top]) <= 0)
+    if len(top):
+        rest = np.setdiff1d(np.flatnonzero(valid), top)
+        assert not np.any(s[rest] > s[top].min())
+    assert len(set(top.tolist())) == len(top)
+    full = oracle.argsort_descending(s)
+    assert len(full) == valid.sum() and np.all(np.diff(s[full]) <= 0)
+
+
+# ---- implicit ALS: behavioural pins (tests/models/test_als_implicit.py) ------------------
+
+
+def test_als_row_matches_float64(oracle, rng):
+    n_rows, n_cols, k = 200, 300, 16
+    mat = sps.random(n_rows, n_cols, 0.05, random_state=1, format="csr", dtype=np.float32)
+    mat.data[:] = 40.0
+    mat = sps.csr_array(mat)
+    other = (rng.standard_normal((n_cols, k)) * 0.3).astype(np.float32)
+    this = np.zeros((n_rows, k), np.float32)
+    otor = oracle.implicit_otor(other, 0.1)
+    frob = oracle.als_half_epoch(mat, this, other, otor)
+    exact = oracle.als_half_epoch_f64(mat, other, 0.1)
+    assert np.linalg.norm(this - exact) / np.linalg.norm(exact) < 1e-5
+    assert frob == pytest.approx(np.linalg.norm(exact), rel=1e-4)
+    empty = np.diff(mat.indptr) == 0
+    assert np.all(this[empty] == 0)  # implicit.rs:98-101
+
+
+def test_als_train_ml_small_behaviour(oracle, ml_small):
+    """
+    tests/models/test_als_implicit.py:327-360 (shapes after training on ml-latest-small),
+    109-120 (finite predictions), 139-218 (fold-in ~= trained embedding).
+    """
+    rmat = ml_small["rmat"]
+    ind = sps.coo_array((np.ones(rmat.nnz, np.float32), (rmat.row, rmat.col)), rmat.shape)
+    st = oracle.als_train(ind, 25, 5, np.random.SeedSequence(42).spawn(3)[2])
+    P, Q = st.user_embeddings, st.item_embeddings
+    assert P.shape == (671, 25) and Q.shape == (9125, 25)
+    assert np.all(np.isfinite(P)) and np.all(np.isfinite(Q))
+    dP = [d[0] for d in st.deltas]
+    assert dP[-1] < dP[0]  # converging
+    empty = np.bincount(ind.col, minlength=9125) == 0
+    assert empty.sum() == 9125 - 9066 and np.all(Q[empty] == 0)
+    # fold-in (the Python/SciPy path, _implicit.py:101-130) == one more user half-epoch row
+    # (the Rust/sposv path) against the same Q and OtOr; and it stays near the trained row
+    # (tests/models/test_als_implicit.py:139-218 allow 0.1 abs after full training)
+    csr = sps.csr_array(oracle.als_prepare_matrix(ind, 40.0))
+    csr.sort_indices()
+    P2 = P.copy()
+    oracle.als_half_epoch(csr, P2, Q, st.OtOr)
+    for u in (0, 10, 100):
+        items = csr.indices[csr.indptr[u] : csr.indptr[u + 1]]
+        x = oracle.als_fold_in(items, np.full(len(items), 40.0, np.float32), Q, st.OtOr)
+        assert np.abs(x - P2[u]).max() < 2e-4 * max(1.0, np.abs(P2[u]).max())
+        assert np.abs(x - P[u]).max() < 0.25
+    s = oracle.score_dense(Q, P[0])
+    assert np.allclose(s, Q @ P[0], atol=1e-5)
+
+
+def test_als_init_matches_reference_recipe(oracle):
+    "(N(0,1) float32 * 0.01)^2, items first then users from ONE generator (_common.py:287-301)."
+    rng = np.random.default_rng(7)
+    q = oracle.als_initial_params(rng, 5, 3)
+    p = oracle.als_initial_params(rng, 4, 3)
+    rng2 = np.random.default_rng(7)
+    q2 = rng2.standard_normal((5, 3), dtype=np.float32) * 0.01
+    q2 *= q2
+    p2 = rng2.standard_normal((4, 3), dtype=np.float32) * 0.01
+    p2 *= p2
+    assert np.array_equal(q, q2) and np.array_equal(p, p2)
