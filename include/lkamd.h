@@ -163,27 +163,6 @@ int lk_iknn_build_fill(const lk_iknn_plan *plan, const void *d_ui_indptr,
                        const int64_t *d_out_indptr, int32_t *d_out_indices, float *d_out_values,
                        void *stream);
 
-#if 0 /* PLANNED entry points -- declared when implemented (see DESIGN.md) */
-/* ------------------------------------------------------------------------
- * Item-kNN scoring for a BATCH of queries.
- * Replaces `_accel.knn.score_explicit` / `score_implicit`
- * (src/lenskit/_accel/knn.pyi:15-29; src/accel/knn/item_score.rs:23-111,
- * src/accel/knn/accum.rs:16-239), which score ONE query per call.
- *   query q has reference (history) items ref_items[ref_ptr[q]..ref_ptr[q+1]) with
- *   centred ratings ref_rates (NULL => implicit) and targets
- *   tgt_items[tgt_ptr[q]..tgt_ptr[q+1]); negative item numbers are nulls.
- *   score_t = sum_{top max_nbrs by sim} s*v / sum s  (explicit)  or  sum s (implicit);
- *   fewer than min_nbrs contributors => NaN.  out_counts = contributors kept
- *   (-1 for a null target).
- * ---------------------------------------------------------------------- */
-size_t lk_iknn_score_workspace_bytes(int64_t n_items, int64_t n_queries);
-int lk_iknn_score_batch(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
-                        const float *d_sim_values, int64_t n_items, int64_t n_queries,
-                        const int64_t *d_ref_ptr, const int32_t *d_ref_items,
-                        const float *d_ref_rates, const int64_t *d_tgt_ptr,
-                        const int32_t *d_tgt_items, int32_t max_nbrs, int32_t min_nbrs,
-                        void *d_ws, float *d_out_scores, int32_t *d_out_counts, void *stream);
-
 /* ------------------------------------------------------------------------
  * Dense scoring with fused top-K.
  * Replaces, for a batch of users, `ALSBase.__call__` scoring
@@ -209,6 +188,27 @@ int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_users, const
  * direct stand-in for `_accel.data.argtopn(scores, n)`. */
 int lk_argtopn(const float *d_scores, int64_t n_rows, int64_t row_len, int32_t n, void *d_ws,
                int32_t *d_out_idx, void *stream);
+
+#if 0 /* PLANNED entry points -- declared when implemented (see DESIGN.md) */
+/* ------------------------------------------------------------------------
+ * Item-kNN scoring for a BATCH of queries.
+ * Replaces `_accel.knn.score_explicit` / `score_implicit`
+ * (src/lenskit/_accel/knn.pyi:15-29; src/accel/knn/item_score.rs:23-111,
+ * src/accel/knn/accum.rs:16-239), which score ONE query per call.
+ *   query q has reference (history) items ref_items[ref_ptr[q]..ref_ptr[q+1]) with
+ *   centred ratings ref_rates (NULL => implicit) and targets
+ *   tgt_items[tgt_ptr[q]..tgt_ptr[q+1]); negative item numbers are nulls.
+ *   score_t = sum_{top max_nbrs by sim} s*v / sum s  (explicit)  or  sum s (implicit);
+ *   fewer than min_nbrs contributors => NaN.  out_counts = contributors kept
+ *   (-1 for a null target).
+ * ---------------------------------------------------------------------- */
+size_t lk_iknn_score_workspace_bytes(int64_t n_items, int64_t n_queries);
+int lk_iknn_score_batch(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
+                        const float *d_sim_values, int64_t n_items, int64_t n_queries,
+                        const int64_t *d_ref_ptr, const int32_t *d_ref_items,
+                        const float *d_ref_rates, const int64_t *d_tgt_ptr,
+                        const int32_t *d_tgt_items, int32_t max_nbrs, int32_t min_nbrs,
+                        void *d_ws, float *d_out_scores, int32_t *d_out_counts, void *stream);
 
 /* Batched fold-in (new-user embedding) -- `ImplicitMFScorer.new_user_embedding`
  * / `_train_new_row` (src/lenskit/als/_implicit.py:77-130): same algebra as one

@@ -258,3 +258,41 @@ def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None) -> 
     finally:
         lib.lk_iknn_plan_destroy(h)
     return DeviceCSR(out_ptr, out_idx, out_val, (n_items, n_items), None)
+
+
+def score_topk(users: torch.Tensor, items: torch.Tensor, k: int, n: int,
+               excl_ptr: torch.Tensor | None = None, excl_items: torch.Tensor | None = None):
+    """
+    Batched dense scoring + top-N (lk_score_topk): ``users`` [B x KP], ``items`` [I x KP]
+    padded device matrices; exclusion CSR (int64 offsets, int32 items) optional.
+    Returns (indices int32 [B x n] with -1 padding, scores f32 [B x n] with NaN padding).
+    """
+    lib = _native.require_gpu()
+    B, kp = users.shape
+    I = items.shape[0]
+    assert kp == padded_dim(k) and items.shape[1] == kp
+    assert users.is_contiguous() and items.is_contiguous()
+    dev = users.device
+    ws = torch.empty(lib.lk_score_topk_workspace_bytes(B, I, n), dtype=torch.uint8, device=dev)
+    out_idx = torch.empty((B, n), dtype=torch.int32, device=dev)
+    out_sc = torch.empty((B, n), dtype=torch.float32, device=dev)
+    if excl_ptr is not None:
+        assert excl_ptr.dtype == torch.int64 and excl_items.dtype == torch.int32
+    check(
+        lib.lk_score_topk(
+            _ptr(users), kp, B, _ptr(items), kp, I, int(k), int(n), _ptr(excl_ptr),
+            _ptr(excl_items), _ptr(ws), _ptr(out_idx), _ptr(out_sc), _stream()
+        ),
+        "lk_score_topk",
+    )  # fmt: skip
+    return out_idx, out_sc
+
+
+def argtopn(scores: torch.Tensor, n: int) -> torch.Tensor:
+    "Per-row top-N indices (lk_argtopn) of a [rows x len] f32 device matrix; -1 padding."
+    lib = _native.require_gpu()
+    assert scores.dtype == torch.float32 and scores.is_contiguous() and scores.dim() == 2
+    rows, ln = scores.shape
+    out = torch.empty((rows, n), dtype=torch.int32, device=scores.device)
+    check(lib.lk_argtopn(_ptr(scores), rows, ln, int(n), None, _ptr(out), _stream()), "lk_argtopn")
+    return out

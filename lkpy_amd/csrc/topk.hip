@@ -1,0 +1,348 @@
+// topk.hip -- batched dense scoring (f32 MFMA) + per-row top-N selection, gfx950.
+//
+// Stands in, for a BATCH of users, for
+//   * `ALSBase.__call__` scoring, scores = Q u  (src/lenskit/als/_common.py:159-170; a
+//     NumPy GEMV per query in the reference), and
+//   * `TopNRanker` -> `ItemList.top_n` -> `_accel.data.argtopn`
+//     (src/lenskit/basic/topn.py:45-69, src/lenskit/data/_items.py:942-998,
+//     src/accel/data/sorting.rs:132-172 with the heap of src/accel/indirect/heap.rs).
+//
+// Scoring: S[b][i] = fma(U[b][k-1], Q[i][k-1], ... fma(U[b][0], Q[i][0], 0)) -- the f32
+// MFMA (v_mfma_f32_32x32x2_f32) is bit-for-bit this k-ordered fmaf chain, so the scores
+// equal the oracle's fixed-order scores exactly and integer top-N index lists can be
+// compared bit-exactly.  The block stages a 64-user x 64-feature and a 256-item x
+// 64-feature panel in LDS (row stride 65 floats: conflict-free ds_read_b32 operand
+// fetches), 4 waves each own 32 users x 128 items (4 accumulator tiles).
+//
+// Selection (one workgroup per user row, scores L2-resident): NaN and excluded items are
+// skipped (sorting.rs:143; candidates = training items minus the query's items,
+// src/lenskit/basic/candidates.py:77-94), MSB-first 8-bit radix select finds the n-th
+// largest key, equal keys are taken by LOWEST index, the <= n winners are bitonic-sorted in
+// LDS by (score desc, index asc).  Deterministic.
+//
+// Roofline: scoring is f32-MFMA bound (2*B*I*k flop); this first version writes the
+// B_tile x I score panel to HBM and reads it back for the selection (not yet fused).
+#include "common.h"
+
+namespace lk {
+
+constexpr int SC_UB = 64;   // users per block tile
+constexpr int SC_IB = 256;  // items per block tile
+constexpr int SC_KC = 64;   // features staged per pass
+constexpr int SC_LD = SC_KC + 1;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void score_panel_kernel(
+    const float *__restrict__ users, int ld_u, int64_t n_users, const float *__restrict__ items,
+    int ld_i, int64_t n_items, int kp, float *__restrict__ scores, int64_t ld_s)
+{
+    __shared__ float lu[SC_UB * SC_LD];
+    __shared__ float li[SC_IB * SC_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t u0 = (int64_t)blockIdx.y * SC_UB;
+    const int64_t i0 = (int64_t)blockIdx.x * SC_IB;
+    const int wu = (wave & 1) * 32;   // wave's user offset inside the tile
+    const int wi = (wave >> 1) * 128;  // wave's item offset inside the tile
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int kc = 0; kc < kp; kc += SC_KC) {
+        // stage [rows x 64 features] panels, coalesced float4 reads
+        for (int e = tid; e < SC_UB * (SC_KC / 4); e += 256) {
+            const int r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (u0 + r < n_users && kc + c4 * 4 < kp)
+                v = *reinterpret_cast<const f32x4 *>(users + (u0 + r) * ld_u + kc + c4 * 4);
+            float *d = &lu[r * SC_LD + c4 * 4];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        for (int e = tid; e < SC_IB * (SC_KC / 4); e += 256) {
+            const int r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i0 + r < n_items && kc + c4 * 4 < kp)
+                v = *reinterpret_cast<const f32x4 *>(items + (i0 + r) * ld_i + kc + c4 * 4);
+            float *d = &li[r * SC_LD + c4 * 4];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        // v_mfma_f32_32x32x2_f32: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll 4
+        for (int kk = 0; kk < SC_KC; kk += 2) {
+            const float a = lu[(wu + r) * SC_LD + kk + h];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float b = li[(wi + t * 32 + r) * SC_LD + kk + h];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // C/D: col (item) = lane&31, row (user) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int64_t it = i0 + wi + t * 32 + (lane & 31);
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int64_t u = u0 + wu + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+            if (u < n_users && it < n_items) scores[u * ld_s + it] = acc[t][rg];
+        }
+    }
+}
+
+// scores[b][excluded item] = NaN  (NaN is skipped by the selection, like the reference)
+__global__ void score_mask_kernel(const int64_t *__restrict__ excl_ptr,
+                                  const int32_t *__restrict__ excl_items, int64_t user_base,
+                                  int64_t n_rows, int64_t n_items, float *__restrict__ scores,
+                                  int64_t ld_s)
+{
+    const int64_t b = blockIdx.x;
+    if (b >= n_rows) return;
+    const int64_t s = excl_ptr[user_base + b], e = excl_ptr[user_base + b + 1];
+    for (int64_t q = s + threadIdx.x; q < e; q += blockDim.x) {
+        const int it = excl_items[q];
+        if (it >= 0 && it < n_items) scores[b * ld_s + it] = __builtin_nanf("");
+    }
+}
+
+__device__ __forceinline__ unsigned f2key(float x)
+{
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    if (u == 0x80000000u) u = 0u;  // -0.0 ranks with +0.0 (they compare equal)
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k)
+{
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __builtin_bit_cast(float, u);
+}
+
+// One workgroup per row: indices of the n largest non-NaN scores, descending, ties by
+// lower index; rows with fewer than n candidates are padded with -1 / NaN.
+template <int MAXN>
+__global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__ scores,
+                                                       int64_t ld_s, int64_t row_len, int n,
+                                                       int32_t *__restrict__ out_idx,
+                                                       float *__restrict__ out_score,
+                                                       int64_t out_ld)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long cand[MAXN];
+    __shared__ unsigned s_prefix, s_need, s_count, s_valid;
+    const int tid = threadIdx.x;
+    const float *row = scores + (int64_t)blockIdx.x * ld_s;
+    int32_t *oidx = out_idx + (int64_t)blockIdx.x * out_ld;
+    float *osc = out_score ? out_score + (int64_t)blockIdx.x * out_ld : nullptr;
+
+    if (tid == 0) {
+        s_prefix = 0;
+        s_need = (unsigned)n;
+        s_count = 0;
+        s_valid = 0;
+    }
+    __syncthreads();
+    // count valid entries
+    {
+        unsigned v = 0;
+        for (int64_t i = tid; i < row_len; i += 256) v += (row[i] == row[i]) ? 1u : 0u;
+        atomicAdd(&s_valid, v);
+    }
+    __syncthreads();
+    const unsigned valid = s_valid;
+    const unsigned take = valid < (unsigned)n ? valid : (unsigned)n;
+    if (tid == 0) s_need = take;
+    __syncthreads();
+
+    unsigned kth = 0;
+    if (take > 0 && take < valid) {
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = s_prefix;
+            const unsigned hmask = (shift == 24) ? 0u : (0xffffffffu << (shift + 8));
+            for (int64_t i = tid; i < row_len; i += 256) {
+                const float x = row[i];
+                if (x == x) {
+                    const unsigned k = f2key(x);
+                    if ((k & hmask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned need = s_need, cum = 0;
+                int b = 255;
+                for (; b > 0; --b) {
+                    if (cum + hist[b] >= need) break;
+                    cum += hist[b];
+                }
+                s_need = need - cum;  // how many to take from bin b (and below bits)
+                s_prefix = prefix | ((unsigned)b << shift);
+            }
+            __syncthreads();
+        }
+        kth = s_prefix;
+    }
+    const unsigned need_eq = (take > 0 && take < valid) ? s_need : 0u;
+    __syncthreads();
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    // (a) everything strictly above the k-th key (or every valid entry when take == valid)
+    for (int64_t i0 = 0; i0 < row_len; i0 += 256) {
+        const int64_t i = i0 + tid;
+        bool keep = false;
+        unsigned k = 0;
+        if (i < row_len) {
+            const float x = row[i];
+            if (x == x) {
+                k = f2key(x);
+                keep = (take == valid) ? true : (k > kth);
+            }
+        }
+        if (keep && take > 0) {
+            const unsigned pos = atomicAdd(&s_count, 1u);
+            cand[pos] = ((unsigned long long)k << 32) | (0xffffffffu - (unsigned)i);
+        }
+    }
+    __syncthreads();
+    // (b) ties on the k-th key: the need_eq LOWEST indices, walked in index order
+    if (need_eq > 0) {
+        __shared__ unsigned wcnt[4];
+        __shared__ unsigned s_taken;
+        if (tid == 0) s_taken = 0;
+        __syncthreads();
+        for (int64_t i0 = 0; i0 < row_len; i0 += 256) {
+            const int64_t i = i0 + tid;
+            bool eq = false;
+            if (i < row_len) {
+                const float x = row[i];
+                eq = (x == x) && (f2key(x) == kth);
+            }
+            const unsigned long long m = __ballot(eq);
+            const int lane = tid & 63, w = tid >> 6;
+            if (lane == 0) wcnt[w] = (unsigned)__popcll(m);
+            __syncthreads();
+            unsigned before = s_taken;
+            for (int q = 0; q < w; ++q) before += wcnt[q];
+            const unsigned rank =
+                before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (eq && rank < need_eq) {
+                const unsigned pos = atomicAdd(&s_count, 1u);
+                cand[pos] = ((unsigned long long)kth << 32) | (0xffffffffu - (unsigned)i);
+            }
+            __syncthreads();
+            if (tid == 0) s_taken += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+            if (s_taken >= need_eq) break;
+        }
+        __syncthreads();
+    }
+    const unsigned m = s_count;  // == take
+    // bitonic sort, descending, on the padded power of two
+    unsigned p2 = 1;
+    while (p2 < m) p2 <<= 1;
+    for (unsigned i = m + tid; i < p2; i += 256) cand[i] = 0ull;
+    __syncthreads();
+    for (unsigned k = 2; k <= p2; k <<= 1) {
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            for (unsigned i = tid; i < p2; i += 256) {
+                const unsigned ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = cand[i], b = cand[ixj];
+                    const bool desc = ((i & k) == 0);
+                    if (desc ? (a < b) : (a > b)) {
+                        cand[i] = b;
+                        cand[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += 256) {
+        if ((unsigned)i < m) {
+            const unsigned long long c = cand[i];
+            oidx[i] = (int32_t)(0xffffffffu - (unsigned)(c & 0xffffffffu));
+            if (osc) osc[i] = key2f((unsigned)(c >> 32));
+        } else {
+            oidx[i] = -1;
+            if (osc) osc[i] = __builtin_nanf("");
+        }
+    }
+}
+
+constexpr int TOPN_MAX = 4096;
+constexpr int64_t SCORE_BATCH = 2048;  // user rows scored per panel
+
+static int64_t padded_items(int64_t n_items) { return (n_items + 63) / 64 * 64; }
+
+}  // namespace lk
+
+extern "C" size_t lk_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t n)
+{
+    (void)n;
+    int64_t rows = n_users < lk::SCORE_BATCH ? n_users : lk::SCORE_BATCH;
+    if (rows < 1) rows = 1;
+    return (size_t)rows * (size_t)lk::padded_items(n_items) * sizeof(float) + 256;
+}
+
+extern "C" int lk_argtopn(const float *d_scores, int64_t n_rows, int64_t row_len, int32_t n,
+                          void *d_ws, int32_t *d_out_idx, void *stream)
+{
+    (void)d_ws;
+    LK_REQUIRE(n >= 0 && n <= lk::TOPN_MAX, "lk_argtopn: n=%d outside [0, %d]", n, lk::TOPN_MAX);
+    LK_REQUIRE(n_rows >= 0 && row_len >= 0, "lk_argtopn: negative size");
+    if (n == 0 || n_rows == 0) return LK_OK;
+    LK_REQUIRE(d_out_idx && (row_len == 0 || d_scores), "lk_argtopn: null pointer");
+    hipLaunchKernelGGL(lk::row_topn_kernel<lk::TOPN_MAX>, dim3((unsigned)n_rows), dim3(256), 0,
+                       lk::as_stream(stream), d_scores, row_len, row_len, n, d_out_idx,
+                       (float *)nullptr, (int64_t)n);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_users,
+                             const float *d_items, int32_t ld_items, int64_t n_items, int32_t k,
+                             int32_t n, const int64_t *d_excl_ptr, const int32_t *d_excl_items,
+                             void *d_ws, int32_t *d_out_idx, float *d_out_score, void *stream)
+{
+    const int KP = lk_padded_dim(k);
+    LK_REQUIRE(KP > 0, "lk_score_topk: unsupported k=%d", k);
+    LK_REQUIRE(ld_users == KP && ld_items == KP,
+               "lk_score_topk: leading dimensions (%d, %d) must equal lk_padded_dim(k)=%d",
+               ld_users, ld_items, KP);
+    LK_REQUIRE(n >= 0 && n <= lk::TOPN_MAX, "lk_score_topk: n=%d outside [0, %d]", n,
+               lk::TOPN_MAX);
+    LK_REQUIRE(n_users >= 0 && n_items >= 0, "lk_score_topk: negative size");
+    if (n_users == 0 || n == 0) return LK_OK;
+    LK_REQUIRE(d_users && d_ws && d_out_idx && (n_items == 0 || d_items),
+               "lk_score_topk: null pointer");
+    hipStream_t st = lk::as_stream(stream);
+    float *panel = static_cast<float *>(d_ws);
+    const int64_t ld_s = lk::padded_items(n_items);
+    const int KS = KP < lk::SC_KC ? lk::SC_KC : KP;  // features are staged 64 at a time
+    (void)KS;
+    for (int64_t ub = 0; ub < n_users; ub += lk::SCORE_BATCH) {
+        const int64_t rows = (n_users - ub) < lk::SCORE_BATCH ? (n_users - ub) : lk::SCORE_BATCH;
+        if (n_items > 0) {
+            dim3 grid((unsigned)((n_items + lk::SC_IB - 1) / lk::SC_IB),
+                      (unsigned)((rows + lk::SC_UB - 1) / lk::SC_UB));
+            hipLaunchKernelGGL(lk::score_panel_kernel, grid, dim3(256), 0, st,
+                               d_users + ub * ld_users, ld_users, rows, d_items, ld_items,
+                               n_items, KP, panel, ld_s);
+            if (d_excl_ptr)
+                hipLaunchKernelGGL(lk::score_mask_kernel, dim3((unsigned)rows), dim3(64), 0, st,
+                                   d_excl_ptr, d_excl_items, ub, rows, n_items, panel, ld_s);
+        }
+        hipLaunchKernelGGL(lk::row_topn_kernel<lk::TOPN_MAX>, dim3((unsigned)rows), dim3(256), 0,
+                           st, panel, ld_s, n_items, n, d_out_idx + ub * n,
+                           d_out_score ? d_out_score + ub * n : nullptr, (int64_t)n);
+    }
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}

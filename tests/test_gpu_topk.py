@@ -1,0 +1,94 @@
+"""GPU parity: dense scoring + top-N vs the oracle -- scores and index lists BIT-EXACT."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k", [8, 25, 64, 128])
+def test_score_topk_bit_exact(gpu, oracle, rng, k):
+    from lkpy_amd import _device as D
+
+    B, I, n = 150, 3000, 100
+    U = rng.standard_normal((B, k)).astype(np.float32)
+    Q = rng.standard_normal((I, k)).astype(np.float32)
+    Q[rng.random(I) < 0.05] = 0.0  # unrated items: zero factors (score 0)
+    # exclusion lists = the query's own items (basic/candidates.py:77-94)
+    lens = rng.integers(0, 80, B)
+    lens[0] = 0
+    ptr = np.zeros(B + 1, np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    ex = np.concatenate([np.sort(rng.choice(I, l, replace=False)) for l in lens]).astype(np.int32)
+    idx, sc = D.score_topk(
+        D.to_device_padded(U, gpu), D.to_device_padded(Q, gpu), k, n,
+        torch.from_numpy(ptr).to(gpu), torch.from_numpy(ex).to(gpu))  # fmt: skip
+    idx, sc = idx.cpu().numpy(), sc.cpu().numpy()
+    for b in range(B):
+        s = oracle.score_dense(Q, U[b])  # fixed k-ordered fmaf chain
+        s[ex[ptr[b] : ptr[b + 1]]] = np.nan
+        want = oracle.argtopn(s, n)  # the reference's heap (sorting.rs:132-172)
+        assert np.array_equal(sc[b].view(np.uint32), s[want].view(np.uint32)), b
+        # continuous random scores: no ties, so the index lists must agree exactly
+        assert np.array_equal(idx[b], want), b
+        assert not np.isin(idx[b], ex[ptr[b] : ptr[b + 1]]).any()
+
+
+def test_argtopn_properties_and_ties(gpu, oracle, rng):
+    """tests/accel/test_argsort.py:60-211 on the kernel, incl. NaN, short rows, heavy ties."""
+    from lkpy_amd import _device as D
+
+    rows, ln = 64, 5000
+    s = np.round(rng.standard_normal((rows, ln)), 1).astype(np.float32)  # many ties
+    s[rng.random((rows, ln)) < 0.1] = np.nan
+    s[0, :] = np.nan  # nothing valid
+    s[1, 50:] = np.nan  # fewer valid entries than n
+    s[2, :] = 1.0  # all tied -> the lowest indices
+    s[3, ::2] = -0.0
+    s[3, 1::2] = 0.0
+    for n in (1, 10, 100, 777):
+        got = D.argtopn(torch.from_numpy(s).to(gpu), n).cpu().numpy()
+        for r in range(rows):
+            valid = ~np.isnan(s[r])
+            g = got[r]
+            m = min(n, int(valid.sum()))
+            assert np.all(g[m:] == -1) and np.all(g[:m] >= 0)
+            g = g[:m]
+            assert len(set(g.tolist())) == m
+            assert np.all(np.diff(s[r][g]) <= 0)  # descending
+            if m:
+                rest = np.setdiff1d(np.flatnonzero(valid), g)
+                assert not np.any(s[r][rest] > s[r][g].min())  # nothing excluded beats the min
+            # same multiset of scores as the reference heap, ties broken by lower index
+            want = oracle.argtopn(s[r], n)
+            assert np.array_equal(np.sort(s[r][want]), np.sort(s[r][g]))
+            expect = np.lexsort((np.arange(ln)[valid], -(s[r][valid] + 0.0)))[:m]
+            assert np.array_equal(g, np.flatnonzero(valid)[expect])
+    assert np.array_equal(D.argtopn(torch.from_numpy(s).to(gpu), 5).cpu().numpy()[2], np.arange(5))
+
+
+def test_score_topk_cfg1_recommendations(gpu, oracle, ml_small):
+    """cfg1 end of pipe: top-10 for every ml-latest-small user from oracle-trained factors,
+    history excluded -- identical lists to scoring + the reference heap on the CPU."""
+    import scipy.sparse as sps
+
+    from lkpy_amd import _device as D
+
+    rmat = ml_small["rmat"]
+    ind = sps.coo_array((np.ones(rmat.nnz, np.float32), (rmat.row, rmat.col)), rmat.shape)
+    st = oracle.als_train(ind, 25, 3, 7)
+    P, Q = st.user_embeddings, st.item_embeddings
+    csr = sps.csr_array(ind)
+    csr.sort_indices()
+    idx, sc = D.score_topk(
+        D.to_device_padded(P, gpu), D.to_device_padded(Q, gpu), 25, 10,
+        torch.from_numpy(csr.indptr.astype(np.int64)).to(gpu),
+        torch.from_numpy(csr.indices.astype(np.int32)).to(gpu))  # fmt: skip
+    idx = idx.cpu().numpy()
+    for u in range(0, P.shape[0], 7):
+        s = oracle.score_dense(Q, P[u])
+        s[csr.indices[csr.indptr[u] : csr.indptr[u + 1]]] = np.nan
+        want = oracle.argtopn(s, 10)
+        if len(np.unique(s[want])) == 10 and s[want][-1] > np.sort(s[~np.isnan(s)])[-11]:
+            assert np.array_equal(idx[u], want), u
+        assert np.array_equal(np.sort(s[idx[u]]), np.sort(s[want]))
