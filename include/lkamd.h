@@ -189,7 +189,6 @@ int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_users, const
 int lk_argtopn(const float *d_scores, int64_t n_rows, int64_t row_len, int32_t n, void *d_ws,
                int32_t *d_out_idx, void *stream);
 
-#if 0 /* PLANNED entry points -- declared when implemented */
 /* ------------------------------------------------------------------------
  * Item-kNN scoring for a BATCH of queries.
  * Replaces `_accel.knn.score_explicit` / `score_implicit`
@@ -200,9 +199,9 @@ int lk_argtopn(const float *d_scores, int64_t n_rows, int64_t row_len, int32_t n
  *   tgt_items[tgt_ptr[q]..tgt_ptr[q+1]); negative item numbers are nulls.
  *   score_t = sum_{top max_nbrs by sim} s*v / sum s  (explicit)  or  sum s (implicit);
  *   fewer than min_nbrs contributors => NaN.  out_counts = contributors kept
- *   (-1 for a null target).
+ *   (-1 for a null target).  Blocking (returns LK_E_NAN_SIM for a NaN similarity).
  * ---------------------------------------------------------------------- */
-size_t lk_iknn_score_workspace_bytes(int64_t n_items, int64_t n_queries);
+size_t lk_iknn_score_workspace_bytes(int64_t n_items, int64_t n_queries, int32_t max_nbrs);
 int lk_iknn_score_batch(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
                         const float *d_sim_values, int64_t n_items, int64_t n_queries,
                         const int64_t *d_ref_ptr, const int32_t *d_ref_items,
@@ -210,15 +209,10 @@ int lk_iknn_score_batch(const int64_t *d_sim_indptr, const int32_t *d_sim_indice
                         const int32_t *d_tgt_items, int32_t max_nbrs, int32_t min_nbrs,
                         void *d_ws, float *d_out_scores, int32_t *d_out_counts, void *stream);
 
-/* Batched fold-in (new-user embedding) -- `ImplicitMFScorer.new_user_embedding`
- * / `_train_new_row` (src/lenskit/als/_implicit.py:77-130): same algebra as one
- * ALS row with OtOr = Q^T Q + user_reg I; histories given as a CSR over items. */
-int lk_als_fold_in(const lk_als_plan *plan, const void *d_hist_ptr, const int32_t *d_hist_items,
-                   const float *d_hist_values, int64_t n_queries, int64_t n_items, int32_t k,
-                   float *d_out_users, int32_t ld_out, const float *d_items, int32_t ld_items,
-                   const float *d_otor, int32_t ld_otor, void *d_ws, void *stream);
-
-#endif /* planned */
+/* Batched fold-in (new-user embeddings) -- `ImplicitMFScorer.new_user_embedding` /
+ * `_train_new_row` (src/lenskit/als/_implicit.py:77-130) -- is the SAME algebra as one ALS
+ * row with OtOr = Q^T Q + user_reg I: build a plan over the histories' CSR offsets and call
+ * lk_als_implicit_half_epoch with `this` = the [n_queries x ld] output and `other` = Q. */
 
 #ifdef __cplusplus
 }

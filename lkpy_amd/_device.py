@@ -296,3 +296,31 @@ def argtopn(scores: torch.Tensor, n: int) -> torch.Tensor:
     out = torch.empty((rows, n), dtype=torch.int32, device=scores.device)
     check(lib.lk_argtopn(_ptr(scores), rows, ln, int(n), None, _ptr(out), _stream()), "lk_argtopn")
     return out
+
+
+def iknn_score_batch(sims: DeviceCSR, ref_ptr, ref_items, ref_rates, tgt_ptr, tgt_items,
+                     max_nbrs: int, min_nbrs: int):
+    """
+    Item-kNN scoring of a batch of queries (lk_iknn_score_batch).  ``sims``: similarity CSR
+    (int64 offsets); ``ref_*``/``tgt_*``: CSR-style (int64 offsets, int32 items) history and
+    target lists, negative items are nulls; ``ref_rates`` f32 (explicit) or None (implicit).
+    Returns (scores f32 with NaN for null, counts int32 with -1 for null targets).
+    """
+    lib = _native.require_gpu()
+    n_items = sims.shape[0]
+    nq = int(ref_ptr.shape[0]) - 1
+    dev = sims.indices.device
+    assert sims.indptr.dtype == torch.int64
+    ws = torch.empty(lib.lk_iknn_score_workspace_bytes(n_items, nq, int(max_nbrs)),
+                     dtype=torch.uint8, device=dev)
+    out_s = torch.empty(int(tgt_items.shape[0]), dtype=torch.float32, device=dev)
+    out_c = torch.empty(int(tgt_items.shape[0]), dtype=torch.int32, device=dev)
+    check(
+        lib.lk_iknn_score_batch(
+            _ptr(sims.indptr), _ptr(sims.indices), _ptr(sims.values), n_items, nq,
+            _ptr(ref_ptr), _ptr(ref_items), _ptr(ref_rates), _ptr(tgt_ptr), _ptr(tgt_items),
+            int(max_nbrs), int(min_nbrs), _ptr(ws), _ptr(out_s), _ptr(out_c), _stream()
+        ),
+        "lk_iknn_score_batch",
+    )  # fmt: skip
+    return out_s, out_c

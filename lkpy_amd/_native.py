@@ -72,6 +72,11 @@ def _declare(lib):
         "lk_iknn_build_fill": (
             c_int, [vp, vp, vp, vp, vp, vp, vp, c_float, c_int64, vp, vp, vp, vp, vp]
         ),
+        "lk_iknn_score_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32]),
+        "lk_iknn_score_batch": (
+            c_int,
+            [vp, vp, vp, c_int64, c_int64, vp, vp, vp, vp, vp, c_int32, c_int32, vp, vp, vp, vp],
+        ),
         "lk_score_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32]),
         "lk_score_topk": (
             c_int,
