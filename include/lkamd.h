@@ -184,6 +184,12 @@ int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_users, const
                   const int64_t *d_excl_ptr, const int32_t *d_excl_items, void *d_ws,
                   int32_t *d_out_idx, float *d_out_score, void *stream);
 
+/* Scores only: out[b][i] = the same exact k-ordered chain, for every (user, item) pair
+ * (`ALSBase.__call__`, src/lenskit/als/_common.py:159-170). */
+int lk_score_dense(const float *d_users, int32_t ld_users, int64_t n_users, const float *d_items,
+                   int32_t ld_items, int64_t n_items, int32_t k, float *d_out, int64_t ld_out,
+                   void *stream);
+
 /* Plain top-N over score vectors already in HBM (one row per query), the
  * direct stand-in for `_accel.data.argtopn(scores, n)`. */
 int lk_argtopn(const float *d_scores, int64_t n_rows, int64_t row_len, int32_t n, void *d_ws,

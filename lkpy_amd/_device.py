@@ -324,3 +324,32 @@ def iknn_score_batch(sims: DeviceCSR, ref_ptr, ref_items, ref_rates, tgt_ptr, tg
         "lk_iknn_score_batch",
     )  # fmt: skip
     return out_s, out_c
+
+
+def score_dense(users: torch.Tensor, items: torch.Tensor, k: int) -> torch.Tensor:
+    "All (user, item) scores, [B x I] f32 (lk_score_dense)."
+    lib = _native.require_gpu()
+    B, kp = users.shape
+    I = items.shape[0]
+    assert kp == padded_dim(k) and items.shape[1] == kp
+    out = torch.empty((B, I), dtype=torch.float32, device=users.device)
+    check(
+        lib.lk_score_dense(_ptr(users), kp, B, _ptr(items), kp, I, int(k), _ptr(out), I, _stream()),
+        "lk_score_dense",
+    )
+    return out
+
+
+def fold_in(hist: DeviceCSR, items: torch.Tensor, otor: torch.Tensor, k: int,
+            solver: int = _native.SOLVER_AUTO) -> torch.Tensor:
+    """
+    Batched new-user embeddings (``ImplicitMFScorer._train_new_row``,
+    src/lenskit/als/_implicit.py:101-130): one ALS row solve per history row of ``hist``
+    (queries x items CSR, values = weight or weight*rating) against ``items`` and
+    ``otor`` = Q^T Q + user_reg I.  Returns [n_queries x KP]; empty histories give zeros.
+    """
+    plan = ALSPlan(hist, k, solver)
+    out = torch.zeros((hist.shape[0], plan.kp), dtype=torch.float32, device=items.device)
+    plan.half_epoch(out, items, otor)
+    plan.check_status()
+    return out

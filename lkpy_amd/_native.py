@@ -82,6 +82,9 @@ def _declare(lib):
             c_int,
             [vp, c_int32, c_int64, vp, c_int32, c_int64, c_int32, c_int32, vp, vp, vp, vp, vp, vp],
         ),
+        "lk_score_dense": (
+            c_int, [vp, c_int32, c_int64, vp, c_int32, c_int64, c_int32, vp, c_int64, vp]
+        ),
         "lk_argtopn": (c_int, [vp, c_int64, c_int64, c_int32, vp, vp, vp]),
         "lk_als_implicit_half_epoch_host": (
             c_int,

@@ -1,0 +1,270 @@
+"""
+Component seam for implicit-feedback ALS: mirror of ``lenskit.als.ImplicitMFScorer`` /
+``ImplicitMFTrainer`` / ``ALSBase`` / ``ALSTrainerBase`` / ``ALSConfig``
+(src/lenskit/als/_common.py:36-356, src/lenskit/als/_implicit.py:24-184), with the same
+config fields, attributes after training (``users``, ``items``, ``user_embeddings``,
+``item_embeddings``, ``_OtOr``, ``trained_epochs``) and scoring semantics, but with the
+epoch loop resident on the GPU (:class:`lkpy_amd._als_engine.ImplicitALSEngine`).
+Learned state is kept as host NumPy arrays so pickling / ``get_parameters`` keep working
+(SURVEY.md section 5 "Checkpoint / resume"); device state is rebuilt lazily.
+"""
+
+from __future__ import annotations
+
+from typing import Literal
+
+import numpy as np
+import scipy.sparse as sps
+import torch
+from pydantic import AliasChoices, BaseModel, Field, PositiveFloat, PositiveInt
+
+from . import _device as D
+from . import _native
+from ._als_engine import HipBackend, ImplicitALSEngine
+from .data import Dataset, ItemList, RecQuery, Vocabulary
+from .pipeline import Component
+from .training import ModelTrainer, TrainingOptions, UsesTrainer
+
+
+class UIPair(BaseModel):
+    user: PositiveFloat
+    item: PositiveFloat
+
+
+class ALSConfig(BaseModel):
+    "src/lenskit/als/_common.py:36-78 (+ EmbeddingSizeMixin's ``embedding_size_exp``)."
+
+    embedding_size: PositiveInt = Field(
+        default=64, validation_alias=AliasChoices("embedding_size", "features"))
+    embedding_size_exp: PositiveInt | None = None
+    epochs: PositiveInt = 10
+    regularization: PositiveFloat | UIPair | dict = 0.1
+    user_embeddings: bool | Literal["prefer"] = True
+
+    def model_post_init(self, _ctx):
+        if self.embedding_size_exp is not None:
+            object.__setattr__(self, "embedding_size", 2 ** int(self.embedding_size_exp))
+        if isinstance(self.regularization, dict):
+            object.__setattr__(self, "regularization", UIPair(**self.regularization))
+
+    @property
+    def user_reg(self) -> float:
+        r = self.regularization
+        return r.user if isinstance(r, UIPair) else float(r)
+
+    @property
+    def item_reg(self) -> float:
+        r = self.regularization
+        return r.item if isinstance(r, UIPair) else float(r)
+
+
+class ImplicitMFConfig(ALSConfig):
+    "src/lenskit/als/_implicit.py:24-32"
+
+    weight: float = 40
+    use_ratings: bool = False
+    solver: Literal["auto", "cholesky", "cg"] = "auto"
+    "Backend knob (also ``LK_ALS_SOLVER``): exact Cholesky (reference method) or CG."
+
+
+_SOLVERS = {"auto": _native.SOLVER_AUTO, "cholesky": _native.SOLVER_CHOLESKY,
+            "chol": _native.SOLVER_CHOLESKY, "cg": _native.SOLVER_CG}
+
+
+class ImplicitMFScorer(UsesTrainer, Component):
+    """
+    Implicit-feedback matrix factorisation trained with ALS (Hu, Koren, Volinsky); the
+    reference solves every row exactly with LAPACK ``sposv`` (class docstring,
+    src/lenskit/als/_implicit.py:52-54) and so does the default GPU solver.
+    """
+
+    config: ImplicitMFConfig
+
+    users: Vocabulary | None = None
+    items: Vocabulary
+    user_embeddings: np.ndarray | None = None
+    item_embeddings: np.ndarray
+    _OtOr: np.ndarray
+
+    def create_trainer(self, data, options):
+        return ImplicitMFTrainer(self, data, options)
+
+    # -- device-side caches (never pickled) ---------------------------------------
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.pop("_dev", None)
+        return st
+
+    def _device_state(self):
+        dev = getattr(self, "_dev", None)
+        if dev is None or dev["src"] is not self.item_embeddings:
+            d = D.device()
+            dev = {"src": self.item_embeddings, "device": d,
+                   "Q": D.to_device_padded(self.item_embeddings, d),
+                   "OtOr": torch.from_numpy(np.ascontiguousarray(self._OtOr)).to(d)}
+            self._dev = dev
+        return dev
+
+    def _solver(self, options: TrainingOptions | None = None) -> int:
+        name = self.config.solver
+        if options is not None:
+            name = options.env_var("LK_ALS_SOLVER", name) or name
+        return _SOLVERS[name.lower()]
+
+    # -- fold-in --------------------------------------------------------------------
+    def _history_rows(self, queries: list[RecQuery]):
+        "histories -> CSR (queries x items) of confidence values (_implicit.py:77-99)."
+        idx, val, ptr = [], [], [0]
+        for q in queries:
+            hist = q.query_items
+            if hist is not None and len(hist) > 0:
+                ri = hist.numbers(vocabulary=self.items, missing="negative")
+                good = ri >= 0
+                if self.config.use_ratings:
+                    ratings = hist.field("rating")
+                    if ratings is None:
+                        raise ValueError("no ratings in user items")
+                    v = np.asarray(ratings)[good] * self.config.weight
+                else:
+                    v = np.full(int(good.sum()), self.config.weight)
+                order = np.argsort(ri[good], kind="stable")
+                idx.append(ri[good][order])
+                val.append(np.asarray(v, dtype=np.float32)[order])
+            ptr.append(ptr[-1] + (len(idx[-1]) if hist is not None and len(hist) > 0 else 0))
+        indices = np.concatenate(idx).astype(np.int32) if idx else np.zeros(0, np.int32)
+        values = np.concatenate(val).astype(np.float32) if val else np.zeros(0, np.float32)
+        return np.asarray(ptr, dtype=np.int64), indices, values
+
+    def new_user_embedding(self, user_num, user_items: ItemList):
+        "One fold-in (_implicit.py:77-99); returns (vector, None)."
+        st = self._device_state()
+        ptr, idx, val = self._history_rows([RecQuery(user_items=user_items)])
+        hist = D.DeviceCSR.from_arrays(ptr, idx, val, (1, len(self.items)), st["device"])
+        u = D.fold_in(hist, st["Q"], st["OtOr"], self.config.embedding_size, self._solver())
+        return D.to_host_unpadded(u, self.config.embedding_size)[0], None
+
+    def _query_embeddings(self, queries: list[RecQuery]) -> tuple[torch.Tensor, np.ndarray]:
+        """
+        Device [B x KP] embedding per query + validity mask, with ``ALSBase.__call__``'s
+        precedence (_common.py:139-157): history present and user_embeddings != "prefer" ->
+        fold-in; else the stored row; else invalid.
+        """
+        st = self._device_state()
+        k = self.config.embedding_size
+        B = len(queries)
+        fold = [q.query_items is not None and len(q.query_items) > 0 and
+                self.config.user_embeddings != "prefer" for q in queries]
+        out = torch.zeros((B, D.padded_dim(k)), dtype=torch.float32, device=st["device"])
+        valid = np.zeros(B, dtype=bool)
+        fi = [i for i in range(B) if fold[i]]
+        if fi:
+            ptr, idx, val = self._history_rows([queries[i] for i in fi])
+            hist = D.DeviceCSR.from_arrays(ptr, idx, val, (len(fi), len(self.items)),
+                                           st["device"])
+            u = D.fold_in(hist, st["Q"], st["OtOr"], k, self._solver())
+            out[torch.as_tensor(fi, device=st["device"])] = u
+            valid[fi] = True
+        rest = [i for i in range(B) if not fold[i]]
+        if rest and self.user_embeddings is not None and self.users is not None:
+            nums = [None if queries[i].user_id is None else
+                    self.users.number(queries[i].user_id, missing=None) for i in rest]
+            have = [(i, n) for i, n in zip(rest, nums) if n is not None]
+            if have:
+                rows = self.user_embeddings[[n for _, n in have]]
+                out[torch.as_tensor([i for i, _ in have], device=st["device"])] = \
+                    D.to_device_padded(rows, st["device"])
+                valid[[i for i, _ in have]] = True
+        return out, valid
+
+    # -- scoring (src/lenskit/als/_common.py:133-175) -----------------------------------
+    def __call__(self, query, items: ItemList) -> ItemList:
+        query = RecQuery.create(query)
+        u, valid = self._query_embeddings([query])
+        if not valid[0]:
+            return ItemList(items, scores=np.nan)
+        st = self._device_state()
+        all_scores = D.score_dense(u, st["Q"], self.config.embedding_size)[0].cpu().numpy()
+        item_nums = items.numbers(vocabulary=self.items, missing="negative")
+        mask = item_nums >= 0
+        scores = np.full(len(items), np.nan, dtype=np.float32)
+        scores[mask] = all_scores[item_nums[mask]]
+        return ItemList(items, scores=scores)
+
+    def recommend_batch(self, queries, n: int, *, exclude_history: bool = True):
+        """
+        Batched fold-in + dense scoring + top-N for many queries at once (the reference
+        loops queries in Python, src/lenskit/batch/_runner.py:283-308).  Returns
+        (item numbers [B x n] with -1 padding, scores [B x n] with NaN padding).
+        """
+        queries = [RecQuery.create(q) for q in queries]
+        u, valid = self._query_embeddings(queries)
+        st = self._device_state()
+        excl_ptr = excl_idx = None
+        if exclude_history:
+            ptr, idx, _ = self._history_rows(queries)
+            excl_ptr = torch.from_numpy(ptr).to(st["device"])
+            excl_idx = torch.from_numpy(idx).to(st["device"])
+        idx, sc = D.score_topk(u, st["Q"], self.config.embedding_size, n, excl_ptr, excl_idx)
+        idx, sc = idx.cpu().numpy(), sc.cpu().numpy()
+        idx[~valid] = -1
+        sc[~valid] = np.nan
+        return idx, sc
+
+
+class ImplicitMFTrainer(ModelTrainer):
+    "``ALSTrainerBase`` + ``ImplicitMFTrainer`` (_common.py:195-356, _implicit.py:133-175)."
+
+    def __init__(self, scorer: ImplicitMFScorer, data: Dataset, options: TrainingOptions):
+        self.scorer = scorer
+        cfg = scorer.config
+        scorer.users, scorer.items = data.users, data.items
+        self.rng = options.random_generator()
+        ui = self.prepare_matrix(data)
+        k = cfg.embedding_size
+        # item matrix FIRST, then users, same generator (_common.py:287-301)
+        scorer.item_embeddings = self.initial_params(data.item_count, k)
+        scorer.user_embeddings = self.initial_params(data.user_count, k)
+        dev = D.device(None if options.configured_device() in ("cuda", "cpu") else
+                       options.configured_device())
+        backend = HipBackend(k, dev, scorer._solver(options))
+        self.engine = ImplicitALSEngine(sps.csr_array(ui), k, cfg.user_reg, cfg.item_reg,
+                                        scorer.user_embeddings, scorer.item_embeddings, backend)
+        self.epochs_trained = 0
+
+    def prepare_matrix(self, data: Dataset) -> sps.coo_array:
+        "_implicit.py:141-149"
+        ints = data.interactions().matrix()
+        rmat = ints.scipy(attribute="rating", layout="coo") if self.scorer.config.use_ratings \
+            else ints.scipy(layout="coo")
+        vals = np.require(rmat.data, dtype=np.float32) * self.scorer.config.weight
+        return sps.coo_array((vals, (rmat.row, rmat.col)), shape=rmat.shape)
+
+    def initial_params(self, nrows: int, ncols: int) -> np.ndarray:
+        "_implicit.py:152-155"
+        mat = self.rng.standard_normal((nrows, ncols), dtype=np.float32) * 0.01
+        mat *= mat
+        return mat
+
+    def train_epoch(self):
+        du, di = self.engine.train_epoch()
+        self.engine.check()  # RuntimeError("ALS solve error: ...") like implicit.rs:79
+        self.epochs_trained += 1
+        self._sync()
+        return {"deltaP": float(du.item()), "deltaQ": float(di.item())}
+
+    def _sync(self):
+        "after every epoch the model must be usable (training.py ModelTrainer contract)"
+        s = self.scorer
+        s.user_embeddings = self.engine.user_embeddings()
+        s.item_embeddings = self.engine.item_embeddings()
+        s._OtOr = self.engine.otor()  # _save_user_otor (_implicit.py:171-175)
+
+    def finalize(self):
+        self._sync()
+        if not self.scorer.config.user_embeddings:  # _common.py:318-325
+            self.scorer.user_embeddings = None
+            self.scorer.users = None
+
+    def get_parameters(self):
+        return {"user_embeddings": self.scorer.user_embeddings,
+                "item_embeddings": self.scorer.item_embeddings}

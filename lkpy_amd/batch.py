@@ -1,0 +1,53 @@
+"""
+Batch inference that routes whole query batches to the fused kernels (SURVEY.md section 8f,
+rank 1): the reference's ``batch.recommend`` / ``batch.predict`` loop queries in Python
+(src/lenskit/batch/_runner.py:259-345); results here are keyed by user like its
+``ItemListCollection``.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .data import ItemList, RecQuery
+from .pipeline import Pipeline
+
+
+def recommend(pipe: Pipeline, users, n: int, *, batch_size: int = 2048) -> dict:
+    "user id -> ordered ItemList of ``n`` recommendations."
+    scorer = pipe.node("scorer").component
+    lookup = pipe.node("history-lookup").component
+    users = list(users)
+    out = {}
+    if hasattr(scorer, "recommend_batch"):
+        for s in range(0, len(users), batch_size):
+            chunk = users[s:s + batch_size]
+            queries = [lookup(RecQuery.create(u)) for u in chunk]
+            idx, sc = scorer.recommend_batch(queries, n)
+            for u, i, v in zip(chunk, idx, sc):
+                keep = i >= 0
+                out[u] = ItemList(item_nums=i[keep], vocabulary=scorer.items, scores=v[keep],
+                                  ordered=True)
+    else:
+        for u in users:
+            out[u] = pipe.run("recommender", query=u, n=n)
+    return out
+
+
+def predict(pipe: Pipeline, pairs: dict) -> dict:
+    "user id -> ItemList of scores for that user's items (``rating-predictor`` semantics)."
+    scorer = pipe.node("scorer").component
+    lookup = pipe.node("history-lookup").component
+    users = list(pairs)
+    lists = [pairs[u] if isinstance(pairs[u], ItemList) else ItemList(np.asarray(pairs[u]))
+             for u in users]
+    if hasattr(scorer, "score_batch"):
+        queries = [lookup(RecQuery.create(u)) for u in users]
+        scored = scorer.score_batch(queries, lists)
+        merger = pipe.nodes.get("rating-merger")
+        if merger is not None:
+            fb = pipe.node("fallback-predictor").component
+            scored = [merger.component(primary=s, backup=fb(q, il))
+                      for s, q, il in zip(scored, queries, lists)]
+        return dict(zip(users, scored))
+    return {u: pipe.run("rating-predictor", query=u, items=il) for u, il in zip(users, lists)}

@@ -291,6 +291,26 @@ extern "C" size_t lk_score_topk_workspace_bytes(int64_t n_users, int64_t n_items
     return (size_t)rows * (size_t)lk::padded_items(n_items) * sizeof(float) + 256;
 }
 
+extern "C" int lk_score_dense(const float *d_users, int32_t ld_users, int64_t n_users,
+                              const float *d_items, int32_t ld_items, int64_t n_items, int32_t k,
+                              float *d_out, int64_t ld_out, void *stream)
+{
+    const int KP = lk_padded_dim(k);
+    LK_REQUIRE(KP > 0, "lk_score_dense: unsupported k=%d", k);
+    LK_REQUIRE(ld_users == KP && ld_items == KP,
+               "lk_score_dense: leading dimensions (%d, %d) must equal lk_padded_dim(k)=%d",
+               ld_users, ld_items, KP);
+    LK_REQUIRE(n_users >= 0 && n_items >= 0 && ld_out >= n_items, "lk_score_dense: bad shape");
+    if (n_users == 0 || n_items == 0) return LK_OK;
+    LK_REQUIRE(d_users && d_items && d_out, "lk_score_dense: null pointer");
+    dim3 grid((unsigned)((n_items + lk::SC_IB - 1) / lk::SC_IB),
+              (unsigned)((n_users + lk::SC_UB - 1) / lk::SC_UB));
+    hipLaunchKernelGGL(lk::score_panel_kernel, grid, dim3(256), 0, lk::as_stream(stream), d_users,
+                       ld_users, n_users, d_items, ld_items, n_items, KP, d_out, ld_out);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
 extern "C" int lk_argtopn(const float *d_scores, int64_t n_rows, int64_t row_len, int32_t n,
                           void *d_ws, int32_t *d_out_idx, void *stream)
 {

@@ -1,0 +1,406 @@
+"""
+Host-side data model: the subset of ``lenskit.data`` the hot-path components touch
+(SURVEY.md section 2c).  Pure NumPy/SciPy plumbing; nothing here computes scores.
+
+Mirrors (names, argument meaning, error behaviour):
+``Vocabulary``  src/lenskit/data/_vocab.py:32-312
+``ItemList``    src/lenskit/data/_items.py:46-1200
+``RecQuery``    src/lenskit/data/_query.py
+``Dataset``     src/lenskit/data/_dataset.py + ``MatrixRelationshipSet.scipy``
+                (src/lenskit/data/_relationships.py:603-657)
+``SparseRowArray`` src/lenskit/data/matrix.py:318-539 (CSR: offsets/indices/values)
+"""
+
+from __future__ import annotations
+
+from typing import Any, Iterable, Literal
+
+import numpy as np
+import pandas as pd
+import scipy.sparse as sps
+
+
+class Vocabulary:
+    "Sorted, unique entity identifiers <-> contiguous numbers (``_vocab.py:32-312``)."
+
+    def __init__(self, ids: Iterable | None = None, name: str | None = None, *, reorder=True):
+        arr = np.asarray([] if ids is None else ids)
+        if reorder:
+            arr = np.unique(arr)  # ids are de-duplicated and sorted (_builder.py:345-346)
+        self._ids = arr
+        self._index = pd.Index(arr)
+        self.name = name
+
+    @property
+    def index(self) -> pd.Index:
+        return self._index
+
+    @property
+    def size(self) -> int:
+        return len(self._ids)
+
+    def __len__(self):
+        return len(self._ids)
+
+    def __eq__(self, other):
+        return isinstance(other, Vocabulary) and np.array_equal(self._ids, other._ids)
+
+    def __hash__(self):
+        return id(self)
+
+    def number(self, term, missing: Literal["error", "none"] | None = "error"):
+        try:
+            num = self._index.get_loc(term)
+            return int(num)
+        except KeyError:
+            if missing == "error":
+                raise
+            return None
+
+    def numbers(self, terms, missing: Literal["error", "negative"] = "error") -> np.ndarray:
+        nums = np.require(self._index.get_indexer_for(np.asarray(terms)), dtype=np.int32)
+        if missing == "error" and np.any(nums < 0):
+            raise KeyError("unknown terms in vocabulary")
+        return nums
+
+    def id(self, num: int):
+        return self._ids[num]
+
+    def ids(self, nums=None) -> np.ndarray:
+        return self._ids if nums is None else self._ids[np.asarray(nums)]
+
+    def __repr__(self):
+        return f"<Vocabulary {self.name or ''}: {len(self)} ids>"
+
+
+class ItemList:
+    """
+    A list of items with optional scores and named fields (``_items.py:46-1200``):
+    ``ItemList(other, scores=...)``, ``ItemList(item_ids)``,
+    ``ItemList(item_nums=..., vocabulary=...)``, ``from_vocabulary``, ``numbers``, ``ids``,
+    ``scores``, ``field``, ``remove``, ``top_n``.
+    """
+
+    def __init__(self, source=None, *, item_ids=None, item_nums=None, vocabulary=None,
+                 ordered: bool = False, scores=None, **fields):  # fmt: skip
+        self._ids = None
+        self._nums = None
+        self._vocab = vocabulary
+        self._fields: dict[str, np.ndarray] = {}
+        self.ordered = ordered
+        if isinstance(source, ItemList):
+            self._ids, self._nums = source._ids, source._nums
+            self._vocab = vocabulary if vocabulary is not None else source._vocab
+            self._fields = dict(source._fields)
+            self.ordered = ordered or False
+        elif isinstance(source, pd.DataFrame):
+            self._ids = source["item_id"].to_numpy()
+            for c in source.columns:
+                if c != "item_id":
+                    self._fields["score" if c == "score" else c] = source[c].to_numpy()
+        elif source is not None:
+            self._ids = np.asarray(source)
+        if item_ids is not None:
+            self._ids = np.asarray(item_ids)
+        if item_nums is not None:
+            self._nums = np.require(item_nums, dtype=np.int32)
+            if vocabulary is None:
+                raise ValueError("item numbers require a vocabulary")
+        n = len(self)
+        if scores is not None:
+            fields["score"] = scores
+        for name, val in fields.items():
+            if val is None:
+                continue
+            arr = np.asarray(val)
+            if arr.ndim == 0:
+                arr = np.full(n, arr)
+            if len(arr) != n:
+                raise ValueError(f"field {name} has {len(arr)} values, list has {n}")
+            if name == "score":
+                arr = np.require(arr, dtype=np.float32)
+            self._fields[name] = arr
+
+    @classmethod
+    def from_vocabulary(cls, vocab: Vocabulary) -> "ItemList":
+        return cls(item_nums=np.arange(len(vocab), dtype=np.int32), vocabulary=vocab)
+
+    def __len__(self):
+        if self._ids is not None:
+            return len(self._ids)
+        if self._nums is not None:
+            return len(self._nums)
+        return 0
+
+    def ids(self) -> np.ndarray:
+        if self._ids is None:
+            if self._nums is None:
+                return np.zeros(0, dtype=np.int64)
+            self._ids = self._vocab.ids(self._nums)
+        return self._ids
+
+    def numbers(self, vocabulary: Vocabulary | None = None,
+                missing: Literal["error", "negative"] = "error") -> np.ndarray:  # fmt: skip
+        if vocabulary is None or (self._vocab is not None and vocabulary is self._vocab):
+            if self._nums is None:
+                if self._vocab is None:
+                    raise RuntimeError("item numbers not available without a vocabulary")
+                self._nums = self._vocab.numbers(self.ids(), missing=missing)
+            return self._nums
+        if self._nums is not None and self._vocab is not None and vocabulary == self._vocab:
+            return self._nums
+        return vocabulary.numbers(self.ids(), missing=missing)
+
+    def scores(self) -> np.ndarray | None:
+        return self._fields.get("score")
+
+    def field(self, name: str, format: str | None = None):
+        if name == "score":
+            return self.scores()
+        return self._fields.get(name)
+
+    @property
+    def vocabulary(self):
+        return self._vocab
+
+    def _take(self, sel, ordered=False) -> "ItemList":
+        out = ItemList(vocabulary=self._vocab, ordered=ordered)
+        out._ids = None if self._ids is None else self._ids[sel]
+        out._nums = None if self._nums is None else self._nums[sel]
+        out._fields = {k: v[sel] for k, v in self._fields.items()}
+        return out
+
+    def remove(self, *, ids=None, numbers=None) -> "ItemList":
+        "Drop the given items (``_items.py:1083-1128``)."
+        if numbers is not None:
+            mine = self.numbers()
+            keep = ~np.isin(mine, np.asarray(numbers))
+        else:
+            keep = ~np.isin(self.ids(), np.asarray(ids))
+        return self._take(keep)
+
+    def top_n(self, n: int | None = None, *, scores: str | None = None) -> "ItemList":
+        """
+        The ``n`` highest-scored items, NaN scores dropped, result ordered
+        (``_items.py:942-998`` -> ``_accel.data.argtopn`` / ``argsort_descending``).
+        """
+        from ._accel import data as _accel_data
+
+        sc = self.scores() if scores is None else self.field(scores)
+        if sc is None:
+            raise RuntimeError("cannot rank items without scores")
+        if n is None or n < 0:
+            picked = _accel_data.argsort_descending(sc)
+        else:
+            picked = _accel_data.argtopn(sc, n)
+        return self._take(np.asarray(picked), ordered=True)
+
+    def to_df(self) -> pd.DataFrame:
+        df = pd.DataFrame({"item_id": self.ids()})
+        for k, v in self._fields.items():
+            df[k] = v
+        if self.ordered:
+            df["rank"] = np.arange(1, len(self) + 1)
+        return df
+
+    def __repr__(self):
+        return f"<ItemList of {len(self)} items, fields {sorted(self._fields)}>"
+
+
+class RecQuery:
+    "A recommendation query (``_query.py``): user id and/or history items."
+
+    def __init__(self, user_id=None, user_items: ItemList | None = None, **kw):
+        self.user_id = user_id
+        self.history_items = user_items if user_items is not None else kw.get("history_items")
+        self.session_items = kw.get("session_items")
+        self.context_items = kw.get("context_items")
+
+    @property
+    def user_items(self):
+        return self.history_items
+
+    @property
+    def query_items(self) -> ItemList | None:
+        "context -> session -> history precedence."
+        for x in (self.context_items, self.session_items, self.history_items):
+            if x is not None:
+                return x
+        return None
+
+    @property
+    def all_items(self):
+        return self.query_items
+
+    @classmethod
+    def create(cls, data) -> "RecQuery":
+        if data is None:
+            return cls()
+        if isinstance(data, RecQuery):
+            return data
+        if isinstance(data, ItemList):
+            return cls(user_items=data)
+        if isinstance(data, (int, str, bytes, np.integer, np.str_)):
+            return cls(user_id=data.item() if isinstance(data, np.generic) else data)
+        raise TypeError(f"invalid query input (type {type(data)})")
+
+
+class SparseRowArray:
+    """
+    CSR rows as three flat arrays -- the layout of the reference's Arrow extension array
+    (``List<Struct{index:i32, value:f32}>``, ``matrix.py:318-539``): int32 offsets (int64
+    when nnz >= 2^31 or for ``large=True``, like ``LargeList``), int32 indices, f32 values.
+    """
+
+    def __init__(self, offsets, indices, values, shape):
+        self.offsets = np.ascontiguousarray(offsets)
+        self.indices = np.ascontiguousarray(indices, dtype=np.int32)
+        self.values = None if values is None else np.ascontiguousarray(values, dtype=np.float32)
+        self.shape = (int(shape[0]), int(shape[1]))
+
+    @property
+    def nnz(self) -> int:
+        return int(self.indices.shape[0])
+
+    @classmethod
+    def from_scipy(cls, mat, *, values: bool = True, large: bool = False) -> "SparseRowArray":
+        csr = sps.csr_array(mat)
+        csr.sort_indices()
+        smax = np.iinfo(np.int32).max
+        dt = np.int64 if (large or csr.nnz > smax) else np.int32  # matrix.py:411-419
+        return cls(csr.indptr.astype(dt), csr.indices, csr.data if values else None, csr.shape)
+
+    @classmethod
+    def from_arrays(cls, offsets, indices, values, shape) -> "SparseRowArray":
+        return cls(offsets, indices, values, shape)
+
+    def to_scipy(self) -> sps.csr_array:
+        vals = self.values if self.values is not None else np.ones(self.nnz, np.float32)
+        return sps.csr_array((vals, self.indices, self.offsets), shape=self.shape)
+
+    def row_extent(self, row: int) -> tuple[int, int]:
+        return int(self.offsets[row]), int(self.offsets[row + 1])
+
+    def to_arrow(self):
+        "Arrow (Large)List<Struct{index,value}> for interop with the reference's boundary."
+        import pyarrow as pa
+
+        fields = [pa.array(self.indices, pa.int32())]
+        names = ["index"]
+        if self.values is not None:
+            fields.append(pa.array(self.values, pa.float32()))
+            names.append("value")
+        st = pa.StructArray.from_arrays(fields, names)
+        if self.offsets.dtype == np.int64:
+            return pa.LargeListArray.from_arrays(pa.array(self.offsets, pa.int64()), st)
+        return pa.ListArray.from_arrays(pa.array(self.offsets, pa.int32()), st)
+
+
+class _Matrix:
+    "``MatrixRelationshipSet`` (rows = users, columns = items)."
+
+    def __init__(self, ds: "Dataset"):
+        self._ds = ds
+
+    @property
+    def row_vocabulary(self):
+        return self._ds.users
+
+    @property
+    def col_vocabulary(self):
+        return self._ds.items
+
+    def scipy(self, attribute: str | None = None, *, layout: str = "csr", legacy: bool = False):
+        "``_relationships.py:603-657``: values 1.0f32 when no attribute is requested."
+        ds = self._ds
+        if attribute is None or (attribute == "count" and "count" not in ds._attrs):
+            values = np.ones(ds.interaction_count, dtype=np.float32)
+        else:
+            if attribute not in ds._attrs:
+                raise KeyError(f"interactions have no attribute {attribute}")
+            values = ds._attrs[attribute]
+        shape = (ds.user_count, ds.item_count)
+        if layout == "coo":
+            return sps.coo_array((values, (ds._rows, ds._cols)), shape=shape)
+        return sps.csr_array((values, ds._cols, ds._indptr), shape=shape)
+
+    def row_items(self, user_id) -> ItemList | None:
+        ds = self._ds
+        u = ds.users.number(user_id, missing=None)
+        if u is None:
+            return None
+        s, e = ds._indptr[u], ds._indptr[u + 1]
+        fields = {k: v[s:e] for k, v in ds._attrs.items()}
+        return ItemList(item_nums=ds._cols[s:e], vocabulary=ds.items, **fields)
+
+
+class _Interactions:
+    def __init__(self, ds):
+        self._ds = ds
+        self.entities = ["user", "item"]
+
+    def matrix(self, row_entity="user", col_entity="item"):
+        return _Matrix(self._ds)
+
+
+class Dataset:
+    "User-item interaction data: vocabularies + (user, item)-sorted interactions."
+
+    def __init__(self, users: Vocabulary, items: Vocabulary, rows, cols, attrs: dict[str, Any]):
+        self.users, self.items = users, items
+        order = np.lexsort((cols, rows))
+        self._rows = np.require(rows, dtype=np.int32)[order]
+        self._cols = np.require(cols, dtype=np.int32)[order]
+        self._attrs = {k: np.asarray(v)[order] for k, v in attrs.items()}
+        self._indptr = np.zeros(len(users) + 1, dtype=np.int32)
+        np.cumsum(np.bincount(self._rows, minlength=len(users)), out=self._indptr[1:])
+
+    @property
+    def user_count(self):
+        return len(self.users)
+
+    @property
+    def item_count(self):
+        return len(self.items)
+
+    @property
+    def interaction_count(self):
+        return len(self._rows)
+
+    def interactions(self, name: str | None = None):
+        return _Interactions(self)
+
+    def interaction_matrix(self, *, format="scipy", layout="csr", field=None):
+        return _Matrix(self).scipy(field, layout=layout)
+
+    def user_row(self, user_id) -> ItemList | None:
+        return _Matrix(self).row_items(user_id)
+
+    @classmethod
+    def from_arrays(cls, user_ids, item_ids, ratings=None, *, all_item_ids=None, **attrs):
+        user_ids, item_ids = np.asarray(user_ids), np.asarray(item_ids)
+        users = Vocabulary(user_ids, "user")
+        items = Vocabulary(item_ids if all_item_ids is None else all_item_ids, "item")
+        if ratings is not None:
+            attrs["rating"] = np.require(ratings, dtype=np.float32)
+        return cls(users, items, users.numbers(user_ids), items.numbers(item_ids), attrs)
+
+
+def from_interactions_df(df: pd.DataFrame, *, user_col="user_id", item_col="item_id",
+                         rating_col="rating") -> Dataset:  # fmt: skip
+    "``lenskit.data.from_interactions_df`` for (user, item[, rating]) frames."
+    ucol = user_col if user_col in df else "user"
+    icol = item_col if item_col in df else "item"
+    ratings = df[rating_col].to_numpy() if rating_col in df else None
+    return Dataset.from_arrays(df[ucol].to_numpy(), df[icol].to_numpy(), ratings)
+
+
+def load_movielens_npz(path) -> Dataset:
+    """
+    The committed ml-latest-small fixture (tests/golden/ml_small.npz) as the reference's
+    ``load_movielens`` builds it: every movies.csv id is an item
+    (src/lenskit/data/sources/movielens.py:327-345).
+    """
+    z = np.load(path)
+    return Dataset.from_arrays(z["user_id"], z["item_id"], z["rating"],
+                               all_item_ids=z["all_item_ids"])  # fmt: skip

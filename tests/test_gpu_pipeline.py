@@ -1,0 +1,217 @@
+"""GPU: the reference's pipeline TOMLs end to end through the component API."""
+import pickle
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sps
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def ml_ds():
+    from lkpy_amd.data import load_movielens_npz
+
+    return load_movielens_npz(GOLDEN / "ml_small.npz")
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def test_als_implicit_toml_trains_like_the_reference(gpu, oracle, ml_small, ml_ds):
+    """pipelines/als-implicit.toml, seed 42: same seed handling and init as the reference
+    => the scorer sees SeedSequence(42).spawn child (2,), items initialised first."""
+    from lkpy_amd.pipeline import Pipeline
+    from lkpy_amd.training import TrainingOptions
+
+    pipe = Pipeline.load_config(GOLDEN / "pipelines" / "als-implicit.toml")
+    scorer = pipe.node("scorer").component
+    scorer.config.epochs = 5
+    pipe.train(ml_ds, TrainingOptions(rng=42))
+    assert scorer.is_trained() and scorer.trained_epochs == 5
+    assert scorer.user_embeddings.shape == (671, 64) and scorer.item_embeddings.shape == (9125, 64)
+    assert scorer._OtOr.shape == (64, 64)
+
+    rmat = ml_small["rmat"]
+    ind = sps.coo_array((np.ones(rmat.nnz, np.float32), (rmat.row, rmat.col)), rmat.shape)
+    want = oracle.als_train(ind, 64, 5, np.random.SeedSequence(42).spawn(3)[2])
+    # two float32 implementations of an ill-conditioned iteration: ~1e-3 apart (see
+    # test_gpu_als.py::test_half_epoch_ml_small_cfg1 for the per-half-epoch analysis)
+    assert _rel(scorer.item_embeddings, want.item_embeddings) < 2e-2
+    assert _rel(scorer.user_embeddings, want.user_embeddings) < 2e-2
+    assert _rel(scorer._OtOr, want.OtOr) < 2e-2
+    empty = np.bincount(ind.col, minlength=9125) == 0
+    assert np.all(scorer.item_embeddings[empty] == 0)
+
+    # recommend through the pipeline == the reference's steps restated on the CPU from the
+    # SAME factors: history lookup, candidates minus history, fold-in, scores, top-N
+    csr = sps.csr_array(ind)
+    Q, OtOr = scorer.item_embeddings, scorer._OtOr
+    same = 0
+    users = ml_small["user_ids"][::29]
+    for uid in users:
+        recs = pipe.run("recommender", query=int(uid), n=10)
+        assert len(recs) == 10 and recs.ordered
+        u = int(np.searchsorted(ml_small["user_ids"], uid))
+        hist = csr.indices[csr.indptr[u] : csr.indptr[u + 1]]
+        x = oracle.als_fold_in(hist, np.full(len(hist), 40.0, np.float32), Q, OtOr)
+        s = oracle.score_dense(Q, x.astype(np.float32))
+        s[hist] = np.nan
+        top = oracle.argtopn(s, 10)
+        got = recs.numbers(vocabulary=scorer.items)
+        assert not np.isin(got, hist).any()
+        assert np.allclose(recs.scores(), s[got], rtol=2e-4, atol=2e-5)
+        same += int(np.array_equal(got, top))
+    assert same >= 0.9 * len(users)  # fold-in differs at ~1e-6: only near-ties may swap
+
+    # NaN semantics (tests/models/test_als_implicit.py:277-298, _common.py:145-170)
+    from lkpy_amd.data import ItemList
+
+    res = scorer(query=int(users[0]), items=ItemList([1, 2, -999]))
+    assert np.isnan(res.scores()[2]) and res.scores().dtype == np.float32
+    assert np.all(np.isnan(scorer(query=-12345, items=ItemList([1, 2])).scores()))
+
+    # pickle round trip: scores equal within 1e-3 (testing/_components.py:146-188)
+    clone = pickle.loads(pickle.dumps(pipe))
+    r1 = pipe.run("scorer", query=int(users[1]), items=ItemList(ml_ds.items.ids()[:500]))
+    r2 = clone.run("scorer", query=int(users[1]), items=ItemList(ml_ds.items.ids()[:500]))
+    assert np.allclose(r1.scores(), r2.scores(), atol=1e-3, equal_nan=True)
+
+
+def test_als_batch_recommend_equals_per_query(gpu, ml_ds):
+    from lkpy_amd import batch
+    from lkpy_amd.als import ImplicitMFScorer
+    from lkpy_amd.pipeline import topn_pipeline
+    from lkpy_amd.training import TrainingOptions
+
+    pipe = topn_pipeline(ImplicitMFScorer(features=25, epochs=3))
+    pipe.train(ml_ds, TrainingOptions(rng=7))
+    users = [int(u) for u in ml_ds.users.ids()[::40]] + [-1]
+    out = batch.recommend(pipe, users, 20)
+    assert len(out[-1]) == 0  # unknown user without history: nothing to recommend
+    for u in users[:-1]:
+        one = pipe.run("recommender", query=u, n=20)
+        assert np.array_equal(out[u].ids(), one.ids())
+        assert np.array_equal(out[u].scores(), one.scores())
+
+
+def test_user_embeddings_false_and_prefer(gpu, ml_ds):
+    "tests/models/test_als_implicit.py:301-324 and the 'prefer' path of _common.py:145-157."
+    from lkpy_amd.als import ImplicitMFScorer
+    from lkpy_amd.data import ItemList
+    from lkpy_amd.pipeline import topn_pipeline
+    from lkpy_amd.training import TrainingOptions
+
+    pipe = topn_pipeline(ImplicitMFScorer(features=16, epochs=2, user_embeddings=False))
+    pipe.train(ml_ds, TrainingOptions(rng=1))
+    sc = pipe.node("scorer").component
+    assert sc.user_embeddings is None and sc.users is None
+    assert len(pipe.run("recommender", query=int(ml_ds.users.id(3)), n=5)) == 5
+    pipe = topn_pipeline(ImplicitMFScorer(features=16, epochs=2, user_embeddings="prefer"))
+    pipe.train(ml_ds, TrainingOptions(rng=1))
+    sc = pipe.node("scorer").component
+    uid = int(ml_ds.users.id(3))
+    items = ItemList(ml_ds.items.ids()[:64])
+    got = sc(query=pipe.node("history-lookup").component(uid), items=items).scores()
+    want = sc.item_embeddings[:64] @ sc.user_embeddings[3]
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-6)
+
+
+def test_iknn_explicit_toml_end_to_end(gpu, oracle, ml_small, ml_ds):
+    from lkpy_amd import batch
+    from lkpy_amd.data import ItemList
+    from lkpy_amd.pipeline import Pipeline
+
+    pipe = Pipeline.load_config(GOLDEN / "pipelines" / "iknn-explicit.toml")
+    pipe.train(ml_ds)
+    knn = pipe.node("scorer").component
+    ui, iu, means, _ = oracle.iknn_prepare(ml_small["rmat"], True)
+    want = oracle.iknn_build(ui, iu, 1.0e-6, None)
+    sm = knn.sim_matrix
+    assert sm.offsets.dtype == np.int64
+    assert np.array_equal(sm.offsets, want.indptr) and np.array_equal(sm.indices, want.indices)
+    assert np.array_equal(sm.values.view(np.uint32), want.data.view(np.uint32))
+    assert np.array_equal(knn.item_means, means)
+    assert np.array_equal(knn.item_counts, np.diff(want.indptr))
+
+    # the reference's golden predictions through batch.predict (k=20 is the TOML default)
+    known = pd.read_csv(GOLDEN / "item-item-preds.csv")
+    pairs = {int(u): ItemList(g.item_id.values) for u, g in known.groupby("user_id")}
+    preds = batch.predict(pipe, pairs)
+    got = np.concatenate([preds[int(u)].scores() for u, _ in known.groupby("user_id")])
+    exp = np.concatenate([g.prediction.values for _, g in known.groupby("user_id")])
+    assert not np.any(np.isnan(got) & ~np.isnan(exp))
+    err = np.abs(got - exp)
+    assert np.sum(err > 1e-5) <= 5 and np.median(err) < 1e-6
+
+    # per-query path, unknown items, fallback merge (std:topn-predict)
+    uid = int(known.user_id.iloc[0])
+    res = pipe.run("scorer", query=uid, items=ItemList([int(known.item_id.iloc[0]), -7]))
+    assert np.isfinite(res.scores()[0]) and np.isnan(res.scores()[1])
+    assert res.field("nbr_counts")[0] > 0
+    full = pipe.run("rating-predictor", query=uid, items=ItemList(ml_ds.items.ids()[:200]))
+    assert np.all(np.isfinite(full.scores()))  # the bias fallback fills the gaps
+    recs = pipe.run("recommender", query=uid, n=10)
+    assert len(recs) == 10 and np.all(np.diff(recs.scores()) <= 0)
+    hist = ml_ds.user_row(uid).ids()
+    assert not np.isin(recs.ids(), hist).any()
+    # no history => all NaN (item.py:238-245)
+    assert np.all(np.isnan(knn(query=-5, items=ItemList([1, 2, 3])).scores()))
+    clone = pickle.loads(pickle.dumps(knn))
+    assert np.array_equal(clone.sim_matrix.values, knn.sim_matrix.values)
+    r2 = clone(query=pipe.node("history-lookup").component(uid), items=ItemList(ml_ds.items.ids()[:50]))
+    r1 = knn(query=pipe.node("history-lookup").component(uid), items=ItemList(ml_ds.items.ids()[:50]))
+    assert np.array_equal(r1.scores(), r2.scores(), equal_nan=True)
+
+
+def test_iknn_constant_ratings_warns(gpu):
+    from lkpy_amd.data import from_interactions_df
+    from lkpy_amd.knn import DataWarning, ItemKNNScorer
+
+    df = pd.DataFrame({"user_id": [1, 1, 2, 2, 3, 3], "item_id": [1, 2, 1, 2, 1, 2], "rating": 1.0})
+    with pytest.warns(DataWarning):
+        ItemKNNScorer(k=5).train(from_interactions_df(df))
+
+
+def test_function_seam(gpu, oracle, ml_small, rng):
+    "The `_accel` stand-ins with the reference's argument lists, through run_accel_task."
+    from lkpy_amd import _accel
+    from lkpy_amd.data import SparseRowArray
+    from lkpy_amd.parallel import run_accel_task
+
+    rmat = ml_small["rmat"]
+    ind = sps.coo_array((np.full(rmat.nnz, 40.0, np.float32), (rmat.row, rmat.col)), rmat.shape)
+    ui = sps.csr_array(ind)
+    k = 25
+    other = (rng.standard_normal((ui.shape[1], k)) * 0.1).astype(np.float32)
+    this = (rng.standard_normal((ui.shape[0], k)) * 0.1).astype(np.float32)
+    otor = oracle.implicit_otor(other, 0.1)
+    want = this.copy()
+    wd = oracle.als_half_epoch(ui, want, other, otor)
+    d = run_accel_task(_accel.als.train_implicit_matrix(SparseRowArray.from_scipy(ui), this,
+                                                        other, otor))
+    assert d == pytest.approx(wd, rel=1e-4)
+    assert _rel(this, want) < 1e-4  # updated IN PLACE
+    with pytest.raises(TypeError):
+        _accel.als.train_implicit_matrix(ui, this.astype(np.float64), other, otor)
+
+    uin, iun, _m, _ = oracle.iknn_prepare(ml_small["rmat"], True)
+    chunks = run_accel_task(_accel.knn.compute_similarities(
+        SparseRowArray.from_scipy(uin), SparseRowArray.from_scipy(iun), uin.shape, 1e-6, None))
+    assert isinstance(chunks, list) and chunks[0].offsets.dtype == np.int64
+    ws = oracle.iknn_build(uin, iun, 1e-6, None)
+    assert np.array_equal(chunks[0].values.view(np.uint32), ws.data.view(np.uint32))
+
+    s = rng.standard_normal(5000).astype(np.float32)
+    s[::7] = np.nan
+    assert np.array_equal(_accel.data.argtopn(s, 50), oracle.argtopn(s, 50))
+    assert len(_accel.data.argtopn(s, 0)) == 0
+    full = _accel.data.argsort_descending(s[:3000])
+    assert np.array_equal(full, oracle.argsort_descending(s[:3000]))
+    import pyarrow as pa
+
+    assert np.array_equal(_accel.data.argtopn(pa.array(s[:100]), 5), oracle.argtopn(s[:100], 5))

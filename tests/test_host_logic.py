@@ -1,0 +1,142 @@
+"""CPU: host-side mirror of the reference interface (no kernels involved)."""
+import pickle
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+
+GOLDEN = Path(__file__).parent / "golden"
+
+
+def test_reference_tomls_load_unchanged():
+    """tests/pipeline/test_human_config.py:24-39 -- als-implicit.toml yields an
+    ImplicitMFScorer scorer and a TopNRanker recommender; iknn-explicit.toml (std:topn-predict)
+    adds the fallback predictor."""
+    from lkpy_amd.als import ImplicitMFScorer
+    from lkpy_amd.basic import BiasScorer, FallbackScorer, TopNRanker
+    from lkpy_amd.knn import ItemKNNScorer
+    from lkpy_amd.pipeline import Pipeline
+
+    p = Pipeline.load_config(GOLDEN / "pipelines" / "als-implicit.toml")
+    assert isinstance(p.node("scorer").component, ImplicitMFScorer)
+    assert p.node("scorer").component.config.user_embeddings is True
+    assert isinstance(p.node("recommender").component, TopNRanker)
+    assert list(p.nodes)[:3] == ["query", "items", "n"]
+    p = Pipeline.load_config(GOLDEN / "pipelines" / "iknn-explicit.toml")
+    assert isinstance(p.node("scorer").component, ItemKNNScorer)
+    assert isinstance(p.node("fallback-predictor").component, BiasScorer)
+    assert isinstance(p.node("rating-predictor").component, FallbackScorer)
+
+
+def test_config_aliases_and_validation():
+    "tests/models/test_als_implicit.py:42-69, test_knn_item_item.py:98-103"
+    from lkpy_amd.als import ImplicitMFConfig, ImplicitMFScorer
+    from lkpy_amd.knn import ItemKNNScorer
+
+    assert ImplicitMFScorer(features=25).config.embedding_size == 25
+    assert ImplicitMFScorer(embedding_size_exp=5).config.embedding_size == 32
+    cfg = ImplicitMFConfig(regularization={"user": 0.2, "item": 0.05})
+    assert cfg.user_reg == 0.2 and cfg.item_reg == 0.05
+    assert ImplicitMFConfig().weight == 40 and ImplicitMFConfig().epochs == 10
+    m = ItemKNNScorer(k=30)
+    assert m.dump_config()["max_nbrs"] == 30 and m.dump_config()["feedback"] == "explicit"
+    assert ItemKNNScorer(min_sim=1e-320).config.min_sim >= np.finfo(np.float64).smallest_normal
+    with pytest.raises(Exception):
+        ItemKNNScorer(bogus=1)
+    with pytest.raises(Exception):
+        ImplicitMFScorer(epochs=0)
+    assert pickle.loads(pickle.dumps(ImplicitMFScorer(features=8))).config.embedding_size == 8
+
+
+def test_dataset_vocabulary_itemlist():
+    from lkpy_amd.data import ItemList, RecQuery, Vocabulary, load_movielens_npz
+
+    ds = load_movielens_npz(GOLDEN / "ml_small.npz")
+    assert (ds.user_count, ds.item_count, ds.interaction_count) == (671, 9125, 100004)
+    m = ds.interactions().matrix().scipy(layout="csr")
+    assert m.dtype == np.float32 and np.all(m.data == 1.0)  # _relationships.py:603-657
+    r = ds.interactions().matrix().scipy("rating", layout="coo")
+    assert r.shape == (671, 9125) and set(np.unique(r.data)) <= set(np.arange(1, 11) * 0.5)
+    assert np.all(np.diff(ds.items.ids()) > 0)
+    v = ds.items
+    assert v.number(v.id(17)) == 17 and v.number(-5, missing=None) is None
+    with pytest.raises(KeyError):
+        v.number(-5)
+    assert v.numbers([v.id(3), -1], missing="negative").tolist() == [3, -1]
+    row = ds.user_row(ds.users.id(0))
+    assert len(row) == m.indptr[1] and row.field("rating") is not None
+    il = ItemList([10, 20, 30], scores=[0.5, np.nan, 2.0], vocabulary=Vocabulary([10, 20, 30]))
+    assert il.scores().dtype == np.float32 and len(il.remove(numbers=[1])) == 2
+    assert ItemList(il, scores=np.nan).scores().tolist() != il.scores().tolist()
+    q = RecQuery.create(5)
+    assert q.user_id == 5 and q.query_items is None
+    assert RecQuery.create(il).query_items is il and RecQuery.create(q) is q
+
+
+def test_history_candidates_bias_components():
+    from lkpy_amd.basic import (BiasScorer, FallbackScorer, TrainingItemsCandidateSelector,
+                                UserTrainingHistoryLookup)
+    from lkpy_amd.data import ItemList, from_interactions_df
+
+    df = pd.DataFrame({"user_id": [1, 1, 2, 2, 3], "item_id": [10, 20, 10, 30, 20],
+                       "rating": [4.0, 3.0, 2.0, 5.0, 1.0]})
+    ds = from_interactions_df(df)
+    look = UserTrainingHistoryLookup()
+    look.train(ds)
+    q = look(1)
+    assert q.history_items.ids().tolist() == [10, 20]
+    assert look(99).history_items is None
+    cand = TrainingItemsCandidateSelector()
+    cand.train(ds)
+    assert cand(q).ids().tolist() == [30]  # training items minus the query's items
+    bias = BiasScorer()
+    bias.train(ds)
+    mu = df.rating.mean()
+    assert bias.global_bias == pytest.approx(mu)
+    bi = df.assign(c=df.rating - mu).groupby("item_id").c.mean()
+    assert bias.item_biases == pytest.approx(bi.values)
+    s = bias(q, ItemList([10, 20, 30, 99]))
+    assert len(s) == 4 and np.all(np.isfinite(s.scores()))
+    fb = FallbackScorer()
+    merged = fb(primary=ItemList([10, 20], scores=[np.nan, 2.0]),
+                backup=ItemList([10, 20], scores=[1.5, 9.0]))
+    assert merged.scores().tolist() == [1.5, 2.0]
+
+
+def test_pipeline_seed_spawning_matches_reference():
+    """Pipeline.train hands the i-th Trainable node the i-th spawned SeedSequence child
+    (src/lenskit/pipeline/_impl.py:346-366): the scorer of std:topn gets spawn_key (2,)."""
+    from lkpy_amd.pipeline import Component, Pipeline
+    from lkpy_amd.training import TrainingOptions
+
+    seen = {}
+
+    class Probe(Component):
+        def is_trained(self):
+            return False
+
+        def train(self, data, options):
+            seen["rng"] = options.rng
+
+        def __call__(self, query, items):
+            return items
+
+    p = Pipeline.std_topn()
+    p.replace_component("scorer", Probe())
+    from lkpy_amd.data import from_interactions_df
+
+    ds = from_interactions_df(pd.DataFrame({"user_id": [1], "item_id": [2], "rating": [3.0]}))
+    p.train(ds, TrainingOptions(rng=42))
+    assert seen["rng"].spawn_key == (2,) and seen["rng"].entropy == 42
+
+
+def test_accel_task_protocol():
+    from lkpy_amd.parallel import AccelTask, run_accel_task
+
+    t = AccelTask(lambda task: (task.set_progress(7), 42)[1], total=7)
+    assert run_accel_task(t) == 42 and t.current_progress() == (7, 7)
+    with pytest.raises(RuntimeError, match="accelerator task failed"):
+        run_accel_task(AccelTask(lambda task: 1 / 0))
+    with pytest.raises(RuntimeError):
+        t.invoke()  # invoke exactly once
