@@ -1,0 +1,124 @@
+"""
+CPU, world_size 2, gloo: the row-sharding / exchange logic of ImplicitALSEngine
+(relabelling, per-rank row blocks, in-place all-gather, Gramian and delta all-reduce).
+The HIP kernels cannot run here, so the ORACLE stands in for the arithmetic through the
+engine's backend interface -- test infrastructure only; the product backend is HipBackend.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class OracleBackend:
+    def __init__(self, k):
+        from oracle import lk_oracle
+
+        self.lko = lk_oracle
+        self.k = self.kp = k
+
+    def make_plan(self, local_csr):
+        m = sps.csr_array(local_csr)
+        m.sort_indices()
+        return m
+
+    def upload(self, mat):
+        return torch.from_numpy(np.ascontiguousarray(mat, dtype=np.float32).copy())
+
+    def download(self, t):
+        return t.numpy().copy()
+
+    def gramian(self, rows, reg):
+        r = rows.numpy().astype(np.float64)
+        return torch.from_numpy((r.T @ r + reg * np.eye(self.k)).astype(np.float32))
+
+    def half_epoch(self, plan, this_slice, other_full, otor):
+        view = this_slice.numpy()  # shares memory: updated in place like the kernel does
+        d = self.lko.als_half_epoch(plan, view, other_full.numpy(), otor.numpy(), 2)
+        return torch.tensor([d], dtype=torch.float32)
+
+    def check(self, plan):
+        pass
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ui, k, P0, Q0, epochs, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lkpy_amd._als_engine import ImplicitALSEngine
+
+        eng = ImplicitALSEngine(ui, k, 0.1, 0.2, P0, Q0, OracleBackend(k))
+        deltas = []
+        for _ in range(epochs):
+            du, di = eng.train_epoch()
+            deltas.append((float(du), float(di)))
+        out[rank] = (eng.user_embeddings(), eng.item_embeddings(), eng.otor(), deltas,
+                     eng.local_nnz)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_deal_rows_balances_and_round_trips():
+    from lkpy_amd._als_engine import deal_rows
+
+    rng = np.random.default_rng(0)
+    lens = rng.geometric(0.02, 1001)
+    for world in (1, 2, 3, 8):
+        new_of_old, old_of_new, rpr = deal_rows(lens, world)
+        assert rpr * world >= len(lens) and len(old_of_new) == rpr * world
+        assert np.array_equal(np.sort(new_of_old), np.sort(np.flatnonzero(old_of_new >= 0)))
+        assert np.array_equal(old_of_new[new_of_old], np.arange(len(lens)))
+        per_rank = [lens[old_of_new[r * rpr:(r + 1) * rpr][old_of_new[r * rpr:(r + 1) * rpr] >= 0]].sum()
+                    for r in range(world)]
+        assert max(per_rank) - min(per_rank) <= lens.max()  # nnz-balanced to one row
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_engine_matches_single_process(oracle, world):
+    rng = np.random.default_rng(5)
+    n_users, n_items, k, epochs = 301, 157, 8, 3
+    dense = rng.random((n_users, n_items)) < 0.06
+    dense[:, 5] = False  # an item nobody rated
+    dense[7, :] = False  # a user without interactions
+    ui = sps.csr_array(dense.astype(np.float32) * 40.0)
+    ui.eliminate_zeros()
+    Q0 = oracle.als_initial_params(rng, n_items, k)
+    P0 = oracle.als_initial_params(rng, n_users, k)
+
+    # single process, plain reference order (no relabelling)
+    P, Q = P0.copy(), Q0.copy()
+    iu = sps.csr_array(ui.T)
+    iu.sort_indices()
+    ref_d = []
+    for _ in range(epochs):
+        du = oracle.als_half_epoch(ui, P, Q, oracle.implicit_otor(Q, 0.1))
+        di = oracle.als_half_epoch(iu, Q, P, oracle.implicit_otor(P, 0.2))
+        ref_d.append((du, di))
+
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, ui, k, P0, Q0, epochs, out), nprocs=world, join=True)
+    assert sorted(out.keys()) == list(range(world))
+    for r in range(world):
+        gP, gQ, gO, gd, lnnz = out[r]
+        assert np.allclose(gP, P, rtol=1e-3, atol=1e-5) and np.allclose(gQ, Q, rtol=1e-3, atol=1e-5)
+        assert np.all(gQ[5] == 0) and np.all(gP[7] == 0)
+        assert np.allclose(gO, oracle.implicit_otor(Q, 0.1), rtol=1e-3, atol=1e-5)
+        assert np.allclose(np.array(gd), np.array(ref_d), rtol=1e-3)
+    # every rank ends with identical replicas
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    # and the shards really split the work
+    assert out[0][4][0] + out[1][4][0] == ui.nnz and abs(out[0][4][0] - out[1][4][0]) < 0.2 * ui.nnz
