@@ -1,0 +1,37 @@
+// als_plan.h -- the ALS plan object shared by the Cholesky and CG half-epoch kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LK_DELTA_BLOCKS 256
+
+struct lk_als_plan {
+    int64_t n_rows = 0;
+    int32_t k = 0, KP = 0, NT = 0, solver = 0;
+    int32_t is64 = 0;  // width of the CSR offsets the plan was built from
+    int64_t n_chunks = 0;
+    int64_t n_long = 0;
+    // device-side schedule
+    int32_t *d_order = nullptr;      // [n_rows] rows, longest first
+    int32_t *d_row_slab = nullptr;   // [n_rows] first slab of the row or -1
+    int32_t *d_chunk_row = nullptr;  // [n_chunks]
+    int64_t *d_chunk_beg = nullptr;  // [n_chunks] CSR entry range
+    int32_t *d_chunk_len = nullptr;
+    // workspace layout (byte offsets)
+    size_t off_status = 0, off_otor = 0, off_delta = 0, off_partial = 0, off_slabs = 0,
+           ws_bytes = 0;
+    float cg_tol = 1e-7f;
+    int32_t cg_max_iter = 0;
+    // optional per-kernel timing (HIP events on the launch stream): ring of
+    // (start, mid, stop) triples -- start..mid = chunk kernel, mid..stop = solve kernel
+    static constexpr int TIMING_RING = 128;
+    bool timing = false;
+    mutable int timing_n = 0;
+    mutable hipEvent_t ev[TIMING_RING][3] = {};
+};
+
+namespace lk {
+// deterministic two-stage sum of the per-row squared deltas -> sqrt (als_chol.hip)
+int launch_delta_reduce(const float *row_delta, int64_t n_rows, float *partial, float *out_frob,
+                        hipStream_t st);
+}  // namespace lk

@@ -165,3 +165,52 @@ def test_not_spd_reports_error(gpu, rng):
     plan.half_epoch(this, other, otor)
     with pytest.raises(RuntimeError, match="ALS solve error"):
         plan.check_status()
+
+
+@pytest.mark.parametrize("k", [64, 100, 128, 256])
+def test_half_epoch_cg(gpu, oracle, rng, k):
+    """The CG solver (k > 64; forced at k = 64): tolerance-terminated, so it converges to the
+    exact (Cholesky / sposv) answer of the reference."""
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    n_rows, n_cols = 1500, 3000
+    mat = _random_csr(rng, n_rows, n_cols, 25, long_rows=(2500, 700))
+    other = (rng.standard_normal((n_cols, k)) * 0.1).astype(np.float32)
+    this = (rng.standard_normal((n_rows, k)) * 0.1).astype(np.float32)
+    otor = oracle.implicit_otor(other, 0.1)
+    want = this.copy()
+    want_frob = oracle.als_half_epoch(mat, want, other, otor)
+
+    csr = D.DeviceCSR.from_scipy(mat, gpu)
+    plan = D.ALSPlan(csr, k, _native.SOLVER_CG if k == 64 else _native.SOLVER_AUTO)
+    assert plan.solver == _native.SOLVER_CG
+    plan.set_cg(1e-7, 2 * k)
+    d_this = D.to_device_padded(this, gpu)
+    d_other = D.to_device_padded(other, gpu)
+    frob = plan.half_epoch(d_this, d_other, D.Gramian(k, gpu)(d_other, 0.1))
+    plan.check_status()
+    got = D.to_host_unpadded(d_this, k)
+    empty = np.diff(mat.indptr) == 0
+    assert np.all(got[empty] == 0.0)
+    assert _rel(got, want) < RTOL, _rel(got, want)
+    rn = np.linalg.norm(want, axis=1)
+    err = np.linalg.norm(got - want, axis=1)
+    assert np.all(err <= 10 * RTOL * np.maximum(rn, 1e-3))
+    assert abs(float(frob.item()) - want_frob) <= 1e-3 * want_frob
+    if d_this.shape[1] > k:
+        assert float(d_this[:, k:].abs().max().item()) == 0.0
+    # deterministic
+    d2 = D.to_device_padded(this, gpu)
+    plan.half_epoch(d2, d_other, D.Gramian(k, gpu)(d_other, 0.1))
+    plan.check_status()
+    assert np.array_equal(D.to_host_unpadded(d2, k), got)
+
+
+def test_cholesky_refuses_large_k(gpu, rng):
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    mat = _random_csr(rng, 10, 20, 3)
+    with pytest.raises(ValueError, match="Cholesky solver supports k <= 64"):
+        D.ALSPlan(D.DeviceCSR.from_scipy(mat, gpu), 128, _native.SOLVER_CHOLESKY)
