@@ -30,6 +30,8 @@
 // Roofline: f32 MFMA bound for k = 64 (nnz*(2k^2+2k) +
 // rows*(k^3/3 + 2k^2) flop per half-epoch); HBM traffic is the CSR stream plus
 // the (L2/MALL-resident) gathered factor rows.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <utility>
 #include <vector>
@@ -131,46 +133,41 @@ __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__re
                                                 int64_t end, const float *__restrict__ other,
                                                 int /*ld == 16*NT*/)
 {
+    // Every load below is UNCONDITIONAL (out-of-range lanes/groups re-read the row's last
+    // entry, which is masked or never consumed): a load inside a branch makes the compiler
+    // drain the whole memory queue (s_waitcnt vmcnt(0)) before every MFMA group and the
+    // ring would hide nothing.
     const int lane = lane_id();
     constexpr int RING = GatherRing<NT>::RING;
     GatherRing<NT> R;
+    const int64_t last = end - 1;  // end > beg
 
-    // batch 0 indices/values
-    int cur_col = 0, nxt_col = 0;
-    float cur_val = 0.f, nxt_val = 0.f;
-    if (beg + lane < end) {
-        cur_col = cols[beg + lane];
-        cur_val = vals[beg + lane];
-    }
+    int cur_col, nxt_col;
+    float cur_val, nxt_val;
     {
-        const int nb0 = (end - beg) < 64 ? (int)(end - beg) : 64;
-        const int ng0 = (nb0 + 3) >> 2;
-#pragma unroll
-        for (int g = 0; g < RING; ++g)
-            if (g < ng0) ring_issue<NT>(R, g, g, cur_col, cur_val, other);
+        const int64_t e = (beg + lane < end) ? beg + lane : last;
+        cur_col = cols[e];
+        cur_val = vals[e];
     }
+#pragma unroll
+    for (int g = 0; g < RING; ++g) ring_issue<NT>(R, g, g, cur_col, cur_val, other);
+
     for (int64_t base = beg; base < end; base += 64) {
         const int nb = (end - base) < 64 ? (int)(end - base) : 64;
         const int ngroups = (nb + 3) >> 2;
-        const int64_t nbase = base + 64;
-        const int nnb = nbase < end ? ((end - nbase) < 64 ? (int)(end - nbase) : 64) : 0;
-        const int nngroups = (nnb + 3) >> 2;
-        nxt_col = 0;
-        nxt_val = 0.f;
-        if (nbase + lane < end) {
-            nxt_col = cols[nbase + lane];
-            nxt_val = vals[nbase + lane];
+        {
+            const int64_t e = (base + 64 + lane < end) ? base + 64 + lane : last;
+            nxt_col = cols[e];
+            nxt_val = vals[e];
         }
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
+            // wave-uniform branch with no memory operation inside
             if (g < ngroups) ring_consume<NT>(G, R, g % RING, g, nb);
-            if (g < 16 - RING) {
-                if (g + RING < ngroups)
-                    ring_issue<NT>(R, g % RING, g + RING, cur_col, cur_val, other);
-            } else {
-                if (g + RING - 16 < nngroups)
-                    ring_issue<NT>(R, g % RING, g + RING - 16, nxt_col, nxt_val, other);
-            }
+            if (g < 16 - RING)
+                ring_issue<NT>(R, g % RING, g + RING, cur_col, cur_val, other);
+            else
+                ring_issue<NT>(R, g % RING, g + RING - 16, nxt_col, nxt_val, other);
         }
         cur_col = nxt_col;
         cur_val = nxt_val;
