@@ -101,14 +101,14 @@ __device__ __forceinline__ void ring_issue(GatherRing<NT> &R, const int slot_idx
     load_q<NT>(other + (int64_t)col * KP + (lane & 15) * NT, R.q[slot_idx]);
 }
 
-template <int NT>
+template <int NT, bool MASKED>
 __device__ __forceinline__ void ring_consume(Gram<NT> &G, const GatherRing<NT> &R,
                                              const int slot_idx, const int g, const int nb)
 {
     const int lane = lane_id();
-    // entries past the row end carry (col 0, v 0): kill their q so that neither
-    // A (v*q*q) nor y ((v+1)*q) sees them
-    const bool live = (g * 4 + (lane >> 4)) < nb;
+    // MASKED (tail batch only): entries past the row end re-read the row's last entry; kill
+    // their q so that neither A (v*q*q) nor y ((v+1)*q) sees them
+    const bool live = !MASKED || (g * 4 + (lane >> 4)) < nb;
     const float v = R.v[slot_idx];
     float q[NT], a[NT];
 #pragma unroll
@@ -152,9 +152,9 @@ __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__re
 #pragma unroll
     for (int g = 0; g < RING; ++g) ring_issue<NT>(R, g, g, cur_col, cur_val, other);
 
-    for (int64_t base = beg; base < end; base += 64) {
-        const int nb = (end - base) < 64 ? (int)(end - base) : 64;
-        const int ngroups = (nb + 3) >> 2;
+    int64_t base = beg;
+    // full batches: one straight-line body of 16 groups, no branches, no masks
+    for (; base + 64 <= end; base += 64) {
         {
             const int64_t e = (base + 64 + lane < end) ? base + 64 + lane : last;
             nxt_col = cols[e];
@@ -162,8 +162,7 @@ __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__re
         }
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            // wave-uniform branch with no memory operation inside
-            if (g < ngroups) ring_consume<NT>(G, R, g % RING, g, nb);
+            ring_consume<NT, false>(G, R, g % RING, g, 64);
             if (g < 16 - RING)
                 ring_issue<NT>(R, g % RING, g + RING, cur_col, cur_val, other);
             else
@@ -171,6 +170,16 @@ __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__re
         }
         cur_col = nxt_col;
         cur_val = nxt_val;
+    }
+    // tail batch (< 64 entries): wave-uniform branches with no memory operation inside
+    if (base < end) {
+        const int nb = (int)(end - base);
+        const int ngroups = (nb + 3) >> 2;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            if (g < ngroups) ring_consume<NT, true>(G, R, g % RING, g, nb);
+            if (g < 16 - RING) ring_issue<NT>(R, g % RING, g + RING, cur_col, cur_val, other);
+        }
     }
 }
 
