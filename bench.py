@@ -63,6 +63,34 @@ def half_bytes(lengths: np.ndarray, k: int):
     return nnz * (4 + 4 + 4 * k) + (rows + 1) * 4 + rows * k * 4 * 2 + k * k * 4
 
 
+def pmc_traffic(kernel_substr: str):
+    """
+    HBM bytes per launch of a kernel from the COMMITTED rocprofv3 PMC summary
+    (profiles/*_counters.csv, written by tools/prof_als.sh + tools/summarize_prof.py on the
+    same workload): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE is doubled because on
+    gfx950 it reports half the bytes of wide (16 B/lane) coalesced reads
+    (MI355X_MICROARCH.md, section HBM).  Counters cannot be collected inside this process, so
+    the value is null when no summary is committed.
+    """
+    import csv
+
+    files = sorted((ROOT / "profiles").glob("r*_als_*_counters.csv"))
+    if not files:
+        return None, None
+    fetch, write = [], []
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            if kernel_substr in row["Kernel_Name"]:
+                if row["Counter_Name"] == "FETCH_SIZE":
+                    fetch.append(float(row["mean"]))
+                elif row["Counter_Name"] == "WRITE_SIZE":
+                    write.append(float(row["mean"]))
+    if not fetch:
+        return None, None
+    w = sum(write) / len(write) if write else 0.0
+    return (2.0 * sum(fetch) / len(fetch) + w) * 1024.0, files[-1].name
+
+
 def cpu_baseline(ui, k, reg, budget_s=20.0):
     """
     Time the CPU oracle (port of src/accel/als/implicit.rs + LAPACK sposv) on a row
@@ -240,6 +268,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": None,
+                "traffic_source": None,
                 "avg_launch_ms": round(avg_ms, 4),
                 "launches": launches,
                 "algorithmic_flops_per_launch": flops_per_launch,
@@ -249,6 +278,8 @@ def main():
                 "chunk_kernel_flops_per_launch": (fu_chunk * nu + fi_chunk * ni) / launches,
             }
 
+    if roof and world == 1 and args.scale == 1.0 and k == 64:
+        roof["traffic"], roof["traffic_source"] = pmc_traffic("als_solve_kernel")
     out = {
         "metric": "ALS-implicit epochs/sec (ML-25M-shaped, k=%d)" % k,
         "value": round(args.steps / elapsed, 3),

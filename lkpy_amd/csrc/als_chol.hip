@@ -278,11 +278,14 @@ __device__ __forceinline__ void chol_step(f32x2 (&a)[KP / 2], float &lj, float &
     const float ajj = bcast(AT(a, J + 1), J + 1);
     minpiv = fminf(minpiv, ajj);
     const float rinv = __builtin_amdgcn_rsqf(ajj);
-    dinv = (lane == J + 1) ? rinv : dinv;
+    // 1/L_jj goes to a small LDS array (read back once, per lane, after the factorisation):
+    // a per-step `dinv = lane == j ? rinv : dinv` select is sunk by the compiler to the end,
+    // which keeps all k rinv values alive in registers
+    if (lane == 0) lds[P::SIZE + J + 1] = rinv;
     const float lnext = (lane > J + 1) ? AT(a, J + 1) * rinv : 0.f;
     AT(a, J + 1) = lnext;
     if constexpr (J + 2 < KP) {
-        if (lane >= P::c0(J + 1)) lds[P::off(J + 1) + lane - P::c0(J + 1)] = lnext;
+        if (lane >= P::c0(J + 1) && lane < KP) lds[P::off(J + 1) + lane - P::c0(J + 1)] = lnext;
     }
     // multipliers L_cJ, c >= J+2, as wave-uniform ds_read_b128 broadcasts; the reads run
     // LOOKAHEAD groups ahead of the FMAs that use them
@@ -348,12 +351,13 @@ __device__ __forceinline__ float chol_solve(f32x2 (&a)[KP / 2], float &b,
         const float ajj = bcast(AT(a, 0), 0);
         minpiv = fminf(minpiv, ajj);
         const float rinv = __builtin_amdgcn_rsqf(ajj);
-        dinv = (lane == 0) ? rinv : dinv;
+        if (lane == 0) lds[P::SIZE] = rinv;
         lj = (lane > 0) ? AT(a, 0) * rinv : 0.f;  // strictly-lower column 0
         AT(a, 0) = lj;
-        lds[P::off(0) + lane - P::c0(0)] = lj;
+        if (lane < KP) lds[P::off(0) + lane - P::c0(0)] = lj;
     }
     chol_steps<KP>(a, lj, dinv, minpiv, lds, std::make_integer_sequence<int, KP - 1>{});
+    dinv = (lane < KP) ? lds[P::SIZE + lane] : 0.f;
     // forward: L z = y.  a[j] is zero for lanes <= j, so no masks: lane i only
     // receives the terms j < i; z_i = b_i * dinv_i.
 #pragma unroll
@@ -366,7 +370,11 @@ __device__ __forceinline__ float chol_solve(f32x2 (&a)[KP / 2], float &b,
     // read four rows at a time (ds_read_b128; rows <= i inside the column are stored
     // zeros, rows below c0(i) are outside it).
     const int my_c0 = (lane + 1) & ~3;
-    const float *mycol = lds + P::off(lane) - my_c0;
+    int my_off = P::off(lane) - my_c0;
+    // tie the column address to the finished forward pass: otherwise all 16 ds_read_b128 of
+    // the back substitution are hoisted above it and sit on 64 VGPRs next to the 64 of `a`
+    asm volatile("" : "+v"(my_off), "+v"(b));
+    const float *mycol = lds + my_off;
 #pragma unroll
     for (int j4 = KP / 4 - 1; j4 >= 0; --j4) {
         f32x4 l4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -401,7 +409,9 @@ struct TPack {
 template <int NT>
 __host__ __device__ constexpr int solve_lds_floats()
 {
-    return TPack<NT>::SIZE > LPack<NT * 16>::SIZE ? TPack<NT>::SIZE : LPack<NT * 16>::SIZE;
+    // the L image is followed by the k reciprocal pivots
+    return TPack<NT>::SIZE > LPack<NT * 16>::SIZE + NT * 16 ? TPack<NT>::SIZE
+                                                            : LPack<NT * 16>::SIZE + NT * 16;
 }
 
 template <int NT, bool IS64>
