@@ -195,6 +195,22 @@ int lk_score_dense(const float *d_users, int32_t ld_users, int64_t n_users, cons
 int lk_argtopn(const float *d_scores, int64_t n_rows, int64_t row_len, int32_t n, void *d_ws,
                int32_t *d_out_idx, void *stream);
 
+/* Per-row top-`save_nbrs` truncation of a built similarity matrix -- the second half of
+ * `sim_row` (src/accel/knn/item_train.rs:139-151): keep the save_nbrs most similar
+ * neighbours of every row, ties at the cut in order of first encounter (first shared user,
+ * then column), rows stay sorted by column.  lk_iknn_build_* take save_nbrs <= 0 (none);
+ * run these on their output.  `nnz` = entries of the input matrix.  _count is blocking. */
+size_t lk_iknn_truncate_workspace_bytes(int64_t n_items, int64_t nnz);
+int lk_iknn_truncate_count(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
+                           const float *d_sim_values, const void *d_iu_indptr,
+                           int iu_indptr_is_64, const int32_t *d_iu_indices, int64_t n_items,
+                           int64_t nnz, int64_t save_nbrs, void *d_ws, int64_t *d_out_indptr,
+                           int64_t *h_total_nnz, void *stream);
+int lk_iknn_truncate_fill(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
+                          const float *d_sim_values, int64_t n_items, int64_t nnz, void *d_ws,
+                          const int64_t *d_out_indptr, int32_t *d_out_indices,
+                          float *d_out_values, void *stream);
+
 /* ------------------------------------------------------------------------
  * Item-kNN scoring for a BATCH of queries.
  * Replaces `_accel.knn.score_explicit` / `score_implicit`

@@ -211,9 +211,10 @@ class ALSPlan:
 
 def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None) -> DeviceCSR:
     """
-    Item-item similarity build (lk_iknn_build_count / _fill): ``ui`` users x items and
-    ``iu`` items x users hold the normalised ratings; returns the similarity matrix as a
-    device CSR with int64 offsets, rows sorted by column.
+    Item-item similarity build (lk_iknn_build_count / _fill, then lk_iknn_truncate_* when
+    ``save_nbrs`` is set): ``ui`` users x items and ``iu`` items x users hold the normalised
+    ratings; returns the similarity matrix as a device CSR with int64 offsets, rows sorted
+    by column.
     """
     lib = _native.require_gpu()
     n_users, n_items = ui.shape
@@ -233,12 +234,11 @@ def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None) -> 
         ws = torch.empty(lib.lk_iknn_plan_workspace_bytes(h), dtype=torch.uint8, device=dev)
         out_ptr = torch.empty(n_items + 1, dtype=torch.int64, device=dev)
         total = ctypes.c_int64(0)
-        sn = -1 if save_nbrs is None else int(save_nbrs)
         ms = float(np.float32(min_sim))  # cast to f32 at the boundary (item_train.rs:37)
         check(
             lib.lk_iknn_build_count(
                 h, _ptr(ui.indptr), _ptr(ui.indices), _ptr(ui.values), _ptr(iu.indptr),
-                _ptr(iu.indices), _ptr(iu.values), ms, sn, _ptr(ws), _ptr(out_ptr),
+                _ptr(iu.indices), _ptr(iu.values), ms, -1, _ptr(ws), _ptr(out_ptr),
                 ctypes.byref(total), _stream()
             ),
             "lk_iknn_build_count",
@@ -249,7 +249,7 @@ def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None) -> 
         check(
             lib.lk_iknn_build_fill(
                 h, _ptr(ui.indptr), _ptr(ui.indices), _ptr(ui.values), _ptr(iu.indptr),
-                _ptr(iu.indices), _ptr(iu.values), ms, sn, _ptr(ws), _ptr(out_ptr),
+                _ptr(iu.indices), _ptr(iu.values), ms, -1, _ptr(ws), _ptr(out_ptr),
                 _ptr(out_idx), _ptr(out_val), _stream()
             ),
             "lk_iknn_build_fill",
@@ -257,7 +257,34 @@ def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None) -> 
         torch.cuda.current_stream().synchronize()
     finally:
         lib.lk_iknn_plan_destroy(h)
-    return DeviceCSR(out_ptr, out_idx, out_val, (n_items, n_items), None)
+    full = DeviceCSR(out_ptr, out_idx, out_val, (n_items, n_items), None)
+    if save_nbrs is None or int(save_nbrs) <= 0:
+        return full
+    # item_train.rs:139-151: per-row top-save_nbrs, ties in order of first encounter
+    del ws
+    tws = torch.empty(lib.lk_iknn_truncate_workspace_bytes(n_items, nnz), dtype=torch.uint8,
+                      device=dev)
+    new_ptr = torch.empty(n_items + 1, dtype=torch.int64, device=dev)
+    check(
+        lib.lk_iknn_truncate_count(
+            _ptr(full.indptr), _ptr(full.indices), _ptr(full.values), _ptr(iu.indptr), is64,
+            _ptr(iu.indices), n_items, nnz, int(save_nbrs), _ptr(tws), _ptr(new_ptr),
+            ctypes.byref(total), _stream()
+        ),
+        "lk_iknn_truncate_count",
+    )  # fmt: skip
+    nnz2 = int(total.value)
+    t_idx = torch.empty(max(nnz2, 1), dtype=torch.int32, device=dev)[:nnz2]
+    t_val = torch.empty(max(nnz2, 1), dtype=torch.float32, device=dev)[:nnz2]
+    check(
+        lib.lk_iknn_truncate_fill(
+            _ptr(full.indptr), _ptr(full.indices), _ptr(full.values), n_items, nnz, _ptr(tws),
+            _ptr(new_ptr), _ptr(t_idx), _ptr(t_val), _stream()
+        ),
+        "lk_iknn_truncate_fill",
+    )  # fmt: skip
+    torch.cuda.current_stream().synchronize()
+    return DeviceCSR(new_ptr, t_idx, t_val, (n_items, n_items), None)
 
 
 def score_topk(users: torch.Tensor, items: torch.Tensor, k: int, n: int,

@@ -72,6 +72,12 @@ def _declare(lib):
         "lk_iknn_build_fill": (
             c_int, [vp, vp, vp, vp, vp, vp, vp, c_float, c_int64, vp, vp, vp, vp, vp]
         ),
+        "lk_iknn_truncate_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+        "lk_iknn_truncate_count": (
+            c_int,
+            [vp, vp, vp, vp, c_int, vp, c_int64, c_int64, c_int64, vp, vp, POINTER(c_int64), vp],
+        ),
+        "lk_iknn_truncate_fill": (c_int, [vp, vp, vp, c_int64, c_int64, vp, vp, vp, vp, vp]),
         "lk_iknn_score_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32]),
         "lk_iknn_score_batch": (
             c_int,

@@ -92,10 +92,40 @@ def test_build_empty(gpu):
     assert np.array_equal(ptr, np.zeros(6, np.int64)) and len(idx) == 0 and len(val) == 0
 
 
-def test_save_nbrs_fails_loudly(gpu, oracle, ml_small):
+@pytest.mark.parametrize("save_nbrs", [1, 20, 100, 500])
+@pytest.mark.parametrize("explicit", [True, False])
+def test_save_nbrs_bit_exact(gpu, oracle, ml_small, save_nbrs, explicit):
+    """Per-row truncation (item_train.rs:139-151) incl. the first-encounter tie order: the
+    implicit model has MANY exact ties (equal co-rating patterns) across the cut."""
     from lkpy_amd import _device as D
 
-    ui, iu, _m, _ = oracle.iknn_prepare(ml_small["rmat"], True)
+    rmat = ml_small["rmat"]
+    if not explicit:
+        rmat = sps.coo_array((np.ones(rmat.nnz, np.float32), (rmat.row, rmat.col)), rmat.shape)
+    ui, iu, _m, _ = oracle.iknn_prepare(rmat, explicit)
+    want = oracle.iknn_build(ui, iu, 1.0e-6, save_nbrs)
     dui, diu = D.DeviceCSR.from_scipy(ui, gpu), D.DeviceCSR.from_scipy(iu, gpu)
-    with pytest.raises(ValueError, match="save_nbrs"):
-        D.iknn_build(dui, diu, 1e-6, 100)
+    out = D.iknn_build(dui, diu, 1.0e-6, save_nbrs)
+    got = (out.indptr.cpu().numpy(), out.indices.cpu().numpy(), out.values.cpu().numpy())
+    _assert_same(got, want)
+    assert np.all(np.diff(got[0]) <= save_nbrs)
+    # the test really exercises ties at the cut
+    full = oracle.iknn_build(ui, iu, 1.0e-6, None)
+    ties = 0
+    for i in np.flatnonzero(np.diff(full.indptr) > save_nbrs)[:400]:
+        v = np.sort(full.data[full.indptr[i] : full.indptr[i + 1]])[::-1]
+        ties += int(v[save_nbrs - 1] == v[save_nbrs])
+    if not explicit and save_nbrs >= 20:
+        assert ties > 0
+
+
+def test_save_nbrs_rejected_by_raw_build(gpu, oracle, ml_small):
+    "The raw build entry points take save_nbrs <= 0 only and say so loudly."
+    import ctypes
+
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    lib = _native.load()
+    assert lib.lk_iknn_truncate_count(None, None, None, None, 0, None, 5, 5, 0, None, None,
+                                      ctypes.byref(ctypes.c_int64(0)), None) == _native.LK_E_INVALID
