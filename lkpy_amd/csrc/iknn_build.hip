@@ -58,27 +58,31 @@ struct lk_iknn_plan {
 
 namespace lk {
 
-// seg[u*(P+1) + p] = number of entries of user u with column < p*W
+// desc[u*P + p] = {first entry (absolute index into the packed user rows), length} of the
+// slice of user u's row that falls into column window p  (two binary searches per pair)
 template <bool IS64>
-__global__ void iknn_seg_kernel(const typename IndPtr<IS64>::type *__restrict__ ui_ptr,
-                                const int32_t *__restrict__ ui_idx, int64_t n_users, int P, int W,
-                                int32_t *__restrict__ seg)
+__global__ void iknn_desc_kernel(const typename IndPtr<IS64>::type *__restrict__ ui_ptr,
+                                 const int32_t *__restrict__ ui_idx, int64_t n_users, int P, int W,
+                                 int2 *__restrict__ desc)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_users * (P + 1)) return;
-    const int64_t u = t / (P + 1);
-    const int p = (int)(t - u * (P + 1));
+    if (t >= n_users * P) return;
+    const int64_t u = t / P;
+    const int p = (int)(t - u * P);
     const int64_t b = ui_ptr[u], e = ui_ptr[u + 1];
-    const int64_t bound = (int64_t)p * W;
-    int64_t lo = b, hi = e;  // first index with column >= bound
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (ui_idx[mid] < bound)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    seg[t] = (int32_t)(lo - b);
+    auto lower = [&](int64_t bound) {
+        int64_t lo = b, hi = e;  // first index with column >= bound
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (ui_idx[mid] < bound)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        return lo;
+    };
+    const int64_t s0 = lower((int64_t)p * W), s1 = lower((int64_t)(p + 1) * W);
+    desc[t] = make_int2((int)s0, (int)(s1 - s0));
 }
 
 // (index, value) of the user rows interleaved as 8-byte pairs: one coalesced 8-byte load
@@ -89,13 +93,15 @@ __global__ void iknn_pack_kernel(const int32_t *__restrict__ idx, const float *_
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz;
          e += (int64_t)gridDim.x * blockDim.x)
         pack[e] = make_int2(idx[e], __builtin_bit_cast(int, val[e]));
+    // 64 entries of padding: slice loads are issued for all 64 lanes unconditionally
+    if (blockIdx.x == 0 && threadIdx.x < 64) pack[nnz + threadIdx.x] = make_int2(0, 0);
 }
 
 template <bool IS64, bool FILL>
 __global__ __launch_bounds__(256) void iknn_build_kernel(
     const typename IndPtr<IS64>::type *__restrict__ ui_ptr, const int2 *__restrict__ ui_pack,
     const typename IndPtr<IS64>::type *__restrict__ iu_ptr, const int32_t *__restrict__ iu_idx,
-    const float *__restrict__ iu_val, const int32_t *__restrict__ seg,
+    const float *__restrict__ iu_val, const int2 *__restrict__ desc,
     const int32_t *__restrict__ tasks, int64_t n_btasks, int64_t n_items, int P, int Q, int W,
     float min_sim, int32_t *__restrict__ task_cnt,
     const int64_t *__restrict__ task_off, int32_t *__restrict__ out_idx,
@@ -121,86 +127,93 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
         const int64_t rb = iu_ptr[row], re = iu_ptr[row + 1];
 
         // ---- accumulate: users of `row` in ascending order -----------------
-        // Per user: one coalesced read of the slice (prefetched RING users ahead), one
-        // v_mul (rounded product) and one LDS float atomic (ds_add_f32, fire-and-forget):
-        // the LDS unit applies a wave's instructions in issue order and the lanes of one
-        // instruction hit distinct columns, so every cell still receives its terms in
-        // ascending-user order, each as round(round(r*v) + acc) -- the reference's
-        // arithmetic -- while the wave never waits for an LDS round trip.
+        // Per user: one coalesced 8-byte-per-lane read of the slice (scalar base + lane
+        // offset, prefetched RING users ahead through a register ring), one v_mul (rounded
+        // product) and one LDS float atomic (ds_add_f32, fire-and-forget): the LDS unit
+        // applies a wave's instructions in issue order and the lanes of one instruction hit
+        // distinct columns, so every cell still receives its terms in ascending-user order,
+        // each as round(round(r*v) + acc) -- the reference's arithmetic.  A batch of 64 users
+        // is one fully unrolled straight-line body (early exit every RING users): with a
+        // loop-carried ring the compiler drains the memory queue at every loop head, and at
+        // one wave per SIMD every branch and dependent scalar is fully exposed, so the body
+        // is kept to ~15 instructions per user.
+        // The (user, weight) stream of the row and the slice descriptors are fetched TWO and
+        // ONE batch ahead (user ids -> descriptor gather -> slices is a chain of three
+        // dependent memory round trips; at one wave per SIMD nothing else would hide it).
+        auto load_users = [&](int64_t b, int &u, float &r) {
+            u = 0;
+            r = 0.f;
+            if (b + lane < re) {
+                u = iu_idx[b + lane];
+                r = iu_val[b + lane];
+            }
+        };
+        auto load_desc = [&](int64_t b, int u) -> int2 {
+            return (b + lane < re) ? desc[(int64_t)u * P + p] : make_int2(0, 0);
+        };
+        int u1, u2;
+        float r0, r1, r2;
+        int2 d0, d1;
+        {
+            int u0;
+            load_users(rb, u0, r0);
+            load_users(rb + 64, u1, r1);
+            d0 = load_desc(rb, u0);
+        }
         for (int64_t base = rb; base < re; base += 64) {
             const int nb = (re - base) < 64 ? (int)(re - base) : 64;
-            unsigned my_beg_lo = 0, my_beg_hi = 0;
-            int my_len = 0;
-            float my_r = 0.f;
-            if (lane < nb) {
-                const int u = iu_idx[base + lane];
-                my_r = iu_val[base + lane];
-                const int s0 = seg[(int64_t)u * (P + 1) + p];
-                const int s1 = seg[(int64_t)u * (P + 1) + p + 1];
-                const int64_t b = (int64_t)ui_ptr[u] + s0;
-                my_beg_lo = (unsigned)b;
-                my_beg_hi = (unsigned)(b >> 32);
-                my_len = s1 - s0;
-            }
+            d1 = load_desc(base + 64, u1);       // next batch's descriptors
+            load_users(base + 128, u2, r2);      // the batch after that
+            const int my_beg = d0.x, my_len = d0.y;
+            const float my_r = r0;
             constexpr int RING = LK_IKNN_RING;
-            int rj[RING];
-            float rv[RING];
-            // wave-uniform lane reads (v_readlane -> SGPR): no LDS traffic, scalar branches
-            auto slice_beg = [&](int k) -> int64_t {
-                const unsigned lo = __builtin_amdgcn_readlane(my_beg_lo, k);
-                const unsigned hi = __builtin_amdgcn_readlane(my_beg_hi, k);
-                return (int64_t)(((unsigned long long)hi << 32) | lo);
-            };
-            // every ring load is UNCONDITIONAL (inactive lanes / users read entry 0 and are
-            // masked afterwards): loads inside branches make the compiler drain the whole
-            // memory queue (vmcnt(0)) at every user, which serialises the gathers
-            auto slot_load = [&](int q, int k) {
-                const int64_t b = slice_beg(k & 63);
-                const int l = (k < nb) ? __builtin_amdgcn_readlane(my_len, k & 63) : 0;
-                const bool on = lane < l;
-                const int64_t a = on ? b + lane : 0;
-                const int2 e = ui_pack[a];
-                rv[q] = __builtin_bit_cast(float, e.y);
-                rj[q] = on ? e.x : -1;
+            int2 ring[RING];
+            // lanes past the end of a slice re-read its last entry (same cache line: no
+            // extra memory request) and are masked at the atomic
+            auto slice_load = [&](int k) -> int2 {
+                const int2 *sp = ui_pack + __builtin_amdgcn_readlane(my_beg, k);
+                const int l1 = __builtin_amdgcn_readlane(my_len, k) - 1;
+                const int li = max(min(lane, l1), 0);
+                return sp[li];
             };
 #pragma unroll
-            for (int q = 0; q < RING; ++q) slot_load(q, q);
-            for (int k0 = 0; k0 < nb; k0 += RING) {
+            for (int q = 0; q < RING; ++q) ring[q] = slice_load(q);
 #pragma unroll
-                for (int q = 0; q < RING; ++q) {
-                    const int k = k0 + q;  // may run past nb: such users have an empty slice
-                    const int len = (k < nb) ? __builtin_amdgcn_readlane(my_len, k & 63) : 0;
-                    const float r = __builtin_bit_cast(
-                        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_r), k & 63));
-                    const int j = rj[q];
-                    const float v = rv[q];
-                    slot_load(q, k + RING);  // refill with user k + RING
-                    // `if other == row { continue }` (item_train.rs:120-122);
-                    // `dots[other] += r * orate` (item_train.rs:128)
-                    if (j >= 0 && j != row) {
-                        float prod = r * v;
-                        asm volatile("" : "+v"(prod));  // keep the rounded product
-                        (void)__hip_atomic_fetch_add(&acc[j - c_lo], prod, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    }
-                    if (len > 64) {  // the rest of a long slice (rare)
-                        const int64_t beg = slice_beg(k & 63);
-                        for (int off = 64; off < len; off += 64) {
-                            if (off + lane < len) {
-                                const int2 e2 = ui_pack[beg + off + lane];
-                                const int j2 = e2.x;
-                                if (j2 != row) {
-                                    float prod = r * __builtin_bit_cast(float, e2.y);
-                                    asm volatile("" : "+v"(prod));
-                                    (void)__hip_atomic_fetch_add(&acc[j2 - c_lo], prod,
-                                                                 __ATOMIC_RELAXED,
-                                                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                }
+            for (int k = 0; k < 64; ++k) {
+                if ((k % RING) == 0 && k >= nb) break;  // wave-uniform
+                const int len = __builtin_amdgcn_readlane(my_len, k);
+                const float r = __builtin_bit_cast(
+                    float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_r), k));
+                const int2 e = ring[k % RING];
+                if (k + RING < 64) ring[k % RING] = slice_load(k + RING);  // past the batch: 0/0
+                // `if other == row { continue }` (item_train.rs:120-122);
+                // `dots[other] += r * orate` (item_train.rs:128)
+                if (lane < len && e.x != row) {
+                    float prod = r * __builtin_bit_cast(float, e.y);
+                    asm volatile("" : "+v"(prod));  // keep the rounded product (no FMA)
+                    (void)__hip_atomic_fetch_add(&acc[e.x - c_lo], prod, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+                if (len > 64) {  // the rest of a long slice (rare)
+                    const int2 *sp = ui_pack + __builtin_amdgcn_readlane(my_beg, k);
+                    for (int off = 64; off < len; off += 64) {
+                        if (off + lane < len) {
+                            const int2 e2 = sp[off + lane];
+                            if (e2.x != row) {
+                                float prod = r * __builtin_bit_cast(float, e2.y);
+                                asm volatile("" : "+v"(prod));
+                                (void)__hip_atomic_fetch_add(&acc[e2.x - c_lo], prod,
+                                                             __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WAVEFRONT);
                             }
                         }
                     }
                 }
             }
+            d0 = d1;
+            r0 = r1;
+            u1 = u2;
+            r1 = r2;
         }
 
         // ---- extract: survivors in column order, clear the window -----------
@@ -296,6 +309,7 @@ extern "C" int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr,
     p->nnz = indptr_is_64 ? static_cast<const int64_t *>(h_ui_indptr)[n_users]
                           : (int64_t) static_cast<const int32_t *>(h_ui_indptr)[n_users];
     LK_REQUIRE(p->n_tasks < (int64_t)INT32_MAX, "lk_iknn_plan_create: too many tasks");
+    LK_REQUIRE(p->nnz < (int64_t)INT32_MAX - 64, "lk_iknn_plan_create: nnz >= 2^31 unsupported");
 
     auto len = [&](int64_t r) -> int64_t {
         if (indptr_is_64) {
@@ -328,9 +342,9 @@ extern "C" int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr,
     }
     size_t off = 0;
     p->off_pack = off;
-    off += lk::align_up((size_t)std::max<int64_t>(p->nnz, 1) * sizeof(int2), 256);
+    off += lk::align_up((size_t)(std::max<int64_t>(p->nnz, 1) + 64) * sizeof(int2), 256);
     p->off_seg = off;
-    off += lk::align_up((size_t)std::max<int64_t>(n_users, 1) * (p->P + 1) * sizeof(int32_t), 256);
+    off += lk::align_up((size_t)std::max<int64_t>(n_users, 1) * p->P * sizeof(int2), 256);
     p->off_cnt = off;
     off += lk::align_up((size_t)(p->n_tasks + 1) * sizeof(int32_t), 256);
     p->off_off = off;
@@ -361,19 +375,18 @@ static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t 
                        float *out_val, hipStream_t st)
 {
     using IT = typename IndPtr<IS64>::type;
-    int32_t *seg = reinterpret_cast<int32_t *>(ws + p->off_seg);
+    int2 *desc = reinterpret_cast<int2 *>(ws + p->off_seg);
     int2 *pack = reinterpret_cast<int2 *>(ws + p->off_pack);
     int32_t *cnt = reinterpret_cast<int32_t *>(ws + p->off_cnt);
     int64_t *off = reinterpret_cast<int64_t *>(ws + p->off_off);
     if (p->n_tasks == 0) return LK_OK;
     if (!FILL) {
-        const int64_t nseg = p->n_users * (p->P + 1);
-        if (nseg > 0)
-            hipLaunchKernelGGL((iknn_seg_kernel<IS64>), dim3((unsigned)((nseg + 255) / 256)),
+        const int64_t nd = p->n_users * p->P;
+        if (nd > 0)
+            hipLaunchKernelGGL((iknn_desc_kernel<IS64>), dim3((unsigned)((nd + 255) / 256)),
                                dim3(256), 0, st, static_cast<const IT *>(ui_ptr), ui_idx,
-                               p->n_users, p->P, p->W, seg);
-        if (p->nnz > 0)
-            hipLaunchKernelGGL(iknn_pack_kernel, dim3(2048), dim3(256), 0, st, ui_idx, ui_val,
+                               p->n_users, p->P, p->W, desc);
+        hipLaunchKernelGGL(iknn_pack_kernel, dim3(2048), dim3(256), 0, st, ui_idx, ui_val,
                                p->nnz, pack);
     }
     const size_t lds = (size_t)4 * p->W * sizeof(float);
@@ -385,7 +398,7 @@ static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t 
     int64_t blocks = std::min<int64_t>(p->n_btasks, (int64_t)256 * per_cu);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st,
                        static_cast<const IT *>(ui_ptr), pack, static_cast<const IT *>(iu_ptr),
-                       iu_idx, iu_val, seg, p->d_task, p->n_btasks, p->n_items, p->P, p->Q, p->W,
+                       iu_idx, iu_val, desc, p->d_task, p->n_btasks, p->n_items, p->P, p->Q, p->W,
                        min_sim, cnt, off, out_idx, out_val);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
