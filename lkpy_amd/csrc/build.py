@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 OUT = HERE.parent / "_lkamd.so"
 OBJ = HERE / "_obj"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall",
+FLAGS = [*os.environ.get("LK_EXTRA_FLAGS", "").split(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function"]
 
 

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     float *acc = lds_acc + (size_t)wave * W;
+    int *scr = reinterpret_cast<int *>(lds_acc + (size_t)4 * W) + wave * 256;  // chunk list scratch
     for (int c = lane; c < W; c += 64) acc[c] = 0.f;
 
     // a workgroup takes one row and four ADJACENT windows (wave w -> window 4*quad + w):
@@ -164,49 +165,67 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
             const int nb = (re - base) < 64 ? (int)(re - base) : 64;
             d1 = load_desc(base + 64, u1);       // next batch's descriptors
             load_users(base + 128, u2, r2);      // the batch after that
-            const int my_beg = d0.x, my_len = d0.y;
-            const float my_r = r0;
-            constexpr int RING = LK_IKNN_RING;
-            int2 ring[RING];
-            // lanes past the end of a slice re-read its last entry (same cache line: no
-            // extra memory request) and are masked at the atomic
-            auto slice_load = [&](int k) -> int2 {
-                const int2 *sp = ui_pack + __builtin_amdgcn_readlane(my_beg, k);
-                const int l1 = __builtin_amdgcn_readlane(my_len, k) - 1;
-                const int li = max(min(lane, l1), 0);
-                return sp[li];
-            };
+            // A user's slice is cut into CHUNKS of <= 64 entries and the chunks of the whole
+            // batch (empty slices contribute none) become the work list: every load of the
+            // pipeline below is one chunk, so long slices (heavy users -- most of the work:
+            // the visit-weighted mean slice has 68 entries) are prefetched like short ones.
+            // Chunk t belongs to the first user whose inclusive chunk count exceeds t.
+            {
+                const int ulen = d0.y;
+                int incl = (ulen + 63) >> 6;
 #pragma unroll
-            for (int q = 0; q < RING; ++q) ring[q] = slice_load(q);
-#pragma unroll
-            for (int k = 0; k < 64; ++k) {
-                if ((k % RING) == 0 && k >= nb) break;  // wave-uniform
-                const int len = __builtin_amdgcn_readlane(my_len, k);
-                const float r = __builtin_bit_cast(
-                    float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_r), k));
-                const int2 e = ring[k % RING];
-                if (k + RING < 64) ring[k % RING] = slice_load(k + RING);  // past the batch: 0/0
-                // `if other == row { continue }` (item_train.rs:120-122);
-                // `dots[other] += r * orate` (item_train.rs:128)
-                if (lane < len && e.x != row) {
-                    float prod = r * __builtin_bit_cast(float, e.y);
-                    asm volatile("" : "+v"(prod));  // keep the rounded product (no FMA)
-                    (void)__hip_atomic_fetch_add(&acc[e.x - c_lo], prod, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int y = __shfl_up(incl, d);
+                    if (lane >= d) incl += y;
                 }
-                if (len > 64) {  // the rest of a long slice (rare)
+                scr[lane] = incl;
+                scr[64 + lane] = d0.x;
+                scr[128 + lane] = ulen;
+                scr[192 + lane] = __builtin_bit_cast(int, r0);
+            }
+            const int T = scr[63];
+            for (int t0 = 0; t0 < T; t0 += 64) {
+                const int t = t0 + lane;
+                int my_beg = 0, my_len = 0;
+                float my_r = 0.f;
+                if (t < T) {
+                    int o = 0;
+#pragma unroll
+                    for (int step = 32; step; step >>= 1)
+                        if (scr[o + step - 1] <= t) o += step;
+                    const int ul = scr[128 + o];
+                    const int j = t - (scr[o] - ((ul + 63) >> 6));
+                    my_beg = scr[64 + o] + 64 * j;
+                    my_len = min(64, ul - 64 * j);
+                    my_r = __builtin_bit_cast(float, scr[192 + o]);
+                }
+                const int nbc = min(64, T - t0);
+                constexpr int RING = LK_IKNN_RING;
+                int2 ring[RING];
+                // lanes past the end of a slice re-read its last entry (same cache line: no
+                // extra memory request) and are masked at the update
+                auto slice_load = [&](int k) -> int2 {
                     const int2 *sp = ui_pack + __builtin_amdgcn_readlane(my_beg, k);
-                    for (int off = 64; off < len; off += 64) {
-                        if (off + lane < len) {
-                            const int2 e2 = sp[off + lane];
-                            if (e2.x != row) {
-                                float prod = r * __builtin_bit_cast(float, e2.y);
-                                asm volatile("" : "+v"(prod));
-                                (void)__hip_atomic_fetch_add(&acc[e2.x - c_lo], prod,
-                                                             __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            }
-                        }
+                    const int l1 = __builtin_amdgcn_readlane(my_len, k) - 1;
+                    const int li = max(min(lane, l1), 0);
+                    return sp[li];
+                };
+#pragma unroll
+                for (int q = 0; q < RING; ++q) ring[q] = slice_load(q);
+#pragma unroll
+                for (int k = 0; k < 64; ++k) {
+                    if ((k % RING) == 0 && k >= nbc) break;  // wave-uniform
+                    const int len = __builtin_amdgcn_readlane(my_len, k);
+                    const float r = __builtin_bit_cast(
+                        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_r), k));
+                    const int2 e = ring[k % RING];
+                    if (k + RING < 64) ring[k % RING] = slice_load(k + RING);  // past the batch: 0/0
+                    // `if other == row { continue }` (item_train.rs:120-122);
+                    // `dots[other] += r * orate` (item_train.rs:128)
+                    if (lane < len && e.x != row) {
+                        float prod = r * __builtin_bit_cast(float, e.y);
+                        asm volatile("" : "+v"(prod));  // keep the rounded product (no FMA)
+                        acc[e.x - c_lo] += prod;
                     }
                 }
             }
@@ -389,7 +408,7 @@ static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t 
         hipLaunchKernelGGL(iknn_pack_kernel, dim3(2048), dim3(256), 0, st, ui_idx, ui_val,
                                p->nnz, pack);
     }
-    const size_t lds = (size_t)4 * p->W * sizeof(float);
+    const size_t lds = (size_t)4 * p->W * sizeof(float) + 4 * 256 * sizeof(int);
     auto kern = iknn_build_kernel<IS64, FILL>;
     LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
