@@ -11,27 +11,31 @@
 // products round(a_ui*a_uj) in ascending-user order (item_train.rs:112-129, Rust does
 // not contract to FMA).  Here ONE WAVE owns a task (row i, column window p) and
 // walks the users of i sequentially, applying each user's items in parallel (they
-// are distinct columns, so there is no intra-instruction conflict); products use
-// __fmul_rn / __fadd_rn.  The accumulation order of every cell is therefore the
-// reference's, independent of scheduling.
+// are distinct columns, so there is no intra-instruction conflict) as a rounded
+// v_mul followed by an LDS read / v_add / write; FMA contraction is switched off.
+// The accumulation order of every cell is therefore the reference's, independent of
+// scheduling.  (LDS float atomics would also be in order, but ds_add_f32 retires
+// ~1 lane per 3 cycles per CU on gfx950 -- tools/ub/lds_atomic.hip -- 30x slower.)
 //
 // Data layout.  Each wave keeps a dense f32 accumulator for a window of W columns in
-// its private quarter of the workgroup's LDS (W = 8192 -> 128 KiB per workgroup, one
-// workgroup per CU).  A row needs P = ceil(n_items / W) tasks.  A small table
-// seg[u][p] (first entry of user u's row with column >= p*W, built once by binary
-// search) lets a task touch only the slice of each user's list that falls into its
-// window.  The (user, weight) stream of item i and the slice bounds are read 64 users
-// at a time (coalesced / gathered once), the slices themselves coalesced, with the
-// next user's slice prefetched while the current one is applied.
+// its private quarter of the workgroup's LDS (W = 4096 -> 64 KiB per workgroup, two
+// workgroups = 8 waves per CU).  A row needs P = ceil(n_items / W) tasks.  A table
+// desc[u][p] = {first entry, length} of the slice of user u's row that falls into
+// window p (built once by binary search) lets a task touch only that slice.  The
+// (user, weight) stream of item i and the descriptors are read 64 users at a time,
+// two / one batch ahead.  The slices of a batch are cut into CHUNKS of <= 64 entries
+// (empty slices vanish, long slices of heavy users become several chunks) and the
+// chunk list is walked with RING chunk loads in flight.
 //
 // Output is produced in two passes over the same kernel (the size is data
 // dependent): COUNT stores the survivors of each task, an exclusive scan turns them
 // into output offsets (windows of a row are consecutive, so rows come out sorted by
 // column), FILL recomputes and writes (column, value).
 //
-// Roofline: LDS read-modify-write bound; algorithmic bytes per product = 8 (the
-// expanded (index, value) stream) -- macs = sum_u n_u^2.
+// Roofline: HBM/L2 gather bound; algorithmic bytes per product = 8 (the expanded
+// (index, value) stream) -- macs = sum_u n_u^2.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -39,7 +43,7 @@
 // never contract mul+add into FMA in this file: bit parity with the reference
 #pragma clang fp contract(off)
 
-#define LK_IKNN_W 8192
+#define LK_IKNN_W 4096  // columns per LDS window (env LK_IKNN_W: smaller, for experiments)
 #ifndef LK_IKNN_RING
 #define LK_IKNN_RING 8
 #endif
@@ -117,6 +121,7 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
     // a workgroup takes one row and four ADJACENT windows (wave w -> window 4*quad + w):
     // the four waves walk the same users, so the adjacent slices they read share cache
     // lines in L1/L2
+    // (`tasks` is dealt to the workgroups serpentine, heavy rows first: see plan_create)
     for (int64_t bt = blockIdx.x; bt < n_btasks; bt += gridDim.x) {
         const int code = tasks[bt];
         const int row = code / Q;
@@ -128,19 +133,17 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
         const int64_t rb = iu_ptr[row], re = iu_ptr[row + 1];
 
         // ---- accumulate: users of `row` in ascending order -----------------
-        // Per user: one coalesced 8-byte-per-lane read of the slice (scalar base + lane
-        // offset, prefetched RING users ahead through a register ring), one v_mul (rounded
-        // product) and one LDS float atomic (ds_add_f32, fire-and-forget): the LDS unit
-        // applies a wave's instructions in issue order and the lanes of one instruction hit
-        // distinct columns, so every cell still receives its terms in ascending-user order,
-        // each as round(round(r*v) + acc) -- the reference's arithmetic.  A batch of 64 users
-        // is one fully unrolled straight-line body (early exit every RING users): with a
-        // loop-carried ring the compiler drains the memory queue at every loop head, and at
-        // one wave per SIMD every branch and dependent scalar is fully exposed, so the body
-        // is kept to ~15 instructions per user.
+        // Per chunk: one coalesced 8-byte-per-lane read (scalar base + lane offset,
+        // prefetched RING chunks ahead through a register ring), one v_mul (rounded
+        // product) and an LDS read / v_add / write of the lanes' distinct columns; a wave's
+        // LDS operations complete in issue order, so every cell receives its terms in
+        // ascending-user order, each as round(round(r*v) + acc) -- the reference's
+        // arithmetic.  64 chunks are one fully unrolled straight-line body (early exit
+        // every RING chunks): with a loop-carried ring the compiler drains the memory
+        // queue at every loop head.
         // The (user, weight) stream of the row and the slice descriptors are fetched TWO and
         // ONE batch ahead (user ids -> descriptor gather -> slices is a chain of three
-        // dependent memory round trips; at one wave per SIMD nothing else would hide it).
+        // dependent memory round trips).
         auto load_users = [&](int64_t b, int &u, float &r) {
             u = 0;
             r = 0.f;
@@ -162,7 +165,6 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
             d0 = load_desc(rb, u0);
         }
         for (int64_t base = rb; base < re; base += 64) {
-            const int nb = (re - base) < 64 ? (int)(re - base) : 64;
             d1 = load_desc(base + 64, u1);       // next batch's descriptors
             load_users(base + 128, u2, r2);      // the batch after that
             // A user's slice is cut into CHUNKS of <= 64 entries and the chunks of the whole
@@ -304,6 +306,13 @@ __global__ void iknn_indptr_kernel(const int64_t *__restrict__ task_off, int64_t
     if (r <= n_items) out_indptr[r] = task_off[r * P];
 }
 
+// one resident workgroup per CU at W = 8192 (128 KiB of LDS); more for small windows
+static size_t iknn_lds_bytes(int W) { return (size_t)4 * W * sizeof(float) + 4 * 256 * sizeof(int); }
+static int64_t iknn_grid(int W)
+{
+    return 256 * (int64_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / iknn_lds_bytes(W)));
+}
+
 }  // namespace lk
 
 extern "C" int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr,
@@ -319,6 +328,10 @@ extern "C" int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr,
     p->n_items = n_items;
     p->is64 = indptr_is_64 ? 1 : 0;
     int64_t W = LK_IKNN_W;
+    if (const char *env = getenv("LK_IKNN_W")) {  // tuning knob: columns per LDS window
+        const long v = atol(env);
+        if (v >= 64 && v <= LK_IKNN_W) W = v / 64 * 64;
+    }
     if (n_items < W) W = std::max<int64_t>(64, (n_items + 63) / 64 * 64);
     p->W = (int32_t)W;
     p->P = (int32_t)std::max<int64_t>(1, (n_items + W - 1) / W);
@@ -342,10 +355,16 @@ extern "C" int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr,
     for (int64_t r = 0; r < n_items; ++r) rows[(size_t)r] = (int32_t)r;
     std::stable_sort(rows.begin(), rows.end(),
                      [&](int32_t a, int32_t b) { return len(a) > len(b); });
+    // Workgroup b of G takes tasks b, b+G, b+2G, ...: deal the weight-sorted list
+    // serpentine (every other round reversed) so the per-workgroup totals stay level.
     std::vector<int32_t> tasks((size_t)p->n_btasks);
-    size_t q = 0;
-    for (int64_t r = 0; r < n_items; ++r)
-        for (int w = 0; w < p->Q; ++w) tasks[q++] = rows[(size_t)r] * p->Q + w;
+    const int64_t G = std::max<int64_t>(1, std::min<int64_t>(p->n_btasks, lk::iknn_grid(p->W)));
+    for (int64_t i = 0; i < p->n_btasks; ++i) {
+        const int64_t round = i / G, pos = i - round * G;
+        const int64_t cnt_in_round = std::min<int64_t>(G, p->n_btasks - round * G);
+        const int64_t src = round * G + ((round & 1) ? cnt_in_round - 1 - pos : pos);
+        tasks[(size_t)i] = rows[(size_t)(src / p->Q)] * p->Q + (int32_t)(src % p->Q);
+    }
     size_t bytes = std::max<size_t>(tasks.size(), 1) * sizeof(int32_t);
     if (hipMalloc(reinterpret_cast<void **>(&p->d_task), bytes) != hipSuccess) {
         delete p;
@@ -408,13 +427,11 @@ static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t 
         hipLaunchKernelGGL(iknn_pack_kernel, dim3(2048), dim3(256), 0, st, ui_idx, ui_val,
                                p->nnz, pack);
     }
-    const size_t lds = (size_t)4 * p->W * sizeof(float) + 4 * 256 * sizeof(int);
+    const size_t lds = iknn_lds_bytes(p->W);
     auto kern = iknn_build_kernel<IS64, FILL>;
     LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // one resident workgroup per CU at W = 8192 (128 KiB of LDS); more for small windows
-    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
-    int64_t blocks = std::min<int64_t>(p->n_btasks, (int64_t)256 * per_cu);
+    int64_t blocks = std::min<int64_t>(p->n_btasks, iknn_grid(p->W));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st,
                        static_cast<const IT *>(ui_ptr), pack, static_cast<const IT *>(iu_ptr),
                        iu_idx, iu_val, desc, p->d_task, p->n_btasks, p->n_items, p->P, p->Q, p->W,
