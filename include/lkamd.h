@@ -144,6 +144,11 @@ int lk_als_implicit_half_epoch_host(const void *h_indptr, int indptr_is_64,
  *   lk_iknn_build_count  -> fills d_out_indptr (n_items+1, int64, exclusive scan)
  *                           and returns the total through *h_total_nnz (blocking);
  *   lk_iknn_build_fill   -> writes d_out_indices / d_out_values.
+ * Both calls take the SAME workspace (it carries the per-task counts / offsets
+ * between them).  When n_items^2 (index, value) pairs fit comfortably in free HBM
+ * (cap: env LK_IKNN_STAGE_GB, default 64) the plan reserves a staging area in the
+ * workspace: the count call then does the whole computation once and the fill call
+ * only compacts; otherwise each call is a full pass over the data.
  * ---------------------------------------------------------------------- */
 typedef struct lk_iknn_plan lk_iknn_plan;
 int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr, const void *h_iu_indptr,

@@ -59,5 +59,5 @@ def run(ratings: sps.csr_array, dev, reps: int = 2) -> dict:
         "nnz_out": int(out.indices.shape[0]),
         "macs": macs,
         "gmacs_per_s": round(macs / best / 1e9, 2),
-        "note": "two passes (count + fill) over CSR resident in HBM; output left in HBM",
+        "note": "one compute pass into an n_items^2 staging area + compaction; CSR resident in HBM, output left in HBM",
     }

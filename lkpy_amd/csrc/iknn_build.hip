@@ -27,10 +27,12 @@
 // (empty slices vanish, long slices of heavy users become several chunks) and the
 // chunk list is walked with RING chunk loads in flight.
 //
-// Output is produced in two passes over the same kernel (the size is data
-// dependent): COUNT stores the survivors of each task, an exclusive scan turns them
-// into output offsets (windows of a row are consecutive, so rows come out sorted by
-// column), FILL recomputes and writes (column, value).
+// The output size is data dependent.  With room for n_items^2 (index, value) pairs
+// in free HBM (the common case on a 288 GB part: 31 GB for 62k items) ONE pass writes
+// each task's survivors compacted at staging[row * n_items + p * W] and counts them;
+// an exclusive scan turns the counts into offsets (windows of a row are consecutive,
+// so rows come out sorted by column) and iknn_unstage_kernel copies them into place.
+// Otherwise the same kernel runs twice: COUNT, scan, then WRITE at the offsets.
 //
 // Roofline: HBM/L2 gather bound; algorithmic bytes per product = 8 (the expanded
 // (index, value) stream) -- macs = sum_u n_u^2.
@@ -58,6 +60,9 @@ struct lk_iknn_plan {
     int64_t nnz = 0;
     int32_t *d_task = nullptr;  // [n_btasks] row*Q + quad, heavy rows first
     size_t off_pack = 0, off_seg = 0, off_cnt = 0, off_off = 0, off_scan = 0, ws_bytes = 0;
+    // single-pass build through a dense-bound staging area (n_items^2 entries) when it fits
+    int32_t staged = 0;
+    size_t off_st_idx = 0, off_st_val = 0;
 };
 
 namespace lk {
@@ -101,7 +106,10 @@ __global__ void iknn_pack_kernel(const int32_t *__restrict__ idx, const float *_
     if (blockIdx.x == 0 && threadIdx.x < 64) pack[nnz + threadIdx.x] = make_int2(0, 0);
 }
 
-template <bool IS64, bool FILL>
+// WRITE: store the survivors (column, value); COUNT: store their number per task.
+// Two-pass build = (COUNT) then (WRITE at the scanned offsets); staged build = one
+// (WRITE + COUNT) pass into a row-strided staging area followed by iknn_unstage_kernel.
+template <bool IS64, bool WRITE, bool COUNT>
 __global__ __launch_bounds__(256) void iknn_build_kernel(
     const typename IndPtr<IS64>::type *__restrict__ ui_ptr, const int2 *__restrict__ ui_pack,
     const typename IndPtr<IS64>::type *__restrict__ iu_ptr, const int32_t *__restrict__ iu_idx,
@@ -238,7 +246,8 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
         }
 
         // ---- extract: survivors in column order, clear the window -----------
-        int64_t wpos = FILL ? task_off[task] : 0;
+        // staged: window p of row r is compacted at r * n_items + p * W
+        int64_t wpos = !WRITE ? 0 : COUNT ? (int64_t)row * n_items + c_lo : task_off[task];
         int count = 0;
         for (int c0 = 0; c0 < wlen; c0 += 64) {
             const int c = c0 + lane;
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
             }
             const bool keep = (c < wlen) && (s >= min_sim);  // item_train.rs:135
             const unsigned long long m = __ballot(keep);
-            if (FILL) {
+            if (WRITE) {
                 if (keep) {
                     const int rank = __builtin_amdgcn_mbcnt_hi(
                         (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
@@ -257,11 +266,10 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
                     out_val[wpos + rank] = s;
                 }
                 wpos += __popcll(m);
-            } else {
-                count += __popcll(m);
             }
+            if (COUNT) count += __popcll(m);
         }
-        if (!FILL && lane == 0) task_cnt[task] = count;
+        if (COUNT && lane == 0) task_cnt[task] = count;
     }
 }
 
@@ -304,6 +312,25 @@ __global__ void iknn_indptr_kernel(const int64_t *__restrict__ task_off, int64_t
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r <= n_items) out_indptr[r] = task_off[r * P];
+}
+
+// staged build: move the survivors of task t from the staging area to their final place
+// (one wave per task, coalesced)
+__global__ __launch_bounds__(256) void iknn_unstage_kernel(
+    const int32_t *__restrict__ task_cnt, const int64_t *__restrict__ task_off, int64_t n_tasks,
+    int64_t n_items, int P, int W, const int32_t *__restrict__ st_idx,
+    const float *__restrict__ st_val, int32_t *__restrict__ out_idx, float *__restrict__ out_val)
+{
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tasks) return;
+    const int lane = threadIdx.x & 63;
+    const int n = task_cnt[t];
+    const int64_t row = t / P;
+    const int64_t src = row * n_items + (t - row * P) * W, dst = task_off[t];
+    for (int e = lane; e < n; e += 64) {
+        out_idx[dst + e] = st_idx[src + e];
+        out_val[dst + e] = st_val[src + e];
+    }
 }
 
 // one resident workgroup per CU at W = 8192 (128 KiB of LDS); more for small windows
@@ -387,6 +414,22 @@ extern "C" int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr,
     off += lk::align_up((size_t)(p->n_tasks + 1) * sizeof(int32_t), 256);
     p->off_off = off;
     off += lk::align_up((size_t)(p->n_tasks + 1) * sizeof(int64_t), 256);
+    // 288 GB of HBM: when n_items^2 (index, value) pairs fit comfortably, every task writes
+    // its survivors straight into a row-strided staging area in ONE pass over the data and
+    // a copy kernel compacts them; otherwise count and fill are two full passes.
+    {
+        const size_t stage = (size_t)n_items * (size_t)n_items * sizeof(int32_t);
+        size_t cap = (size_t)64 << 30, free_b = 0, total_b = 0;
+        if (const char *env = getenv("LK_IKNN_STAGE_GB")) cap = (size_t)atol(env) << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap = std::min(cap, free_b / 3);
+        if (n_items > 0 && 2 * stage <= cap) {
+            p->staged = 1;
+            p->off_st_idx = off;
+            off += lk::align_up(stage, 256);
+            p->off_st_val = off;
+            off += lk::align_up(stage, 256);
+        }
+    }
     p->ws_bytes = off;
     *out = p;
     return LK_OK;
@@ -406,7 +449,7 @@ extern "C" size_t lk_iknn_plan_workspace_bytes(const lk_iknn_plan *p)
 
 namespace lk {
 
-template <bool IS64, bool FILL>
+template <bool IS64, bool WRITE, bool COUNT>
 static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t *ui_idx,
                        const float *ui_val, const void *iu_ptr, const int32_t *iu_idx,
                        const float *iu_val, float min_sim, char *ws, int32_t *out_idx,
@@ -418,7 +461,7 @@ static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t 
     int32_t *cnt = reinterpret_cast<int32_t *>(ws + p->off_cnt);
     int64_t *off = reinterpret_cast<int64_t *>(ws + p->off_off);
     if (p->n_tasks == 0) return LK_OK;
-    if (!FILL) {
+    if (COUNT) {
         const int64_t nd = p->n_users * p->P;
         if (nd > 0)
             hipLaunchKernelGGL((iknn_desc_kernel<IS64>), dim3((unsigned)((nd + 255) / 256)),
@@ -428,7 +471,7 @@ static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t 
                                p->nnz, pack);
     }
     const size_t lds = iknn_lds_bytes(p->W);
-    auto kern = iknn_build_kernel<IS64, FILL>;
+    auto kern = iknn_build_kernel<IS64, WRITE, COUNT>;
     LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t blocks = std::min<int64_t>(p->n_btasks, iknn_grid(p->W));
@@ -474,12 +517,18 @@ extern "C" int lk_iknn_build_count(const lk_iknn_plan *plan, const void *d_ui_in
         *h_total_nnz = 0;
         return LK_OK;
     }
-    rc = plan->is64 ? lk::launch_iknn<true, false>(plan, d_ui_indptr, d_ui_indices, d_ui_values,
-                                                  d_iu_indptr, d_iu_indices, d_iu_values,
-                                                  min_sim, ws, nullptr, nullptr, st)
-                    : lk::launch_iknn<false, false>(plan, d_ui_indptr, d_ui_indices, d_ui_values,
-                                                   d_iu_indptr, d_iu_indices, d_iu_values,
-                                                   min_sim, ws, nullptr, nullptr, st);
+    {
+        const void *up = d_ui_indptr, *ip = d_iu_indptr;
+        int32_t *si = plan->staged ? reinterpret_cast<int32_t *>(ws + plan->off_st_idx) : nullptr;
+        float *sv = plan->staged ? reinterpret_cast<float *>(ws + plan->off_st_val) : nullptr;
+#define LK_IKNN_LAUNCH(IS64, WRITE)                                                          \
+    lk::launch_iknn<IS64, WRITE, true>(plan, up, d_ui_indices, d_ui_values, ip, d_iu_indices, \
+                                       d_iu_values, min_sim, ws, si, sv, st)
+        rc = plan->staged ? (plan->is64 ? LK_IKNN_LAUNCH(true, true) : LK_IKNN_LAUNCH(false, true))
+                          : (plan->is64 ? LK_IKNN_LAUNCH(true, false)
+                                        : LK_IKNN_LAUNCH(false, false));
+#undef LK_IKNN_LAUNCH
+    }
     if (rc != LK_OK) return rc;
     hipLaunchKernelGGL(lk::iknn_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, plan->n_tasks, off);
     hipLaunchKernelGGL(lk::iknn_indptr_kernel, dim3((unsigned)((plan->n_items + 256) / 256)),
@@ -505,11 +554,23 @@ extern "C" int lk_iknn_build_fill(const lk_iknn_plan *plan, const void *d_ui_ind
     // d_out_indices / d_out_values may be null when the count pass found nothing
     hipStream_t st = lk::as_stream(stream);
     char *ws = static_cast<char *>(d_ws);
-    return plan->is64 ? lk::launch_iknn<true, true>(plan, d_ui_indptr, d_ui_indices, d_ui_values,
-                                                   d_iu_indptr, d_iu_indices, d_iu_values,
-                                                   min_sim, ws, d_out_indices, d_out_values, st)
-                      : lk::launch_iknn<false, true>(plan, d_ui_indptr, d_ui_indices,
-                                                     d_ui_values, d_iu_indptr, d_iu_indices,
-                                                     d_iu_values, min_sim, ws, d_out_indices,
-                                                     d_out_values, st);
+    if (plan->staged) {  // the count call already computed everything: compact the staging area
+        if (!d_out_indices || !d_out_values) return LK_OK;  // nothing survived
+        hipLaunchKernelGGL(lk::iknn_unstage_kernel, dim3((unsigned)((plan->n_tasks + 3) / 4)),
+                           dim3(256), 0, st, reinterpret_cast<const int32_t *>(ws + plan->off_cnt),
+                           reinterpret_cast<const int64_t *>(ws + plan->off_off), plan->n_tasks,
+                           plan->n_items, plan->P, plan->W,
+                           reinterpret_cast<const int32_t *>(ws + plan->off_st_idx),
+                           reinterpret_cast<const float *>(ws + plan->off_st_val), d_out_indices,
+                           d_out_values);
+        LK_HIP_CHECK(hipGetLastError());
+        return LK_OK;
+    }
+    return plan->is64
+               ? lk::launch_iknn<true, true, false>(plan, d_ui_indptr, d_ui_indices, d_ui_values,
+                                                    d_iu_indptr, d_iu_indices, d_iu_values,
+                                                    min_sim, ws, d_out_indices, d_out_values, st)
+               : lk::launch_iknn<false, true, false>(plan, d_ui_indptr, d_ui_indices, d_ui_values,
+                                                     d_iu_indptr, d_iu_indices, d_iu_values,
+                                                     min_sim, ws, d_out_indices, d_out_values, st);
 }

@@ -59,6 +59,17 @@ def test_build_windows_and_edges(gpu, oracle, rng):
         _assert_same(got, want)
 
 
+def test_build_two_pass_fallback(gpu, oracle, ml_small, monkeypatch):
+    """Without room for the n_items^2 staging area the build runs as two full passes
+    (count, fill); same bits."""
+    from lkpy_amd import _device as D
+
+    monkeypatch.setenv("LK_IKNN_STAGE_GB", "0")
+    ui, iu, _means, _ = oracle.iknn_prepare(ml_small["rmat"], True)
+    want = oracle.iknn_build(ui, iu, 1.0e-6, None)
+    _assert_same(_build_gpu(D, gpu, ui, iu, 1.0e-6), want)
+
+
 def test_build_toy_closed_form(gpu, oracle):
     """The reference's 14-rating toy set: sim(6,7) equals the hand-computed centred
     cosine (tests/models/test_knn_item_item.py:106-162)."""
