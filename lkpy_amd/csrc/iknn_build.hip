@@ -106,10 +106,14 @@ __global__ void iknn_pack_kernel(const int32_t *__restrict__ idx, const float *_
     if (blockIdx.x == 0 && threadIdx.x < 64) pack[nnz + threadIdx.x] = make_int2(0, 0);
 }
 
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
 // WRITE: store the survivors (column, value); COUNT: store their number per task.
 // Two-pass build = (COUNT) then (WRITE at the scanned offsets); staged build = one
 // (WRITE + COUNT) pass into a row-strided staging area followed by iknn_unstage_kernel.
-template <bool IS64, bool WRITE, bool COUNT>
+// ADDR32: every byte offset into the packed user rows fits 32 bits (nnz < 2^29 - 64): a chunk
+// load is then `global_load v, voffset, s[pack]` with voffset = chunk offset + 8 * lane.
+template <bool IS64, bool WRITE, bool COUNT, bool ADDR32>
 __global__ __launch_bounds__(256) void iknn_build_kernel(
     const typename IndPtr<IS64>::type *__restrict__ ui_ptr, const int2 *__restrict__ ui_pack,
     const typename IndPtr<IS64>::type *__restrict__ iu_ptr, const int32_t *__restrict__ iu_idx,
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
             const int T = scr[63];
             for (int t0 = 0; t0 < T; t0 += 64) {
                 const int t = t0 + lane;
-                int my_beg = 0, my_len = 0;
+                int my_beg = 0, my_len = 0, my_l1 = 0;
                 float my_r = 0.f;
                 if (t < T) {
                     int o = 0;
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
                     const int j = t - (scr[o] - ((ul + 63) >> 6));
                     my_beg = scr[64 + o] + 64 * j;
                     my_len = min(64, ul - 64 * j);
+                    my_l1 = my_len - 1;  // chunks are never empty
                     my_r = __builtin_bit_cast(float, scr[192 + o]);
                 }
                 const int nbc = min(64, T - t0);
@@ -214,10 +219,19 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
                 int2 ring[RING];
                 // lanes past the end of a slice re-read its last entry (same cache line: no
                 // extra memory request) and are masked at the update
+                const uint32_t my_off8 = (uint32_t)my_beg << 3;  // ADDR32 only
                 auto slice_load = [&](int k) -> int2 {
+                    const uint32_t li =
+                        min((uint32_t)lane, (uint32_t)__builtin_amdgcn_readlane(my_l1, k));
+                    if (ADDR32) {
+                        typedef const __attribute__((address_space(1))) char *gptr;
+                        typedef const __attribute__((address_space(1))) i32x2 *gptr2;
+                        const uint32_t voff =
+                            (li << 3) + (uint32_t)__builtin_amdgcn_readlane((int)my_off8, k);
+                        const i32x2 v = *(gptr2)((gptr)ui_pack + voff);
+                        return make_int2(v.x, v.y);
+                    }
                     const int2 *sp = ui_pack + __builtin_amdgcn_readlane(my_beg, k);
-                    const int l1 = __builtin_amdgcn_readlane(my_len, k) - 1;
-                    const int li = max(min(lane, l1), 0);
                     return sp[li];
                 };
 #pragma unroll
@@ -232,7 +246,9 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
                     if (k + RING < 64) ring[k % RING] = slice_load(k + RING);  // past the batch: 0/0
                     // `if other == row { continue }` (item_train.rs:120-122);
                     // `dots[other] += r * orate` (item_train.rs:128)
-                    if (lane < len && e.x != row) {
+                    // the self pair (item_train.rs:120-122) is accumulated like any other and
+                    // dropped at extraction: no other cell sees it
+                    if (lane < len) {
                         float prod = r * __builtin_bit_cast(float, e.y);
                         asm volatile("" : "+v"(prod));  // keep the rounded product (no FMA)
                         acc[e.x - c_lo] += prod;
@@ -256,7 +272,8 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
                 s = acc[c];
                 acc[c] = 0.f;
             }
-            const bool keep = (c < wlen) && (s >= min_sim);  // item_train.rs:135
+            // item_train.rs:120-122 (no self similarity), :135 (threshold)
+            const bool keep = (c < wlen) && (c_lo + c != row) && (s >= min_sim);
             const unsigned long long m = __ballot(keep);
             if (WRITE) {
                 if (keep) {
@@ -471,7 +488,10 @@ static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t 
                                p->nnz, pack);
     }
     const size_t lds = iknn_lds_bytes(p->W);
-    auto kern = iknn_build_kernel<IS64, WRITE, COUNT>;
+    // (env LK_IKNN_ADDR64 forces the general addressing path: test hook)
+    const bool a32 = (p->nnz + 64) < ((int64_t)1 << 29) && !getenv("LK_IKNN_ADDR64");
+    auto kern = a32 ? iknn_build_kernel<IS64, WRITE, COUNT, true>
+                    : iknn_build_kernel<IS64, WRITE, COUNT, false>;
     LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t blocks = std::min<int64_t>(p->n_btasks, iknn_grid(p->W));

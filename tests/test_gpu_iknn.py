@@ -70,6 +70,16 @@ def test_build_two_pass_fallback(gpu, oracle, ml_small, monkeypatch):
     _assert_same(_build_gpu(D, gpu, ui, iu, 1.0e-6), want)
 
 
+def test_build_wide_addressing(gpu, oracle, ml_small, monkeypatch):
+    "The addressing path for nnz >= 2^29 (64-bit chunk addresses), forced on a small input."
+    from lkpy_amd import _device as D
+
+    monkeypatch.setenv("LK_IKNN_ADDR64", "1")
+    ui, iu, _means, _ = oracle.iknn_prepare(ml_small["rmat"], True)
+    want = oracle.iknn_build(ui, iu, 1.0e-6, None)
+    _assert_same(_build_gpu(D, gpu, ui, iu, 1.0e-6), want)
+
+
 def test_build_toy_closed_form(gpu, oracle):
     """The reference's 14-rating toy set: sim(6,7) equals the hand-computed centred
     cosine (tests/models/test_knn_item_item.py:106-162)."""
