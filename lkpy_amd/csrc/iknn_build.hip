@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
                 scr[128 + lane] = ulen;
                 scr[192 + lane] = __builtin_bit_cast(int, r0);
             }
-            const int T = scr[63];
+            const int T = __builtin_amdgcn_readfirstlane(scr[63]);
             for (int t0 = 0; t0 < T; t0 += 64) {
                 const int t = t0 + lane;
                 int my_beg = 0, my_len = 0, my_l1 = 0;
@@ -239,16 +239,16 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
 #pragma unroll
                 for (int k = 0; k < 64; ++k) {
                     if ((k % RING) == 0 && k >= nbc) break;  // wave-uniform
-                    const int len = __builtin_amdgcn_readlane(my_len, k);
                     const float r = __builtin_bit_cast(
                         float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_r), k));
                     const int2 e = ring[k % RING];
                     if (k + RING < 64) ring[k % RING] = slice_load(k + RING);  // past the batch: 0/0
-                    // `if other == row { continue }` (item_train.rs:120-122);
-                    // `dots[other] += r * orate` (item_train.rs:128)
-                    // the self pair (item_train.rs:120-122) is accumulated like any other and
-                    // dropped at extraction: no other cell sees it
-                    if (lane < len) {
+                    // `dots[other] += r * orate` (item_train.rs:128).  No lane mask: the lanes
+                    // past the end of the chunk hold copies of its last entry, so they read the
+                    // same cell, compute the same sum and store the same bits as the last real
+                    // lane.  The self pair (item_train.rs:120-122) is accumulated like any
+                    // other and dropped at extraction: no other cell sees it.
+                    if (k < nbc) {  // wave-uniform (scalar compare + branch)
                         float prod = r * __builtin_bit_cast(float, e.y);
                         asm volatile("" : "+v"(prod));  // keep the rounded product (no FMA)
                         acc[e.x - c_lo] += prod;
@@ -290,18 +290,23 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
     }
 }
 
-// exclusive scan of int32 counts into int64 offsets (n+1 outputs), one workgroup
+// exclusive scan of the int32 task counts into int64 offsets (n_rows*P + 1 outputs), one
+// workgroup; a thread takes one ROW (its P adjacent counts), so the serial loop runs over
+// n_rows / 1024 steps
 __global__ __launch_bounds__(1024) void iknn_scan_kernel(const int32_t *__restrict__ cnt,
-                                                        int64_t n, int64_t *__restrict__ off)
+                                                        int64_t n_rows, int P,
+                                                        int64_t *__restrict__ off)
 {
     __shared__ int64_t wsum[16];
     __shared__ int64_t carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int64_t base = 0; base < n; base += 1024) {
+    for (int64_t base = 0; base < n_rows; base += 1024) {
         const int64_t i = base + threadIdx.x;
-        const int64_t v = (i < n) ? (int64_t)cnt[i] : 0;
+        int64_t v = 0;
+        if (i < n_rows)
+            for (int q = 0; q < P; ++q) v += cnt[i * P + q];
         int64_t x = v;  // inclusive scan inside the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -313,12 +318,18 @@ __global__ __launch_bounds__(1024) void iknn_scan_kernel(const int32_t *__restri
         int64_t woff = 0;
         for (int w = 0; w < wave; ++w) woff += wsum[w];
         const int64_t carry = carry_s;
-        if (i < n) off[i] = carry + woff + x - v;
+        if (i < n_rows) {
+            int64_t run = carry + woff + x - v;
+            for (int q = 0; q < P; ++q) {
+                off[i * P + q] = run;
+                run += cnt[i * P + q];
+            }
+        }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = carry + woff + x;
         __syncthreads();
     }
-    if (threadIdx.x == 0) off[n] = carry_s;
+    if (threadIdx.x == 0) off[n_rows * P] = carry_s;
 }
 
 // counts / offsets are indexed by TASK ID = row*P + p (item order, windows of a row
@@ -550,7 +561,8 @@ extern "C" int lk_iknn_build_count(const lk_iknn_plan *plan, const void *d_ui_in
 #undef LK_IKNN_LAUNCH
     }
     if (rc != LK_OK) return rc;
-    hipLaunchKernelGGL(lk::iknn_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, plan->n_tasks, off);
+    hipLaunchKernelGGL(lk::iknn_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, plan->n_items,
+                       plan->P, off);
     hipLaunchKernelGGL(lk::iknn_indptr_kernel, dim3((unsigned)((plan->n_items + 256) / 256)),
                        dim3(256), 0, st, off, plan->n_items, plan->P, d_out_indptr);
     LK_HIP_CHECK(hipGetLastError());
