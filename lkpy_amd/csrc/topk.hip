@@ -28,7 +28,7 @@ namespace lk {
 
 constexpr int SC_UB = 64;   // users per block tile
 constexpr int SC_IB = 256;  // items per block tile
-constexpr int SC_KC = 64;   // features staged per pass
+constexpr int SC_KC = 32;   // features staged per pass (42 KiB of LDS: 3 workgroups per CU)
 constexpr int SC_LD = SC_KC + 1;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -123,22 +123,14 @@ __device__ __forceinline__ float key2f(unsigned k)
     return __builtin_bit_cast(float, u);
 }
 
-// One workgroup per row: indices of the n largest non-NaN scores, descending, ties by
-// lower index; rows with fewer than n candidates are padded with -1 / NaN.
-template <int MAXN>
-__global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__ scores,
-                                                       int64_t ld_s, int64_t row_len, int n,
-                                                       int32_t *__restrict__ out_idx,
-                                                       float *__restrict__ out_score,
-                                                       int64_t out_ld)
+// Radix-select path (any n <= MAXN, any row): MSB-first 8-bit radix select of the n-th
+// largest key, ties by lowest index, winners left UNSORTED in cand[0 .. count).
+__device__ __forceinline__ unsigned row_topn_radix(const float *__restrict__ row, int64_t row_len,
+                                                   int n, unsigned long long *cand)
 {
     __shared__ unsigned hist[256];
-    __shared__ unsigned long long cand[MAXN];
     __shared__ unsigned s_prefix, s_need, s_count, s_valid;
     const int tid = threadIdx.x;
-    const float *row = scores + (int64_t)blockIdx.x * ld_s;
-    int32_t *oidx = out_idx + (int64_t)blockIdx.x * out_ld;
-    float *osc = out_score ? out_score + (int64_t)blockIdx.x * out_ld : nullptr;
 
     if (tid == 0) {
         s_prefix = 0;
@@ -242,7 +234,95 @@ __global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__
         }
         __syncthreads();
     }
-    const unsigned m = s_count;  // == take
+    return s_count;  // == take
+}
+
+// One workgroup per row: indices of the n largest non-NaN scores, descending, ties by
+// lower index; rows with fewer than n candidates are padded with -1 / NaN.
+//
+// Fast path (n <= 256): every thread keeps the largest key of its strided share of the
+// row; the n-th largest of those 256 maxima is a lower bound tau of the n-th largest
+// entry (at least n entries are >= tau), typically passed by only a small multiple of n
+// entries.  A second sweep collects the entries >= tau (wave ballot + one LDS counter
+// update per wave), and the exact order (score desc, index asc) is settled by the same
+// bitonic sort as before.  No per-element LDS atomics: the radix histograms cost ~3 cycles
+// per element per CU.  Rows the bound cannot handle (fewer than n threads saw a valid
+// entry, or more than MAXN entries pass) take the radix path; results are identical.
+template <int MAXN>
+__global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__ scores,
+                                                       int64_t ld_s, int64_t row_len, int n,
+                                                       int32_t *__restrict__ out_idx,
+                                                       float *__restrict__ out_score,
+                                                       int64_t out_ld)
+{
+    __shared__ unsigned long long cand[MAXN];
+    __shared__ unsigned tmax[256];
+    __shared__ unsigned f_count;
+    const int tid = threadIdx.x;
+    const float *row = scores + (int64_t)blockIdx.x * ld_s;
+    int32_t *oidx = out_idx + (int64_t)blockIdx.x * out_ld;
+    float *osc = out_score ? out_score + (int64_t)blockIdx.x * out_ld : nullptr;
+
+    unsigned m = 0;
+    bool done = false;
+    if (n <= 256) {
+        unsigned best = 0;  // valid keys are >= 0x007fffff (f2key(-inf)); 0 = nothing seen
+        for (int64_t i = tid; i < row_len; i += 256) {
+            const float x = row[i];
+            if (x == x) best = max(best, f2key(x));
+        }
+        tmax[tid] = best;
+        if (tid == 0) f_count = 0;
+        __syncthreads();
+        for (unsigned k = 2; k <= 256; k <<= 1) {
+            for (unsigned j = k >> 1; j > 0; j >>= 1) {
+                const unsigned i = tid, ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned a = tmax[i], b = tmax[ixj];
+                    const bool desc = ((i & k) == 0);
+                    if (desc ? (a < b) : (a > b)) {
+                        tmax[i] = b;
+                        tmax[ixj] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        const unsigned tau = tmax[n - 1];
+        if (tau > 0) {
+            const int lane = tid & 63;
+            for (int64_t i0 = 0; i0 < row_len; i0 += 256) {
+                const int64_t i = i0 + tid;
+                bool keep = false;
+                unsigned k = 0;
+                if (i < row_len) {
+                    const float x = row[i];
+                    if (x == x) {
+                        k = f2key(x);
+                        keep = k >= tau;
+                    }
+                }
+                const unsigned long long mask = __ballot(keep);
+                if (mask) {
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(&f_count, (unsigned)__popcll(mask));
+                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                    const unsigned pos = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                    if (keep && pos < (unsigned)MAXN)
+                        cand[pos] = ((unsigned long long)k << 32) | (0xffffffffu - (unsigned)i);
+                }
+            }
+            __syncthreads();
+            if (f_count <= (unsigned)MAXN) {
+                m = f_count;
+                done = true;
+            }
+        }
+    }
+    if (!done) {
+        __syncthreads();
+        m = row_topn_radix(row, row_len, n, cand);
+    }
     // bitonic sort, descending, on the padded power of two
     unsigned p2 = 1;
     while (p2 < m) p2 <<= 1;
