@@ -52,25 +52,46 @@ __global__ __launch_bounds__(256) void score_panel_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    for (int kc = 0; kc < kp; kc += SC_KC) {
-        // stage [rows x 64 features] panels, coalesced float4 reads
-        for (int e = tid; e < SC_UB * (SC_KC / 4); e += 256) {
-            const int r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Software pipeline: the next 32-feature slab of both panels is fetched into registers
+    // (coalesced float4 reads) while the MFMAs of the current slab run out of LDS.
+    constexpr int UV = SC_UB * (SC_KC / 4) / 256;  // float4 per thread, user panel
+    constexpr int IV = SC_IB * (SC_KC / 4) / 256;  // float4 per thread, item panel
+    f32x4 ru[UV], ri[IV];
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int q = 0; q < UV; ++q) {
+            const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
+            ru[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (u0 + r < n_users && kc + c4 * 4 < kp)
-                v = *reinterpret_cast<const f32x4 *>(users + (u0 + r) * ld_u + kc + c4 * 4);
-            float *d = &lu[r * SC_LD + c4 * 4];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                ru[q] = *reinterpret_cast<const f32x4 *>(users + (u0 + r) * ld_u + kc + c4 * 4);
         }
-        for (int e = tid; e < SC_IB * (SC_KC / 4); e += 256) {
-            const int r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < IV; ++q) {
+            const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
+            ri[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (i0 + r < n_items && kc + c4 * 4 < kp)
-                v = *reinterpret_cast<const f32x4 *>(items + (i0 + r) * ld_i + kc + c4 * 4);
-            float *d = &li[r * SC_LD + c4 * 4];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                ri[q] = *reinterpret_cast<const f32x4 *>(items + (i0 + r) * ld_i + kc + c4 * 4);
         }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < UV; ++q) {
+            const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
+            float *d = &lu[r * SC_LD + c4 * 4];
+            d[0] = ru[q].x; d[1] = ru[q].y; d[2] = ru[q].z; d[3] = ru[q].w;
+        }
+#pragma unroll
+        for (int q = 0; q < IV; ++q) {
+            const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
+            float *d = &li[r * SC_LD + c4 * 4];
+            d[0] = ri[q].x; d[1] = ri[q].y; d[2] = ri[q].z; d[3] = ri[q].w;
+        }
+    };
+    fetch(0);
+    for (int kc = 0; kc < kp; kc += SC_KC) {
+        stage();
         __syncthreads();
+        if (kc + SC_KC < kp) fetch(kc + SC_KC);
         // v_mfma_f32_32x32x2_f32: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]
         const int r = lane & 31, h = lane >> 5;
 #pragma unroll 4
@@ -82,7 +103,7 @@ __global__ __launch_bounds__(256) void score_panel_kernel(
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
             }
         }
-        __syncthreads();
+        __syncthreads();  // everyone is done reading before the next slab is staged
     }
     // C/D: col (item) = lane&31, row (user) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -267,7 +288,18 @@ __global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__
     bool done = false;
     if (n <= 256) {
         unsigned best = 0;  // valid keys are >= 0x007fffff (f2key(-inf)); 0 = nothing seen
-        for (int64_t i = tid; i < row_len; i += 256) {
+        // 16-byte loads when the row allows it (score panels always do)
+        const bool vec = (reinterpret_cast<uintptr_t>(row) & 15u) == 0;
+        const int64_t n4 = vec ? row_len / 4 : 0;
+        const f32x4 *row4 = reinterpret_cast<const f32x4 *>(row);
+        for (int64_t i = tid; i < n4; i += 256) {
+            const f32x4 v = row4[i];
+            if (v.x == v.x) best = max(best, f2key(v.x));
+            if (v.y == v.y) best = max(best, f2key(v.y));
+            if (v.z == v.z) best = max(best, f2key(v.z));
+            if (v.w == v.w) best = max(best, f2key(v.w));
+        }
+        for (int64_t i = n4 * 4 + tid; i < row_len; i += 256) {
             const float x = row[i];
             if (x == x) best = max(best, f2key(x));
         }
@@ -291,17 +323,8 @@ __global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__
         const unsigned tau = tmax[n - 1];
         if (tau > 0) {
             const int lane = tid & 63;
-            for (int64_t i0 = 0; i0 < row_len; i0 += 256) {
-                const int64_t i = i0 + tid;
-                bool keep = false;
-                unsigned k = 0;
-                if (i < row_len) {
-                    const float x = row[i];
-                    if (x == x) {
-                        k = f2key(x);
-                        keep = k >= tau;
-                    }
-                }
+            // collect (wave-uniform control flow: every lane of a wave calls it together)
+            auto offer = [&](bool keep, unsigned k, int64_t i) {
                 const unsigned long long mask = __ballot(keep);
                 if (mask) {
                     unsigned base = 0;
@@ -311,6 +334,26 @@ __global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__
                     if (keep && pos < (unsigned)MAXN)
                         cand[pos] = ((unsigned long long)k << 32) | (0xffffffffu - (unsigned)i);
                 }
+            };
+            for (int64_t i0 = 0; i0 < n4; i0 += 256) {
+                const int64_t i = i0 + tid;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool in = i < n4;
+                if (in) v = row4[i];
+                const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned k = f2key(xs[c]);
+                    offer(in && xs[c] == xs[c] && k >= tau, k, i * 4 + c);
+                }
+            }
+            for (int64_t i0 = n4 * 4; i0 < row_len; i0 += 256) {
+                const int64_t i = i0 + tid;
+                float x = 0.f;
+                const bool in = i < row_len;
+                if (in) x = row[i];
+                const unsigned k = f2key(x);
+                offer(in && x == x && k >= tau, k, i);
             }
             __syncthreads();
             if (f_count <= (unsigned)MAXN) {
