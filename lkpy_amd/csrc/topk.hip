@@ -22,6 +22,8 @@
 //
 // Roofline: scoring is f32-MFMA bound (2*B*I*k flop); this first version writes the
 // B_tile x I score panel to HBM and reads it back for the selection (not yet fused).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace lk {
@@ -400,7 +402,18 @@ __global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__
 }
 
 constexpr int TOPN_MAX = 4096;
-constexpr int64_t SCORE_BATCH = 2048;  // user rows scored per panel
+constexpr int64_t SCORE_BATCH_DEFAULT = 2048;  // user rows scored per panel
+
+// rows per score panel (env LK_SCORE_BATCH: tuning knob, multiple of 64)
+static int64_t score_batch()
+{
+    static const int64_t v = [] {
+        const char *e = getenv("LK_SCORE_BATCH");
+        const long x = e ? atol(e) : 0;
+        return (x >= 64 && x <= 65536) ? (int64_t)(x / 64 * 64) : SCORE_BATCH_DEFAULT;
+    }();
+    return v;
+}
 
 static int64_t padded_items(int64_t n_items) { return (n_items + 63) / 64 * 64; }
 
@@ -409,7 +422,7 @@ static int64_t padded_items(int64_t n_items) { return (n_items + 63) / 64 * 64; 
 extern "C" size_t lk_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t n)
 {
     (void)n;
-    int64_t rows = n_users < lk::SCORE_BATCH ? n_users : lk::SCORE_BATCH;
+    int64_t rows = n_users < lk::score_batch() ? n_users : lk::score_batch();
     if (rows < 1) rows = 1;
     return (size_t)rows * (size_t)lk::padded_items(n_items) * sizeof(float) + 256;
 }
@@ -470,8 +483,8 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
     const int64_t ld_s = lk::padded_items(n_items);
     const int KS = KP < lk::SC_KC ? lk::SC_KC : KP;  // features are staged 64 at a time
     (void)KS;
-    for (int64_t ub = 0; ub < n_users; ub += lk::SCORE_BATCH) {
-        const int64_t rows = (n_users - ub) < lk::SCORE_BATCH ? (n_users - ub) : lk::SCORE_BATCH;
+    for (int64_t ub = 0; ub < n_users; ub += lk::score_batch()) {
+        const int64_t rows = (n_users - ub) < lk::score_batch() ? (n_users - ub) : lk::score_batch();
         if (n_items > 0) {
             dim3 grid((unsigned)((n_items + lk::SC_IB - 1) / lk::SC_IB),
                       (unsigned)((rows + lk::SC_UB - 1) / lk::SC_UB));
