@@ -69,10 +69,20 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
     int *__restrict__ status)
 {
     constexpr int FPL = KP / 64;
+    constexpr bool OTOR_LDS = KP <= 128;  // 16 / 64 KiB: loaded once per (persistent) workgroup
+    constexpr int GB = 8;                 // items gathered per wave and batch
     __shared__ float part[4][KP];
+    extern __shared__ __attribute__((aligned(16))) float otor_s[];  // OTOR_LDS: KP*KP floats
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const int f0 = lane * FPL;  // first feature of this lane
+    if (OTOR_LDS) {  // zero padded to KP x KP
+        for (int e = threadIdx.x; e < KP * KP; e += 256) {
+            const int g = e / KP, f = e % KP;
+            otor_s[e] = (g < k && f < k) ? otor[(int64_t)g * ld_otor + f] : 0.f;
+        }
+        __syncthreads();
+    }
 
     for (int64_t t = blockIdx.x; t < n_rows; t += gridDim.x) {
         const int row = order[t];
@@ -91,11 +101,36 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
             Vec<FPL> u;
 #pragma unroll
             for (int c = 0; c < FPL; ++c) u.v[c] = 0.f;
-            for (int64_t e = beg + wave; e < end; e += 4) {
-                const Vec<FPL> q = vload<FPL>(other + (int64_t)indices[e] * KP + f0);
-                const float coef = values[e] * vdot<FPL>(q, p);
+            // items: wave w takes batches w, w+4, ... of GB consecutive entries; the GB
+            // gathers of a batch are in flight together and their GB dot-product
+            // reductions are interleaved (independent shuffle chains)
+            for (int64_t e0 = beg + (int64_t)wave * GB; e0 < end; e0 += 4 * GB) {
+                Vec<FPL> q[GB];
+                float dotp[GB], val[GB];
 #pragma unroll
-                for (int c = 0; c < FPL; ++c) u.v[c] = fmaf(coef, q.v[c], u.v[c]);
+                for (int j = 0; j < GB; ++j) {
+                    const bool in = e0 + j < end;
+                    const int64_t it = in ? indices[e0 + j] : indices[beg];
+                    val[j] = in ? values[e0 + j] : 0.f;
+                    q[j] = vload<FPL>(other + it * KP + f0);
+                }
+#pragma unroll
+                for (int j = 0; j < GB; ++j) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int c = 0; c < FPL; ++c) sacc = fmaf(q[j].v[c], p.v[c], sacc);
+                    dotp[j] = sacc;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                    for (int j = 0; j < GB; ++j) dotp[j] += __shfl_xor(dotp[j], off, 64);
+#pragma unroll
+                for (int j = 0; j < GB; ++j) {
+                    const float coef = val[j] * dotp[j];
+#pragma unroll
+                    for (int c = 0; c < FPL; ++c) u.v[c] = fmaf(coef, q[j].v[c], u.v[c]);
+                }
             }
             for (int g = wave * (KP / 4); g < (wave + 1) * (KP / 4); ++g) {
                 if (g >= k) break;
@@ -105,11 +140,17 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
                 for (int c = 0; c < FPL; ++c)
                     if ((g % FPL) == c) pg = bcast(p.v[c], g / FPL);
                 // row g of the symmetric OtOr == column g; pad features contribute nothing
+                if (OTOR_LDS) {
+                    const Vec<FPL> o = vload<FPL>(&otor_s[g * KP + f0]);
 #pragma unroll
-                for (int c = 0; c < FPL; ++c) {
-                    const int f = f0 + c;
-                    const float o = (f < k) ? otor[(int64_t)g * ld_otor + f] : 0.f;
-                    u.v[c] = fmaf(pg, o, u.v[c]);
+                    for (int c = 0; c < FPL; ++c) u.v[c] = fmaf(pg, o.v[c], u.v[c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < FPL; ++c) {
+                        const int f = f0 + c;
+                        const float o = (f < k) ? otor[(int64_t)g * ld_otor + f] : 0.f;
+                        u.v[c] = fmaf(pg, o, u.v[c]);
+                    }
                 }
             }
             __syncthreads();  // previous readers of `part` are done
@@ -128,14 +169,26 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
             Vec<FPL> yw, dw;
 #pragma unroll
             for (int c = 0; c < FPL; ++c) yw.v[c] = dw.v[c] = 0.f;
-            for (int64_t e = beg + wave; e < end; e += 4) {
-                const Vec<FPL> q = vload<FPL>(other + (int64_t)indices[e] * KP + f0);
-                const float v = values[e];
+            for (int64_t e0 = beg + (int64_t)wave * GB; e0 < end; e0 += 4 * GB) {
+                Vec<FPL> q[GB];
+                float val[GB];
 #pragma unroll
-                for (int c = 0; c < FPL; ++c) {
-                    yw.v[c] = fmaf(v + 1.0f, q.v[c], yw.v[c]);
-                    dw.v[c] = fmaf(v * q.v[c], q.v[c], dw.v[c]);
+                for (int j = 0; j < GB; ++j) {
+                    const bool in = e0 + j < end;
+                    const int64_t it = in ? indices[e0 + j] : indices[beg];
+                    val[j] = in ? values[e0 + j] : -1.0f;  // (v + 1) = 0 and v q q = -q q ...
+                    q[j] = vload<FPL>(other + it * KP + f0);
+                    if (!in)
+#pragma unroll
+                        for (int c = 0; c < FPL; ++c) q[j].v[c] = 0.f;  // ... of a zero row
                 }
+#pragma unroll
+                for (int j = 0; j < GB; ++j)
+#pragma unroll
+                    for (int c = 0; c < FPL; ++c) {
+                        yw.v[c] = fmaf(val[j] + 1.0f, q[j].v[c], yw.v[c]);
+                        dw.v[c] = fmaf(val[j] * q[j].v[c], q[j].v[c], dw.v[c]);
+                    }
             }
             __syncthreads();
 #pragma unroll
@@ -226,7 +279,13 @@ static int launch_cg(const lk_als_plan *p, const void *indptr, const int32_t *in
     const int max_iter = p->cg_max_iter > 0 ? p->cg_max_iter : k;
     if (n_rows > 0) {
         int64_t blocks = n_rows < 256 * 8 ? n_rows : 256 * 8;
-        hipLaunchKernelGGL((als_cg_kernel<KP, IS64>), dim3((unsigned)blocks), dim3(256), 0, st,
+        const size_t lds = KP <= 128 ? (size_t)KP * KP * sizeof(float) : 0;  // OtOr resident
+        auto kern = als_cg_kernel<KP, IS64>;
+        if (lds > 0)
+            LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st,
                            static_cast<const IT *>(indptr), indices, values, p->d_order, n_rows,
                            other, this_, otor, ld_otor, k, p->cg_tol, max_iter, row_delta,
                            status);
