@@ -127,8 +127,35 @@ __global__ __launch_bounds__(TR_THREADS) void iknn_trunc_select_kernel(
         return;
     }
     auto vkey = [&](int64_t e) { return __builtin_bit_cast(unsigned, val[e]); };
-    auto all = [&](int64_t) { return true; };
-    const unsigned kth = block_radix_select<true>(n, (unsigned)save_nbrs, vkey, all, hist,
+    // Lower bound of the save_nbrs-th largest similarity: the save_nbrs-th largest of the
+    // 256 per-thread maxima (at least save_nbrs entries are >= it).  The radix select then
+    // only histograms the few entries above the bound -- per-element LDS atomics are the
+    // expensive part of it (~3 cycles per element per CU).
+    unsigned tau = 0;
+    if (save_nbrs <= TR_THREADS) {
+        __shared__ unsigned tmax[TR_THREADS];
+        unsigned best = 0;
+        for (int64_t e = tid; e < n; e += TR_THREADS) best = max(best, vkey(e));
+        tmax[tid] = best;
+        __syncthreads();
+        for (unsigned k = 2; k <= TR_THREADS; k <<= 1) {
+            for (unsigned j = k >> 1; j > 0; j >>= 1) {
+                const unsigned i = tid, ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned a = tmax[i], c = tmax[ixj];
+                    const bool desc = ((i & k) == 0);
+                    if (desc ? (a < c) : (a > c)) {
+                        tmax[i] = c;
+                        tmax[ixj] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        tau = tmax[save_nbrs - 1];  // > 0: n > save_nbrs entries, all positive
+    }
+    auto above = [&](int64_t e) { return vkey(e) >= tau; };
+    const unsigned kth = block_radix_select<true>(n, (unsigned)save_nbrs, vkey, above, hist,
                                                   &s_prefix, &s_need);
     const unsigned need_eq = s_need;
     __syncthreads();
