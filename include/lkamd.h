@@ -153,6 +153,13 @@ int lk_als_implicit_half_epoch_host(const void *h_indptr, int indptr_is_64,
 typedef struct lk_iknn_plan lk_iknn_plan;
 int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr, const void *h_iu_indptr,
                         int indptr_is_64, int64_t n_users, int64_t n_items);
+/* Shard of the build: output rows (items) [row_begin, row_end) only -- rows are independent
+ * (`compute_similarities` is a par_iter over rows, item_train.rs:56-70), so ranks of a
+ * multi-GPU job each build a row block with no collective.  d_out_indptr then has
+ * (row_end - row_begin + 1) entries; column numbers stay global. */
+int lk_iknn_plan_create_rows(lk_iknn_plan **out, const void *h_ui_indptr,
+                             const void *h_iu_indptr, int indptr_is_64, int64_t n_users,
+                             int64_t n_items, int64_t row_begin, int64_t row_end);
 void lk_iknn_plan_destroy(lk_iknn_plan *plan);
 size_t lk_iknn_plan_workspace_bytes(const lk_iknn_plan *plan);
 
@@ -205,14 +212,15 @@ int lk_argtopn(const float *d_scores, int64_t n_rows, int64_t row_len, int32_t n
  * neighbours of every row, ties at the cut in order of first encounter (first shared user,
  * then column), rows stay sorted by column.  lk_iknn_build_* take save_nbrs <= 0 (none);
  * run these on their output.  `nnz` = entries of the input matrix.  _count is blocking. */
-size_t lk_iknn_truncate_workspace_bytes(int64_t n_items, int64_t nnz);
+size_t lk_iknn_truncate_workspace_bytes(int64_t n_rows, int64_t nnz);
+/* n_rows rows of the similarity matrix; row r is item (row_begin + r) (0 for a full build) */
 int lk_iknn_truncate_count(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
                            const float *d_sim_values, const void *d_iu_indptr,
-                           int iu_indptr_is_64, const int32_t *d_iu_indices, int64_t n_items,
-                           int64_t nnz, int64_t save_nbrs, void *d_ws, int64_t *d_out_indptr,
-                           int64_t *h_total_nnz, void *stream);
+                           int iu_indptr_is_64, const int32_t *d_iu_indices, int64_t n_rows,
+                           int64_t row_begin, int64_t nnz, int64_t save_nbrs, void *d_ws,
+                           int64_t *d_out_indptr, int64_t *h_total_nnz, void *stream);
 int lk_iknn_truncate_fill(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
-                          const float *d_sim_values, int64_t n_items, int64_t nnz, void *d_ws,
+                          const float *d_sim_values, int64_t n_rows, int64_t nnz, void *d_ws,
                           const int64_t *d_out_indptr, int32_t *d_out_indices,
                           float *d_out_values, void *stream);
 

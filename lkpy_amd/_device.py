@@ -209,30 +209,34 @@ class ALSPlan:
             pass
 
 
-def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None) -> DeviceCSR:
+def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None,
+               rows: tuple[int, int] | None = None) -> DeviceCSR:
     """
     Item-item similarity build (lk_iknn_build_count / _fill, then lk_iknn_truncate_* when
     ``save_nbrs`` is set): ``ui`` users x items and ``iu`` items x users hold the normalised
     ratings; returns the similarity matrix as a device CSR with int64 offsets, rows sorted
-    by column.
+    by column.  ``rows = (begin, end)`` builds only that block of output rows (one rank's
+    shard: rows are independent, no collective); the result then has ``end - begin`` rows.
     """
     lib = _native.require_gpu()
     n_users, n_items = ui.shape
+    r0, r1 = (0, n_items) if rows is None else (int(rows[0]), int(rows[1]))
+    n_rows = r1 - r0
     assert iu.shape == (n_items, n_users)
     assert ui.h_indptr.dtype == iu.h_indptr.dtype
     dev = ui.indices.device
     is64 = 1 if ui.h_indptr.dtype == np.int64 else 0
     h = ctypes.c_void_p(0)
     check(
-        lib.lk_iknn_plan_create(
+        lib.lk_iknn_plan_create_rows(
             ctypes.byref(h), ui.h_indptr.ctypes.data_as(ctypes.c_void_p),
-            iu.h_indptr.ctypes.data_as(ctypes.c_void_p), is64, n_users, n_items
+            iu.h_indptr.ctypes.data_as(ctypes.c_void_p), is64, n_users, n_items, r0, r1
         ),
-        "lk_iknn_plan_create",
+        "lk_iknn_plan_create_rows",
     )  # fmt: skip
     try:
         ws = torch.empty(lib.lk_iknn_plan_workspace_bytes(h), dtype=torch.uint8, device=dev)
-        out_ptr = torch.empty(n_items + 1, dtype=torch.int64, device=dev)
+        out_ptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
         total = ctypes.c_int64(0)
         ms = float(np.float32(min_sim))  # cast to f32 at the boundary (item_train.rs:37)
         check(
@@ -257,18 +261,18 @@ def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None) -> 
         torch.cuda.current_stream().synchronize()
     finally:
         lib.lk_iknn_plan_destroy(h)
-    full = DeviceCSR(out_ptr, out_idx, out_val, (n_items, n_items), None)
+    full = DeviceCSR(out_ptr, out_idx, out_val, (n_rows, n_items), None)
     if save_nbrs is None or int(save_nbrs) <= 0:
         return full
     # item_train.rs:139-151: per-row top-save_nbrs, ties in order of first encounter
     del ws
-    tws = torch.empty(lib.lk_iknn_truncate_workspace_bytes(n_items, nnz), dtype=torch.uint8,
+    tws = torch.empty(lib.lk_iknn_truncate_workspace_bytes(n_rows, nnz), dtype=torch.uint8,
                       device=dev)
-    new_ptr = torch.empty(n_items + 1, dtype=torch.int64, device=dev)
+    new_ptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
     check(
         lib.lk_iknn_truncate_count(
             _ptr(full.indptr), _ptr(full.indices), _ptr(full.values), _ptr(iu.indptr), is64,
-            _ptr(iu.indices), n_items, nnz, int(save_nbrs), _ptr(tws), _ptr(new_ptr),
+            _ptr(iu.indices), n_rows, r0, nnz, int(save_nbrs), _ptr(tws), _ptr(new_ptr),
             ctypes.byref(total), _stream()
         ),
         "lk_iknn_truncate_count",
@@ -278,13 +282,13 @@ def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None) -> 
     t_val = torch.empty(max(nnz2, 1), dtype=torch.float32, device=dev)[:nnz2]
     check(
         lib.lk_iknn_truncate_fill(
-            _ptr(full.indptr), _ptr(full.indices), _ptr(full.values), n_items, nnz, _ptr(tws),
+            _ptr(full.indptr), _ptr(full.indices), _ptr(full.values), n_rows, nnz, _ptr(tws),
             _ptr(new_ptr), _ptr(t_idx), _ptr(t_val), _stream()
         ),
         "lk_iknn_truncate_fill",
     )  # fmt: skip
     torch.cuda.current_stream().synchronize()
-    return DeviceCSR(new_ptr, t_idx, t_val, (n_items, n_items), None)
+    return DeviceCSR(new_ptr, t_idx, t_val, (n_rows, n_items), None)
 
 
 def score_topk(users: torch.Tensor, items: torch.Tensor, k: int, n: int,

@@ -64,6 +64,9 @@ def _declare(lib):
             c_int, [vp, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int32)]
         ),
         "lk_iknn_plan_create": (c_int, [POINTER(vp), vp, vp, c_int, c_int64, c_int64]),
+        "lk_iknn_plan_create_rows": (
+            c_int, [POINTER(vp), vp, vp, c_int, c_int64, c_int64, c_int64, c_int64]
+        ),
         "lk_iknn_plan_destroy": (None, [vp]),
         "lk_iknn_plan_workspace_bytes": (c_size_t, [vp]),
         "lk_iknn_build_count": (
@@ -75,7 +78,8 @@ def _declare(lib):
         "lk_iknn_truncate_workspace_bytes": (c_size_t, [c_int64, c_int64]),
         "lk_iknn_truncate_count": (
             c_int,
-            [vp, vp, vp, vp, c_int, vp, c_int64, c_int64, c_int64, vp, vp, POINTER(c_int64), vp],
+            [vp, vp, vp, vp, c_int, vp, c_int64, c_int64, c_int64, c_int64, vp, vp,
+             POINTER(c_int64), vp],
         ),
         "lk_iknn_truncate_fill": (c_int, [vp, vp, vp, c_int64, c_int64, vp, vp, vp, vp, vp]),
         "lk_iknn_score_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32]),

@@ -52,13 +52,14 @@
 
 struct lk_iknn_plan {
     int64_t n_users = 0, n_items = 0;
+    int64_t row_lo = 0, n_rows = 0;  // output rows [row_lo, row_lo + n_rows) built by this plan
     int32_t is64 = 0;
     int32_t W = 0, P = 0;
     int32_t Q = 0;             // window quads per row: ceil(P / 4)
-    int64_t n_tasks = 0;       // n_items * P   (counts/offsets are indexed by row*P + p)
-    int64_t n_btasks = 0;      // n_items * Q   (what a workgroup takes: one row, 4 windows)
+    int64_t n_tasks = 0;       // n_rows * P   (counts/offsets are indexed by local row*P + p)
+    int64_t n_btasks = 0;      // n_rows * Q   (what a workgroup takes: one row, 4 windows)
     int64_t nnz = 0;
-    int32_t *d_task = nullptr;  // [n_btasks] row*Q + quad, heavy rows first
+    int32_t *d_task = nullptr;  // [n_btasks] local row*Q + quad, heavy rows first
     size_t off_pack = 0, off_seg = 0, off_cnt = 0, off_off = 0, off_scan = 0, ws_bytes = 0;
     // single-pass build through a dense-bound staging area (n_items^2 entries) when it fits
     int32_t staged = 0;
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
     const typename IndPtr<IS64>::type *__restrict__ ui_ptr, const int2 *__restrict__ ui_pack,
     const typename IndPtr<IS64>::type *__restrict__ iu_ptr, const int32_t *__restrict__ iu_idx,
     const float *__restrict__ iu_val, const int2 *__restrict__ desc,
-    const int32_t *__restrict__ tasks, int64_t n_btasks, int64_t n_items, int P, int Q, int W,
+    const int32_t *__restrict__ tasks, int64_t n_btasks, int64_t n_items, int64_t row_lo, int P,
+    int Q, int W,
     float min_sim, int32_t *__restrict__ task_cnt,
     const int64_t *__restrict__ task_off, int32_t *__restrict__ out_idx,
     float *__restrict__ out_val)
@@ -136,10 +138,11 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
     // (`tasks` is dealt to the workgroups serpentine, heavy rows first: see plan_create)
     for (int64_t bt = blockIdx.x; bt < n_btasks; bt += gridDim.x) {
         const int code = tasks[bt];
-        const int row = code / Q;
-        const int p = (code - row * Q) * 4 + wave;
+        const int lrow = code / Q;            // row of this plan's shard
+        const int row = (int)row_lo + lrow;  // item id
+        const int p = (code - lrow * Q) * 4 + wave;
         if (p >= P) continue;
-        const int task = row * P + p;
+        const int task = lrow * P + p;
         const int c_lo = p * W;
         const int wlen = (int)((n_items - c_lo) < W ? (n_items - c_lo) : W);
         const int64_t rb = iu_ptr[row], re = iu_ptr[row + 1];
@@ -262,8 +265,8 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
         }
 
         // ---- extract: survivors in column order, clear the window -----------
-        // staged: window p of row r is compacted at r * n_items + p * W
-        int64_t wpos = !WRITE ? 0 : COUNT ? (int64_t)row * n_items + c_lo : task_off[task];
+        // staged: window p of (local) row r is compacted at r * n_items + p * W
+        int64_t wpos = !WRITE ? 0 : COUNT ? (int64_t)lrow * n_items + c_lo : task_off[task];
         int count = 0;
         for (int c0 = 0; c0 < wlen; c0 += 64) {
             const int c = c0 + lane;
@@ -374,13 +377,28 @@ extern "C" int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr,
                                    const void *h_iu_indptr, int indptr_is_64, int64_t n_users,
                                    int64_t n_items)
 {
+    return lk_iknn_plan_create_rows(out, h_ui_indptr, h_iu_indptr, indptr_is_64, n_users,
+                                    n_items, 0, n_items);
+}
+
+extern "C" int lk_iknn_plan_create_rows(lk_iknn_plan **out, const void *h_ui_indptr,
+                                        const void *h_iu_indptr, int indptr_is_64,
+                                        int64_t n_users, int64_t n_items, int64_t row_begin,
+                                        int64_t row_end)
+{
     LK_REQUIRE(out && h_ui_indptr && h_iu_indptr, "lk_iknn_plan_create: null pointer");
     LK_REQUIRE(n_users >= 0 && n_items >= 0 && n_items < (int64_t)INT32_MAX &&
                    n_users < (int64_t)INT32_MAX,
                "lk_iknn_plan_create: bad shape");
+    LK_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= n_items,
+               "lk_iknn_plan_create: bad row range [%lld, %lld) of %lld items",
+               (long long)row_begin, (long long)row_end, (long long)n_items);
+    const int64_t n_rows = row_end - row_begin;
     auto *p = new lk_iknn_plan();
     p->n_users = n_users;
     p->n_items = n_items;
+    p->row_lo = row_begin;
+    p->n_rows = n_rows;
     p->is64 = indptr_is_64 ? 1 : 0;
     int64_t W = LK_IKNN_W;
     if (const char *env = getenv("LK_IKNN_W")) {  // tuning knob: columns per LDS window
@@ -391,8 +409,8 @@ extern "C" int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr,
     p->W = (int32_t)W;
     p->P = (int32_t)std::max<int64_t>(1, (n_items + W - 1) / W);
     p->Q = (p->P + 3) / 4;
-    p->n_tasks = n_items * p->P;
-    p->n_btasks = n_items * p->Q;
+    p->n_tasks = n_rows * p->P;
+    p->n_btasks = n_rows * p->Q;
     p->nnz = indptr_is_64 ? static_cast<const int64_t *>(h_ui_indptr)[n_users]
                           : (int64_t) static_cast<const int32_t *>(h_ui_indptr)[n_users];
     LK_REQUIRE(p->n_tasks < (int64_t)INT32_MAX, "lk_iknn_plan_create: too many tasks");
@@ -406,10 +424,11 @@ extern "C" int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr,
         const int32_t *ip = static_cast<const int32_t *>(h_iu_indptr);
         return (int64_t)ip[r + 1] - ip[r];
     };
-    std::vector<int32_t> rows((size_t)n_items);
-    for (int64_t r = 0; r < n_items; ++r) rows[(size_t)r] = (int32_t)r;
-    std::stable_sort(rows.begin(), rows.end(),
-                     [&](int32_t a, int32_t b) { return len(a) > len(b); });
+    std::vector<int32_t> rows((size_t)n_rows);  // LOCAL row numbers, heaviest first
+    for (int64_t r = 0; r < n_rows; ++r) rows[(size_t)r] = (int32_t)r;
+    std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) {
+        return len(row_begin + a) > len(row_begin + b);
+    });
     // Workgroup b of G takes tasks b, b+G, b+2G, ...: deal the weight-sorted list
     // serpentine (every other round reversed) so the per-workgroup totals stay level.
     std::vector<int32_t> tasks((size_t)p->n_btasks);
@@ -446,11 +465,11 @@ extern "C" int lk_iknn_plan_create(lk_iknn_plan **out, const void *h_ui_indptr,
     // its survivors straight into a row-strided staging area in ONE pass over the data and
     // a copy kernel compacts them; otherwise count and fill are two full passes.
     {
-        const size_t stage = (size_t)n_items * (size_t)n_items * sizeof(int32_t);
+        const size_t stage = (size_t)n_rows * (size_t)n_items * sizeof(int32_t);
         size_t cap = (size_t)64 << 30, free_b = 0, total_b = 0;
         if (const char *env = getenv("LK_IKNN_STAGE_GB")) cap = (size_t)atol(env) << 30;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap = std::min(cap, free_b / 3);
-        if (n_items > 0 && 2 * stage <= cap) {
+        if (n_rows > 0 && 2 * stage <= cap) {
             p->staged = 1;
             p->off_st_idx = off;
             off += lk::align_up(stage, 256);
@@ -508,7 +527,8 @@ static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t 
     int64_t blocks = std::min<int64_t>(p->n_btasks, iknn_grid(p->W));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st,
                        static_cast<const IT *>(ui_ptr), pack, static_cast<const IT *>(iu_ptr),
-                       iu_idx, iu_val, desc, p->d_task, p->n_btasks, p->n_items, p->P, p->Q, p->W,
+                       iu_idx, iu_val, desc, p->d_task, p->n_btasks, p->n_items, p->row_lo, p->P, p->Q,
+                       p->W,
                        min_sim, cnt, off, out_idx, out_val);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
@@ -543,7 +563,7 @@ extern "C" int lk_iknn_build_count(const lk_iknn_plan *plan, const void *d_ui_in
     int32_t *cnt = reinterpret_cast<int32_t *>(ws + plan->off_cnt);
     int64_t *off = reinterpret_cast<int64_t *>(ws + plan->off_off);
     if (plan->n_tasks == 0) {
-        LK_HIP_CHECK(hipMemsetAsync(d_out_indptr, 0, sizeof(int64_t) * (plan->n_items + 1), st));
+        LK_HIP_CHECK(hipMemsetAsync(d_out_indptr, 0, sizeof(int64_t) * (plan->n_rows + 1), st));
         LK_HIP_CHECK(hipStreamSynchronize(st));
         *h_total_nnz = 0;
         return LK_OK;
@@ -561,10 +581,10 @@ extern "C" int lk_iknn_build_count(const lk_iknn_plan *plan, const void *d_ui_in
 #undef LK_IKNN_LAUNCH
     }
     if (rc != LK_OK) return rc;
-    hipLaunchKernelGGL(lk::iknn_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, plan->n_items,
+    hipLaunchKernelGGL(lk::iknn_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, plan->n_rows,
                        plan->P, off);
-    hipLaunchKernelGGL(lk::iknn_indptr_kernel, dim3((unsigned)((plan->n_items + 256) / 256)),
-                       dim3(256), 0, st, off, plan->n_items, plan->P, d_out_indptr);
+    hipLaunchKernelGGL(lk::iknn_indptr_kernel, dim3((unsigned)((plan->n_rows + 256) / 256)),
+                       dim3(256), 0, st, off, plan->n_rows, plan->P, d_out_indptr);
     LK_HIP_CHECK(hipGetLastError());
     LK_HIP_CHECK(hipMemcpyAsync(h_total_nnz, off + plan->n_tasks, sizeof(int64_t),
                                 hipMemcpyDeviceToHost, st));

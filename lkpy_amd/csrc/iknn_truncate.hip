@@ -109,7 +109,7 @@ template <bool IS64>
 __global__ __launch_bounds__(TR_THREADS) void iknn_trunc_select_kernel(
     const int64_t *__restrict__ s_ptr, const int32_t *__restrict__ s_idx,
     const float *__restrict__ s_val, const typename IndPtr<IS64>::type *__restrict__ iu_ptr,
-    const int32_t *__restrict__ iu_idx, int64_t n_items, int save_nbrs,
+    const int32_t *__restrict__ iu_idx, int64_t row_begin, int save_nbrs,
     uint8_t *__restrict__ keep, int32_t *__restrict__ first_u, int32_t *__restrict__ new_cnt)
 {
     __shared__ unsigned hist[256];
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(TR_THREADS) void iknn_trunc_select_kernel(
         // ties: order of first encounter = (first common user, column)
         int32_t *fu = first_u + b;
         for (int64_t e = tid; e < n; e += TR_THREADS)
-            if (vkey(e) == kth) fu[e] = first_common_user<IS64>(iu_ptr, iu_idx, row, idx[e]);
+            if (vkey(e) == kth)
+                fu[e] = first_common_user<IS64>(iu_ptr, iu_idx, (int)row_begin + row, idx[e]);
         __syncthreads();
         auto tied = [&](int64_t e) { return vkey(e) == kth; };
         auto ukey = [&](int64_t e) { return (unsigned)fu[e]; };
@@ -283,12 +284,14 @@ extern "C" size_t lk_iknn_truncate_workspace_bytes(int64_t n_items, int64_t nnz)
 extern "C" int lk_iknn_truncate_count(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
                                       const float *d_sim_values, const void *d_iu_indptr,
                                       int iu_indptr_is_64, const int32_t *d_iu_indices,
-                                      int64_t n_items, int64_t nnz, int64_t save_nbrs, void *d_ws,
-                                      int64_t *d_out_indptr, int64_t *h_total_nnz, void *stream)
+                                      int64_t n_items, int64_t row_begin, int64_t nnz,
+                                      int64_t save_nbrs, void *d_ws, int64_t *d_out_indptr,
+                                      int64_t *h_total_nnz, void *stream)
 {
     LK_REQUIRE(save_nbrs > 0 && save_nbrs < (int64_t)INT32_MAX,
                "lk_iknn_truncate_count: save_nbrs must be positive");
-    LK_REQUIRE(n_items >= 0 && nnz >= 0, "lk_iknn_truncate_count: negative size");
+    LK_REQUIRE(n_items >= 0 && nnz >= 0 && row_begin >= 0,
+               "lk_iknn_truncate_count: negative size");
     LK_REQUIRE(d_sim_indptr && d_ws && d_out_indptr && h_total_nnz && d_iu_indptr,
                "lk_iknn_truncate_count: null pointer");
     hipStream_t st = lk::as_stream(stream);
@@ -302,12 +305,12 @@ extern "C" int lk_iknn_truncate_count(const int64_t *d_sim_indptr, const int32_t
             hipLaunchKernelGGL((lk::iknn_trunc_select_kernel<true>), dim3((unsigned)n_items),
                                dim3(lk::TR_THREADS), 0, st, d_sim_indptr, d_sim_indices,
                                d_sim_values, static_cast<const int64_t *>(d_iu_indptr),
-                               d_iu_indices, n_items, (int)save_nbrs, keep, first_u, cnt);
+                               d_iu_indices, row_begin, (int)save_nbrs, keep, first_u, cnt);
         else
             hipLaunchKernelGGL((lk::iknn_trunc_select_kernel<false>), dim3((unsigned)n_items),
                                dim3(lk::TR_THREADS), 0, st, d_sim_indptr, d_sim_indices,
                                d_sim_values, static_cast<const int32_t *>(d_iu_indptr),
-                               d_iu_indices, n_items, (int)save_nbrs, keep, first_u, cnt);
+                               d_iu_indices, row_begin, (int)save_nbrs, keep, first_u, cnt);
     }
     hipLaunchKernelGGL(lk::trunc_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, n_items,
                        d_out_indptr);

@@ -80,6 +80,31 @@ def test_build_wide_addressing(gpu, oracle, ml_small, monkeypatch):
     _assert_same(_build_gpu(D, gpu, ui, iu, 1.0e-6), want)
 
 
+@pytest.mark.parametrize("save_nbrs", [None, 20])
+def test_build_row_shards(gpu, oracle, ml_small, save_nbrs):
+    """Multi-GPU sharding of the build: every rank builds a block of output rows with no
+    collective; the blocks stacked are bit-identical to the full build."""
+    from lkpy_amd import _device as D
+
+    ui, iu, _means, _ = oracle.iknn_prepare(ml_small["rmat"], True)
+    want = oracle.iknn_build(ui, iu, 1.0e-6, save_nbrs)
+    dui, diu = D.DeviceCSR.from_scipy(ui, gpu), D.DeviceCSR.from_scipy(iu, gpu)
+    n = ui.shape[1]
+    cuts = [0, n // 3, n // 3, (2 * n) // 3 + 5, n]  # uneven blocks incl. an empty one
+    ptrs, idxs, vals = [np.zeros(1, np.int64)], [], []
+    base = 0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = D.iknn_build(dui, diu, 1.0e-6, save_nbrs, rows=(lo, hi))
+        assert part.shape == (hi - lo, n)
+        p = part.indptr.cpu().numpy()
+        assert p[0] == 0 and len(p) == hi - lo + 1
+        ptrs.append(p[1:] + base)
+        base += int(p[-1])
+        idxs.append(part.indices.cpu().numpy())
+        vals.append(part.values.cpu().numpy())
+    _assert_same((np.concatenate(ptrs), np.concatenate(idxs), np.concatenate(vals)), want)
+
+
 def test_build_toy_closed_form(gpu, oracle):
     """The reference's 14-rating toy set: sim(6,7) equals the hand-computed centred
     cosine (tests/models/test_knn_item_item.py:106-162)."""
@@ -148,5 +173,5 @@ def test_save_nbrs_rejected_by_raw_build(gpu, oracle, ml_small):
     from lkpy_amd import _native
 
     lib = _native.load()
-    assert lib.lk_iknn_truncate_count(None, None, None, None, 0, None, 5, 5, 0, None, None,
+    assert lib.lk_iknn_truncate_count(None, None, None, None, 0, None, 5, 0, 5, 0, None, None,
                                       ctypes.byref(ctypes.c_int64(0)), None) == _native.LK_E_INVALID
