@@ -9,12 +9,14 @@ its symbols works without a GPU (used by the CPU-only tests).
 from __future__ import annotations
 
 import ctypes
+import os
 import re
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "_lkamd.so"
+# LK_AMD_LIBRARY: load another build of the library (kernel-variant experiments)
+LIB_PATH = Path(os.environ.get("LK_AMD_LIBRARY", _PKG / "_lkamd.so"))
 HEADER_PATH = _PKG.parent / "include" / "lkamd.h"
 
 LK_OK = 0

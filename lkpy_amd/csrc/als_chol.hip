@@ -39,8 +39,12 @@
 #include "als_plan.h"
 #include "common.h"
 
-#define LK_ALS_CHUNK 1024     // CSR entries per chunk of a long row
+#ifndef LK_ALS_CHUNK
+#define LK_ALS_CHUNK 1024  // CSR entries per chunk of a long row
+#endif
+#ifndef LK_ALS_LONG_ROW
 #define LK_ALS_LONG_ROW 2048  // rows longer than this are chunked
+#endif
 
 namespace lk {
 
