@@ -39,6 +39,17 @@
 #include "als_plan.h"
 #include "common.h"
 
+#ifndef LK_ALS_RING
+#define LK_ALS_RING 4  // gather ring slots (8 costs 20 more registers: no gain at 3 waves/SIMD)
+#endif
+#ifndef LK_ALS_LOOKAHEAD
+#define LK_ALS_LOOKAHEAD 8  // multiplier groups read ahead in chol_step
+#endif
+#ifndef LK_ALS_SOLVE_ATTR
+// At least 3 waves per SIMD: the k = 64 kernel then fits 168 registers with 13 dwords of
+// scratch instead of 248 registers (2 waves per SIMD): +14 % epochs/s (tools/als_variants.py)
+#define LK_ALS_SOLVE_ATTR __attribute__((amdgpu_waves_per_eu(3)))
+#endif
 #ifndef LK_ALS_CHUNK
 #define LK_ALS_CHUNK 1024  // CSR entries per chunk of a long row
 #endif
@@ -81,13 +92,14 @@ __device__ __forceinline__ void load_q(const float *p, float (&q)[NT])
 //
 // Software pipeline: entries are taken in batches of 64 (one coalesced load of
 // indices + values per wave, fetched ONE BATCH AHEAD), each batch is 16 groups of
-// 4 entries (= one K=4 MFMA step).  The gathered factor rows live in an 8-slot
-// register ring: the gather for group g+8 is issued as soon as group g has been
-// consumed -- across batch boundaries too -- so ~8 x 320 MFMA cycles of work cover
-// every gather and the wave never drains its memory queue inside a row.
+// 4 entries (= one K=4 MFMA step).  The gathered factor rows live in a RING-slot
+// register ring: the gather for group g+RING is issued as soon as group g has been
+// consumed -- across batch boundaries too -- so RING x ~320 MFMA cycles of this wave's work,
+// plus the other two waves of the SIMD, cover every gather and the wave never drains its
+// memory queue inside a row.
 template <int NT>
 struct GatherRing {
-    static constexpr int RING = 8;
+    static constexpr int RING = LK_ALS_RING;  // must divide 16 (groups per batch)
     float q[RING][NT];
     float v[RING];
 };
@@ -295,7 +307,7 @@ __device__ __forceinline__ void chol_step(f32x2 (&a)[KP / 2], float &lj, float &
     // LOOKAHEAD groups ahead of the FMAs that use them
     constexpr int C0 = (J + 2) & ~3;
     constexpr int NG = (KP - C0) / 4;
-    constexpr int LOOKAHEAD = 4;
+    constexpr int LOOKAHEAD = LK_ALS_LOOKAHEAD;
     if constexpr (NG > 0) {
         const float *col = lds + P::off(J) - P::c0(J);
         const f32x2 nl = f32x2{-lj, -lj};
@@ -419,7 +431,7 @@ __host__ __device__ constexpr int solve_lds_floats()
 }
 
 template <int NT, bool IS64>
-__global__ __launch_bounds__(256) void als_solve_kernel(
+__global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_rows,
     const int32_t *__restrict__ row_slab, const float *__restrict__ other, int ld_other,
