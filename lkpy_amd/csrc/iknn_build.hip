@@ -60,7 +60,7 @@ struct lk_iknn_plan {
     int64_t n_btasks = 0;      // n_rows * Q   (what a workgroup takes: one row, 4 windows)
     int64_t nnz = 0;
     int32_t *d_task = nullptr;  // [n_btasks] local row*Q + quad, heavy rows first
-    size_t off_pack = 0, off_seg = 0, off_cnt = 0, off_off = 0, off_scan = 0, ws_bytes = 0;
+    size_t off_pack = 0, off_seg = 0, off_cnt = 0, off_off = 0, off_rows = 0, ws_bytes = 0;
     // single-pass build through a dense-bound staging area (n_items^2 entries) when it fits
     int32_t staged = 0;
     size_t off_st_idx = 0, off_st_val = 0;
@@ -293,57 +293,72 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
     }
 }
 
-// exclusive scan of the int32 task counts into int64 offsets (n_rows*P + 1 outputs), one
-// workgroup; a thread takes one ROW (its P adjacent counts), so the serial loop runs over
-// n_rows / 1024 steps
-__global__ __launch_bounds__(1024) void iknn_scan_kernel(const int32_t *__restrict__ cnt,
-                                                        int64_t n_rows, int P,
-                                                        int64_t *__restrict__ off)
+// Exclusive scan of the int32 task counts into int64 offsets (n_rows*P + 1 outputs) in three
+// parallel steps: per-row sums, a one-workgroup scan of the row sums in which every thread
+// owns a CONTIGUOUS chunk of rows (two sweeps of independent loads, one block-wide scan of
+// 1024 partials), and the per-row expansion -- which also emits the CSR row offsets.
+__global__ void iknn_rowsum_kernel(const int32_t *__restrict__ cnt, int64_t n_rows, int P,
+                                   int64_t *__restrict__ row_sum)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    int64_t v = 0;
+    for (int q = 0; q < P; ++q) v += cnt[r * P + q];
+    row_sum[r] = v;
+}
+
+// in place: row_sum[r] -> exclusive prefix; row_sum[n_rows] = total
+__global__ __launch_bounds__(1024) void iknn_scan_kernel(int64_t *__restrict__ row_sum,
+                                                        int64_t n_rows)
 {
     __shared__ int64_t wsum[16];
-    __shared__ int64_t carry_s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n_rows; base += 1024) {
-        const int64_t i = base + threadIdx.x;
-        int64_t v = 0;
-        if (i < n_rows)
-            for (int q = 0; q < P; ++q) v += cnt[i * P + q];
-        int64_t x = v;  // inclusive scan inside the wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t per = (n_rows + 1023) / 1024;
+    const int64_t lo = std::min<int64_t>(n_rows, (int64_t)tid * per);
+    const int64_t hi = std::min<int64_t>(n_rows, lo + per);
+    int64_t v = 0;
+    for (int64_t i = lo; i < hi; ++i) v += row_sum[i];
+    int64_t x = v;  // inclusive scan of the 1024 chunk sums
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int64_t y = __shfl_up(x, o, 64);
-            if (lane >= o) x += y;
-        }
-        if (lane == 63) wsum[wave] = x;
-        __syncthreads();
-        int64_t woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        const int64_t carry = carry_s;
-        if (i < n_rows) {
-            int64_t run = carry + woff + x - v;
-            for (int q = 0; q < P; ++q) {
-                off[i * P + q] = run;
-                run += cnt[i * P + q];
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + x;
-        __syncthreads();
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
     }
-    if (threadIdx.x == 0) off[n_rows * P] = carry_s;
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int64_t run = x - v;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    for (int64_t i = lo; i < hi; ++i) {
+        const int64_t c = row_sum[i];
+        row_sum[i] = run;
+        run += c;
+    }
+    if (tid == 1023) row_sum[n_rows] = run;  // the last chunk ends at n_rows
+}
+
+__global__ void iknn_taskoff_kernel(const int32_t *__restrict__ cnt,
+                                    const int64_t *__restrict__ row_off, int64_t n_rows, int P,
+                                    int64_t *__restrict__ task_off,
+                                    int64_t *__restrict__ out_indptr)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rows) return;
+    const int64_t base = row_off[r];
+    out_indptr[r] = base;
+    if (r == n_rows) {
+        task_off[n_rows * P] = base;
+        return;
+    }
+    int64_t run = base;
+    for (int q = 0; q < P; ++q) {
+        task_off[r * P + q] = run;
+        run += cnt[r * P + q];
+    }
 }
 
 // counts / offsets are indexed by TASK ID = row*P + p (item order, windows of a row
 // adjacent), so the scan yields rows in item order sorted by column; `tasks` is only
-// the visiting order (heavy rows first).  out_indptr[r] = off[r*P].
-__global__ void iknn_indptr_kernel(const int64_t *__restrict__ task_off, int64_t n_items, int P,
-                                   int64_t *__restrict__ out_indptr)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r <= n_items) out_indptr[r] = task_off[r * P];
-}
+// the visiting order (heavy rows first).
 
 // staged build: move the survivors of task t from the staging area to their final place
 // (one wave per task, coalesced)
@@ -461,6 +476,8 @@ extern "C" int lk_iknn_plan_create_rows(lk_iknn_plan **out, const void *h_ui_ind
     off += lk::align_up((size_t)(p->n_tasks + 1) * sizeof(int32_t), 256);
     p->off_off = off;
     off += lk::align_up((size_t)(p->n_tasks + 1) * sizeof(int64_t), 256);
+    p->off_rows = off;
+    off += lk::align_up((size_t)(n_rows + 1) * sizeof(int64_t), 256);
     // 288 GB of HBM: when n_items^2 (index, value) pairs fit comfortably, every task writes
     // its survivors straight into a row-strided staging area in ONE pass over the data and
     // a copy kernel compacts them; otherwise count and fill are two full passes.
@@ -581,10 +598,16 @@ extern "C" int lk_iknn_build_count(const lk_iknn_plan *plan, const void *d_ui_in
 #undef LK_IKNN_LAUNCH
     }
     if (rc != LK_OK) return rc;
-    hipLaunchKernelGGL(lk::iknn_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, plan->n_rows,
-                       plan->P, off);
-    hipLaunchKernelGGL(lk::iknn_indptr_kernel, dim3((unsigned)((plan->n_rows + 256) / 256)),
-                       dim3(256), 0, st, off, plan->n_rows, plan->P, d_out_indptr);
+    {
+        int64_t *row_off = reinterpret_cast<int64_t *>(ws + plan->off_rows);
+        const unsigned gb = (unsigned)((plan->n_rows + 256) / 256);
+        hipLaunchKernelGGL(lk::iknn_rowsum_kernel, dim3(gb), dim3(256), 0, st, cnt, plan->n_rows,
+                           plan->P, row_off);
+        hipLaunchKernelGGL(lk::iknn_scan_kernel, dim3(1), dim3(1024), 0, st, row_off,
+                           plan->n_rows);
+        hipLaunchKernelGGL(lk::iknn_taskoff_kernel, dim3(gb), dim3(256), 0, st, cnt, row_off,
+                           plan->n_rows, plan->P, off, d_out_indptr);
+    }
     LK_HIP_CHECK(hipGetLastError());
     LK_HIP_CHECK(hipMemcpyAsync(h_total_nnz, off + plan->n_tasks, sizeof(int64_t),
                                 hipMemcpyDeviceToHost, st));
