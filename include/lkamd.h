@@ -107,6 +107,17 @@ int lk_als_implicit_half_epoch(const lk_als_plan *plan, const void *d_indptr,
                                int64_t n_cols, int32_t k, float *d_this, int32_t ld_this,
                                const float *d_other, int32_t ld_other, const float *d_otor,
                                int32_t ld_otor, void *d_ws, float *d_out_frob, void *stream);
+/* Explicit-feedback (biased-MF) half-epoch: replaces `_accel.als.train_explicit_matrix(matrix,
+ * this, other, reg)` (src/lenskit/_accel/als.pyi, src/accel/als/explicit.rs:33-119):
+ *   A = sum_j q_j q_j^T + reg * n * I,  A x = sum_j r_j q_j   (r = bias-normalised ratings),
+ * empty rows -> zeros; same plan, workspace, in-place update, status word and return value
+ * (sqrt of the summed squared row deltas at d_out_frob) as the implicit form.  Exact solver
+ * only (k <= 64). */
+int lk_als_explicit_half_epoch(const lk_als_plan *plan, const void *d_indptr,
+                               const int32_t *d_indices, const float *d_values, int64_t n_rows,
+                               int64_t n_cols, int32_t k, float *d_this, int32_t ld_this,
+                               const float *d_other, int32_t ld_other, float reg, void *d_ws,
+                               float *d_out_frob, void *stream);
 /* Optional per-kernel timing with HIP events recorded on the launch stream
  * (bench.py's roofline leg).  get_timing waits for the recorded events, returns the
  * summed durations (ms) of the chunk kernel and of the solve kernel over the

@@ -100,6 +100,9 @@ class HipBackend:
         "-> device scalar sqrt(sum ||delta||^2) of the slice"
         return plan.half_epoch(this_slice, other_full, otor)
 
+    def half_epoch_explicit(self, plan, this_slice, other_full, reg: float) -> torch.Tensor:
+        return plan.half_epoch_explicit(this_slice, other_full, reg)
+
     def check(self, plan):
         plan.check_status()
 
@@ -108,6 +111,8 @@ class HipBackend:
 
 
 class ImplicitALSEngine:
+    "Row-sharded ALS engine; ``explicit=True`` switches to the biased-MF (explicit) model."
+
     def __init__(
         self,
         ui: sps.csr_array,
@@ -118,9 +123,13 @@ class ImplicitALSEngine:
         item_init: np.ndarray,
         backend,
         group=None,
+        explicit: bool = False,
     ):
         self.k = int(k)
         self.backend = backend
+        # explicit = the biased-MF model (src/lenskit/als/_explicit.py, explicit.rs): the CSR
+        # values are bias-normalised ratings, A = M^T M + reg n I; no Gramian, same exchanges
+        self.explicit = bool(explicit)
         self.user_reg, self.item_reg = float(user_reg), float(item_reg)
         self.group = group
         self.world = dist.get_world_size(group) if (group is not None or _dist_on()) else 1
@@ -153,7 +162,8 @@ class ImplicitALSEngine:
         self.P = backend.upload(P)
         self.Q = backend.upload(Q)
         # Gramian of the initial Q (user half of epoch 1 needs it); padding rows are 0
-        self._qtq = self._gramian(self.Q, self.i_lo, self.i_hi, self.user_reg)
+        self._qtq = None if self.explicit else self._gramian(self.Q, self.i_lo, self.i_hi,
+                                                             self.user_reg)
         self.epochs_trained = 0
 
     # -- collectives ---------------------------------------------------------
@@ -173,6 +183,17 @@ class ImplicitALSEngine:
     def train_epoch(self):
         "One epoch; returns device tensors (|dP|, |dQ|) -- no host sync inside."
         b = self.backend
+        if self.explicit:
+            du = b.half_epoch_explicit(self.u_plan, self.P[self.u_lo : self.u_hi], self.Q,
+                                       self.user_reg)
+            du = self._delta(du)
+            self._exchange(self.P, self.u_lo, self.u_hi)
+            di = b.half_epoch_explicit(self.i_plan, self.Q[self.i_lo : self.i_hi], self.P,
+                                       self.item_reg)
+            di = self._delta(di)
+            self._exchange(self.Q, self.i_lo, self.i_hi)
+            self.epochs_trained += 1
+            return du, di
         # user half: previous Q (src/lenskit/als/_common.py:251)
         du = b.half_epoch(self.u_plan, self.P[self.u_lo : self.u_hi], self.Q, self._qtq)
         du = self._delta(du)
@@ -208,7 +229,8 @@ class ImplicitALSEngine:
         return self.backend.download(self.Q)[self.i_new]
 
     def otor(self) -> np.ndarray:
-        "Q^T Q + user_reg I (k x k) -- the scorer's ``_OtOr``."
+        "Q^T Q + user_reg I (k x k) -- the scorer's ``_OtOr`` (implicit model only)."
+        assert not self.explicit
         g = self._qtq
         return g.cpu().numpy() if isinstance(g, torch.Tensor) else np.asarray(g)
 

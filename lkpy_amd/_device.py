@@ -183,6 +183,24 @@ class ALSPlan:
         )  # fmt: skip
         return self.frob
 
+    def half_epoch_explicit(self, this: torch.Tensor, other: torch.Tensor, reg: float):
+        """
+        One explicit-feedback (biased-MF) half-epoch (lk_als_explicit_half_epoch;
+        src/accel/als/explicit.rs:33-119): the CSR values are the bias-normalised ratings.
+        """
+        csr = self.csr
+        assert this.shape == (csr.shape[0], self.kp) and other.shape == (csr.shape[1], self.kp)
+        assert this.is_contiguous() and other.is_contiguous()
+        check(
+            _native.load().lk_als_explicit_half_epoch(
+                self._h, _ptr(csr.indptr), _ptr(csr.indices), _ptr(csr.values),
+                csr.shape[0], csr.shape[1], self.k, _ptr(this), self.kp, _ptr(other), self.kp,
+                float(np.float32(reg)), _ptr(self.ws), _ptr(self.frob), _stream()
+            ),
+            "lk_als_explicit_half_epoch",
+        )  # fmt: skip
+        return self.frob
+
     def enable_timing(self, enable: bool = True):
         check(_native.load().lk_als_plan_enable_timing(self._h, 1 if enable else 0))
 
@@ -382,5 +400,18 @@ def fold_in(hist: DeviceCSR, items: torch.Tensor, otor: torch.Tensor, k: int,
     plan = ALSPlan(hist, k, solver)
     out = torch.zeros((hist.shape[0], plan.kp), dtype=torch.float32, device=items.device)
     plan.half_epoch(out, items, otor)
+    plan.check_status()
+    return out
+
+
+def fold_in_explicit(hist: DeviceCSR, items: torch.Tensor, reg: float, k: int) -> torch.Tensor:
+    """
+    Batched new-user embeddings of the biased-MF model (``_train_bias_row_cholesky``,
+    src/lenskit/als/_explicit.py:121-149): one explicit row solve per history row of ``hist``
+    (queries x items CSR, values = bias-normalised ratings).  Returns [n_queries x KP].
+    """
+    plan = ALSPlan(hist, k, _native.SOLVER_CHOLESKY)
+    out = torch.zeros((hist.shape[0], plan.kp), dtype=torch.float32, device=items.device)
+    plan.half_epoch_explicit(out, items, reg)
     plan.check_status()
     return out

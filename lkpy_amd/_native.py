@@ -60,6 +60,11 @@ def _declare(lib):
             [vp, vp, vp, vp, c_int64, c_int64, c_int32, vp, c_int32, vp, c_int32, vp, c_int32, vp,
              vp, vp],
         ),
+        "lk_als_explicit_half_epoch": (
+            c_int,
+            [vp, vp, vp, vp, c_int64, c_int64, c_int32, vp, c_int32, vp, c_int32, c_float, vp, vp,
+             vp],
+        ),
         "lk_als_check_status": (c_int, [vp, vp, vp]),
         "lk_als_plan_enable_timing": (c_int, [vp, c_int]),
         "lk_als_plan_get_timing": (

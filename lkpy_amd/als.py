@@ -1,5 +1,6 @@
 """
-Component seam for implicit-feedback ALS: mirror of ``lenskit.als.ImplicitMFScorer`` /
+Component seam for ALS matrix factorisation (implicit feedback; the explicit / biased-MF model
+is at the end of the file): mirror of ``lenskit.als.ImplicitMFScorer`` /
 ``ImplicitMFTrainer`` / ``ALSBase`` / ``ALSTrainerBase`` / ``ALSConfig``
 (src/lenskit/als/_common.py:36-356, src/lenskit/als/_implicit.py:24-184), with the same
 config fields, attributes after training (``users``, ``items``, ``user_embeddings``,
@@ -21,6 +22,7 @@ from pydantic import AliasChoices, BaseModel, Field, PositiveFloat, PositiveInt
 from . import _device as D
 from . import _native
 from ._als_engine import HipBackend, ImplicitALSEngine
+from .basic import BiasModel
 from .data import Dataset, ItemList, RecQuery, Vocabulary
 from .pipeline import Component
 from .training import ModelTrainer, TrainingOptions, UsesTrainer
@@ -258,6 +260,160 @@ class ImplicitMFTrainer(ModelTrainer):
         s.user_embeddings = self.engine.user_embeddings()
         s.item_embeddings = self.engine.item_embeddings()
         s._OtOr = self.engine.otor()  # _save_user_otor (_implicit.py:171-175)
+
+    def finalize(self):
+        self._sync()
+        if not self.scorer.config.user_embeddings:  # _common.py:318-325
+            self.scorer.user_embeddings = None
+            self.scorer.users = None
+
+    def get_parameters(self):
+        return {"user_embeddings": self.scorer.user_embeddings,
+                "item_embeddings": self.scorer.item_embeddings}
+
+
+# ---------------------------------------------------------------------------------------
+# Explicit feedback: biased matrix factorisation
+# ---------------------------------------------------------------------------------------
+
+
+class BiasedMFConfig(ALSConfig):
+    "src/lenskit/als/_explicit.py:25-29"
+
+    damping: float | tuple[float, float] | dict[str, float] = 5.0
+
+
+class BiasedMFScorer(UsesTrainer, Component):
+    """
+    Biased matrix factorisation trained with ALS on bias-normalised ratings
+    (``BiasedMFScorer``, src/lenskit/als/_explicit.py:32-90): the bias model stays on the
+    host, the row solves (training and fold-in) run in the explicit mode of the HIP kernel.
+    Scoring follows ``ALSBase.__call__`` (src/lenskit/als/_common.py:133-175) +
+    ``finalize_scores`` (adds b_g + b_i + b_u back).
+    """
+
+    config: BiasedMFConfig
+
+    users: Vocabulary | None = None
+    items: Vocabulary
+    user_embeddings: np.ndarray | None = None
+    item_embeddings: np.ndarray
+    bias: BiasModel
+
+    def create_trainer(self, data, options):
+        return BiasedMFTrainer(self, data, options)
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.pop("_dev", None)
+        return st
+
+    def _device_state(self):
+        dev = getattr(self, "_dev", None)
+        if dev is None or dev["src"] is not self.item_embeddings:
+            d = D.device()
+            dev = {"src": self.item_embeddings, "device": d,
+                   "Q": D.to_device_padded(self.item_embeddings, d)}
+            self._dev = dev
+        return dev
+
+    def new_user_embedding(self, user_num, user_items: ItemList):
+        "_explicit.py:56-74: normalise the ratings with the bias model, one explicit row solve."
+        inums = user_items.numbers(vocabulary=self.items, missing="negative")
+        ratings = user_items.field("rating")
+        assert ratings is not None
+        ratings = np.asarray(ratings, dtype=np.float32)
+        mask = (inums >= 0) & np.isfinite(ratings)
+        biases, u_bias = self.bias.compute_for_items(user_items, None, user_items)
+        resid = (ratings - biases)[mask]
+        order = np.argsort(inums[mask], kind="stable")
+        st = self._device_state()
+        hist = D.DeviceCSR.from_arrays(
+            np.array([0, int(mask.sum())], dtype=np.int64), inums[mask][order].astype(np.int32),
+            resid[order].astype(np.float32), (1, len(self.items)), st["device"])
+        u = D.fold_in_explicit(hist, st["Q"], self.config.user_reg, self.config.embedding_size)
+        return D.to_host_unpadded(u, self.config.embedding_size)[0], u_bias
+
+    def finalize_scores(self, user_num, items: ItemList, user_bias) -> ItemList:
+        "_explicit.py:76-93"
+        scores = items.scores()
+        if user_bias is None:
+            if user_num is not None and self.bias.user_biases is not None:
+                user_bias = self.bias.user_biases[user_num]
+            else:
+                user_bias = 0.0
+        biases = self.bias.compute_for_items(items, bias=user_bias)
+        return ItemList(items, scores=scores + biases)
+
+    def __call__(self, query, items: ItemList) -> ItemList:
+        query = RecQuery.create(query)
+        user_num = None
+        if query.user_id is not None and self.users is not None:
+            user_num = self.users.number(query.user_id, missing=None)
+        u_feat, u_off = None, None
+        hist = query.query_items
+        if hist is not None and len(hist) > 0 and self.config.user_embeddings != "prefer":
+            u_feat, u_off = self.new_user_embedding(user_num, hist)
+        if u_feat is None:
+            if user_num is None or self.user_embeddings is None:
+                return ItemList(items, scores=np.nan)
+            u_feat = self.user_embeddings[user_num, :]
+        st = self._device_state()
+        k = self.config.embedding_size
+        u = D.to_device_padded(np.ascontiguousarray(u_feat, dtype=np.float32)[None, :],
+                               st["device"])
+        all_scores = D.score_dense(u, st["Q"], k)[0].cpu().numpy()
+        item_nums = items.numbers(vocabulary=self.items, missing="negative")
+        mask = item_nums >= 0
+        scores = np.full(len(items), np.nan, dtype=np.float32)
+        scores[mask] = all_scores[item_nums[mask]]
+        return self.finalize_scores(user_num, ItemList(items, scores=scores), u_off)
+
+
+class BiasedMFTrainer(ModelTrainer):
+    "``ALSTrainerBase`` + ``BiasedMFTrainer`` (_common.py:195-356, _explicit.py:93-118)."
+
+    def __init__(self, scorer: BiasedMFScorer, data: Dataset, options: TrainingOptions):
+        self.scorer = scorer
+        cfg = scorer.config
+        scorer.users, scorer.items = data.users, data.items
+        self.rng = options.random_generator()
+        ui = self.prepare_matrix(data)
+        k = cfg.embedding_size
+        # item matrix FIRST, then users, same generator (_common.py:287-301)
+        scorer.item_embeddings = self.initial_params(data.item_count, k)
+        scorer.user_embeddings = self.initial_params(data.user_count, k)
+        dev = D.device(None if options.configured_device() in ("cuda", "cpu") else
+                       options.configured_device())
+        backend = HipBackend(k, dev, _native.SOLVER_CHOLESKY)
+        self.engine = ImplicitALSEngine(sps.csr_array(ui), k, cfg.user_reg, cfg.item_reg,
+                                        scorer.user_embeddings, scorer.item_embeddings, backend,
+                                        explicit=True)
+        self.epochs_trained = 0
+
+    def prepare_matrix(self, data: Dataset) -> sps.coo_array:
+        "_explicit.py:95-102: ratings minus the learned biases, float32"
+        rmat = data.interactions().matrix().scipy(attribute="rating", layout="coo")
+        self.scorer.bias = BiasModel.learn(data, damping=self.scorer.config.damping)
+        return self.scorer.bias.transform_matrix(rmat).astype(np.float32)
+
+    def initial_params(self, nrows: int, ncols: int) -> np.ndarray:
+        "_explicit.py:104-108: N(0,1) rows scaled to unit length"
+        mat = self.rng.standard_normal((nrows, ncols), dtype=np.float32)
+        mat /= np.linalg.norm(mat, axis=1).reshape((nrows, 1))
+        return mat
+
+    def train_epoch(self):
+        du, di = self.engine.train_epoch()
+        self.engine.check()  # RuntimeError("ALS solve error: ...") like explicit.rs:72
+        self.epochs_trained += 1
+        self._sync()
+        return {"deltaP": float(du.item()), "deltaQ": float(di.item())}
+
+    def _sync(self):
+        s = self.scorer
+        s.user_embeddings = self.engine.user_embeddings()
+        s.item_embeddings = self.engine.item_embeddings()
 
     def finalize(self):
         self._sync()

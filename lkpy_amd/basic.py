@@ -93,63 +93,114 @@ def _damping(d, which):
     return float(d)
 
 
-class BiasScorer(Component):
-    """``BiasScorer`` / ``BiasModel.learn`` (src/lenskit/basic/bias.py:85-250):
-    score = mu + b_i + b_u."""
+class BiasModel:
+    """
+    User-item bias model  b_ui = b_g + b_i + b_u  with Bayesian damping
+    (``BiasModel``, src/lenskit/basic/bias.py:35-275): reusable by components that normalise
+    ratings (the biased-MF ALS) as well as by :class:`BiasScorer`.
+    """
 
-    config: BiasConfig
+    def __init__(self, damping=0.0, global_bias: float = 0.0):
+        self.damping = damping
+        self.global_bias = float(global_bias)
+        self.items = self.users = None
+        self.item_biases = self.user_biases = None
 
-    def is_trained(self):
-        return hasattr(self, "global_bias")
-
-    def train(self, data: Dataset, options: TrainingOptions = TrainingOptions()):
+    @classmethod
+    def learn(cls, data: Dataset, damping=0.0, *, entities=("user", "item")) -> "BiasModel":
+        "bias.py:83-150, call for call (float64 sums, float32 biases)."
         ratings = data.interaction_matrix(format="scipy", layout="coo", field="rating")
         nrows, ncols = ratings.shape
-        self.global_bias = float(np.mean(ratings.data))
-        centered = ratings.data - self.global_bias
-        self.items, self.users = None, None
-        self.item_biases, self.user_biases = None, None
-        if "item" in self.config.entities:
-            counts = np.full(ncols, _damping(self.config.damping, "item"))
+        model = cls(damping, float(np.mean(ratings.data)))
+        centered = ratings.data - model.global_bias
+        if "item" in entities:
+            counts = np.full(ncols, _damping(damping, "item"))
             sums = np.zeros(ncols)
             np.add.at(counts, ratings.col, 1)
             np.add.at(sums, ratings.col, centered)
             i_bias = np.zeros(ncols, dtype=np.float32)
             np.divide(sums, counts, out=i_bias, where=counts > 0)
-            self.items, self.item_biases = data.items, i_bias
+            model.items, model.item_biases = data.items, i_bias
             centered = centered - i_bias[ratings.col]
-        if "user" in self.config.entities:
-            counts = np.full(nrows, _damping(self.config.damping, "user"))
+        if "user" in entities:
+            counts = np.full(nrows, _damping(damping, "user"))
             sums = np.zeros(nrows)
             np.add.at(counts, ratings.row, 1)
             np.add.at(sums, ratings.row, centered)
             u_bias = np.zeros(nrows, dtype=np.float32)
             np.divide(sums, counts, out=u_bias, where=counts > 0)
-            self.users, self.user_biases = data.users, u_bias
+            model.users, model.user_biases = data.users, u_bias
+        return model
 
-    def __call__(self, query, items: ItemList) -> ItemList:
-        query = RecQuery.create(query)
+    def compute_for_items(self, items: ItemList, user_id=None, user_items: ItemList | None = None,
+                          *, bias: float | None = None):
+        """
+        bias.py:166-241: composite biases of ``items``; with ``bias`` (a known user bias) only
+        the scores are returned, otherwise (scores, user_bias) with the user bias taken from
+        ``user_items``' ratings when present, else from the stored value of ``user_id``.
+        """
         scores = np.full(len(items), self.global_bias, dtype=np.float32)
         if self.item_biases is not None:
             idx = items.numbers(vocabulary=self.items, missing="negative")
             m = idx >= 0
             scores[m] += self.item_biases[idx[m]]
-        hist = query.history_items
-        ratings = hist.field("rating") if hist is not None else None
+        if bias is not None:
+            return scores + bias
+        ratings = user_items.field("rating") if user_items is not None else None
+        user_bias = 0.0
         if self.users is not None:
             if ratings is not None:
                 uoff = np.asarray(ratings, dtype=np.float64) - self.global_bias
                 if self.item_biases is not None:
-                    r_idx = hist.numbers(vocabulary=self.items, missing="negative")
+                    r_idx = user_items.numbers(vocabulary=self.items, missing="negative")
                     rm = r_idx >= 0
                     uoff[rm] -= self.item_biases[r_idx[rm]]
-                ub = np.sum(uoff) / (np.sum(np.isfinite(uoff)) +
-                                     _damping(self.config.damping, "user"))
-                scores += 0 if np.isnan(ub) else np.float32(ub)
-            elif query.user_id is not None:
-                uno = self.users.number(query.user_id, missing=None)
+                user_bias = np.sum(uoff) / (np.sum(np.isfinite(uoff)) +
+                                            _damping(self.damping, "user"))
+                if np.isnan(user_bias):
+                    user_bias = 0
+                scores += np.float32(user_bias)
+            elif user_id is not None:
+                uno = self.users.number(user_id, missing=None)
                 if uno is not None:
-                    scores += self.user_biases[uno]
+                    user_bias = self.user_biases[uno]
+                    scores += user_bias
+        return scores, user_bias
+
+    def transform_matrix(self, matrix):
+        "bias.py:246-275: subtract the biases from a COO ratings matrix."
+        import scipy.sparse as sps
+
+        values = matrix.data - self.global_bias
+        if self.item_biases is not None:
+            values -= self.item_biases[matrix.col]
+        if self.user_biases is not None:
+            values -= self.user_biases[matrix.row]
+        return sps.coo_array((values, (matrix.row, matrix.col)), shape=matrix.shape)
+
+
+class BiasScorer(Component):
+    """``BiasScorer`` (src/lenskit/basic/bias.py:278-360) over :class:`BiasModel`:
+    score = mu + b_i + b_u."""
+
+    config: BiasConfig
+
+    def is_trained(self):
+        return hasattr(self, "model")
+
+    def train(self, data: Dataset, options: TrainingOptions = TrainingOptions()):
+        self.model = BiasModel.learn(data, self.config.damping, entities=self.config.entities)
+
+    # the learned parameters, under the names the reference's scorer exposes
+    global_bias = property(lambda self: self.model.global_bias)
+    item_biases = property(lambda self: self.model.item_biases)
+    user_biases = property(lambda self: self.model.user_biases)
+    items = property(lambda self: self.model.items)
+    users = property(lambda self: self.model.users)
+
+    def __call__(self, query, items: ItemList) -> ItemList:
+        query = RecQuery.create(query)
+        scores, _ = self.model.compute_for_items(items, query.user_id, query.history_items)
         return ItemList(items, scores=scores)
 
 

@@ -119,18 +119,22 @@ __device__ __forceinline__ void ring_issue(GatherRing<NT> &R, const int slot_idx
 
 template <int NT, bool MASKED>
 __device__ __forceinline__ void ring_consume(Gram<NT> &G, const GatherRing<NT> &R,
-                                             const int slot_idx, const int g, const int nb)
+                                             const int slot_idx, const int g, const int nb,
+                                             const bool expl)
 {
     const int lane = lane_id();
     // MASKED (tail batch only): entries past the row end re-read the row's last entry; kill
     // their q so that neither A (v*q*q) nor y ((v+1)*q) sees them
     const bool live = !MASKED || (g * 4 + (lane >> 4)) < nb;
     const float v = R.v[slot_idx];
+    // implicit: A += v q q^T, y += (v + 1) q  (implicit.rs:110-117)
+    // explicit: A += q q^T,   y += v q        (explicit.rs:103,109; v = normalised rating)
+    const float va = expl ? 1.0f : v;
     float q[NT], a[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         q[t] = live ? R.q[slot_idx][t] : 0.f;
-        a[t] = q[t] * v;  // `mtl = mt * vals` (implicit.rs:110-111)
+        a[t] = q[t] * va;  // `mtl = mt * vals` (implicit.rs:110-111); exact for va == 1
     }
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj)
@@ -138,7 +142,7 @@ __device__ __forceinline__ void ring_consume(Gram<NT> &G, const GatherRing<NT> &
         for (int ti = 0; ti <= tj; ++ti)
             G.t[tidx(ti, tj)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], q[tj],
                                                                      G.t[tidx(ti, tj)], 0, 0, 0);
-    const float v1 = v + 1.0f;  // `vals += 1.0` (implicit.rs:116)
+    const float v1 = expl ? v : v + 1.0f;  // `vals += 1.0` (implicit.rs:116)
 #pragma unroll
     for (int t = 0; t < NT; ++t) G.y[t] = fmaf(q[t], v1, G.y[t]);
 }
@@ -147,7 +151,7 @@ template <int NT>
 __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__restrict__ cols,
                                                 const float *__restrict__ vals, int64_t beg,
                                                 int64_t end, const float *__restrict__ other,
-                                                int /*ld == 16*NT*/)
+                                                int /*ld == 16*NT*/, const bool expl)
 {
     // Every load below is UNCONDITIONAL (out-of-range lanes/groups re-read the row's last
     // entry, which is masked or never consumed): a load inside a branch makes the compiler
@@ -178,7 +182,7 @@ __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__re
         }
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            ring_consume<NT, false>(G, R, g % RING, g, 64);
+            ring_consume<NT, false>(G, R, g % RING, g, 64, expl);
             if (g < 16 - RING)
                 ring_issue<NT>(R, g % RING, g + RING, cur_col, cur_val, other);
             else
@@ -193,7 +197,7 @@ __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__re
         const int ngroups = (nb + 3) >> 2;
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            if (g < ngroups) ring_consume<NT, true>(G, R, g % RING, g, nb);
+            if (g < ngroups) ring_consume<NT, true>(G, R, g % RING, g, nb, expl);
             if (g < 16 - RING) ring_issue<NT>(R, g % RING, g + RING, cur_col, cur_val, other);
         }
     }
@@ -231,7 +235,7 @@ __device__ __forceinline__ void slab_add(Gram<NT> &G, const float *__restrict__ 
 }
 
 // ---- chunk kernel: one wave per chunk of a long row ------------------------
-template <int NT>
+template <int NT, bool EXPL>
 __global__ __launch_bounds__(256) void als_chunk_kernel(
     const int32_t *__restrict__ indices, const float *__restrict__ values,
     const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_len,
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256) void als_chunk_kernel(
 #pragma unroll
     for (int t = 0; t < NT; ++t) G.y[t] = 0.f;
     const int64_t beg = chunk_beg[c];
-    gram_accumulate<NT>(G, indices, values, beg, beg + chunk_len[c], other, ld);
+    gram_accumulate<NT>(G, indices, values, beg, beg + chunk_len[c], other, ld, EXPL);
     slab_store<NT>(G, slabs + (size_t)c * slab_floats<NT>());
 }
 
@@ -430,14 +434,16 @@ __host__ __device__ constexpr int solve_lds_floats()
                                                             : LPack<NT * 16>::SIZE + NT * 16;
 }
 
-template <int NT, bool IS64>
+// EXPL: explicit-feedback model (explicit.rs) instead of the implicit one (implicit.rs); a
+// template parameter so that the implicit instantiation carries nothing of it
+template <int NT, bool IS64, bool EXPL>
 __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_rows,
     const int32_t *__restrict__ row_slab, const float *__restrict__ other, int ld_other,
     float *__restrict__ this_, int ld_this, const float *__restrict__ otor_p,
     const float *__restrict__ slabs, float *__restrict__ row_delta, int *__restrict__ status,
-    int k)
+    int k, float reg)
 {
     constexpr int KP = NT * 16;
     __shared__ __attribute__((aligned(16))) float lds_all[4][solve_lds_floats<NT>()];
@@ -481,7 +487,17 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
         for (int s = 0; s < ns; ++s)
             slab_add<NT>(G, slabs + (size_t)(first_slab + s) * slab_floats<NT>());
     } else {
-        gram_accumulate<NT>(G, indices, values, beg, end, other, ld_other);
+        gram_accumulate<NT>(G, indices, values, beg, end, other, ld_other, EXPL);
+    }
+    if (EXPL) {
+        // explicit.rs:104-107: mtm[i][i] += reg * n, AFTER the product, real features only
+        // (the pad features keep the identity they got from otor_p)
+        const float dg = reg * (float)(end - beg);
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (slot * 4 + r == sub && (slot * 4 + r) * NT + ti < k) G.t[tidx(ti, ti)][r] += dg;
     }
 
     // y: combine the 4 entry slots -> every lane has the full y for feature (t, sub)
@@ -549,7 +565,7 @@ __global__ void als_prep_otor_kernel(const float *__restrict__ otor, int ld_otor
     int fr = (pr & 15) * NT + (pr >> 4), fc = (pc & 15) * NT + (pc >> 4);
     float v;
     if (fr < k && fc < k)
-        v = otor[fr * ld_otor + fc];
+        v = otor ? otor[fr * ld_otor + fc] : 0.f;  // explicit mode: no OtOr term
     else
         v = (pr == pc) ? 1.0f : 0.0f;
     otor_p[idx] = v;
@@ -602,11 +618,11 @@ int launch_delta_reduce(const float *row_delta, int64_t n_rows, float *partial, 
     return LK_OK;
 }
 
-template <int NT, bool IS64>
+template <int NT, bool IS64, bool EXPL = false>
 static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *indices,
                        const float *values, int64_t n_rows, int k, float *this_, int ld_this,
                        const float *other, int ld_other, const float *otor, int ld_otor,
-                       char *ws, float *out_frob, hipStream_t st)
+                       char *ws, float *out_frob, hipStream_t st, float reg = 0.f)
 {
     constexpr int KP = NT * 16;
     int *status = reinterpret_cast<int *>(ws + p->off_status);
@@ -621,17 +637,17 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
     const bool tm = p->timing && p->timing_n < lk_als_plan::TIMING_RING;
     if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][0], st));
     if (p->n_chunks > 0) {
-        hipLaunchKernelGGL(als_chunk_kernel<NT>, dim3((unsigned)((p->n_chunks + 3) / 4)),
+        hipLaunchKernelGGL((als_chunk_kernel<NT, EXPL>), dim3((unsigned)((p->n_chunks + 3) / 4)),
                            dim3(256), 0, st, indices, values, p->d_chunk_beg, p->d_chunk_len,
                            p->n_chunks, other, ld_other, slabs);
     }
     if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
     if (n_rows > 0) {
         using IT = typename IndPtr<IS64>::type;
-        hipLaunchKernelGGL((als_solve_kernel<NT, IS64>), dim3((unsigned)((n_rows + 3) / 4)),
+        hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL>), dim3((unsigned)((n_rows + 3) / 4)),
                            dim3(256), 0, st, static_cast<const IT *>(indptr), indices, values,
                            p->d_order, n_rows, p->d_row_slab, other, ld_other, this_, ld_this,
-                           otor_p, slabs, row_delta, status, k);
+                           otor_p, slabs, row_delta, status, k, reg);
     }
     if (tm) {
         LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][2], st));
@@ -859,6 +875,47 @@ extern "C" int lk_als_implicit_half_epoch(const lk_als_plan *plan, const void *d
     }
 #undef LK_CHOL_CASE
     lk::set_error("lk_als_implicit_half_epoch: no Cholesky kernel for padded k=%d", plan->KP);
+    return LK_E_INVALID;
+}
+
+extern "C" int lk_als_explicit_half_epoch(const lk_als_plan *plan, const void *d_indptr,
+                                          const int32_t *d_indices, const float *d_values,
+                                          int64_t n_rows, int64_t n_cols, int32_t k,
+                                          float *d_this, int32_t ld_this, const float *d_other,
+                                          int32_t ld_other, float reg, void *d_ws,
+                                          float *d_out_frob, void *stream)
+{
+    LK_REQUIRE(plan != nullptr, "lk_als_explicit_half_epoch: null plan");
+    LK_REQUIRE(n_rows == plan->n_rows && k == plan->k,
+               "lk_als_explicit_half_epoch: plan built for %lld rows, k=%d; got %lld rows, k=%d",
+               (long long)plan->n_rows, plan->k, (long long)n_rows, k);
+    LK_REQUIRE(ld_this == plan->KP && ld_other == plan->KP,
+               "lk_als_explicit_half_epoch: factor leading dimensions (%d, %d) must equal "
+               "lk_padded_dim(k)=%d",
+               ld_this, ld_other, plan->KP);
+    LK_REQUIRE(d_indptr && d_this && d_ws && d_out_frob,
+               "lk_als_explicit_half_epoch: null pointer");
+    LK_REQUIRE(n_cols >= 0 && (n_cols == 0 || d_other), "lk_als_explicit_half_epoch: null other");
+    LK_REQUIRE(plan->solver != LK_SOLVER_CG,
+               "lk_als_explicit_half_epoch: only the exact (Cholesky) solver is built for the "
+               "explicit model (k <= 64)");
+    hipStream_t st = lk::as_stream(stream);
+    char *ws = static_cast<char *>(d_ws);
+#define LK_CHOL_CASE(NT)                                                                         \
+    return plan->is64                                                                            \
+               ? lk::launch_chol<NT, true, true>(plan, d_indptr, d_indices, d_values, n_rows, k, \
+                                                 d_this, ld_this, d_other, ld_other, nullptr, 0, \
+                                                 ws, d_out_frob, st, reg)                        \
+               : lk::launch_chol<NT, false, true>(plan, d_indptr, d_indices, d_values, n_rows,   \
+                                                  k, d_this, ld_this, d_other, ld_other,         \
+                                                  nullptr, 0, ws, d_out_frob, st, reg)
+    switch (plan->NT) {
+        case 1: LK_CHOL_CASE(1);
+        case 2: LK_CHOL_CASE(2);
+        case 4: LK_CHOL_CASE(4);
+    }
+#undef LK_CHOL_CASE
+    lk::set_error("lk_als_explicit_half_epoch: no Cholesky kernel for padded k=%d", plan->KP);
     return LK_E_INVALID;
 }
 

@@ -183,6 +183,118 @@ int lko_als_implicit_half_epoch(void *sposv_ptr, const int64_t *indptr, const in
 }
 
 /* ------------------------------------------------------------------------- */
+/* Explicit (biased-MF) ALS: src/accel/als/explicit.rs:56-119                    */
+/* ------------------------------------------------------------------------- */
+
+/* One row: train_row_solve, explicit.rs:80-119.  A = M^T M + reg*n*I (the
+ * diagonal term is added AFTER the product, explicit.rs:104-107), rhs = M^T vals. */
+static float lko_als_explicit_row(lko_sposv_fn sposv, const int64_t *indptr,
+                                  const int32_t *indices, const float *values, int64_t row, int k,
+                                  float *row_data, const float *other, float reg, float *m,
+                                  float *a, float *y, int *err)
+{
+    int64_t sp = indptr[row], ep = indptr[row + 1];
+    int64_t n = ep - sp;
+    if (n == 0) { /* explicit.rs:91-94 */
+        for (int f = 0; f < k; f++) row_data[f] = 0.0f;
+        return 0.0f;
+    }
+    for (int64_t j = 0; j < n; j++)
+        memcpy(m + j * k, other + (int64_t)indices[sp + j] * k, sizeof(float) * k);
+    memset(a, 0, sizeof(float) * k * k);
+    for (int64_t j = 0; j < n; j++) { /* mtm = mt.dot(&o_picked)  (explicit.rs:103) */
+        const float *mj = m + j * k;
+        for (int f = 0; f < k; f++) {
+            float l = mj[f];
+            float *af = a + (int64_t)f * k;
+            for (int g = 0; g < k; g++) af[g] += l * mj[g];
+        }
+    }
+    {
+        float dg = reg * (float)n; /* reg * cols.len() as f32 */
+        for (int f = 0; f < k; f++) a[(int64_t)f * k + f] += dg;
+    }
+    memset(y, 0, sizeof(float) * k); /* v = mt.dot(&vals)  (explicit.rs:109) */
+    for (int64_t j = 0; j < n; j++) {
+        const float *mj = m + j * k;
+        float v = values[sp + j];
+        for (int f = 0; f < k; f++) y[f] += mj[f] * v;
+    }
+    {
+        char uplo = 'U';
+        int kk = k, nrhs = 1, info = 0;
+        sposv(&uplo, &kk, &nrhs, a, &kk, y, &kk, &info);
+        if (info != 0) {
+            *err = info;
+            return 0.0f;
+        }
+    }
+    float d2 = 0.0f;
+    for (int f = 0; f < k; f++) {
+        float d = y[f] - row_data[f];
+        row_data[f] = y[f];
+        d2 += d * d;
+    }
+    return d2;
+}
+
+/* Half-epoch: ExplicitTrainTask::invoke, explicit.rs:56-77; same contract as the implicit
+ * half-epoch above. */
+int lko_als_explicit_half_epoch(void *sposv_ptr, const int64_t *indptr, const int32_t *indices,
+                                const float *values, int64_t n_rows, int k, float *this_,
+                                const float *other, float reg, int n_threads, float *out_frob)
+{
+    lko_sposv_fn sposv = (lko_sposv_fn)sposv_ptr;
+    int64_t max_n = 0;
+    for (int64_t r = 0; r < n_rows; r++) {
+        int64_t n = indptr[r + 1] - indptr[r];
+        if (n > max_n) max_n = n;
+    }
+    int failed = 0;
+#ifdef _OPENMP
+    if (n_threads <= 0 || n_threads > LKO_MAX_THREADS) {
+        int cap = lko_num_threads();
+        n_threads = (n_threads <= 0 || n_threads > cap) ? cap : n_threads;
+    }
+#else
+    n_threads = 1;
+#endif
+    float *partials = (float *)calloc((size_t)n_threads, sizeof(float));
+#pragma omp parallel num_threads(n_threads)
+    {
+#ifdef _OPENMP
+        int tid = omp_get_thread_num();
+#else
+        int tid = 0;
+#endif
+        float *m = (float *)malloc(sizeof(float) * (size_t)(max_n > 0 ? max_n : 1) * k);
+        float *a = (float *)malloc(sizeof(float) * (size_t)k * k);
+        float *y = (float *)malloc(sizeof(float) * (size_t)k);
+        float acc = 0.0f;
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t r = 0; r < n_rows; r++) {
+            int err = 0;
+            float d2 = lko_als_explicit_row(sposv, indptr, indices, values, r, k, this_ + r * k,
+                                            other, reg, m, a, y, &err);
+            if (err) {
+#pragma omp critical
+                if (!failed) failed = err;
+            }
+            acc += d2;
+        }
+        partials[tid] = acc;
+        free(m);
+        free(a);
+        free(y);
+    }
+    float frob = 0.0f;
+    for (int t = 0; t < n_threads; t++) frob += partials[t];
+    free(partials);
+    *out_frob = sqrtf(frob);
+    return failed;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Item-item similarity build: src/accel/knn/item_train.rs:95-152              */
 /* ------------------------------------------------------------------------- */
 

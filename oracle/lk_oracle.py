@@ -139,6 +139,55 @@ def als_half_epoch(
     return float(frob.value)
 
 
+def als_explicit_half_epoch(
+    matrix: sps.csr_array, this: np.ndarray, other: np.ndarray, reg: float, n_threads=0
+) -> float:
+    """
+    ``train_explicit_matrix`` (src/accel/als/explicit.rs:33-119): one half-epoch of the
+    biased-MF ALS on the bias-normalised ratings; ``this`` is updated IN PLACE, returns
+    sqrt(sum ||delta row||^2) (f32).
+    """
+    assert this.dtype == np.float32 and this.flags.c_contiguous and this.flags.writeable
+    other = np.ascontiguousarray(other, dtype=np.float32)
+    n_rows, k = this.shape
+    assert matrix.shape[0] == n_rows and other.shape == (matrix.shape[1], k)
+    indptr = np.ascontiguousarray(matrix.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(matrix.indices, dtype=np.int32)
+    values = np.ascontiguousarray(matrix.data, dtype=np.float32)
+    frob = ctypes.c_float(0.0)
+    rc = lib().lko_als_explicit_half_epoch(
+        ctypes.c_void_p(_sposv_pointer()), _p(indptr, _i64p), _p(indices, _i32p),
+        _p(values, _f32p), ctypes.c_int64(n_rows), ctypes.c_int(k), _p(this, _f32p),
+        _p(other, _f32p), ctypes.c_float(reg), ctypes.c_int(n_threads), ctypes.byref(frob),
+    )  # fmt: skip
+    if rc != 0:
+        raise RuntimeError(f"ALS solve error: LAPACK info {rc}")  # explicit.rs:72
+    return float(frob.value)
+
+
+def als_explicit_half_epoch_f64(matrix: sps.csr_array, other: np.ndarray, reg: float):
+    "REFEREE (float64) for the explicit half-epoch, like :func:`als_half_epoch_f64`."
+    o64 = np.asarray(other, dtype=np.float64)
+    k = o64.shape[1]
+    out = np.zeros((matrix.shape[0], k), dtype=np.float64)
+    indptr, indices, data = matrix.indptr, matrix.indices, matrix.data
+    for r in range(matrix.shape[0]):
+        s, e = indptr[r], indptr[r + 1]
+        if e == s:
+            continue
+        M = o64[indices[s:e]]
+        A = M.T @ M + reg * (e - s) * np.eye(k)
+        out[r] = np.linalg.solve(A, M.T @ data[s:e].astype(np.float64))
+    return out
+
+
+def als_explicit_initial_params(rng: np.random.Generator, nrows: int, ncols: int) -> np.ndarray:
+    "``BiasedMFTrainer.initial_params`` (src/lenskit/als/_explicit.py:104-108): unit rows."
+    mat = rng.standard_normal((nrows, ncols), dtype=np.float32)
+    mat /= np.linalg.norm(mat, axis=1).reshape((nrows, 1))
+    return mat
+
+
 def als_half_epoch_f64(matrix: sps.csr_array, other: np.ndarray, reg: float) -> np.ndarray:
     """
     REFEREE, not the reference: the same half-epoch in float64 (Gramian, normal

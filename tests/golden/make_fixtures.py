@@ -14,7 +14,7 @@ Outputs (all under tests/golden/):
   ``rating`` (ratings.csv order) and ``all_item_ids`` (every movies.csv id; the
   modern MovieLens loader registers *all* of them as items,
   ``src/lenskit/data/sources/movielens.py:327-345``, so empty item rows exist).
-* ``pipelines/als-implicit.toml``, ``pipelines/iknn-explicit.toml`` -- verbatim copies of the
+* ``pipelines/als-implicit.toml``, ``iknn-explicit.toml``, ``als-explicit.toml`` -- verbatim copies of the
   reference's pipeline definitions (``pipelines/*.toml``), test INPUTS: the backend must load
   and run them unchanged (tests/test_gpu_pipeline.py, tests/test_host_logic.py).
 * ``item-item-preds.csv`` -- the reference's golden item-kNN predictions
@@ -47,7 +47,7 @@ def main():
     shutil.copyfile(REF / "tests/models/item-item-preds.csv", OUT / "item-item-preds.csv")
     # the two pipeline definitions the north star names: they must load and run UNCHANGED
     (OUT / "pipelines").mkdir(exist_ok=True)
-    for name in ("als-implicit.toml", "iknn-explicit.toml"):
+    for name in ("als-implicit.toml", "iknn-explicit.toml", "als-explicit.toml"):
         shutil.copyfile(REF / "pipelines" / name, OUT / "pipelines" / name)
     print("ratings", len(ratings), "items", len(movies))
 

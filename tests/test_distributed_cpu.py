@@ -42,6 +42,11 @@ class OracleBackend:
         d = self.lko.als_half_epoch(plan, view, other_full.numpy(), otor.numpy(), 2)
         return torch.tensor([d], dtype=torch.float32)
 
+    def half_epoch_explicit(self, plan, this_slice, other_full, reg):
+        view = this_slice.numpy()
+        d = self.lko.als_explicit_half_epoch(plan, view, other_full.numpy(), reg, 2)
+        return torch.tensor([d], dtype=torch.float32)
+
     def check(self, plan):
         pass
 
@@ -52,20 +57,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, ui, k, P0, Q0, epochs, out):
+def _worker(rank, world, port, ui, k, P0, Q0, epochs, out, explicit=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lkpy_amd._als_engine import ImplicitALSEngine
 
-        eng = ImplicitALSEngine(ui, k, 0.1, 0.2, P0, Q0, OracleBackend(k))
+        eng = ImplicitALSEngine(ui, k, 0.1, 0.2, P0, Q0, OracleBackend(k), explicit=explicit)
         deltas = []
         for _ in range(epochs):
             du, di = eng.train_epoch()
             deltas.append((float(du), float(di)))
-        out[rank] = (eng.user_embeddings(), eng.item_embeddings(), eng.otor(), deltas,
-                     eng.local_nnz)
+        out[rank] = (eng.user_embeddings(), eng.item_embeddings(),
+                     None if explicit else eng.otor(), deltas, eng.local_nnz)
     finally:
         dist.destroy_process_group()
 
@@ -122,3 +127,37 @@ def test_sharded_engine_matches_single_process(oracle, world):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     # and the shards really split the work
     assert out[0][4][0] + out[1][4][0] == ui.nnz and abs(out[0][4][0] - out[1][4][0]) < 0.2 * ui.nnz
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_explicit_engine_matches_single_process(oracle, world):
+    "The biased-MF (explicit) mode of the engine: same sharding and exchanges, no Gramian."
+    rng = np.random.default_rng(6)
+    n_users, n_items, k, epochs = 211, 97, 6, 3
+    mask = rng.random((n_users, n_items)) < 0.08
+    mask[:, 3] = False
+    mask[11, :] = False
+    vals = rng.standard_normal((n_users, n_items)).astype(np.float32)
+    vals[vals == 0] = 0.5
+    ui = sps.csr_array(np.where(mask, vals, 0).astype(np.float32))
+    ui.eliminate_zeros()
+    Q0 = oracle.als_explicit_initial_params(rng, n_items, k)
+    P0 = oracle.als_explicit_initial_params(rng, n_users, k)
+    P, Q = P0.copy(), Q0.copy()
+    iu = sps.csr_array(ui.T)
+    iu.sort_indices()
+    ref_d = []
+    for _ in range(epochs):
+        du = oracle.als_explicit_half_epoch(ui, P, Q, 0.1)
+        di = oracle.als_explicit_half_epoch(iu, Q, P, 0.2)
+        ref_d.append((du, di))
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ui, k, P0, Q0, epochs, out, True), nprocs=world,
+             join=True)
+    for r in range(world):
+        gP, gQ, _, gd, _ = out[r]
+        assert np.allclose(gP, P, rtol=1e-3, atol=1e-5) and np.allclose(gQ, Q, rtol=1e-3, atol=1e-5)
+        assert np.all(gQ[3] == 0) and np.all(gP[11] == 0)
+        assert np.allclose(np.array(gd), np.array(ref_d), rtol=1e-3)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

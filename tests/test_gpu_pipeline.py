@@ -215,3 +215,68 @@ def test_function_seam(gpu, oracle, ml_small, rng):
     import pyarrow as pa
 
     assert np.array_equal(_accel.data.argtopn(pa.array(s[:100]), 5), oracle.argtopn(s[:100], 5))
+
+
+def test_als_explicit_toml_trains_like_the_reference(gpu, oracle, ml_small, ml_ds):
+    """
+    ``pipelines/als-explicit.toml`` (the reference's file) through the component seam
+    (SURVEY.md 8f-2): bias model on the host, ALS epochs in the explicit mode of the HIP
+    kernel.  The trained factors are compared with the oracle run from the same init on
+    the same normalised matrix; predictions stay in the rating range, fold-in agrees with
+    the stored embedding, unknown items/users give NaN
+    (tests/models/test_als_explicit.py:48-180).
+    """
+    from lkpy_amd import als
+    from lkpy_amd.data import ItemList, RecQuery
+    from lkpy_amd.pipeline import Pipeline
+    from lkpy_amd.training import Trainable, TrainingOptions
+
+    pipe = Pipeline.load_config(GOLDEN / "pipelines" / "als-explicit.toml")
+    scorer = pipe.node("scorer").component
+    assert isinstance(scorer, als.BiasedMFScorer)
+    scorer.config.embedding_size = 20
+    scorer.config.epochs = 4
+    pipe.train(ml_ds, TrainingOptions(rng=42))
+    assert scorer.is_trained() and scorer.trained_epochs == 4
+    assert scorer.user_embeddings.shape == (671, 20) and scorer.item_embeddings.shape == (9125, 20)
+    rmat = ml_small["rmat"]
+    assert scorer.bias.global_bias == pytest.approx(float(np.mean(rmat.data)))
+
+    # oracle: same bias model, same seed child / init recipe, same epoch order
+    norm = scorer.bias.transform_matrix(sps.coo_array(rmat)).astype(np.float32)
+    ui = sps.csr_array(norm)
+    iu = sps.csr_array(ui.T)
+    ui.sort_indices()
+    iu.sort_indices()
+    trainables = [n for n, node in pipe.nodes.items()
+                  if node.component is not None and isinstance(node.component, Trainable)]
+    idx = trainables.index("scorer")
+    rng = np.random.default_rng(np.random.SeedSequence(42).spawn(idx + 1)[idx])
+    Q = oracle.als_explicit_initial_params(rng, ui.shape[1], 20)
+    P = oracle.als_explicit_initial_params(rng, ui.shape[0], 20)
+    for _ in range(4):
+        oracle.als_explicit_half_epoch(ui, P, Q, scorer.config.user_reg)
+        oracle.als_explicit_half_epoch(iu, Q, P, scorer.config.item_reg)
+    assert _rel(scorer.user_embeddings, P) < 5e-3 and _rel(scorer.item_embeddings, Q) < 5e-3
+    empty = np.bincount(rmat.col, minlength=9125) == 0
+    assert np.all(scorer.item_embeddings[empty] == 0)
+
+    # predictions: rating range, fold-in close to the stored row, NaN semantics
+    uid = int(ml_small["user_ids"][10])
+    items = ItemList(ml_ds.items.ids()[:200])
+    stored = pipe.run("scorer", query=uid, items=items).scores()
+    assert np.all(np.isfinite(stored)) and stored.min() > -1.0 and stored.max() < 7.0
+    hist = ml_ds.user_row(uid)
+    folded = scorer(RecQuery(user_id=uid, user_items=hist), items).scores()
+    assert np.allclose(folded, stored, rtol=9e-2, atol=0.3)
+    res = scorer(query=uid, items=ItemList([1, 2, -999]))
+    assert np.isnan(res.scores()[2]) and np.all(np.isfinite(res.scores()[:2]))
+    assert np.all(np.isnan(scorer(query=-12345, items=ItemList([1, 2])).scores()))
+    # rating-predictor of the std:topn-predict pipeline
+    pred = pipe.run("rating-predictor", query=uid, items=ItemList([1, 2, 3]))
+    assert np.all(np.isfinite(pred.scores()))
+    recs = pipe.run("recommender", query=uid, n=10)
+    assert len(recs) == 10 and recs.ordered
+    clone = pickle.loads(pickle.dumps(pipe))
+    r2 = clone.run("scorer", query=uid, items=items)
+    assert np.allclose(stored, r2.scores(), atol=1e-3)

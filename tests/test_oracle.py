@@ -243,3 +243,26 @@ def test_als_init_matches_reference_recipe(oracle):
     p2 = rng2.standard_normal((4, 3), dtype=np.float32) * 0.01
     p2 *= p2
     assert np.array_equal(q, q2) and np.array_equal(p, p2)
+
+
+def test_als_explicit_row_matches_float64(oracle, rng):
+    """explicit.rs:80-119 restated: A = M^T M + reg n I, rhs M^T r; against float64, with an
+    empty row (zeros, no delta) and the returned Frobenius delta."""
+    import scipy.sparse as sps
+
+    n_rows, n_cols, k = 90, 60, 12
+    mask = rng.random((n_rows, n_cols)) < 0.15
+    mask[4, :] = False
+    vals = rng.standard_normal((n_rows, n_cols)).astype(np.float32)
+    m = sps.csr_array(np.where(mask, vals, 0).astype(np.float32))
+    m.eliminate_zeros()
+    Q = oracle.als_explicit_initial_params(rng, n_cols, k)
+    P = oracle.als_explicit_initial_params(rng, n_rows, k)
+    assert np.allclose(np.linalg.norm(Q, axis=1), 1.0, atol=1e-6)  # _explicit.py:104-108
+    P1 = P.copy()
+    frob = oracle.als_explicit_half_epoch(m, P1, Q, 0.25)
+    want = oracle.als_explicit_half_epoch_f64(m, Q, 0.25)
+    assert np.allclose(P1, want, rtol=1e-4, atol=1e-5)
+    assert np.all(P1[4] == 0)
+    rows = np.arange(n_rows) != 4  # the empty row is zeroed but contributes no delta
+    assert frob == pytest.approx(np.sqrt(((P1 - P)[rows] ** 2).sum()), rel=1e-4)
