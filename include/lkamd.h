@@ -260,6 +260,21 @@ int lk_iknn_score_batch(const int64_t *d_sim_indptr, const int32_t *d_sim_indice
  * row with OtOr = Q^T Q + user_reg I: build a plan over the histories' CSR offsets and call
  * lk_als_implicit_half_epoch with `this` = the [n_queries x ld] output and `other` = Q. */
 
+/* ------------------------------------------------------------------------
+ * Stable CSR transpose on the device.
+ * Replaces `_accel.data.transpose_csr(structure, permute)` (src/lenskit/_accel/data.pyi:12,
+ * src/accel/data/transpose.rs:19-108; `SparseRowArray.transpose`, data/matrix.py:512-530):
+ * out_indptr [n_cols+1] (same width as the input offsets), out_indices [nnz] = source rows,
+ * out_perm [nnz] (same width; NULL = not wanted) = source entry position of every output
+ * entry; inside an output row the input's entry order is kept (counting sort), so the
+ * result equals the reference's entry for entry.  Asynchronous on `stream`.
+ * ---------------------------------------------------------------------- */
+size_t lk_csr_transpose_workspace_bytes(int64_t nnz, int64_t n_cols, int indptr_is_64);
+int lk_csr_transpose(const void *d_indptr, int indptr_is_64, const int32_t *d_indices,
+                     int64_t n_rows, int64_t n_cols, int64_t nnz, void *d_out_indptr,
+                     int32_t *d_out_indices, void *d_out_perm, void *d_ws, size_t ws_bytes,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,5 @@
 """``lenskit._accel.data`` stand-ins on the path: ``argtopn`` / ``argsort_descending``
-(src/accel/data/sorting.rs:69-172)."""
+(src/accel/data/sorting.rs:69-172) and ``transpose_csr`` (src/accel/data/transpose.rs:19-108)."""
 from __future__ import annotations
 
 import numpy as np
@@ -44,3 +44,20 @@ def argsort_descending(scores) -> np.ndarray:
     if valid == 0:
         return np.empty(0, dtype=np.int32)
     return argtopn(s, valid)
+
+
+def transpose_csr(matrix, permute: bool):
+    """
+    ``transpose_csr(structure, permute)`` (src/lenskit/_accel/data.pyi:12,
+    src/accel/data/transpose.rs:19-108): (row offsets, column indices, permutation | None) of
+    the transposed structure, same offset width as the input; stable (entries of an output
+    row in input order).
+    """
+    from ._util import as_csr_arrays
+
+    offsets, indices, _vals, shape = as_csr_arrays(matrix)
+    dev = D.device()
+    csr = D.DeviceCSR.from_arrays(offsets, indices, np.zeros(len(indices), np.float32), shape, dev)
+    t = D.csr_transpose(csr, with_values=bool(permute))
+    perm = t.perm.cpu().numpy() if permute else None
+    return t.indptr.cpu().numpy(), t.indices.cpu().numpy(), perm

@@ -415,3 +415,31 @@ def fold_in_explicit(hist: DeviceCSR, items: torch.Tensor, reg: float, k: int) -
     plan.half_epoch_explicit(out, items, reg)
     plan.check_status()
     return out
+
+
+def csr_transpose(csr: DeviceCSR, with_values: bool = True) -> DeviceCSR:
+    """
+    Stable transpose on the device (lk_csr_transpose; ``SparseRowArray.transpose`` /
+    ``_accel.data.transpose_csr``, src/lenskit/data/matrix.py:512-530,
+    src/accel/data/transpose.rs:19-108): entries of an output row keep the input's entry
+    order, i.e. ascending source row.  Offsets keep the input's width.
+    """
+    lib = _native.require_gpu()
+    n_rows, n_cols = csr.shape
+    nnz = int(csr.indices.shape[0])
+    dev = csr.indices.device
+    is64 = 1 if csr.indptr.dtype == torch.int64 else 0
+    wb = lib.lk_csr_transpose_workspace_bytes(nnz, n_cols, is64)
+    ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+    t_ptr = torch.empty(n_cols + 1, dtype=csr.indptr.dtype, device=dev)
+    t_idx = torch.empty(nnz, dtype=torch.int32, device=dev)
+    perm = torch.empty(nnz, dtype=csr.indptr.dtype, device=dev) if with_values else None
+    check(
+        lib.lk_csr_transpose(_ptr(csr.indptr), is64, _ptr(csr.indices), n_rows, n_cols, nnz,
+                             _ptr(t_ptr), _ptr(t_idx), _ptr(perm), _ptr(ws), wb, _stream()),
+        "lk_csr_transpose",
+    )
+    vals = csr.values[perm.long()] if with_values and csr.values is not None else None
+    out = DeviceCSR(t_ptr, t_idx, vals, (n_cols, n_rows), None)
+    out.perm = perm
+    return out

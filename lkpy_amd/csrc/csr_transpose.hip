@@ -1,0 +1,155 @@
+// csr_transpose.hip -- stable CSR transpose on the device, gfx950.
+//
+// Stands in for `transpose_csr` / `transpose_structure` (src/accel/data/transpose.rs:19-108;
+// used by `SparseRowArray.transpose`, src/lenskit/data/matrix.py:512-530): a counting sort of
+// the entries by column that keeps, inside each output row (= input column), the input's
+// entry order (= ascending input row).  Outputs: offsets of the transposed matrix, its
+// column indices (= input rows) and, optionally, the permutation (input entry position of
+// every output entry) with which values are carried over.
+//
+// A stable LSD radix sort of (column -> entry position) IS that counting sort, so the
+// result is identical to the reference's, entry for entry (integer work: bit-exact).  The
+// sort is rocPRIM's device radix sort (a plain library primitive, like rocBLAS for a plain
+// GEMM); the offsets come from a binary search per output row over the sorted columns, the
+// source rows from a binary search per entry over the input offsets.  HBM bound:
+// ~ (4 + W) * nnz bytes per sort pass over ceil(log2(n_cols) / 8) passes.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace lk {
+
+template <typename VT>
+__global__ void tr_iota_kernel(VT *__restrict__ v, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        v[i] = (VT)i;
+}
+
+// out_ptr[c] = first position in the sorted column list with column >= c
+template <typename IT>
+__global__ void tr_offsets_kernel(const uint32_t *__restrict__ sorted_cols, int64_t nnz,
+                                  int64_t n_cols, IT *__restrict__ out_ptr)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_cols) return;
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)sorted_cols[mid] < c)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    out_ptr[c] = (IT)lo;
+}
+
+// out_idx[pos] = row containing input entry perm[pos]; out_perm[pos] = perm[pos]
+template <typename IT, typename VT>
+__global__ void tr_rows_kernel(const IT *__restrict__ in_ptr, int64_t n_rows,
+                               const VT *__restrict__ perm, int64_t nnz,
+                               int32_t *__restrict__ out_idx, IT *__restrict__ out_perm)
+{
+    for (int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < nnz;
+         pos += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = (int64_t)perm[pos];
+        int64_t lo = 0, hi = n_rows;  // last row with in_ptr[row] <= e
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)in_ptr[mid + 1] <= e)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        out_idx[pos] = (int32_t)lo;
+        if (out_perm) out_perm[pos] = (IT)e;
+    }
+}
+
+static int key_bits(int64_t n_cols)
+{
+    int b = 1;
+    while (b < 32 && ((int64_t)1 << b) < n_cols) ++b;
+    return b;
+}
+
+template <typename IT, typename VT>
+static int transpose_impl(const IT *in_ptr, const int32_t *in_idx, int64_t n_rows, int64_t n_cols,
+                          int64_t nnz, IT *out_ptr, int32_t *out_idx, IT *out_perm, char *ws,
+                          size_t ws_bytes, hipStream_t st)
+{
+    uint32_t *keys_out = reinterpret_cast<uint32_t *>(ws);
+    size_t off = align_up((size_t)nnz * 4, 256);
+    VT *vals_in = reinterpret_cast<VT *>(ws + off);
+    off += align_up((size_t)nnz * sizeof(VT), 256);
+    VT *vals_out = reinterpret_cast<VT *>(ws + off);
+    off += align_up((size_t)nnz * sizeof(VT), 256);
+    void *tmp = ws + off;
+    size_t tmp_bytes = ws_bytes > off ? ws_bytes - off : 0;
+    const uint32_t *keys_in = reinterpret_cast<const uint32_t *>(in_idx);
+    if (nnz > 0) {
+        hipLaunchKernelGGL(tr_iota_kernel<VT>, dim3(1024), dim3(256), 0, st, vals_in, nnz);
+        LK_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in,
+                                               vals_out, (size_t)nnz, 0u,
+                                               (unsigned)key_bits(n_cols), st));
+        hipLaunchKernelGGL((tr_rows_kernel<IT, VT>), dim3(2048), dim3(256), 0, st, in_ptr, n_rows,
+                           vals_out, nnz, out_idx, out_perm);
+    }
+    hipLaunchKernelGGL(tr_offsets_kernel<IT>, dim3((unsigned)((n_cols + 256) / 256)), dim3(256),
+                       0, st, keys_out, nnz, n_cols, out_ptr);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+template <typename VT>
+static size_t sort_temp_bytes(int64_t nnz, int64_t n_cols)
+{
+    size_t bytes = 0;
+    if (nnz <= 0) return 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)nullptr,
+                                    (uint32_t *)nullptr, (const VT *)nullptr, (VT *)nullptr,
+                                    (size_t)nnz, 0u, (unsigned)key_bits(n_cols), (hipStream_t)0);
+    return bytes;
+}
+
+}  // namespace lk
+
+extern "C" size_t lk_csr_transpose_workspace_bytes(int64_t nnz, int64_t n_cols, int indptr_is_64)
+{
+    if (nnz < 0 || n_cols < 0) return 0;
+    const size_t vt = indptr_is_64 ? 8 : 4;
+    const size_t tmp = indptr_is_64 ? lk::sort_temp_bytes<uint64_t>(nnz, n_cols)
+                                    : lk::sort_temp_bytes<uint32_t>(nnz, n_cols);
+    return lk::align_up((size_t)nnz * 4, 256) + 2 * lk::align_up((size_t)nnz * vt, 256) +
+           lk::align_up(tmp, 256) + 256;
+}
+
+extern "C" int lk_csr_transpose(const void *d_indptr, int indptr_is_64, const int32_t *d_indices,
+                                int64_t n_rows, int64_t n_cols, int64_t nnz, void *d_out_indptr,
+                                int32_t *d_out_indices, void *d_out_perm, void *d_ws,
+                                size_t ws_bytes, void *stream)
+{
+    LK_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "lk_csr_transpose: negative size");
+    LK_REQUIRE(n_rows < (int64_t)INT32_MAX && n_cols < (int64_t)INT32_MAX,
+               "lk_csr_transpose: dimensions must fit int32 indices");
+    LK_REQUIRE(indptr_is_64 || nnz < (int64_t)INT32_MAX,
+               "lk_csr_transpose: nnz needs 64-bit offsets");
+    LK_REQUIRE(d_indptr && d_out_indptr && d_ws && (nnz == 0 || (d_indices && d_out_indices)),
+               "lk_csr_transpose: null pointer");
+    LK_REQUIRE(ws_bytes >= lk_csr_transpose_workspace_bytes(nnz, n_cols, indptr_is_64),
+               "lk_csr_transpose: workspace too small");
+    hipStream_t st = lk::as_stream(stream);
+    char *ws = static_cast<char *>(d_ws);
+    if (indptr_is_64)
+        return lk::transpose_impl<int64_t, uint64_t>(
+            static_cast<const int64_t *>(d_indptr), d_indices, n_rows, n_cols, nnz,
+            static_cast<int64_t *>(d_out_indptr), d_out_indices,
+            static_cast<int64_t *>(d_out_perm), ws, ws_bytes, st);
+    return lk::transpose_impl<int32_t, uint32_t>(
+        static_cast<const int32_t *>(d_indptr), d_indices, n_rows, n_cols, nnz,
+        static_cast<int32_t *>(d_out_indptr), d_out_indices, static_cast<int32_t *>(d_out_perm),
+        ws, ws_bytes, st);
+}

@@ -281,6 +281,14 @@ class SparseRowArray:
     def row_extent(self, row: int) -> tuple[int, int]:
         return int(self.offsets[row]), int(self.offsets[row + 1])
 
+    def transpose(self) -> "SparseRowArray":
+        "``SparseRowArray.transpose`` (matrix.py:512-530) through the device transpose."
+        from ._accel.data import transpose_csr
+
+        ptr, idx, perm = transpose_csr(self, self.values is not None)
+        vals = None if self.values is None else self.values[perm]
+        return SparseRowArray(ptr, idx, vals, (self.shape[1], self.shape[0]))
+
     def to_arrow(self):
         "Arrow (Large)List<Struct{index,value}> for interop with the reference's boundary."
         import pyarrow as pa

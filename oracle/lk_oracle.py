@@ -495,3 +495,20 @@ def load_ml_small(path=None):
         shape=(len(user_ids), len(item_ids)),
     )
     return {"user_ids": user_ids, "item_ids": item_ids, "rmat": rmat}
+
+
+def transpose_csr(indptr: np.ndarray, indices: np.ndarray, n_cols: int):
+    """
+    ``transpose_structure`` (src/accel/data/transpose.rs:42-108): counting sort of the entries
+    by column; returns (row_ptrs [n_cols+1], col_inds [nnz] = source rows, permutation [nnz] =
+    source entry positions), offsets in the input's dtype.  A stable argsort of the columns is
+    exactly the reference's three loops (count, prefix sum, place in input order).
+    """
+    indptr = np.asarray(indptr)
+    indices = np.asarray(indices, dtype=np.int32)
+    counts = np.bincount(indices, minlength=n_cols)
+    row_ptrs = np.zeros(n_cols + 1, dtype=indptr.dtype)
+    np.cumsum(counts, out=row_ptrs[1:])
+    perm = np.argsort(indices, kind="stable").astype(indptr.dtype)
+    rows = np.repeat(np.arange(len(indptr) - 1, dtype=np.int32), np.diff(indptr))
+    return row_ptrs, rows[perm], perm
