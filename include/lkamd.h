@@ -275,6 +275,25 @@ int lk_csr_transpose(const void *d_indptr, int indptr_is_64, const int32_t *d_in
                      int32_t *d_out_indices, void *d_out_perm, void *d_ws, size_t ws_bytes,
                      void *stream);
 
+/* ------------------------------------------------------------------------
+ * Item-kNN rating normalisation (`ItemKNNScorer._center_ratings` / `_normalize_rows`,
+ * src/lenskit/knn/item.py:202-228) on the ITEM-MAJOR matrix produced by lk_csr_transpose:
+ *   lk_iknn_prep_center: c = r - means[item] (d_means NULL: implicit feedback, c = r),
+ *       d_sumsq[item] = the |c|^2 of the item added one by one in entry (= user) order --
+ *       the order of the reference's norm -- and *d_nonzero_flag = any |c| > 1e-8;
+ *   lk_iknn_prep_scale: value = c * d_recip[item], written item-major and, through the
+ *       transpose's permutation (same width as the offsets), user-major.
+ * The per-item means (np.add.reduceat sums / counts) and recip = 1 / max(sqrt(sumsq),
+ * FLT_MIN) are computed by the caller with the reference's own NumPy calls, which makes the
+ * whole preparation bit-identical to the reference's.
+ * ---------------------------------------------------------------------- */
+int lk_iknn_prep_center(const void *d_item_indptr, int indptr_is_64, const float *d_item_values,
+                        const float *d_means, int64_t n_items, float *d_centered,
+                        float *d_sumsq, int32_t *d_nonzero_flag, void *stream);
+int lk_iknn_prep_scale(const void *d_item_indptr, int indptr_is_64, const void *d_perm,
+                       const float *d_centered, const float *d_recip, int64_t n_items,
+                       float *d_item_values_out, float *d_user_values_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -443,3 +443,66 @@ def csr_transpose(csr: DeviceCSR, with_values: bool = True) -> DeviceCSR:
     out = DeviceCSR(t_ptr, t_idx, vals, (n_cols, n_rows), None)
     out.perm = perm
     return out
+
+
+def iknn_prepare(ratings, explicit: bool = True, dev=None):
+    """
+    Item-kNN rating normalisation (``ItemKNNScorer._center_ratings`` / ``_normalize_rows``,
+    src/lenskit/knn/item.py:202-228) with the data on the device: ``ratings`` is the
+    users x items matrix (SciPy; values ignored and taken as 1 when ``explicit`` is false).
+    Returns (ui DeviceCSR, iu DeviceCSR, item means | None, all_zero flag) -- the two
+    orientations the similarity build consumes -- bit-identical to the reference's SciPy
+    preparation: the structure comes from the stable device transpose, every elementwise
+    step and the sequential sum of squares from csrc/iknn_prepare.hip, and the two per-item
+    vectors whose rounding depends on the host's NumPy (``np.add.reduceat`` sums, sqrt /
+    reciprocal of the norms) from the very calls the reference makes, on [n_items] arrays.
+    """
+    import scipy.sparse as sps
+
+    lib = _native.require_gpu()
+    dev = device(dev)
+    csr = sps.csr_array(ratings).astype(np.float32)
+    csr.sort_indices()
+    if not explicit:
+        csr = sps.csr_array((np.ones(csr.nnz, np.float32), csr.indices, csr.indptr), csr.shape)
+    n_users, n_items = csr.shape
+    dcsr = DeviceCSR.from_arrays(csr.indptr, csr.indices, csr.data, csr.shape, dev)
+    t = csr_transpose(dcsr)  # item-major values, offsets, users, permutation
+    is64 = 1 if t.indptr.dtype == torch.int64 else 0
+    t_ptr = t.indptr.cpu().numpy()
+    counts = np.diff(t_ptr)
+    means = d_means = None
+    if explicit:
+        # rmat.sum(axis=0) on the CSC matrix == np.add.reduceat over the non-empty items
+        # (scipy.sparse._compressed._cs_matrix.sum -> _minor_reduce), in the host's NumPy
+        vals_items = t.values.cpu().numpy()
+        nonempty = np.flatnonzero(counts)
+        sums = np.zeros(n_items, dtype=np.float32)
+        if len(nonempty):
+            sums[nonempty] = np.add.reduceat(vals_items, t_ptr[nonempty])
+        means = np.zeros(n_items, dtype=np.float32)
+        np.divide(sums, counts, out=means, where=counts > 0)
+        d_means = torch.from_numpy(means).to(dev)
+    nnz = t.nnz
+    cent = torch.empty(nnz, dtype=torch.float32, device=dev)
+    sumsq = torch.empty(n_items, dtype=torch.float32, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(
+        lib.lk_iknn_prep_center(_ptr(t.indptr), is64, _ptr(t.values), _ptr(d_means), n_items,
+                                _ptr(cent), _ptr(sumsq), _ptr(flag), _stream()),
+        "lk_iknn_prep_center",
+    )
+    norms = np.sqrt(sumsq.cpu().numpy())  # spla.norm(rmat, 2, axis=0)
+    recip = np.true_divide(1.0, np.maximum(norms, np.finfo("f4").smallest_normal))
+    d_recip = torch.from_numpy(np.ascontiguousarray(recip, dtype=np.float32)).to(dev)
+    v_items = torch.empty(nnz, dtype=torch.float32, device=dev)
+    v_users = torch.empty(nnz, dtype=torch.float32, device=dev)
+    check(
+        lib.lk_iknn_prep_scale(_ptr(t.indptr), is64, _ptr(t.perm), _ptr(cent), _ptr(d_recip),
+                               n_items, _ptr(v_items), _ptr(v_users), _stream()),
+        "lk_iknn_prep_scale",
+    )
+    all_zero = explicit and int(flag.item()) == 0
+    ui = DeviceCSR(dcsr.indptr, dcsr.indices, v_users, (n_users, n_items), dcsr.h_indptr)
+    iu = DeviceCSR(t.indptr, t.indices, v_items, (n_items, n_users), t_ptr)
+    return ui, iu, means, all_zero

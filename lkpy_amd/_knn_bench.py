@@ -62,12 +62,15 @@ def _score_batch_leg(D, ratings, means, sims, dev, n_users=10_000, n_targets=100
 def run(ratings: sps.csr_array, dev, reps: int = 2) -> dict:
     from . import _device as D
 
-    t0 = time.perf_counter()
-    ui, iu, means = prepare_explicit(ratings)
-    t_prep = time.perf_counter() - t0
-    dui = D.DeviceCSR.from_scipy(ui, dev)
-    diu = D.DeviceCSR.from_scipy(iu, dev)
+    # preparation (centre, normalise, both orientations): on the device, bit-identical to the
+    # reference's SciPy calls; timed from host CSR to normalised matrices resident in HBM
+    D.iknn_prepare(ratings[:64], True, dev)  # load kernels / sort plans outside the timing
     torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    dui, diu, means, _ = D.iknn_prepare(ratings, True, dev)
+    torch.cuda.synchronize(dev)
+    t_prep = time.perf_counter() - t0
+    ulen = np.diff(dui.h_indptr)
     times = []
     out = None
     for _ in range(reps):
@@ -77,7 +80,7 @@ def run(ratings: sps.csr_array, dev, reps: int = 2) -> dict:
         out = D.iknn_build(dui, diu, 1.0e-6, None)
         torch.cuda.synchronize(dev)
         times.append(time.perf_counter() - t0)
-    macs = int((np.diff(ui.indptr).astype(np.int64) ** 2).sum())
+    macs = int((ulen.astype(np.int64) ** 2).sum())
     best = min(times)
     nnz_out = int(out.indices.shape[0])
     del out
@@ -98,11 +101,11 @@ def run(ratings: sps.csr_array, dev, reps: int = 2) -> dict:
         "unit": "s",
         "higher_is_better": False,
         "build_seconds_all": [round(t, 4) for t in times],
-        "host_prepare_seconds": round(t_prep, 3),
+        "prepare_seconds": round(t_prep, 3),
         "nnz_out": nnz_out,
         "build_save_nbrs_100_seconds": round(min(t100), 4),
         "save_nbrs_100_nnz": int(sims.indices.shape[0]),
-        "train_seconds_incl_host_prepare": round(t_prep + best, 3),
+        "train_seconds_incl_prepare": round(t_prep + best, 3),
         "batch_score": score,
         "macs": macs,
         "gmacs_per_s": round(macs / best / 1e9, 2),

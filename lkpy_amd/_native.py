@@ -103,6 +103,8 @@ def _declare(lib):
             c_int, [vp, c_int32, c_int64, vp, c_int32, c_int64, c_int32, vp, c_int64, vp]
         ),
         "lk_argtopn": (c_int, [vp, c_int64, c_int64, c_int32, vp, vp, vp]),
+        "lk_iknn_prep_center": (c_int, [vp, c_int, vp, vp, c_int64, vp, vp, vp, vp]),
+        "lk_iknn_prep_scale": (c_int, [vp, c_int, vp, vp, vp, c_int64, vp, vp, vp]),
         "lk_csr_transpose_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
         "lk_csr_transpose": (
             c_int, [vp, c_int, vp, c_int64, c_int64, c_int64, vp, vp, vp, vp, c_size_t, vp]

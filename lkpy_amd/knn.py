@@ -11,7 +11,6 @@ import warnings
 from typing import Literal
 
 import numpy as np
-import scipy.sparse.linalg as spla
 import torch
 from pydantic import AliasChoices, BaseModel, Field, PositiveFloat, PositiveInt, field_validator
 
@@ -65,13 +64,13 @@ class ItemKNNScorer(Component):
         field = "rating" if self.config.explicit else None
         rmat = data.interactions().matrix().scipy(field, layout="coo").astype(np.float32)
         n_rows, n_items = rmat.shape
-        rmat, means = self._center_ratings(rmat)
-        rmat = self._normalize_rows(rmat)
-        ui = rmat.tocsr()
-        iu = rmat.T.tocsr()
         dev = D.device()
-        dui = D.DeviceCSR.from_scipy(ui, dev)
-        diu = D.DeviceCSR.from_scipy(iu, dev)
+        # centring + normalisation (item.py:142-156,202-228) on the device, bit-identical to
+        # the SciPy calls of the reference (see _device.iknn_prepare)
+        dui, diu, means, all_zero = D.iknn_prepare(rmat, self.config.explicit, dev)
+        if all_zero:
+            warnings.warn("Ratings seem to have the same value, centering is not recommended.",
+                          DataWarning)
         out = D.iknn_build(dui, diu, self.config.min_sim, self.config.save_nbrs)
         self.items = data.items
         self.item_means = None if means is None else np.asarray(means)
@@ -81,27 +80,6 @@ class ItemKNNScorer(Component):
                                          out.values.cpu().numpy(), (n_items, n_items))
         assert self.sim_matrix.offsets.dtype == np.int64  # LargeList (item.py:176)
         self._dev = {"sims": out, "device": dev}
-
-    def _center_ratings(self, rmat):
-        "item.py:202-220"
-        if not self.config.explicit:
-            return rmat, None
-        rmat = rmat.tocsc()
-        counts = np.diff(rmat.indptr)
-        sums = rmat.sum(axis=0)
-        means = np.zeros(sums.shape, dtype=np.float32)
-        np.divide(sums, counts, out=means, where=counts > 0)
-        rmat.data = rmat.data - np.repeat(means, counts)
-        if np.allclose(rmat.data, 0.0):
-            warnings.warn("Ratings seem to have the same value, centering is not recommended.",
-                          DataWarning)
-        return rmat, means
-
-    def _normalize_rows(self, rmat):
-        "item.py:222-228"
-        norms = spla.norm(rmat, 2, axis=0)
-        cmat = rmat / np.maximum(norms, np.finfo("f4").smallest_normal)
-        return cmat.astype(np.float32)
 
     def _device_sims(self):
         dev = getattr(self, "_dev", None)
