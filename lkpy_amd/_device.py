@@ -449,7 +449,8 @@ def iknn_prepare(ratings, explicit: bool = True, dev=None):
     """
     Item-kNN rating normalisation (``ItemKNNScorer._center_ratings`` / ``_normalize_rows``,
     src/lenskit/knn/item.py:202-228) with the data on the device: ``ratings`` is the
-    users x items matrix (SciPy; values ignored and taken as 1 when ``explicit`` is false).
+    users x items matrix (SciPy; for implicit feedback the caller passes the interaction
+    matrix of ones, like the reference) and ``explicit`` selects the item-mean centring.
     Returns (ui DeviceCSR, iu DeviceCSR, item means | None, all_zero flag) -- the two
     orientations the similarity build consumes -- bit-identical to the reference's SciPy
     preparation: the structure comes from the stable device transpose, every elementwise
@@ -463,8 +464,6 @@ def iknn_prepare(ratings, explicit: bool = True, dev=None):
     dev = device(dev)
     csr = sps.csr_array(ratings).astype(np.float32)
     csr.sort_indices()
-    if not explicit:
-        csr = sps.csr_array((np.ones(csr.nnz, np.float32), csr.indices, csr.indptr), csr.shape)
     n_users, n_items = csr.shape
     dcsr = DeviceCSR.from_arrays(csr.indptr, csr.indices, csr.data, csr.shape, dev)
     t = csr_transpose(dcsr)  # item-major values, offsets, users, permutation

@@ -19,6 +19,8 @@ def test_prepare_ml_small_bit_exact(gpu, oracle, ml_small, explicit):
     from lkpy_amd import _device as D
 
     rmat = ml_small["rmat"]
+    if not explicit:  # the interaction matrix of an implicit-feedback model holds ones
+        rmat = sps.coo_array((np.ones(rmat.nnz, np.float32), (rmat.row, rmat.col)), rmat.shape)
     ui, iu, means, zero = oracle.iknn_prepare(rmat, explicit)
     dui, diu, dmeans, dzero = D.iknn_prepare(rmat, explicit, gpu)
     _same(dui, ui)
