@@ -310,7 +310,14 @@ def main():
     if roof:
         out["roofline"] = roof
 
-    if rank == 0 and world == 1 and not args.no_topk:
+    # The secondary legs must never cost the headline line: a failure is reported in place.
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as exc:  # noqa: BLE001 -- reported, not swallowed
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+
+    def topk_leg():
         # dense scoring + top-100 for ALL users with the factors just trained (north star:
         # "batched dense top-K scoring", f32 MFMA); exclusion of the users' own items included
         from lkpy_amd import _device as D
@@ -325,7 +332,7 @@ def main():
             ts.append(time.perf_counter() - t0)
         tb = min(ts)
         fl = 2.0 * eng.P.shape[0] * eng.Q.shape[0] * k
-        out["topk"] = {
+        return {
             "metric": "dense scoring + top-100 of all users x all items (k=%d), seconds" % k,
             "value": round(tb, 4),
             "unit": "s",
@@ -335,17 +342,24 @@ def main():
             "note": "GEMM + exclusion mask + selection; the score panel kernel alone reaches "
             "0.62 of the f32 MFMA peak at k=128 (profiles/r01_topk_*)",
         }
-    if rank == 0 and world == 1 and not args.no_knn:
-        try:
-            from lkpy_amd import _knn_bench  # noqa: F401
 
-            out["knn"] = _knn_bench.run(ratings, dev)
-            if not args.no_cpu:
-                out["knn"]["cpu_baseline"] = cpu_baseline_knn(ratings)
-        except ImportError:
-            pass
+    def knn_leg():
+        from lkpy_amd import _knn_bench
+
+        res = _knn_bench.run(ratings, dev)
+        if not args.no_cpu:
+            try:
+                res["cpu_baseline"] = cpu_baseline_knn(ratings)
+            except Exception as exc:  # noqa: BLE001
+                res["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
+        return res
+
+    if rank == 0 and world == 1 and not args.no_topk:
+        leg("topk", topk_leg)
+    if rank == 0 and world == 1 and not args.no_knn:
+        leg("knn", knn_leg)
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(ui, k, reg)
+        leg("cpu_baseline", lambda: cpu_baseline(ui, k, reg))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
