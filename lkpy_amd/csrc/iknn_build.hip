@@ -559,8 +559,8 @@ static int check_args(const lk_iknn_plan *plan, const void *a, const void *b, co
     LK_REQUIRE(plan && ws, "%s: null plan/workspace", who);
     LK_REQUIRE(plan->n_tasks == 0 || (a && b), "%s: null CSR pointer", who);
     LK_REQUIRE(save_nbrs <= 0,
-               "%s: save_nbrs truncation is not implemented in the HIP build yet "
-               "(save_nbrs must be <= 0 / None)",
+               "%s: pass save_nbrs <= 0 here and truncate the result with "
+               "lk_iknn_truncate_count / lk_iknn_truncate_fill",
                who);
     return LK_OK;
 }
