@@ -183,3 +183,39 @@ def test_bias_model_normalisation_round_trip():
     assert ub2 == pytest.approx(exp)
     assert m.compute_for_items(ItemList([10]), bias=0.25)[0] == pytest.approx(
         mu + m.item_biases[0] + 0.25)
+
+
+def test_biased_mf_host_side(oracle):
+    """The host half of the biased-MF component (src/lenskit/als/_explicit.py): config
+    defaults, the unit-row init recipe, and ``finalize_scores`` adding b_g + b_i + b_u back."""
+    from types import SimpleNamespace
+
+    from lkpy_amd.als import BiasedMFConfig, BiasedMFScorer, BiasedMFTrainer
+    from lkpy_amd.basic import BiasModel
+    from lkpy_amd.data import ItemList, from_interactions_df
+
+    cfg = BiasedMFConfig(features=20, regularization={"user": 0.2, "item": 0.05})
+    assert cfg.embedding_size == 20 and cfg.user_reg == 0.2 and cfg.item_reg == 0.05
+    assert cfg.damping == 5.0 and cfg.epochs == 10
+
+    # initial_params: same stream, same arithmetic as the oracle's restatement
+    fake = SimpleNamespace(rng=np.random.default_rng(7))
+    got = BiasedMFTrainer.initial_params(fake, 50, 8)
+    want = oracle.als_explicit_initial_params(np.random.default_rng(7), 50, 8)
+    assert np.array_equal(got, want) and got.dtype == np.float32
+
+    df = pd.DataFrame({"user_id": [1, 1, 2, 2, 3], "item_id": [10, 20, 10, 30, 20],
+                       "rating": [4.0, 3.0, 2.0, 5.0, 1.0]})
+    ds = from_interactions_df(df)
+    sc = BiasedMFScorer()
+    sc.bias = BiasModel.learn(ds, damping=5.0)
+    sc.items, sc.users = ds.items, ds.users
+    raw = ItemList([10, 20, 30], scores=np.array([0.5, -0.25, 0.0], np.float32))
+    out = sc.finalize_scores(0, raw, None)  # stored user 0 -> its stored bias
+    b = sc.bias
+    want = raw.scores() + b.global_bias + b.item_biases + b.user_biases[0]
+    assert np.allclose(out.scores(), want)
+    out2 = sc.finalize_scores(None, raw, 0.75)  # fold-in supplies the user bias
+    assert np.allclose(out2.scores(), raw.scores() + b.global_bias + b.item_biases + 0.75)
+    out3 = sc.finalize_scores(None, raw, None)  # unknown user, no ratings: bias 0
+    assert np.allclose(out3.scores(), raw.scores() + b.global_bias + b.item_biases)
