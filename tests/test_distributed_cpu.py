@@ -161,3 +161,38 @@ def test_sharded_explicit_engine_matches_single_process(oracle, world):
         assert np.all(gQ[3] == 0) and np.all(gP[11] == 0)
         assert np.allclose(np.array(gd), np.array(ref_d), rtol=1e-3)
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("explicit", [False, True])
+def test_engine_single_process_relabelling_round_trip(oracle, explicit):
+    """world = 1 (no process group): the longest-first relabelling of users and items is
+    invisible from outside -- factors come back in the caller's order and equal the plain
+    reference-order run."""
+    from lkpy_amd._als_engine import ImplicitALSEngine
+
+    rng = np.random.default_rng(9)
+    n_users, n_items, k = 120, 70, 5
+    mask = rng.random((n_users, n_items)) < 0.1
+    vals = np.where(mask, rng.standard_normal((n_users, n_items)) if explicit else 40.0, 0)
+    ui = sps.csr_array(vals.astype(np.float32))
+    ui.eliminate_zeros()
+    iu = sps.csr_array(ui.T)
+    iu.sort_indices()
+    init = oracle.als_explicit_initial_params if explicit else oracle.als_initial_params
+    Q0, P0 = init(rng, n_items, k), init(rng, n_users, k)
+    P, Q = P0.copy(), Q0.copy()
+    for _ in range(2):
+        if explicit:
+            oracle.als_explicit_half_epoch(ui, P, Q, 0.1)
+            oracle.als_explicit_half_epoch(iu, Q, P, 0.2)
+        else:
+            oracle.als_half_epoch(ui, P, Q, oracle.implicit_otor(Q, 0.1))
+            oracle.als_half_epoch(iu, Q, P, oracle.implicit_otor(P, 0.2))
+    eng = ImplicitALSEngine(ui, k, 0.1, 0.2, P0, Q0, OracleBackend(k), explicit=explicit)
+    assert eng.world == 1
+    for _ in range(2):
+        eng.train_epoch()
+    assert np.allclose(eng.user_embeddings(), P, rtol=1e-3, atol=1e-5)
+    assert np.allclose(eng.item_embeddings(), Q, rtol=1e-3, atol=1e-5)
+    if not explicit:
+        assert np.allclose(eng.otor(), oracle.implicit_otor(Q, 0.1), rtol=1e-3, atol=1e-5)

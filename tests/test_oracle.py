@@ -296,3 +296,45 @@ def test_transpose_csr_matches_scipy_and_reference_loops(oracle, rng):
     t.sort_indices()
     assert np.array_equal(ptr, t.indptr) and np.array_equal(idx, t.indices)
     assert np.array_equal(m.data[perm], t.data)
+
+
+def test_oracle_properties_hypothesis(oracle):
+    """Randomised invariants of the integer / selection oracles (they are the checkers of the
+    GPU tests, so they get their own adversarial inputs): transpose twice = identity and the
+    permutation is a bijection; top-N is a prefix of the full descending sort, never contains
+    NaN, and is stable under appending smaller values."""
+    import scipy.sparse as sps
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 30), st.integers(1, 30), st.floats(0.0, 0.6), st.integers(0, 2**31 - 1))
+    def transpose_roundtrip(n_rows, n_cols, density, seed):
+        m = sps.random(n_rows, n_cols, density=density, format="csr", dtype=np.float32,
+                       random_state=seed)
+        m.sort_indices()
+        ptr, idx, perm = oracle.transpose_csr(m.indptr, m.indices, n_cols)
+        assert sorted(perm.tolist()) == list(range(m.nnz))
+        assert ptr[0] == 0 and ptr[-1] == m.nnz and np.all(np.diff(ptr) >= 0)
+        ptr2, idx2, perm2 = oracle.transpose_csr(ptr, idx, n_rows)
+        assert np.array_equal(ptr2, m.indptr) and np.array_equal(idx2, m.indices)
+        assert np.array_equal(perm[perm2], np.arange(m.nnz))
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(st.one_of(st.floats(-5, 5, width=32), st.just(float("nan"))), min_size=1,
+                    max_size=60), st.integers(1, 70))
+    def topn_prefix(values, n):
+        s = np.asarray(values, dtype=np.float32)
+        top = oracle.argtopn(s, n)
+        full = oracle.argsort_descending(s)
+        valid = int(np.sum(~np.isnan(s)))
+        assert len(top) == min(n, valid) and len(full) == valid
+        assert not np.isnan(s[top]).any()
+        assert np.array_equal(s[top], s[full][: len(top)])  # same scores, position by position
+        assert np.all(np.diff(s[top]) <= 0)
+        bigger = np.concatenate([s, np.full(3, -9.0, np.float32)])
+        if len(top) == n:
+            assert np.array_equal(s[top], bigger[oracle.argtopn(bigger, n)])
+
+    transpose_roundtrip()
+    topn_prefix()
