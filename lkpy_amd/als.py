@@ -115,7 +115,13 @@ class ImplicitMFScorer(UsesTrainer, Component):
 
     # -- fold-in --------------------------------------------------------------------
     def _history_rows(self, queries: list[RecQuery]):
-        "histories -> CSR (queries x items) of confidence values (_implicit.py:77-99)."
+        """
+        histories -> CSR (queries x items) of confidence values (_implicit.py:77-99).
+        History items the model does not know are DROPPED: the reference builds the ``ri_good``
+        mask for exactly that (_implicit.py:82-90) although its ``numbers()`` call raises
+        ``KeyError`` first (default ``missing="error"``, data/_items.py:617,654-655); a batch
+        must not fail because one history mentions a new item.
+        """
         idx, val, ptr = [], [], [0]
         for q in queries:
             hist = q.query_items

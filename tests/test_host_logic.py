@@ -219,3 +219,27 @@ def test_biased_mf_host_side(oracle):
     assert np.allclose(out2.scores(), raw.scores() + b.global_bias + b.item_biases + 0.75)
     out3 = sc.finalize_scores(None, raw, None)  # unknown user, no ratings: bias 0
     assert np.allclose(out3.scores(), raw.scores() + b.global_bias + b.item_biases)
+
+
+def test_implicit_history_rows_drop_unknown_items():
+    """Fold-in input of the batched kernel: histories become a CSR of
+    confidence values, sorted by item number; items the model does not know are dropped, an
+    empty or missing history gives an empty row."""
+    from lkpy_amd.als import ImplicitMFConfig, ImplicitMFScorer
+    from lkpy_amd.data import ItemList, RecQuery, Vocabulary
+
+    sc = ImplicitMFScorer(ImplicitMFConfig(weight=40.0))
+    sc.items = Vocabulary(np.array([10, 20, 30, 40]))
+    qs = [RecQuery(user_items=ItemList([30, 999, 10])), RecQuery(user_id=5),
+          RecQuery(user_items=ItemList([40]))]
+    ptr, idx, val = sc._history_rows(qs)
+    assert ptr.tolist() == [0, 2, 2, 3] and ptr.dtype == np.int64
+    assert idx.tolist() == [0, 2, 3] and idx.dtype == np.int32  # sorted, 999 dropped
+    assert val.tolist() == [40.0, 40.0, 40.0] and val.dtype == np.float32
+    sc2 = ImplicitMFScorer(ImplicitMFConfig(weight=2.0, use_ratings=True))
+    sc2.items = sc.items
+    _, idx2, val2 = sc2._history_rows(
+        [RecQuery(user_items=ItemList([20, 10], rating=np.array([3.0, 5.0])))])
+    assert idx2.tolist() == [0, 1] and val2.tolist() == [10.0, 6.0]  # rating * weight, reordered
+    with pytest.raises(ValueError):
+        sc2._history_rows([RecQuery(user_items=ItemList([20]))])  # use_ratings without ratings
