@@ -66,6 +66,33 @@ int lk_unpad_rows(const float *d_src, int64_t n, int32_t k, int32_t ld_src, floa
                   int32_t ld_dst, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Task control: cooperative cancel + live progress for the long-running entry points.
+ * Replaces the `AccelTask` pyclass protocol (src/accel/tasks/mod.rs:33-106: `cancel()` sets a
+ * flag the rayon workers poll, `current_progress()` reads an atomic row counter) that
+ * `run_accel_task` drives from the main thread while `invoke` runs on a helper thread
+ * (src/lenskit/parallel/_task.py:34-57).
+ *   - the control block owns two words in pinned, device-mapped host memory: `cancel`
+ *     (lk_task_ctl_cancel stores 1; callable from any thread while kernels run) and
+ *     `rows_done` (the kernels post their running count there every 256 units;
+ *     lk_task_ctl_progress reads it without touching the device or the stream);
+ *   - attach it with lk_als_plan_set_ctl / lk_iknn_plan_set_ctl (NULL detaches); attached
+ *     kernels skip every row (task) that has not started once the cancel is seen, and the
+ *     entry point that synchronises next -- lk_als_check_status, lk_iknn_build_count,
+ *     lk_iknn_build_fill -- returns LK_E_CANCELLED (outputs are then unspecified, like a
+ *     cancelled rayon job's);
+ *   - progress unit = rows (tasks/mod.rs:97-105); exact after the synchronising call.
+ * Without a control block the kernels carry no polling code at all.
+ * ---------------------------------------------------------------------- */
+typedef struct lk_task_ctl lk_task_ctl;
+int lk_task_ctl_create(lk_task_ctl **out);
+void lk_task_ctl_destroy(lk_task_ctl *ctl);
+void lk_task_ctl_cancel(lk_task_ctl *ctl);
+int lk_task_ctl_cancelled(const lk_task_ctl *ctl);
+/* clear the cancel flag and the progress count (before reusing the block) */
+void lk_task_ctl_reset(lk_task_ctl *ctl);
+int lk_task_ctl_progress(const lk_task_ctl *ctl, int64_t *rows_done, int64_t *rows_total);
+
+/* ------------------------------------------------------------------------
  * Gramian:  out = M^T M + reg * I          (k x k, row-major, ld_out floats)
  * Replaces `_implicit_otor` (src/lenskit/als/_implicit.py:177-184), a NumPy
  * sgemm in the reference.  `d_ws` must hold lk_gramian_workspace_bytes(k).
@@ -101,6 +128,8 @@ int32_t lk_als_plan_solver(const lk_als_plan *plan);
 /* CG controls (ignored by the Cholesky solver): stop when ||r|| <= tol*||y|| or
  * after max_iter iterations (<=0: k iterations).  Defaults 1e-7 / k. */
 int lk_als_plan_set_cg(lk_als_plan *plan, float tol, int32_t max_iter);
+/* Attach a task-control block (cancel / progress) to every half-epoch run with this plan. */
+int lk_als_plan_set_ctl(lk_als_plan *plan, lk_task_ctl *ctl);
 
 int lk_als_implicit_half_epoch(const lk_als_plan *plan, const void *d_indptr,
                                const int32_t *d_indices, const float *d_values, int64_t n_rows,
@@ -172,6 +201,7 @@ int lk_iknn_plan_create_rows(lk_iknn_plan **out, const void *h_ui_indptr,
                              const void *h_iu_indptr, int indptr_is_64, int64_t n_users,
                              int64_t n_items, int64_t row_begin, int64_t row_end);
 void lk_iknn_plan_destroy(lk_iknn_plan *plan);
+int lk_iknn_plan_set_ctl(lk_iknn_plan *plan, lk_task_ctl *ctl);
 size_t lk_iknn_plan_workspace_bytes(const lk_iknn_plan *plan);
 
 int lk_iknn_build_count(const lk_iknn_plan *plan, const void *d_ui_indptr,
@@ -213,8 +243,14 @@ int lk_score_dense(const float *d_users, int32_t ld_users, int64_t n_users, cons
                    int32_t ld_items, int64_t n_items, int32_t k, float *d_out, int64_t ld_out,
                    void *stream);
 
-/* Plain top-N over score vectors already in HBM (one row per query), the
- * direct stand-in for `_accel.data.argtopn(scores, n)`. */
+/* Plain top-N over score vectors already in HBM (one row per query), the direct stand-in for
+ * `_accel.data.argtopn(scores, n)` (src/accel/data/sorting.rs:132-172) and, with n < 0, for
+ * `_accel.data.argsort_descending(scores)` (sorting.rs:69-103): every valid entry by descending
+ * score.  d_out_idx is [n_rows x min(n, row_len)] (n < 0: [n_rows x row_len]), -1 padded.
+ * n <= 4096 runs the selection kernel and needs no workspace; n < 0 or n > 4096 is a full
+ * stable sort and needs lk_argtopn_workspace_bytes(n_rows, row_len, n) bytes at d_ws.
+ * (lk_score_topk likewise: n < 0 ranks all candidates, output [n_users x n_items].) */
+size_t lk_argtopn_workspace_bytes(int64_t n_rows, int64_t row_len, int32_t n);
 int lk_argtopn(const float *d_scores, int64_t n_rows, int64_t row_len, int32_t n, void *d_ws,
                int32_t *d_out_idx, void *stream);
 

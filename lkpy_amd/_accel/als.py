@@ -21,6 +21,8 @@ def train_implicit_matrix(matrix, this: np.ndarray, other: np.ndarray, otor: np.
             this.flags.c_contiguous and this.flags.writeable):
         raise TypeError("this must be a writeable C-contiguous float32 array")
     offsets, indices, values, shape = as_csr_arrays(matrix)
+    if values is None:
+        raise TypeError("train_implicit_matrix needs a sparse matrix with values")
     rows, k = this.shape
     other = np.ascontiguousarray(other, dtype=np.float32)
     otor = np.ascontiguousarray(otor, dtype=np.float32)
@@ -30,13 +32,14 @@ def train_implicit_matrix(matrix, this: np.ndarray, other: np.ndarray, otor: np.
         dev = D.device()
         csr = D.DeviceCSR.from_arrays(offsets, indices, values, shape, dev)
         plan = D.ALSPlan(csr, k, solver)
+        ctl = D.TaskCtl()
+        plan.set_ctl(ctl)
+        task.attach(ctl)  # cancel() / current_progress() now reach the running kernels
         d_this = D.to_device_padded(this, dev)
         d_other = D.to_device_padded(other, dev)
         d_otor = torch.from_numpy(otor).to(dev)
-        if task.cancelled:
-            raise KeyboardInterrupt("cancelled")
         frob = plan.half_epoch(d_this, d_other, d_otor)
-        plan.check_status()
+        plan.check_status()  # KeyboardInterrupt if cancelled, RuntimeError if a solve failed
         this[...] = D.to_host_unpadded(d_this, k)
         task.set_progress(rows)
         return float(frob.item())

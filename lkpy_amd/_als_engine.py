@@ -161,6 +161,12 @@ class ImplicitALSEngine:
         Q[self.i_new] = item_init
         self.P = backend.upload(P)
         self.Q = backend.upload(Q)
+        if self.world > 1:
+            # every rank must start from the SAME factors (the first user half mixes the local Q
+            # with an all-reduced Gramian): rank 0's initialisation wins, whatever the ranks'
+            # generators drew (unseeded runs draw differently on every rank)
+            dist.broadcast(self.P, src=_global_rank(group, 0), group=self.group)
+            dist.broadcast(self.Q, src=_global_rank(group, 0), group=self.group)
         # Gramian of the initial Q (user half of epoch 1 needs it); padding rows are 0
         self._qtq = None if self.explicit else self._gramian(self.Q, self.i_lo, self.i_hi,
                                                              self.user_reg)
@@ -233,6 +239,10 @@ class ImplicitALSEngine:
         assert not self.explicit
         g = self._qtq
         return g.cpu().numpy() if isinstance(g, torch.Tensor) else np.asarray(g)
+
+
+def _global_rank(group, group_rank: int) -> int:
+    return dist.get_global_rank(group, group_rank) if group is not None else group_rank
 
 
 def _dist_on() -> bool:

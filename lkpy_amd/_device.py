@@ -114,6 +114,43 @@ class DeviceCSR:
         return cls.from_arrays(mat.indptr, mat.indices, mat.data, mat.shape, dev)
 
 
+class TaskCtl:
+    """
+    Cancel + progress words of a long-running call (``lk_task_ctl``; the ``AccelTask``
+    protocol of src/accel/tasks/mod.rs:62-106): ``cancel()`` may be called from any thread
+    while the kernels run, ``progress()`` reads the live row count from pinned host memory.
+    """
+
+    def __init__(self):
+        lib = _native.require_gpu()
+        self._h = ctypes.c_void_p(0)
+        check(lib.lk_task_ctl_create(ctypes.byref(self._h)), "lk_task_ctl_create")
+
+    def cancel(self):
+        _native.load().lk_task_ctl_cancel(self._h)
+
+    @property
+    def cancelled(self) -> bool:
+        return bool(_native.load().lk_task_ctl_cancelled(self._h))
+
+    def reset(self):
+        _native.load().lk_task_ctl_reset(self._h)
+
+    def progress(self) -> tuple[int, int]:
+        "(rows done, rows total) of the call in flight (or of the last finished one)"
+        d, t = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(_native.load().lk_task_ctl_progress(self._h, ctypes.byref(d), ctypes.byref(t)))
+        return int(d.value), int(t.value)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _native.load().lk_task_ctl_destroy(self._h)
+                self._h = ctypes.c_void_p(0)
+        except Exception:
+            pass
+
+
 class Gramian:
     "``M^T M + reg I`` (lk_gramian) with a reusable workspace."
 
@@ -161,6 +198,11 @@ class ALSPlan:
                               device=dev)
         self.frob = torch.zeros(1, dtype=torch.float32, device=dev)
         self.solver = int(lib.lk_als_plan_solver(self._h))
+
+    def set_ctl(self, ctl: "TaskCtl | None"):
+        "Attach (or detach) a cancel / progress block; check_status then reports a cancel."
+        self._ctl = ctl  # keep it alive as long as the plan refers to it
+        check(_native.load().lk_als_plan_set_ctl(self._h, ctl._h if ctl is not None else None))
 
     def set_cg(self, tol: float, max_iter: int = 0):
         check(_native.load().lk_als_plan_set_cg(self._h, float(tol), int(max_iter)))
@@ -228,7 +270,7 @@ class ALSPlan:
 
 
 def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None,
-               rows: tuple[int, int] | None = None) -> DeviceCSR:
+               rows: tuple[int, int] | None = None, ctl: "TaskCtl | None" = None) -> DeviceCSR:
     """
     Item-item similarity build (lk_iknn_build_count / _fill, then lk_iknn_truncate_* when
     ``save_nbrs`` is set): ``ui`` users x items and ``iu`` items x users hold the normalised
@@ -253,6 +295,8 @@ def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None,
         "lk_iknn_plan_create_rows",
     )  # fmt: skip
     try:
+        if ctl is not None:
+            check(lib.lk_iknn_plan_set_ctl(h, ctl._h), "lk_iknn_plan_set_ctl")
         ws = torch.empty(lib.lk_iknn_plan_workspace_bytes(h), dtype=torch.uint8, device=dev)
         out_ptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
         total = ctypes.c_int64(0)
@@ -322,9 +366,11 @@ def score_topk(users: torch.Tensor, items: torch.Tensor, k: int, n: int,
     assert kp == padded_dim(k) and items.shape[1] == kp
     assert users.is_contiguous() and items.is_contiguous()
     dev = users.device
+    n = int(n)
+    cols = I if n < 0 else n  # n < 0: rank every candidate (TopNRanker without n)
     ws = torch.empty(lib.lk_score_topk_workspace_bytes(B, I, n), dtype=torch.uint8, device=dev)
-    out_idx = torch.empty((B, n), dtype=torch.int32, device=dev)
-    out_sc = torch.empty((B, n), dtype=torch.float32, device=dev)
+    out_idx = torch.empty((B, cols), dtype=torch.int32, device=dev)
+    out_sc = torch.empty((B, cols), dtype=torch.float32, device=dev)
     if excl_ptr is not None:
         assert excl_ptr.dtype == torch.int64 and excl_items.dtype == torch.int32
     check(
@@ -338,12 +384,23 @@ def score_topk(users: torch.Tensor, items: torch.Tensor, k: int, n: int,
 
 
 def argtopn(scores: torch.Tensor, n: int) -> torch.Tensor:
-    "Per-row top-N indices (lk_argtopn) of a [rows x len] f32 device matrix; -1 padding."
+    """
+    Per-row top-N indices (lk_argtopn) of a [rows x len] f32 device matrix, -1 padding;
+    ``n < 0`` ranks every valid entry (``argsort_descending``).  Lists of up to 4096 take the
+    selection kernel, longer ones (and ``n < 0``) the full stable sort.
+    """
     lib = _native.require_gpu()
     assert scores.dtype == torch.float32 and scores.is_contiguous() and scores.dim() == 2
     rows, ln = scores.shape
-    out = torch.empty((rows, n), dtype=torch.int32, device=scores.device)
-    check(lib.lk_argtopn(_ptr(scores), rows, ln, int(n), None, _ptr(out), _stream()), "lk_argtopn")
+    n = int(n)
+    cols = ln if n < 0 else min(n, ln)
+    out = torch.empty((rows, cols), dtype=torch.int32, device=scores.device)
+    if cols == 0 or rows == 0:
+        return out
+    wb = lib.lk_argtopn_workspace_bytes(rows, ln, n if n < 0 else cols)
+    ws = torch.empty(wb, dtype=torch.uint8, device=scores.device) if wb else None
+    check(lib.lk_argtopn(_ptr(scores), rows, ln, n if n < 0 else cols, _ptr(ws), _ptr(out),
+                         _stream()), "lk_argtopn")
     return out
 
 

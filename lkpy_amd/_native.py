@@ -48,6 +48,15 @@ def _declare(lib):
         "lk_padded_dim": (c_int32, [c_int32]),
         "lk_pad_rows": (c_int, [vp, c_int64, c_int32, c_int32, vp, c_int32, vp]),
         "lk_unpad_rows": (c_int, [vp, c_int64, c_int32, c_int32, vp, c_int32, vp]),
+        "lk_task_ctl_create": (c_int, [POINTER(vp)]),
+        "lk_task_ctl_destroy": (None, [vp]),
+        "lk_task_ctl_cancel": (None, [vp]),
+        "lk_task_ctl_cancelled": (c_int, [vp]),
+        "lk_task_ctl_reset": (None, [vp]),
+        "lk_task_ctl_progress": (c_int, [vp, POINTER(c_int64), POINTER(c_int64)]),
+        "lk_als_plan_set_ctl": (c_int, [vp, vp]),
+        "lk_iknn_plan_set_ctl": (c_int, [vp, vp]),
+        "lk_argtopn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32]),
         "lk_gramian_workspace_bytes": (c_size_t, [c_int32]),
         "lk_gramian": (c_int, [vp, c_int64, c_int32, c_int32, c_float, vp, c_int32, vp, vp]),
         "lk_als_plan_create": (c_int, [POINTER(vp), vp, c_int, c_int64, c_int32, c_int32]),

@@ -28,6 +28,42 @@ from .pipeline import Component
 from .training import ModelTrainer, TrainingOptions, UsesTrainer
 
 
+class _DeviceBacked:
+    """
+    A learned array attribute (``user_embeddings``, ``item_embeddings``, ``_OtOr``) that lives on
+    the host -- so that pickling / ``get_parameters`` work as in the reference -- but is only
+    REFRESHED FROM HBM WHEN SOMEBODY READS IT: while a trainer is live the factors stay on the
+    device across epochs (one PCIe crossing in, one out) and ``train_epoch`` merely marks the
+    host copies stale.  The ``ModelTrainer`` contract "the model is usable after every epoch"
+    (src/lenskit/training.py:336-378) holds: the first read after an epoch downloads.
+    """
+
+    def __set_name__(self, owner, name):
+        self.slot = "_h_" + name
+
+    def __get__(self, obj, cls=None):
+        if obj is None:
+            return self
+        pend = obj.__dict__.get("_pending_sync")
+        if pend is not None:
+            pend()
+        return obj.__dict__.get(self.slot)
+
+    def __set__(self, obj, value):
+        obj.__dict__[self.slot] = value
+
+
+def _scorer_state(obj) -> dict:
+    "``__getstate__`` of the ALS scorers: host arrays only (synchronised first), no device state."
+    pend = obj.__dict__.get("_pending_sync")
+    if pend is not None:
+        pend()
+    st = dict(obj.__dict__)
+    st.pop("_dev", None)
+    st.pop("_pending_sync", None)
+    return st
+
+
 class UIPair(BaseModel):
     user: PositiveFloat
     item: PositiveFloat
@@ -84,18 +120,16 @@ class ImplicitMFScorer(UsesTrainer, Component):
 
     users: Vocabulary | None = None
     items: Vocabulary
-    user_embeddings: np.ndarray | None = None
-    item_embeddings: np.ndarray
-    _OtOr: np.ndarray
+    user_embeddings = _DeviceBacked()  # np.ndarray [users x k] f32 | None
+    item_embeddings = _DeviceBacked()  # np.ndarray [items x k] f32
+    _OtOr = _DeviceBacked()  # np.ndarray [k x k] f32: Q^T Q + user_reg I
 
     def create_trainer(self, data, options):
         return ImplicitMFTrainer(self, data, options)
 
     # -- device-side caches (never pickled) ---------------------------------------
     def __getstate__(self):
-        st = dict(self.__dict__)
-        st.pop("_dev", None)
-        return st
+        return _scorer_state(self)
 
     def _device_state(self):
         dev = getattr(self, "_dev", None)
@@ -257,12 +291,14 @@ class ImplicitMFTrainer(ModelTrainer):
         du, di = self.engine.train_epoch()
         self.engine.check()  # RuntimeError("ALS solve error: ...") like implicit.rs:79
         self.epochs_trained += 1
-        self._sync()
+        # the factors stay in HBM; the host copies are refreshed on first read (_DeviceBacked)
+        self.scorer.__dict__["_pending_sync"] = self._sync
         return {"deltaP": float(du.item()), "deltaQ": float(di.item())}
 
     def _sync(self):
-        "after every epoch the model must be usable (training.py ModelTrainer contract)"
+        "download the current factors (called lazily through the scorer's attributes)"
         s = self.scorer
+        s.__dict__.pop("_pending_sync", None)
         s.user_embeddings = self.engine.user_embeddings()
         s.item_embeddings = self.engine.item_embeddings()
         s._OtOr = self.engine.otor()  # _save_user_otor (_implicit.py:171-175)
@@ -302,17 +338,15 @@ class BiasedMFScorer(UsesTrainer, Component):
 
     users: Vocabulary | None = None
     items: Vocabulary
-    user_embeddings: np.ndarray | None = None
-    item_embeddings: np.ndarray
+    user_embeddings = _DeviceBacked()
+    item_embeddings = _DeviceBacked()
     bias: BiasModel
 
     def create_trainer(self, data, options):
         return BiasedMFTrainer(self, data, options)
 
     def __getstate__(self):
-        st = dict(self.__dict__)
-        st.pop("_dev", None)
-        return st
+        return _scorer_state(self)
 
     def _device_state(self):
         dev = getattr(self, "_dev", None)
@@ -413,11 +447,12 @@ class BiasedMFTrainer(ModelTrainer):
         du, di = self.engine.train_epoch()
         self.engine.check()  # RuntimeError("ALS solve error: ...") like explicit.rs:72
         self.epochs_trained += 1
-        self._sync()
+        self.scorer.__dict__["_pending_sync"] = self._sync  # lazy download (_DeviceBacked)
         return {"deltaP": float(du.item()), "deltaQ": float(di.item())}
 
     def _sync(self):
         s = self.scorer
+        s.__dict__.pop("_pending_sync", None)
         s.user_embeddings = self.engine.user_embeddings()
         s.item_embeddings = self.engine.item_embeddings()
 

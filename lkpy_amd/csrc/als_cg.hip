@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
     const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_rows,
     const float *__restrict__ other, float *__restrict__ this_, const float *__restrict__ otor,
     int ld_otor, int k, float tol, int max_iter, float *__restrict__ row_delta,
-    int *__restrict__ status)
+    int *__restrict__ status, TaskCtlDev ctl)
 {
     constexpr int FPL = KP / 64;
     constexpr bool OTOR_LDS = KP <= 128;  // 16 / 64 KiB: loaded once per (persistent) workgroup
@@ -84,7 +84,15 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
         __syncthreads();
     }
 
+    __shared__ int s_cancel;
     for (int64_t t = blockIdx.x; t < n_rows; t += gridDim.x) {
+        if (ctl.d_cancel) {  // AccelTask.cancel: rows not started yet are skipped
+            if (threadIdx.x == 0) s_cancel = ctl_cancelled(ctl, (blockIdx.x & 31) == 0) ? 1 : 0;
+            __syncthreads();
+            const int c = s_cancel;
+            __syncthreads();
+            if (c) return;
+        }
         const int row = order[t];
         const int64_t beg = indptr[row], end = indptr[row + 1];
         float *xrow = this_ + (int64_t)row * KP;
@@ -93,6 +101,7 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
 #pragma unroll
                 for (int c = 0; c < FPL; ++c) xrow[f0 + c] = 0.f;
             if (threadIdx.x == 0) row_delta[row] = 0.f;
+            if (ctl.d_done && threadIdx.x == 0) ctl_advance(ctl, 1);
             continue;
         }
         // A p accumulated over this wave's share of the items and of the OtOr rows,
@@ -261,6 +270,7 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
             if (lane == 0) row_delta[row] = dd;
         }
         if (__any(bad) && threadIdx.x == 0) atomicCAS(status, 0, row + 1);
+        if (ctl.d_done && threadIdx.x == 0) ctl_advance(ctl, 1);
         __syncthreads();
     }
 }
@@ -276,6 +286,11 @@ static int launch_cg(const lk_als_plan *p, const void *indptr, const int32_t *in
     float *row_delta = reinterpret_cast<float *>(ws + p->off_delta);
     float *partial = reinterpret_cast<float *>(ws + p->off_partial);
     LK_HIP_CHECK(hipMemsetAsync(status, 0, 64, st));
+    if (p->ctl) {
+        LK_HIP_CHECK(hipMemsetAsync(row_delta, 0, (size_t)n_rows * sizeof(float), st));
+        int rc = ctl_begin(p->ctl, n_rows, n_rows, st);
+        if (rc != LK_OK) return rc;
+    }
     const int max_iter = p->cg_max_iter > 0 ? p->cg_max_iter : k;
     if (n_rows > 0) {
         int64_t blocks = n_rows < 256 * 8 ? n_rows : 256 * 8;
@@ -288,7 +303,7 @@ static int launch_cg(const lk_als_plan *p, const void *indptr, const int32_t *in
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st,
                            static_cast<const IT *>(indptr), indices, values, p->d_order, n_rows,
                            other, this_, otor, ld_otor, k, p->cg_tol, max_iter, row_delta,
-                           status);
+                           status, p->ctl ? p->ctl->dev() : TaskCtlDev{});
     }
     return launch_delta_reduce(row_delta, n_rows, partial, out_frob, st);
 }

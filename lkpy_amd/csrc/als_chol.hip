@@ -436,14 +436,17 @@ __host__ __device__ constexpr int solve_lds_floats()
 
 // EXPL: explicit-feedback model (explicit.rs) instead of the implicit one (implicit.rs); a
 // template parameter so that the implicit instantiation carries nothing of it
-template <int NT, bool IS64, bool EXPL>
+// CTL: poll the task-control block (cancel) before the row and count it when done; a
+// template parameter so that the uncontrolled instantiation -- the training engine's -- is
+// instruction for instruction the tuned kernel
+template <int NT, bool IS64, bool EXPL, bool CTL>
 __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_rows,
     const int32_t *__restrict__ row_slab, const float *__restrict__ other, int ld_other,
     float *__restrict__ this_, int ld_this, const float *__restrict__ otor_p,
     const float *__restrict__ slabs, float *__restrict__ row_delta, int *__restrict__ status,
-    int k, float reg)
+    int k, float reg, TaskCtlDev ctl)
 {
     constexpr int KP = NT * 16;
     __shared__ __attribute__((aligned(16))) float lds_all[4][solve_lds_floats<NT>()];
@@ -453,6 +456,12 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     const int sub = lane & 15, slot = lane >> 4;
     const int64_t t = (int64_t)blockIdx.x * 4 + wave;
     if (t >= n_rows) return;
+    if constexpr (CTL) {
+        // AccelTask.cancel (src/accel/tasks/mod.rs:88-95): rows not started yet are skipped
+        int c = 0;
+        if (lane == 0) c = ctl_cancelled(ctl, (blockIdx.x & 63) == 0 && wave == 0) ? 1 : 0;
+        if (__builtin_amdgcn_readfirstlane(c)) return;
+    }
     const int row = order[t];
     const int64_t beg = indptr[row], end = indptr[row + 1];
     float *lds = lds_all[wave];
@@ -465,6 +474,8 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     if (end == beg) {  // implicit.rs:98-101
         if (lane < KP) xrow[lane] = 0.f;
         if (lane == 0) row_delta[row] = 0.f;
+        if constexpr (CTL)
+            if (lane == 0) ctl_advance(ctl, 1);
         return;
     }
 
@@ -551,6 +562,8 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     }
     const float d2 = wave_sum(d * d);
     if (lane == 0) row_delta[row] = d2;
+    if constexpr (CTL)
+        if (lane == 0) ctl_advance(ctl, 1);  // progress unit = rows (tasks/mod.rs:97-105)
 }
 
 // OtOr [k x k] -> primed [KP x KP] with identity on the pad features.
@@ -632,6 +645,13 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
     float *slabs = reinterpret_cast<float *>(ws + p->off_slabs);
 
     LK_HIP_CHECK(hipMemsetAsync(status, 0, 64, st));
+    if (p->ctl) {
+        // a cancelled half-epoch leaves the rows not yet started untouched; their deltas
+        // must not be garbage in the (discarded) sum
+        LK_HIP_CHECK(hipMemsetAsync(row_delta, 0, (size_t)n_rows * sizeof(float), st));
+        int rc = ctl_begin(p->ctl, n_rows, n_rows, st);
+        if (rc != LK_OK) return rc;
+    }
     hipLaunchKernelGGL(als_prep_otor_kernel<NT>, dim3((KP * KP + 255) / 256), dim3(256), 0, st,
                        otor, ld_otor, k, otor_p);
     const bool tm = p->timing && p->timing_n < lk_als_plan::TIMING_RING;
@@ -644,10 +664,18 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
     if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
     if (n_rows > 0) {
         using IT = typename IndPtr<IS64>::type;
-        hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL>), dim3((unsigned)((n_rows + 3) / 4)),
-                           dim3(256), 0, st, static_cast<const IT *>(indptr), indices, values,
-                           p->d_order, n_rows, p->d_row_slab, other, ld_other, this_, ld_this,
-                           otor_p, slabs, row_delta, status, k, reg);
+        if (p->ctl)
+            hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, true>),
+                               dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st,
+                               static_cast<const IT *>(indptr), indices, values, p->d_order,
+                               n_rows, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
+                               slabs, row_delta, status, k, reg, p->ctl->dev());
+        else
+            hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, false>),
+                               dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st,
+                               static_cast<const IT *>(indptr), indices, values, p->d_order,
+                               n_rows, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
+                               slabs, row_delta, status, k, reg, TaskCtlDev{});
     }
     if (tm) {
         LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][2], st));
@@ -826,6 +854,13 @@ extern "C" void lk_als_plan_destroy(lk_als_plan *p)
 extern "C" size_t lk_als_plan_workspace_bytes(const lk_als_plan *p) { return p ? p->ws_bytes : 0; }
 extern "C" int32_t lk_als_plan_solver(const lk_als_plan *p) { return p ? p->solver : -1; }
 
+extern "C" int lk_als_plan_set_ctl(lk_als_plan *p, lk_task_ctl *ctl)
+{
+    LK_REQUIRE(p != nullptr, "lk_als_plan_set_ctl: null plan");
+    p->ctl = ctl;
+    return LK_OK;
+}
+
 extern "C" int lk_als_plan_set_cg(lk_als_plan *p, float tol, int32_t max_iter)
 {
     LK_REQUIRE(p != nullptr, "lk_als_plan_set_cg: null plan");
@@ -926,6 +961,11 @@ extern "C" int lk_als_check_status(const lk_als_plan *plan, void *d_ws, void *st
     LK_HIP_CHECK(hipMemcpyAsync(status, static_cast<char *>(d_ws) + plan->off_status,
                                 sizeof(status), hipMemcpyDeviceToHost, lk::as_stream(stream)));
     LK_HIP_CHECK(hipStreamSynchronize(lk::as_stream(stream)));
+    if (plan->ctl) {
+        // AccelTask protocol: a cancelled task reports the interruption, not a result
+        int rc = lk::ctl_finish(plan->ctl, lk::as_stream(stream));
+        if (rc != LK_OK) return rc;
+    }
     if (status[0] != 0) {
         // reference: RuntimeError("ALS solve error: ...") (src/accel/als/implicit.rs:79)
         lk::set_error("ALS solve error: normal matrix of row %d is not positive definite",

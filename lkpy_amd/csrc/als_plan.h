@@ -20,6 +20,7 @@ struct lk_als_plan {
     // workspace layout (byte offsets)
     size_t off_status = 0, off_otor = 0, off_delta = 0, off_partial = 0, off_slabs = 0,
            ws_bytes = 0;
+    struct lk_task_ctl *ctl = nullptr;  // optional cancel / progress block (lk_als_plan_set_ctl)
     float cg_tol = 1e-7f;
     int32_t cg_max_iter = 0;
     // optional per-kernel timing (HIP events on the launch stream): ring of

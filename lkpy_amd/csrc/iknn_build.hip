@@ -64,6 +64,7 @@ struct lk_iknn_plan {
     // single-pass build through a dense-bound staging area (n_items^2 entries) when it fits
     int32_t staged = 0;
     size_t off_st_idx = 0, off_st_val = 0;
+    lk_task_ctl *ctl = nullptr;  // optional cancel / progress block (lk_iknn_plan_set_ctl)
 };
 
 namespace lk {
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
     int Q, int W,
     float min_sim, int32_t *__restrict__ task_cnt,
     const int64_t *__restrict__ task_off, int32_t *__restrict__ out_idx,
-    float *__restrict__ out_val)
+    float *__restrict__ out_val, TaskCtlDev ctl)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_acc[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -142,6 +143,11 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
         const int row = (int)row_lo + lrow;  // item id
         const int p = (code - lrow * Q) * 4 + wave;
         if (p >= P) continue;
+        if (ctl.d_cancel) {  // AccelTask.cancel: tasks not started keep their zero count
+            int c = 0;
+            if (lane == 0) c = ctl_cancelled(ctl, wave == 0 && (bt & 63) == 0) ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(c)) break;
+        }
         const int task = lrow * P + p;
         const int c_lo = p * W;
         const int wlen = (int)((n_items - c_lo) < W ? (n_items - c_lo) : W);
@@ -290,6 +296,7 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
             if (COUNT) count += __popcll(m);
         }
         if (COUNT && lane == 0) task_cnt[task] = count;
+        if (ctl.d_done && lane == 0) ctl_advance(ctl, 1);  // unit: one (row, window) task
     }
 }
 
@@ -506,6 +513,13 @@ extern "C" void lk_iknn_plan_destroy(lk_iknn_plan *p)
     delete p;
 }
 
+extern "C" int lk_iknn_plan_set_ctl(lk_iknn_plan *p, lk_task_ctl *ctl)
+{
+    LK_REQUIRE(p != nullptr, "lk_iknn_plan_set_ctl: null plan");
+    p->ctl = ctl;
+    return LK_OK;
+}
+
 extern "C" size_t lk_iknn_plan_workspace_bytes(const lk_iknn_plan *p)
 {
     return p ? p->ws_bytes : 0;
@@ -542,11 +556,17 @@ static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t 
     LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t blocks = std::min<int64_t>(p->n_btasks, iknn_grid(p->W));
+    if (p->ctl) {
+        if (COUNT) LK_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)p->n_tasks, st));
+        int rc = ctl_begin(p->ctl, p->n_rows, p->n_tasks, st);
+        if (rc != LK_OK) return rc;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st,
                        static_cast<const IT *>(ui_ptr), pack, static_cast<const IT *>(iu_ptr),
                        iu_idx, iu_val, desc, p->d_task, p->n_btasks, p->n_items, p->row_lo, p->P, p->Q,
                        p->W,
-                       min_sim, cnt, off, out_idx, out_val);
+                       min_sim, cnt, off, out_idx, out_val,
+                       p->ctl ? p->ctl->dev() : TaskCtlDev{});
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }
@@ -612,6 +632,7 @@ extern "C" int lk_iknn_build_count(const lk_iknn_plan *plan, const void *d_ui_in
     LK_HIP_CHECK(hipMemcpyAsync(h_total_nnz, off + plan->n_tasks, sizeof(int64_t),
                                 hipMemcpyDeviceToHost, st));
     LK_HIP_CHECK(hipStreamSynchronize(st));
+    if (plan->ctl) return lk::ctl_finish(plan->ctl, st);  // LK_E_CANCELLED if interrupted
     return LK_OK;
 }
 
@@ -641,11 +662,16 @@ extern "C" int lk_iknn_build_fill(const lk_iknn_plan *plan, const void *d_ui_ind
         LK_HIP_CHECK(hipGetLastError());
         return LK_OK;
     }
-    return plan->is64
-               ? lk::launch_iknn<true, true, false>(plan, d_ui_indptr, d_ui_indices, d_ui_values,
-                                                    d_iu_indptr, d_iu_indices, d_iu_values,
-                                                    min_sim, ws, d_out_indices, d_out_values, st)
-               : lk::launch_iknn<false, true, false>(plan, d_ui_indptr, d_ui_indices, d_ui_values,
-                                                     d_iu_indptr, d_iu_indices, d_iu_values,
-                                                     min_sim, ws, d_out_indices, d_out_values, st);
+    rc = plan->is64
+             ? lk::launch_iknn<true, true, false>(plan, d_ui_indptr, d_ui_indices, d_ui_values,
+                                                  d_iu_indptr, d_iu_indices, d_iu_values, min_sim,
+                                                  ws, d_out_indices, d_out_values, st)
+             : lk::launch_iknn<false, true, false>(plan, d_ui_indptr, d_ui_indices, d_ui_values,
+                                                   d_iu_indptr, d_iu_indices, d_iu_values,
+                                                   min_sim, ws, d_out_indices, d_out_values, st);
+    if (rc == LK_OK && plan->ctl) {  // the second full pass is cancellable too (blocking then)
+        LK_HIP_CHECK(hipStreamSynchronize(st));
+        rc = lk::ctl_finish(plan->ctl, st);
+    }
+    return rc;
 }

@@ -83,3 +83,95 @@ extern "C" int lk_unpad_rows(const float *d_src, int64_t n, int32_t k, int32_t l
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }
+
+// ---------------------------------------------------------------------------
+// lk_task_ctl: cancel + progress words (AccelTask.cancel / current_progress,
+// src/accel/tasks/mod.rs:62-106, src/lenskit/parallel/_task.py:34-57)
+// ---------------------------------------------------------------------------
+
+namespace lk {
+
+int ctl_begin(lk_task_ctl *ctl, int64_t rows_total, int64_t units_total, hipStream_t st)
+{
+    ctl->rows_total = rows_total;
+    ctl->units_total = units_total;
+    // progress restarts; a cancel requested before the launch stays visible (h_words[0])
+    *reinterpret_cast<volatile unsigned long long *>(ctl->h_words + 2) = 0ull;
+    LK_HIP_CHECK(hipMemsetAsync(ctl->d_words, 0, 16, st));
+    return LK_OK;
+}
+
+int ctl_finish(lk_task_ctl *ctl, hipStream_t st)
+{
+    int w[4] = {0, 0, 0, 0};
+    LK_HIP_CHECK(hipMemcpyAsync(w, ctl->d_words, sizeof(w), hipMemcpyDeviceToHost, st));
+    LK_HIP_CHECK(hipStreamSynchronize(st));
+    unsigned long long done;
+    memcpy(&done, w + 2, 8);
+    *reinterpret_cast<volatile unsigned long long *>(ctl->h_words + 2) = done;
+    if (w[0] != 0) {
+        set_error("cancelled after %llu of %lld work units", done, (long long)ctl->units_total);
+        return LK_E_CANCELLED;
+    }
+    return LK_OK;
+}
+
+}  // namespace lk
+
+extern "C" int lk_task_ctl_create(lk_task_ctl **out)
+{
+    LK_REQUIRE(out != nullptr, "lk_task_ctl_create: null pointer");
+    auto *c = new lk_task_ctl();
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&c->h_words), 64,
+                                 hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) {
+        memset(c->h_words, 0, 64);
+        e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->dh_words), c->h_words, 0);
+    }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_words), 64);
+    if (e == hipSuccess) e = hipMemset(c->d_words, 0, 64);
+    if (e != hipSuccess) {
+        lk::set_error("lk_task_ctl_create: %s", hipGetErrorString(e));
+        lk_task_ctl_destroy(c);
+        return LK_E_HIP;
+    }
+    *out = c;
+    return LK_OK;
+}
+
+extern "C" void lk_task_ctl_destroy(lk_task_ctl *c)
+{
+    if (!c) return;
+    if (c->d_words) (void)hipFree(c->d_words);
+    if (c->h_words) (void)hipHostFree(c->h_words);
+    delete c;
+}
+
+extern "C" void lk_task_ctl_cancel(lk_task_ctl *c)
+{
+    if (c && c->h_words) __atomic_store_n(c->h_words, 1, __ATOMIC_RELEASE);
+}
+
+extern "C" int lk_task_ctl_cancelled(const lk_task_ctl *c)
+{
+    return (c && c->h_words) ? __atomic_load_n(c->h_words, __ATOMIC_ACQUIRE) : 0;
+}
+
+extern "C" void lk_task_ctl_reset(lk_task_ctl *c)
+{
+    if (!c || !c->h_words) return;
+    __atomic_store_n(c->h_words, 0, __ATOMIC_RELEASE);
+    *reinterpret_cast<volatile unsigned long long *>(c->h_words + 2) = 0ull;
+}
+
+extern "C" int lk_task_ctl_progress(const lk_task_ctl *c, int64_t *rows_done, int64_t *rows_total)
+{
+    LK_REQUIRE(c && rows_done && rows_total, "lk_task_ctl_progress: null pointer");
+    const unsigned long long done =
+        *reinterpret_cast<const volatile unsigned long long *>(c->h_words + 2);
+    *rows_total = c->rows_total;
+    *rows_done = c->units_total > 0
+                     ? (int64_t)((__int128)done * c->rows_total / c->units_total)
+                     : 0;
+    return LK_OK;
+}

@@ -134,18 +134,6 @@ __global__ void score_mask_kernel(const int64_t *__restrict__ excl_ptr,
     }
 }
 
-__device__ __forceinline__ unsigned f2key(float x)
-{
-    unsigned u = __builtin_bit_cast(unsigned, x);
-    if (u == 0x80000000u) u = 0u;  // -0.0 ranks with +0.0 (they compare equal)
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key2f(unsigned k)
-{
-    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __builtin_bit_cast(float, u);
-}
-
 // Radix-select path (any n <= MAXN, any row): MSB-first 8-bit radix select of the n-th
 // largest key, ties by lowest index, winners left UNSORTED in cand[0 .. count).
 __device__ __forceinline__ unsigned row_topn_radix(const float *__restrict__ row, int64_t row_len,
@@ -421,10 +409,18 @@ static int64_t padded_items(int64_t n_items) { return (n_items + 63) / 64 * 64; 
 
 extern "C" size_t lk_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t n)
 {
-    (void)n;
     int64_t rows = n_users < lk::score_batch() ? n_users : lk::score_batch();
     if (rows < 1) rows = 1;
-    return (size_t)rows * (size_t)lk::padded_items(n_items) * sizeof(float) + 256;
+    size_t bytes = lk::align_up((size_t)rows * (size_t)lk::padded_items(n_items) * sizeof(float), 256) + 256;
+    // n < 0 (rank everything) or n beyond the selection kernel's capacity: full sort of the panel
+    if (n < 0 || n > lk::TOPN_MAX) bytes += lk::topn_sort_workspace_bytes(rows, n_items);
+    return bytes;
+}
+
+extern "C" size_t lk_argtopn_workspace_bytes(int64_t n_rows, int64_t row_len, int32_t n)
+{
+    if (n >= 0 && n <= lk::TOPN_MAX) return 0;
+    return lk::topn_sort_workspace_bytes(n_rows, row_len);
 }
 
 extern "C" int lk_score_dense(const float *d_users, int32_t ld_users, int64_t n_users,
@@ -450,11 +446,18 @@ extern "C" int lk_score_dense(const float *d_users, int32_t ld_users, int64_t n_
 extern "C" int lk_argtopn(const float *d_scores, int64_t n_rows, int64_t row_len, int32_t n,
                           void *d_ws, int32_t *d_out_idx, void *stream)
 {
-    (void)d_ws;
-    LK_REQUIRE(n >= 0 && n <= lk::TOPN_MAX, "lk_argtopn: n=%d outside [0, %d]", n, lk::TOPN_MAX);
     LK_REQUIRE(n_rows >= 0 && row_len >= 0, "lk_argtopn: negative size");
     if (n == 0 || n_rows == 0) return LK_OK;
     LK_REQUIRE(d_out_idx && (row_len == 0 || d_scores), "lk_argtopn: null pointer");
+    if (n < 0 || n > lk::TOPN_MAX) {
+        // `argsort_descending` (sorting.rs:69-103) / a list longer than the selection kernel
+        // holds: full stable sort; the output has min(n, row_len) columns (n < 0: row_len)
+        const int64_t cols = (n < 0 || n > row_len) ? row_len : n;
+        if (cols == 0) return LK_OK;
+        LK_REQUIRE(d_ws, "lk_argtopn: n=%d needs the workspace of lk_argtopn_workspace_bytes", n);
+        return lk::topn_sort(d_scores, row_len, n_rows, row_len, cols, d_ws, d_out_idx, nullptr,
+                             cols, lk::as_stream(stream));
+    }
     hipLaunchKernelGGL(lk::row_topn_kernel<lk::TOPN_MAX>, dim3((unsigned)n_rows), dim3(256), 0,
                        lk::as_stream(stream), d_scores, row_len, row_len, n, d_out_idx,
                        (float *)nullptr, (int64_t)n);
@@ -472,10 +475,13 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
     LK_REQUIRE(ld_users == KP && ld_items == KP,
                "lk_score_topk: leading dimensions (%d, %d) must equal lk_padded_dim(k)=%d",
                ld_users, ld_items, KP);
-    LK_REQUIRE(n >= 0 && n <= lk::TOPN_MAX, "lk_score_topk: n=%d outside [0, %d]", n,
-               lk::TOPN_MAX);
     LK_REQUIRE(n_users >= 0 && n_items >= 0, "lk_score_topk: negative size");
     if (n_users == 0 || n == 0) return LK_OK;
+    // n < 0: rank every candidate (TopNRanker without n, basic/topn.py:61-69); the output then
+    // has n_items columns.  Lists beyond the selection kernel's capacity are fully sorted.
+    const bool full = n < 0 || n > lk::TOPN_MAX;
+    const int64_t out_cols = n < 0 ? n_items : n;
+    if (out_cols == 0) return LK_OK;
     LK_REQUIRE(d_users && d_ws && d_out_idx && (n_items == 0 || d_items),
                "lk_score_topk: null pointer");
     hipStream_t st = lk::as_stream(stream);
@@ -494,6 +500,17 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
             if (d_excl_ptr)
                 hipLaunchKernelGGL(lk::score_mask_kernel, dim3((unsigned)rows), dim3(64), 0, st,
                                    d_excl_ptr, d_excl_items, ub, rows, n_items, panel, ld_s);
+        }
+        if (full) {
+            char *sort_ws = static_cast<char *>(d_ws) +
+                            lk::align_up((size_t)(n_users < lk::score_batch() ? n_users : lk::score_batch()) *
+                                             (size_t)ld_s * sizeof(float), 256) + 256;
+            int rc = lk::topn_sort(panel, ld_s, rows, n_items, out_cols, sort_ws,
+                                   d_out_idx + ub * out_cols,
+                                   d_out_score ? d_out_score + ub * out_cols : nullptr, out_cols,
+                                   st);
+            if (rc != LK_OK) return rc;
+            continue;
         }
         hipLaunchKernelGGL(lk::row_topn_kernel<lk::TOPN_MAX>, dim3((unsigned)rows), dim3(256), 0,
                            st, panel, ld_s, n_items, n, d_out_idx + ub * n,

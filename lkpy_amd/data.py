@@ -8,7 +8,7 @@ Mirrors (names, argument meaning, error behaviour):
 ``RecQuery``    src/lenskit/data/_query.py
 ``Dataset``     src/lenskit/data/_dataset.py + ``MatrixRelationshipSet.scipy``
                 (src/lenskit/data/_relationships.py:603-657)
-``SparseRowArray`` src/lenskit/data/matrix.py:318-539 (CSR: offsets/indices/values)
+``SparseRowArray`` src/lenskit/data/matrix.py:318-539 -> :mod:`lkpy_amd.matrix` (Arrow)
 """
 
 from __future__ import annotations
@@ -245,63 +245,7 @@ class RecQuery:
         raise TypeError(f"invalid query input (type {type(data)})")
 
 
-class SparseRowArray:
-    """
-    CSR rows as three flat arrays -- the layout of the reference's Arrow extension array
-    (``List<Struct{index:i32, value:f32}>``, ``matrix.py:318-539``): int32 offsets (int64
-    when nnz >= 2^31 or for ``large=True``, like ``LargeList``), int32 indices, f32 values.
-    """
-
-    def __init__(self, offsets, indices, values, shape):
-        self.offsets = np.ascontiguousarray(offsets)
-        self.indices = np.ascontiguousarray(indices, dtype=np.int32)
-        self.values = None if values is None else np.ascontiguousarray(values, dtype=np.float32)
-        self.shape = (int(shape[0]), int(shape[1]))
-
-    @property
-    def nnz(self) -> int:
-        return int(self.indices.shape[0])
-
-    @classmethod
-    def from_scipy(cls, mat, *, values: bool = True, large: bool = False) -> "SparseRowArray":
-        csr = sps.csr_array(mat)
-        csr.sort_indices()
-        smax = np.iinfo(np.int32).max
-        dt = np.int64 if (large or csr.nnz > smax) else np.int32  # matrix.py:411-419
-        return cls(csr.indptr.astype(dt), csr.indices, csr.data if values else None, csr.shape)
-
-    @classmethod
-    def from_arrays(cls, offsets, indices, values, shape) -> "SparseRowArray":
-        return cls(offsets, indices, values, shape)
-
-    def to_scipy(self) -> sps.csr_array:
-        vals = self.values if self.values is not None else np.ones(self.nnz, np.float32)
-        return sps.csr_array((vals, self.indices, self.offsets), shape=self.shape)
-
-    def row_extent(self, row: int) -> tuple[int, int]:
-        return int(self.offsets[row]), int(self.offsets[row + 1])
-
-    def transpose(self) -> "SparseRowArray":
-        "``SparseRowArray.transpose`` (matrix.py:512-530) through the device transpose."
-        from ._accel.data import transpose_csr
-
-        ptr, idx, perm = transpose_csr(self, self.values is not None)
-        vals = None if self.values is None else self.values[perm]
-        return SparseRowArray(ptr, idx, vals, (self.shape[1], self.shape[0]))
-
-    def to_arrow(self):
-        "Arrow (Large)List<Struct{index,value}> for interop with the reference's boundary."
-        import pyarrow as pa
-
-        fields = [pa.array(self.indices, pa.int32())]
-        names = ["index"]
-        if self.values is not None:
-            fields.append(pa.array(self.values, pa.float32()))
-            names.append("value")
-        st = pa.StructArray.from_arrays(fields, names)
-        if self.offsets.dtype == np.int64:
-            return pa.LargeListArray.from_arrays(pa.array(self.offsets, pa.int64()), st)
-        return pa.ListArray.from_arrays(pa.array(self.offsets, pa.int32()), st)
+from .matrix import SparseRowArray  # noqa: E402,F401  (Arrow extension array; matrix.py)
 
 
 class _Matrix:
@@ -360,7 +304,10 @@ class Dataset:
         self._rows = np.require(rows, dtype=np.int32)[order]
         self._cols = np.require(cols, dtype=np.int32)[order]
         self._attrs = {k: np.asarray(v)[order] for k, v in attrs.items()}
-        self._indptr = np.zeros(len(users) + 1, dtype=np.int32)
+        # int32 offsets like Arrow List; int64 once the interaction count needs it
+        # (src/lenskit/data/matrix.py:411-419)
+        dt = np.int32 if len(self._rows) < np.iinfo(np.int32).max else np.int64
+        self._indptr = np.zeros(len(users) + 1, dtype=dt)
         np.cumsum(np.bincount(self._rows, minlength=len(users)), out=self._indptr[1:])
 
     @property

@@ -76,20 +76,28 @@ class ItemKNNScorer(Component):
         self.item_means = None if means is None else np.asarray(means)
         offsets = out.indptr.cpu().numpy()
         self.item_counts = np.diff(offsets)
-        self.sim_matrix = SparseRowArray(offsets, out.indices.cpu().numpy(),
-                                         out.values.cpu().numpy(), (n_items, n_items))
-        assert self.sim_matrix.offsets.dtype == np.int64  # LargeList (item.py:176)
+        # Arrow extension array, int64 offsets (item.py:176-177: LargeList -> from_array)
+        self.sim_matrix = SparseRowArray.from_arrays(
+            offsets, out.indices.cpu().numpy(), out.values.cpu().numpy(),
+            shape=(n_items, n_items))
+        import pyarrow as pa
+
+        assert pa.types.is_large_list(self.sim_matrix.type.storage_type)
         self._dev = {"sims": out, "device": dev}
 
     def _device_sims(self):
         dev = getattr(self, "_dev", None)
         if dev is None:
             d = D.device()
-            sm = self.sim_matrix
+            from .matrix import csr_arrays
+
+            so, si, sv, shape = csr_arrays(self.sim_matrix)
             dev = {"device": d,
-                   "sims": D.DeviceCSR(torch.from_numpy(sm.offsets.astype(np.int64)).to(d),
-                                       torch.from_numpy(sm.indices).to(d),
-                                       torch.from_numpy(sm.values).to(d), sm.shape, None)}
+                   "sims": D.DeviceCSR(
+                       torch.from_numpy(np.asarray(so, dtype=np.int64)).to(d),
+                       torch.from_numpy(np.ascontiguousarray(si)).to(d),
+                       torch.from_numpy(np.ascontiguousarray(sv, dtype=np.float32)).to(d),
+                       shape, None)}
             self._dev = dev
         return dev
 

@@ -1,0 +1,355 @@
+"""
+Arrow sparse-row arrays: the wire format of the function seam.
+
+Mirror of the Arrow extension types of ``lenskit.data.matrix``
+(src/lenskit/data/matrix.py:35-37,104-560) and of their Rust views
+(src/accel/sparse/csr.rs:44-223, src/accel/sparse/consumer.rs:96-142), with the SAME extension
+names, storage types and accessors, so that arrays produced here are consumed unchanged by
+the reference's callers (``pa.chunked_array(smat).combine_chunks()`` ->
+``SparseRowArray.from_array``, src/lenskit/knn/item.py:173-177) and arrays produced by the
+reference are accepted here:
+
+* ``lenskit.sparse_index``       ``int32`` column index carrying the row dimension,
+* ``lenskit.sparse_row``         ``(Large)List<Struct{index: sparse_index, value: T}>``,
+* ``lenskit.sparse_index_list``  ``(Large)List<sparse_index>`` (structure only).
+
+Pure Arrow / NumPy plumbing: nothing here computes.  If the real ``lenskit`` has already
+registered the extension names in this process, its classes are used instead.
+"""
+
+from __future__ import annotations
+
+import json
+from typing import Any
+
+import numpy as np
+import pyarrow as pa
+import scipy.sparse as sps
+
+SPARSE_IDX_EXT_NAME = "lenskit.sparse_index"
+SPARSE_IDX_LIST_EXT_NAME = "lenskit.sparse_index_list"
+SPARSE_ROW_EXT_NAME = "lenskit.sparse_row"
+
+
+class SparseIndexType(pa.ExtensionType):
+    "``int32`` column numbers + the row dimension (matrix.py:104-143)."
+
+    def __init__(self, dimension: int):
+        self.dimension = int(dimension)
+        super().__init__(pa.int32(), SPARSE_IDX_EXT_NAME)
+
+    def check_dimension(self, expected: int | None) -> int:
+        if expected is not None and expected != self.dimension:
+            raise ValueError(f"dimension mismatch: expected {expected}, found {self.dimension}")
+        return self.dimension
+
+    def __arrow_ext_serialize__(self) -> bytes:
+        return json.dumps({"dimension": self.dimension}).encode()
+
+    @classmethod
+    def __arrow_ext_deserialize__(cls, storage_type, serialized):
+        data = json.loads(serialized.decode())
+        if not pa.types.is_int32(storage_type):
+            raise TypeError("sparse index must be int32")
+        return cls(data["dimension"])
+
+    def __reduce__(self):
+        return SparseIndexType, (self.dimension,)
+
+
+def _check_index_type(index_type: pa.DataType, dimension: int | None) -> int:
+    "matrix.py:543-555"
+    if isinstance(index_type, SparseIndexType):
+        return index_type.check_dimension(dimension)
+    if not pa.types.is_int32(index_type):
+        raise TypeError(f"index field must be int32, found {index_type}")
+    if dimension is None:
+        raise TypeError("legacy sparse rows need an explicit dimension")
+    return dimension
+
+
+class SparseIndexListType(pa.ExtensionType):
+    "Structure-only rows: ``(Large)List<sparse_index>`` (matrix.py:146-214)."
+
+    value_type = None
+
+    def __init__(self, dimension: int, large: bool = False):
+        self.index_type = SparseIndexType(dimension)
+        ctor = pa.large_list if large else pa.list_
+        super().__init__(ctor(self.index_type), SPARSE_IDX_LIST_EXT_NAME)
+
+    @classmethod
+    def from_type(cls, data_type: pa.DataType, dimension: int | None = None):
+        if isinstance(data_type, SparseIndexListType):
+            data_type.index_type.check_dimension(dimension)
+            return data_type
+        if pa.types.is_list(data_type):
+            large = False
+        elif pa.types.is_large_list(data_type):
+            large = True
+        else:
+            raise TypeError(f"expected list type, found {data_type}")
+        dimension = _check_index_type(data_type.value_type, dimension)
+        return cls(dimension, large=large)
+
+    @property
+    def dimension(self) -> int:
+        return self.index_type.dimension
+
+    def __arrow_ext_serialize__(self) -> bytes:
+        return b""
+
+    @classmethod
+    def __arrow_ext_deserialize__(cls, storage_type, serialized):
+        return cls.from_type(storage_type)
+
+    def __arrow_ext_class__(self):
+        return SparseRowArray
+
+    def __reduce__(self):
+        return SparseIndexListType, (self.dimension, pa.types.is_large_list(self.storage_type))
+
+
+class SparseRowType(pa.ExtensionType):
+    "Rows with values: ``(Large)List<Struct{index, value}>`` (matrix.py:217-315)."
+
+    def __init__(self, dimension: int, value_type: pa.DataType | None = pa.float32(),
+                 large: bool = False):
+        self.value_type = value_type
+        self.index_type = SparseIndexType(dimension)
+        ctor = pa.large_list if large else pa.list_
+        if value_type is None:
+            element = self.index_type
+        else:
+            element = pa.struct([("index", self.index_type), ("value", value_type)])
+        super().__init__(ctor(element), SPARSE_ROW_EXT_NAME)
+
+    @classmethod
+    def from_type(cls, data_type: pa.DataType, dimension: int | None = None) -> "SparseRowType":
+        if isinstance(data_type, SparseRowType):
+            data_type.index_type.check_dimension(dimension)
+            return data_type
+        if pa.types.is_list(data_type):
+            large = False
+        elif pa.types.is_large_list(data_type):
+            large = True
+        else:
+            raise TypeError(f"expected list type, found {data_type}")
+        inner = data_type.value_type
+        if not pa.types.is_struct(inner):
+            raise TypeError(f"expected struct type, found {inner}")
+        if inner.num_fields != 2:
+            raise TypeError(f"element struct must have 2 elements, found {inner.num_fields}")
+        idx_f = inner.field(0)
+        if idx_f.name != "index":
+            raise TypeError(f"first field of element struct must be 'index', found {idx_f.name}")
+        dimension = _check_index_type(idx_f.type, dimension)
+        val_f = inner.field(1)
+        if val_f.name != "value":
+            raise TypeError(f"second field of element struct must be 'value', found {val_f.name}")
+        return cls(dimension, val_f.type, large=large)
+
+    @property
+    def dimension(self) -> int:
+        return self.index_type.dimension
+
+    def __arrow_ext_serialize__(self) -> bytes:
+        return b""
+
+    @classmethod
+    def __arrow_ext_deserialize__(cls, storage_type, serialized):
+        return cls.from_type(storage_type)
+
+    def __arrow_ext_class__(self):
+        return SparseRowArray
+
+    def __reduce__(self):
+        return SparseRowType, (self.dimension, self.value_type,
+                               pa.types.is_large_list(self.storage_type))
+
+
+class SparseRowArray(pa.ExtensionArray):
+    """
+    An array of sparse rows = a CSR matrix (matrix.py:318-539): ``offsets`` (int32, or int64
+    for ``LargeList``), ``indices`` (int32) and ``values`` are zero-copy Arrow views of the
+    three CSR buffers -- exactly what the HIP kernels read (``include/lkamd.h``, "CSR").
+    """
+
+    @classmethod
+    def from_arrays(cls, offsets, indices, values=None, *, shape=None) -> "SparseRowArray":
+        offsets = pa.array(offsets)
+        large = pa.types.is_int64(offsets.type)
+        if isinstance(indices, pa.ExtensionArray):
+            indices = indices.storage
+        indices = pa.array(indices, type=pa.int32())
+        if shape:
+            _nr, nc = shape
+        else:
+            import pyarrow.compute as pc
+
+            nc = pc.max(indices).as_py() + 1
+        if values is not None:
+            values = pa.array(values)
+            row_type = SparseRowType(nc, values.type, large)
+            idx = pa.ExtensionArray.from_storage(row_type.index_type, indices)
+            # non-nullable fields, like the Rust side builds them (consumer.rs:98-103)
+            fields = [pa.field("index", row_type.index_type), pa.field("value", values.type)]
+            elements = pa.StructArray.from_arrays([idx, values], fields=fields)
+        else:
+            row_type = SparseIndexListType(nc, large)
+            elements = pa.ExtensionArray.from_storage(row_type.index_type, indices)
+        if large:
+            storage = pa.LargeListArray.from_arrays(offsets, elements)
+        else:
+            storage = pa.ListArray.from_arrays(offsets, elements)
+        return pa.ExtensionArray.from_storage(row_type, storage.cast(row_type.storage_type))
+
+    @classmethod
+    def from_array(cls, array: pa.Array, dimension: int | None = None) -> "SparseRowArray":
+        "Interpret an Arrow array as sparse rows; legacy layouts included (matrix.py:364-385)."
+        if isinstance(array, pa.ChunkedArray):
+            array = array.combine_chunks()
+            if isinstance(array, pa.ChunkedArray):  # pyarrow >= 15 may keep one chunk
+                array = array.chunk(0) if array.num_chunks == 1 else pa.concat_arrays(array.chunks)
+        if isinstance(array, SparseRowArray):
+            array.type.index_type.check_dimension(dimension)
+            return array
+        if isinstance(array.type, (SparseRowType, SparseIndexListType)):
+            array.type.index_type.check_dimension(dimension)
+            return pa.ExtensionArray.from_storage(array.type, array)
+        vt = getattr(array.type, "value_type", None)
+        if vt is not None and not pa.types.is_struct(vt):
+            et = SparseIndexListType.from_type(array.type, dimension)
+        else:
+            et = SparseRowType.from_type(array.type, dimension)
+        return pa.ExtensionArray.from_storage(et, array.cast(et.storage_type))
+
+    @classmethod
+    def from_scipy(cls, matrix, *, values: bool = True, large: bool | None = None):
+        "matrix.py:387-424: int32 offsets unless nnz >= 2^31 or ``large=True``."
+        matrix = sps.csr_array(matrix)
+        matrix.sort_indices()
+        smax = np.iinfo(np.int32).max
+        offsets = matrix.indptr
+        if large:
+            offsets = np.require(offsets, np.int64)
+        elif matrix.nnz < smax:
+            offsets = np.require(offsets, dtype=np.int32)
+        elif large is False:
+            raise ValueError(f"sparse matrix size {matrix.nnz:,d} too large for list")
+        vals = pa.array(matrix.data) if values else None
+        return cls.from_arrays(offsets, np.require(matrix.indices, np.int32), vals,
+                               shape=matrix.shape)
+
+    def to_scipy(self) -> sps.csr_array:
+        if not self.has_values:
+            raise TypeError("structure-only arrays cannot convert to scipy")
+        return sps.csr_array(
+            (self.values.to_numpy(), self.indices.to_numpy(), self.offsets.to_numpy()),
+            shape=(len(self), self.type.dimension),
+        )
+
+    @property
+    def dimension(self) -> int:
+        return self.type.dimension
+
+    @property
+    def shape(self) -> tuple[int, int]:
+        return (len(self), self.dimension)
+
+    @property
+    def has_values(self) -> bool:
+        return self.type.value_type is not None
+
+    @property
+    def offsets(self) -> pa.Array:
+        return self.storage.offsets
+
+    @property
+    def indices(self) -> pa.Int32Array:
+        vals = self.storage.values
+        idx = vals.field(0) if self.has_values else vals
+        return idx.storage if isinstance(idx, pa.ExtensionArray) else idx
+
+    @property
+    def values(self) -> pa.Array | None:
+        return self.storage.values.field(1) if self.has_values else None
+
+    @property
+    def nnz(self) -> int:
+        return self.offsets[len(self)].as_py()
+
+    def structure(self) -> "SparseRowArray":
+        if self.has_values:
+            return self.from_arrays(self.offsets, self.indices, shape=self.shape)
+        return self
+
+    def transpose(self) -> "SparseRowArray":
+        "matrix.py:512-530, through the device transpose (``lk_csr_transpose``)."
+        from ._accel import data as _data_accel
+
+        nr, nc = self.shape
+        row_ptr, col_ind, perm = _data_accel.transpose_csr(self.structure(), self.has_values)
+        if perm is None:
+            return self.from_arrays(row_ptr, col_ind, shape=(nc, nr))
+        return self.from_arrays(row_ptr, col_ind, self.values.take(perm), shape=(nc, nr))
+
+    def row_extent(self, row: int) -> tuple[int, int]:
+        return self.storage.offsets[row].as_py(), self.storage.offsets[row + 1].as_py()
+
+    def row_indices(self, row: int) -> pa.Int32Array:
+        sp, ep = self.row_extent(row)
+        return self.indices.slice(sp, ep - sp)
+
+    def row_values(self, row: int):
+        if not self.has_values:
+            return None
+        sp, ep = self.row_extent(row)
+        return self.values.slice(sp, ep - sp)
+
+
+def _register():
+    for t in (SparseIndexType(0), SparseIndexListType(0), SparseRowType(0)):
+        try:
+            pa.register_extension_type(t)
+        except pa.ArrowKeyError:
+            pass  # the real lenskit (or an earlier import) owns the name already
+
+
+_register()
+
+
+def csr_arrays(matrix: Any):
+    """
+    Anything the reference's boundary accepts as a CSR matrix -> NumPy views
+    ``(offsets, indices, values | None, (rows, cols))`` without copying the buffers:
+    a :class:`SparseRowArray` (ours or ``lenskit.data.matrix``'s), a raw Arrow
+    ``ListArray`` / ``LargeListArray`` of ``Struct{index, value}`` or of ``int32`` carrying the
+    ``lenskit.sparse_index`` extension (what the Rust side receives through the C Data
+    Interface, src/accel/sparse/csr.rs:160-204), or a SciPy sparse matrix.  Wrong types raise
+    ``TypeError`` like ``CSRMatrix::from_arrow``.
+    """
+    if sps.issparse(matrix):
+        matrix = SparseRowArray.from_scipy(matrix)
+    if isinstance(matrix, pa.ChunkedArray):
+        matrix = matrix.combine_chunks()
+    if not isinstance(matrix, pa.Array):
+        raise TypeError(f"invalid array type {type(matrix)}, expected List or LargeList")
+    try:
+        sra = SparseRowArray.from_array(matrix)
+    except TypeError as e:
+        raise TypeError(f"invalid array type: {e}") from e
+    if sra.null_count:
+        raise TypeError("sparse row arrays cannot contain null rows")
+    n = len(sra)
+    off = sra.offsets.to_numpy(zero_copy_only=False)
+    # a sliced array keeps the parent's buffers: rebase
+    base = int(off[0]) if n else 0
+    idx = sra.indices.to_numpy(zero_copy_only=False)
+    vals = None if not sra.has_values else sra.values.to_numpy(zero_copy_only=False)
+    if base:
+        end = int(off[-1])
+        off = off - off[0]
+        idx = idx[base:end]
+        vals = None if vals is None else vals[base:end]
+    return off, idx, vals, (n, sra.dimension)

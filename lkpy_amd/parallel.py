@@ -14,7 +14,16 @@ R = TypeVar("R")
 
 
 class AccelTask(Generic[R]):
-    "A unit of GPU work with the reference's task protocol."
+    """
+    A unit of GPU work with the reference's task protocol (src/accel/tasks/mod.rs:33-106).
+
+    ``invoke`` runs the work (once, on a helper thread; the C-ABI calls release the GIL like
+    ``py.detach`` in implicit.rs:75).  ``cancel()`` and ``current_progress()`` may be called
+    from the main thread meanwhile: they go through the device-visible control words of
+    ``lk_task_ctl`` (``include/lkamd.h``) -- the running kernels poll the cancel word and skip
+    every row not yet started; the live row count is read from pinned host memory.  A
+    cancelled ``invoke`` raises ``KeyboardInterrupt`` (``LK_E_CANCELLED``).
+    """
 
     def __init__(self, fn: Callable[["AccelTask"], R], total: int | None = None):
         self._fn = fn
@@ -22,16 +31,28 @@ class AccelTask(Generic[R]):
         self._done = 0
         self._total = total
         self._invoked = False
+        self._ctl = None  # lkpy_amd._device.TaskCtl, created by the work function
 
     def invoke(self, *, pool=None) -> R:
         if self._invoked:
             raise RuntimeError("task already invoked")
         self._invoked = True
+        if self._cancel.is_set():
+            raise KeyboardInterrupt("cancelled")
         return self._fn(self)
 
+    def attach(self, ctl) -> None:
+        "called by the work function once the device control block exists"
+        self._ctl = ctl
+        if self._cancel.is_set():
+            ctl.cancel()
+
     def cancel(self) -> None:
-        "Cooperative: honoured between kernel launches."
+        "tasks/mod.rs:88-95; seen by the running kernels, not only between launches"
         self._cancel.set()
+        ctl = self._ctl
+        if ctl is not None:
+            ctl.cancel()
 
     @property
     def cancelled(self) -> bool:
@@ -41,7 +62,15 @@ class AccelTask(Generic[R]):
         self._done = done
 
     def current_progress(self):
-        return (self._done, self._total) if self._total is not None else self._done
+        "tasks/mod.rs:97-105: rows completed (and the total, when known)"
+        ctl = self._ctl
+        done = self._done
+        if ctl is not None:
+            try:
+                done = max(done, ctl.progress()[0])
+            except Exception:
+                pass
+        return (done, self._total) if self._total is not None else done
 
 
 class AccelTaskThread(threading.Thread, Generic[R]):

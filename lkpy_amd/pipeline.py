@@ -211,21 +211,24 @@ class Pipeline:
     # -- training (src/lenskit/pipeline/_impl.py:316-372) -------------------------
     def train(self, data, options: TrainingOptions | None = None) -> None:
         options = options or TrainingOptions()
+        # _impl.py:346-352: only a SEED is wrapped and spawned; None, a Generator or a
+        # BitGenerator is handed to every component unchanged
         if isinstance(options.rng, np.random.SeedSequence):
             seed = options.rng
-        elif isinstance(options.rng, np.random.Generator):
-            seed = options.rng.bit_generator.seed_seq
+        elif options.rng is None or isinstance(options.rng, (np.random.Generator,
+                                                             np.random.BitGenerator)):
+            seed = None
         else:
             seed = np.random.SeedSequence(options.rng)
         for node in self.nodes.values():
             comp = node.component
             if comp is None or not isinstance(comp, Trainable):
                 continue
-            # every Trainable node consumes one spawned child, in node order
-            child = seed.spawn(1)[0]
-            if not options.retrain and comp.is_trained():
-                continue
-            comp.train(data, replace(options, rng=child))
+            if comp.is_trained() and not options.retrain:
+                continue  # skipped components consume no child seed (_impl.py:360-361)
+            # one spawned child per component actually trained, in node order (_impl.py:363-366)
+            c_opts = options if seed is None else replace(options, rng=seed.spawn(1)[0])
+            comp.train(data, c_opts)
 
     # -- execution ------------------------------------------------------------------
     def run(self, node: str | None = None, /, **inputs):

@@ -295,6 +295,143 @@ int lko_als_explicit_half_epoch(void *sposv_ptr, const int64_t *indptr, const in
 }
 
 /* ------------------------------------------------------------------------- */
+/* REFEREE (not the reference): the implicit half-epoch in float64 + cond(A)    */
+/* ------------------------------------------------------------------------- */
+
+/* The exact answer both float32 implementations (the reference's ndarray + sposv path
+ * restated above, and the HIP kernels) approximate: OtOr, every normal matrix and every solve
+ * in float64.  Also returns an estimate of cond_2(A) per row (power iteration for the largest
+ * eigenvalue, inverse iteration through the float64 Cholesky factor for the smallest; both
+ * converge from below, so the estimate is a LOWER bound of the true condition number).  Used
+ * by the at-scale parity accounting: a float32 solve can only be expected within
+ * ~cond(A)*2^-24 of exact, so "1e-4 vs the reference" is checked on rows whose cond allows it
+ * and the others are listed.  otor64: k x k float64 (O^T O + reg I computed by the caller in
+ * float64); out_x: n_rows x k float64; out_cond: n_rows (0 for empty rows). */
+int lko_als_implicit_referee_f64(const int64_t *indptr, const int32_t *indices,
+                                 const float *values, int64_t n_rows, int k, const float *other,
+                                 const double *otor64, int n_threads, double *out_x,
+                                 double *out_cond)
+{
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+    if (n_threads > 256) n_threads = 256;
+#else
+    n_threads = 1;
+#endif
+    int bad = 0;
+#pragma omp parallel num_threads(n_threads)
+    {
+        double *a = (double *)malloc(sizeof(double) * (size_t)k * k);
+        double *l = (double *)malloc(sizeof(double) * (size_t)k * k);
+        double *y = (double *)malloc(sizeof(double) * (size_t)k);
+        double *w = (double *)malloc(sizeof(double) * (size_t)k);
+        double *t = (double *)malloc(sizeof(double) * (size_t)k);
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t r = 0; r < n_rows; r++) {
+            int64_t sp = indptr[r], ep = indptr[r + 1];
+            double *x = out_x + r * k;
+            if (ep == sp) {
+                for (int f = 0; f < k; f++) x[f] = 0.0;
+                if (out_cond) out_cond[r] = 0.0;
+                continue;
+            }
+            memcpy(a, otor64, sizeof(double) * (size_t)k * k);
+            memset(y, 0, sizeof(double) * (size_t)k);
+            for (int64_t j = sp; j < ep; j++) {
+                const float *q = other + (int64_t)indices[j] * k;
+                double v = (double)values[j];
+                for (int f = 0; f < k; f++) {
+                    double lf = (double)q[f] * v;
+                    double *af = a + (int64_t)f * k;
+                    for (int g = 0; g < k; g++) af[g] += lf * (double)q[g];
+                    y[f] += (double)q[f] * (v + 1.0);
+                }
+            }
+            /* Cholesky A = L L^T (lower, row-major) */
+            int ok = 1;
+            memcpy(l, a, sizeof(double) * (size_t)k * k);
+            for (int j = 0; j < k && ok; j++) {
+                double d = l[j * k + j];
+                for (int c = 0; c < j; c++) d -= l[j * k + c] * l[j * k + c];
+                if (!(d > 0.0)) {
+                    ok = 0;
+                    break;
+                }
+                d = sqrt(d);
+                l[j * k + j] = d;
+                for (int i = j + 1; i < k; i++) {
+                    double s = l[i * k + j];
+                    for (int c = 0; c < j; c++) s -= l[i * k + c] * l[j * k + c];
+                    l[i * k + j] = s / d;
+                }
+            }
+            if (!ok) {
+#pragma omp atomic write
+                bad = 1;
+                continue;
+            }
+#define LKO_SOLVE(vec)                                                    \
+    do {                                                                  \
+        for (int i = 0; i < k; i++) {                                     \
+            double s = (vec)[i];                                          \
+            for (int c = 0; c < i; c++) s -= l[i * k + c] * (vec)[c];     \
+            (vec)[i] = s / l[i * k + i];                                  \
+        }                                                                 \
+        for (int i = k - 1; i >= 0; i--) {                                \
+            double s = (vec)[i];                                          \
+            for (int c = i + 1; c < k; c++) s -= l[c * k + i] * (vec)[c]; \
+            (vec)[i] = s / l[i * k + i];                                  \
+        }                                                                 \
+    } while (0)
+            memcpy(x, y, sizeof(double) * (size_t)k);
+            LKO_SOLVE(x);
+            if (out_cond) {
+                /* largest eigenvalue: power iteration on A */
+                double lmax = 0.0, lmin_inv = 0.0;
+                for (int f = 0; f < k; f++) w[f] = 1.0 + 0.37 * (double)((f * 7919) % 13);
+                for (int it = 0; it < 30; it++) {
+                    double nrm = 0.0;
+                    for (int f = 0; f < k; f++) {
+                        double s = 0.0;
+                        for (int g = 0; g < k; g++) s += a[f * k + g] * w[g];
+                        t[f] = s;
+                        nrm += s * s;
+                    }
+                    nrm = sqrt(nrm);
+                    lmax = nrm; /* ||A w|| with ||w|| = 1 */
+                    for (int f = 0; f < k; f++) w[f] = t[f] / nrm;
+                    if (it == 0) lmax = 0.0;
+                }
+                /* smallest eigenvalue: inverse iteration (A^-1 through the factor) */
+                for (int f = 0; f < k; f++) w[f] = 1.0 + 0.61 * (double)((f * 104729) % 11);
+                {
+                    double n0 = 0.0;
+                    for (int f = 0; f < k; f++) n0 += w[f] * w[f];
+                    n0 = sqrt(n0);
+                    for (int f = 0; f < k; f++) w[f] /= n0;
+                }
+                for (int it = 0; it < 30; it++) {
+                    LKO_SOLVE(w);
+                    double nrm = 0.0;
+                    for (int f = 0; f < k; f++) nrm += w[f] * w[f];
+                    nrm = sqrt(nrm);
+                    lmin_inv = nrm;
+                    for (int f = 0; f < k; f++) w[f] /= nrm;
+                }
+                out_cond[r] = lmax * lmin_inv;
+            }
+#undef LKO_SOLVE
+        }
+        free(a);
+        free(l);
+        free(y);
+        free(w);
+        free(t);
+    }
+    return bad;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Item-item similarity build: src/accel/knn/item_train.rs:95-152              */
 /* ------------------------------------------------------------------------- */
 
@@ -370,20 +507,20 @@ static int64_t lko_sim_row(int64_t row, const int64_t *ui_ptr, const int32_t *ui
 /* compute_similarities (item_train.rs:33-93) + ArrowCSRConsumer
  * (src/accel/sparse/consumer.rs:24-142, order-preserving).  Output is a CSR
  * with int64 offsets (LargeList), malloc'ed here; free with lko_free. */
-int lko_iknn_build(const int64_t *ui_ptr, const int32_t *ui_idx, const float *ui_val,
-                   const int64_t *iu_ptr, const int32_t *iu_idx, const float *iu_val,
-                   int64_t n_users, int64_t n_items, float min_sim, int64_t save_nbrs,
-                   int n_threads, int64_t *out_ptr, int32_t **out_idx, float **out_val)
+static int lko_iknn_build_sel(const int64_t *ui_ptr, const int32_t *ui_idx, const float *ui_val,
+                              const int64_t *iu_ptr, const int32_t *iu_idx, const float *iu_val,
+                              int64_t n_items, const int32_t *sel, int64_t n_out, float min_sim,
+                              int64_t save_nbrs, int n_threads, int64_t *out_ptr,
+                              int32_t **out_idx, float **out_val)
 {
-    (void)n_users;
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
     if (n_threads > 256) n_threads = 256;
 #else
     n_threads = 1;
 #endif
-    lko_pair **rows = (lko_pair **)calloc((size_t)n_items, sizeof(lko_pair *));
-    int64_t *lens = (int64_t *)calloc((size_t)n_items + 1, sizeof(int64_t));
+    lko_pair **rows = (lko_pair **)calloc((size_t)(n_out > 0 ? n_out : 1), sizeof(lko_pair *));
+    int64_t *lens = (int64_t *)calloc((size_t)n_out + 1, sizeof(int64_t));
 #pragma omp parallel num_threads(n_threads)
     {
         int32_t *counts = (int32_t *)calloc((size_t)n_items, sizeof(int32_t));
@@ -392,8 +529,8 @@ int lko_iknn_build(const int64_t *ui_ptr, const int32_t *ui_idx, const float *ui
         lko_pair *out = (lko_pair *)malloc(sizeof(lko_pair) * (size_t)n_items);
         lko_pair *tmp = (lko_pair *)malloc(sizeof(lko_pair) * (size_t)n_items);
 #pragma omp for schedule(dynamic, 16)
-        for (int64_t r = 0; r < n_items; r++) {
-            int64_t n = lko_sim_row(r, ui_ptr, ui_idx, ui_val, iu_ptr, iu_idx, iu_val, min_sim,
+        for (int64_t r = 0; r < n_out; r++) {
+            int64_t n = lko_sim_row(sel ? (int64_t)sel[r] : r, ui_ptr, ui_idx, ui_val, iu_ptr, iu_idx, iu_val, min_sim,
                                     save_nbrs, counts, dots, used, out, tmp);
             lens[r] = n;
             if (n > 0) {
@@ -408,15 +545,15 @@ int lko_iknn_build(const int64_t *ui_ptr, const int32_t *ui_idx, const float *ui
         free(tmp);
     }
     int64_t total = 0;
-    for (int64_t r = 0; r < n_items; r++) {
+    for (int64_t r = 0; r < n_out; r++) {
         out_ptr[r] = total;
         total += lens[r];
     }
-    out_ptr[n_items] = total;
+    out_ptr[n_out] = total;
     int32_t *oi = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));
     float *ov = (float *)malloc(sizeof(float) * (size_t)(total > 0 ? total : 1));
 #pragma omp parallel for schedule(static) num_threads(n_threads)
-    for (int64_t r = 0; r < n_items; r++) {
+    for (int64_t r = 0; r < n_out; r++) {
         int64_t base = out_ptr[r];
         for (int64_t q = 0; q < lens[r]; q++) {
             oi[base + q] = rows[r][q].idx;
@@ -429,6 +566,29 @@ int lko_iknn_build(const int64_t *ui_ptr, const int32_t *ui_idx, const float *ui
     *out_idx = oi;
     *out_val = ov;
     return 0;
+}
+
+int lko_iknn_build(const int64_t *ui_ptr, const int32_t *ui_idx, const float *ui_val,
+                   const int64_t *iu_ptr, const int32_t *iu_idx, const float *iu_val,
+                   int64_t n_users, int64_t n_items, float min_sim, int64_t save_nbrs,
+                   int n_threads, int64_t *out_ptr, int32_t **out_idx, float **out_val)
+{
+    (void)n_users;
+    return lko_iknn_build_sel(ui_ptr, ui_idx, ui_val, iu_ptr, iu_idx, iu_val, n_items, NULL,
+                              n_items, min_sim, save_nbrs, n_threads, out_ptr, out_idx, out_val);
+}
+
+/* The same for a SUBSET of output rows (`rows[n_sel]`, any order): out_ptr has n_sel + 1
+ * entries, row q of the result is sim_row(rows[q]).  Used for at-scale parity checks where
+ * the full matrix (~10^9 entries on ML-25M) is too large to build on the host. */
+int lko_iknn_build_rows(const int64_t *ui_ptr, const int32_t *ui_idx, const float *ui_val,
+                        const int64_t *iu_ptr, const int32_t *iu_idx, const float *iu_val,
+                        int64_t n_items, const int32_t *rows, int64_t n_sel, float min_sim,
+                        int64_t save_nbrs, int n_threads, int64_t *out_ptr, int32_t **out_idx,
+                        float **out_val)
+{
+    return lko_iknn_build_sel(ui_ptr, ui_idx, ui_val, iu_ptr, iu_idx, iu_val, n_items, rows,
+                              n_sel, min_sim, save_nbrs, n_threads, out_ptr, out_idx, out_val);
 }
 
 /* sim_row for a SUBSET of rows, results discarded except the kept-neighbour count:

@@ -212,6 +212,34 @@ def als_half_epoch_f64(matrix: sps.csr_array, other: np.ndarray, reg: float) -> 
     return out
 
 
+def als_referee_f64(matrix: sps.csr_array, other: np.ndarray, reg: float, n_threads=0,
+                    with_cond: bool = True):
+    """
+    REFEREE at scale (C, float64, OpenMP; ``lko_als_implicit_referee_f64``): the same answer
+    as :func:`als_half_epoch_f64` for every row, plus a lower-bound estimate of cond_2(A) per
+    row (power / inverse iteration).  Returns (x float64 [rows x k], cond float64 [rows]).
+    """
+    other = np.ascontiguousarray(other, dtype=np.float32)
+    k = other.shape[1]
+    o64 = other.astype(np.float64)
+    otor = np.ascontiguousarray(o64.T @ o64 + reg * np.eye(k))
+    indptr = np.ascontiguousarray(matrix.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(matrix.indices, dtype=np.int32)
+    values = np.ascontiguousarray(matrix.data, dtype=np.float32)
+    n = matrix.shape[0]
+    x = np.empty((n, k), dtype=np.float64)
+    cond = np.zeros(n, dtype=np.float64)
+    _f64p = ctypes.POINTER(ctypes.c_double)
+    rc = lib().lko_als_implicit_referee_f64(
+        _p(indptr, _i64p), _p(indices, _i32p), _p(values, _f32p), ctypes.c_int64(n),
+        ctypes.c_int(k), _p(other, _f32p), _p(otor, _f64p), ctypes.c_int(n_threads),
+        _p(x, _f64p), _p(cond, _f64p) if with_cond else None,
+    )  # fmt: skip
+    if rc != 0:
+        raise RuntimeError("referee: a normal matrix is not positive definite in float64")
+    return x, cond
+
+
 def als_initial_params(rng: np.random.Generator, nrows: int, ncols: int) -> np.ndarray:
     "``ImplicitMFTrainer.initial_params`` (src/lenskit/als/_implicit.py:152-155)."
     mat = rng.standard_normal((nrows, ncols), dtype=np.float32) * 0.01
@@ -409,6 +437,39 @@ def iknn_build(
     lib().lko_free(oi)
     lib().lko_free(ov)
     return sps.csr_array((val, idx, out_ptr), shape=(n_items, n_items))
+
+
+def iknn_build_rows(ui, iu, rows, min_sim=1.0e-6, save_nbrs=None, n_threads=0) -> sps.csr_array:
+    """
+    ``sim_row`` (src/accel/knn/item_train.rs:95-152) for the given output rows only: returns a
+    [len(rows) x n_items] CSR (int64 offsets) whose row q is the similarity row of item
+    ``rows[q]``.  For at-scale parity checks (the full ML-25M matrix has ~10^9 entries).
+    """
+    n_users, n_items = ui.shape
+    uip = np.ascontiguousarray(ui.indptr, dtype=np.int64)
+    uii = np.ascontiguousarray(ui.indices, dtype=np.int32)
+    uiv = np.ascontiguousarray(ui.data, dtype=np.float32)
+    iup = np.ascontiguousarray(iu.indptr, dtype=np.int64)
+    iui = np.ascontiguousarray(iu.indices, dtype=np.int32)
+    iuv = np.ascontiguousarray(iu.data, dtype=np.float32)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    out_ptr = np.empty(len(rows) + 1, dtype=np.int64)
+    oi = _i32p()
+    ov = _f32p()
+    lib().lko_iknn_build_rows(
+        _p(uip, _i64p), _p(uii, _i32p), _p(uiv, _f32p),
+        _p(iup, _i64p), _p(iui, _i32p), _p(iuv, _f32p),
+        ctypes.c_int64(n_items), _p(rows, _i32p), ctypes.c_int64(len(rows)),
+        ctypes.c_float(np.float32(min_sim)),
+        ctypes.c_int64(-1 if save_nbrs is None else int(save_nbrs)), ctypes.c_int(n_threads),
+        _p(out_ptr, _i64p), ctypes.byref(oi), ctypes.byref(ov),
+    )  # fmt: skip
+    nnz = int(out_ptr[-1])
+    idx = np.ctypeslib.as_array(oi, shape=(max(nnz, 1),))[:nnz].copy()
+    val = np.ctypeslib.as_array(ov, shape=(max(nnz, 1),))[:nnz].copy()
+    lib().lko_free(oi)
+    lib().lko_free(ov)
+    return sps.csr_array((val, idx, out_ptr), shape=(len(rows), n_items))
 
 
 def iknn_sample_rows(ui, iu, rows, min_sim=1.0e-6, save_nbrs=None, n_threads=0) -> int:

@@ -1,0 +1,115 @@
+"""
+At-scale parity accounting -- TEST INFRASTRUCTURE ONLY (used by ``tests/`` and by the
+``parity`` / ``cpu_baseline`` legs of ``bench.py``, never by the product package).
+
+``north_star``: factors within 1e-4 relative of the reference CPU path.  Two float32
+implementations of ``x = A^-1 y`` (the reference's ndarray + LAPACK ``sposv`` arithmetic,
+restated in ``lk_oracle.c``, and the HIP kernels) can each only be expected within about
+``cond(A) * 2^-24`` of the exact solution, so the 1e-4 criterion is decidable only for rows
+whose conditioning permits it.  The accounting below therefore reports, per half-epoch run
+from IDENTICAL inputs on both sides:
+
+* the matrix-level relative error GPU vs oracle (Frobenius),
+* how many rows exceed 1e-4 (row-wise ``||x_gpu - x_oracle|| / ||x_oracle||``) and the
+  condition numbers of exactly those rows (lower-bound estimates from the float64 referee),
+* the claim that is asserted: EVERY row with ``cond * 2^-24 < 1e-5`` is within 1e-4, and the
+  GPU is no further from the float64 referee than the reference arithmetic is (matrix level,
+  factor 2 slack),
+* a histogram of row error against cond (decades), so nothing hides behind a loose bound.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+U32 = 2.0**-24  # unit roundoff of float32
+RTOL = 1.0e-4  # north_star tolerance
+COND_LIMIT = 1.0e-5 / U32  # rows with cond below this must meet RTOL (~168)
+
+
+def _row_rel(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    "row-wise ||a - b|| / ||b|| (0 where both are zero rows)"
+    num = np.linalg.norm(a.astype(np.float64) - b.astype(np.float64), axis=1)
+    den = np.linalg.norm(b.astype(np.float64), axis=1)
+    out = np.zeros_like(num)
+    nz = den > 0
+    out[nz] = num[nz] / den[nz]
+    out[~nz & (num > 0)] = np.inf
+    return out
+
+
+def _rel(a, b) -> float:
+    d = np.linalg.norm(a.astype(np.float64) - b.astype(np.float64))
+    return float(d / max(np.linalg.norm(b.astype(np.float64)), 1e-300))
+
+
+def als_half_accounting(got: np.ndarray, want: np.ndarray, exact: np.ndarray | None,
+                        cond: np.ndarray | None) -> dict:
+    """
+    ``got``: GPU rows, ``want``: oracle (reference arithmetic) rows, ``exact``: float64 referee
+    rows, ``cond``: per-row condition estimates -- all for the same half-epoch from the same
+    inputs.  Returns the accounting dict; ``ok`` is the asserted claim.
+    """
+    e_go = _row_rel(got, want)
+    over = e_go > RTOL
+    res = {
+        "rows": int(got.shape[0]),
+        "rel_gpu_vs_oracle": _rel(got, want),
+        "row_rel_max": float(e_go.max()) if len(e_go) else 0.0,
+        "row_rel_p50": float(np.median(e_go)) if len(e_go) else 0.0,
+        "row_rel_p999": float(np.quantile(e_go, 0.999)) if len(e_go) else 0.0,
+        "rows_over_1e-4": int(over.sum()),
+    }
+    ok = True
+    if exact is not None:
+        res["rel_gpu_vs_f64"] = _rel(got, exact)
+        res["rel_oracle_vs_f64"] = _rel(want, exact)
+        # at least as accurate as the reference arithmetic (factor 2 + 1e-6 slack)
+        ok &= res["rel_gpu_vs_f64"] <= 2.0 * res["rel_oracle_vs_f64"] + 1.0e-6
+    if cond is not None:
+        cu = cond * U32
+        decidable = cu < 1.0e-5
+        res["rows_decidable"] = int(decidable.sum())  # cond * 2^-24 < 1e-5
+        res["decidable_rows_over_1e-4"] = int((over & decidable).sum())
+        ok &= res["decidable_rows_over_1e-4"] == 0
+        if over.any():
+            res["min_cond_of_rows_over"] = float(cond[over].min())
+            res["max_cond_of_rows_over"] = float(cond[over].max())
+        res["max_cond"] = float(cond.max()) if len(cond) else 0.0
+        # histogram: error normalised by cond * u, by decade of cond
+        nzc = cond > 0
+        hist = {}
+        if nzc.any():
+            dec = np.floor(np.log10(np.maximum(cond[nzc], 1.0))).astype(int)
+            for d in np.unique(dec):
+                m = dec == d
+                hist["1e%d" % d] = {
+                    "rows": int(m.sum()),
+                    "row_rel_max": float(e_go[nzc][m].max()),
+                    "row_rel_over_cond_u_max": float((e_go[nzc][m] / cu[nzc][m]).max()),
+                }
+        res["by_cond_decade"] = hist
+        if exact is not None:
+            e_g = _row_rel(got, exact)
+            e_o = _row_rel(want, exact)
+            res["row_err_over_cond_u_max_gpu"] = float((e_g[nzc] / cu[nzc]).max()) if nzc.any() else 0.0
+            res["row_err_over_cond_u_max_oracle"] = float((e_o[nzc] / cu[nzc]).max()) if nzc.any() else 0.0
+    res["ok"] = bool(ok)
+    return res
+
+
+def knn_rows_equal(gpu_ptr, gpu_idx, gpu_val, want) -> dict:
+    """
+    Bitwise comparison of sampled similarity rows: ``gpu_*`` is a CSR (offsets, int32 columns,
+    f32 values) of the sampled rows as the GPU produced them, ``want`` the oracle's
+    ``iknn_build_rows`` result for the same rows.
+    """
+    wp = np.asarray(want.indptr, dtype=np.int64)
+    gp = np.asarray(gpu_ptr, dtype=np.int64)
+    same_ptr = bool(np.array_equal(gp - gp[0], wp))
+    same_idx = same_ptr and bool(np.array_equal(np.asarray(gpu_idx, np.int32), want.indices))
+    same_val = same_idx and bool(
+        np.array_equal(np.asarray(gpu_val, np.float32).view(np.uint32),
+                       np.asarray(want.data, np.float32).view(np.uint32)))
+    return {"rows_checked": int(len(wp) - 1), "entries_checked": int(wp[-1]),
+            "bitwise_equal": bool(same_ptr and same_idx and same_val)}

@@ -131,10 +131,13 @@ def test_iknn_explicit_toml_end_to_end(gpu, oracle, ml_small, ml_ds):
     knn = pipe.node("scorer").component
     ui, iu, means, _ = oracle.iknn_prepare(ml_small["rmat"], True)
     want = oracle.iknn_build(ui, iu, 1.0e-6, None)
-    sm = knn.sim_matrix
-    assert sm.offsets.dtype == np.int64
-    assert np.array_equal(sm.offsets, want.indptr) and np.array_equal(sm.indices, want.indices)
-    assert np.array_equal(sm.values.view(np.uint32), want.data.view(np.uint32))
+    import pyarrow as pa
+
+    sm = knn.sim_matrix  # Arrow extension array, LargeList storage (knn/item.py:176-177)
+    assert pa.types.is_large_list(sm.type.storage_type) and sm.shape == want.shape
+    assert np.array_equal(sm.offsets.to_numpy(), want.indptr)
+    assert np.array_equal(sm.indices.to_numpy(), want.indices)
+    assert np.array_equal(sm.values.to_numpy().view(np.uint32), want.data.view(np.uint32))
     assert np.array_equal(knn.item_means, means)
     assert np.array_equal(knn.item_counts, np.diff(want.indptr))
 
@@ -162,7 +165,7 @@ def test_iknn_explicit_toml_end_to_end(gpu, oracle, ml_small, ml_ds):
     # no history => all NaN (item.py:238-245)
     assert np.all(np.isnan(knn(query=-5, items=ItemList([1, 2, 3])).scores()))
     clone = pickle.loads(pickle.dumps(knn))
-    assert np.array_equal(clone.sim_matrix.values, knn.sim_matrix.values)
+    assert clone.sim_matrix.equals(knn.sim_matrix)
     r2 = clone(query=pipe.node("history-lookup").component(uid), items=ItemList(ml_ds.items.ids()[:50]))
     r1 = knn(query=pipe.node("history-lookup").component(uid), items=ItemList(ml_ds.items.ids()[:50]))
     assert np.array_equal(r1.scores(), r2.scores(), equal_nan=True)
@@ -202,9 +205,12 @@ def test_function_seam(gpu, oracle, ml_small, rng):
     uin, iun, _m, _ = oracle.iknn_prepare(ml_small["rmat"], True)
     chunks = run_accel_task(_accel.knn.compute_similarities(
         SparseRowArray.from_scipy(uin), SparseRowArray.from_scipy(iun), uin.shape, 1e-6, None))
-    assert isinstance(chunks, list) and chunks[0].offsets.dtype == np.int64
+    import pyarrow as pa
+
+    assert isinstance(chunks, list) and isinstance(chunks[0], pa.LargeListArray)
     ws = oracle.iknn_build(uin, iun, 1e-6, None)
-    assert np.array_equal(chunks[0].values.view(np.uint32), ws.data.view(np.uint32))
+    got_vals = chunks[0].values.field("value").to_numpy()
+    assert np.array_equal(got_vals.view(np.uint32), ws.data.view(np.uint32))
 
     s = rng.standard_normal(5000).astype(np.float32)
     s[::7] = np.nan

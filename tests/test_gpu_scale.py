@@ -1,0 +1,126 @@
+"""
+GPU parity AT BASELINE SCALE (cfg2 / cfg3 shapes): the ML-25M-shaped synthetic that
+``bench.py`` measures on, not a shrunken stand-in.
+
+* ALS (cfg2, k = 64): one full epoch from a trained state, GPU and oracle run FROM IDENTICAL
+  INPUTS for each half, every one of the 162 541 + 62 423 rows compared, with the float64
+  referee and per-row condition estimates deciding where 1e-4 is decidable
+  (``oracle/parity.py``; src/accel/als/implicit.rs:87-125).
+* item-kNN (cfg3): >= 2 000 sampled rows of the 62 423-item build compared BITWISE with the
+  oracle's ``sim_row`` (src/accel/knn/item_train.rs:95-152) -- the staged single-pass path
+  (staging offsets beyond 2^32) and the two-pass path (``LK_IKNN_STAGE_GB=0``).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ml25m():
+    from lkpy_amd import synth
+
+    return synth.ml25m_like()
+
+
+def test_als_epoch_cfg2_all_rows(gpu, oracle, ml25m):
+    import torch
+
+    from lkpy_amd import _native
+    from lkpy_amd._als_engine import HipBackend, ImplicitALSEngine
+    from oracle import parity
+
+    k, reg, weight = 64, 0.1, 40.0
+    ui = sps.csr_array((np.full(ml25m.nnz, weight, dtype=np.float32), ml25m.indices,
+                        ml25m.indptr), shape=ml25m.shape)
+    iu = sps.csr_array(ui.T)
+    iu.sort_indices()
+    rng = np.random.default_rng(42)
+    Q0 = oracle.als_initial_params(rng, ui.shape[1], k)
+    P0 = oracle.als_initial_params(rng, ui.shape[0], k)
+    eng = ImplicitALSEngine(ui, k, reg, reg, P0, Q0, HipBackend(k, gpu, _native.SOLVER_CHOLESKY))
+    for _ in range(3):  # a trained state: the conditioning of real epochs, not of the tiny init
+        eng.train_epoch()
+    eng.check()
+    P, Q = eng.user_embeddings(), eng.item_embeddings()
+    eng.train_epoch()
+    eng.check()
+    P1, Q1 = eng.user_embeddings(), eng.item_embeddings()
+    torch.cuda.synchronize()
+
+    report = {}
+    # user half: inputs (P, Q); item half: inputs (Q, P1 as the GPU produced it)
+    for name, mat, this, other, got in (("user", ui, P, Q, P1), ("item", iu, Q, P1, Q1)):
+        want = np.ascontiguousarray(this.copy())
+        oracle.als_half_epoch(mat, want, other, oracle.implicit_otor(other, reg))
+        exact, cond = oracle.als_referee_f64(mat, other, reg)
+        acc = parity.als_half_accounting(got, want, exact, cond)
+        report[name] = acc
+        empty = np.diff(mat.indptr) == 0
+        assert np.all(got[empty] == 0)  # implicit.rs:98-101
+    print("\ncfg2 at-scale ALS parity:")
+    for name, acc in report.items():
+        print(" ", name, {k_: v for k_, v in acc.items() if k_ != "by_cond_decade"})
+        for dec, h in acc["by_cond_decade"].items():
+            print("     cond", dec, h)
+    for name, acc in report.items():
+        # every decidable row (cond * 2^-24 < 1e-5) within 1e-4; GPU at least as close to the
+        # float64 answer as the reference arithmetic
+        assert acc["ok"], (name, acc)
+
+
+def _sample_rows(rng, n_items, n):
+    return np.sort(rng.choice(n_items, n, replace=False)).astype(np.int32)
+
+
+def _gather_rows(out, rows):
+    "rows of a DeviceCSR similarity matrix -> host (ptr, idx, val)"
+    import torch
+
+    r = torch.as_tensor(rows.astype(np.int64), device=out.indptr.device)
+    beg, end = out.indptr[r], out.indptr[r + 1]
+    lens = end - beg
+    ptr = torch.zeros(len(rows) + 1, dtype=torch.int64, device=lens.device)
+    ptr[1:] = torch.cumsum(lens, 0)
+    pos = torch.arange(int(ptr[-1].item()), device=lens.device)
+    src = pos - torch.repeat_interleave(ptr[:-1], lens) + torch.repeat_interleave(beg, lens)
+    return ptr.cpu().numpy(), out.indices[src].cpu().numpy(), out.values[src].cpu().numpy()
+
+
+@pytest.mark.parametrize("staged", [True, False])
+def test_knn_build_cfg3_sampled_rows(gpu, oracle, ml25m, staged, monkeypatch):
+    import torch
+
+    from lkpy_amd import _device as D
+    from oracle import parity
+
+    if not staged:
+        monkeypatch.setenv("LK_IKNN_STAGE_GB", "0")
+    dui, diu, _means, _ = D.iknn_prepare(ml25m, True, gpu)
+    out = D.iknn_build(dui, diu, 1.0e-6, None)
+    assert out.indptr.dtype == torch.int64
+    nnz = int(out.indices.shape[0])
+    assert nnz > 2**29  # the regime no small test reaches
+    # the oracle side consumes the SAME normalised matrices (their bit-identity with the
+    # reference's SciPy preparation is tests/test_gpu_iknn_prepare.py's subject)
+    ui = sps.csr_array((dui.values.cpu().numpy(), dui.indices.cpu().numpy(), dui.h_indptr),
+                       shape=dui.shape)
+    iu = sps.csr_array((diu.values.cpu().numpy(), diu.indices.cpu().numpy(), diu.h_indptr),
+                       shape=diu.shape)
+    rng = np.random.default_rng(3)
+    rows = _sample_rows(rng, ui.shape[1], 2048)
+    # plus the heaviest rows (longest item columns): the multi-window / long-slice regime
+    heavy = np.argsort(-np.diff(iu.indptr))[:16].astype(np.int32)
+    rows = np.unique(np.concatenate([rows, heavy]))
+    want = oracle.iknn_build_rows(ui, iu, rows, 1.0e-6, None)
+    got = _gather_rows(out, rows)
+    res = parity.knn_rows_equal(*got, want)
+    print("\ncfg3 at-scale kNN parity (%s):" % ("staged" if staged else "two-pass"), res,
+          "of", nnz, "similarities")
+    assert res["bitwise_equal"], res
+    # structural invariants over the WHOLE output (size-independent properties)
+    ptr = out.indptr
+    assert int(ptr[0].item()) == 0 and int(ptr[-1].item()) == nnz
+    assert bool((ptr[1:] >= ptr[:-1]).all())
+    assert float(out.values.min().item()) >= 1.0e-6  # item_train.rs:135

@@ -47,7 +47,8 @@ def test_transpose_empty_and_structure_only(gpu, oracle):
     want = sps.csr_array(m.T)
     want.sort_indices()
     assert tr.shape == (25, 40)
-    assert np.array_equal(tr.offsets, want.indptr) and np.array_equal(tr.indices, want.indices)
-    assert np.array_equal(tr.values, want.data)
+    assert np.array_equal(tr.offsets.to_numpy(), want.indptr)
+    assert np.array_equal(tr.indices.to_numpy(), want.indices)
+    assert np.array_equal(tr.values.to_numpy(), want.data)
     s_only = SparseRowArray.from_scipy(m, values=False).transpose()
-    assert s_only.values is None and np.array_equal(s_only.indices, want.indices)
+    assert s_only.values is None and np.array_equal(s_only.indices.to_numpy(), want.indices)
