@@ -47,7 +47,7 @@ extern "C" {
 
 #define LK_SOLVER_CHOLESKY 0 /* exact SPD solve: the reference's method (LAPACK sposv) */
 #define LK_SOLVER_CG 1       /* tolerance-terminated conjugate gradient */
-#define LK_SOLVER_AUTO 2     /* Cholesky for k <= 64, CG above */
+#define LK_SOLVER_AUTO 2     /* = Cholesky: exact at every k <= 256, like the reference */
 
 const char *lk_last_error(void);
 const char *lk_version(void);
@@ -141,7 +141,7 @@ int lk_als_implicit_half_epoch(const lk_als_plan *plan, const void *d_indptr,
  *   A = sum_j q_j q_j^T + reg * n * I,  A x = sum_j r_j q_j   (r = bias-normalised ratings),
  * empty rows -> zeros; same plan, workspace, in-place update, status word and return value
  * (sqrt of the summed squared row deltas at d_out_frob) as the implicit form.  Exact solver
- * only (k <= 64). */
+ * only. */
 int lk_als_explicit_half_epoch(const lk_als_plan *plan, const void *d_indptr,
                                const int32_t *d_indices, const float *d_values, int64_t n_rows,
                                int64_t n_cols, int32_t k, float *d_this, int32_t ld_this,

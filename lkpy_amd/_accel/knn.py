@@ -63,9 +63,10 @@ def _score(sims, ref_items, ref_rates, tgt_items, max_nbrs, min_nbrs):
         raise TypeError("invalid similarity matrix: no values")
     assert sshape[0] == sshape[1]  # item_score.rs:113-118
     dev = D.device()
-    dsims = D.DeviceCSR(torch.from_numpy(np.asarray(so, dtype=np.int64)).to(dev),
-                        torch.from_numpy(np.ascontiguousarray(sidx)).to(dev),
-                        torch.from_numpy(np.ascontiguousarray(sval, dtype=np.float32)).to(dev),
+    # (np.array: Arrow buffers are read-only views; torch wants writable host memory)
+    dsims = D.DeviceCSR(torch.from_numpy(np.array(so, dtype=np.int64)).to(dev),
+                        torch.from_numpy(np.array(sidx, dtype=np.int32)).to(dev),
+                        torch.from_numpy(np.array(sval, dtype=np.float32)).to(dev),
                         sshape, None)
     # reference items are walked from the raw value buffer, nulls included
     # (item_score.rs:38-49); the device scorer SKIPS invalid (negative) entries instead

@@ -82,6 +82,10 @@ class ALSConfig(BaseModel):
     def model_post_init(self, _ctx):
         if self.embedding_size_exp is not None:
             object.__setattr__(self, "embedding_size", 2 ** int(self.embedding_size_exp))
+        if self.embedding_size > 256:
+            # fail at configuration time, not in the middle of training (lk_padded_dim)
+            raise ValueError(
+                f"embedding_size {self.embedding_size} exceeds the device kernels' limit of 256")
         if isinstance(self.regularization, dict):
             object.__setattr__(self, "regularization", UIPair(**self.regularization))
 
@@ -102,7 +106,9 @@ class ImplicitMFConfig(ALSConfig):
     weight: float = 40
     use_ratings: bool = False
     solver: Literal["auto", "cholesky", "cg"] = "auto"
-    "Backend knob (also ``LK_ALS_SOLVER``): exact Cholesky (reference method) or CG."
+    """Backend knob (also ``LK_ALS_SOLVER``): ``auto`` = ``cholesky`` = the exact solve the
+    reference performs (LAPACK sposv), at every supported embedding size (k <= 256); ``cg`` =
+    tolerance-terminated conjugate gradient (64 <= padded k <= 256), on request only."""
 
 
 _SOLVERS = {"auto": _native.SOLVER_AUTO, "cholesky": _native.SOLVER_CHOLESKY,

@@ -1,0 +1,731 @@
+// als_blk.hip -- exact (Cholesky) ALS row solve for 64 < k <= 256 on gfx950: ONE WORKGROUP
+// (4 waves) PER ROW, the normal matrix resident in MFMA accumulators from the first CSR entry
+// to the last pivot.
+//
+// Stands in, for embedding sizes the one-wave-per-row kernel of als_chol.hip cannot hold, for
+// `train_row_solve` (src/accel/als/implicit.rs:87-125) / `train_explicit_row`
+// (src/accel/als/explicit.rs:80-119) with `POSV::solve` = LAPACK sposv
+// (src/accel/als/solve.rs:65-107): per CSR row
+//     A = OtOr + sum_j v_j q_j q_j^T,   y = sum_j (v_j + 1) q_j,   x = A^-1 y   (exactly solved).
+//
+// Data distribution.  A' (= A in "primed" feature order, a symmetric permutation that leaves
+// the solution unchanged) is cut into 16x16 tiles; the upper tiles (ti <= tj) are dealt 2x2
+// block-cyclic to the four waves: wave (wr, wc) owns tile (ti, tj) iff ti = wr, tj = wc (mod 2).
+// Every wave then holds an (NT/2)x(NT/2) upper-triangular grid of LOCAL tiles with static
+// register indices (one code path for all waves; the wave coordinates enter only through
+// addresses and a few wave-uniform branches), NT(NT+1)/2 tiles of 4 accumulator registers in
+// total: 36 registers per wave at k = 128, 144 at k = 256.  The accumulators hold -A', so
+// that both the Gram update (-v q q^T) and the Cholesky trailing update (+L L^T) are plain
+// MFMA accumulations.
+//
+// Phases (v_mfma_f32_16x16x4_f32 throughout; f32 MFMA is bit-for-bit an fmaf chain):
+//  1. Gram: CSR entries four at a time (one K = 4 MFMA step); a lane loads exactly the NT/2
+//     features of the gathered factor row that its wave's A operands need and the NT/2 its B
+//     operands need (primed order makes both contiguous), so the four waves together fetch a
+//     row twice, from L1/L2.
+//  2. Blocked right-looking Cholesky, block size 16.  Step b: the owners of block row b write
+//     -acc to an LDS panel (k-group-major layout: every panel access below is conflict-free);
+//     every wave factors the 16x16 diagonal block in registers (lane = row, v_readlane
+//     multipliers) WHILE solving its own panel rows against it (same multipliers: the
+//     triangular solve rides along for free), the right-hand side being one more row; the
+//     finished panel L(:, b) goes back to LDS in MFMA-operand layout and the trailing update
+//     acc(ti, tj) += L(ti, b) L(tj, b)^T runs on the matrix cores, 4 MFMAs per tile.  The
+//     owners of block row b reload their L tiles into the accumulators they vacated: L ends up
+//     REGISTER RESIDENT (the packed factor of a 256 x 256 matrix is 131 KB -- it would take
+//     a whole CU's LDS and leave one row per CU; like this two rows per CU overlap their
+//     latency-bound pivot chains with each other's MFMA phases).
+//  3. Back substitution, block row by block row from the bottom: tile-times-vector partial
+//     sums straight from the accumulator registers (4 FMAs + a 16-lane reduction per tile),
+//     the 16x16 diagonal solves in one wave against the strictly-lower diagonal blocks kept
+//     in LDS (16 KB at k = 256).
+//
+// Rows longer than LK_ALS_LONG_ROW entries are pre-reduced by the chunk kernel (one workgroup
+// per chunk, same Gram phase) into slabs that the solving workgroup sums in chunk order:
+// bit-reproducible, independent of scheduling.
+//
+// Roofline: f32 MFMA (157.3 TFLOP/s).  Flops per row: n(2k^2 + 2k) +
+// k^3/3 + 2k^2; executed MFMA work: n/4 * NT(NT+1)/2 (Gram, upper tiles only) +
+// 4 * sum_{b<NT} (NT-1-b)(NT-b)/2 (trailing updates) instructions of 2048 flop.
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "als_plan.h"
+#include "common.h"
+
+namespace lk {
+namespace blk {
+
+template <int B, int E, class F>
+__device__ __forceinline__ void sfor(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        sfor<B + 1, E>(f);
+    }
+}
+
+__host__ __device__ constexpr int lt(int I, int J) { return J * (J + 1) / 2 + I; }
+
+template <int NT>
+struct Cfg {
+    static constexpr int KP = NT * 16;
+    static constexpr int NL = NT / 2;               // local tile grid of a wave: NL x NL, upper
+    static constexpr int T = NL * (NL + 1) / 2;     // accumulator tiles per wave
+    // primed order: p = t*16 + s  <->  feature f = s*NT + pos(t); even blocks first, then odd,
+    // so that the blocks a wave needs as A (t = wr mod 2) or B (t = wc mod 2) operands are NL
+    // CONTIGUOUS floats of the gathered row
+    __host__ __device__ static constexpr int pos(int t) { return (t & 1) * NL + (t >> 1); }
+    // LDS layout (floats)
+    static constexpr int P_SUB = KP * 4;            // one k-group sub-panel: [row][4]
+    static constexpr int P_SIZE = 4 * P_SUB;        // panel: [k-group g][row][4], 16 KB at KP = 256
+    static constexpr int OFF_P0 = 0;
+    static constexpr int OFF_P1 = P_SIZE;           // double buffered: one barrier less per step
+    static constexpr int OFF_LD = 2 * P_SIZE;       // NT strictly-lower diagonal blocks [16][16]
+    static constexpr int OFF_RINV = OFF_LD + NT * 256;  // 1 / L_jj
+    static constexpr int OFF_Y = OFF_RINV + KP;     // rhs, forward-substituted in place
+    static constexpr int OFF_Z = OFF_Y + KP;        // z = L^-1 y
+    static constexpr int OFF_X = OFF_Z + KP;        // solution (primed)
+    static constexpr int OFF_ZB = OFF_X + KP;       // z of the current block, double buffered
+    static constexpr int OFF_SP = OFF_ZB + 32;      // back substitution: partial sums of 2 waves
+    static constexpr int OFF_RED = OFF_SP + 32;     // delta reduction
+    static constexpr int LDS_FLOATS = OFF_RED + 8;
+    // slab of one chunk: [wave][T*4 + NL][64]
+    static constexpr int SLAB_WAVE = (T * 4 + NL) * 64;
+    static constexpr int SLAB = 4 * SLAB_WAVE;
+};
+
+template <int N>
+__device__ __forceinline__ void load_vec(const float *p, float (&q)[N])
+{
+    static_assert(N == 2 || N % 4 == 0, "vector loads of 2 or multiples of 4 floats");
+    if constexpr (N == 2) {
+        const f32x2 t = *reinterpret_cast<const f32x2 *>(p);
+        q[0] = t.x;
+        q[1] = t.y;
+    } else {
+#pragma unroll
+        for (int c = 0; c < N / 4; ++c) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(p + 4 * c);
+            q[4 * c + 0] = t.x;
+            q[4 * c + 1] = t.y;
+            q[4 * c + 2] = t.z;
+            q[4 * c + 3] = t.w;
+        }
+    }
+}
+
+// operands of one K = 4 MFMA step for this wave: entry e = lane >> 4 of the group
+template <int NT>
+struct Ops {
+    float qa[NT / 2];  // blocks t = 2I + wr, element s = lane & 15
+    float qb[NT / 2];  // blocks t = 2J + wc
+    float v;
+};
+
+template <int NT>
+__device__ __forceinline__ void ops_issue(Ops<NT> &o, int g, int col_reg, float val_reg,
+                                          const float *__restrict__ other, int lane, int wr, int wc)
+{
+    constexpr int NL = NT / 2;
+    const int s = (g * 4 + (lane >> 4)) & 63;
+    const int col = __shfl(col_reg, s, 64);
+    o.v = __shfl(val_reg, s, 64);
+    const float *base = other + (int64_t)col * (NT * 16) + (lane & 15) * NT;
+    load_vec<NL>(base + wr * NL, o.qa);
+    load_vec<NL>(base + wc * NL, o.qb);
+}
+
+// acc -= v q q^T (implicit; explicit: acc -= q q^T), y += (v + 1) q (explicit: v q).
+// ONE straight-line MFMA sequence for every wave and every group (entries past the end of the
+// row are zeroed by a select; the diagonal local tiles of wave (1,0), which would be LOWER
+// tiles, are computed like the others and simply never read): any branch around an MFMA makes
+// the compiler keep two copies of the accumulators and shuffle them at the loop head.
+template <int NT, bool EXPL>
+__device__ __forceinline__ void ops_consume(f32x4 (&acc)[Cfg<NT>::T], float (&yacc)[NT / 2],
+                                            const Ops<NT> &o, bool live)
+{
+    constexpr int NL = NT / 2;
+    // `mtl = mt * vals` (implicit.rs:110-111), negated (exact); `vals += 1.0` (implicit.rs:116)
+    const float va = EXPL ? -1.0f : -o.v;
+    const float v1 = EXPL ? o.v : o.v + 1.0f;
+    float na[NL], qb[NL];
+#pragma unroll
+    for (int I = 0; I < NL; ++I) {
+        const float q = live ? o.qa[I] : 0.f;
+        na[I] = q * va;
+        yacc[I] = fmaf(q, v1, yacc[I]);
+    }
+#pragma unroll
+    for (int J = 0; J < NL; ++J) qb[J] = live ? o.qb[J] : 0.f;
+    sfor<0, NL>([&](auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        sfor<0, J + 1>([&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            acc[lt(I, J)] = __builtin_amdgcn_mfma_f32_16x16x4f32(na[I], qb[J], acc[lt(I, J)], 0, 0, 0);
+        });
+    });
+}
+
+// CSR entries [beg, end) of one row (or chunk) into acc / yacc.  Entries are taken in batches
+// of 64 (one coalesced load of indices + values per wave), four per MFMA step; the operands of
+// the next step are in flight while the current one runs.  Every load is unconditional
+// (lanes / groups past the end re-read the last entry and are masked at use).
+template <int NT, bool EXPL>
+__device__ __forceinline__ void gram_accumulate(f32x4 (&acc)[Cfg<NT>::T], float (&yacc)[NT / 2],
+                                                const int32_t *__restrict__ cols,
+                                                const float *__restrict__ vals, int64_t beg,
+                                                int64_t end, const float *__restrict__ other,
+                                                int lane, int wr, int wc)
+{
+    const int64_t last = end - 1;  // end > beg
+    for (int64_t base = beg; base < end; base += 64) {
+        const int64_t e = (base + lane < end) ? base + lane : last;
+        const int col_reg = cols[e];
+        const float val_reg = vals[e];
+        const int nb = (end - base) < 64 ? (int)(end - base) : 64;
+        const int ng = (nb + 3) >> 2;
+        Ops<NT> cur, nxt;
+        ops_issue<NT>(cur, 0, col_reg, val_reg, other, lane, wr, wc);
+        for (int g = 0; g < ng; ++g) {
+            const int gn = (g + 1 < ng) ? g + 1 : g;
+            ops_issue<NT>(nxt, gn, col_reg, val_reg, other, lane, wr, wc);
+            ops_consume<NT, EXPL>(acc, yacc, cur, (g * 4 + (lane >> 4)) < nb);
+            cur = nxt;
+        }
+    }
+}
+
+// ---- chunk kernel: one workgroup per chunk of a long row -----------------------------------
+template <int NT, bool EXPL>
+__global__ __launch_bounds__(256) void als_blk_chunk_kernel(
+    const int32_t *__restrict__ indices, const float *__restrict__ values,
+    const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_len,
+    const float *__restrict__ other, float *__restrict__ slabs)
+{
+    using C = Cfg<NT>;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int wr = wave & 1, wc = wave >> 1;
+    const int64_t c = blockIdx.x;
+    f32x4 acc[C::T];
+    float yacc[C::NL];
+#pragma unroll
+    for (int t = 0; t < C::T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) yacc[i] = 0.f;
+    const int64_t beg = chunk_beg[c];
+    gram_accumulate<NT, EXPL>(acc, yacc, indices, values, beg, beg + chunk_len[c], other, lane, wr,
+                              wc);
+    float *slab = slabs + (size_t)c * C::SLAB + (size_t)wave * C::SLAB_WAVE;
+#pragma unroll
+    for (int t = 0; t < C::T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(t * 4 + r) * 64 + lane] = acc[t][r];
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) slab[(C::T * 4 + i) * 64 + lane] = yacc[i];
+}
+
+// ---- one step of the blocked factorisation ---------------------------------------------------
+template <int NT, int b>
+__device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__restrict__ lds,
+                                          int tid, int lane, int wave, int wr, int wc,
+                                          float &minpiv)
+{
+    using C = Cfg<NT>;
+    constexpr int NL = C::NL;
+    constexpr int R = C::KP - 16 * b;  // panel rows: block row b and everything below
+    constexpr int Ib = b >> 1;         // local tile row of block row b (in its owners)
+    float *P = lds + ((b & 1) ? C::OFF_P1 : C::OFF_P0);
+    const int sub = lane & 15, slot = lane >> 4;
+    const bool phantom = wr > wc;
+
+    // (1) the owners of block row b publish A'(b-block rows, columns >= b) = -acc, transposed
+    // by symmetry into panel rows: tile (b, tj), lane (j = sub, slot) holds
+    // D[i = 4 slot + r][j] = A'[16 tj + j][16 b + 4 slot + r] -> panel row 16 (tj - b) + j,
+    // columns 4 slot .. 4 slot + 3 = k-group `slot`
+    if (wr == (b & 1)) {
+        sfor<Ib, NL>([&](auto Jc) {
+            constexpr int J = decltype(Jc)::value;
+            if (J > Ib || !phantom) {  // J == Ib: tile (b, b - wr + wc) exists iff wc >= wr
+                const int prow = 16 * (2 * J + wc - b) + sub;
+                const f32x4 v = acc[lt(Ib, J)];
+                *reinterpret_cast<f32x4 *>(&P[slot * C::P_SUB + prow * 4]) =
+                    f32x4{-v.x, -v.y, -v.z, -v.w};
+            }
+        });
+    }
+    __syncthreads();
+
+    // (2) lane = panel row.  a: this thread's own row (16 columns of the block); d: diagonal
+    // block row (lane & 15), replicated in every wave so that the multipliers are v_readlane
+    // broadcasts and no wave waits for another.  Thread 0 carries the right-hand side instead
+    // of a matrix row (rows 0..15 of the panel ARE the diagonal block: their `a` is redundant).
+    float a[16], d[16];
+    {
+        const int prow = tid < R ? tid : R - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(&P[g * C::P_SUB + prow * 4]);
+            a[4 * g + 0] = t.x;
+            a[4 * g + 1] = t.y;
+            a[4 * g + 2] = t.z;
+            a[4 * g + 3] = t.w;
+            const f32x4 u = *reinterpret_cast<const f32x4 *>(&P[g * C::P_SUB + sub * 4]);
+            d[4 * g + 0] = u.x;
+            d[4 * g + 1] = u.y;
+            d[4 * g + 2] = u.z;
+            d[4 * g + 3] = u.w;
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = lds[C::OFF_Y + 16 * b + c];
+        }
+    }
+    float myrinv = 0.f;
+    sfor<0, 16>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const float piv = bcast(d[j], j);
+        minpiv = fminf(minpiv, piv);
+        const float rinv = __builtin_amdgcn_rsqf(piv);
+        myrinv = (sub == j) ? rinv : myrinv;
+        d[j] *= rinv;  // lanes >= j: L[lane][j] (lane j: sqrt(pivot))
+        a[j] *= rinv;  // own row: x_j = (a_j - sum_{c<j} x_c L[j][c]) / L[j][j]
+        sfor<j + 1, 16>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const float m = bcast(d[j], c);  // L[c][j]
+            d[c] = fmaf(-d[j], m, d[c]);
+            a[c] = fmaf(-a[j], m, a[c]);
+        });
+    });
+
+    // (3) L panel rows back in place (MFMA-operand layout), diagonal block + 1/L_jj to their
+    // permanent home, z_b = L_bb^-1 (y_b - ...) from thread 0
+    if (tid >= 16 && tid < R) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4 *>(&P[g * C::P_SUB + tid * 4]) =
+                f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+    }
+    if (wave == 0 && lane < 16) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4 *>(&lds[C::OFF_LD + b * 256 + lane * 16 + 4 * g]) =
+                f32x4{4 * g + 0 < lane ? d[4 * g + 0] : 0.f, 4 * g + 1 < lane ? d[4 * g + 1] : 0.f,
+                      4 * g + 2 < lane ? d[4 * g + 2] : 0.f, 4 * g + 3 < lane ? d[4 * g + 3] : 0.f};
+        lds[C::OFF_RINV + 16 * b + lane] = myrinv;
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                lds[C::OFF_ZB + (b & 1) * 16 + c] = a[c];
+                lds[C::OFF_Z + 16 * b + c] = a[c];
+            }
+        }
+    }
+    __syncthreads();
+
+    if constexpr (b + 1 < NT) {
+        // (4) forward substitution of the rows below: y_r -= L[r][b-block] . z_b
+        if (tid >= 16 && tid < R) {
+            float s = lds[C::OFF_Y + 16 * b + tid];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 z =
+                    *reinterpret_cast<const f32x4 *>(&lds[C::OFF_ZB + (b & 1) * 16 + 4 * g]);
+                s = fmaf(-a[4 * g + 0], z.x, s);
+                s = fmaf(-a[4 * g + 1], z.y, s);
+                s = fmaf(-a[4 * g + 2], z.z, s);
+                s = fmaf(-a[4 * g + 3], z.w, s);
+            }
+            lds[C::OFF_Y + 16 * b + tid] = s;
+        }
+        // (5) trailing update acc(ti, tj) += L(ti, b) L(tj, b)^T for ti, tj > b.  Operand for
+        // MFMA step kk: lane (m = sub, kg = slot) supplies L[16 (t - b) + m][4 kg + kk] -- the
+        // contraction index is enumerated as c = 4 kg + kk on BOTH operands, so one
+        // ds_read_b128 per block feeds four MFMAs.
+        // Branch-free: a block that is not below the panel for THIS wave gets a zero operand
+        // (its MFMAs add nothing; the other waves need the same instructions at that point
+        // anyway), so that every accumulator is updated in place by one instruction stream.
+        f32x4 lb[NL];
+        sfor<0, NL>([&](auto Jc) {
+            constexpr int J = decltype(Jc)::value;
+            if constexpr (2 * J + 1 > b) {
+                const bool on = 2 * J + wc > b;
+                const int prow = on ? 16 * (2 * J + wc - b) + sub : sub;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(&P[slot * C::P_SUB + prow * 4]);
+                lb[J] = on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        });
+        sfor<0, NL>([&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            if constexpr (2 * I + 1 > b) {
+                const bool on = 2 * I + wr > b;
+                const int prow = on ? 16 * (2 * I + wr - b) + sub : sub;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(&P[slot * C::P_SUB + prow * 4]);
+                const f32x4 la = on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                sfor<I, NL>([&](auto Jc) {
+                    constexpr int J = decltype(Jc)::value;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc[lt(I, J)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            la[kk], lb[J][kk], acc[lt(I, J)], 0, 0, 0);
+                });
+            }
+        });
+        // (6) the owners of block row b take their L tiles back into the registers they
+        // vacated: tile (b, tj) in accumulator layout is exactly the B operand of block tj
+        // (a select, not a branch: see above)
+        sfor<Ib, NL>([&](auto Jc) {
+            constexpr int J = decltype(Jc)::value;
+            if constexpr (2 * J + 1 > b) {
+                const bool mine = (wr == (b & 1)) && (2 * J + wc > b);
+                acc[lt(Ib, J)] = mine ? lb[J] : acc[lt(Ib, J)];
+            }
+        });
+    }
+}
+
+// ---- one block of the back substitution  L^T x = z ---------------------------------------
+template <int NT, int b>
+__device__ __forceinline__ void back_step(const f32x4 (&acc)[Cfg<NT>::T], float *__restrict__ lds,
+                                          int lane, int wave, int wr, int wc)
+{
+    using C = Cfg<NT>;
+    constexpr int NL = C::NL;
+    constexpr int Ib = b >> 1;
+    const int sub = lane & 15, slot = lane >> 4;
+    // s_b[c] = sum_{r > b} sum_j L[16 r + j][16 b + c] x[16 r + j]: tile (b, r) holds
+    // L[16 r + sub][16 b + 4 slot + rr] in register rr
+    if (wr == (b & 1)) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        sfor<Ib, NL>([&](auto Jc) {
+            constexpr int J = decltype(Jc)::value;
+            if constexpr (2 * J + 1 > b) {
+                if (2 * J + wc > b) {
+                    const float xv = lds[C::OFF_X + 16 * (2 * J + wc) + sub];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] = fmaf(acc[lt(Ib, J)][r], xv, t[r]);
+                }
+            }
+        });
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] += __shfl_xor(t[r], m, 64);
+        if (sub == 0)
+            *reinterpret_cast<f32x4 *>(&lds[C::OFF_SP + wc * 16 + slot * 4]) =
+                f32x4{t[0], t[1], t[2], t[3]};
+    }
+    __syncthreads();
+    // diagonal block: lane = column c; x_j for j = 15 .. 0, each broadcast to the lanes c < j
+    if (wave == 0) {
+        const int c = lane & 15;
+        float dc = lds[C::OFF_Z + 16 * b + c] - lds[C::OFF_SP + c] - lds[C::OFF_SP + 16 + c];
+        const float ri = lds[C::OFF_RINV + 16 * b + c];
+        float lc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lc[j] = lds[C::OFF_LD + b * 256 + j * 16 + c];  // L[j][c], j > c
+        float xc = 0.f;
+        sfor<0, 16>([&](auto jj) {
+            constexpr int j = 15 - decltype(jj)::value;
+            const float xj = bcast(dc * ri, j);
+            xc = (c == j) ? xj : xc;
+            dc = fmaf(-lc[j], xj, dc);  // strictly lower: touches the lanes c < j only
+        });
+        if (lane < 16) lds[C::OFF_X + 16 * b + c] = xc;
+    }
+    __syncthreads();
+}
+
+template <int NT, int... Bs>
+__device__ __forceinline__ void chol_all(f32x4 (&acc)[Cfg<NT>::T], float *lds, int tid, int lane,
+                                         int wave, int wr, int wc, float &minpiv,
+                                         std::integer_sequence<int, Bs...>)
+{
+    (chol_step<NT, Bs>(acc, lds, tid, lane, wave, wr, wc, minpiv), ...);
+}
+
+template <int NT, int... Bs>
+__device__ __forceinline__ void back_all(const f32x4 (&acc)[Cfg<NT>::T], float *lds, int lane,
+                                         int wave, int wr, int wc, std::integer_sequence<int, Bs...>)
+{
+    (back_step<NT, NT - 1 - Bs>(acc, lds, lane, wave, wr, wc), ...);
+}
+
+#ifndef LK_ALS_BLK_ATTR16
+#define LK_ALS_BLK_ATTR16 __attribute__((amdgpu_waves_per_eu(2)))
+#endif
+#ifndef LK_ALS_BLK_ATTR8
+#define LK_ALS_BLK_ATTR8 __attribute__((amdgpu_waves_per_eu(4)))
+#endif
+
+// ---- solve kernel: one workgroup per row ------------------------------------------------------
+template <int NT, bool IS64, bool EXPL, bool CTL>
+__device__ __forceinline__ void als_blk_solve_body(
+    const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_rows,
+    const int32_t *__restrict__ row_slab, const float *__restrict__ other,
+    float *__restrict__ this_, const float *__restrict__ notor_p,
+    const float *__restrict__ slabs, float *__restrict__ row_delta, int *__restrict__ status,
+    int k, float reg, TaskCtlDev ctl, float *lds)
+{
+    using C = Cfg<NT>;
+    constexpr int KP = C::KP, NL = C::NL;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = lane_id();
+    const int wr = wave & 1, wc = wave >> 1;
+    const int sub = lane & 15, slot = lane >> 4;
+    const bool phantom = wr > wc;
+    const int64_t t = blockIdx.x;
+    if (t >= n_rows) return;
+    if constexpr (CTL) {  // AccelTask.cancel: rows not started yet are skipped
+        // one decision per WORKGROUP (the waves meet at barriers later: they must agree)
+        if (tid == 0) lds[C::OFF_RED + 4] = ctl_cancelled(ctl, (blockIdx.x & 63) == 0) ? 1.f : 0.f;
+        __syncthreads();
+        const bool c = lds[C::OFF_RED + 4] != 0.f;
+        __syncthreads();
+        if (c) return;
+    }
+    const int row = order[t];
+    const int64_t beg = indptr[row], end = indptr[row + 1];
+    float *xrow = this_ + (int64_t)row * KP;
+    if (end == beg) {  // implicit.rs:98-101
+        if (tid < KP) xrow[tid] = 0.f;
+        if (tid == 0) {
+            row_delta[row] = 0.f;
+            if constexpr (CTL) ctl_advance(ctl, 1);
+        }
+        return;
+    }
+
+    // -- phase 1: -A' = -OtOr' - sum v q q^T in the accumulators ------------------------------
+    f32x4 acc[C::T];
+    float yacc[NL];
+    sfor<0, NL>([&](auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        sfor<0, J + 1>([&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            const int ti = 2 * I + wr, tj = 2 * J + wc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[lt(I, J)][r] =
+                    (I == J && phantom) ? 0.f
+                                        : notor_p[(ti * 16 + slot * 4 + r) * KP + tj * 16 + sub];
+        });
+    });
+#pragma unroll
+    for (int i = 0; i < NL; ++i) yacc[i] = 0.f;
+
+    const int first_slab = row_slab[row];
+    if (first_slab >= 0) {
+        const int64_t n = end - beg;
+        const int ns = (int)((n + LK_ALS_CHUNK_BLK - 1) / LK_ALS_CHUNK_BLK);
+        for (int s = 0; s < ns; ++s) {
+            const float *slab =
+                slabs + (size_t)(first_slab + s) * C::SLAB + (size_t)wave * C::SLAB_WAVE;
+#pragma unroll
+            for (int tt = 0; tt < C::T; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[tt][r] += slab[(tt * 4 + r) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < NL; ++i) yacc[i] += slab[(C::T * 4 + i) * 64 + lane];
+        }
+    } else {
+        gram_accumulate<NT, EXPL>(acc, yacc, indices, values, beg, end, other, lane, wr, wc);
+    }
+    if (EXPL) {
+        // explicit.rs:104-107: A[i][i] += reg * n on the real features (acc = -A)
+        const float dg = reg * (float)(end - beg);
+        if (wr == wc) {
+            sfor<0, NL>([&](auto Ic) {
+                constexpr int I = decltype(Ic)::value;
+                const int f = sub * NT + C::pos(2 * I + wr);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (slot * 4 + r == sub && f < k) acc[lt(I, I)][r] -= dg;
+            });
+        }
+    }
+    // y: combine the four entry slots; the waves (wr, 0) publish blocks t = 2 I + wr
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        yacc[i] += __shfl_xor(yacc[i], 16, 64);
+        yacc[i] += __shfl_xor(yacc[i], 32, 64);
+    }
+    if (wc == 0 && slot == 0) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) lds[C::OFF_Y + (2 * i + wr) * 16 + sub] = yacc[i];
+    }
+    // (the first barrier of chol_step<0> orders these stores before thread 0 reads them)
+
+    // -- phase 2: blocked Cholesky with the forward substitution riding along ------------------
+    float minpiv = 3.0e38f;
+    chol_all<NT>(acc, lds, tid, lane, wave, wr, wc, minpiv, std::make_integer_sequence<int, NT>{});
+
+    // -- phase 3: back substitution ----------------------------------------------------------
+    back_all<NT>(acc, lds, lane, wave, wr, wc, std::make_integer_sequence<int, NT>{});
+
+    // -- output: un-prime through LDS so that the row is written coalesced --------------------
+    if (tid < KP) {
+        const int f = (tid & 15) * NT + C::pos(tid >> 4);
+        lds[C::OFF_Y + f] = lds[C::OFF_X + tid];
+    }
+    __syncthreads();
+    float dd = 0.f;
+    bool bad = !(minpiv > 0.f);
+    if (tid < KP && tid < k) {
+        const float x = lds[C::OFF_Y + tid];
+        const float old = xrow[tid];
+        xrow[tid] = x;
+        dd = x - old;
+        bad = bad || !(fabsf(x) <= 3.0e38f);
+    }
+    const float d2 = wave_sum(dd * dd);
+    if (lane == 0) lds[C::OFF_RED + wave] = d2;
+    if (__any(bad) && lane == 0) atomicCAS(status, 0, row + 1);
+    __syncthreads();
+    if (tid == 0) {
+        row_delta[row] = ((lds[C::OFF_RED] + lds[C::OFF_RED + 1]) + lds[C::OFF_RED + 2]) +
+                         lds[C::OFF_RED + 3];
+        if constexpr (CTL) ctl_advance(ctl, 1);
+    }
+}
+
+#define LK_BLK_KERNEL(NAME, NTV, ATTR)                                                          \
+    template <bool IS64, bool EXPL, bool CTL>                                                   \
+    __global__ __launch_bounds__(256) ATTR void NAME(                                           \
+        const typename IndPtr<IS64>::type *__restrict__ indptr,                                 \
+        const int32_t *__restrict__ indices, const float *__restrict__ values,                  \
+        const int32_t *__restrict__ order, int64_t n_rows, const int32_t *__restrict__ row_slab, \
+        const float *__restrict__ other, float *__restrict__ this_,                             \
+        const float *__restrict__ notor_p, const float *__restrict__ slabs,                     \
+        float *__restrict__ row_delta, int *__restrict__ status, int k, float reg,              \
+        TaskCtlDev ctl)                                                                         \
+    {                                                                                           \
+        __shared__ __attribute__((aligned(16))) float lds[Cfg<NTV>::LDS_FLOATS];                \
+        als_blk_solve_body<NTV, IS64, EXPL, CTL>(indptr, indices, values, order, n_rows,        \
+                                                 row_slab, other, this_, notor_p, slabs,        \
+                                                 row_delta, status, k, reg, ctl, lds);          \
+    }
+
+LK_BLK_KERNEL(als_blk_solve_kernel16, 16, LK_ALS_BLK_ATTR16)
+LK_BLK_KERNEL(als_blk_solve_kernel8, 8, LK_ALS_BLK_ATTR8)
+#undef LK_BLK_KERNEL
+
+// -OtOr [k x k] -> primed [KP x KP] of this file's feature order, -1 on the pad diagonal
+template <int NT>
+__global__ void als_blk_prep_otor_kernel(const float *__restrict__ otor, int ld_otor, int k,
+                                         float *__restrict__ notor_p)
+{
+    using C = Cfg<NT>;
+    constexpr int KP = C::KP;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= KP * KP) return;
+    const int pr = idx / KP, pc = idx % KP;
+    const int fr = (pr & 15) * NT + C::pos(pr >> 4), fc = (pc & 15) * NT + C::pos(pc >> 4);
+    float v;
+    if (fr < k && fc < k)
+        v = otor ? -otor[fr * ld_otor + fc] : 0.f;  // explicit mode: no OtOr term
+    else
+        v = (pr == pc) ? -1.0f : 0.0f;
+    notor_p[idx] = v;
+}
+
+template <int NT, bool IS64, bool EXPL>
+static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *indices,
+                      const float *values, int64_t n_rows, int k, float *this_, const float *other,
+                      const float *otor, int ld_otor, char *ws, float *out_frob, hipStream_t st,
+                      float reg)
+{
+    using C = Cfg<NT>;
+    using IT = typename IndPtr<IS64>::type;
+    int *status = reinterpret_cast<int *>(ws + p->off_status);
+    float *notor_p = reinterpret_cast<float *>(ws + p->off_otor);
+    float *row_delta = reinterpret_cast<float *>(ws + p->off_delta);
+    float *partial = reinterpret_cast<float *>(ws + p->off_partial);
+    float *slabs = reinterpret_cast<float *>(ws + p->off_slabs);
+
+    LK_HIP_CHECK(hipMemsetAsync(status, 0, 64, st));
+    if (p->ctl) {
+        LK_HIP_CHECK(hipMemsetAsync(row_delta, 0, (size_t)n_rows * sizeof(float), st));
+        int rc = ctl_begin(p->ctl, n_rows, n_rows, st);
+        if (rc != LK_OK) return rc;
+    }
+    hipLaunchKernelGGL(als_blk_prep_otor_kernel<NT>, dim3((C::KP * C::KP + 255) / 256), dim3(256),
+                       0, st, otor, ld_otor, k, notor_p);
+    const bool tm = p->timing && p->timing_n < lk_als_plan::TIMING_RING;
+    if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][0], st));
+    if (p->n_chunks > 0)
+        hipLaunchKernelGGL((als_blk_chunk_kernel<NT, EXPL>), dim3((unsigned)p->n_chunks), dim3(256),
+                           0, st, indices, values, p->d_chunk_beg, p->d_chunk_len, other, slabs);
+    if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
+    if (n_rows > 0) {
+        const dim3 grid((unsigned)n_rows), block(256);
+        const IT *ip = static_cast<const IT *>(indptr);
+#define LK_BLK_LAUNCH(KERN, CTLV)                                                                \
+    hipLaunchKernelGGL((KERN<IS64, EXPL, CTLV>), grid, block, 0, st, ip, indices, values,        \
+                       p->d_order, n_rows, p->d_row_slab, other, this_, notor_p, slabs,          \
+                       row_delta, status, k, reg, (CTLV) ? p->ctl->dev() : TaskCtlDev{})
+        if constexpr (NT == 16) {
+            if (p->ctl)
+                LK_BLK_LAUNCH(als_blk_solve_kernel16, true);
+            else
+                LK_BLK_LAUNCH(als_blk_solve_kernel16, false);
+        } else {
+            if (p->ctl)
+                LK_BLK_LAUNCH(als_blk_solve_kernel8, true);
+            else
+                LK_BLK_LAUNCH(als_blk_solve_kernel8, false);
+        }
+#undef LK_BLK_LAUNCH
+    }
+    if (tm) {
+        LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][2], st));
+        p->timing_n++;
+    }
+    int rc = launch_delta_reduce(row_delta, n_rows, partial, out_frob, st);
+    if (rc != LK_OK) return rc;
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+}  // namespace blk
+
+size_t als_blk_slab_floats(int NT)
+{
+    return NT == 16 ? (size_t)blk::Cfg<16>::SLAB : (size_t)blk::Cfg<8>::SLAB;
+}
+
+// Exact half-epoch for KP = 128 / 256 (dispatch target of lk_als_implicit_half_epoch /
+// lk_als_explicit_half_epoch); `otor` null = explicit model.
+int als_blk_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
+                       const float *values, int64_t n_rows, int k, float *this_, const float *other,
+                       const float *otor, int ld_otor, char *ws, float *out_frob, hipStream_t st,
+                       bool expl, float reg)
+{
+#define LK_BLK_CASE(NTV)                                                                      \
+    do {                                                                                      \
+        if (expl)                                                                             \
+            return is64 ? blk::launch_blk<NTV, true, true>(p, indptr, indices, values, n_rows, \
+                                                           k, this_, other, otor, ld_otor, ws, \
+                                                           out_frob, st, reg)                 \
+                        : blk::launch_blk<NTV, false, true>(p, indptr, indices, values, n_rows, \
+                                                            k, this_, other, otor, ld_otor,   \
+                                                            ws, out_frob, st, reg);           \
+        return is64 ? blk::launch_blk<NTV, true, false>(p, indptr, indices, values, n_rows, k, \
+                                                        this_, other, otor, ld_otor, ws,      \
+                                                        out_frob, st, reg)                    \
+                    : blk::launch_blk<NTV, false, false>(p, indptr, indices, values, n_rows,  \
+                                                         k, this_, other, otor, ld_otor, ws,  \
+                                                         out_frob, st, reg);                  \
+    } while (0)
+    if (p->KP == 256) LK_BLK_CASE(16);
+    if (p->KP == 128) LK_BLK_CASE(8);
+#undef LK_BLK_CASE
+    set_error("blocked Cholesky: unsupported padded embedding size %d", p->KP);
+    return LK_E_INVALID;
+}
+
+}  // namespace lk

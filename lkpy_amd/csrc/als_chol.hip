@@ -50,12 +50,6 @@
 // scratch instead of 248 registers (2 waves per SIMD): +14 % epochs/s (tools/als_variants.py)
 #define LK_ALS_SOLVE_ATTR __attribute__((amdgpu_waves_per_eu(3)))
 #endif
-#ifndef LK_ALS_CHUNK
-#define LK_ALS_CHUNK 1024  // CSR entries per chunk of a long row
-#endif
-#ifndef LK_ALS_LONG_ROW
-#define LK_ALS_LONG_ROW 2048  // rows longer than this are chunked
-#endif
 
 namespace lk {
 
@@ -728,11 +722,12 @@ extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int i
     LK_REQUIRE(n_rows >= 0 && n_rows < (int64_t)INT32_MAX, "lk_als_plan_create: bad n_rows");
     int KP = lk_padded_dim(k);
     LK_REQUIRE(KP > 0, "lk_als_plan_create: unsupported embedding size k=%d (1..256)", k);
-    if (solver == LK_SOLVER_AUTO) solver = (KP <= 64) ? LK_SOLVER_CHOLESKY : LK_SOLVER_CG;
+    // the reference solves every row exactly (sposv): so does AUTO, at every k
+    if (solver == LK_SOLVER_AUTO) solver = LK_SOLVER_CHOLESKY;
     LK_REQUIRE(solver == LK_SOLVER_CHOLESKY || solver == LK_SOLVER_CG,
                "lk_als_plan_create: unknown solver %d", solver);
-    LK_REQUIRE(!(solver == LK_SOLVER_CHOLESKY && KP > 64),
-               "lk_als_plan_create: the Cholesky solver supports k <= 64 (got %d); use CG", k);
+    LK_REQUIRE(!(solver == LK_SOLVER_CG && KP < 64),
+               "lk_als_plan_create: the CG solver needs k > 32 (got %d)", k);
 
     auto *p = new lk_als_plan();
     p->n_rows = n_rows;
@@ -799,7 +794,9 @@ extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int i
     p->off_partial = off;
     off += lk::align_up((size_t)lk::DELTA_BLOCKS * sizeof(float), 256);
     p->off_slabs = off;
-    size_t slab_f = (size_t)(lk::als_tiles(p->NT) * 4 + p->NT) * 64;
+    // one-wave slabs (als_chol.hip, k <= 64) or four-wave slabs (als_blk.hip, k = 128 / 256)
+    size_t slab_f = KP > 64 ? lk::als_blk_slab_floats(p->NT)
+                            : (size_t)(lk::als_tiles(p->NT) * 4 + p->NT) * 64;
     off += lk::align_up((size_t)std::max<int64_t>(p->n_chunks, 1) * slab_f * sizeof(float), 256);
     p->ws_bytes = off;
     *out = p;
@@ -895,6 +892,10 @@ extern "C" int lk_als_implicit_half_epoch(const lk_als_plan *plan, const void *d
         return lk::als_cg_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows, k,
                                      d_this, ld_this, d_other, ld_other, d_otor, ld_otor, ws,
                                      d_out_frob, st);
+    if (plan->KP > 64)
+        return lk::als_blk_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows, k,
+                                      d_this, d_other, d_otor, ld_otor, ws, d_out_frob, st, false,
+                                      0.f);
 #define LK_CHOL_CASE(NT)                                                                        \
     return plan->is64 ? lk::launch_chol<NT, true>(plan, d_indptr, d_indices, d_values, n_rows, \
                                                   k, d_this, ld_this, d_other, ld_other,       \
@@ -933,9 +934,12 @@ extern "C" int lk_als_explicit_half_epoch(const lk_als_plan *plan, const void *d
     LK_REQUIRE(n_cols >= 0 && (n_cols == 0 || d_other), "lk_als_explicit_half_epoch: null other");
     LK_REQUIRE(plan->solver != LK_SOLVER_CG,
                "lk_als_explicit_half_epoch: only the exact (Cholesky) solver is built for the "
-               "explicit model (k <= 64)");
+               "explicit model");
     hipStream_t st = lk::as_stream(stream);
     char *ws = static_cast<char *>(d_ws);
+    if (plan->KP > 64)
+        return lk::als_blk_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows, k,
+                                      d_this, d_other, nullptr, 0, ws, d_out_frob, st, true, reg);
 #define LK_CHOL_CASE(NT)                                                                         \
     return plan->is64                                                                            \
                ? lk::launch_chol<NT, true, true>(plan, d_indptr, d_indices, d_values, n_rows, k, \

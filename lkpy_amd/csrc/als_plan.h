@@ -5,6 +5,14 @@
 
 #define LK_DELTA_BLOCKS 256
 
+#ifndef LK_ALS_CHUNK
+#define LK_ALS_CHUNK 1024  // CSR entries per chunk of a long row
+#endif
+#ifndef LK_ALS_LONG_ROW
+#define LK_ALS_LONG_ROW 2048  // rows longer than this are chunked
+#endif
+#define LK_ALS_CHUNK_BLK LK_ALS_CHUNK  // same chunking for the workgroup-per-row kernel (als_blk.hip)
+
 struct lk_als_plan {
     int64_t n_rows = 0;
     int32_t k = 0, KP = 0, NT = 0, solver = 0;
@@ -32,6 +40,12 @@ struct lk_als_plan {
 };
 
 namespace lk {
+// exact half-epoch for padded k = 128 / 256: one workgroup per row (als_blk.hip)
+size_t als_blk_slab_floats(int NT);
+int als_blk_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
+                       const float *values, int64_t n_rows, int k, float *this_, const float *other,
+                       const float *otor, int ld_otor, char *ws, float *out_frob, hipStream_t st,
+                       bool expl, float reg);
 // deterministic two-stage sum of the per-row squared deltas -> sqrt (als_chol.hip)
 int launch_delta_reduce(const float *row_delta, int64_t n_rows, float *partial, float *out_frob,
                         hipStream_t st);

@@ -98,6 +98,10 @@ int ctl_begin(lk_task_ctl *ctl, int64_t rows_total, int64_t units_total, hipStre
     // progress restarts; a cancel requested before the launch stays visible (h_words[0])
     *reinterpret_cast<volatile unsigned long long *>(ctl->h_words + 2) = 0ull;
     LK_HIP_CHECK(hipMemsetAsync(ctl->d_words, 0, 16, st));
+    // a cancel requested before the launch is planted in HBM directly: no row starts at all
+    // (otherwise every resident workgroup would begin before the first PCIe poll returns)
+    if (__atomic_load_n(ctl->h_words, __ATOMIC_ACQUIRE))
+        LK_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctl->d_words), 1, 1, st));
     return LK_OK;
 }
 

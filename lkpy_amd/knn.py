@@ -94,9 +94,9 @@ class ItemKNNScorer(Component):
             so, si, sv, shape = csr_arrays(self.sim_matrix)
             dev = {"device": d,
                    "sims": D.DeviceCSR(
-                       torch.from_numpy(np.asarray(so, dtype=np.int64)).to(d),
-                       torch.from_numpy(np.ascontiguousarray(si)).to(d),
-                       torch.from_numpy(np.ascontiguousarray(sv, dtype=np.float32)).to(d),
+                       torch.from_numpy(np.array(so, dtype=np.int64)).to(d),
+                       torch.from_numpy(np.array(si, dtype=np.int32)).to(d),
+                       torch.from_numpy(np.array(sv, dtype=np.float32)).to(d),
                        shape, None)}
             self._dev = dev
         return dev

@@ -12,9 +12,13 @@ from IDENTICAL inputs on both sides:
 * the matrix-level relative error GPU vs oracle (Frobenius),
 * how many rows exceed 1e-4 (row-wise ``||x_gpu - x_oracle|| / ||x_oracle||``) and the
   condition numbers of exactly those rows (lower-bound estimates from the float64 referee),
-* the claim that is asserted: EVERY row with ``cond * 2^-24 < 1e-5`` is within 1e-4, and the
+* the claims that are asserted: EVERY row with ``cond * 2^-24 < 1e-5`` is within 1e-4; the
   GPU is no further from the float64 referee than the reference arithmetic is (matrix level,
-  factor 2 slack),
+  factor 2 slack); and -- the statement that is not vacuous on real data, where
+  ``cond(A) >= 100`` for every non-empty row because ``cond(OtOr)`` already is -- EVERY row of
+  the GPU result lies within ``NORM_BOUND * cond * 2^-24`` of the float64 answer (the a-priori
+  forward error of a backward-stable float32 solve, measured constant: 1.3 / 2.4 for the HIP
+  kernels on the ML-25M-shaped epoch, 1.3 / 7.3 for the reference arithmetic),
 * a histogram of row error against cond (decades), so nothing hides behind a loose bound.
 """
 
@@ -25,6 +29,7 @@ import numpy as np
 U32 = 2.0**-24  # unit roundoff of float32
 RTOL = 1.0e-4  # north_star tolerance
 COND_LIMIT = 1.0e-5 / U32  # rows with cond below this must meet RTOL (~168)
+NORM_BOUND = 4.0  # every GPU row within NORM_BOUND * cond * u of the float64 answer
 
 
 def _row_rel(a: np.ndarray, b: np.ndarray) -> np.ndarray:
@@ -94,6 +99,8 @@ def als_half_accounting(got: np.ndarray, want: np.ndarray, exact: np.ndarray | N
             e_o = _row_rel(want, exact)
             res["row_err_over_cond_u_max_gpu"] = float((e_g[nzc] / cu[nzc]).max()) if nzc.any() else 0.0
             res["row_err_over_cond_u_max_oracle"] = float((e_o[nzc] / cu[nzc]).max()) if nzc.any() else 0.0
+            # cond is a LOWER-bound estimate, which only makes this test stricter
+            ok &= res["row_err_over_cond_u_max_gpu"] <= NORM_BOUND
     res["ok"] = bool(ok)
     return res
 

@@ -183,7 +183,7 @@ def test_half_epoch_cg(gpu, oracle, rng, k):
     want_frob = oracle.als_half_epoch(mat, want, other, otor)
 
     csr = D.DeviceCSR.from_scipy(mat, gpu)
-    plan = D.ALSPlan(csr, k, _native.SOLVER_CG if k == 64 else _native.SOLVER_AUTO)
+    plan = D.ALSPlan(csr, k, _native.SOLVER_CG)  # AUTO is the exact solver at every k
     assert plan.solver == _native.SOLVER_CG
     plan.set_cg(1e-7, 2 * k)
     d_this = D.to_device_padded(this, gpu)
@@ -207,10 +207,83 @@ def test_half_epoch_cg(gpu, oracle, rng, k):
     assert np.array_equal(D.to_host_unpadded(d2, k), got)
 
 
-def test_cholesky_refuses_large_k(gpu, rng):
+@pytest.mark.parametrize("k,is64", [(100, False), (128, True), (200, False), (256, False)])
+def test_half_epoch_exact_large_k(gpu, oracle, rng, k, is64):
+    """
+    The exact solver for 64 < k <= 256 (csrc/als_blk.hip: one workgroup per row, blocked
+    Cholesky on the matrix cores) against the oracle's sposv path
+    (src/accel/als/implicit.rs:87-125, solve.rs:65-107): chunked long rows, empty rows, rows
+    shorter than one MFMA step, padded (k = 100, 200) and full-width embeddings, both offset
+    widths; AUTO selects it; bit-reproducible.
+    """
     from lkpy_amd import _device as D
     from lkpy_amd import _native
 
-    mat = _random_csr(rng, 10, 20, 3)
-    with pytest.raises(ValueError, match="Cholesky solver supports k <= 64"):
-        D.ALSPlan(D.DeviceCSR.from_scipy(mat, gpu), 128, _native.SOLVER_CHOLESKY)
+    n_rows, n_cols = 700, 3000
+    mat = _random_csr(rng, n_rows, n_cols, 30, long_rows=(2500, 1100))
+    other = (rng.standard_normal((n_cols, k)) * 0.1).astype(np.float32)
+    this = (rng.standard_normal((n_rows, k)) * 0.1).astype(np.float32)
+    otor = oracle.implicit_otor(other, 0.1)
+    want = this.copy()
+    want_frob = oracle.als_half_epoch(mat, want, other, otor)
+    exact, _ = oracle.als_referee_f64(mat, other, 0.1, with_cond=False)
+
+    dt = np.int64 if is64 else np.int32
+    csr = D.DeviceCSR.from_arrays(mat.indptr.astype(dt), mat.indices, mat.data, mat.shape, gpu)
+    plan = D.ALSPlan(csr, k, _native.SOLVER_AUTO)
+    assert plan.solver == _native.SOLVER_CHOLESKY
+    d_this = D.to_device_padded(this, gpu)
+    d_other = D.to_device_padded(other, gpu)
+    d_otor = D.Gramian(k, gpu)(d_other, 0.1)
+    frob = plan.half_epoch(d_this, d_other, d_otor)
+    plan.check_status()
+    got = D.to_host_unpadded(d_this, k)
+    empty = np.diff(mat.indptr) == 0
+    assert empty.any() and np.all(got[empty] == 0.0)
+    assert _rel(got, want) < RTOL, _rel(got, want)
+    # as close to the float64 answer as the reference arithmetic (factor 2)
+    assert _rel(got, exact) <= 2 * _rel(want, exact) + 1e-6
+    rn = np.linalg.norm(want, axis=1)
+    err = np.linalg.norm(got - want, axis=1)
+    assert np.all(err <= 5 * RTOL * np.maximum(rn, 1e-3))
+    assert abs(float(frob.item()) - want_frob) <= 1e-4 * want_frob
+    if d_this.shape[1] > k:
+        assert float(d_this[:, k:].abs().max().item()) == 0.0
+    d2 = D.to_device_padded(this, gpu)
+    plan.half_epoch(d2, d_other, d_otor)
+    plan.check_status()
+    assert np.array_equal(D.to_host_unpadded(d2, k), got)
+
+
+def test_large_k_not_spd_and_tiny_rows(gpu, oracle, rng):
+    "k = 128: a non-SPD normal matrix is reported; rows of 1..5 entries (less than one MFMA group)"
+    import torch
+
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    k = 128
+    mat = sps.csr_array((np.array([1.0], np.float32), np.array([0], np.int32),
+                         np.array([0, 1], np.int64)), shape=(1, 2))
+    plan = D.ALSPlan(D.DeviceCSR.from_scipy(mat, gpu), k, _native.SOLVER_CHOLESKY)
+    this = torch.zeros((1, k), device=gpu)
+    plan.half_epoch(this, torch.ones((2, k), device=gpu), -torch.eye(k, device=gpu) * 100.0)
+    with pytest.raises(RuntimeError, match="ALS solve error"):
+        plan.check_status()
+
+    lens = np.array([1, 2, 3, 4, 5, 0, 7, 64, 65, 130], dtype=np.int64)
+    n_cols = 400
+    idx = np.concatenate([np.sort(rng.choice(n_cols, n, replace=False)) for n in lens])
+    ptr = np.concatenate([[0], np.cumsum(lens)])
+    small = sps.csr_array((np.full(len(idx), 40.0, np.float32), idx.astype(np.int32), ptr),
+                          shape=(len(lens), n_cols))
+    other = (rng.standard_normal((n_cols, k)) * 0.2).astype(np.float32)
+    this0 = np.zeros((len(lens), k), np.float32)
+    want = this0.copy()
+    oracle.als_half_epoch(small, want, other, oracle.implicit_otor(other, 0.1))
+    p2 = D.ALSPlan(D.DeviceCSR.from_scipy(small, gpu), k, _native.SOLVER_CHOLESKY)
+    d_this = D.to_device_padded(this0, gpu)
+    d_other = D.to_device_padded(other, gpu)
+    p2.half_epoch(d_this, d_other, D.Gramian(k, gpu)(d_other, 0.1))
+    p2.check_status()
+    assert _rel(D.to_host_unpadded(d_this, k), want) < RTOL

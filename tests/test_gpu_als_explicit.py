@@ -8,7 +8,7 @@ from test_gpu_als import RTOL, _random_csr, _rel
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("k", [10, 25, 64])
+@pytest.mark.parametrize("k", [10, 25, 64, 128, 200])
 @pytest.mark.parametrize("is64", [False, True])
 def test_explicit_half_epoch_random(gpu, oracle, rng, k, is64):
     """explicit.rs:80-119 on the kernel: A = M^T M + reg n I, rhs M^T r; short rows, rows that
