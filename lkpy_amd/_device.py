@@ -99,6 +99,9 @@ class DeviceCSR:
             indptr = indptr.astype(np.int64)
         indices = np.ascontiguousarray(indices, dtype=np.int32)
         values = np.ascontiguousarray(values, dtype=np.float32)
+        # zero-copy views of Arrow buffers are read-only; torch.from_numpy wants writable memory
+        indptr, indices, values = (a if a.flags.writeable else a.copy()
+                                   for a in (indptr, indices, values))
         return cls(
             torch.from_numpy(indptr).to(dev),
             torch.from_numpy(indices).to(dev),
