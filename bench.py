@@ -6,22 +6,27 @@ bench.py -- headline benchmark of the MI355X backend (BASELINE.json metric).
 
 Workload (N = 1): BASELINE.json configs[1] -- "MovieLens-25M, als-implicit k=64, 20
 epochs, 1 x MI355X".  MovieLens-25M itself is not on the box (no network), so the
-input is the seeded ML-25M-shaped synthetic of ``lkpy_amd.synth`` (same user/item
-counts, ~same nnz and activity skew).  A *step* is ONE ALS
-EPOCH: user half-epoch + item half-epoch + both Gramians (+ the exchanges when
-N > 1), with CSR and factors already resident in HBM.  ``value`` = epochs/second.
+input is the seeded ML-25M-shaped synthetic of ``lkpy_amd.synth``.
+A *step* is ONE ALS EPOCH: user half-epoch + item half-epoch + both Gramians (+ the
+exchanges when N > 1), with CSR and factors already resident in HBM.  ``value`` = epochs/s.
 
 For N > 1 the driver launches one process per GPU (torch.distributed.run); users and
 items are row-sharded (lkpy_amd._als_engine) and total work is fixed => "strong".
 
-One JSON line on rank 0.  Extra objects:
-  roofline     -- the dominant kernel (als_solve_kernel, f32 MFMA bound): algorithmic
-                  flops per launch / average launch duration (HIP events recorded on
-                  the launch stream inside the library, lk_als_plan_get_timing).
-  cpu_baseline -- the CPU oracle (a port of the reference's Rust + LAPACK path) timed
-                  on this box's host cores on a bounded row sample (rank 0, N = 1).
-  knn          -- item-kNN model build seconds on the same data (BASELINE.json
-                  metric's second half), when the build kernel is available.
+One JSON line on rank 0.  Extra objects (rank 0, N = 1):
+  roofline     -- the dominant kernel (f32 MFMA bound): algorithmic flops per launch
+                   / average launch duration from HIP events recorded on the
+                  launch stream inside the library; ``frac_executed`` counts the MFMA work
+                  actually issued (upper tiles only: (NT+1)/(2 NT) of the 2k^2 convention).
+  parity       -- GPU vs oracle FROM IDENTICAL INPUTS at full scale: every ALS row of one
+                  epoch (with the float64 referee and cond(A) accounting of
+                  oracle/parity.py), sampled item-kNN rows bitwise.
+  cpu_baseline -- the CPU oracle (a port of the reference's Rust + LAPACK path) timed on this
+                  box's host cores: the very half-epochs of the parity leg (all rows).
+  fit          -- what ``north_star`` names: ``ImplicitMFScorer(...).train(dataset)`` end to
+                  end (matrix preparation, upload, relabel + transpose in HBM, plans, epochs,
+                  download), with the per-epoch times of the reference's own log line.
+  topk / knn   -- the other two legs of the metric, each with roofline + cpu_baseline.
 """
 
 from __future__ import annotations
@@ -39,7 +44,9 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix)
-LONG_ROW = int(os.environ.get("LK_BENCH_LONG_ROW", 2048))  # LK_ALS_LONG_ROW in lkpy_amd/csrc/als_chol.hip
+HBM_PEAK_GBS = 8000.0  # same guide: HBM3E peak 8 TB/s
+LONG_ROW = int(os.environ.get("LK_BENCH_LONG_ROW", 2048))  # LK_ALS_LONG_ROW (csrc/als_plan.h)
+CHUNK = 1024  # LK_ALS_CHUNK
 
 
 def half_flops(lengths: np.ndarray, k: int):
@@ -57,24 +64,48 @@ def half_flops(lengths: np.ndarray, k: int):
     return short_nnz * per_nnz + nonempty * per_row, long_nnz * per_nnz
 
 
+def half_mfma_flops(lengths: np.ndarray, kp: int):
+    """
+    Matrix-core flops the solve kernel actually ISSUES in one half-epoch: v_mfma_f32_16x16x4
+    instructions x 2048.  Gram: one instruction per upper tile per group of 4 entries
+    (NT(NT+1)/2 per group; long rows are the chunk kernel's); for padded k > 64 also the
+    blocked Cholesky's trailing updates, 4 * sum_b (NT-1-b)(NT-b)/2 per row
+    (csrc/als_blk.hip).  The k <= 64 kernel factorises on the VALU: that work (k^3/3 per row)
+    is added as plain flops.
+    """
+    lengths = lengths.astype(np.int64)
+    nt = kp // 16
+    tri = nt * (nt + 1) // 2
+    short = lengths[(lengths > 0) & (lengths <= LONG_ROW)]
+    groups = int(((short + 3) // 4).sum())
+    nonempty = int((lengths > 0).sum())
+    fl = groups * tri * 2048.0
+    if kp > 64:
+        chol = 4 * sum((nt - 1 - b) * (nt - b) // 2 for b in range(nt))
+        fl += nonempty * chol * 2048.0
+    else:
+        fl += nonempty * (kp**3 / 3.0)
+    return fl
+
+
 def half_bytes(lengths: np.ndarray, k: int):
     "Algorithmic HBM bytes of one half-epoch (SURVEY.md section 8d)."
     nnz, rows = int(lengths.sum()), len(lengths)
     return nnz * (4 + 4 + 4 * k) + (rows + 1) * 4 + rows * k * 4 * 2 + k * k * 4
 
 
-def pmc_traffic(kernel_substr: str):
+def pmc_traffic(pattern: str, kernel_substr: str):
     """
-    HBM bytes per launch of a kernel from the COMMITTED rocprofv3 PMC summary
-    (profiles/*_counters.csv, written by tools/prof_als.sh + tools/summarize_prof.py on the
-    same workload): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE is doubled because on
-    gfx950 it reports half the bytes of wide (16 B/lane) coalesced reads
-    (MI355X_MICROARCH.md, section HBM).  Counters cannot be collected inside this process, so
-    the value is null when no summary is committed.
+    HBM bytes per launch of a kernel from the newest COMMITTED rocprofv3 PMC summary
+    (profiles/<pattern>, written by tools/prof_*.sh + tools/summarize_prof.py on the same
+    workload): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE is doubled because on gfx950
+    it reports half the bytes of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md,
+    section HBM).  Counters cannot be collected inside this process, so the value is null
+    when no summary is committed.
     """
     import csv
 
-    files = sorted((ROOT / "profiles").glob("r*_als_*_counters.csv"))
+    files = sorted((ROOT / "profiles").glob(pattern))
     if not files:
         return None, None
     fetch, write = [], []
@@ -91,79 +122,204 @@ def pmc_traffic(kernel_substr: str):
     return (2.0 * sum(fetch) / len(fetch) + w) * 1024.0, files[-1].name
 
 
-def cpu_baseline(ui, k, reg, budget_s=20.0):
+def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
     """
-    Time the CPU oracle (port of src/accel/als/implicit.rs + LAPACK sposv) on a row
-    sample of the same workload and extrapolate to epochs/second by nnz.
+    One more epoch on the GPU from the trained state, and the SAME two half-epochs on the CPU
+    oracle from identical inputs (user half from (P, Q); item half from (Q, P_new as the GPU
+    produced it)), timed: the oracle run is both the parity reference and the cpu_baseline.
+    ``row_frac`` < 1 (large k: the oracle's cost grows with k^2..k^3) restricts both sides to
+    a seeded row sample; the kernel still ran every row.
     """
-    from oracle import lk_oracle as lko
-
     import scipy.sparse as sps
 
-    rng = np.random.default_rng(1)
+    from oracle import lk_oracle as lko
+    from oracle import parity
+
+    P, Q = eng.user_embeddings(), eng.item_embeddings()
+    eng.train_epoch()
+    eng.check()
+    P1, Q1 = eng.user_embeddings(), eng.item_embeddings()
     iu = sps.csr_array(ui.T)
     iu.sort_indices()
-    P = lko.als_initial_params(rng, ui.shape[0], k)
-    Q = lko.als_initial_params(rng, ui.shape[1], k)
     threads = lko.num_threads()
-    est = 0.0
-    used = 0.0
-    desc = []
-    for name, mat, this, other in (("user", ui, P, Q), ("item", iu, Q, P)):
+    rng = np.random.default_rng(5)
+    out, secs, desc = {}, 0.0, []
+    for name, mat, this, other, got in (("user", ui, P, Q, P1), ("item", iu, Q, P1, Q1)):
         n = mat.shape[0]
-        # calibrate on 0.5 % of the rows, then take what fits the budget
-        frac = 0.005
-        for _ in range(2):
-            rows = np.sort(rng.choice(n, max(64, int(n * frac)), replace=False))
-            sub = sps.csr_array(mat[rows])
-            tt = np.ascontiguousarray(this[rows])
-            otor = lko.implicit_otor(other, reg)
-            t0 = time.perf_counter()
-            lko.als_half_epoch(sub, tt, other, otor, threads)
-            dt = time.perf_counter() - t0
-            used += dt
-            full = dt * mat.nnz / max(sub.nnz, 1)
-            frac = min(1.0, frac * (budget_s / 2) / max(dt, 1e-3) * 0.5)
-        est += full
-        desc.append(f"{name} half: {len(rows)} of {n} rows ({sub.nnz} nnz) in {dt:.2f}s")
-    return {
-        "value": 1.0 / est,
+        if row_frac < 1.0:
+            rows = np.sort(rng.choice(n, max(256, int(n * row_frac)), replace=False))
+            sub, t0_, got_ = sps.csr_array(mat[rows]), this[rows], got[rows]
+        else:
+            rows, sub, t0_, got_ = None, mat, this, got
+        want = np.ascontiguousarray(t0_.copy())
+        otor = lko.implicit_otor(other, reg)
+        t0 = time.perf_counter()
+        lko.als_half_epoch(sub, want, other, otor, threads)
+        dt = time.perf_counter() - t0
+        full = dt * mat.nnz / max(sub.nnz, 1)
+        secs += full
+        desc.append(f"{name} half: {sub.shape[0]} of {n} rows ({sub.nnz} nnz) in {dt:.2f}s")
+        exact, cond = lko.als_referee_f64(sub, other, reg)
+        acc = parity.als_half_accounting(got_, want, exact, cond)
+        acc.pop("by_cond_decade", None)
+        out[name] = acc
+    par = {
+        "what": "one epoch from the trained state, GPU vs oracle from identical inputs, "
+        + ("every row" if row_frac >= 1.0 else f"a {row_frac:.3f} row sample"),
+        "als_rel_P": out["user"]["rel_gpu_vs_oracle"],
+        "als_rel_Q": out["item"]["rel_gpu_vs_oracle"],
+        "rows_over_1e-4": out["user"]["rows_over_1e-4"] + out["item"]["rows_over_1e-4"],
+        "min_cond_of_those": min(
+            (o["min_cond_of_rows_over"] for o in out.values() if "min_cond_of_rows_over" in o),
+            default=None),
+        "max_cond_of_those": max(
+            (o["max_cond_of_rows_over"] for o in out.values() if "max_cond_of_rows_over" in o),
+            default=None),
+        "decidable_rows_over_1e-4": sum(o["decidable_rows_over_1e-4"] for o in out.values()),
+        "gpu_row_err_over_cond_u_max": max(o["row_err_over_cond_u_max_gpu"] for o in out.values()),
+        "oracle_row_err_over_cond_u_max": max(
+            o["row_err_over_cond_u_max_oracle"] for o in out.values()),
+        "ok": bool(all(o["ok"] for o in out.values())),
+        "user": out["user"],
+        "item": out["item"],
+    }
+    cpu = {
+        "value": 1.0 / secs,
         "unit": "epochs/s",
         "cores": threads,
         "kind": "port",
-        "sample": "; ".join(desc) + "; extrapolated by nnz to a full epoch",
+        "sample": "; ".join(desc) + ("" if row_frac >= 1.0 else "; extrapolated by nnz"),
         "host_cpus": os.cpu_count(),
-        "cpu_seconds_used": round(used, 2),
+        "cpu_seconds_per_epoch": round(secs, 3),
+    }
+    return par, cpu
+
+
+def fit_leg(ratings, k, epochs, weight):
+    """
+    ``ImplicitMFScorer(embedding_size=k, epochs=epochs).train(dataset)``: the call
+    ``north_star`` names, end to end, and the per-epoch wall times the reference logs
+    (src/lenskit/training.py:320-329, ``finished epoch ... time=``).
+    """
+    import logging
+
+    import torch
+
+    from lkpy_amd import training
+    from lkpy_amd.als import ImplicitMFScorer
+    from lkpy_amd.data import Dataset, Vocabulary
+    from lkpy_amd.training import TrainingOptions
+
+    n_users, n_items = ratings.shape
+    rows = np.repeat(np.arange(n_users, dtype=np.int32), np.diff(ratings.indptr))
+    ds = Dataset(Vocabulary(np.arange(n_users), "user", reorder=False),
+                 Vocabulary(np.arange(n_items), "item", reorder=False),
+                 rows, ratings.indices, {"rating": ratings.data})
+
+    class Tap(logging.Handler):
+        times: list = []
+
+        def emit(self, record):
+            if "finished epoch" in record.getMessage() and len(record.args) >= 2:
+                self.times.append(float(record.args[1]))
+
+    tap = Tap()
+    tap.times = []
+    training._log.addHandler(tap)
+    old_level = training._log.level
+    training._log.setLevel(logging.INFO)
+    try:
+        scorer = ImplicitMFScorer(embedding_size=k, epochs=epochs, weight=weight)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        scorer.train(ds, TrainingOptions(rng=42))
+        torch.cuda.synchronize()
+        fit = time.perf_counter() - t0
+    finally:
+        training._log.removeHandler(tap)
+        training._log.setLevel(old_level)
+    assert scorer.item_embeddings.shape == (n_items, k)
+    ep = tap.times
+    return {
+        "what": f"ImplicitMFScorer(embedding_size={k}, epochs={epochs}).train(dataset), host "
+        "Dataset in, host factor arrays out",
+        "fit_seconds": round(fit, 4),
+        "epoch_seconds_logged": [round(t, 5) for t in ep],
+        "epochs_per_s_from_log": round(len(ep[1:]) / sum(ep[1:]), 2) if len(ep) > 1 else None,
+        "setup_and_download_seconds": round(fit - sum(ep), 4) if ep else None,
     }
 
 
-def cpu_baseline_knn(ratings, budget_s=15.0):
+def topk_cpu_baseline(P, Q, excl, n, budget_s=8.0):
     """
-    Time the CPU oracle's ``sim_row`` (port of src/accel/knn/item_train.rs:95-152) on a
-    random sample of item rows and extrapolate the full build by multiply-accumulates.
+    The reference's path for one user -- scores = Q @ u (``ALSBase.__call__``), candidates =
+    all items minus the user's own, heap top-N -- through the oracle's restatement, on a user
+    sample, extrapolated to all users.
     """
-    from lkpy_amd._knn_bench import prepare_explicit
     from oracle import lk_oracle as lko
 
-    ui, iu, _ = prepare_explicit(ratings)
+    rng = np.random.default_rng(7)
+    n_users = P.shape[0]
+    users = rng.choice(n_users, min(n_users, 64), replace=False)
+    t0 = time.perf_counter()
+    done = 0
+    for u in users:
+        sc = lko.score_dense(Q, P[u])
+        sc[excl.indices[excl.indptr[u]:excl.indptr[u + 1]]] = np.nan
+        lko.argtopn(sc, n)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(dt / done * n_users, 2), "unit": "s", "cores": 1, "kind": "port",
+            "sample": f"{done} of {n_users} users in {dt:.2f}s (score_dense + exclusion + "
+            "heap top-N per user, the reference's per-query loop), extrapolated by users"}
+
+
+def _gather_rows(out, rows):
+    "rows of a DeviceCSR similarity matrix -> host (ptr, idx, val); torch as plumbing only"
+    import torch
+
+    r = torch.as_tensor(rows.astype(np.int64), device=out.indptr.device)
+    beg, end = out.indptr[r], out.indptr[r + 1]
+    lens = end - beg
+    ptr = torch.zeros(len(rows) + 1, dtype=torch.int64, device=lens.device)
+    ptr[1:] = torch.cumsum(lens, 0)
+    pos = torch.arange(int(ptr[-1].item()), device=lens.device)
+    src = pos - torch.repeat_interleave(ptr[:-1], lens) + torch.repeat_interleave(beg, lens)
+    return ptr.cpu().numpy(), out.indices[src].cpu().numpy(), out.values[src].cpu().numpy()
+
+
+def knn_cpu_and_parity(dui, diu, out):
+    """
+    bench.py's checker leg (the ONLY place this module touches ``oracle/``): the oracle's
+    ``sim_row`` (port of src/accel/knn/item_train.rs:95-152) on a seeded row sample of the SAME
+    normalised matrices -- timed (cpu_baseline, extrapolated by multiply-accumulates) and
+    compared bitwise with the GPU's rows (parity).
+    """
+    import scipy.sparse as sps
+    import torch  # noqa: F401
+
+    from oracle import lk_oracle as lko
+    from oracle import parity
+
+    ui = sps.csr_array((dui.values.cpu().numpy(), dui.indices.cpu().numpy(), dui.h_indptr),
+                       shape=dui.shape)
+    iu = sps.csr_array((diu.values.cpu().numpy(), diu.indices.cpu().numpy(), diu.h_indptr),
+                       shape=diu.shape)
     ulen = np.diff(ui.indptr).astype(np.int64)
-    row_macs = np.add.reduceat(ulen[iu.indices], iu.indptr[:-1].astype(np.int64))
+    row_macs = np.add.reduceat(ulen[iu.indices], np.minimum(iu.indptr[:-1], iu.nnz - 1)
+                               .astype(np.int64))
     row_macs[np.diff(iu.indptr) == 0] = 0
     total = int(row_macs.sum())
     rng = np.random.default_rng(2)
     threads = min(lko.num_threads(), os.cpu_count() or 1)
-    n = max(64, ui.shape[1] // 400)
-    dt, rows = 0.0, None
-    for _ in range(3):
-        rows = np.sort(rng.choice(ui.shape[1], min(n, ui.shape[1]), replace=False))
-        t0 = time.perf_counter()
-        lko.iknn_sample_rows(ui, iu, rows, 1.0e-6, None, threads)
-        dt = time.perf_counter() - t0
-        if dt > budget_s / 4 or n >= ui.shape[1]:
-            break
-        n = int(min(ui.shape[1], n * min(8.0, budget_s / 2 / max(dt, 1e-3))))
+    rows = np.sort(rng.choice(ui.shape[1], min(2048, ui.shape[1]), replace=False)).astype(np.int32)
+    t0 = time.perf_counter()
+    want = lko.iknn_build_rows(ui, iu, rows, 1.0e-6, None, threads)
+    dt = time.perf_counter() - t0
     frac = float(row_macs[rows].sum()) / max(total, 1)
-    return {
+    cpu = {
         "value": round(dt / max(frac, 1e-12), 2),
         "unit": "s",
         "cores": threads,
@@ -171,6 +327,11 @@ def cpu_baseline_knn(ratings, budget_s=15.0):
         "sample": f"{len(rows)} of {ui.shape[1]} item rows ({frac * 100:.2f}% of the "
         f"multiply-accumulates) in {dt:.2f}s, extrapolated by MACs",
     }
+    par = parity.knn_rows_equal(*_gather_rows(out, rows), want)
+    return cpu, {"knn_rows_checked": par["rows_checked"],
+                 "knn_entries_checked": par["entries_checked"],
+                 "knn_bitwise_equal": par["bitwise_equal"]}
+
 
 
 def main():
@@ -180,9 +341,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the dataset (debug only)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the parity + cpu_baseline legs")
     ap.add_argument("--no-knn", action="store_true", help="skip the item-kNN build leg")
     ap.add_argument("--no-topk", action="store_true", help="skip the dense top-N scoring leg")
+    ap.add_argument("--no-fit", action="store_true", help="skip the end-to-end fit leg")
     args = ap.parse_args()
 
     import torch
@@ -220,7 +382,11 @@ def main():
     P0 *= P0
 
     backend = HipBackend(k, dev, _native.SOLVER_AUTO)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
     eng = ImplicitALSEngine(ui, k, reg, reg, P0, Q0, backend)
+    torch.cuda.synchronize(dev)
+    setup_seconds = time.perf_counter() - t0
 
     def barrier():
         if world > 1:
@@ -230,10 +396,8 @@ def main():
     for _ in range(args.warmup):
         eng.train_epoch()
     eng.check()
-    timing_ok = hasattr(eng.u_plan, "enable_timing")
-    if timing_ok:
-        eng.u_plan.enable_timing(True)
-        eng.i_plan.enable_timing(True)
+    eng.u_plan.enable_timing(True)
+    eng.i_plan.enable_timing(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -249,38 +413,49 @@ def main():
 
     # ---- roofline of the dominant kernel (local shard of this rank) ----
     roof = None
-    if timing_ok:
-        cu, su, nu = eng.u_plan.get_timing()
-        ci, si, ni = eng.i_plan.get_timing()
-        ulen = np.diff(eng.u_plan.csr.h_indptr)
-        ilen = np.diff(eng.i_plan.csr.h_indptr)
-        fu_solve, fu_chunk = half_flops(ulen, k)
-        fi_solve, fi_chunk = half_flops(ilen, k)
-        launches = nu + ni
-        if launches > 0 and (su + si) > 0:
-            flops_per_launch = (fu_solve * nu + fi_solve * ni) / launches
-            avg_ms = (su + si) / launches
-            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            roof = {
-                "kernel": "als_solve_kernel<NT=%d>" % (backend.kp // 16),
-                "bound": "mfma",
-                "achieved": round(achieved, 3),
-                "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
-                "traffic_source": None,
-                "avg_launch_ms": round(avg_ms, 4),
-                "launches": launches,
-                "algorithmic_flops_per_launch": flops_per_launch,
-                "algorithmic_bytes_per_launch": (half_bytes(ulen, k) * nu + half_bytes(ilen, k) * ni)
-                / launches,
-                "chunk_kernel_ms_per_launch": round((cu + ci) / launches, 4),
-                "chunk_kernel_flops_per_launch": (fu_chunk * nu + fi_chunk * ni) / launches,
-            }
-
-    if roof and world == 1 and args.scale == 1.0 and k == 64:
-        roof["traffic"], roof["traffic_source"] = pmc_traffic("als_solve_kernel")
+    cu, su, nu = eng.u_plan.get_timing()
+    ci, si, ni = eng.i_plan.get_timing()
+    eng.u_plan.enable_timing(False)
+    eng.i_plan.enable_timing(False)
+    ulen = np.diff(eng.u_plan.csr.h_indptr)
+    ilen = np.diff(eng.i_plan.csr.h_indptr)
+    fu_solve, fu_chunk = half_flops(ulen, k)
+    fi_solve, fi_chunk = half_flops(ilen, k)
+    launches = nu + ni
+    kname = ("als_solve_kernel<NT=%d>" if backend.kp <= 64 else "als_blk_solve_kernel%d") % (
+        backend.kp // 16)
+    if launches > 0 and (su + si) > 0:
+        flops_per_launch = (fu_solve * nu + fi_solve * ni) / launches
+        exec_per_launch = (half_mfma_flops(ulen, backend.kp) * nu
+                           + half_mfma_flops(ilen, backend.kp) * ni) / launches
+        avg_ms = (su + si) / launches
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        roof = {
+            "kernel": kname,
+            "bound": "mfma",
+            "achieved": round(achieved, 3),
+            "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+            "frac_executed": round(exec_per_launch / (avg_ms * 1e-3) / 1e12
+                                   / F32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "traffic_source": None,
+            "avg_launch_ms": round(avg_ms, 4),
+            "launches": launches,
+            "algorithmic_flops_per_launch": flops_per_launch,
+            "executed_flops_per_launch": exec_per_launch,
+            "algorithmic_bytes_per_launch": (half_bytes(ulen, k) * nu + half_bytes(ilen, k) * ni)
+            / launches,
+            "chunk_kernel_ms_per_launch": round((cu + ci) / launches, 4),
+            "chunk_kernel_flops_per_launch": (fu_chunk * nu + fi_chunk * ni) / launches,
+            "note": "frac = SURVEY 8d algorithmic flops (2k^2 per entry) / time / peak; "
+            "frac_executed = matrix-core work actually issued (upper tiles only)",
+        }
+    if roof and world == 1 and args.scale == 1.0:
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(
+            "r*_als_k%d_counters.csv" % k if k != 64 else "r*_als_*_counters.csv",
+            kname.split("<")[0])
     out = {
         "metric": "ALS-implicit epochs/sec (ML-25M-shaped, k=%d)" % k,
         "value": round(args.steps / elapsed, 3),
@@ -293,7 +468,8 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (seeded ML-25M-shaped: lkpy_amd.synth.ml25m_like, seed 20260925)",
+        "data": "synthetic (seeded ML-25M-shaped: lkpy_amd.synth.ml25m_like, seed 20260925; "
+        "longest user row %d, busiest item %d)" % (info["user_len_max"], info["item_len_max"]),
         "config": {
             "workload": "MovieLens-25M-shaped, als-implicit k=%d, %d timed epochs, %d x MI355X"
             % (k, args.steps, world),
@@ -306,6 +482,7 @@ def main():
             "parallelism": "row-sharded x%d" % world if world > 1 else "single GPU",
         },
         "final_deltas": [float(du.item()), float(di.item())],
+        "setup_seconds": round(setup_seconds, 4),
     }
     if roof:
         out["roofline"] = roof
@@ -316,6 +493,12 @@ def main():
             out[name] = fn()
         except Exception as exc:  # noqa: BLE001 -- reported, not swallowed
             out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+
+    def als_parity_leg():
+        frac = 1.0 if k <= 64 else max(0.02, (64.0 / k) ** 3)
+        par, cpu = als_parity_and_cpu(eng, ui, k, reg, frac)
+        out["cpu_baseline"] = cpu
+        return par
 
     def topk_leg():
         # dense scoring + top-100 for ALL users with the factors just trained (north star:
@@ -331,35 +514,49 @@ def main():
             torch.cuda.synchronize(dev)
             ts.append(time.perf_counter() - t0)
         tb = min(ts)
-        fl = 2.0 * eng.P.shape[0] * eng.Q.shape[0] * k
-        return {
+        B, I = eng.P.shape[0], eng.Q.shape[0]
+        fl = 2.0 * B * I * k
+        res = {
             "metric": "dense scoring + top-100 of all users x all items (k=%d), seconds" % k,
             "value": round(tb, 4),
             "unit": "s",
-            "users_per_s": round(eng.P.shape[0] / tb, 1),
-            "achieved_tflops": round(fl / tb / 1e12, 2),
-            "mfma_frac_end_to_end": round(fl / tb / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-            "note": "GEMM + exclusion mask + selection; the score panel kernel alone reaches "
-            "0.62 of the f32 MFMA peak at k=128 (profiles/r01_topk_*)",
+            "users_per_s": round(B / tb, 1),
+            "roofline": {
+                "bound": "mfma", "achieved": round(fl / tb / 1e12, 2),
+                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(fl / tb / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                "algorithmic_flops": fl,
+                "algorithmic_bytes": B * k * 4 + I * k * 4 * ((B + 2047) // 2048) + B * 100 * 8,
+                "note": "end to end: GEMM + exclusion + selection, whole call wall time",
+            },
         }
-
-    def knn_leg():
-        from lkpy_amd import _knn_bench
-
-        res = _knn_bench.run(ratings, dev)
         if not args.no_cpu:
             try:
-                res["cpu_baseline"] = cpu_baseline_knn(ratings)
+                res["cpu_baseline"] = topk_cpu_baseline(
+                    eng.user_embeddings(), eng.item_embeddings(), sps.csr_array(ratings), 100)
             except Exception as exc:  # noqa: BLE001
                 res["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
         return res
 
-    if rank == 0 and world == 1 and not args.no_topk:
+    def knn_leg():
+        from lkpy_amd import _knn_bench
+
+        return _knn_bench.run(ratings, dev, checker=None if args.no_cpu else knn_cpu_and_parity)
+
+    single = rank == 0 and world == 1
+    if single and not args.no_cpu:
+        leg("parity", als_parity_leg)
+    if single and not args.no_topk:
         leg("topk", topk_leg)
-    if rank == 0 and world == 1 and not args.no_knn:
+    if single:
+        del eng  # free the engine's HBM before the other legs
+        torch.cuda.empty_cache()
+    if single and not args.no_fit:
+        leg("fit", lambda: fit_leg(ratings, k, args.steps, weight))
+    if single and not args.no_knn:
         leg("knn", knn_leg)
-    if rank == 0 and world == 1 and not args.no_cpu:
-        leg("cpu_baseline", lambda: cpu_baseline(ui, k, reg))
+        if isinstance(out.get("parity"), dict) and isinstance(out["knn"], dict):
+            out["parity"]["knn"] = out["knn"].pop("parity", None)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -202,6 +202,12 @@ int lk_iknn_plan_create_rows(lk_iknn_plan **out, const void *h_ui_indptr,
                              int64_t n_items, int64_t row_begin, int64_t row_end);
 void lk_iknn_plan_destroy(lk_iknn_plan *plan);
 int lk_iknn_plan_set_ctl(lk_iknn_plan *plan, lk_task_ctl *ctl);
+/* Optional timing of the similarity kernel with HIP events recorded on the launch stream
+ * (bench.py's roofline leg): get_timing waits for the events, returns the summed duration
+ * (ms) of the build-kernel launches recorded since the last call (one for a staged build,
+ * two for a two-pass build) and resets. */
+int lk_iknn_plan_enable_timing(lk_iknn_plan *plan, int enable);
+int lk_iknn_plan_get_timing(lk_iknn_plan *plan, double *ms_build, int32_t *n_launches);
 size_t lk_iknn_plan_workspace_bytes(const lk_iknn_plan *plan);
 
 int lk_iknn_build_count(const lk_iknn_plan *plan, const void *d_ui_indptr,
@@ -310,6 +316,18 @@ int lk_csr_transpose(const void *d_indptr, int indptr_is_64, const int32_t *d_in
                      int64_t n_rows, int64_t n_cols, int64_t nnz, void *d_out_indptr,
                      int32_t *d_out_indices, void *d_out_perm, void *d_ws, size_t ws_bytes,
                      void *stream);
+
+/* Relabelling of a CSR matrix on the device (set-up of the sharded ALS engine; the reference
+ * builds both orientations on the host with SciPy, src/lenskit/als/_common.py:216-222):
+ * output row r takes the entries of input row d_row_src[r] (-1: an empty padding row), every
+ * column c becomes d_col_map[c]; the entry order inside a row is kept (NOT re-sorted by the new
+ * column numbers: the row solve sums over a row's entries, any order).  d_out_indptr holds the
+ * offsets of the result (same width as the input's), computed by the caller from the row
+ * lengths; d_values / d_out_values may be NULL (structure only).  Asynchronous on `stream`. */
+int lk_csr_relabel(const void *d_indptr, int indptr_is_64, const int32_t *d_indices,
+                   const float *d_values, int64_t n_rows_out, const int32_t *d_row_src,
+                   const void *d_out_indptr, const int32_t *d_col_map, int32_t *d_out_indices,
+                   float *d_out_values, void *stream);
 
 /* ------------------------------------------------------------------------
  * Item-kNN rating normalisation (`ItemKNNScorer._center_ratings` / `_normalize_rows`,

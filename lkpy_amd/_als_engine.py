@@ -87,6 +87,59 @@ class HipBackend:
         csr = self.D.DeviceCSR.from_scipy(local_csr, self.dev)
         return self.D.ALSPlan(csr, self.k, self.solver)
 
+    def make_plans_on_device(self, ui: sps.csr_array, u_old, i_new, i_old, u_rng, i_rng):
+        """
+        Both orientations of the RELABELLED matrix built in HBM from one upload of the original
+        CSR (``lk_csr_relabel`` + the stable device transpose ``lk_csr_transpose``) instead of
+        SciPy COO round trips on the host (2.2 s of the 2.3 s set-up on ML-25M): rows gathered in
+        dealt order, columns mapped, entry order inside a row kept (the row solve sums over a
+        row's entries; any order).  Returns the plans of this rank's user rows ``u_rng`` and item
+        rows ``i_rng`` -- views into the full device matrices, offsets not rebased.
+        """
+        D = self.D
+        lib = _native.require_gpu()
+        import ctypes
+
+        dev = self.dev
+        n_users, n_items = ui.shape
+        nu, ni = len(u_old), len(i_old)
+        src = D.DeviceCSR.from_arrays(ui.indptr, ui.indices, ui.data, ui.shape, dev)
+        pdt = src.h_indptr.dtype
+        ulen = np.diff(src.h_indptr)
+        ilen = np.bincount(ui.indices, minlength=n_items)
+        new_ulen = np.where(u_old >= 0, ulen[np.maximum(u_old, 0)], 0)
+        new_ilen = np.where(i_old >= 0, ilen[np.maximum(i_old, 0)], 0)
+        h_uptr = np.zeros(nu + 1, dtype=pdt)
+        np.cumsum(new_ulen, out=h_uptr[1:])
+        h_iptr = np.zeros(ni + 1, dtype=pdt)
+        np.cumsum(new_ilen, out=h_iptr[1:])
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        d_uptr = to(h_uptr)
+        nnz = src.nnz
+        idx = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
+        val = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)[:nnz]
+        # (named, not inline: a temporary tensor would be released -- and its block handed to the
+        # next upload -- before the kernel that reads it is even launched)
+        d_row_src = to(u_old.astype(np.int32))
+        d_col_map = to(i_new.astype(np.int32))
+        _native.check(lib.lk_csr_relabel(
+            D._ptr(src.indptr), 1 if src.is64 else 0, D._ptr(src.indices), D._ptr(src.values), nu,
+            D._ptr(d_row_src), D._ptr(d_uptr), D._ptr(d_col_map), D._ptr(idx), D._ptr(val),
+            D._stream()), "lk_csr_relabel")
+        ui_new = D.DeviceCSR(d_uptr, idx, val, (nu, ni), h_uptr)
+        iu_new = D.csr_transpose(ui_new)  # stable: entries of an item row by ascending new user
+        iu_new.h_indptr = h_iptr
+        del src
+
+        def local(full, h_ptr, lo, hi, n_cols):
+            view = D.DeviceCSR(full.indptr[lo : hi + 1], full.indices, full.values,
+                               (hi - lo, n_cols), h_ptr[lo : hi + 1])
+            return D.ALSPlan(view, self.k, self.solver)
+
+        return (local(ui_new, h_uptr, u_rng[0], u_rng[1], ni),
+                local(iu_new, h_iptr, i_rng[0], i_rng[1], nu),
+                (int(h_uptr[u_rng[1]] - h_uptr[u_rng[0]]), int(h_iptr[i_rng[1]] - h_iptr[i_rng[0]])))
+
     def upload(self, mat: np.ndarray) -> torch.Tensor:
         return self.D.to_device_padded(mat, self.dev)
 
@@ -144,16 +197,22 @@ class ImplicitALSEngine:
         self.i_new, self.i_old, self.i_rpr = deal_rows(ilen, self.world)
         nu, ni = self.world * self.u_rpr, self.world * self.i_rpr
 
-        ui_new = _relabel_csr(ui, self.u_new, nu, self.i_new, ni)
-        iu_new = sps.csr_array(ui_new.T)
-        iu_new.sort_indices()
         r = self.rank
         self.u_lo, self.u_hi = r * self.u_rpr, (r + 1) * self.u_rpr
         self.i_lo, self.i_hi = r * self.i_rpr, (r + 1) * self.i_rpr
-        self.u_plan = backend.make_plan(ui_new[self.u_lo : self.u_hi])
-        self.i_plan = backend.make_plan(iu_new[self.i_lo : self.i_hi])
-        self.local_nnz = (int(ui_new.indptr[self.u_hi] - ui_new.indptr[self.u_lo]),
-                          int(iu_new.indptr[self.i_hi] - iu_new.indptr[self.i_lo]))  # fmt: skip
+        if hasattr(backend, "make_plans_on_device"):
+            # product path: one upload, relabel + transpose in HBM
+            self.u_plan, self.i_plan, self.local_nnz = backend.make_plans_on_device(
+                ui, self.u_old, self.i_new, self.i_old, (self.u_lo, self.u_hi),
+                (self.i_lo, self.i_hi))
+        else:  # host restatement (CPU / gloo tests of the sharding logic)
+            ui_new = _relabel_csr(ui, self.u_new, nu, self.i_new, ni)
+            iu_new = sps.csr_array(ui_new.T)
+            iu_new.sort_indices()
+            self.u_plan = backend.make_plan(ui_new[self.u_lo : self.u_hi])
+            self.i_plan = backend.make_plan(iu_new[self.i_lo : self.i_hi])
+            self.local_nnz = (int(ui_new.indptr[self.u_hi] - ui_new.indptr[self.u_lo]),
+                              int(iu_new.indptr[self.i_hi] - iu_new.indptr[self.i_lo]))  # fmt: skip
 
         P = np.zeros((nu, self.k), dtype=np.float32)
         Q = np.zeros((ni, self.k), dtype=np.float32)

@@ -273,7 +273,8 @@ class ALSPlan:
 
 
 def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None,
-               rows: tuple[int, int] | None = None, ctl: "TaskCtl | None" = None) -> DeviceCSR:
+               rows: tuple[int, int] | None = None, ctl: "TaskCtl | None" = None,
+               timing: dict | None = None) -> DeviceCSR:
     """
     Item-item similarity build (lk_iknn_build_count / _fill, then lk_iknn_truncate_* when
     ``save_nbrs`` is set): ``ui`` users x items and ``iu`` items x users hold the normalised
@@ -300,6 +301,8 @@ def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None,
     try:
         if ctl is not None:
             check(lib.lk_iknn_plan_set_ctl(h, ctl._h), "lk_iknn_plan_set_ctl")
+        if timing is not None:
+            check(lib.lk_iknn_plan_enable_timing(h, 1), "lk_iknn_plan_enable_timing")
         ws = torch.empty(lib.lk_iknn_plan_workspace_bytes(h), dtype=torch.uint8, device=dev)
         out_ptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
         total = ctypes.c_int64(0)
@@ -324,6 +327,11 @@ def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None,
             "lk_iknn_build_fill",
         )  # fmt: skip
         torch.cuda.current_stream().synchronize()
+        if timing is not None:
+            ms, nl = ctypes.c_double(0), ctypes.c_int32(0)
+            check(lib.lk_iknn_plan_get_timing(h, ctypes.byref(ms), ctypes.byref(nl)))
+            timing["build_kernel_ms"] = ms.value
+            timing["build_kernel_launches"] = nl.value
     finally:
         lib.lk_iknn_plan_destroy(h)
     full = DeviceCSR(out_ptr, out_idx, out_val, (n_rows, n_items), None)

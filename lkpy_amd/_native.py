@@ -56,6 +56,8 @@ def _declare(lib):
         "lk_task_ctl_progress": (c_int, [vp, POINTER(c_int64), POINTER(c_int64)]),
         "lk_als_plan_set_ctl": (c_int, [vp, vp]),
         "lk_iknn_plan_set_ctl": (c_int, [vp, vp]),
+        "lk_iknn_plan_enable_timing": (c_int, [vp, c_int]),
+        "lk_iknn_plan_get_timing": (c_int, [vp, POINTER(ctypes.c_double), POINTER(c_int32)]),
         "lk_argtopn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32]),
         "lk_gramian_workspace_bytes": (c_size_t, [c_int32]),
         "lk_gramian": (c_int, [vp, c_int64, c_int32, c_int32, c_float, vp, c_int32, vp, vp]),
@@ -118,6 +120,7 @@ def _declare(lib):
         "lk_csr_transpose": (
             c_int, [vp, c_int, vp, c_int64, c_int64, c_int64, vp, vp, vp, vp, c_size_t, vp]
         ),
+        "lk_csr_relabel": (c_int, [vp, c_int, vp, vp, c_int64, vp, vp, vp, vp, vp, vp]),
         "lk_als_implicit_half_epoch_host": (
             c_int,
             [vp, c_int, vp, vp, c_int64, c_int64, c_int32, vp, vp, vp, c_int32, vp],

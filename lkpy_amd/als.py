@@ -279,13 +279,18 @@ class ImplicitMFTrainer(ModelTrainer):
                                         scorer.user_embeddings, scorer.item_embeddings, backend)
         self.epochs_trained = 0
 
-    def prepare_matrix(self, data: Dataset) -> sps.coo_array:
-        "_implicit.py:141-149"
+    def prepare_matrix(self, data: Dataset) -> sps.csr_array:
+        """
+        _implicit.py:141-149 + the ``from_scipy(ui_rates)`` of _common.py:218: confidence values
+        ``weight`` (or ``weight * rating``) in CSR.  The reference goes through COO and lets
+        SciPy convert; the dataset already holds (user, item)-sorted, duplicate-free
+        interactions, so the CSR arrays are taken as they are -- same matrix, no host sort.
+        """
         ints = data.interactions().matrix()
-        rmat = ints.scipy(attribute="rating", layout="coo") if self.scorer.config.use_ratings \
-            else ints.scipy(layout="coo")
-        vals = np.require(rmat.data, dtype=np.float32) * self.scorer.config.weight
-        return sps.coo_array((vals, (rmat.row, rmat.col)), shape=rmat.shape)
+        rmat = ints.scipy(attribute="rating", layout="csr") if self.scorer.config.use_ratings \
+            else ints.scipy(layout="csr")
+        vals = np.require(rmat.data, dtype=np.float32) * np.float32(self.scorer.config.weight)
+        return sps.csr_array((vals, rmat.indices, rmat.indptr), shape=rmat.shape)
 
     def initial_params(self, nrows: int, ncols: int) -> np.ndarray:
         "_implicit.py:152-155"

@@ -69,6 +69,28 @@ __global__ void tr_rows_kernel(const IT *__restrict__ in_ptr, int64_t n_rows,
     }
 }
 
+// relabelled matrix: output row r = input row row_src[r] (or empty), columns mapped; one wave
+// per output row, entries copied in order
+template <typename IT>
+__global__ __launch_bounds__(256) void relabel_kernel(
+    const IT *__restrict__ in_ptr, const int32_t *__restrict__ in_idx,
+    const float *__restrict__ in_val, int64_t n_rows_out, const int32_t *__restrict__ row_src,
+    const IT *__restrict__ out_ptr, const int32_t *__restrict__ col_map,
+    int32_t *__restrict__ out_idx, float *__restrict__ out_val)
+{
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows_out) return;
+    const int src = row_src[r];
+    if (src < 0) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t sb = (int64_t)in_ptr[src], n = (int64_t)in_ptr[src + 1] - sb;
+    const int64_t db = (int64_t)out_ptr[r];
+    for (int64_t e = lane; e < n; e += 64) {
+        out_idx[db + e] = col_map[in_idx[sb + e]];
+        if (out_val) out_val[db + e] = in_val[sb + e];
+    }
+}
+
 static int key_bits(int64_t n_cols)
 {
     int b = 1;
@@ -152,4 +174,28 @@ extern "C" int lk_csr_transpose(const void *d_indptr, int indptr_is_64, const in
         static_cast<const int32_t *>(d_indptr), d_indices, n_rows, n_cols, nnz,
         static_cast<int32_t *>(d_out_indptr), d_out_indices, static_cast<int32_t *>(d_out_perm),
         ws, ws_bytes, st);
+}
+
+extern "C" int lk_csr_relabel(const void *d_indptr, int indptr_is_64, const int32_t *d_indices,
+                              const float *d_values, int64_t n_rows_out, const int32_t *d_row_src,
+                              const void *d_out_indptr, const int32_t *d_col_map,
+                              int32_t *d_out_indices, float *d_out_values, void *stream)
+{
+    LK_REQUIRE(n_rows_out >= 0, "lk_csr_relabel: negative size");
+    if (n_rows_out == 0) return LK_OK;
+    LK_REQUIRE(d_indptr && d_row_src && d_out_indptr && d_col_map, "lk_csr_relabel: null pointer");
+    hipStream_t st = lk::as_stream(stream);
+    const dim3 grid((unsigned)((n_rows_out + 3) / 4)), block(256);
+    if (indptr_is_64)
+        hipLaunchKernelGGL(lk::relabel_kernel<int64_t>, grid, block, 0, st,
+                           static_cast<const int64_t *>(d_indptr), d_indices, d_values, n_rows_out,
+                           d_row_src, static_cast<const int64_t *>(d_out_indptr), d_col_map,
+                           d_out_indices, d_out_values);
+    else
+        hipLaunchKernelGGL(lk::relabel_kernel<int32_t>, grid, block, 0, st,
+                           static_cast<const int32_t *>(d_indptr), d_indices, d_values, n_rows_out,
+                           d_row_src, static_cast<const int32_t *>(d_out_indptr), d_col_map,
+                           d_out_indices, d_out_values);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
 }

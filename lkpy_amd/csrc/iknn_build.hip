@@ -65,6 +65,10 @@ struct lk_iknn_plan {
     int32_t staged = 0;
     size_t off_st_idx = 0, off_st_val = 0;
     lk_task_ctl *ctl = nullptr;  // optional cancel / progress block (lk_iknn_plan_set_ctl)
+    // optional timing of the build kernel (HIP events on the launch stream; bench.py roofline)
+    bool timing = false;
+    mutable int timing_n = 0;
+    mutable hipEvent_t ev[4][2] = {};
 };
 
 namespace lk {
@@ -506,9 +510,38 @@ extern "C" int lk_iknn_plan_create_rows(lk_iknn_plan **out, const void *h_ui_ind
     return LK_OK;
 }
 
+extern "C" int lk_iknn_plan_enable_timing(lk_iknn_plan *p, int enable)
+{
+    LK_REQUIRE(p != nullptr, "lk_iknn_plan_enable_timing: null plan");
+    if (enable && !p->ev[0][0])
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 2; ++j) LK_HIP_CHECK(hipEventCreate(&p->ev[i][j]));
+    p->timing = enable != 0;
+    p->timing_n = 0;
+    return LK_OK;
+}
+
+extern "C" int lk_iknn_plan_get_timing(lk_iknn_plan *p, double *ms_build, int32_t *n_launches)
+{
+    LK_REQUIRE(p && ms_build && n_launches, "lk_iknn_plan_get_timing: null pointer");
+    *ms_build = 0.0;
+    *n_launches = p->timing_n;
+    for (int i = 0; i < p->timing_n; ++i) {
+        float a = 0.f;
+        LK_HIP_CHECK(hipEventSynchronize(p->ev[i][1]));
+        LK_HIP_CHECK(hipEventElapsedTime(&a, p->ev[i][0], p->ev[i][1]));
+        *ms_build += a;
+    }
+    p->timing_n = 0;
+    return LK_OK;
+}
+
 extern "C" void lk_iknn_plan_destroy(lk_iknn_plan *p)
 {
     if (!p) return;
+    if (p->ev[0][0])
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 2; ++j) (void)hipEventDestroy(p->ev[i][j]);
     if (p->d_task) (void)hipFree(p->d_task);
     delete p;
 }
@@ -561,12 +594,18 @@ static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t 
         int rc = ctl_begin(p->ctl, p->n_rows, p->n_tasks, st);
         if (rc != LK_OK) return rc;
     }
+    const bool tm = p->timing && p->timing_n < 4;
+    if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][0], st));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st,
                        static_cast<const IT *>(ui_ptr), pack, static_cast<const IT *>(iu_ptr),
                        iu_idx, iu_val, desc, p->d_task, p->n_btasks, p->n_items, p->row_lo, p->P, p->Q,
                        p->W,
                        min_sim, cnt, off, out_idx, out_val,
                        p->ctl ? p->ctl->dev() : TaskCtlDev{});
+    if (tm) {
+        LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
+        p->timing_n++;
+    }
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }
