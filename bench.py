@@ -334,6 +334,205 @@ def knn_cpu_and_parity(dui, diu, out):
 
 
 
+def main_cfg5(args):
+    """
+    BASELINE.json configs[4] / SURVEY.md 8d "cfg5 concrete input": U = 10^7, I = 10^6,
+    nnz = 10^8 generated in HBM from seed 5 (Philox; csrc/synth.hip), values 40, als-implicit
+    k = 256 (exact solver), `--steps` timed epochs after `--warmup`; dense top-100 for a user
+    slice x ALL items with the history excluded.  `--scale` shrinks users, items and nnz
+    together.  With --gpus N (torch.distributed.run) the users / items are row-sharded as for
+    cfg2; on one GPU the whole problem runs on that GPU.
+    """
+    import torch
+    import torch.distributed as dist
+
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native, synth
+    from lkpy_amd._als_engine import HipBackend, ImplicitALSEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    _native.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    k = args.k if args.k != 64 else 256
+    reg = 0.1
+    c = synth.CFG5
+    n_users = max(1024, int(c["n_users"] * args.scale))
+    n_items = max(1024, int(c["n_items"] * args.scale))
+    nnz = int(c["nnz"] * args.scale)
+    t0 = time.perf_counter()
+    csr = synth.zipf_csr_on_device(dev, n_users, n_items, nnz, seed=c["seed"], value=40.0)
+    torch.cuda.synchronize(dev)
+    gen_seconds = time.perf_counter() - t0
+    backend = HipBackend(k, dev, _native.SOLVER_AUTO)
+    t0 = time.perf_counter()
+    eng = ImplicitALSEngine(csr, k, reg, reg, None, None, backend)
+    torch.cuda.synchronize(dev)
+    setup_seconds = time.perf_counter() - t0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        eng.train_epoch()
+    eng.check()
+    eng.u_plan.enable_timing(True)
+    eng.i_plan.enable_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        du, di = eng.train_epoch()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.check()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    cu, su, nu = eng.u_plan.get_timing()
+    ci, si, ni = eng.i_plan.get_timing()
+    ulen = np.diff(eng.u_plan.csr.h_indptr)
+    ilen = np.diff(eng.i_plan.csr.h_indptr)
+    fu, fuc = half_flops(ulen, k)
+    fi, fic = half_flops(ilen, k)
+    # per epoch: both solve launches + both chunk launches
+    ep_ms = (su + si + cu + ci) / max(nu, 1)
+    ep_flops = fu + fi + fuc + fic
+    ex_flops = half_mfma_flops(ulen, backend.kp) + half_mfma_flops(ilen, backend.kp)
+    out = {
+        "metric": "ALS-implicit epochs/sec (cfg5 synthetic %.3gM x %.3gM x %.3gM, k=%d)"
+        % (n_users / 1e6, n_items / 1e6, nnz / 1e6, k),
+        "value": round(args.steps / elapsed, 4),
+        "unit": "epochs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (generated in HBM: lkpy_amd.synth.zipf_csr_on_device, Philox seed %d; "
+        "degrees truncated-Zipf mean %.1f, items ~ Zipf(1.0))" % (c["seed"], nnz / n_users),
+        "config": {
+            "workload": "cfg5: %d users x %d items x %d interactions, als-implicit k=%d, "
+            "%d timed epochs, %d x MI355X" % (n_users, n_items, nnz, k, args.steps, world),
+            "solver": "cholesky" if eng.u_plan.solver == 0 else "cg",
+            "reg": reg, "weight": 40.0,
+            "longest_user_row": int(ulen.max()), "busiest_item": int(ilen.max()),
+            "parallelism": "row-sharded x%d" % world if world > 1 else "single GPU",
+        },
+        "final_deltas": [float(du.item()), float(di.item())],
+        "generate_seconds": round(gen_seconds, 3),
+        "setup_seconds": round(setup_seconds, 3),
+        "roofline": {
+            "kernel": "als_blk_solve_kernel%d + als_blk_chunk_kernel" % (backend.kp // 16),
+            "bound": "mfma",
+            "achieved": round(ep_flops / (ep_ms * 1e-3) / 1e12, 3),
+            "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ep_flops / (ep_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+            "frac_executed": round(ex_flops / ((su + si) / max(nu, 1) * 1e-3) / 1e12
+                                   / F32_MFMA_PEAK_TFLOPS, 4),
+            "kernel_ms_per_epoch": {"user_solve": round(su / max(nu, 1), 3),
+                                    "item_solve": round(si / max(ni, 1), 3),
+                                    "user_chunk": round(cu / max(nu, 1), 3),
+                                    "item_chunk": round(ci / max(ni, 1), 3)},
+            "algorithmic_flops_per_epoch": ep_flops,
+            "algorithmic_bytes_per_epoch": half_bytes(ulen, k) + half_bytes(ilen, k),
+            "traffic": None,
+        },
+    }
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as exc:  # noqa: BLE001 -- reported, not swallowed
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+
+    def parity_leg():
+        # SURVEY 8d: "cfg5 on CPU: time 1 half-epoch on a 1 % row sample and extrapolate";
+        # the same sample is the parity check (user half from identical inputs)
+        import scipy.sparse as sps
+
+        from oracle import lk_oracle as lko
+        from oracle import parity
+
+        Qh = eng.backend.download(eng.Q)  # relabelled order on both sides
+        plan = eng.u_plan
+        rng = np.random.default_rng(3)
+        rows = np.sort(rng.choice(plan.csr.shape[0], max(256, plan.csr.shape[0] // 400),
+                                  replace=False))
+        hp = plan.csr.h_indptr.astype(np.int64)
+        lens = (hp[rows + 1] - hp[rows])
+        ptr = np.zeros(len(rows) + 1, np.int64)
+        np.cumsum(lens, out=ptr[1:])
+        take = torch.from_numpy(np.concatenate(
+            [np.arange(hp[r], hp[r + 1]) for r in rows]).astype(np.int64)).to(dev)
+        idx = plan.csr.indices[take].cpu().numpy()
+        val = plan.csr.values[take].cpu().numpy()
+        sub = sps.csr_array((val, idx, ptr), shape=(len(rows), Qh.shape[0]))
+        # the GPU's user half from this Q: one more user half-epoch, rows read back
+        otor = eng._qtq
+        eng.backend.half_epoch(plan, eng.P[eng.u_lo:eng.u_hi], eng.Q, otor)
+        plan.check_status()
+        got = eng.backend.download(eng.P[torch.from_numpy(rows).to(dev)])
+        want = np.zeros_like(got)
+        threads = lko.num_threads()
+        t0 = time.perf_counter()
+        lko.als_half_epoch(sub, want, Qh, lko.implicit_otor(Qh, reg), threads)
+        dt = time.perf_counter() - t0
+        exact, cond = lko.als_referee_f64(sub, Qh, reg)
+        acc = parity.als_half_accounting(got, want, exact, cond)
+        acc.pop("by_cond_decade", None)
+        fl_s, _ = half_flops(lens, k)
+        est = dt * (fu + fuc + fi + fic) / max(fl_s, 1.0)
+        out["cpu_baseline"] = {
+            "value": 1.0 / est, "unit": "epochs/s", "cores": threads, "kind": "port",
+            "sample": f"user half on {len(rows)} of {plan.csr.shape[0]} rows ({sub.nnz} nnz) in "
+            f"{dt:.2f}s, extrapolated to an epoch by algorithmic flops",
+            "host_cpus": os.cpu_count()}
+        return {"what": "user half-epoch, GPU vs oracle from identical inputs, sampled rows",
+                **acc}
+
+    def topk_leg():
+        B = args.topk_users or max(64, eng.P.shape[0] // 8)
+        B = min(B, eng.P.shape[0])
+        hp = eng.u_plan.csr.h_indptr.astype(np.int64)
+        excl_ptr = torch.from_numpy(hp[: B + 1]).to(dev)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        D.score_topk(eng.P[:B], eng.Q, k, 100, excl_ptr, eng.u_plan.csr.indices)
+        torch.cuda.synchronize(dev)
+        tb = time.perf_counter() - t0
+        fl = 2.0 * B * eng.Q.shape[0] * k
+        return {"metric": "dense scoring + top-100, %d users x %d items (k=%d), seconds"
+                % (B, eng.Q.shape[0], k),
+                "value": round(tb, 3), "unit": "s", "users_per_s": round(B / tb, 1),
+                "roofline": {"bound": "mfma", "achieved": round(fl / tb / 1e12, 2),
+                             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(fl / tb / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                             "algorithmic_flops": fl}}
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        leg("parity", parity_leg)
+    if rank == 0 and world == 1 and not args.no_topk:
+        leg("topk", topk_leg)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -345,7 +544,14 @@ def main():
     ap.add_argument("--no-knn", action="store_true", help="skip the item-kNN build leg")
     ap.add_argument("--no-topk", action="store_true", help="skip the dense top-N scoring leg")
     ap.add_argument("--no-fit", action="store_true", help="skip the end-to-end fit leg")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg5"],
+                    help="cfg2: ML-25M-shaped (the default, BASELINE.json configs[1..3]); "
+                    "cfg5: synthetic 10M x 1M x 100M generated in HBM, k = 256 (configs[4])")
+    ap.add_argument("--topk-users", type=int, default=0,
+                    help="cfg5: users of the dense top-K leg (default: 1/8 of the users)")
     args = ap.parse_args()
+    if args.config == "cfg5":
+        return main_cfg5(args)
 
     import torch
     import torch.distributed as dist

@@ -348,6 +348,18 @@ int lk_iknn_prep_scale(const void *d_item_indptr, int indptr_is_64, const void *
                        const float *d_centered, const float *d_recip, int64_t n_items,
                        float *d_item_values_out, float *d_user_values_out, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Synthetic interaction matrix in HBM (bench tooling; SURVEY.md section 8d "cfg5 concrete
+ * input": Philox-seeded, shard-wise on the device -- the reference has no counterpart, its
+ * benchmarks read MovieLens files).  Given the row offsets d_indptr [n_rows+1] (int64; the
+ * degrees are the caller's), row r receives exactly its degree DISTINCT items in ascending
+ * order, item rank drawn ~ Zipf(1.0) from Philox4x32-10(key = seed, counter = (r, j)) and
+ * duplicates pushed to the next free rank; any row range can be generated independently.
+ * Rows longer than 32 entries (at most 4096) must be listed in d_long_rows. */
+int lk_synth_zipf_rows(const int64_t *d_indptr, int64_t n_rows, int64_t n_items, uint64_t seed,
+                       const int32_t *d_long_rows, int64_t n_long_rows, int32_t *d_out_indices,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,7 +87,7 @@ class HipBackend:
         csr = self.D.DeviceCSR.from_scipy(local_csr, self.dev)
         return self.D.ALSPlan(csr, self.k, self.solver)
 
-    def make_plans_on_device(self, ui: sps.csr_array, u_old, i_new, i_old, u_rng, i_rng):
+    def make_plans_on_device(self, ui, u_old, i_new, i_old, u_rng, i_rng, ilen=None):
         """
         Both orientations of the RELABELLED matrix built in HBM from one upload of the original
         CSR (``lk_csr_relabel`` + the stable device transpose ``lk_csr_transpose``) instead of
@@ -103,10 +103,14 @@ class HipBackend:
         dev = self.dev
         n_users, n_items = ui.shape
         nu, ni = len(u_old), len(i_old)
-        src = D.DeviceCSR.from_arrays(ui.indptr, ui.indices, ui.data, ui.shape, dev)
+        if isinstance(ui, D.DeviceCSR):  # already resident (e.g. generated in HBM)
+            src = ui
+        else:
+            src = D.DeviceCSR.from_arrays(ui.indptr, ui.indices, ui.data, ui.shape, dev)
         pdt = src.h_indptr.dtype
         ulen = np.diff(src.h_indptr)
-        ilen = np.bincount(ui.indices, minlength=n_items)
+        if ilen is None:
+            ilen = np.bincount(ui.indices, minlength=n_items)
         new_ulen = np.where(u_old >= 0, ulen[np.maximum(u_old, 0)], 0)
         new_ilen = np.where(i_old >= 0, ilen[np.maximum(i_old, 0)], 0)
         h_uptr = np.zeros(nu + 1, dtype=pdt)
@@ -142,6 +146,16 @@ class HipBackend:
 
     def upload(self, mat: np.ndarray) -> torch.Tensor:
         return self.D.to_device_padded(mat, self.dev)
+
+    def random_init(self, n: int, old_of_new: np.ndarray, seed: int) -> torch.Tensor:
+        "[n x KP] factors ~ (N(0,1) * 0.01)^2 drawn on the device; padding rows / columns zero"
+        g = torch.Generator(device=self.dev)
+        g.manual_seed(seed)
+        m = torch.zeros((n, self.kp), dtype=torch.float32, device=self.dev)
+        m[:, : self.k] = (torch.randn((n, self.k), generator=g, device=self.dev) * 0.01) ** 2
+        if (old_of_new < 0).any():
+            m[torch.from_numpy(np.flatnonzero(old_of_new < 0)).to(self.dev)] = 0.0
+        return m
 
     def download(self, mat: torch.Tensor) -> np.ndarray:
         return self.D.to_host_unpadded(mat, self.k)
@@ -188,11 +202,15 @@ class ImplicitALSEngine:
         self.world = dist.get_world_size(group) if (group is not None or _dist_on()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         n_users, n_items = ui.shape
-        ui = sps.csr_array(ui)
         self.n_users, self.n_items = n_users, n_items
-
-        ulen = np.diff(ui.indptr)
-        ilen = np.bincount(ui.indices, minlength=n_items)
+        on_device = hasattr(ui, "h_indptr")  # a DeviceCSR: the matrix is already in HBM
+        if on_device:
+            ulen = np.diff(ui.h_indptr)
+            ilen = torch.bincount(ui.indices, minlength=n_items).cpu().numpy()
+        else:
+            ui = sps.csr_array(ui)
+            ulen = np.diff(ui.indptr)
+            ilen = np.bincount(ui.indices, minlength=n_items)
         self.u_new, self.u_old, self.u_rpr = deal_rows(ulen, self.world)
         self.i_new, self.i_old, self.i_rpr = deal_rows(ilen, self.world)
         nu, ni = self.world * self.u_rpr, self.world * self.i_rpr
@@ -204,8 +222,9 @@ class ImplicitALSEngine:
             # product path: one upload, relabel + transpose in HBM
             self.u_plan, self.i_plan, self.local_nnz = backend.make_plans_on_device(
                 ui, self.u_old, self.i_new, self.i_old, (self.u_lo, self.u_hi),
-                (self.i_lo, self.i_hi))
+                (self.i_lo, self.i_hi), ilen)
         else:  # host restatement (CPU / gloo tests of the sharding logic)
+            assert not on_device
             ui_new = _relabel_csr(ui, self.u_new, nu, self.i_new, ni)
             iu_new = sps.csr_array(ui_new.T)
             iu_new.sort_indices()
@@ -214,12 +233,18 @@ class ImplicitALSEngine:
             self.local_nnz = (int(ui_new.indptr[self.u_hi] - ui_new.indptr[self.u_lo]),
                               int(iu_new.indptr[self.i_hi] - iu_new.indptr[self.i_lo]))  # fmt: skip
 
-        P = np.zeros((nu, self.k), dtype=np.float32)
-        Q = np.zeros((ni, self.k), dtype=np.float32)
-        P[self.u_new] = user_init
-        Q[self.i_new] = item_init
-        self.P = backend.upload(P)
-        self.Q = backend.upload(Q)
+        if user_init is None:
+            # bench-scale models (10^7 x 256): the reference's recipe ((N(0,1) * 0.01)^2, items
+            # first) drawn in HBM instead of crossing PCIe with 11 GB of host random numbers
+            self.Q = backend.random_init(ni, self.i_old, seed=1)
+            self.P = backend.random_init(nu, self.u_old, seed=2)
+        else:
+            P = np.zeros((nu, self.k), dtype=np.float32)
+            Q = np.zeros((ni, self.k), dtype=np.float32)
+            P[self.u_new] = user_init
+            Q[self.i_new] = item_init
+            self.P = backend.upload(P)
+            self.Q = backend.upload(Q)
         if self.world > 1:
             # every rank must start from the SAME factors (the first user half mixes the local Q
             # with an all-reduced Gramian): rank 0's initialisation wins, whatever the ranks'

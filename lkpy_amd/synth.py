@@ -103,3 +103,76 @@ def describe(mat: sps.csr_array) -> dict:
         "empty_items": int((il == 0).sum()),
         "sum_user_len_sq": int((ul.astype(np.int64) ** 2).sum()),
     }
+
+
+# ---------------------------------------------------------------------------------------
+# cfg5: 10^7 users x 10^6 items x 10^8 interactions, generated in HBM
+# ---------------------------------------------------------------------------------------
+
+CFG5 = dict(n_users=10_000_000, n_items=1_000_000, nnz=100_000_000, seed=5, max_degree=4096)
+
+
+def zipf_degrees(n_rows: int, nnz: int, seed: int, max_degree: int = 4096) -> np.ndarray:
+    """
+    Per-user degrees ~ truncated power law P(d) ~ d^-s on [1, max_degree] with the exponent
+    solved for the requested mean (10 for cfg5), drawn from ``np.random.Philox(seed)``, then
+    nudged by +-1 on random rows so that they sum to ``nnz`` EXACTLY (min 1 kept).
+    """
+    d = np.arange(1, max_degree + 1, dtype=np.float64)
+    target = nnz / n_rows
+    lo, hi = 0.5, 4.0
+    for _ in range(60):  # bisection on the exponent
+        s = 0.5 * (lo + hi)
+        w = d ** -s
+        if (w * d).sum() / w.sum() > target:
+            lo = s
+        else:
+            hi = s
+    w = d ** -(0.5 * (lo + hi))
+    cdf = np.cumsum(w / w.sum())
+    cdf[-1] = 1.0
+    rng = np.random.Generator(np.random.Philox(seed))
+    deg = (np.searchsorted(cdf, rng.random(n_rows), side="right") + 1).astype(np.int64)
+    deg = np.minimum(deg, max_degree)
+    diff = int(nnz - deg.sum())
+    while diff != 0:
+        step = 1 if diff > 0 else -1
+        ok = np.flatnonzero((deg < max_degree) if step > 0 else (deg > 1))
+        pick = rng.choice(ok, min(abs(diff), len(ok)), replace=False)
+        deg[pick] += step
+        diff = int(nnz - deg.sum())
+    return deg
+
+
+def zipf_csr_on_device(dev, n_users: int, n_items: int, nnz: int, seed: int = 5,
+                       value: float = 40.0, max_degree: int = 4096):
+    """
+    The cfg5-style matrix as a :class:`lkpy_amd._device.DeviceCSR` (users x items, values =
+    ``value``), generated by ``lk_synth_zipf_rows`` (csrc/synth.hip) -- only the 8-byte-per-user
+    offsets cross PCIe.  Rows hold distinct items in ascending order.
+    """
+    import ctypes
+
+    import torch
+
+    from . import _device as D
+    from . import _native
+
+    lib = _native.require_gpu()
+    deg = zipf_degrees(n_users, nnz, seed, max_degree)
+    indptr = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    long_rows = np.flatnonzero(deg > 32).astype(np.int32)
+    d_ptr = torch.from_numpy(indptr).to(dev)
+    d_long = torch.from_numpy(long_rows).to(dev)
+    idx = torch.empty(nnz, dtype=torch.int32, device=dev)
+    _native.check(lib.lk_synth_zipf_rows(
+        D._ptr(d_ptr), n_users, n_items, ctypes.c_uint64(seed), D._ptr(d_long), len(long_rows),
+        D._ptr(idx), D._stream()), "lk_synth_zipf_rows")
+    vals = torch.full((nnz,), float(value), dtype=torch.float32, device=dev)
+    if nnz < np.iinfo(np.int32).max:
+        h_ptr = indptr.astype(np.int32)
+        d_ptr = d_ptr.to(torch.int32)
+    else:
+        h_ptr = indptr
+    return D.DeviceCSR(d_ptr, idx, vals, (n_users, n_items), h_ptr)
