@@ -16,7 +16,7 @@ from IDENTICAL inputs on both sides:
   GPU is no further from the float64 referee than the reference arithmetic is (matrix level,
   factor 2 slack); and -- the statement that is not vacuous on real data, where
   ``cond(A) >= 100`` for every non-empty row because ``cond(OtOr)`` already is -- EVERY row of
-  the GPU result lies within ``NORM_BOUND * cond * 2^-24`` of the float64 answer (the a-priori
+  the GPU result lies within ``NORM_BOUND * cond * 2^-24 + FLOOR`` of the float64 answer (the a-priori
   forward error of a backward-stable float32 solve, measured constant: 1.3 / 2.4 for the HIP
   kernels on the ML-25M-shaped epoch, 1.3 / 7.3 for the reference arithmetic),
 * a histogram of row error against cond (decades), so nothing hides behind a loose bound.
@@ -29,7 +29,8 @@ import numpy as np
 U32 = 2.0**-24  # unit roundoff of float32
 RTOL = 1.0e-4  # north_star tolerance
 COND_LIMIT = 1.0e-5 / U32  # rows with cond below this must meet RTOL (~168)
-NORM_BOUND = 4.0  # every GPU row within NORM_BOUND * cond * u of the float64 answer
+NORM_BOUND = 4.0  # every GPU row within NORM_BOUND * cond * u + FLOOR of the float64 answer
+FLOOR = 1.0e-5
 
 
 def _row_rel(a: np.ndarray, b: np.ndarray) -> np.ndarray:
@@ -99,8 +100,12 @@ def als_half_accounting(got: np.ndarray, want: np.ndarray, exact: np.ndarray | N
             e_o = _row_rel(want, exact)
             res["row_err_over_cond_u_max_gpu"] = float((e_g[nzc] / cu[nzc]).max()) if nzc.any() else 0.0
             res["row_err_over_cond_u_max_oracle"] = float((e_o[nzc] / cu[nzc]).max()) if nzc.any() else 0.0
-            # cond is a LOWER-bound estimate, which only makes this test stricter
-            ok &= res["row_err_over_cond_u_max_gpu"] <= NORM_BOUND
+            # cond is a LOWER-bound estimate, which only makes this test stricter; FLOOR covers
+            # what no condition number explains: forming A and y is itself a k- and n-term
+            # float32 accumulation (~ k * u ~ 1e-5 at k = 256), ten times below the tolerance
+            viol = e_g[nzc] > NORM_BOUND * cu[nzc] + FLOOR
+            res["rows_beyond_forward_bound"] = int(viol.sum())
+            ok &= not viol.any()
     res["ok"] = bool(ok)
     return res
 
