@@ -340,6 +340,10 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
             }
             lds[C::OFF_Y + 16 * b + tid] = s;
         }
+        // keep the operand loads of (5) below this point: hoisted above, they would be live
+        // together with a[] and push the kernel past its 256-register budget (scratch spills
+        // cost a memory round trip each -- they were half of the kernel's time)
+        __builtin_amdgcn_sched_barrier(0);
         // (5) trailing update acc(ti, tj) += L(ti, b) L(tj, b)^T for ti, tj > b.  Operand for
         // MFMA step kk: lane (m = sub, kg = slot) supplies L[16 (t - b) + m][4 kg + kk] -- the
         // contraction index is enumerated as c = 4 kg + kk on BOTH operands, so one
@@ -371,6 +375,8 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
                         acc[lt(I, J)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                             la[kk], lb[J][kk], acc[lt(I, J)], 0, 0, 0);
                 });
+                // one A operand in flight ahead of the MFMAs that use it, not all NL of them
+                __builtin_amdgcn_sched_barrier(0);
             }
         });
         // (6) the owners of block row b take their L tiles back into the registers they
@@ -525,10 +531,14 @@ __device__ __forceinline__ void als_blk_solve_body(
         for (int s = 0; s < ns; ++s) {
             const float *slab =
                 slabs + (size_t)(first_slab + s) * C::SLAB + (size_t)wave * C::SLAB_WAVE;
-#pragma unroll
-            for (int tt = 0; tt < C::T; ++tt)
+            sfor<0, C::T>([&](auto tc) {
+                constexpr int tt = decltype(tc)::value;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[tt][r] += slab[(tt * 4 + r) * 64 + lane];
+                // at most 8 tiles' worth of loads in flight (all T at once would need 4 T
+                // temporaries next to the 4 T accumulators)
+                if constexpr (tt % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+            });
 #pragma unroll
             for (int i = 0; i < NL; ++i) yacc[i] += slab[(C::T * 4 + i) * 64 + lane];
         }
