@@ -749,6 +749,55 @@ def main():
 
         return _knn_bench.run(ratings, dev, checker=None if args.no_cpu else knn_cpu_and_parity)
 
+    def sharded_legs():
+        """
+        N > 1: the two legs that shard without a data-path collective (lkpy_amd/_sharded.py):
+        every rank scores its block of users / builds its block of similarity rows; the time
+        is barrier-bracketed and the maximum over ranks.  Blocks stay on their ranks.
+        """
+        from lkpy_amd import _device as D
+        from lkpy_amd import _sharded
+
+        def timed(fn):
+            barrier()
+            t0 = time.perf_counter()
+            fn()
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        res = {}
+        if not args.no_topk:
+            hp = eng.u_plan.csr.full_h_indptr.astype(np.int64)
+            excl_ptr = torch.from_numpy(hp).to(dev)
+            run = lambda: _sharded.score_topk_sharded(  # noqa: E731
+                eng.P, eng.Q, k, 100, excl_ptr, eng.u_plan.csr.indices, collect=False)
+            run()
+            tb = timed(run)
+            fl = 2.0 * eng.P.shape[0] * eng.Q.shape[0] * k
+            res["topk"] = {"metric": "dense scoring + top-100 of all users x all items, users "
+                           "sharded over %d GPUs, seconds" % world, "value": round(tb, 4),
+                           "unit": "s", "users_per_s": round(eng.P.shape[0] / tb, 1),
+                           "mfma_frac_aggregate": round(fl / tb / 1e12 / F32_MFMA_PEAK_TFLOPS
+                                                        / world, 4)}
+        if not args.no_knn:
+            dui, diu, _means, _ = D.iknn_prepare(ratings, True, dev)
+            run = lambda: _sharded.iknn_build_sharded(dui, diu, 1.0e-6, None, collect=False)  # noqa: E731
+            run()
+            tb = timed(run)
+            res["knn"] = {"metric": "item-kNN model build seconds, output rows sharded over %d "
+                          "GPUs (blocks left on their ranks)" % world, "value": round(tb, 4),
+                          "unit": "s", "higher_is_better": False}
+        return res
+
+    if world > 1:
+        try:
+            extra = sharded_legs()
+        except Exception as exc:  # noqa: BLE001 -- reported, not swallowed
+            extra = {"sharded_legs_error": f"{type(exc).__name__}: {exc}"}
+        out.update(extra)
+
     single = rank == 0 and world == 1
     if single and not args.no_cpu:
         leg("parity", als_parity_leg)

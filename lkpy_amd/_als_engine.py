@@ -138,6 +138,7 @@ class HipBackend:
         def local(full, h_ptr, lo, hi, n_cols):
             view = D.DeviceCSR(full.indptr[lo : hi + 1], full.indices, full.values,
                                (hi - lo, n_cols), h_ptr[lo : hi + 1])
+            view.full_h_indptr = h_ptr  # offsets of ALL rows (every rank holds the full arrays)
             return D.ALSPlan(view, self.k, self.solver)
 
         return (local(ui_new, h_uptr, u_rng[0], u_rng[1], ni),

@@ -196,3 +196,101 @@ def test_engine_single_process_relabelling_round_trip(oracle, explicit):
     assert np.allclose(eng.item_embeddings(), Q, rtol=1e-3, atol=1e-5)
     if not explicit:
         assert np.allclose(eng.otor(), oracle.implicit_otor(Q, 0.1), rtol=1e-3, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------
+# item-kNN build / dense top-N sharded over ranks (lkpy_amd/_sharded.py), oracle standing in
+# ---------------------------------------------------------------------------------------
+
+
+def _knn_worker(rank, world, port, ui, iu, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lkpy_amd import _sharded
+        from oracle import lk_oracle as lko
+
+        w = _sharded.iknn_row_weights(ui.indptr, iu.indptr, iu.indices)
+
+        def build(lo, hi):  # the oracle's sim_row for this rank's rows
+            blk = lko.iknn_build_rows(ui, iu, np.arange(lo, hi, dtype=np.int32), 1.0e-6, 20)
+            return (torch.from_numpy(blk.indptr.astype(np.int64)),
+                    torch.from_numpy(blk.indices.astype(np.int32)),
+                    torch.from_numpy(blk.data.astype(np.float32)))
+
+        ranges, res = _sharded.build_rows_sharded(build, iu.shape[0], w)
+        out[rank] = (ranges, None if res is None else tuple(t.numpy() for t in res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_knn_build_sharded_world2(oracle, ml_small):
+    ui, iu, _m, _ = oracle.iknn_prepare(ml_small["rmat"], True)
+    want = oracle.iknn_build(ui, iu, 1.0e-6, 20)
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_knn_worker, args=(2, _free_port(), ui, iu, out), nprocs=2, join=True)
+    ranges, res = out[0]
+    assert out[1][1] is None  # only the destination rank holds the stitched matrix
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == ui.shape[1]
+    # balanced by multiply-accumulates, not by row count
+    from lkpy_amd import _sharded
+
+    w = _sharded.iknn_row_weights(ui.indptr, iu.indptr, iu.indices)
+    a, b = w[: ranges[0][1]].sum(), w[ranges[0][1] :].sum()
+    assert abs(a - b) / (a + b) < 0.05
+    ptr, idx, val = res
+    assert ptr.dtype == np.int64 and np.array_equal(ptr, want.indptr)
+    assert np.array_equal(idx, want.indices)
+    assert np.array_equal(val.view(np.uint32), want.data.view(np.uint32))
+
+
+def _topk_worker(rank, world, port, P, Q, n, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lkpy_amd import _sharded
+        from oracle import lk_oracle as lko
+
+        def block(lo, hi):
+            idx = np.full((hi - lo, n), -1, np.int32)
+            sc = np.full((hi - lo, n), np.nan, np.float32)
+            for u in range(lo, hi):
+                s = lko.score_dense(Q, P[u])
+                top = lko.argtopn(s, n)
+                idx[u - lo, : len(top)] = top
+                sc[u - lo, : len(top)] = s[top]
+            return torch.from_numpy(idx), torch.from_numpy(sc)
+
+        ranges, res = _sharded.topk_sharded(block, P.shape[0], n)
+        out[rank] = (ranges, None if res is None else tuple(t.numpy() for t in res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_topk_sharded_world2(oracle, rng):
+    P = rng.standard_normal((37, 16)).astype(np.float32)  # odd count: uneven blocks
+    Q = rng.standard_normal((300, 16)).astype(np.float32)
+    n = 10
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_topk_worker, args=(2, _free_port(), P, Q, n, out), nprocs=2, join=True)
+    ranges, res = out[0]
+    assert ranges == [(0, 19), (19, 37)] and out[1][1] is None
+    idx, sc = res
+    for u in range(37):
+        s = oracle.score_dense(Q, P[u])
+        assert np.array_equal(idx[u], oracle.argtopn(s, n))
+        assert np.array_equal(sc[u], s[idx[u]])
+
+
+def test_balanced_ranges_edge_cases():
+    from lkpy_amd._sharded import balanced_ranges, shard_rows_even
+
+    assert balanced_ranges(np.array([1.0, 1, 1, 1]), 2) == [(0, 2), (2, 4)]
+    r = balanced_ranges(np.array([100.0, 1, 1, 1, 1]), 3)
+    assert r[0][0] == 0 and r[-1][1] == 5 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    assert balanced_ranges(np.zeros(0), 2) == [(0, 0), (0, 0)]
+    assert shard_rows_even(5, 2) == [(0, 3), (3, 5)] and shard_rows_even(2, 4)[-1] == (2, 2)
