@@ -544,6 +544,10 @@ def main():
     ap.add_argument("--no-knn", action="store_true", help="skip the item-kNN build leg")
     ap.add_argument("--no-topk", action="store_true", help="skip the dense top-N scoring leg")
     ap.add_argument("--no-fit", action="store_true", help="skip the end-to-end fit leg")
+    ap.add_argument("--sharded-legs", action="store_true",
+                    help="N > 1: also time the sharded item-kNN build and dense top-N (off by "
+                    "default: the scaling run's headline must not depend on legs that no "
+                    "multi-GPU box has exercised yet)")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg5"],
                     help="cfg2: ML-25M-shaped (the default, BASELINE.json configs[1..3]); "
                     "cfg5: synthetic 10M x 1M x 100M generated in HBM, k = 256 (configs[4])")
@@ -791,7 +795,7 @@ def main():
                           "unit": "s", "higher_is_better": False}
         return res
 
-    if world > 1:
+    if world > 1 and args.sharded_legs:
         try:
             extra = sharded_legs()
         except Exception as exc:  # noqa: BLE001 -- reported, not swallowed
