@@ -287,18 +287,33 @@ class ImplicitALSEngine:
             return du, di
         # user half: previous Q (src/lenskit/als/_common.py:251)
         du = b.half_epoch(self.u_plan, self.P[self.u_lo : self.u_hi], self.Q, self._qtq)
-        du = self._delta(du)
         self._exchange(self.P, self.u_lo, self.u_hi)
-        ptp = self._gramian(self.P, self.u_lo, self.u_hi, self.item_reg)
+        ptp, du = self._gramian_and_delta(self.P, self.u_lo, self.u_hi, self.item_reg, du)
         # item half: NEW P (_common.py:253)
         di = b.half_epoch(self.i_plan, self.Q[self.i_lo : self.i_hi], self.P, ptp)
-        di = self._delta(di)
         self._exchange(self.Q, self.i_lo, self.i_hi)
         # Q^T Q + user_reg I: next epoch's user half AND the scorer's _OtOr
         # (_save_user_otor, src/lenskit/als/_implicit.py:171-175)
-        self._qtq = self._gramian(self.Q, self.i_lo, self.i_hi, self.user_reg)
+        self._qtq, di = self._gramian_and_delta(self.Q, self.i_lo, self.i_hi, self.user_reg, di)
         self.epochs_trained += 1
         return du, di
+
+    def _gramian_and_delta(self, full: torch.Tensor, lo: int, hi: int, reg: float,
+                           d: torch.Tensor):
+        """
+        The slice Gramian (k x k) and the slice's squared delta travel in ONE all-reduce
+        (k*k + 1 floats: latency-bound on xGMI, so one message instead of two); returns
+        (M^T M + reg I, sqrt(sum of squared row deltas)).
+        """
+        if self.world == 1:
+            return self.backend.gramian(full, reg), d.clone()
+        g = self.backend.gramian(full[lo:hi], reg if self.rank == 0 else 0.0)
+        kk = self.k * self.k
+        buf = torch.empty(kk + 1, dtype=torch.float32, device=g.device)
+        buf[:kk] = g.reshape(-1)
+        buf[kk:] = (d * d).reshape(-1)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        return buf[:kk].reshape(self.k, self.k).contiguous(), buf[kk:].sqrt()
 
     def _delta(self, d: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
