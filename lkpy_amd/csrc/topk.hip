@@ -23,6 +23,7 @@
 // Roofline: scoring is f32-MFMA bound (2*B*I*k flop); this first version writes the
 // B_tile x I score panel to HBM and reads it back for the selection (not yet fused).
 #include <cstdlib>
+#include <vector>
 
 #include "common.h"
 
@@ -35,88 +36,315 @@ constexpr int SC_LD = SC_KC + 1;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void score_panel_kernel(
+// FILTER = false: write the score tile to `scores`.  FILTER = true (fused selection, stage 2):
+// nothing is written but the entries that reach the row's threshold tau[u] (a lower bound of
+// its n-th largest candidate score, from stage 1): they are appended to the row's candidate
+// list as (key << 32 | ~index) -- the B x I score matrix never exists in memory.
+// UT: 32-user sub-tiles per wave.  Workgroup tile = (64 UT) users x 256 items, wave tile =
+// (32 UT) users x 128 items.  UT = 2 (the fused path: no C tile to write, so the accumulators
+// may fill the registers) halves the operand bytes per flop -- at k = 64 the 64 x 256 tile is
+// bound by L2 -> LDS traffic, not by the matrix cores.
+template <bool FILTER, int UT>
+__device__ __forceinline__ void score_panel_body(
     const float *__restrict__ users, int ld_u, int64_t n_users, const float *__restrict__ items,
-    int ld_i, int64_t n_items, int kp, float *__restrict__ scores, int64_t ld_s)
+    int ld_i, int64_t n_items, int kp, float *__restrict__ scores, int64_t ld_s,
+    const float *__restrict__ tau, unsigned long long *__restrict__ cand,
+    unsigned *__restrict__ cand_cnt, int cand_cap, float *lds_all)
 {
-    __shared__ float lu[SC_UB * SC_LD];
-    __shared__ float li[SC_IB * SC_LD];
+    constexpr int UB = SC_UB * UT;
+    float *lu = lds_all;
+    float *li = lds_all + UB * SC_LD;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t u0 = (int64_t)blockIdx.y * SC_UB;
-    const int64_t i0 = (int64_t)blockIdx.x * SC_IB;
-    const int wu = (wave & 1) * 32;   // wave's user offset inside the tile
-    const int wi = (wave >> 1) * 128;  // wave's item offset inside the tile
+    // panel writer: grid (item tiles, user tiles), one tile per workgroup.  Fused filter: grid
+    // (user tiles): the workgroup OWNS its rows and walks every item tile, so the per-row
+    // candidate counters live in LDS and no global atomic is ever issued.
+    const int64_t u0 = (int64_t)(FILTER ? blockIdx.x : blockIdx.y) * UB;
+    const int wu = (wave & 1) * 32 * UT;  // wave's user offset inside the tile
+    const int wi = (wave >> 1) * 128;     // wave's item offset inside the tile
+    const int64_t n_itiles = (n_items + SC_IB - 1) / SC_IB;
 
-    f32x16 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // per-row state of the fused filter, behind the operand slabs
+    float *s_tau = lds_all + (UB + SC_IB) * SC_LD;
+    unsigned *s_cnt = reinterpret_cast<unsigned *>(s_tau + UB);
+    if constexpr (FILTER) {
+        for (int r = tid; r < UB; r += 256) {
+            s_tau[r] = (u0 + r < n_users) ? tau[u0 + r] : __builtin_inff();
+            s_cnt[r] = 0u;
+        }
+    }
 
-    // Software pipeline: the next 32-feature slab of both panels is fetched into registers
-    // (coalesced float4 reads) while the MFMAs of the current slab run out of LDS.
-    constexpr int UV = SC_UB * (SC_KC / 4) / 256;  // float4 per thread, user panel
+    constexpr int UV = UB * (SC_KC / 4) / 256;     // float4 per thread, user panel
     constexpr int IV = SC_IB * (SC_KC / 4) / 256;  // float4 per thread, item panel
     f32x4 ru[UV], ri[IV];
-    auto fetch = [&](int kc) {
+
+    const int64_t it_begin = FILTER ? 0 : (int64_t)blockIdx.x;
+    const int64_t it_end = FILTER ? n_itiles : it_begin + 1;
+    int64_t itile = it_begin;
+    do {
+        const int64_t i0 = itile * SC_IB;
+        f32x16 acc[UT][4];
 #pragma unroll
-        for (int q = 0; q < UV; ++q) {
-            const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
-            ru[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (u0 + r < n_users && kc + c4 * 4 < kp)
-                ru[q] = *reinterpret_cast<const f32x4 *>(users + (u0 + r) * ld_u + kc + c4 * 4);
-        }
+        for (int ut = 0; ut < UT; ++ut)
 #pragma unroll
-        for (int q = 0; q < IV; ++q) {
-            const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
-            ri[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i0 + r < n_items && kc + c4 * 4 < kp)
-                ri[q] = *reinterpret_cast<const f32x4 *>(items + (i0 + r) * ld_i + kc + c4 * 4);
-        }
-    };
-    auto stage = [&]() {
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int q = 0; q < UV; ++q) {
-            const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
-            float *d = &lu[r * SC_LD + c4 * 4];
-            d[0] = ru[q].x; d[1] = ru[q].y; d[2] = ru[q].z; d[3] = ru[q].w;
-        }
+                for (int r = 0; r < 16; ++r) acc[ut][t][r] = 0.f;
+
+        // Software pipeline: the next 32-feature slab of both panels is fetched into registers
+        // (coalesced float4 reads) while the MFMAs of the current slab run out of LDS.
+        auto fetch = [&](int kc) {
 #pragma unroll
-        for (int q = 0; q < IV; ++q) {
-            const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
-            float *d = &li[r * SC_LD + c4 * 4];
-            d[0] = ri[q].x; d[1] = ri[q].y; d[2] = ri[q].z; d[3] = ri[q].w;
-        }
-    };
-    fetch(0);
-    for (int kc = 0; kc < kp; kc += SC_KC) {
-        stage();
-        __syncthreads();
-        if (kc + SC_KC < kp) fetch(kc + SC_KC);
-        // v_mfma_f32_32x32x2_f32: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]
-        const int r = lane & 31, h = lane >> 5;
-#pragma unroll 4
-        for (int kk = 0; kk < SC_KC; kk += 2) {
-            const float a = lu[(wu + r) * SC_LD + kk + h];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float b = li[(wi + t * 32 + r) * SC_LD + kk + h];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            for (int q = 0; q < UV; ++q) {
+                const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
+                ru[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (u0 + r < n_users && kc + c4 * 4 < kp)
+                    ru[q] = *reinterpret_cast<const f32x4 *>(users + (u0 + r) * ld_u + kc + c4 * 4);
             }
-        }
-        __syncthreads();  // everyone is done reading before the next slab is staged
-    }
-    // C/D: col (item) = lane&31, row (user) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int64_t it = i0 + wi + t * 32 + (lane & 31);
+            for (int q = 0; q < IV; ++q) {
+                const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
+                ri[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i0 + r < n_items && kc + c4 * 4 < kp)
+                    ri[q] = *reinterpret_cast<const f32x4 *>(items + (i0 + r) * ld_i + kc + c4 * 4);
+            }
+        };
+        auto stage = [&]() {
 #pragma unroll
-        for (int rg = 0; rg < 16; ++rg) {
-            const int64_t u = u0 + wu + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
-            if (u < n_users && it < n_items) scores[u * ld_s + it] = acc[t][rg];
+            for (int q = 0; q < UV; ++q) {
+                const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
+                float *d = &lu[r * SC_LD + c4 * 4];
+                d[0] = ru[q].x; d[1] = ru[q].y; d[2] = ru[q].z; d[3] = ru[q].w;
+            }
+#pragma unroll
+            for (int q = 0; q < IV; ++q) {
+                const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
+                float *d = &li[r * SC_LD + c4 * 4];
+                d[0] = ri[q].x; d[1] = ri[q].y; d[2] = ri[q].z; d[3] = ri[q].w;
+            }
+        };
+        fetch(0);
+        for (int kc = 0; kc < kp; kc += SC_KC) {
+            stage();
+            __syncthreads();
+            if (kc + SC_KC < kp) fetch(kc + SC_KC);
+            // v_mfma_f32_32x32x2_f32: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]
+            const int r = lane & 31, h = lane >> 5;
+#pragma unroll 4
+            for (int kk = 0; kk < SC_KC; kk += 2) {
+                float a[UT];
+#pragma unroll
+                for (int ut = 0; ut < UT; ++ut) a[ut] = lu[(wu + ut * 32 + r) * SC_LD + kk + h];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float b = li[(wi + t * 32 + r) * SC_LD + kk + h];
+#pragma unroll
+                    for (int ut = 0; ut < UT; ++ut)
+                        acc[ut][t] =
+                            __builtin_amdgcn_mfma_f32_32x32x2f32(a[ut], b, acc[ut][t], 0, 0, 0);
+                }
+            }
+            __syncthreads();  // everyone is done reading before the next slab is staged
+        }
+        // C/D: col (item) = lane&31, row (user) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        if constexpr (!FILTER) {
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int64_t it = i0 + wi + t * 32 + (lane & 31);
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const int64_t u =
+                            u0 + wu + ut * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+                        if (u < n_users && it < n_items) scores[u * ld_s + it] = acc[ut][t][rg];
+                    }
+                }
+        } else {
+            // Hits (score >= tau of its row; NaN fails) are rare after stage 1 -- a few per row
+            // and tile.  A memory operation per hit inside 64 * UT divergent branches would
+            // serialise the wave on latency, so the hits are first compacted wave-wide into this
+            // wave's share of the (idle until the next tile is staged) operand LDS; then a lane
+            // per hit takes its slot from the row's LDS counter and writes the candidate.
+            constexpr int STAGE = 2048;  // entries per wave: key (u32) + row << 8 | column (u16)
+            static_assert(4 * STAGE * 6 <= (UB + SC_IB) * SC_LD * 4, "staging must fit the operand LDS");
+            unsigned *skey = reinterpret_cast<unsigned *>(lds_all) + wave * STAGE;
+            unsigned short *src = reinterpret_cast<unsigned short *>(
+                                      reinterpret_cast<unsigned *>(lds_all) + 4 * STAGE) + wave * STAGE;
+            const unsigned long long lt_mask = (1ull << lane) - 1ull;
+            int base = 0;  // wave-uniform
+            auto flush = [&]() {
+                for (int i = lane; i < base; i += 64) {
+                    const unsigned key = skey[i], rc = src[i];
+                    const unsigned row = rc >> 8;
+                    const unsigned it = (unsigned)(i0 + (rc & 0xffu));
+                    const unsigned pos = atomicAdd(&s_cnt[row], 1u);  // LDS
+                    if (pos < (unsigned)cand_cap)
+                        cand[(u0 + row) * cand_cap + pos] =
+                            ((unsigned long long)key << 32) | (0xffffffffu - it);
+                }
+                base = 0;
+            };
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) {
+                float th[16];
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg)
+                    th[rg] = s_tau[wu + ut * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5)];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    // a group of 16 sites appends at most 1024 entries: one capacity check
+                    if (base > STAGE - 1024) flush();
+                    const int col = wi + t * 32 + (lane & 31);
+                    const bool in = i0 + col < n_items;
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const float x = acc[ut][t][rg];
+                        const bool hit = in && x >= th[rg];
+                        const unsigned long long m = __ballot(hit);
+                        if (m) {  // wave-uniform
+                            if (hit) {
+                                const int slot = base + __popcll(m & lt_mask);
+                                const int row = wu + ut * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+                                skey[slot] = f2key(x);
+                                src[slot] = (unsigned short)((row << 8) | col);
+                            }
+                            base += __popcll(m);
+                        }
+                    }
+                }
+            }
+            flush();
+            __syncthreads();  // the staging area is the next tile's operand slab
+        }
+        if constexpr (!FILTER) break;  // one tile per workgroup: no loop at all for the compiler
+        ++itile;
+    } while (itile < it_end);
+    if constexpr (FILTER) {
+        __syncthreads();
+        for (int r = tid; r < UB; r += 256)
+            if (u0 + r < n_users) cand_cnt[u0 + r] = s_cnt[r];
+    }
+}
+
+#define LK_SCORE_ARGS                                                                            \
+    const float *__restrict__ users, int ld_u, int64_t n_users, const float *__restrict__ items, \
+        int ld_i, int64_t n_items, int kp, float *__restrict__ scores, int64_t ld_s,             \
+        const float *__restrict__ tau, unsigned long long *__restrict__ cand,                    \
+        unsigned *__restrict__ cand_cnt, int cand_cap
+
+// the panel writer: 64 x 256 tile, 3 workgroups per CU
+__global__ __launch_bounds__(256) void score_panel_kernel(LK_SCORE_ARGS)
+{
+    __shared__ __attribute__((aligned(16))) float lds_all[(SC_UB + SC_IB) * SC_LD];
+    score_panel_body<false, 1>(users, ld_u, n_users, items, ld_i, n_items, kp, scores, ld_s, tau,
+                               cand, cand_cnt, cand_cap, lds_all);
+}
+
+// the fused filter: 128 x 256 tile, 128 accumulator registers, held to 2 workgroups per CU
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void score_filter_kernel(
+    LK_SCORE_ARGS)
+{
+    __shared__ __attribute__((aligned(16))) float lds_all[(2 * SC_UB + SC_IB) * SC_LD + 4 * SC_UB];
+    score_panel_body<true, 2>(users, ld_u, n_users, items, ld_i, n_items, kp, scores, ld_s, tau,
+                              cand, cand_cnt, cand_cap, lds_all);
+}
+#undef LK_SCORE_ARGS
+
+// stage 3 of the fused selection: one workgroup per row.  The candidates (every entry >= tau)
+// are loaded, the row's excluded items are struck out through a small LDS hash of the
+// candidates' item numbers (the exclusion list may be in any order and of any length: it is
+// only walked once), and the survivors are bitonic-sorted by (score desc, index asc).  Rows
+// whose candidate list overflowed are flagged for the unfused path.
+template <int CAP>
+__global__ __launch_bounds__(256) void cand_select_kernel(
+    const unsigned long long *__restrict__ cand, const unsigned *__restrict__ cand_cnt,
+    const int64_t *__restrict__ excl_ptr, const int32_t *__restrict__ excl_items,
+    int64_t user_base, int n, int32_t *__restrict__ out_idx, float *__restrict__ out_score,
+    int64_t out_ld, int *__restrict__ overflow)
+{
+    __shared__ unsigned long long key[CAP];
+    __shared__ int hslot[2 * CAP];  // open addressing: candidate position + 1, 0 = empty
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const unsigned m = cand_cnt[b];
+    int32_t *oidx = out_idx + b * out_ld;
+    float *osc = out_score ? out_score + b * out_ld : nullptr;
+    if (m > (unsigned)CAP) {  // handled by the caller through the unfused path
+        if (tid == 0) atomicExch(overflow, 1);
+        return;
+    }
+    unsigned p2 = 1;
+    while (p2 < m) p2 <<= 1;
+    if (p2 < 2) p2 = 2;
+    for (unsigned i = tid; i < p2; i += 256) key[i] = i < m ? cand[b * CAP + i] : 0ull;
+    for (int i = tid; i < 2 * CAP; i += 256) hslot[i] = 0;
+    __syncthreads();
+    if (excl_ptr) {
+        const int64_t eb = excl_ptr[user_base + b], ee = excl_ptr[user_base + b + 1];
+        if (ee > eb) {
+            for (unsigned i = tid; i < m; i += 256) {
+                const unsigned it = 0xffffffffu - (unsigned)(key[i] & 0xffffffffu);
+                unsigned h = (it * 2654435761u) & (2 * CAP - 1);
+                while (atomicCAS(&hslot[h], 0, (int)i + 1) != 0) h = (h + 1) & (2 * CAP - 1);
+            }
+            __syncthreads();
+            for (int64_t e = eb + tid; e < ee; e += 256) {
+                const unsigned it = (unsigned)excl_items[e];
+                unsigned h = (it * 2654435761u) & (2 * CAP - 1);
+                for (;;) {
+                    const int s = hslot[h];
+                    if (s == 0) break;
+                    const unsigned ci = 0xffffffffu - (unsigned)(key[s - 1] & 0xffffffffu);
+                    if (ci == it) {
+                        key[s - 1] = 0ull;  // excluded: sorts to the end, never emitted
+                        break;
+                    }
+                    h = (h + 1) & (2 * CAP - 1);
+                }
+            }
+            __syncthreads();
         }
     }
+    for (unsigned k = 2; k <= p2; k <<= 1) {
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            for (unsigned i = tid; i < p2; i += 256) {
+                const unsigned ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = key[i], c = key[ixj];
+                    const bool desc = ((i & k) == 0);
+                    if (desc ? (a < c) : (a > c)) {
+                        key[i] = c;
+                        key[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += 256) {
+        const unsigned long long c = (unsigned)i < p2 ? key[i] : 0ull;
+        if (c != 0ull) {
+            oidx[i] = (int32_t)(0xffffffffu - (unsigned)(c & 0xffffffffu));
+            if (osc) osc[i] = key2f((unsigned)(c >> 32));
+        } else {
+            oidx[i] = -1;
+            if (osc) osc[i] = __builtin_nanf("");
+        }
+    }
+}
+
+// tau[b] = the n-th best score of the stage-1 sample (or -inf when the sample holds fewer
+// than n candidates: everything then passes and the row falls back through the overflow flag)
+__global__ void tau_from_topn_kernel(const float *__restrict__ sub_scores, int64_t ld, int n,
+                                     int64_t n_rows, float *__restrict__ tau,
+                                     unsigned *__restrict__ cand_cnt)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_rows) return;
+    const float x = sub_scores[b * ld + n - 1];
+    tau[b] = (x == x) ? x : -__builtin_inff();
+    cand_cnt[b] = 0u;
 }
 
 // scores[b][excluded item] = NaN  (NaN is skipped by the selection, like the reference)
@@ -405,6 +633,73 @@ static int64_t score_batch()
 
 static int64_t padded_items(int64_t n_items) { return (n_items + 63) / 64 * 64; }
 
+// ---- fused scoring + selection (never materialises the B x I score matrix) -----------------
+// Stage 1: the first n_sub items are scored into a small panel; the n-th best of those
+// candidates (exclusions applied) is tau_b, a LOWER BOUND of the row's n-th best over all
+// items.  Stage 2: the full GEMM, whose epilogue appends the entries >= tau_b to the row's
+// candidate list (expected n * I / n_sub entries).  Stage 3: exclusions struck out, exact
+// (score desc, index asc) order among the candidates.  Same results as the panel path, bit
+// for bit; rows whose list overflows FUSED_CAP go through the panel path.
+constexpr int FUSED_CAP = 2048;        // candidates per row
+constexpr int64_t FUSED_ROWS = 65536;  // rows per batch: 512 workgroups of 128 users fill the chip twice over
+constexpr int FUSED_MAX_N = 128;       // expected candidates <= 8 n <= FUSED_CAP / 2
+
+static int64_t fused_min_items()
+{
+    const char *e = getenv("LK_TOPK_FUSED_MIN_ITEMS");  // test hook / tuning knob (read per call)
+    return e ? (int64_t)atol(e) : (int64_t)16384;
+}
+
+static int64_t fused_min_users()
+{
+    const char *e = getenv("LK_TOPK_FUSED_MIN_USERS");  // test hook / tuning knob
+    return e ? (int64_t)atol(e) : (int64_t)8192;  // fewer rows: too few workgroups, panel path
+}
+
+static bool use_fused(int64_t n_users, int64_t n_items, int32_t n)
+{
+    return n >= 1 && n <= FUSED_MAX_N && n_items >= fused_min_items() &&
+           n_items >= 64 * (int64_t)n && n_users >= fused_min_users();
+}
+
+// items of the stage-1 sample: an eighth of the catalogue, at least 16 n, a multiple of 256
+static int64_t fused_sub_items(int64_t n_items, int32_t n)
+{
+    int64_t s = n_items / 8;
+    if (s < 16 * (int64_t)n) s = 16 * (int64_t)n;
+    s = (s + 255) / 256 * 256;
+    return s < n_items ? s : n_items;
+}
+
+struct FusedLayout {
+    size_t off_sub, off_tau, off_cnt, off_cand, off_sidx, off_ssc, off_flags, bytes;
+};
+
+static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n)
+{
+    const int64_t rows = n_users < FUSED_ROWS ? n_users : FUSED_ROWS;
+    const int64_t nsub = padded_items(fused_sub_items(n_items, n));
+    const int64_t batches = (n_users + FUSED_ROWS - 1) / FUSED_ROWS;
+    FusedLayout L;
+    size_t off = 0;
+    L.off_sub = off;
+    off += align_up((size_t)rows * nsub * 4, 256);
+    L.off_tau = off;
+    off += align_up((size_t)rows * 4, 256);
+    L.off_cnt = off;
+    off += align_up((size_t)rows * 4, 256);
+    L.off_cand = off;
+    off += align_up((size_t)rows * FUSED_CAP * 8, 256);
+    L.off_sidx = off;
+    off += align_up((size_t)rows * n * 4, 256);
+    L.off_ssc = off;
+    off += align_up((size_t)rows * n * 4, 256);
+    L.off_flags = off;
+    off += align_up((size_t)(batches > 0 ? batches : 1) * 4, 256);
+    L.bytes = off;
+    return L;
+}
+
 }  // namespace lk
 
 extern "C" size_t lk_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t n)
@@ -414,6 +709,8 @@ extern "C" size_t lk_score_topk_workspace_bytes(int64_t n_users, int64_t n_items
     size_t bytes = lk::align_up((size_t)rows * (size_t)lk::padded_items(n_items) * sizeof(float), 256) + 256;
     // n < 0 (rank everything) or n beyond the selection kernel's capacity: full sort of the panel
     if (n < 0 || n > lk::TOPN_MAX) bytes += lk::topn_sort_workspace_bytes(rows, n_items);
+    // fused path: its buffers sit behind the panel (the panel serves overflowing batches)
+    if (lk::use_fused(n_users, n_items, n)) bytes += lk::fused_layout(n_users, n_items, n).bytes;
     return bytes;
 }
 
@@ -437,8 +734,10 @@ extern "C" int lk_score_dense(const float *d_users, int32_t ld_users, int64_t n_
     LK_REQUIRE(d_users && d_items && d_out, "lk_score_dense: null pointer");
     dim3 grid((unsigned)((n_items + lk::SC_IB - 1) / lk::SC_IB),
               (unsigned)((n_users + lk::SC_UB - 1) / lk::SC_UB));
-    hipLaunchKernelGGL(lk::score_panel_kernel, grid, dim3(256), 0, lk::as_stream(stream), d_users,
-                       ld_users, n_users, d_items, ld_items, n_items, KP, d_out, ld_out);
+    hipLaunchKernelGGL(lk::score_panel_kernel, grid, dim3(256), 0, lk::as_stream(stream),
+                       d_users, ld_users, n_users, d_items, ld_items, n_items, KP, d_out, ld_out,
+                       (const float *)nullptr, (unsigned long long *)nullptr, (unsigned *)nullptr,
+                       0);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }
@@ -487,34 +786,104 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
     hipStream_t st = lk::as_stream(stream);
     float *panel = static_cast<float *>(d_ws);
     const int64_t ld_s = lk::padded_items(n_items);
-    const int KS = KP < lk::SC_KC ? lk::SC_KC : KP;  // features are staged 64 at a time
-    (void)KS;
-    for (int64_t ub = 0; ub < n_users; ub += lk::score_batch()) {
-        const int64_t rows = (n_users - ub) < lk::score_batch() ? (n_users - ub) : lk::score_batch();
+    const int64_t pb = n_users < lk::score_batch() ? n_users : lk::score_batch();
+    const size_t panel_bytes = lk::align_up((size_t)pb * (size_t)ld_s * sizeof(float), 256) + 256;
+
+    // the panel path for rows [ub, ub + rows): GEMM, exclusion mask, selection (or full sort)
+    auto run_panel = [&](int64_t ub, int64_t rows) -> int {
         if (n_items > 0) {
             dim3 grid((unsigned)((n_items + lk::SC_IB - 1) / lk::SC_IB),
                       (unsigned)((rows + lk::SC_UB - 1) / lk::SC_UB));
             hipLaunchKernelGGL(lk::score_panel_kernel, grid, dim3(256), 0, st,
                                d_users + ub * ld_users, ld_users, rows, d_items, ld_items,
-                               n_items, KP, panel, ld_s);
+                               n_items, KP, panel, ld_s, (const float *)nullptr,
+                               (unsigned long long *)nullptr, (unsigned *)nullptr, 0);
             if (d_excl_ptr)
                 hipLaunchKernelGGL(lk::score_mask_kernel, dim3((unsigned)rows), dim3(64), 0, st,
                                    d_excl_ptr, d_excl_items, ub, rows, n_items, panel, ld_s);
         }
         if (full) {
-            char *sort_ws = static_cast<char *>(d_ws) +
-                            lk::align_up((size_t)(n_users < lk::score_batch() ? n_users : lk::score_batch()) *
-                                             (size_t)ld_s * sizeof(float), 256) + 256;
-            int rc = lk::topn_sort(panel, ld_s, rows, n_items, out_cols, sort_ws,
-                                   d_out_idx + ub * out_cols,
-                                   d_out_score ? d_out_score + ub * out_cols : nullptr, out_cols,
-                                   st);
-            if (rc != LK_OK) return rc;
-            continue;
+            char *sort_ws = static_cast<char *>(d_ws) + panel_bytes;
+            return lk::topn_sort(panel, ld_s, rows, n_items, out_cols, sort_ws,
+                                 d_out_idx + ub * out_cols,
+                                 d_out_score ? d_out_score + ub * out_cols : nullptr, out_cols, st);
         }
         hipLaunchKernelGGL(lk::row_topn_kernel<lk::TOPN_MAX>, dim3((unsigned)rows), dim3(256), 0,
                            st, panel, ld_s, n_items, n, d_out_idx + ub * n,
                            d_out_score ? d_out_score + ub * n : nullptr, (int64_t)n);
+        return LK_OK;
+    };
+
+    if (!full && lk::use_fused(n_users, n_items, n)) {
+        const lk::FusedLayout L = lk::fused_layout(n_users, n_items, n);
+        char *fw = static_cast<char *>(d_ws) + panel_bytes;
+        float *sub = reinterpret_cast<float *>(fw + L.off_sub);
+        float *tau = reinterpret_cast<float *>(fw + L.off_tau);
+        unsigned *cnt = reinterpret_cast<unsigned *>(fw + L.off_cnt);
+        auto *cand = reinterpret_cast<unsigned long long *>(fw + L.off_cand);
+        int32_t *sidx = reinterpret_cast<int32_t *>(fw + L.off_sidx);
+        float *ssc = reinterpret_cast<float *>(fw + L.off_ssc);
+        int *flags = reinterpret_cast<int *>(fw + L.off_flags);
+        const int64_t n_sub = lk::fused_sub_items(n_items, n);
+        const int64_t ld_sub = lk::padded_items(n_sub);
+        const int64_t batches = (n_users + lk::FUSED_ROWS - 1) / lk::FUSED_ROWS;
+        LK_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(int) * (size_t)batches, st));
+        for (int64_t bi = 0; bi < batches; ++bi) {
+            const int64_t ub = bi * lk::FUSED_ROWS;
+            const int64_t rows = (n_users - ub) < lk::FUSED_ROWS ? (n_users - ub) : lk::FUSED_ROWS;
+            const float *ub_users = d_users + ub * ld_users;
+            const dim3 ugrid_sub((unsigned)((n_sub + lk::SC_IB - 1) / lk::SC_IB),
+                                 (unsigned)((rows + lk::SC_UB - 1) / lk::SC_UB));
+            // stage 1: threshold from the first n_sub items
+            hipLaunchKernelGGL(lk::score_panel_kernel, ugrid_sub, dim3(256), 0, st, ub_users,
+                               ld_users, rows, d_items, ld_items, n_sub, KP, sub, ld_sub,
+                               (const float *)nullptr, (unsigned long long *)nullptr,
+                               (unsigned *)nullptr, 0);
+            if (d_excl_ptr)
+                hipLaunchKernelGGL(lk::score_mask_kernel, dim3((unsigned)rows), dim3(64), 0, st,
+                                   d_excl_ptr, d_excl_items, ub, rows, n_sub, sub, ld_sub);
+            hipLaunchKernelGGL(lk::row_topn_kernel<lk::TOPN_MAX>, dim3((unsigned)rows), dim3(256),
+                               0, st, sub, ld_sub, n_sub, n, sidx, ssc, (int64_t)n);
+            hipLaunchKernelGGL(lk::tau_from_topn_kernel, dim3((unsigned)((rows + 255) / 256)),
+                               dim3(256), 0, st, ssc, (int64_t)n, n, rows, tau, cnt);
+            // stage 2: the full contraction, candidates only
+            // one workgroup per 128 users, walking all item tiles (no global atomics)
+            const dim3 ugrid((unsigned)((rows + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB)));
+            hipLaunchKernelGGL(lk::score_filter_kernel, ugrid, dim3(256), 0, st, ub_users,
+                               ld_users, rows, d_items, ld_items, n_items, KP, (float *)nullptr,
+                               (int64_t)0, tau, cand, cnt, lk::FUSED_CAP);
+            // stage 3: exclusions, exact order
+            hipLaunchKernelGGL(lk::cand_select_kernel<lk::FUSED_CAP>, dim3((unsigned)rows),
+                               dim3(256), 0, st, cand, cnt, d_excl_ptr, d_excl_items, ub, n,
+                               d_out_idx + ub * n, d_out_score ? d_out_score + ub * n : nullptr,
+                               (int64_t)n, flags + bi);
+        }
+        LK_HIP_CHECK(hipGetLastError());
+        // batches with an overflowing row (heavy ties at the threshold, fewer than n candidates in
+        // the sample, ...) are redone through the panel path: same results by construction
+        std::vector<int> h_flags((size_t)batches, 0);
+        LK_HIP_CHECK(hipMemcpyAsync(h_flags.data(), flags, sizeof(int) * (size_t)batches,
+                                    hipMemcpyDeviceToHost, st));
+        LK_HIP_CHECK(hipStreamSynchronize(st));
+        for (int64_t bi = 0; bi < batches; ++bi) {
+            if (!h_flags[(size_t)bi]) continue;
+            const int64_t b0 = bi * lk::FUSED_ROWS;
+            const int64_t bn = (n_users - b0) < lk::FUSED_ROWS ? (n_users - b0) : lk::FUSED_ROWS;
+            for (int64_t ub = b0; ub < b0 + bn; ub += lk::score_batch()) {
+                const int64_t rows = (b0 + bn - ub) < lk::score_batch() ? (b0 + bn - ub)
+                                                                        : lk::score_batch();
+                int rc = run_panel(ub, rows);
+                if (rc != LK_OK) return rc;
+            }
+        }
+        LK_HIP_CHECK(hipGetLastError());
+        return LK_OK;
+    }
+
+    for (int64_t ub = 0; ub < n_users; ub += lk::score_batch()) {
+        const int64_t rows = (n_users - ub) < lk::score_batch() ? (n_users - ub) : lk::score_batch();
+        int rc = run_panel(ub, rows);
+        if (rc != LK_OK) return rc;
     }
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;

@@ -111,3 +111,67 @@ def test_score_topk_cfg1_recommendations(gpu, oracle, ml_small):
         if len(np.unique(s[want])) == 10 and s[want][-1] > np.sort(s[~np.isnan(s)])[-11]:
             assert np.array_equal(idx[u], want), u
         assert np.array_equal(np.sort(s[idx[u]]), np.sort(s[want]))
+
+
+def _oracle_topn(oracle, Q, u, excl, n):
+    s = oracle.score_dense(Q, u)
+    s[excl] = np.nan
+    want = oracle.argsort_descending(s)[:n]  # (score desc, index asc): the kernels' tie rule
+    return s, want
+
+
+@pytest.mark.parametrize("k,n", [(64, 100), (25, 10), (128, 128)])
+def test_score_topk_fused_path(gpu, oracle, rng, k, n, monkeypatch):
+    """
+    The fused scoring + selection path (catalogues >= 16 384 items: stage-1 threshold from an
+    item sample, stage-2 GEMM emitting candidates only, stage-3 exact order) gives the SAME
+    lists as the panel path and as the oracle: exclusion lists in any order and of any length,
+    exact ties across the threshold, rows with fewer than n candidates, rows that overflow the
+    candidate buffer (all scores equal) and fall back.
+    """
+    from lkpy_amd import _device as D
+
+    monkeypatch.setenv("LK_TOPK_FUSED_MIN_USERS", "1")
+    B, I = 200, 20000
+    U = rng.standard_normal((B, k)).astype(np.float32)
+    Q = rng.standard_normal((I, k)).astype(np.float32)
+    Q[rng.random(I) < 0.05] = 0.0
+    Q[5000:5200] = Q[100:300]  # exact score ties between distant items, for every user
+    U[3] = 0.0  # every score 0: all tied -> candidate overflow -> panel fallback for the batch
+    lens = rng.integers(0, 300, B)
+    lens[0] = 0
+    lens[1] = I - 40  # fewer than n candidates remain
+    lens[2] = 15000  # a long list
+    ptr = np.zeros(B + 1, np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    ex = np.concatenate([rng.choice(I, l, replace=False) for l in lens]).astype(np.int32)  # unsorted
+    dU, dQ = D.to_device_padded(U, gpu), D.to_device_padded(Q, gpu)
+    dptr, dex = torch.from_numpy(ptr).to(gpu), torch.from_numpy(ex).to(gpu)
+    idx, sc = D.score_topk(dU, dQ, k, n, dptr, dex)
+    idx, sc = idx.cpu().numpy(), sc.cpu().numpy()
+    for b in list(range(12)) + list(rng.choice(B, 30, replace=False)):
+        s, want = _oracle_topn(oracle, Q, U[b], ex[ptr[b] : ptr[b + 1]], n)
+        m = len(want)
+        assert np.array_equal(idx[b, :m], want), b
+        assert np.all(idx[b, m:] == -1) and np.all(np.isnan(sc[b, m:]))
+        assert np.array_equal(sc[b, :m].view(np.uint32), s[want].view(np.uint32)), b
+    # and the panel path (fused path switched off) agrees on every row, bit for bit
+    monkeypatch.setenv("LK_TOPK_FUSED_MIN_ITEMS", "1000000000")
+    idx2, sc2 = D.score_topk(dU, dQ, k, n, dptr, dex)
+    assert np.array_equal(idx2.cpu().numpy(), idx)
+    assert np.array_equal(sc2.cpu().numpy().view(np.uint32), sc.view(np.uint32))
+
+
+def test_score_topk_fused_no_overflow_rows(gpu, oracle, rng, monkeypatch):
+    "a clean batch (no fallback): scores without exclusions, n = 100"
+    from lkpy_amd import _device as D
+
+    monkeypatch.setenv("LK_TOPK_FUSED_MIN_USERS", "1")
+    B, I, k, n = 70, 33000, 64, 100
+    U = rng.standard_normal((B, k)).astype(np.float32)
+    Q = (rng.standard_normal((I, k)) * rng.random((I, 1))).astype(np.float32)
+    idx, sc = D.score_topk(D.to_device_padded(U, gpu), D.to_device_padded(Q, gpu), k, n)
+    idx, sc = idx.cpu().numpy(), sc.cpu().numpy()
+    for b in range(0, B, 7):
+        s, want = _oracle_topn(oracle, Q, U[b], np.zeros(0, np.int64), n)
+        assert np.array_equal(idx[b], want) and np.array_equal(sc[b], s[want])
