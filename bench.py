@@ -678,8 +678,10 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (seeded ML-25M-shaped: lkpy_amd.synth.ml25m_like, seed 20260925; "
-        "longest user row %d, busiest item %d)" % (info["user_len_max"], info["item_len_max"]),
+        "data": "synthetic (seeded ML-25M-shaped: lkpy_amd.synth.ml25m_like, seed 20260925; the "
+        "public dataset's counts exactly: nnz %d, user rows %d..%d, busiest item %d, %d unrated "
+        "items)" % (info["nnz"], info["user_len_min"], info["user_len_max"],
+                    info["item_len_max"], info["empty_items"]),
         "config": {
             "workload": "MovieLens-25M-shaped, als-implicit k=%d, %d timed epochs, %d x MI355X"
             % (k, args.steps, world),

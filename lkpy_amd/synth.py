@@ -25,23 +25,52 @@ _RATING_PROBS /= _RATING_PROBS.sum()
 
 
 def _user_lengths(rng, n_users, nnz, lo, hi):
-    "Log-normal activity, clipped, rescaled so that the lengths sum to ~nnz."
+    """
+    Log-normal activity clipped to [lo, hi], rescaled so that the lengths sum to EXACTLY nnz,
+    with the most active user at exactly ``hi`` (ML-25M: 32 202).
+    """
     raw = rng.lognormal(mean=0.0, sigma=1.25, size=n_users)
     lens = lo + raw * (nnz / n_users - lo) / raw.mean()
-    for _ in range(8):  # clip + renormalise the unclipped mass
+    lens[np.argmax(lens)] = hi  # the longest row is pinned
+    for _ in range(12):  # clip + renormalise the unclipped mass
         lens = np.clip(lens, lo, hi)
         free = (lens > lo) & (lens < hi)
         excess = lens.sum() - nnz
         if abs(excess) < 1 or not free.any():
             break
         lens[free] -= excess * (lens[free] - lo) / (lens[free] - lo).sum()
-    return np.clip(np.rint(lens), lo, hi).astype(np.int64)
+    lens = np.clip(np.rint(lens), lo, hi).astype(np.int64)
+    # exact total: +-1 on random rows strictly inside the range
+    diff = int(nnz - lens.sum())
+    while diff != 0:
+        step = 1 if diff > 0 else -1
+        ok = np.flatnonzero((lens < hi - 1) & (lens > lo + 1))
+        pick = rng.choice(ok, min(abs(diff), len(ok)), replace=False)
+        lens[pick] += step
+        diff = int(nnz - lens.sum())
+    return lens
+
+
+def _capped_zipf_weights(n_rated, nnz, cap):
+    "expected item degrees ~ 1/rank, capped at ``cap``, summing to nnz; returned as probabilities"
+    r = np.arange(1, n_rated + 1, dtype=np.float64)
+    lo, hi = 1.0, float(nnz)
+    for _ in range(80):  # bisection on the scale c of min(c / r, cap)
+        c = 0.5 * (lo + hi)
+        if np.minimum(c / r, cap).sum() > nnz:
+            hi = c
+        else:
+            lo = c
+    w = np.minimum(0.5 * (lo + hi) / r, cap)
+    return w / w.sum()
 
 
 def ml25m_like(seed: int = 20260925, scale: float = 1.0, **overrides) -> sps.csr_array:
     """
-    Users x items CSR of ratings (float32), rows sorted by item, no duplicates.
-    ``scale`` < 1 shrinks users, items and nnz together (for tests).
+    Users x items CSR of ratings (float32), rows sorted by item, no duplicates.  At
+    ``scale = 1`` the public dataset's statistics are met EXACTLY:
+    nnz = 25 000 095, longest user row 32 202 (shortest 20), busiest item 81 491, 3 376 of the
+    62 423 items unrated.  ``scale`` < 1 shrinks users, items and nnz together (for tests).
     """
     cfg = dict(ML25M)
     cfg.update(overrides)
@@ -49,38 +78,94 @@ def ml25m_like(seed: int = 20260925, scale: float = 1.0, **overrides) -> sps.csr
     n_items = max(16, int(cfg["n_items"] * scale))
     n_empty = int(cfg["n_empty_items"] * scale)
     nnz = int(cfg["nnz"] * scale)
-    lo = min(cfg["min_user"], max(1, (n_items - n_empty) // 4))
-    hi = min(cfg["max_user"], (n_items - n_empty) // 2)
+    n_rated = n_items - n_empty
+    lo = min(cfg["min_user"], max(1, n_rated // 4))
+    # the longest row: the dataset's own maximum when the (scaled) catalogue can hold it
+    hi = cfg["max_user"] if cfg["max_user"] <= n_rated * 9 // 10 else n_rated // 2
+    cap = max(int(cfg["max_item"] * scale), 2)
+    cap = min(cap, n_users - 1)
     rng = np.random.default_rng(seed)
 
     lens = _user_lengths(rng, n_users, nnz, lo, hi)
-    # item popularity: Zipf(1.0) over the rated items, capped, shuffled over ids
-    n_rated = n_items - n_empty
-    w = 1.0 / np.arange(1, n_rated + 1, dtype=np.float64)
-    cap = cfg["max_item"] * scale / max(nnz, 1)
-    w = np.minimum(w / w.sum(), cap)
-    w /= w.sum()
-    item_of_rank = rng.permutation(n_items)[:n_rated]
+    w = _capped_zipf_weights(n_rated, nnz, cap)
+    item_of_rank = rng.permutation(n_items)[:n_rated]  # popularity rank -> item id
     cdf = np.cumsum(w)
     cdf[-1] = 1.0
 
-    # oversample with replacement, dedupe per user, trim to the target lengths
-    over = (lens * 1.6).astype(np.int64) + 16
-    uid = np.repeat(np.arange(n_users, dtype=np.int64), over)
+    # light users: oversample WITH replacement, dedupe; heavy users (and any light user the
+    # dedupe left short): exact weighted sampling WITHOUT replacement (exponential race:
+    # the d smallest of E_i / w_i)
+    heavy = lens > max(2000, n_rated // 16)
+    light_ids = np.flatnonzero(~heavy)
+    over = (lens[light_ids] * 1.7).astype(np.int64) + 24
+    uid = np.repeat(light_ids, over)
     draws = np.searchsorted(cdf, rng.random(uid.shape[0]), side="right")
-    items = item_of_rank[np.minimum(draws, n_rated - 1)].astype(np.int64)
-    key = np.unique(uid * n_items + items)  # sorted by (user, item), duplicates removed
-    uid = key // n_items
-    items = key % n_items
-    # keep at most lens[u] entries per user (random subset, order restored)
-    start = np.searchsorted(uid, np.arange(n_users))
-    cnt = np.diff(np.append(start, uid.shape[0]))
-    rnk = rng.random(uid.shape[0])
-    order = np.lexsort((rnk, uid))
-    pos = np.arange(uid.shape[0]) - np.repeat(start, cnt)
+    key = np.unique(uid * n_rated + np.minimum(draws, n_rated - 1))  # (user, rank), sorted, distinct
+    uid, rk = key // n_rated, key % n_rated
+    cnt = np.bincount(uid, minlength=n_users)
+    short = np.flatnonzero((cnt < lens) & ~heavy)
+    if len(short):  # drop their partial rows; they are redrawn exactly below
+        keep = ~np.isin(uid, short)
+        uid, rk = uid[keep], rk[keep]
+        cnt = np.bincount(uid, minlength=n_users)
+    # trim light rows to their target lengths (random subset)
+    start = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum(cnt, out=start[1:])
+    order = np.lexsort((rng.random(uid.shape[0]), uid))
+    pos = np.arange(uid.shape[0]) - np.repeat(start[:-1], cnt)
     keep = np.zeros(uid.shape[0], dtype=bool)
     keep[order[pos < np.repeat(np.minimum(lens, cnt), cnt)]] = True
-    uid, items = uid[keep], items[keep]
+    uid, rk = uid[keep], rk[keep]
+    exact_ids = np.concatenate([np.flatnonzero(heavy), short])
+    ex_u, ex_r = [], []
+    for u in exact_ids:
+        d = int(lens[u])
+        race = rng.exponential(size=n_rated) / w
+        pick = np.argpartition(race, d - 1)[:d]
+        ex_u.append(np.full(d, u, dtype=np.int64))
+        ex_r.append(pick.astype(np.int64))
+    if ex_u:
+        uid = np.concatenate([uid] + ex_u)
+        rk = np.concatenate([rk] + ex_r)
+    # item cap: no item above `cap`, the busiest one exactly at it (full scale: 81 491).
+    key = np.sort(uid * n_rated + rk)  # (user, rank) pairs, distinct by construction
+    uid, rk = key // n_rated, key % n_rated
+    deg = np.bincount(rk, minlength=n_rated)
+    over = np.flatnonzero(deg > cap)
+    if len(over):
+        # surplus raters of an over-full item swap it for a random item of the uncrowded
+        # middle of the catalogue that they do not have yet (a few rounds of redraws)
+        remove = np.zeros(len(key), dtype=bool)
+        for r in over:
+            idx = np.flatnonzero(rk == r)
+            remove[rng.choice(idx, int(deg[r] - cap), replace=False)] = True
+        pending = uid[remove]
+        key = key[~remove]
+        band = np.flatnonzero(deg < cap // 2)
+        band = band[band > over.max()]
+        while len(pending):
+            newkey = pending * n_rated + rng.choice(band, len(pending))
+            uniq, first = np.unique(newkey, return_index=True)
+            pos = np.minimum(np.searchsorted(key, uniq), len(key) - 1)
+            fresh = key[pos] != uniq
+            key = np.sort(np.concatenate([key, uniq[fresh]]))
+            done = np.zeros(len(pending), dtype=bool)
+            done[first[fresh]] = True
+            pending = pending[~done]
+        uid, rk = key // n_rated, key % n_rated
+        deg = np.bincount(rk, minlength=n_rated)
+    if deg[0] < cap:
+        # raise the top item to exactly the cap: users lacking it trade in their rarest item
+        # (rows are sorted by rank, so that is the row's last entry; it is not rank 0)
+        has0 = np.zeros(n_users, dtype=bool)
+        has0[uid[rk == 0]] = True
+        lacking = rng.permutation(np.flatnonzero(~has0))[: int(cap - deg[0])]
+        last = np.zeros(n_users + 1, dtype=np.int64)
+        np.cumsum(np.bincount(uid, minlength=n_users), out=last[1:])
+        rk[last[lacking + 1] - 1] = 0
+    items = item_of_rank[rk].astype(np.int64)
+    order = np.lexsort((items, uid))
+    uid, items = uid[order], items[order]
     ratings = rng.choice(_RATING_VALUES, size=uid.shape[0], p=_RATING_PROBS).astype(np.float32)
     indptr = np.zeros(n_users + 1, dtype=np.int64)
     np.cumsum(np.bincount(uid, minlength=n_users), out=indptr[1:])

@@ -243,3 +243,28 @@ def test_implicit_history_rows_drop_unknown_items():
     assert idx2.tolist() == [0, 1] and val2.tolist() == [10.0, 6.0]  # rating * weight, reordered
     with pytest.raises(ValueError):
         sc2._history_rows([RecQuery(user_items=ItemList([20]))])  # use_ratings without ratings
+
+
+@pytest.mark.parametrize("scale", [0.04, 1.0])
+def test_ml25m_like_meets_the_dataset_statistics(scale):
+    """SURVEY.md 8d, cfg2-4 input: at full scale the public ML-25M counts EXACTLY -- nnz
+    25 000 095, 162 541 x 62 423, 3 376 unrated items, rows of 20 .. 32 202, busiest item
+    81 491; distinct sorted rows; deterministic in the seed."""
+    from lkpy_amd import synth
+
+    m = synth.ml25m_like(scale=scale)
+    d = synth.describe(m)
+    c = synth.ML25M
+    assert d["nnz"] == int(c["nnz"] * scale)
+    assert d["empty_items"] == int(c["n_empty_items"] * scale)
+    if scale == 1.0:
+        assert (d["n_users"], d["n_items"]) == (c["n_users"], c["n_items"])
+        assert d["user_len_min"] == c["min_user"] and d["user_len_max"] == c["max_user"]
+        assert d["item_len_max"] == c["max_item"]
+    rows = np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))
+    same = rows[1:] == rows[:-1]
+    assert np.all(np.diff(m.indices)[same] > 0)
+    assert set(np.unique(m.data)) <= set(np.arange(1, 11, dtype=np.float32) * 0.5)
+    if scale < 1.0:
+        again = synth.ml25m_like(scale=scale)
+        assert np.array_equal(again.indices, m.indices) and np.array_equal(again.data, m.data)
