@@ -305,6 +305,34 @@ int lk_iknn_score_batch(const int64_t *d_sim_indptr, const int32_t *d_sim_indice
                         const int32_t *d_tgt_items, int32_t max_nbrs, int32_t min_nbrs,
                         void *d_ws, float *d_out_scores, int32_t *d_out_counts, void *stream);
 
+/* ------------------------------------------------------------------------
+ * User-kNN scoring for a BATCH of queries.
+ * Replaces `_accel.knn.user_score_items_explicit / _implicit(tgt_items, nbr_rows, nbr_sims,
+ * ratings, max_nbrs, min_nbrs)` (src/accel/knn/user_score.rs:21-98): query q has neighbours
+ * nbr_rows[nbr_ptr[q]..nbr_ptr[q+1]) (rows of the users x items ratings CSR, int64 offsets)
+ * with similarities nbr_sims; every neighbour, in the given order, offers (weight = its
+ * similarity, value = its rating) to the items it rated; per target item the `max_nbrs`
+ * largest weights are kept (same ScoreAccumulator as item-kNN, accum.rs:16-239) and
+ * score = sum(w * v) / sum(w)  (explicit)  or  sum(w)  (d_rat_values NULL: implicit);
+ * fewer than min_nbrs contributors => NaN.  Negative neighbour rows / target items are nulls.
+ * Workspace: lk_iknn_score_workspace_bytes(n_items, n_queries, max_nbrs).  Blocking.
+ * ---------------------------------------------------------------------- */
+int lk_uknn_score_batch(const int64_t *d_rat_indptr, const int32_t *d_rat_indices,
+                        const float *d_rat_values, int64_t n_users, int64_t n_items,
+                        int64_t n_queries, const int64_t *d_nbr_ptr, const int32_t *d_nbr_rows,
+                        const float *d_nbr_sims, const int64_t *d_tgt_ptr,
+                        const int32_t *d_tgt_items, int32_t max_nbrs, int32_t min_nbrs, void *d_ws,
+                        float *d_out_scores, int32_t *d_out_counts, void *stream);
+
+/* Neighbour similarities of user-kNN, `nbr_sims = user_vectors @ ratings`
+ * (src/lenskit/knn/user.py:196) for a batch of dense query vectors:
+ *   out[q][r] = sum over the entries (c, v) of CSR row r of  v * x[c][q]
+ * x is [n_cols x ld_x] (column-major over queries: the queries' values of one item are
+ * contiguous), out is [n_queries x ld_out].  Products accumulate in entry order (fmaf). */
+int lk_csr_rows_dot(const void *d_indptr, int indptr_is_64, const int32_t *d_indices,
+                    const float *d_values, int64_t n_rows, const float *d_x, int64_t ld_x,
+                    int64_t n_queries, float *d_out, int64_t ld_out, void *stream);
+
 /* Batched fold-in (new-user embeddings) -- `ImplicitMFScorer.new_user_embedding` /
  * `_train_new_row` (src/lenskit/als/_implicit.py:77-130) -- is the SAME algebra as one ALS
  * row with OtOr = Q^T Q + user_reg I: build a plan over the histories' CSR offsets and call

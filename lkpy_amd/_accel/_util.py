@@ -26,8 +26,8 @@ def nullable_i32(a) -> np.ndarray:
             raise TypeError(f"invalid item array type {a.type}, expected Int32")
         if a.null_count:
             a = a.fill_null(-1)
-        return np.ascontiguousarray(a.to_numpy(zero_copy_only=False), dtype=np.int32)
-    return np.ascontiguousarray(a, dtype=np.int32)
+        return np.array(a.to_numpy(zero_copy_only=False), dtype=np.int32)  # writable copy
+    return np.array(a, dtype=np.int32)
 
 
 def f32_with_nulls(values: np.ndarray) -> pa.FloatArray:

@@ -99,3 +99,45 @@ def score_explicit(sims, ref_items, ref_rates, tgt_items, max_nbrs: int, min_nbr
 def score_implicit(sims, ref_items, tgt_items, max_nbrs: int, min_nbrs: int):
     "-> (pa.FloatArray, pa.Int32Array) -- item_score.rs:72-111."
     return _score(sims, ref_items, None, tgt_items, max_nbrs, min_nbrs)
+
+
+def _user_score(tgt_items, nbr_rows, nbr_sims, ratings, max_nbrs, min_nbrs, explicit: bool):
+    ro, ridx, rval, rshape = as_csr_arrays(ratings)
+    if explicit and rval is None:
+        raise TypeError("invalid ratings matrix: no values")  # CSRMatrix::from_arrow
+    dev = D.device()
+    drat = D.DeviceCSR(torch.from_numpy(np.array(ro, dtype=np.int64)).to(dev),
+                       torch.from_numpy(np.array(ridx, dtype=np.int32)).to(dev),
+                       torch.from_numpy(np.array(rval, dtype=np.float32)).to(dev)
+                       if explicit else None, rshape, None)
+    ti = nullable_i32(tgt_items)
+    # null neighbours (either array) are skipped: user_score.rs:41-44,80-83
+    nr = nullable_i32(nbr_rows)
+    if isinstance(nbr_sims, (pa.Array, pa.ChunkedArray)):
+        if isinstance(nbr_sims, pa.ChunkedArray):
+            nbr_sims = nbr_sims.combine_chunks()
+        if not pa.types.is_floating(nbr_sims.type):
+            raise TypeError(f"invalid neighbor sims type {nbr_sims.type}, expected float32")
+        null = nbr_sims.is_null().to_numpy(zero_copy_only=False) if nbr_sims.null_count else None
+        ns = np.array(nbr_sims.fill_null(0).to_numpy(zero_copy_only=False), dtype=np.float32)
+        if null is not None:
+            nr = np.where(null, -1, nr).astype(np.int32)
+    else:
+        ns = np.ascontiguousarray(nbr_sims, dtype=np.float32)
+    one = lambda n: torch.tensor([0, n], dtype=torch.int64, device=dev)  # noqa: E731
+    s, _c = D.uknn_score_batch(drat, one(len(nr)), torch.from_numpy(nr).to(dev),
+                               torch.from_numpy(ns).to(dev), one(len(ti)),
+                               torch.from_numpy(ti).to(dev), max_nbrs, min_nbrs)
+    return f32_with_nulls(s.cpu().numpy())
+
+
+def user_score_items_explicit(tgt_items, nbr_rows, nbr_sims, ratings, max_nbrs: int,
+                              min_nbrs: int):
+    "-> pa.FloatArray with nulls -- src/accel/knn/user_score.rs:21-58."
+    return _user_score(tgt_items, nbr_rows, nbr_sims, ratings, max_nbrs, min_nbrs, True)
+
+
+def user_score_items_implicit(tgt_items, nbr_rows, nbr_sims, ratings, max_nbrs: int,
+                              min_nbrs: int):
+    "-> pa.FloatArray with nulls -- src/accel/knn/user_score.rs:60-98 (structure-only ratings)."
+    return _user_score(tgt_items, nbr_rows, nbr_sims, ratings, max_nbrs, min_nbrs, False)

@@ -443,6 +443,52 @@ def iknn_score_batch(sims: DeviceCSR, ref_ptr, ref_items, ref_rates, tgt_ptr, tg
     return out_s, out_c
 
 
+def uknn_score_batch(ratings: DeviceCSR, nbr_ptr, nbr_rows, nbr_sims, tgt_ptr, tgt_items,
+                     max_nbrs: int, min_nbrs: int):
+    """
+    User-kNN scoring of a batch of queries (lk_uknn_score_batch; src/accel/knn/user_score.rs):
+    ``ratings`` users x items CSR (int64 offsets; ``values`` None = implicit feedback),
+    neighbours / targets as CSR-style (int64 offsets) lists.  Returns (scores, counts).
+    """
+    lib = _native.require_gpu()
+    n_users, n_items = ratings.shape
+    nq = int(nbr_ptr.shape[0]) - 1
+    dev = ratings.indices.device
+    assert ratings.indptr.dtype == torch.int64
+    ws = torch.empty(lib.lk_iknn_score_workspace_bytes(n_items, nq, int(max_nbrs)),
+                     dtype=torch.uint8, device=dev)
+    out_s = torch.empty(int(tgt_items.shape[0]), dtype=torch.float32, device=dev)
+    out_c = torch.empty(int(tgt_items.shape[0]), dtype=torch.int32, device=dev)
+    check(
+        lib.lk_uknn_score_batch(
+            _ptr(ratings.indptr), _ptr(ratings.indices), _ptr(ratings.values), n_users, n_items,
+            nq, _ptr(nbr_ptr), _ptr(nbr_rows), _ptr(nbr_sims), _ptr(tgt_ptr), _ptr(tgt_items),
+            int(max_nbrs), int(min_nbrs), _ptr(ws), _ptr(out_s), _ptr(out_c), _stream()
+        ),
+        "lk_uknn_score_batch",
+    )  # fmt: skip
+    return out_s, out_c
+
+
+def csr_rows_dot(csr: DeviceCSR, x: torch.Tensor) -> torch.Tensor:
+    """
+    ``out[q][r] = <row r of csr, x[:, q]>`` for the dense columns of ``x`` ([n_cols x B],
+    row-major) -- the neighbour similarities of user-kNN (lk_csr_rows_dot).  Returns [B x rows].
+    """
+    lib = _native.require_gpu()
+    n_rows, n_cols = csr.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[0] == n_cols
+    B = int(x.shape[1])
+    out = torch.empty((B, n_rows), dtype=torch.float32, device=x.device)
+    check(
+        lib.lk_csr_rows_dot(_ptr(csr.indptr), 1 if csr.is64 else 0, _ptr(csr.indices),
+                            _ptr(csr.values), n_rows, _ptr(x), B, B, _ptr(out), n_rows,
+                            _stream()),
+        "lk_csr_rows_dot",
+    )
+    return out
+
+
 def score_dense(users: torch.Tensor, items: torch.Tensor, k: int) -> torch.Tensor:
     "All (user, item) scores, [B x I] f32 (lk_score_dense)."
     lib = _native.require_gpu()

@@ -40,9 +40,15 @@ __host__ __device__ inline size_t ks_slab_bytes(int64_t n_items, int max_nbrs)
     return (per + 255) / 256 * 256;
 }
 
+// SWAP = false: item-kNN (matrix = similarities, entry value = weight, the reference row's
+// rating = value).  SWAP = true: user-kNN (`user_score_items_*`,
+// src/accel/knn/user_score.rs:21-98): matrix = the users' ratings, the reference rows are the
+// neighbours, their similarity (ref_rates) = weight, the entry value (rating; none for
+// implicit feedback: s_val null) = value.  `n_rows` = rows of the matrix, `n_items` = columns.
+template <bool SWAP>
 __global__ __launch_bounds__(KS_THREADS) void iknn_score_kernel(
     const int64_t *__restrict__ s_ptr, const int32_t *__restrict__ s_idx,
-    const float *__restrict__ s_val, int64_t n_items, int64_t n_queries,
+    const float *__restrict__ s_val, int64_t n_rows, int64_t n_items, int64_t n_queries,
     const int64_t *__restrict__ ref_ptr, const int32_t *__restrict__ ref_items,
     const float *__restrict__ ref_rates, const int64_t *__restrict__ tgt_ptr,
     const int32_t *__restrict__ tgt_items, int max_nbrs, int min_nbrs, char *__restrict__ ws,
@@ -55,7 +61,7 @@ __global__ __launch_bounds__(KS_THREADS) void iknn_score_kernel(
     float *slot_s = reinterpret_cast<float *>(slab + (size_t)n_items * 8);
     float *slot_v = slot_s + (size_t)n_items * max_nbrs;
     const int tid = threadIdx.x;
-    const bool explicit_ = ref_rates != nullptr;
+    const bool explicit_ = SWAP ? (s_val != nullptr) : (ref_rates != nullptr);
 
     for (int64_t q = blockIdx.x; q < n_queries; q += gridDim.x) {
         const int64_t rb = ref_ptr[q], re = ref_ptr[q + 1];
@@ -71,14 +77,16 @@ __global__ __launch_bounds__(KS_THREADS) void iknn_score_kernel(
         // scatter the history rows, one reference item at a time, in history order
         for (int64_t r = rb; r < re; ++r) {
             const int ri = ref_items[r];
-            if (ri < 0 || ri >= n_items) continue;  // wave-uniform: null reference item
-            const float rv = explicit_ ? ref_rates[r] : 0.f;
+            if (ri < 0 || ri >= n_rows) continue;  // wave-uniform: null reference row
+            const float rscalar = (SWAP || explicit_) ? ref_rates[r] : 0.f;
             const int64_t sb = s_ptr[ri], se = s_ptr[ri + 1];
             for (int64_t e = sb + tid; e < se; e += KS_THREADS) {
                 const int t = s_idx[e];
                 const int c = cnt[t];
                 if (c < 0) continue;
-                const float s = s_val[e];
+                // (weight, value) of this contribution
+                const float s = SWAP ? rscalar : s_val[e];
+                const float rv = SWAP ? (explicit_ ? s_val[e] : 0.f) : rscalar;
                 if (s != s) {
                     atomicCAS(status, 0, 1);
                     continue;
@@ -166,8 +174,9 @@ extern "C" int lk_iknn_score_batch(const int64_t *d_sim_indptr, const int32_t *d
     int *status = reinterpret_cast<int *>(ws);
     LK_HIP_CHECK(hipMemsetAsync(status, 0, 256, st));
     int64_t wgs = n_queries < lk::KS_MAX_WGS ? n_queries : lk::KS_MAX_WGS;
-    hipLaunchKernelGGL(lk::iknn_score_kernel, dim3((unsigned)wgs), dim3(lk::KS_THREADS), 0, st,
-                       d_sim_indptr, d_sim_indices, d_sim_values, n_items, n_queries, d_ref_ptr,
+    hipLaunchKernelGGL(lk::iknn_score_kernel<false>, dim3((unsigned)wgs), dim3(lk::KS_THREADS), 0,
+                       st, d_sim_indptr, d_sim_indices, d_sim_values, n_items, n_items, n_queries,
+                       d_ref_ptr,
                        d_ref_items, d_ref_rates, d_tgt_ptr, d_tgt_items, max_nbrs, min_nbrs,
                        ws + 256, lk::ks_slab_bytes(n_items, max_nbrs), d_out_scores, d_out_counts,
                        status);
@@ -179,5 +188,99 @@ extern "C" int lk_iknn_score_batch(const int64_t *d_sim_indptr, const int32_t *d
         lk::set_error("similarity is null");
         return LK_E_NAN_SIM;
     }
+    return LK_OK;
+}
+
+extern "C" int lk_uknn_score_batch(const int64_t *d_rat_indptr, const int32_t *d_rat_indices,
+                                   const float *d_rat_values, int64_t n_users, int64_t n_items,
+                                   int64_t n_queries, const int64_t *d_nbr_ptr,
+                                   const int32_t *d_nbr_rows, const float *d_nbr_sims,
+                                   const int64_t *d_tgt_ptr, const int32_t *d_tgt_items,
+                                   int32_t max_nbrs, int32_t min_nbrs, void *d_ws,
+                                   float *d_out_scores, int32_t *d_out_counts, void *stream)
+{
+    LK_REQUIRE(max_nbrs >= 1 && min_nbrs >= 1, "lk_uknn_score_batch: max_nbrs/min_nbrs must be >= 1");
+    LK_REQUIRE(n_users >= 0 && n_items >= 0 && n_queries >= 0, "lk_uknn_score_batch: negative size");
+    if (n_queries == 0) return LK_OK;
+    LK_REQUIRE(d_rat_indptr && d_nbr_ptr && d_tgt_ptr && d_ws && d_out_scores && d_out_counts,
+               "lk_uknn_score_batch: null pointer");
+    hipStream_t st = lk::as_stream(stream);
+    char *ws = static_cast<char *>(d_ws);
+    int *status = reinterpret_cast<int *>(ws);
+    LK_HIP_CHECK(hipMemsetAsync(status, 0, 256, st));
+    int64_t wgs = n_queries < lk::KS_MAX_WGS ? n_queries : lk::KS_MAX_WGS;
+    hipLaunchKernelGGL(lk::iknn_score_kernel<true>, dim3((unsigned)wgs), dim3(lk::KS_THREADS), 0,
+                       st, d_rat_indptr, d_rat_indices, d_rat_values, n_users, n_items, n_queries,
+                       d_nbr_ptr, d_nbr_rows, d_nbr_sims, d_tgt_ptr, d_tgt_items, max_nbrs,
+                       min_nbrs, ws + 256, lk::ks_slab_bytes(n_items, max_nbrs), d_out_scores,
+                       d_out_counts, status);
+    LK_HIP_CHECK(hipGetLastError());
+    int h = 0;
+    LK_HIP_CHECK(hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, st));
+    LK_HIP_CHECK(hipStreamSynchronize(st));
+    if (h != 0) {
+        lk::set_error("similarity is null");
+        return LK_E_NAN_SIM;
+    }
+    return LK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Neighbour similarities of user-kNN: sims[q][u] = <user_vectors[u], x_q> for a batch of dense
+// query vectors (`nbr_sims = self.user_vectors @ ratings`, src/lenskit/knn/user.py:196): one
+// wave per matrix row, lane = query (blocks of 64 queries), the row's entries broadcast.
+// x is [n_items x ld_x] (item-major: the queries of one item are contiguous).
+// ---------------------------------------------------------------------------
+namespace lk {
+template <bool IS64>
+__global__ __launch_bounds__(256) void csr_rows_dot_kernel(
+    const typename IndPtr<IS64>::type *__restrict__ ptr, const int32_t *__restrict__ idx,
+    const float *__restrict__ val, int64_t n_rows, const float *__restrict__ x, int64_t ld_x,
+    int64_t n_queries, float *__restrict__ out, int64_t ld_out)
+{
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t b = ptr[row], e = ptr[row + 1];
+    for (int64_t q0 = 0; q0 < n_queries; q0 += 64) {
+        const int64_t q = q0 + lane;
+        float acc = 0.f;
+        for (int64_t base = b; base < e; base += 64) {
+            // 64 entries of the row per coalesced load, then broadcast one by one
+            const int64_t me = base + lane;
+            const int it = me < e ? idx[me] : 0;
+            const float v = me < e ? val[me] : 0.f;
+            const int n = (e - base) < 64 ? (int)(e - base) : 64;
+            for (int j = 0; j < n; ++j) {
+                const int itj = __shfl(it, j, 64);
+                const float vj = __shfl(v, j, 64);
+                if (q < n_queries) acc = fmaf(vj, x[(int64_t)itj * ld_x + q], acc);
+            }
+        }
+        if (q < n_queries) out[q * ld_out + row] = acc;
+    }
+}
+}  // namespace lk
+
+extern "C" int lk_csr_rows_dot(const void *d_indptr, int indptr_is_64, const int32_t *d_indices,
+                               const float *d_values, int64_t n_rows, const float *d_x,
+                               int64_t ld_x, int64_t n_queries, float *d_out, int64_t ld_out,
+                               void *stream)
+{
+    LK_REQUIRE(n_rows >= 0 && n_queries >= 0 && ld_x >= n_queries && ld_out >= n_rows,
+               "lk_csr_rows_dot: bad shape");
+    if (n_rows == 0 || n_queries == 0) return LK_OK;
+    LK_REQUIRE(d_indptr && d_x && d_out, "lk_csr_rows_dot: null pointer");
+    hipStream_t st = lk::as_stream(stream);
+    const dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
+    if (indptr_is_64)
+        hipLaunchKernelGGL(lk::csr_rows_dot_kernel<true>, grid, block, 0, st,
+                           static_cast<const int64_t *>(d_indptr), d_indices, d_values, n_rows,
+                           d_x, ld_x, n_queries, d_out, ld_out);
+    else
+        hipLaunchKernelGGL(lk::csr_rows_dot_kernel<false>, grid, block, 0, st,
+                           static_cast<const int32_t *>(d_indptr), d_indices, d_values, n_rows,
+                           d_x, ld_x, n_queries, d_out, ld_out);
+    LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }

@@ -1,5 +1,8 @@
 """
-Component seam for item-based k-NN: mirror of ``lenskit.knn.ItemKNNScorer`` /
+Component seam for neighbourhood models -- item-based k-NN and user-based
+k-NN (end of the file, mirror of ``lenskit.knn.UserKNNScorer``, src/lenskit/knn/user.py:25-316).
+
+Item-based k-NN: mirror of ``lenskit.knn.ItemKNNScorer`` /
 ``ItemKNNConfig`` (src/lenskit/knn/item.py:41-295).  Matrix preparation is the reference's
 own SciPy code path (item-mean centring, L2 normalisation); the similarity build and the
 scoring run in the HIP kernels.
@@ -11,6 +14,7 @@ import warnings
 from typing import Literal
 
 import numpy as np
+import scipy.sparse as sps
 import torch
 from pydantic import AliasChoices, BaseModel, Field, PositiveFloat, PositiveInt, field_validator
 
@@ -149,6 +153,182 @@ class ItemKNNScorer(Component):
                 sc[m] += self.item_means[ti[m]]  # item.py:282
             out.append(ItemList(items, scores=sc, nbr_counts=c[t_ptr[qi]:t_ptr[qi + 1]]))
         return out
+
+    def __call__(self, query, items: ItemList) -> ItemList:
+        return self.score_batch([query], [items])[0]
+
+
+# ---------------------------------------------------------------------------------------
+# User-based k-NN
+# ---------------------------------------------------------------------------------------
+
+
+class UserKNNConfig(BaseModel, extra="forbid"):
+    "src/lenskit/knn/user.py:39-71"
+
+    max_nbrs: PositiveInt = Field(20, validation_alias=AliasChoices("max_nbrs", "nnbrs", "k"))
+    min_nbrs: PositiveInt = 1
+    min_sim: PositiveFloat = 1.0e-6
+    feedback: Literal["explicit", "implicit"] = "explicit"
+
+    @field_validator("min_sim", mode="after")
+    @staticmethod
+    def clamp_min_sim(sim) -> float:
+        return max(sim, float(np.finfo(np.float64).smallest_normal))
+
+    @property
+    def explicit(self) -> bool:
+        return self.feedback == "explicit"
+
+
+class UserKNNScorer(Component):
+    """
+    User-user nearest-neighbour collaborative filtering (``UserKNNScorer``,
+    src/lenskit/knn/user.py:74-316).  "Training" memorises the mean-centred and the
+    row-normalised rating matrices with the reference's own SciPy calls; scoring runs on the
+    device for whole batches of queries: neighbour similarities = normalised matrix x query
+    vector (``lk_csr_rows_dot``), neighbours with sim >= min_sim in ascending user order,
+    per-item accumulation of the ``max_nbrs`` most similar raters (``lk_uknn_score_batch``).
+    """
+
+    config: UserKNNConfig
+
+    users: Vocabulary
+    items: Vocabulary
+    user_means: np.ndarray | None
+    user_vectors: sps.csr_array
+    user_ratings: SparseRowArray
+
+    def is_trained(self):
+        return hasattr(self, "user_ratings")
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.pop("_dev", None)
+        return st
+
+    def train(self, data: Dataset, options: TrainingOptions = TrainingOptions()):
+        "user.py:122-168: centre by user mean (explicit), normalise rows, keep both matrices"
+        import scipy.sparse.linalg as spla
+
+        rmat = data.interactions().matrix().scipy(
+            attribute="rating" if self.config.explicit else None).astype(np.float32)
+        means = None
+        if self.config.explicit:
+            counts = np.diff(rmat.indptr)
+            sums = rmat.sum(axis=1)
+            means = np.zeros(sums.shape, dtype=np.float32)
+            np.divide(sums, counts, out=means, where=counts > 0)
+            rmat.data = rmat.data - np.repeat(means, counts)
+            if np.allclose(rmat.data, 0.0):
+                warnings.warn("Ratings seem to have the same value, centering is not "
+                              "recommended.", DataWarning)
+        norms = spla.norm(rmat, 2, axis=1)
+        cmat = rmat / np.maximum(norms, np.finfo("f4").smallest_normal).reshape(-1, 1)
+        self.user_vectors = sps.csr_array(cmat.tocsr())
+        self.user_ratings = SparseRowArray.from_scipy(rmat, values=self.config.explicit)
+        self.users = data.users
+        self.user_means = means
+        self.items = data.items
+        self.__dict__.pop("_dev", None)
+
+    def _device_state(self):
+        st = getattr(self, "_dev", None)
+        if st is None:
+            from .matrix import csr_arrays
+
+            d = D.device()
+            uv = self.user_vectors
+            uv.sort_indices()
+            ro, ri, rv, shape = csr_arrays(self.user_ratings)
+            st = {
+                "device": d,
+                "vectors": D.DeviceCSR.from_arrays(uv.indptr, uv.indices, uv.data, uv.shape, d),
+                "ratings": D.DeviceCSR(
+                    torch.from_numpy(np.array(ro, dtype=np.int64)).to(d),
+                    torch.from_numpy(np.array(ri, dtype=np.int32)).to(d),
+                    None if rv is None else torch.from_numpy(np.array(rv, np.float32)).to(d),
+                    shape, None),
+            }
+            self._dev = st
+        return st
+
+    def _user_data(self, query: RecQuery):
+        "``_get_user_data`` (user.py:264-307): (user number | None, dense item vector, mean)"
+        index = self.users.number(query.user_id, missing=None) \
+            if query.user_id is not None else None
+        hist = query.query_items
+        n_items = len(self.items)
+        if hist is None:
+            if index is None:
+                return None
+            uv = self.user_vectors
+            row = np.zeros(n_items, dtype=np.float32)
+            s, e = uv.indptr[index], uv.indptr[index + 1]
+            row[uv.indices[s:e]] = uv.data[s:e]
+            umean = float(self.user_means[index]) if self.config.explicit else 0.0
+            return index, row, umean
+        if len(hist) == 0:
+            return None
+        ratings = np.zeros(n_items, dtype=np.float32)
+        nos = hist.numbers(missing="negative", vocabulary=self.items)
+        ok = nos >= 0
+        if self.config.explicit:
+            urv = hist.field("rating")
+            if urv is None:
+                return None
+            urv = np.require(urv, dtype=np.float32)
+            umean = float(urv.mean())
+            ratings[nos[ok]] = urv[ok] - umean
+        else:
+            umean = 0.0
+            ratings[nos[ok]] = 1.0
+        return index, ratings, umean
+
+    def score_batch(self, queries, item_lists) -> list[ItemList]:
+        "Many (query, items) pairs through two kernel launches (user.py:171-262 per pair)."
+        st = self._device_state()
+        d = st["device"]
+        queries = [RecQuery.create(q) for q in queries]
+        data = [self._user_data(q) if len(il) > 0 else None
+                for q, il in zip(queries, item_lists)]
+        live = [i for i, u in enumerate(data) if u is not None]
+        out: list[ItemList | None] = [None] * len(queries)
+        for i, il in enumerate(item_lists):
+            if data[i] is None:
+                out[i] = ItemList(il, scores=np.nan)
+        if not live:
+            return out  # type: ignore[return-value]
+        # neighbour similarities for the whole batch: [B x users]
+        X = np.stack([data[i][1] for i in live], axis=1)  # [items x B]
+        sims = D.csr_rows_dot(st["vectors"], torch.from_numpy(np.ascontiguousarray(X)).to(d))
+        for b, i in enumerate(live):
+            if data[i][0] is not None:
+                sims[b, data[i][0]] = 0.0  # zero out the self-similarity (user.py:199-201)
+        mask = sims >= float(np.float32(self.config.min_sim))  # user.py:206 (f32 comparison)
+        counts = mask.sum(dim=1)
+        nbr_ptr = torch.zeros(len(live) + 1, dtype=torch.int64, device=d)
+        nbr_ptr[1:] = torch.cumsum(counts, 0)
+        nbr_rows = mask.nonzero()[:, 1].to(torch.int32)  # per query, ascending user number
+        nbr_sims = sims[mask]
+        t_idx, t_ptr = [], [0]
+        for i in live:
+            ti = item_lists[i].numbers(vocabulary=self.items, missing="negative")
+            t_idx.append(ti)
+            t_ptr.append(t_ptr[-1] + len(ti))
+        tgt = torch.from_numpy(np.concatenate(t_idx).astype(np.int32)).to(d)
+        s, _c = D.uknn_score_batch(st["ratings"], nbr_ptr, nbr_rows.contiguous(),
+                                   nbr_sims.contiguous(),
+                                   torch.from_numpy(np.asarray(t_ptr, np.int64)).to(d), tgt,
+                                   self.config.max_nbrs, self.config.min_nbrs)
+        s = s.cpu().numpy()
+        has_nbrs = counts.cpu().numpy() > 0
+        for b, i in enumerate(live):
+            sc = s[t_ptr[b]:t_ptr[b + 1]].copy()
+            if not has_nbrs[b]:
+                sc[:] = np.nan  # no candidate neighbours (user.py:217-219)
+            out[i] = ItemList(item_lists[i], scores=sc + np.float32(data[i][2]))
+        return out  # type: ignore[return-value]
 
     def __call__(self, query, items: ItemList) -> ItemList:
         return self.score_batch([query], [items])[0]

@@ -353,3 +353,49 @@ def csr_arrays(matrix: Any):
         idx = idx[base:end]
         vals = None if vals is None else vals[base:end]
     return off, idx, vals, (n, sra.dimension)
+
+
+def fast_col_cooc(rows, cols, shape, *, progress=None, include_diagonal: bool = True,
+                  ordered: bool = False, dense: bool = False):
+    """
+    Column co-occurrence counts ``M^T M`` of a binary matrix given as COO coordinates --
+    ``lenskit.data.matrix.fast_col_cooc`` (src/lenskit/data/matrix.py:599-646) over
+    ``_accel.data.count_cooc`` / ``dense_cooc`` (src/accel/data/cooc.rs:47-192, symmetric pair
+    counter src/accel/data/pairs/symmetric.rs).  On the device this IS the item-item
+    accumulation of the similarity build with unit values: every shared group adds 1.0f to the
+    pair's cell (exact integers up to 2^24), cells >= 0.5 are kept; the diagonal (the column
+    counts) is added on request.  Returns a ``coo_array`` of int32 counts (both triangles), or a
+    dense int32 array with ``dense=True``.  ``ordered=True`` (position-ordered pair counts
+    inside a group) is not part of the similarity path and is not offered.
+    """
+    import torch  # noqa: F401
+
+    from . import _device as D
+
+    if ordered:
+        raise NotImplementedError("ordered co-occurrence counts are not offered by the device "
+                                  "path (only the symmetric M^T M form)")
+    m, n = shape
+    rows = np.asarray(rows if not isinstance(rows, pa.Array) else rows.to_numpy(), dtype=np.int32)
+    cols = np.asarray(cols if not isinstance(cols, pa.Array) else cols.to_numpy(), dtype=np.int32)
+    if len(rows) != len(cols):
+        raise ValueError("array length mismatch")  # cooc.rs:60-62
+    ones = np.ones(len(rows), dtype=np.float32)
+    ui = sps.csr_array((ones, (rows, cols)), shape=(m, n))
+    ui.sum_duplicates()
+    ui.data[:] = 1.0  # a binary matrix: an (group, item) pair counts once
+    ui.sort_indices()
+    iu = sps.csr_array(ui.T)
+    iu.sort_indices()
+    dev = D.device()
+    out = D.iknn_build(D.DeviceCSR.from_scipy(ui, dev), D.DeviceCSR.from_scipy(iu, dev), 0.5)
+    ptr = out.indptr.cpu().numpy()
+    r = np.repeat(np.arange(n, dtype=np.int32), np.diff(ptr))
+    c = out.indices.cpu().numpy()
+    v = np.rint(out.values.cpu().numpy()).astype(np.int32)
+    if include_diagonal:
+        cnt = np.diff(iu.indptr).astype(np.int32)
+        nz = np.flatnonzero(cnt).astype(np.int32)
+        r, c, v = np.concatenate([r, nz]), np.concatenate([c, nz]), np.concatenate([v, cnt[nz]])
+    res = sps.coo_array((v, (r, c)), shape=(n, n))
+    return res.toarray() if dense else res

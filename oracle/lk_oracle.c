@@ -800,6 +800,67 @@ int lko_iknn_score(const int64_t *s_ptr, const int32_t *s_idx, const float *s_va
 }
 
 /* ------------------------------------------------------------------------- */
+/* User-kNN scoring: src/accel/knn/user_score.rs:21-98 (same ScoreAccumulator)  */
+/* ------------------------------------------------------------------------- */
+
+/* user_score_items_explicit / _implicit: the neighbours (rows of the ratings matrix) are
+ * walked in the given order, each pushing (weight = its similarity, value = its rating) into
+ * the accumulators of the items it rated; null neighbours (negative row or NaN similarity are
+ * the caller's nulls) are skipped (user_score.rs:41-44,80-83).  rat_val NULL = implicit.
+ * Returns 1 for a NaN weight reaching an accumulator (accum.rs:146-151). */
+int lko_uknn_score(const int64_t *rat_ptr, const int32_t *rat_idx, const float *rat_val,
+                   int64_t n_items, const int32_t *nbr_rows, const float *nbr_sims,
+                   const uint8_t *nbr_valid, int64_t n_nbrs, const int32_t *tgt_items,
+                   int64_t n_tgt, int max_nbrs, int min_nbrs, float *out_scores,
+                   uint8_t *out_valid)
+{
+    const int explicit_ = rat_val != NULL;
+    lko_acc *accs = (lko_acc *)calloc((size_t)n_items, sizeof(lko_acc));
+    for (int64_t t = 0; t < n_tgt; t++) {
+        int32_t ti = tgt_items[t];
+        if (ti >= 0 && accs[ti].state == 0) {
+            accs[ti].state = 1;
+            accs[ti].e = (lko_acc_entry *)malloc(sizeof(lko_acc_entry) * (size_t)(max_nbrs + 2));
+        }
+    }
+    int bad = 0;
+    for (int64_t q = 0; q < n_nbrs && !bad; q++) {
+        if (nbr_valid && !nbr_valid[q]) continue;
+        int32_t nb = nbr_rows[q];
+        float sim = nbr_sims[q];
+        for (int64_t i = rat_ptr[nb]; i < rat_ptr[nb + 1]; i++) {
+            int32_t item = rat_idx[i];
+            if (accs[item].state != 0) {
+                if (isnan(sim)) {
+                    bad = 1;
+                    break;
+                }
+                lko_acc_add(&accs[item], max_nbrs, sim, explicit_ ? rat_val[i] : 0.0f);
+            }
+        }
+    }
+    for (int64_t t = 0; t < n_tgt; t++) {
+        int32_t ti = tgt_items[t];
+        out_scores[t] = 0.0f;
+        out_valid[t] = 0;
+        if (ti < 0) continue;
+        lko_acc *a = &accs[ti];
+        int len = (a->state >= 2) ? a->len : 0;
+        if (len >= min_nbrs) {
+            float tw = 0.0f, ws = 0.0f;
+            for (int i = 0; i < len; i++) tw += a->e[i].weight;
+            for (int i = 0; i < len; i++) ws += a->e[i].weight * a->e[i].data;
+            out_scores[t] = explicit_ ? ws / tw : tw;
+            out_valid[t] = 1;
+        }
+    }
+    for (int64_t i = 0; i < n_items; i++)
+        if (accs[i].e) free(accs[i].e);
+    free(accs);
+    return bad;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Top-N: src/accel/data/sorting.rs:132-172 + src/accel/indirect/heap.rs       */
 /* ------------------------------------------------------------------------- */
 

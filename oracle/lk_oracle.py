@@ -530,6 +530,75 @@ def iknn_score(
     return scores, counts
 
 
+def uknn_score(ratings: sps.csr_array, nbr_rows, nbr_sims, tgt_items, max_nbrs: int,
+               min_nbrs: int, explicit: bool = True) -> np.ndarray:
+    """
+    ``user_score_items_explicit`` / ``_implicit`` (src/accel/knn/user_score.rs:21-98): scores
+    (f32, NaN where the reference returns null) of ``tgt_items`` from the neighbours
+    ``nbr_rows`` (rows of ``ratings``, users x items) with similarities ``nbr_sims``.
+    """
+    rp = np.ascontiguousarray(ratings.indptr, dtype=np.int64)
+    ri = np.ascontiguousarray(ratings.indices, dtype=np.int32)
+    rv = np.ascontiguousarray(ratings.data, dtype=np.float32) if explicit else None
+    nr = np.ascontiguousarray(nbr_rows, dtype=np.int32)
+    ns = np.ascontiguousarray(nbr_sims, dtype=np.float32)
+    ti = np.ascontiguousarray(tgt_items, dtype=np.int32)
+    scores = np.empty(len(ti), dtype=np.float32)
+    valid = np.empty(len(ti), dtype=np.uint8)
+    rc = lib().lko_uknn_score(
+        _p(rp, _i64p), _p(ri, _i32p), _p(rv, _f32p) if explicit else None,
+        ctypes.c_int64(ratings.shape[1]), _p(nr, _i32p), _p(ns, _f32p), None,
+        ctypes.c_int64(len(nr)), _p(ti, _i32p), ctypes.c_int64(len(ti)),
+        ctypes.c_int(max_nbrs), ctypes.c_int(min_nbrs), _p(scores, _f32p), _p(valid, _u8p),
+    )  # fmt: skip
+    if rc:
+        raise ValueError("similarity is null")
+    scores[valid == 0] = np.nan
+    return scores
+
+
+def uknn_prepare(rmat: sps.csr_array, explicit: bool = True):
+    """
+    ``UserKNNScorer.train`` (src/lenskit/knn/user.py:122-168): user-mean centring (explicit
+    only) and row normalisation with the reference's SciPy calls; returns (user_vectors CSR,
+    centred ratings CSR, user means | None).
+    """
+    rmat = sps.csr_array(rmat).astype(np.float32)
+    means = None
+    if explicit:
+        counts = np.diff(rmat.indptr)
+        sums = rmat.sum(axis=1)
+        means = np.zeros(sums.shape, dtype=np.float32)
+        np.divide(sums, counts, out=means, where=counts > 0)
+        rmat.data = rmat.data - np.repeat(means, counts)
+    norms = spla.norm(rmat, 2, axis=1)
+    cmat = rmat / np.maximum(norms, np.finfo("f4").smallest_normal).reshape(-1, 1)
+    return sps.csr_array(cmat.tocsr()), rmat, means
+
+
+def uknn_predict(user_vectors, user_ratings, user_means, uidx, items, max_nbrs, min_nbrs,
+                 min_sim, explicit: bool = True) -> np.ndarray:
+    """
+    ``UserKNNScorer.__call__`` for a known user without supplied history
+    (src/lenskit/knn/user.py:171-262): neighbour similarities by sparse matrix-vector product,
+    self-similarity zeroed, ``>= min_sim`` kept (ascending user order), scores + user mean.
+    """
+    row = user_vectors[[uidx], :].toarray()[0, :]
+    umean = float(user_means[uidx]) if explicit else 0.0
+    nbr_sims = user_vectors @ row
+    nbr_sims[uidx] = 0
+    mask = nbr_sims >= min_sim
+    if not mask.any():
+        return np.full(len(items), np.nan, dtype=np.float32)
+    items = np.asarray(items, dtype=np.int32)
+    ok = items >= 0
+    sc = uknn_score(user_ratings, np.flatnonzero(mask), nbr_sims[mask], items[ok], max_nbrs,
+                    min_nbrs, explicit)
+    out = np.full(len(items), np.nan, dtype=np.float32)
+    out[ok] = sc + np.float32(umean)
+    return out
+
+
 # --------------------------------------------------------------------------
 # fixtures
 # --------------------------------------------------------------------------

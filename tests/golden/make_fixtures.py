@@ -21,6 +21,8 @@ Outputs (all under tests/golden/):
   (``tests/models/item-item-preds.csv``, consumed by
   ``tests/models/test_knn_item_item.py:413-453``): 1288 (user,item,prediction)
   rows for ItemKNNScorer(k=20, min_sim=1e-6) on ml-latest-small.
+* ``user-user-preds.csv`` -- the reference's golden user-kNN predictions
+  (``tests/models/user-user-preds.csv``): 1756 rows for UserKNNScorer(k=30, min_sim=1e-6).
 """
 from __future__ import annotations
 
@@ -45,6 +47,9 @@ def main():
         all_item_ids=movies["movieId"].to_numpy(np.int32),
     )
     shutil.copyfile(REF / "tests/models/item-item-preds.csv", OUT / "item-item-preds.csv")
+    # the reference's golden user-kNN predictions (tests/models/user-user-preds.csv, consumed by
+    # tests/models/test_knn_user_user.py:204-237): UserKNNScorer(k=30, min_sim=1e-6)
+    shutil.copyfile(REF / "tests/models/user-user-preds.csv", OUT / "user-user-preds.csv")
     # the two pipeline definitions the north star names: they must load and run UNCHANGED
     (OUT / "pipelines").mkdir(exist_ok=True)
     for name in ("als-implicit.toml", "iknn-explicit.toml", "als-explicit.toml"):

@@ -268,3 +268,15 @@ def test_ml25m_like_meets_the_dataset_statistics(scale):
     if scale < 1.0:
         again = synth.ml25m_like(scale=scale)
         assert np.array_equal(again.indices, m.indices) and np.array_equal(again.data, m.data)
+
+
+def test_user_knn_component_constructs_and_validates():
+    "config mirror of src/lenskit/knn/user.py:39-71 (no GPU needed to build the component)"
+    from lkpy_amd.knn import UserKNNConfig, UserKNNScorer
+
+    u = UserKNNScorer(k=30, min_sim=1.0e-6)
+    assert u.config.max_nbrs == 30 and u.config.explicit and not u.is_trained()
+    assert UserKNNConfig(nnbrs=5, feedback="implicit").max_nbrs == 5
+    assert UserKNNConfig(min_sim=1e-320).min_sim >= float(np.finfo(np.float64).smallest_normal)
+    with pytest.raises(Exception):
+        UserKNNConfig(bogus=1)

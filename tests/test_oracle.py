@@ -338,3 +338,25 @@ def test_oracle_properties_hypothesis(oracle):
 
     transpose_roundtrip()
     topn_prefix()
+
+
+def test_user_knn_golden_predictions(oracle, ml_small):
+    """The oracle's restatement of `user_score_items_explicit` (src/accel/knn/user_score.rs) +
+    `UserKNNScorer` (src/lenskit/knn/user.py) reproduces the reference's golden vector
+    tests/models/user-user-preds.csv (UserKNNScorer(k=30, min_sim=1e-6),
+    tests/models/test_knn_user_user.py:204-237; the reference's own tolerance is 0.01)."""
+    import pandas as pd
+    import scipy.sparse as sps
+
+    uv, ur, means = oracle.uknn_prepare(sps.csr_array(ml_small["rmat"]), True)
+    known = pd.read_csv(GOLDEN / "user-user-preds.csv")
+    assert len(known) == 1756
+    worst, missing = 0.0, 0
+    for uid, g in known.groupby("user_id"):
+        uidx = int(np.searchsorted(ml_small["user_ids"], uid))
+        items = np.searchsorted(ml_small["item_ids"], g.item_id.values).astype(np.int32)
+        p = oracle.uknn_predict(uv, ur, means.ravel(), uidx, items, 30, 1, 1e-6, True)
+        missing += int(np.sum(np.isnan(p) & ~np.isnan(g.prediction.values)))
+        err = np.abs(p - g.prediction.values)
+        worst = max(worst, float(err[~np.isnan(err)].max()))
+    assert missing == 0 and worst < 1e-4, (missing, worst)
