@@ -53,6 +53,19 @@
 
 namespace lk {
 
+#ifdef LK_ALS_PHASES
+// Diagnostic build only (tools/als_variants.py): shader-clock cycles per phase of the solve
+// kernel, summed over waves: [0] row set-up (row id, extents), [1] normal matrix, [2]
+// transposition, [3] factorisation, [4] substitutions, [5] store + delta, [6] rows, [7] whole
+__device__ unsigned long long lk_als_phase_acc[8];
+#define LK_PHASE_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define LK_PHASE_ADD(i, a, b) \
+    if (lane_id() == 0) atomicAdd(&lk_als_phase_acc[i], (unsigned long long)((b) - (a)))
+#else
+#define LK_PHASE_T(var)
+#define LK_PHASE_ADD(i, a, b)
+#endif
+
 __host__ __device__ constexpr int als_tiles(int NT) { return NT * (NT + 1) / 2; }
 // packed index of upper tile (ti <= tj)
 __host__ __device__ constexpr int tidx(int ti, int tj) { return tj * (tj + 1) / 2 + ti; }
@@ -352,7 +365,12 @@ __device__ __forceinline__ void chol_steps(f32x2 (&a)[KP / 2], float &lj, float 
 // non-finite solution => not SPD).
 template <int KP>
 __device__ __forceinline__ float chol_solve(f32x2 (&a)[KP / 2], float &b,
-                                            float *__restrict__ lds)
+                                            float *__restrict__ lds
+#ifdef LK_ALS_PHASES
+                                            ,
+                                            unsigned long long *tmid
+#endif
+)
 {
     using P = LPack<KP>;
     const int lane = lane_id();
@@ -371,6 +389,10 @@ __device__ __forceinline__ float chol_solve(f32x2 (&a)[KP / 2], float &b,
         if (lane < KP) lds[P::off(0) + lane - P::c0(0)] = lj;
     }
     chol_steps<KP>(a, lj, dinv, minpiv, lds, std::make_integer_sequence<int, KP - 1>{});
+#ifdef LK_ALS_PHASES
+    asm volatile("" : "+v"(lj), "+v"(b));
+    *tmid = __builtin_amdgcn_s_memtime();
+#endif
     dinv = (lane < KP) ? lds[P::SIZE + lane] : 0.f;
     // forward: L z = y.  a[j] is zero for lanes <= j, so no masks: lane i only
     // receives the terms j < i; z_i = b_i * dinv_i.
@@ -450,6 +472,7 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     const int sub = lane & 15, slot = lane >> 4;
     const int64_t t = (int64_t)blockIdx.x * 4 + wave;
     if (t >= n_rows) return;
+    LK_PHASE_T(ph0);
     if constexpr (CTL) {
         // AccelTask.cancel (src/accel/tasks/mod.rs:88-95): rows not started yet are skipped
         int c = 0;
@@ -473,6 +496,7 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
         return;
     }
 
+    LK_PHASE_T(ph1);
     Gram<NT> G;
     // start from OtOr (primed, padded with identity on the pad features)
 #pragma unroll
@@ -505,6 +529,10 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
                 if (slot * 4 + r == sub && (slot * 4 + r) * NT + ti < k) G.t[tidx(ti, ti)][r] += dg;
     }
 
+#ifdef LK_ALS_PHASES
+    asm volatile("" : "+v"(G.t[0]), "+v"(G.t[als_tiles(NT) - 1]));
+#endif
+    LK_PHASE_T(ph2);
     // y: combine the 4 entry slots -> every lane has the full y for feature (t, sub)
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
@@ -544,7 +572,16 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     if (lane >= KP) b = 0.f;
 
     const float old = my_valid ? xrow[my_f] : 0.f;
+#ifdef LK_ALS_PHASES
+    asm volatile("" : "+v"(a[0]), "+v"(a[KP / 2 - 1]), "+v"(b));
+    LK_PHASE_T(ph3);
+    unsigned long long ph4 = 0;
+    const float minpiv = chol_solve<KP>(a, b, lds, &ph4);
+    asm volatile("" : "+v"(b));
+    LK_PHASE_T(ph5);
+#else
     const float minpiv = chol_solve<KP>(a, b, lds);
+#endif
     // not SPD: a non-positive pivot, or NaN/Inf anywhere in the solution
     const bool bad = !(minpiv > 0.f) || (my_valid && !(fabsf(b) <= 3.0e38f));
     if (__any(bad) && lane == 0) atomicCAS(status, 0, row + 1);
@@ -558,6 +595,17 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     if (lane == 0) row_delta[row] = d2;
     if constexpr (CTL)
         if (lane == 0) ctl_advance(ctl, 1);  // progress unit = rows (tasks/mod.rs:97-105)
+#ifdef LK_ALS_PHASES
+    LK_PHASE_T(ph6);
+    LK_PHASE_ADD(0, ph0, ph1);
+    LK_PHASE_ADD(1, ph1, ph2);
+    LK_PHASE_ADD(2, ph2, ph3);
+    LK_PHASE_ADD(3, ph3, ph4);
+    LK_PHASE_ADD(4, ph4, ph5);
+    LK_PHASE_ADD(5, ph5, ph6);
+    LK_PHASE_ADD(6, 0ull, 1ull);
+    LK_PHASE_ADD(7, ph0, ph6);
+#endif
 }
 
 // OtOr [k x k] -> primed [KP x KP] with identity on the pad features.
@@ -693,6 +741,19 @@ int als_cg_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const 
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+
+#ifdef LK_ALS_PHASES
+extern "C" int lk_als_phase_read(unsigned long long *out8, int reset)
+{
+    LK_HIP_CHECK(hipDeviceSynchronize());
+    LK_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(lk::lk_als_phase_acc), 64));
+    if (reset) {
+        unsigned long long z[8] = {};
+        LK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(lk::lk_als_phase_acc), z, 64));
+    }
+    return LK_OK;
+}
+#endif
 
 extern "C" int32_t lk_padded_dim(int32_t k)
 {
