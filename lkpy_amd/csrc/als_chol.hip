@@ -45,6 +45,18 @@
 #ifndef LK_ALS_LOOKAHEAD
 #define LK_ALS_LOOKAHEAD 8  // multiplier groups read ahead in chol_step
 #endif
+#ifndef LK_ALS_GRAM_FENCE
+#define LK_ALS_GRAM_FENCE 1
+#endif
+#ifndef LK_ALS_PANEL
+#define LK_ALS_PANEL 2  // 2: hybrid (lane = row panels + MFMA updates); 1: panel; 0: lane = row Cholesky
+#endif
+#ifndef LK_ALS_SOLVE_ATTR
+#if LK_ALS_PANEL
+// the panel solver keeps the matrix in its 40 accumulator registers: 4 waves per SIMD
+#define LK_ALS_SOLVE_ATTR __attribute__((amdgpu_waves_per_eu(4)))
+#endif
+#endif
 #ifndef LK_ALS_SOLVE_ATTR
 // At least 3 waves per SIMD: the k = 64 kernel then fits 168 registers with 13 dwords of
 // scratch instead of 248 registers (2 waves per SIMD): +14 % epochs/s (tools/als_variants.py)
@@ -55,12 +67,13 @@ namespace lk {
 
 #ifdef LK_ALS_PHASES
 // Diagnostic build only (tools/als_variants.py): shader-clock cycles per phase of the solve
-// kernel, summed over waves: [0] row set-up (row id, extents), [1] normal matrix, [2]
-// transposition, [3] factorisation, [4] substitutions, [5] store + delta, [6] rows, [7] whole
-__device__ unsigned long long lk_als_phase_acc[8];
+// kernel, one record of 8 words per task (plan order): [0] row set-up (row id, extents), [1]
+// normal matrix, [2] transposition, [3] factorisation, [4] substitutions, [5] store + delta,
+// [6] row length, [7] whole
+__device__ unsigned *lk_als_phase_buf;
 #define LK_PHASE_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define LK_PHASE_ADD(i, a, b) \
-    if (lane_id() == 0) atomicAdd(&lk_als_phase_acc[i], (unsigned long long)((b) - (a)))
+    if (lane_id() == 0 && lk_als_phase_buf) lk_als_phase_buf[t * 8 + (i)] = (unsigned)((b) - (a))
 #else
 #define LK_PHASE_T(var)
 #define LK_PHASE_ADD(i, a, b)
@@ -111,16 +124,19 @@ struct GatherRing {
     float v[RING];
 };
 
+// The batch of 64 (column, value) pairs is staged in wave-private LDS (128 words per batch:
+// columns, then values): group g's four entries are then ds_read_b32 at an IMMEDIATE offset
+// from one base register.  (A ds_bpermute from the loaded registers needs a distinct address
+// register for each of the 16 groups: 16 VGPRs the 4-waves-per-SIMD build does not have.)
 template <int NT>
 __device__ __forceinline__ void ring_issue(GatherRing<NT> &R, const int slot_idx, const int g,
-                                           const int col_reg, const float val_reg,
+                                           const float *stage_slot,
                                            const float *__restrict__ other)
 {
     constexpr int KP = NT * 16;
     const int lane = lane_id();
-    const int s = (g * 4 + (lane >> 4)) & 63;
-    const int col = __shfl(col_reg, s, 64);
-    R.v[slot_idx] = __shfl(val_reg, s, 64);
+    const int col = __builtin_bit_cast(int, stage_slot[g * 4]);
+    R.v[slot_idx] = stage_slot[64 + g * 4];
     load_q<NT>(other + (int64_t)col * KP + (lane & 15) * NT, R.q[slot_idx]);
 }
 
@@ -154,11 +170,14 @@ __device__ __forceinline__ void ring_consume(Gram<NT> &G, const GatherRing<NT> &
     for (int t = 0; t < NT; ++t) G.y[t] = fmaf(q[t], v1, G.y[t]);
 }
 
+constexpr int GRAM_STAGE_WORDS = 256;  // two batches of 64 (column, value) pairs
+
 template <int NT>
 __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__restrict__ cols,
                                                 const float *__restrict__ vals, int64_t beg,
                                                 int64_t end, const float *__restrict__ other,
-                                                int /*ld == 16*NT*/, const bool expl)
+                                                int /*ld == 16*NT*/, const bool expl,
+                                                float *stage /* GRAM_STAGE_WORDS, wave-private */)
 {
     // Every load below is UNCONDITIONAL (out-of-range lanes/groups re-read the row's last
     // entry, which is masked or never consumed): a load inside a branch makes the compiler
@@ -166,18 +185,22 @@ __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__re
     // ring would hide nothing.
     const int lane = lane_id();
     constexpr int RING = GatherRing<NT>::RING;
+    static_assert(RING >= 1 && RING <= 8 && 16 % RING == 0, "gather ring: 1, 2, 4 or 8 slots");
     GatherRing<NT> R;
     const int64_t last = end - 1;  // end > beg
 
-    int cur_col, nxt_col;
-    float cur_val, nxt_val;
+    // stage_cur / stage_nxt: this lane's view (entry slot = lane >> 4) of the two batch buffers
+    float *wr_cur = stage + lane, *wr_nxt = stage + 128 + lane;
+    const float *rd_cur = stage + (lane >> 4), *rd_nxt = stage + 128 + (lane >> 4);
+    int nxt_col;
+    float nxt_val;
     {
         const int64_t e = (beg + lane < end) ? beg + lane : last;
-        cur_col = cols[e];
-        cur_val = vals[e];
+        wr_cur[0] = __builtin_bit_cast(float, cols[e]);
+        wr_cur[64] = vals[e];
     }
 #pragma unroll
-    for (int g = 0; g < RING; ++g) ring_issue<NT>(R, g, g, cur_col, cur_val, other);
+    for (int g = 0; g < RING; ++g) ring_issue<NT>(R, g, g, rd_cur, other);
 
     int64_t base = beg;
     // full batches: one straight-line body of 16 groups, no branches, no masks
@@ -190,13 +213,27 @@ __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__re
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             ring_consume<NT, false>(G, R, g % RING, g, 64, expl);
+            if (g == 16 - RING - 2) {
+                // the next batch goes to LDS two groups before its first entries are needed
+                wr_nxt[0] = __builtin_bit_cast(float, nxt_col);
+                wr_nxt[64] = nxt_val;
+            }
             if (g < 16 - RING)
-                ring_issue<NT>(R, g % RING, g + RING, cur_col, cur_val, other);
+                ring_issue<NT>(R, g % RING, g + RING, rd_cur, other);
             else
-                ring_issue<NT>(R, g % RING, g + RING - 16, nxt_col, nxt_val, other);
+                ring_issue<NT>(R, g % RING, g + RING - 16, rd_nxt, other);
+#if LK_ALS_GRAM_FENCE
+            // keep the scheduler from hoisting later groups' gathers over this point: the ring
+            // depth (and with it the register count) is RING, not whatever fits
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
-        cur_col = nxt_col;
-        cur_val = nxt_val;
+        float *tw = wr_cur;
+        wr_cur = wr_nxt;
+        wr_nxt = tw;
+        const float *tr = rd_cur;
+        rd_cur = rd_nxt;
+        rd_nxt = tr;
     }
     // tail batch (< 64 entries): wave-uniform branches with no memory operation inside
     if (base < end) {
@@ -205,7 +242,7 @@ __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__re
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             if (g < ngroups) ring_consume<NT, true>(G, R, g % RING, g, nb, expl);
-            if (g < 16 - RING) ring_issue<NT>(R, g % RING, g + RING, cur_col, cur_val, other);
+            if (g < 16 - RING) ring_issue<NT>(R, g % RING, g + RING, rd_cur, other);
         }
     }
 }
@@ -248,6 +285,7 @@ __global__ __launch_bounds__(256) void als_chunk_kernel(
     const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_len,
     int64_t n_chunks, const float *__restrict__ other, int ld, float *__restrict__ slabs)
 {
+    __shared__ float stage_all[4][GRAM_STAGE_WORDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t c = (int64_t)blockIdx.x * 4 + wave;
     if (c >= n_chunks) return;
@@ -257,7 +295,8 @@ __global__ __launch_bounds__(256) void als_chunk_kernel(
 #pragma unroll
     for (int t = 0; t < NT; ++t) G.y[t] = 0.f;
     const int64_t beg = chunk_beg[c];
-    gram_accumulate<NT>(G, indices, values, beg, beg + chunk_len[c], other, ld, EXPL);
+    gram_accumulate<NT>(G, indices, values, beg, beg + chunk_len[c], other, ld, EXPL,
+                        stage_all[wave]);
     slab_store<NT>(G, slabs + (size_t)c * slab_floats<NT>());
 }
 
@@ -428,23 +467,332 @@ __device__ __forceinline__ float chol_solve(f32x2 (&a)[KP / 2], float &b,
     return minpiv;
 }
 
+// ---- panel Cholesky on the accumulator tiles (LK_ALS_PANEL) -----------------------------------
+//
+// The normal matrix never leaves the MFMA accumulator layout (tile (ti, tj), lane (slot, sub),
+// register r = A'[16 ti + 4 slot + r][16 tj + sub]).  Right-looking Cholesky in panels of FOUR
+// columns J .. J+3 (J = 4m; tile column TJ = m / 4, row group MG = m % 4 of that tile):
+//   1. extraction: by symmetry the panel A'[row][J + s] is register s of row group MG of the
+//      tiles (TJ, t); one masked ds_write_b128 + one ds_read_b32 per tile puts it into the
+//      PANEL layout p[t], lane (s, c) = A'[16 t + c][J + s] -- four row groups, four columns;
+//   2. the four columns are factored in that layout: pivot by v_readlane, the finished column
+//      is broadcast from its row group to the other three (ds_bpermute) and applied to the
+//      columns right of it, to the right-hand side (the forward substitution L z = y rides
+//      along) and written to the strictly-lower L image the back substitution reads;
+//   3. the rank-4 update of everything right of the panel is ONE v_mfma_f32_16x16x4_f32 per
+//      tile: in the panel layout -p[ti] IS the A operand and p[tj] IS the B operand.
+// 80 MFMAs replace the ~1000 v_pk_fma + 500 ds_read_b128 of the lane = row version, the
+// transposition disappears, and the solver needs ~30 registers beside the 40 of the tiles,
+// which is what lets four waves share a SIMD (tools/emul/panel_chol.py is the lane-level
+// NumPy model the index arithmetic was checked with).
+template <int NT>
+__host__ __device__ constexpr int panel_lds_floats()
+{
+    // L image | KP reciprocal pivots | KP z values | extraction scratch (64 floats per tile)
+    return LPack<NT * 16>::SIZE + 2 * NT * 16 + NT * 64;
+}
+
+template <int NT, int M>
+__device__ __forceinline__ void panel_step(Gram<NT> &G, float &minpiv, float *__restrict__ lds,
+                                           const int lane)
+{
+    constexpr int KP = NT * 16, J = 4 * M, TJ = M >> 2, MG = M & 3, JC = 4 * MG;
+    using P = LPack<KP>;
+    const int slot = lane >> 4, sub = lane & 15;
+    float *rinvarr = lds + P::SIZE;
+    float *zarr = rinvarr + KP;
+    float *scr = zarr + KP;
+
+    float p[NT];
+    // 1. extraction into the panel layout
+#pragma unroll
+    for (int t = TJ; t < NT; ++t)
+        if (slot == MG) *reinterpret_cast<f32x4 *>(&scr[(t * 16 + sub) * 4]) = G.t[tidx(TJ, t)];
+#pragma unroll
+    for (int t = TJ; t < NT; ++t) p[t] = scr[(t * 16 + sub) * 4 + slot];
+
+    // 2. the four columns
+#pragma unroll
+    for (int s0 = 0; s0 < 4; ++s0) {
+        const int j = J + s0;
+        const float piv = bcast(p[TJ], 16 * s0 + JC + s0);
+        minpiv = fminf(minpiv, piv);
+        const float rinv = __builtin_amdgcn_rsqf(piv);
+        if (lane == 0) rinvarr[j] = rinv;
+        // finish column s0 (row group s0).  The cells above the diagonal are NOT cleared: they
+        // only ever reach rows / columns that are dead by then (finished rows of the tiles and
+        // of y) -- except in the L image, which stores zeros for them.
+        const float rsel = slot == s0 ? rinv : 1.0f;
+#pragma unroll
+        for (int t = TJ; t < NT; ++t) p[t] *= rsel;
+        // L[16 t + c][j] for every row group
+        float bc[NT];
+#pragma unroll
+        for (int t = TJ; t < NT; ++t) bc[t] = __shfl(p[t], 16 * s0 + sub, 64);
+        if (s0 < 3) {
+            // columns right of it inside the panel: P[row][s] -= L[row][j] * L[J + s][j]
+            const float sc = __shfl(p[TJ], 16 * s0 + JC + slot, 64);
+            const float scm = slot > s0 ? sc : 0.f;
+#pragma unroll
+            for (int t = TJ; t < NT; ++t) p[t] = fmaf(-bc[t], scm, p[t]);
+        }
+        // forward substitution: z_j = y_j / L_jj; y -= L[:, j] z_j
+        const float zj = bcast(G.y[TJ], JC + s0) * rinv;
+        if (lane == 0) zarr[j] = zj;
+#pragma unroll
+        for (int t = TJ; t < NT; ++t) G.y[t] = fmaf(-bc[t], zj, G.y[t]);
+        // strictly-lower L image, column j: rows >= c0(j), zeros on and above the diagonal
+        const int c0j = P::c0(j), lo = c0j - 16 * TJ;
+        float *col = lds + P::off(j) - c0j;
+        if (lo < 16) {
+            const float v = (sub > JC + s0) ? bc[TJ] : 0.f;
+            if (slot == 0 && sub >= lo) col[16 * TJ + sub] = v;
+        }
+#pragma unroll
+        for (int t = TJ + 1; t < NT; ++t)
+            if (slot == 0) col[16 * t + sub] = bc[t];
+    }
+    // 3. rank-4 update of the tiles right of / below the panel (tile row TJ first: the next
+    // panel of this tile column is extracted from it)
+    float np[NT];
+#pragma unroll
+    for (int t = TJ; t < NT; ++t) np[t] = -p[t];
+#pragma unroll
+    for (int ti = TJ; ti < NT; ++ti)
+#pragma unroll
+        for (int t2 = ti; t2 < NT; ++t2)
+            G.t[tidx(ti, t2)] = __builtin_amdgcn_mfma_f32_16x16x4f32(np[ti], p[t2],
+                                                                     G.t[tidx(ti, t2)], 0, 0, 0);
+}
+
+template <int NT, int... Ms>
+__device__ __forceinline__ void panel_steps(Gram<NT> &G, float &minpiv, float *__restrict__ lds,
+                                            const int lane, std::integer_sequence<int, Ms...>)
+{
+    (panel_step<NT, Ms>(G, minpiv, lds, lane), ...);
+}
+
+// G: accumulator tiles of A' and the right-hand side (every lane: y'[16 t + sub]).  Returns
+// the smallest pivot; b = solution for primed row `lane`.
+template <int NT>
+__device__ __forceinline__ float panel_solve(Gram<NT> &G, float &b, float *__restrict__ lds
+#ifdef LK_ALS_PHASES
+                                             ,
+                                             unsigned long long *tmid
+#endif
+)
+{
+    constexpr int KP = NT * 16;
+    using P = LPack<KP>;
+    // the lane number is made opaque here so that nothing derived from it for the solver
+    // (row-group masks, LDS addresses) is kept alive across the normal-matrix loop
+    int lane = lane_id();
+    asm volatile("" : "+v"(lane));
+    float minpiv = 3.0e38f;
+    panel_steps<NT>(G, minpiv, lds, lane, std::make_integer_sequence<int, KP / 4>{});
+#ifdef LK_ALS_PHASES
+    asm volatile("" : "+v"(G.y[0]));
+    *tmid = __builtin_amdgcn_s_memtime();
+#endif
+    // backward: L^T x = z, lane = primed row.  Lane i needs L[j][i] (j > i) = column i of the
+    // LDS image, read four rows at a time (ds_read_b128; rows <= i inside the column are
+    // stored zeros, rows below c0(i) are outside it).
+    const float dinv = (lane < KP) ? lds[P::SIZE + lane] : 0.f;
+    b = (lane < KP) ? lds[P::SIZE + KP + lane] : 0.f;
+    const int my_c0 = (lane + 1) & ~3;
+    const float *mycol = lds + P::off(lane) - my_c0;
+#pragma unroll
+    for (int j4 = KP / 4 - 1; j4 >= 0; --j4) {
+        f32x4 l4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lane < KP - 1 && 4 * j4 >= my_c0) l4 = *reinterpret_cast<const f32x4 *>(mycol + 4 * j4);
+#pragma unroll
+        for (int u = 3; u >= 0; --u) {
+            const int j = 4 * j4 + u;
+            if (j >= 1) {
+                const float xj = bcast(b * dinv, j);
+                b = fmaf(-l4[u], xj, b);
+            }
+        }
+    }
+    b *= dinv;
+    return minpiv;
+}
+
+// ---- hybrid Cholesky (LK_ALS_PANEL == 2) -------------------------------------------------------
+//
+// The matrix stays in the accumulator tiles; panels of FOUR columns J .. J+3 are
+//   E. extracted into the lane = row layout (lane i: A'[i][J .. J+3]; by symmetry these are the
+//      four registers of row group MG of the tiles (TJ, t): one masked ds_write_b128 per tile,
+//      one ds_read_b128 per lane),
+//   F. factored there with registers and v_readlane only (no LDS in the dependent chain); the
+//      forward substitution rides along and every finished column goes to the strictly-lower
+//      L image of the back substitution,
+//   C. turned into MFMA operands by a 4 x 4 (register x row group) transposition made of two
+//      v_permlane32_swap and two v_permlane16_swap: q[t], lane (s, c) = L[16 t + c][J + s],
+//   U. applied to everything right of the panel: ONE v_mfma_f32_16x16x4_f32 per tile with
+//      -q[ti] as the A operand and q[tj] as the B operand.
+// tools/emul/hybrid_chol.py is the lane-level NumPy model of this; tools/ub/permlane_swap.hip
+// checks the swap semantics on the device.
+template <int NT>
+__host__ __device__ constexpr int hybrid_lds_floats()
+{
+    // L image | KP reciprocal pivots | extraction scratch (64 lanes x 4)
+    return LPack<NT * 16>::SIZE + NT * 16 + 256;
+}
+
+// (inline asm: chained __builtin_amdgcn_permlane*_swap calls are miscompiled by hipcc 7.2 --
+// both results of the later swaps land in one register; the s_nop covers the two wait states
+// a VALU write of an operand needs before the swap reads it)
+__device__ __forceinline__ void swap32(float &a, float &b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16(float &a, float &b)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+template <int NT, int M>
+__device__ __forceinline__ void hybrid_step(Gram<NT> &G, float &b, float &minpiv,
+                                            float *__restrict__ lds, const int lane)
+{
+    constexpr int KP = NT * 16, J = 4 * M, TJ = M >> 2, MG = M & 3;
+    using P = LPack<KP>;
+    const int slot = lane >> 4;
+    float *rinvarr = lds + P::SIZE;
+    float *scr = rinvarr + KP;
+
+    // E. extraction
+#pragma unroll
+    for (int t = TJ; t < NT; ++t)
+        if (slot == MG)
+            *reinterpret_cast<f32x4 *>(&scr[(t * 16 + (lane & 15)) * 4]) = G.t[tidx(TJ, t)];
+    f32x4 pv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (slot >= TJ && lane < KP) pv = *reinterpret_cast<const f32x4 *>(&scr[lane * 4]);
+    float pr[4] = {pv.x, pv.y, pv.z, pv.w};
+
+    // F. the four columns
+    float lp[4];
+#pragma unroll
+    for (int s0 = 0; s0 < 4; ++s0) {
+        const int j = J + s0;
+        const float piv = bcast(pr[s0], j);
+        minpiv = fminf(minpiv, piv);
+        const float rinv = __builtin_amdgcn_rsqf(piv);
+        if (lane == 0) rinvarr[j] = rinv;
+        const float lj = (lane > j) ? pr[s0] * rinv : 0.f;  // strictly-lower column j
+        if (j + 1 < KP) {
+            if (lane >= P::c0(j) && lane < KP) lds[P::off(j) + lane - P::c0(j)] = lj;
+        }
+        // forward substitution: z_j = y_j / L_jj, y -= L[:, j] z_j
+        const float zj = bcast(b, j) * rinv;
+        b = fmaf(-lj, zj, b);
+#pragma unroll
+        for (int s = s0 + 1; s < 4; ++s) pr[s] = fmaf(-lj, bcast(lj, J + s), pr[s]);
+        lp[s0] = lj;
+    }
+    if constexpr (J + 4 < KP) {
+        // C. register x row-group transposition: lp[s] @ group t  ->  q[t] @ group s
+        swap32(lp[0], lp[2]);
+        swap32(lp[1], lp[3]);
+        swap16(lp[0], lp[1]);
+        swap16(lp[2], lp[3]);
+        // U. rank-4 update (tile row TJ first: the next panel is extracted from it)
+        float nq[NT];
+#pragma unroll
+        for (int t = TJ; t < NT; ++t) nq[t] = -lp[t];
+#pragma unroll
+        for (int ti = TJ; ti < NT; ++ti)
+#pragma unroll
+            for (int t2 = ti; t2 < NT; ++t2)
+                G.t[tidx(ti, t2)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                    nq[ti], lp[t2], G.t[tidx(ti, t2)], 0, 0, 0);
+    }
+}
+
+template <int NT, int... Ms>
+__device__ __forceinline__ void hybrid_steps(Gram<NT> &G, float &b, float &minpiv,
+                                             float *__restrict__ lds, const int lane,
+                                             std::integer_sequence<int, Ms...>)
+{
+    (hybrid_step<NT, Ms>(G, b, minpiv, lds, lane), ...);
+}
+
+// G: accumulator tiles of A' and the right-hand side (every lane: y'[16 t + sub]).  Returns
+// the smallest pivot; b = solution for primed row `lane`.
+template <int NT>
+__device__ __forceinline__ float hybrid_solve(Gram<NT> &G, float &b, float *__restrict__ lds
+#ifdef LK_ALS_PHASES
+                                              ,
+                                              unsigned long long *tmid
+#endif
+)
+{
+    constexpr int KP = NT * 16;
+    using P = LPack<KP>;
+    // the lane number is made opaque here so that nothing derived from it for the solver
+    // (row-group masks, LDS addresses) is kept alive across the normal-matrix loop
+    int lane = lane_id();
+    asm volatile("" : "+v"(lane));
+    // rhs for primed row `lane`: tile lane >> 4, sub lane & 15 -> G.y[lane >> 4] of this lane
+    b = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) b = ((lane >> 4) == tt) ? G.y[tt] : b;
+    float minpiv = 3.0e38f;
+    hybrid_steps<NT>(G, b, minpiv, lds, lane, std::make_integer_sequence<int, KP / 4>{});
+#ifdef LK_ALS_PHASES
+    asm volatile("" : "+v"(b));
+    *tmid = __builtin_amdgcn_s_memtime();
+#endif
+    // backward: L^T x = z, lane = primed row (z = b / L_jj after the folded forward pass)
+    const float dinv = (lane < KP) ? lds[P::SIZE + lane] : 0.f;
+    b *= dinv;
+    const int my_c0 = (lane + 1) & ~3;
+    const float *mycol = lds + P::off(lane) - my_c0;
+#pragma unroll
+    for (int j4 = KP / 4 - 1; j4 >= 0; --j4) {
+        f32x4 l4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lane < KP - 1 && 4 * j4 >= my_c0) l4 = *reinterpret_cast<const f32x4 *>(mycol + 4 * j4);
+#pragma unroll
+        for (int u = 3; u >= 0; --u) {
+            const int j = 4 * j4 + u;
+            if (j >= 1) {
+                const float xj = bcast(b * dinv, j);
+                b = fmaf(-l4[u], xj, b);
+            }
+        }
+    }
+    b *= dinv;
+    return minpiv;
+}
+
 // transposition buffer: row R' (tile row tr = R' >> 4) keeps its (tr+1)*16 lower
-// entries; stride inside tile row tr is (tr+1)*16 + 4 floats (16-byte aligned).
+// entries; stride inside tile row tr is (tr+1)*16 + 4 floats (16-byte aligned).  For NT = 4
+// the transposition runs in TWO passes (tile rows 0..2, then tile row 3 alone, both from
+// offset 0): 6.9 KiB instead of 11 KiB, so that the wave's LDS is the 8.7 KiB of the L image
+// and FOUR workgroups fit a CU.
 template <int NT>
 struct TPack {
+    static constexpr int SPLIT = NT == 4 ? 3 : NT;  // tile rows of the first pass
     __host__ __device__ static constexpr int stride(int tr) { return (tr + 1) * 16 + 4; }
     __host__ __device__ static constexpr int base(int tr)
     {
         int b = 0;
-        for (int t = 0; t < tr; ++t) b += 16 * stride(t);
+        for (int t = (tr >= SPLIT ? SPLIT : 0); t < tr; ++t) b += 16 * stride(t);
         return b;
     }
-    static constexpr int SIZE = base(NT);
+    static constexpr int SIZE = base(SPLIT) > 16 * stride(NT - 1) ? base(SPLIT)
+                                                                  : (NT > SPLIT ? 16 * stride(NT - 1) : base(NT));
 };
 
 template <int NT>
 __host__ __device__ constexpr int solve_lds_floats()
 {
+#if LK_ALS_PANEL == 2
+    return hybrid_lds_floats<NT>();
+#elif LK_ALS_PANEL
+    return panel_lds_floats<NT>() > GRAM_STAGE_WORDS ? panel_lds_floats<NT>() : GRAM_STAGE_WORDS;
+#endif
     // the L image is followed by the k reciprocal pivots
     return TPack<NT>::SIZE > LPack<NT * 16>::SIZE + NT * 16 ? TPack<NT>::SIZE
                                                             : LPack<NT * 16>::SIZE + NT * 16;
@@ -516,7 +864,8 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
         for (int s = 0; s < ns; ++s)
             slab_add<NT>(G, slabs + (size_t)(first_slab + s) * slab_floats<NT>());
     } else {
-        gram_accumulate<NT>(G, indices, values, beg, end, other, ld_other, EXPL);
+        // (the solver's LDS is idle while the normal matrix is built: its head stages the CSR)
+        gram_accumulate<NT>(G, indices, values, beg, end, other, ld_other, EXPL, lds);
     }
     if (EXPL) {
         // explicit.rs:104-107: mtm[i][i] += reg * n, AFTER the product, real features only
@@ -539,31 +888,69 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
         G.y[tt] += __shfl_xor(G.y[tt], 16, 64);
         G.y[tt] += __shfl_xor(G.y[tt], 32, 64);
     }
+#if LK_ALS_PANEL
+    const float old = my_valid ? xrow[my_f] : 0.f;
+    float b;
+#ifdef LK_ALS_PHASES
+    LK_PHASE_T(ph3);
+    unsigned long long ph4 = 0;
+#if LK_ALS_PANEL == 2
+    const float minpiv = hybrid_solve<NT>(G, b, lds, &ph4);
+#else
+    const float minpiv = panel_solve<NT>(G, b, lds, &ph4);
+#endif
+    asm volatile("" : "+v"(b));
+    LK_PHASE_T(ph5);
+#else
+#if LK_ALS_PANEL == 2
+    const float minpiv = hybrid_solve<NT>(G, b, lds);
+#else
+    const float minpiv = panel_solve<NT>(G, b, lds);
+#endif
+#endif
+#else
     // tile (ti,tj): lane holds D[i = slot*4+r][j = sub] = A'[ti*16+i][tj*16+j]
     //             = A'[row' = tj*16+sub][col' = ti*16 + slot*4 + r]  (symmetry)
-#pragma unroll
-    for (int tj = 0; tj < NT; ++tj)
-#pragma unroll
-        for (int ti = 0; ti <= tj; ++ti)
-            *reinterpret_cast<f32x4 *>(
-                &lds[TPack<NT>::base(tj) + sub * TPack<NT>::stride(tj) + ti * 16 + slot * 4]) =
-                G.t[tidx(ti, tj)];
-
+    // lane = primed row: tile row slot (= lane >> 4), row-in-tile sub
     f32x2 a[KP / 2];
     float b = 0.f;
     {
-        // lane = primed row: tile row slot (= lane >> 4), row-in-tile sub
+        using T = TPack<NT>;
         int rowoff = 0;
 #pragma unroll
         for (int tr = 0; tr < NT; ++tr)
-            rowoff = (slot == tr) ? TPack<NT>::base(tr) + sub * TPack<NT>::stride(tr) : rowoff;
+            rowoff = (slot == tr) ? T::base(tr) + sub * T::stride(tr) : rowoff;
 #pragma unroll
-        for (int c4 = 0; c4 < KP / 4; ++c4) {
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (lane < KP && (c4 >> 2) <= slot)
-                v = *reinterpret_cast<const f32x4 *>(&lds[rowoff + c4 * 4]);
-            a[c4 * 2 + 0] = f32x2{v.x, v.y};
-            a[c4 * 2 + 1] = f32x2{v.z, v.w};
+        for (int pass = 0; pass < (T::SPLIT < NT ? 2 : 1); ++pass) {
+            const int t0 = pass == 0 ? 0 : T::SPLIT, t1 = pass == 0 ? T::SPLIT : NT;
+#pragma unroll
+            for (int tj = t0; tj < t1; ++tj)
+#pragma unroll
+                for (int ti = 0; ti <= tj; ++ti)
+                    *reinterpret_cast<f32x4 *>(
+                        &lds[T::base(tj) + sub * T::stride(tj) + ti * 16 + slot * 4]) =
+                        G.t[tidx(ti, tj)];
+            // the wave's LDS operations complete in order: no barrier between the passes
+            const bool mine = lane < KP && slot >= t0 && slot < t1;
+#pragma unroll
+            for (int c4 = 0; c4 < KP / 4; ++c4) {
+                if ((c4 >> 2) >= t1) continue;  // beyond this pass's widest row
+                f32x4 v = pass == 0 ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                    : f32x4{a[c4 * 2][0], a[c4 * 2][1], a[c4 * 2 + 1][0],
+                                            a[c4 * 2 + 1][1]};
+                if (mine && (c4 >> 2) <= slot)
+                    v = *reinterpret_cast<const f32x4 *>(&lds[rowoff + c4 * 4]);
+                a[c4 * 2 + 0] = f32x2{v.x, v.y};
+                a[c4 * 2 + 1] = f32x2{v.z, v.w};
+            }
+            if (pass == 0 && T::SPLIT < NT) {
+                // columns only the last tile row has: defined (zero) before pass 2 merges
+#pragma unroll
+                for (int c4 = T::SPLIT * 4; c4 < KP / 4; ++c4) {
+                    a[c4 * 2 + 0] = f32x2{0.f, 0.f};
+                    a[c4 * 2 + 1] = f32x2{0.f, 0.f};
+                }
+            }
         }
     }
     // rhs for primed row `lane`: tile lane>>4, sub lane&15 -> G.y[lane>>4] of this lane
@@ -581,6 +968,7 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     LK_PHASE_T(ph5);
 #else
     const float minpiv = chol_solve<KP>(a, b, lds);
+#endif
 #endif
     // not SPD: a non-positive pivot, or NaN/Inf anywhere in the solution
     const bool bad = !(minpiv > 0.f) || (my_valid && !(fabsf(b) <= 3.0e38f));
@@ -603,7 +991,7 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     LK_PHASE_ADD(3, ph3, ph4);
     LK_PHASE_ADD(4, ph4, ph5);
     LK_PHASE_ADD(5, ph5, ph6);
-    LK_PHASE_ADD(6, 0ull, 1ull);
+    LK_PHASE_ADD(6, (unsigned long long)beg, (unsigned long long)end);
     LK_PHASE_ADD(7, ph0, ph6);
 #endif
 }
@@ -743,14 +1131,10 @@ int als_cg_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const 
 // ---------------------------------------------------------------------------
 
 #ifdef LK_ALS_PHASES
-extern "C" int lk_als_phase_read(unsigned long long *out8, int reset)
+extern "C" int lk_als_phase_set(void *d_buf)
 {
     LK_HIP_CHECK(hipDeviceSynchronize());
-    LK_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(lk::lk_als_phase_acc), 64));
-    if (reset) {
-        unsigned long long z[8] = {};
-        LK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(lk::lk_als_phase_acc), z, 64));
-    }
+    LK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(lk::lk_als_phase_buf), &d_buf, sizeof(void *)));
     return LK_OK;
 }
 #endif

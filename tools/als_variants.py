@@ -43,6 +43,39 @@ for path in [default] + [Path(p).resolve() for p in sys.argv[1:]]:
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / 10)
     eng.check()
-    print(json.dumps({"lib": Path(path).name, "ms_per_epoch": round(best * 1e3, 3),
-                      "epochs_per_s": round(1 / best, 1), "delta": float(di)}), flush=True)
+    rec = {"lib": Path(path).name, "ms_per_epoch": round(best * 1e3, 3),
+           "epochs_per_s": round(1 / best, 1), "delta": float(di)}
+    lib = _native.load()
+    if hasattr(lib, "lk_als_phase_set"):  # -DLK_ALS_PHASES build: cycles per phase and row
+        import ctypes
+
+        names = ["setup", "gram", "transpose", "factor", "subst", "store", "len", "whole"]
+        for half in ("user", "item"):
+            n = eng.P.shape[0] if half == "user" else eng.Q.shape[0]
+            buf = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+            lib.lk_als_phase_set(ctypes.c_void_p(buf.data_ptr()))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if half == "user":
+                eng.backend.half_epoch(eng.u_plan, eng.P, eng.Q, eng._qtq)
+            else:
+                eng.backend.half_epoch(eng.i_plan, eng.Q, eng.P,
+                                       eng.backend.gramian(eng.P, eng.item_reg))
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3
+            lib.lk_als_phase_set(ctypes.c_void_p(0))
+            b = buf.cpu().numpy().astype(np.int64)
+            b = b[b[:, 7] > 0]
+            out = {"rows": int(len(b)), "ms": round(ms, 3)}
+            # all solved rows, then by row length (plan order = longest first)
+            for tag, sel in [("all", slice(None)), ("len>2048", b[:, 6] > 2048),
+                             ("512..2048", (b[:, 6] > 512) & (b[:, 6] <= 2048)),
+                             ("128..512", (b[:, 6] > 128) & (b[:, 6] <= 512)),
+                             ("<=128", b[:, 6] <= 128)]:
+                x = b[sel]
+                if len(x):
+                    out[tag] = {"n": int(len(x)), **{nm: int(x[:, i].mean()) for i, nm in
+                                                     enumerate(names)}}
+            rec[half] = out
+    print(json.dumps(rec), flush=True)
     del eng

@@ -1,5 +1,6 @@
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gputest.log
-timeout 600 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?" >> gpurun_out/bench.err
-PROF_CMD="python tools/topk_only.py 64 100" timeout 500 bash tools/prof_topk.sh r02 > gpurun_out/prof_topk.log 2>&1
-tail -3 gpurun_out/gputest.log; cat gpurun_out/bench.log; tail -3 gpurun_out/bench.err
+tools/ub/permlane_swap
+timeout 600 python -m pytest tests/test_gpu_als.py tests/test_gpu_als_explicit.py tests/test_gpu_pipeline.py tests/test_gpu_scale.py -m gpu -q -x > gpurun_out/gputest_als.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gputest_als.log
+tail -4 gpurun_out/gputest_als.log
+timeout 600 python tools/als_variants.py tools/_variants/lkamd_old3.so tools/_variants/lkamd_h4r2.so tools/_variants/lkamd_h3r4.so tools/_variants/lkamd_phases.so tools/_variants/lkamd_h3phases.so > gpurun_out/variants_d.log 2>&1
+cat gpurun_out/variants_d.log
