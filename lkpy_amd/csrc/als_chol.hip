@@ -45,6 +45,12 @@
 #ifndef LK_ALS_LOOKAHEAD
 #define LK_ALS_LOOKAHEAD 8  // multiplier groups read ahead in chol_step
 #endif
+#ifndef LK_ALS_GRAM_DMA
+#define LK_ALS_GRAM_DMA 1  // k = 64: gathered rows prefetched into LDS (global_load_lds)
+#endif
+#ifndef LK_ALS_DMA_PIPE
+#define LK_ALS_DMA_PIPE 1  // operands of group g+1 fetched from the ring before group g's MFMAs
+#endif
 #ifndef LK_ALS_GRAM_FENCE
 #define LK_ALS_GRAM_FENCE 1
 #endif
@@ -247,6 +253,232 @@ __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__re
     }
 }
 
+// ---- the same accumulation with the gathered rows prefetched into LDS (k = 64 only) ---------
+//
+// `global_load_lds_dwordx4`: every lane names 16 bytes of a factor row and the memory pipe
+// writes them to LDS at M0 + 16 * lane -- one instruction moves a group's four rows (1 KiB)
+// without touching a VGPR.  The solver's L image (8.4 KiB) is idle while the normal matrix is
+// built, so it holds a ring of DMA_RING = 8 groups = 32 CSR entries in flight per wave, twice
+// the register ring, for 20 registers less; the operands come back with one ds_read_b128 per
+// lane (each lane reads the 16 bytes "its" load brought: conflict-free by construction).
+// hipcc does not count these loads, so the waits are explicit: when group g is consumed the
+// groups g+1 .. g+DMA_RING-1 (or fewer at the end of the row) were issued after it, and
+// `s_waitcnt vmcnt(that many)` is exactly "group g has landed" (loads retire in order; any
+// other memory operation in between only makes the wait more conservative).
+#ifndef LK_ALS_DMA_RING
+#define LK_ALS_DMA_RING 8
+#endif
+constexpr int DMA_RING = LK_ALS_DMA_RING;
+constexpr int GRAM_DMA_WORDS = DMA_RING * 256;  // ring, followed by nothing
+
+template <int N>
+__device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// at most `n` (wave-uniform, 0 .. DMA_RING-1) loads still in flight
+__device__ __forceinline__ void wait_vm_upto(const int n)
+{
+    if (n >= 7) wait_vm<7>();
+    else if (n == 6) wait_vm<6>();
+    else if (n == 5) wait_vm<5>();
+    else if (n == 4) wait_vm<4>();
+    else if (n == 3) wait_vm<3>();
+    else if (n == 2) wait_vm<2>();
+    else if (n == 1) wait_vm<1>();
+    else wait_vm<0>();
+}
+
+// group g of the staged batch -> ring slot `slot_idx` (compile-time)
+__device__ __forceinline__ void dma_issue(const unsigned ring_lds, const int slot_idx, const int g,
+                                          const float *stage_slot,
+                                          const float *__restrict__ other)
+{
+    const int lane = lane_id();
+    const int col = __builtin_bit_cast(int, stage_slot[g * 4]);
+    const float *src = other + (int64_t)col * 64 + (lane & 15) * 4;
+    const unsigned dst = ring_lds + slot_idx * 1024;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(dst)
+        : "memory");
+}
+
+struct DmaOperand {
+    f32x4 q;
+    float v;
+};
+// group g's operands out of the ring (its load must have landed: wait_vm first)
+__device__ __forceinline__ DmaOperand dma_fetch(const float *ring, const int slot_idx, const int g,
+                                                const float *stage_slot)
+{
+    DmaOperand o;
+    o.q = *reinterpret_cast<const f32x4 *>(ring + slot_idx * 256 + lane_id() * 4);
+    o.v = stage_slot[64 + g * 4];
+    return o;
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void dma_apply(Gram<4> &G, const DmaOperand &o, const int g,
+                                          const int nb, const bool expl)
+{
+    const int lane = lane_id();
+    const bool live = !MASKED || (g * 4 + (lane >> 4)) < nb;
+    const float v = o.v;
+    const float va = expl ? 1.0f : v;
+    float q[4] = {o.q.x, o.q.y, o.q.z, o.q.w}, a[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        q[t] = live ? q[t] : 0.f;
+        a[t] = q[t] * va;
+    }
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti <= tj; ++ti)
+            G.t[tidx(ti, tj)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], q[tj],
+                                                                     G.t[tidx(ti, tj)], 0, 0, 0);
+    const float v1 = expl ? v : v + 1.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) G.y[t] = fmaf(q[t], v1, G.y[t]);
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void dma_consume(Gram<4> &G, const float *ring, const int slot_idx,
+                                            const int g, const int nb, const float *stage_slot,
+                                            const bool expl)
+{
+    dma_apply<MASKED>(G, dma_fetch(ring, slot_idx, g, stage_slot), g, nb, expl);
+}
+
+// ring: GRAM_DMA_WORDS floats, stage: GRAM_STAGE_WORDS floats, both wave-private LDS
+__device__ __forceinline__ void gram_accumulate_dma(Gram<4> &G, const int32_t *__restrict__ cols,
+                                                    const float *__restrict__ vals, int64_t beg,
+                                                    int64_t end, const float *__restrict__ other,
+                                                    const bool expl, float *ring, float *stage)
+{
+    constexpr int RING = DMA_RING;
+    static_assert(RING == 8 || RING == 4, "DMA ring: 4 or 8 groups");
+    const int lane = lane_id();
+    const int64_t last = end - 1;  // end > beg
+    const unsigned ring_lds =
+        __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t) reinterpret_cast<void *>(ring));
+
+    float *wr_cur = stage + lane, *wr_nxt = stage + 128 + lane;
+    const float *rd_cur = stage + (lane >> 4), *rd_nxt = stage + 128 + (lane >> 4);
+    {
+        const int64_t e = (beg + lane < end) ? beg + lane : last;
+        wr_cur[0] = __builtin_bit_cast(float, cols[e]);
+        wr_cur[64] = vals[e];
+    }
+    // groups of the whole row; group gg lives in batch gg / 16
+    const int total = (int)((end - beg + 3) >> 2);
+#pragma unroll
+    for (int g = 0; g < RING; ++g)
+        if (g < total) dma_issue(ring_lds, g, g, rd_cur, other);
+
+    int64_t base = beg;
+    int g0 = 0;  // first group of the current batch
+    // batches that are followed by at least RING more groups: no guards, constant waits
+    for (; g0 + 16 + RING <= total; base += 64, g0 += 16) {
+        int nxt_col;
+        float nxt_val;
+        {
+            const int64_t e = (base + 64 + lane < end) ? base + 64 + lane : last;
+            nxt_col = cols[e];
+            nxt_val = vals[e];
+        }
+#if LK_ALS_DMA_PIPE
+        // operands one group ahead: group g+1 is read out of the ring (its load is the next
+        // one to land) before the 10 MFMAs of group g are issued, so the ds_read latency
+        // hides behind them.  (Group 0's operands of the NEXT batch are fetched by that
+        // batch's first iteration: the pipeline restarts at batch boundaries.)
+        wait_vm<RING - 1>();
+        DmaOperand cur = dma_fetch(ring, 0, 0, rd_cur);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            DmaOperand nxt = cur;
+            if (g + 1 < 16) {
+                wait_vm<RING - 2>();
+                nxt = dma_fetch(ring, (g + 1) % RING, g + 1, rd_cur);
+            }
+            dma_apply<false>(G, cur, g, 64, expl);
+            if (g == 16 - RING - 2) {
+                wr_nxt[0] = __builtin_bit_cast(float, nxt_col);
+                wr_nxt[64] = nxt_val;
+            }
+            if (g < 16 - RING)
+                dma_issue(ring_lds, g % RING, g + RING, rd_cur, other);
+            else
+                dma_issue(ring_lds, g % RING, g + RING - 16, rd_nxt, other);
+            cur = nxt;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            wait_vm<RING - 1>();
+            dma_consume<false>(G, ring, g % RING, g, 64, rd_cur, expl);
+            if (g == 16 - RING - 2) {
+                wr_nxt[0] = __builtin_bit_cast(float, nxt_col);
+                wr_nxt[64] = nxt_val;
+            }
+            if (g < 16 - RING)
+                dma_issue(ring_lds, g % RING, g + RING, rd_cur, other);
+            else
+                dma_issue(ring_lds, g % RING, g + RING - 16, rd_nxt, other);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+        float *tw = wr_cur;
+        wr_cur = wr_nxt;
+        wr_nxt = tw;
+        const float *tr = rd_cur;
+        rd_cur = rd_nxt;
+        rd_nxt = tr;
+    }
+    // the last batches: wave-uniform guards, waits that shrink towards the end of the row
+    for (; g0 < total; base += 64, g0 += 16) {
+        const int nb = (int)((end - base < 64) ? end - base : 64);
+        const bool more = g0 + 16 < total;  // another batch follows
+        int nxt_col = 0;
+        float nxt_val = 0.f;
+        if (more) {
+            const int64_t e = (base + 64 + lane < end) ? base + 64 + lane : last;
+            nxt_col = cols[e];
+            nxt_val = vals[e];
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int gg = g0 + g;
+            if (gg < total) {
+                const int later = total - 1 - gg;  // groups issued after this one
+                wait_vm_upto(later < RING - 1 ? later : RING - 1);
+                dma_consume<true>(G, ring, g % RING, g, nb, rd_cur, expl);
+            }
+            if (g == 16 - RING - 2 && more) {
+                wr_nxt[0] = __builtin_bit_cast(float, nxt_col);
+                wr_nxt[64] = nxt_val;
+            }
+            if (gg + RING < total) {
+                if (g < 16 - RING)
+                    dma_issue(ring_lds, g % RING, g + RING, rd_cur, other);
+                else
+                    dma_issue(ring_lds, g % RING, g + RING - 16, rd_nxt, other);
+            }
+        }
+        float *tw = wr_cur;
+        wr_cur = wr_nxt;
+        wr_nxt = tw;
+        const float *tr = rd_cur;
+        rd_cur = rd_nxt;
+        rd_nxt = tr;
+    }
+}
+
 // slab layout: [(NTILES*4 + NT)][64] floats, register-major / lane-minor
 template <int NT>
 __host__ __device__ constexpr int slab_floats()
@@ -285,7 +517,9 @@ __global__ __launch_bounds__(256) void als_chunk_kernel(
     const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_len,
     int64_t n_chunks, const float *__restrict__ other, int ld, float *__restrict__ slabs)
 {
-    __shared__ float stage_all[4][GRAM_STAGE_WORDS];
+    constexpr bool DMA = LK_ALS_GRAM_DMA && NT == 4;
+    __shared__ __attribute__((aligned(16))) float
+        stage_all[4][GRAM_STAGE_WORDS + (DMA ? GRAM_DMA_WORDS : 0)];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t c = (int64_t)blockIdx.x * 4 + wave;
     if (c >= n_chunks) return;
@@ -295,8 +529,12 @@ __global__ __launch_bounds__(256) void als_chunk_kernel(
 #pragma unroll
     for (int t = 0; t < NT; ++t) G.y[t] = 0.f;
     const int64_t beg = chunk_beg[c];
-    gram_accumulate<NT>(G, indices, values, beg, beg + chunk_len[c], other, ld, EXPL,
-                        stage_all[wave]);
+    if constexpr (DMA)
+        gram_accumulate_dma(G, indices, values, beg, beg + chunk_len[c], other, EXPL,
+                            stage_all[wave] + GRAM_STAGE_WORDS, stage_all[wave]);
+    else
+        gram_accumulate<NT>(G, indices, values, beg, beg + chunk_len[c], other, ld, EXPL,
+                            stage_all[wave]);
     slab_store<NT>(G, slabs + (size_t)c * slab_floats<NT>());
 }
 
@@ -864,8 +1102,15 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
         for (int s = 0; s < ns; ++s)
             slab_add<NT>(G, slabs + (size_t)(first_slab + s) * slab_floats<NT>());
     } else {
-        // (the solver's LDS is idle while the normal matrix is built: its head stages the CSR)
-        gram_accumulate<NT>(G, indices, values, beg, end, other, ld_other, EXPL, lds);
+        // (the solver's LDS is idle while the normal matrix is built: it stages the CSR
+        // batches and, for k = 64, holds the ring of prefetched factor rows)
+#if LK_ALS_GRAM_DMA && LK_ALS_PANEL == 2
+        if constexpr (NT == 4)
+            gram_accumulate_dma(G, indices, values, beg, end, other, EXPL, lds,
+                                lds + LPack<KP>::SIZE + KP);
+        else
+#endif
+            gram_accumulate<NT>(G, indices, values, beg, end, other, ld_other, EXPL, lds);
     }
     if (EXPL) {
         // explicit.rs:104-107: mtm[i][i] += reg * n, AFTER the product, real features only
