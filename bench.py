@@ -70,8 +70,9 @@ def half_mfma_flops(lengths: np.ndarray, kp: int):
     instructions x 2048.  Gram: one instruction per upper tile per group of 4 entries
     (NT(NT+1)/2 per group; long rows are the chunk kernel's); for padded k > 64 also the
     blocked Cholesky's trailing updates, 4 * sum_b (NT-1-b)(NT-b)/2 per row
-    (csrc/als_blk.hip).  The k <= 64 kernel factorises on the VALU: that work (k^3/3 per row)
-    is added as plain flops.
+    (csrc/als_blk.hip).  The k <= 64 kernel factorises in 4-column panels (VALU) with MFMA
+    trailing updates (79 instructions per row at k = 64, full tiles): counted as the k^3/3
+    useful flops per row, not as what the matrix cores execute for it.
     """
     lengths = lengths.astype(np.int64)
     nt = kp // 16
@@ -753,7 +754,12 @@ def main():
     def knn_leg():
         from lkpy_amd import _knn_bench
 
-        return _knn_bench.run(ratings, dev, checker=None if args.no_cpu else knn_cpu_and_parity)
+        res = _knn_bench.run(ratings, dev, checker=None if args.no_cpu else knn_cpu_and_parity)
+        if isinstance(res.get("roofline"), dict) and args.scale == 1.0:
+            # HBM bytes of the build kernel from the committed PMC summary of the same workload
+            res["roofline"]["traffic"], res["roofline"]["traffic_source"] = pmc_traffic(
+                "r*_knn_*_counters.csv", "iknn_build_kernel")
+        return res
 
     def sharded_legs():
         """

@@ -333,6 +333,24 @@ int lk_csr_rows_dot(const void *d_indptr, int indptr_is_64, const int32_t *d_ind
                     const float *d_values, int64_t n_rows, const float *d_x, int64_t ld_x,
                     int64_t n_queries, float *d_out, int64_t ld_out, void *stream);
 
+/* ------------------------------------------------------------------------
+ * EASE (`EASEScorer`, src/lenskit/knn/ease.py:88-147).
+ * lk_ease_gram: the dense matrix the model inverts, G = X^T X + reg I for the binary
+ *   users x items matrix X (`rates.co_occurrences("item", include_self=True, dense=True)` +
+ *   the regularisation on the diagonal, ease.py:111-119; counting kernels
+ *   src/accel/data/cooc.rs:47-192), from the off-diagonal co-occurrence counts in CSR form
+ *   (the similarity build run on unit values, int64 offsets) and the item counts.
+ * lk_ease_score_batch: `scores = q_vec @ self.weights` (ease.py:161-168) for a batch of
+ *   queries: out[q][c] = sum over the history items i of query q of weights[i][c]
+ *   (hist_items[hist_ptr[q]..hist_ptr[q+1]); items outside [0, n_items) are skipped).
+ * ---------------------------------------------------------------------- */
+int lk_ease_gram(const int64_t *d_cooc_indptr, const int32_t *d_cooc_indices,
+                 const float *d_cooc_values, const int32_t *d_item_counts, int64_t n_items,
+                 float reg, float *d_out, int64_t ld_out, void *stream);
+int lk_ease_score_batch(const int64_t *d_hist_ptr, const int32_t *d_hist_items,
+                        int64_t n_queries, const float *d_weights, int64_t n_items, int64_t ld_w,
+                        float *d_out, int64_t ld_out, void *stream);
+
 /* Batched fold-in (new-user embeddings) -- `ImplicitMFScorer.new_user_embedding` /
  * `_train_new_row` (src/lenskit/als/_implicit.py:77-130) -- is the SAME algebra as one ALS
  * row with OtOr = Q^T Q + user_reg I: build a plan over the histories' CSR offsets and call

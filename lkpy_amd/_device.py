@@ -489,6 +489,42 @@ def csr_rows_dot(csr: DeviceCSR, x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def ease_gram(cooc: DeviceCSR, item_counts: torch.Tensor, reg: float) -> torch.Tensor:
+    """
+    ``X^T X + reg I`` as a dense [n x n] f32 device matrix (lk_ease_gram) from the off-diagonal
+    co-occurrence counts (``iknn_build`` of the binary matrix, threshold 0.5) and the item counts.
+    """
+    lib = _native.require_gpu()
+    n = int(cooc.shape[0])
+    out = torch.empty((n, n), dtype=torch.float32, device=cooc.indices.device)
+    assert cooc.indptr.dtype == torch.int64 and item_counts.dtype == torch.int32
+    check(
+        lib.lk_ease_gram(_ptr(cooc.indptr), _ptr(cooc.indices), _ptr(cooc.values),
+                         _ptr(item_counts), n, float(reg), _ptr(out), n, _stream()),
+        "lk_ease_gram",
+    )
+    return out
+
+
+def ease_score_batch(hist_ptr: torch.Tensor, hist_items: torch.Tensor,
+                     weights: torch.Tensor) -> torch.Tensor:
+    "Sum of the history items' weight rows per query, [B x n_items] f32 (lk_ease_score_batch)."
+    lib = _native.require_gpu()
+    n = int(weights.shape[0])
+    B = int(hist_ptr.shape[0]) - 1
+    assert hist_ptr.dtype == torch.int64 and hist_items.dtype == torch.int32
+    assert weights.dtype == torch.float32 and weights.is_contiguous()
+    out = torch.empty((B, n), dtype=torch.float32, device=weights.device)
+    for lo in range(0, B, 65535):
+        hi = min(B, lo + 65535)
+        check(
+            lib.lk_ease_score_batch(_ptr(hist_ptr[lo:]), _ptr(hist_items), hi - lo,
+                                    _ptr(weights), n, n, _ptr(out[lo:]), n, _stream()),
+            "lk_ease_score_batch",
+        )
+    return out
+
+
 def score_dense(users: torch.Tensor, items: torch.Tensor, k: int) -> torch.Tensor:
     "All (user, item) scores, [B x I] f32 (lk_score_dense)."
     lib = _native.require_gpu()

@@ -113,6 +113,10 @@ def _declare(lib):
         "lk_csr_rows_dot": (
             c_int, [vp, c_int, vp, vp, c_int64, vp, c_int64, c_int64, vp, c_int64, vp]
         ),
+        "lk_ease_gram": (c_int, [vp, vp, vp, vp, c_int64, c_float, vp, c_int64, vp]),
+        "lk_ease_score_batch": (
+            c_int, [vp, vp, c_int64, vp, c_int64, c_int64, vp, c_int64, vp]
+        ),
         "lk_score_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32]),
         "lk_score_topk": (
             c_int,

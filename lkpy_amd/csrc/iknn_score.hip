@@ -284,3 +284,86 @@ extern "C" int lk_csr_rows_dot(const void *d_indptr, int indptr_is_64, const int
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }
+
+// ---------------------------------------------------------------------------
+// EASE (src/lenskit/knn/ease.py).
+//
+// lk_ease_gram: the dense, regularised co-occurrence Gramian the model inverts,
+//     G = X^T X + reg I   (X = the binary users x items matrix; ease.py:111-119),
+// from the device similarity build run on unit values (off-diagonal cells: every shared user
+// adds 1.0f, exact integers) plus the item counts on the diagonal.  One lane per stored cell.
+//
+// lk_ease_score_batch: scores = q_vec @ weights (ease.py:161-168) for a batch of queries:
+// q_vec is the 0/1 indicator of the query's history, so a query's scores are the SUM of the
+// history items' weight rows.  Workgroup = (query, 256-column strip), rows added in history
+// order (plain f32 adds: deterministic).
+// ---------------------------------------------------------------------------
+namespace lk {
+__global__ void ease_gram_fill_kernel(const int64_t *__restrict__ ptr,
+                                      const int32_t *__restrict__ idx,
+                                      const float *__restrict__ val, int64_t n,
+                                      float *__restrict__ g, int64_t ld)
+{
+    const int64_t row = blockIdx.x;
+    const int64_t b = ptr[row], e = ptr[row + 1];
+    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) g[row * ld + idx[i]] = val[i];
+}
+
+__global__ void ease_gram_diag_kernel(const int32_t *__restrict__ counts, int64_t n, float reg,
+                                      float *__restrict__ g, int64_t ld)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) g[i * ld + i] = (float)counts[i] + reg;
+}
+
+__global__ __launch_bounds__(256) void ease_score_kernel(
+    const int64_t *__restrict__ hist_ptr, const int32_t *__restrict__ hist_items,
+    const float *__restrict__ w, int64_t n_items, int64_t ld_w, float *__restrict__ out,
+    int64_t ld_out)
+{
+    const int64_t q = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_items) return;
+    const int64_t b = hist_ptr[q], e = hist_ptr[q + 1];
+    float acc = 0.f;
+    for (int64_t i = b; i < e; ++i) {
+        const int32_t it = hist_items[i];
+        if (it >= 0 && it < n_items) acc += w[(int64_t)it * ld_w + c];
+    }
+    out[q * ld_out + c] = acc;
+}
+}  // namespace lk
+
+extern "C" int lk_ease_gram(const int64_t *d_cooc_indptr, const int32_t *d_cooc_indices,
+                            const float *d_cooc_values, const int32_t *d_item_counts,
+                            int64_t n_items, float reg, float *d_out, int64_t ld_out, void *stream)
+{
+    LK_REQUIRE(n_items >= 0 && ld_out >= n_items, "lk_ease_gram: bad shape");
+    if (n_items == 0) return LK_OK;
+    LK_REQUIRE(d_cooc_indptr && d_item_counts && d_out, "lk_ease_gram: null pointer");
+    hipStream_t st = lk::as_stream(stream);
+    LK_HIP_CHECK(hipMemsetAsync(d_out, 0, (size_t)n_items * ld_out * sizeof(float), st));
+    hipLaunchKernelGGL(lk::ease_gram_fill_kernel, dim3((unsigned)n_items), dim3(256), 0, st,
+                       d_cooc_indptr, d_cooc_indices, d_cooc_values, n_items, d_out, ld_out);
+    hipLaunchKernelGGL(lk::ease_gram_diag_kernel, dim3((unsigned)((n_items + 255) / 256)),
+                       dim3(256), 0, st, d_item_counts, n_items, reg, d_out, ld_out);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+extern "C" int lk_ease_score_batch(const int64_t *d_hist_ptr, const int32_t *d_hist_items,
+                                   int64_t n_queries, const float *d_weights, int64_t n_items,
+                                   int64_t ld_w, float *d_out, int64_t ld_out, void *stream)
+{
+    LK_REQUIRE(n_queries >= 0 && n_items >= 0 && ld_w >= n_items && ld_out >= n_items,
+               "lk_ease_score_batch: bad shape");
+    if (n_queries == 0 || n_items == 0) return LK_OK;
+    LK_REQUIRE(d_hist_ptr && d_weights && d_out, "lk_ease_score_batch: null pointer");
+    LK_REQUIRE(n_queries <= 65535, "lk_ease_score_batch: at most 65535 queries per call");
+    hipLaunchKernelGGL(lk::ease_score_kernel,
+                       dim3((unsigned)((n_items + 255) / 256), (unsigned)n_queries), dim3(256), 0,
+                       lk::as_stream(stream), d_hist_ptr, d_hist_items, d_weights, n_items, ld_w,
+                       d_out, ld_out);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}

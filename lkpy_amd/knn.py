@@ -1,6 +1,7 @@
 """
 Component seam for neighbourhood models -- item-based k-NN and user-based
-k-NN (end of the file, mirror of ``lenskit.knn.UserKNNScorer``, src/lenskit/knn/user.py:25-316).
+k-NN (mirror of ``lenskit.knn.UserKNNScorer``, src/lenskit/knn/user.py:25-316) and EASE (end of
+the file, mirror of ``lenskit.knn.EASEScorer``, src/lenskit/knn/ease.py).
 
 Item-based k-NN: mirror of ``lenskit.knn.ItemKNNScorer`` /
 ``ItemKNNConfig`` (src/lenskit/knn/item.py:41-295).  Matrix preparation is the reference's
@@ -329,6 +330,116 @@ class UserKNNScorer(Component):
                 sc[:] = np.nan  # no candidate neighbours (user.py:217-219)
             out[i] = ItemList(item_lists[i], scores=sc + np.float32(data[i][2]))
         return out  # type: ignore[return-value]
+
+    def __call__(self, query, items: ItemList) -> ItemList:
+        return self.score_batch([query], [items])[0]
+
+
+class EASEConfig(BaseModel, extra="forbid"):
+    "``EASEConfig`` (src/lenskit/knn/ease.py:36-44)."
+
+    regularization: PositiveFloat = 1
+    "Regularization term for EASE."
+
+
+class EASEScorer(Component):
+    """
+    Embarrassingly shallow autoencoder (``EASEScorer``, src/lenskit/knn/ease.py:47-170;
+    SURVEY.md section 8f rank 4).  Training: the dense item-item co-occurrence Gramian
+    ``X^T X + reg I`` is built on the device (the similarity-build kernel on unit values +
+    ``lk_ease_gram``), inverted there with the very PyTorch calls of the reference's
+    ``_chol_invert_torch`` (``torch.linalg.cholesky_ex`` + ``torch.cholesky_inverse``,
+    ease.py:190-208 -- a library factorisation, as in the reference), and turned into the
+    weight matrix ``B = inv / -diag(inv)`` with a zero diagonal.  Scoring = sum of the history
+    items' weight rows (``lk_ease_score_batch``), whole batches of queries at a time.
+    """
+
+    config: EASEConfig
+
+    items: Vocabulary
+    weights: np.ndarray
+
+    def is_trained(self):
+        return hasattr(self, "weights")
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.pop("_dev", None)
+        return st
+
+    def train(self, data: Dataset, options: TrainingOptions = TrainingOptions()):
+        solver = options.env_var("LK_EASE_SOLVER", None)
+        if solver and solver not in ("torch", "scipy"):
+            raise ValueError(f"unsupported option: LK_EASE_SOLVER={solver}")  # ease.py:96-97
+        if solver == "scipy":
+            raise ValueError("LK_EASE_SOLVER=scipy: the device backend has no host solver")
+        n_items = data.item_count
+        ui = data.interactions().matrix().scipy(attribute=None).astype(np.float32)
+        ui = sps.csr_array(ui)
+        ui.sum_duplicates()
+        ui.data[:] = 1.0  # co-occurrences count (user, item) pairs once
+        ui.sort_indices()
+        iu = sps.csr_array(ui.T)
+        iu.sort_indices()
+        d = D.device()
+        cooc = D.iknn_build(D.DeviceCSR.from_scipy(ui, d), D.DeviceCSR.from_scipy(iu, d), 0.5)
+        counts = torch.from_numpy(np.diff(iu.indptr).astype(np.int32)).to(d)
+        gram = D.ease_gram(cooc, counts, float(self.config.regularization))
+        del cooc
+        with torch.inference_mode():
+            decomp, info = torch.linalg.cholesky_ex(gram)
+            if info.item():
+                # ease.py:202-203
+                raise RuntimeError(f"matrix minor {info.item()} is not positive-definite.")
+            inv = torch.cholesky_inverse(decomp, out=gram)
+            del decomp
+            # divide cells by the column's diagonal entry, zero the diagonal (ease.py:140-142)
+            inv /= -torch.diagonal(inv).reshape(1, -1).clone()
+            inv.fill_diagonal_(0.0)
+            mat = inv.cpu().numpy()
+        self.items = data.items
+        self.weights = mat
+        self.__dict__.pop("_dev", None)
+        assert self.weights.shape == (n_items, n_items)
+
+    def _device_weights(self):
+        w = getattr(self, "_dev", None)
+        if w is None:
+            w = torch.from_numpy(np.ascontiguousarray(self.weights, dtype=np.float32)).to(
+                D.device())
+            self._dev = w
+        return w
+
+    def score_batch(self, queries, item_lists) -> list[ItemList]:
+        "Scores for a batch of (query, items) pairs; one device call for all of them."
+        w = self._device_weights()
+        hists, ok = [], []
+        for query in queries:
+            query = RecQuery.create(query)
+            q_items = query.query_items
+            good = np.empty(0, np.int32)
+            if q_items is not None:
+                q_inos = q_items.numbers(vocabulary=self.items, missing="negative")
+                good = q_inos[q_inos >= 0].astype(np.int32)
+            hists.append(good)
+            ok.append(len(good) > 0)  # ease.py:150-158: no usable history => all NaN
+        ptr = np.zeros(len(hists) + 1, dtype=np.int64)
+        np.cumsum([len(h) for h in hists], out=ptr[1:])
+        cat = np.concatenate(hists) if hists else np.empty(0, np.int32)
+        scores = D.ease_score_batch(torch.from_numpy(ptr).to(w.device),
+                                    torch.from_numpy(np.ascontiguousarray(cat)).to(w.device),
+                                    w).cpu().numpy()
+        out = []
+        for i, items in enumerate(item_lists):
+            if not ok[i]:
+                out.append(ItemList(items, scores=np.nan))
+                continue
+            t_inos = items.numbers(vocabulary=self.items, missing="negative")
+            sc = np.full(len(items), np.nan, dtype=np.float32)
+            t_ok = t_inos >= 0
+            sc[t_ok] = scores[i][t_inos[t_ok]]
+            out.append(ItemList(items, scores=sc))
+        return out
 
     def __call__(self, query, items: ItemList) -> ItemList:
         return self.score_batch([query], [items])[0]

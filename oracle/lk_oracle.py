@@ -604,6 +604,45 @@ def uknn_predict(user_vectors, user_ratings, user_means, uidx, items, max_nbrs, 
 # --------------------------------------------------------------------------
 
 
+def ease_train(ui: sps.csr_array, reg: float = 1.0) -> np.ndarray:
+    """
+    EASE weights as ``EASEScorer.train`` computes them (src/lenskit/knn/ease.py:108-146): dense
+    co-occurrence counts of the binary users x items matrix incl. the diagonal (f32),
+    ``+ reg`` on the diagonal, SPD inverse (``_chol_invert_scipy``: ``spla.inv(assume_a="pos")``,
+    ease.py:182-187), every column divided by minus its diagonal entry, diagonal zeroed.
+    Parity unpinned: the reference holds no golden EASE weights (tests/knn/test_ease.py only
+    runs the generic component tests); the inverse is LAPACK's.
+    """
+    import scipy.linalg as spla
+
+    x = sps.csr_array(ui, dtype=np.float32)
+    x.sum_duplicates()
+    x.data[:] = 1.0
+    cooc = np.asarray((x.T @ x).todense(), dtype=np.float32)
+    n = cooc.shape[0]
+    di = np.diag_indices(n)
+    cooc[di] += np.float32(reg)
+    # `spla.inv(assume_a="pos")` (SciPy >= 1.17) = LAPACK potrf + potri; SciPy 1.15 here
+    # offers the same two routines directly
+    c, info = spla.lapack.spotrf(cooc, lower=1, overwrite_a=1)
+    if info:
+        raise RuntimeError(f"matrix minor {info} is not positive-definite.")
+    mat, info = spla.lapack.spotri(c, lower=1, overwrite_c=1)
+    assert info == 0
+    mat = np.tril(mat) + np.tril(mat, -1).T  # potri fills one triangle
+    mat /= -np.diag(mat).reshape(1, -1)
+    mat[di] = 0
+    return mat
+
+
+def ease_score(weights: np.ndarray, hist_items: np.ndarray) -> np.ndarray:
+    "``q_vec @ self.weights`` with the 0/1 history indicator (ease.py:161-168)."
+    n = weights.shape[0]
+    q_vec = np.zeros(n, dtype=np.float32)
+    q_vec[hist_items] = 1.0
+    return q_vec @ weights
+
+
 def load_ml_small(path=None):
     """
     The ml-latest-small fixture as the reference's ``ml_ds`` sees it

@@ -360,3 +360,20 @@ def test_user_knn_golden_predictions(oracle, ml_small):
         err = np.abs(p - g.prediction.values)
         worst = max(worst, float(err[~np.isnan(err)].max()))
     assert missing == 0 and worst < 1e-4, (missing, worst)
+
+
+def test_ease_oracle_closed_form(oracle, rng):
+    "oracle.ease_train against the textbook EASE solution B = I - P diag(1/diag P), P = (G + reg I)^-1"
+    import scipy.sparse as sps
+
+    m = sps.random(80, 30, density=0.15, random_state=rng, format="csr", dtype=np.float32)
+    m.data[:] = 1.0
+    w = oracle.ease_train(sps.csr_array(m), 3.0)
+    x = m.toarray().astype(np.float64)
+    p = np.linalg.inv(x.T @ x + 3.0 * np.eye(30))
+    b = np.eye(30) - p / np.diag(p).reshape(1, -1)
+    b[np.diag_indices(30)] = 0.0
+    assert np.all(np.diag(w) == 0.0)
+    assert np.allclose(w, b, rtol=1e-4, atol=1e-6)
+    hist = np.array([1, 4, 9])
+    assert np.allclose(oracle.ease_score(w, hist), w[hist].sum(axis=0), rtol=1e-6, atol=1e-7)

@@ -1,5 +1,7 @@
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_als.py tests/test_gpu_als_explicit.py tests/test_gpu_pipeline.py tests/test_gpu_scale.py -m gpu -q -x > gpurun_out/gputest_als.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gputest_als.log
-tail -4 gpurun_out/gputest_als.log
-timeout 600 python tools/als_variants.py tools/_variants/lkamd_nopipe.so tools/_variants/lkamd_nodma.so > gpurun_out/variants_g.log 2>&1
-cut -c1-420 gpurun_out/variants_g.log
+timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gputest.log
+tail -3 gpurun_out/gputest.log
+timeout 600 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?" >> gpurun_out/bench.err
+timeout 600 bash tools/prof_als.sh r02b > gpurun_out/prof_als.log 2>&1
+timeout 600 bash tools/prof_knn.sh r02 > gpurun_out/prof_knn.log 2>&1
+cut -c1-600 gpurun_out/bench.log; tail -2 gpurun_out/bench.err
