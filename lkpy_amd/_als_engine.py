@@ -148,6 +148,14 @@ class HipBackend:
     def upload(self, mat: np.ndarray) -> torch.Tensor:
         return self.D.to_device_padded(mat, self.dev)
 
+    def upload_permuted(self, mat: np.ndarray, new_of_old: np.ndarray, n_new: int) -> torch.Tensor:
+        "[n_new x KP] device matrix with row new_of_old[i] = mat[i] (other rows zero)"
+        src = self.D.to_device_padded(np.ascontiguousarray(mat, dtype=np.float32), self.dev)
+        out = torch.zeros((n_new, src.shape[1]), dtype=torch.float32, device=self.dev)
+        out.index_copy_(0, torch.from_numpy(np.asarray(new_of_old, dtype=np.int64)).to(self.dev),
+                        src)
+        return out
+
     def random_init(self, n: int, old_of_new: np.ndarray, seed: int) -> torch.Tensor:
         "[n x KP] factors ~ (N(0,1) * 0.01)^2 drawn on the device; padding rows / columns zero"
         g = torch.Generator(device=self.dev)
@@ -160,6 +168,11 @@ class HipBackend:
 
     def download(self, mat: torch.Tensor) -> np.ndarray:
         return self.D.to_host_unpadded(mat, self.k)
+
+    def download_rows(self, mat: torch.Tensor, rows: np.ndarray) -> np.ndarray:
+        "rows of a device factor matrix, in the given order, as a host [len(rows) x k] array"
+        idx = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(mat.device)
+        return self.D.to_host_unpadded(mat.index_select(0, idx), self.k)
 
     def gramian(self, rows: torch.Tensor, reg: float) -> torch.Tensor:
         return self._gram(rows, reg)
@@ -192,6 +205,7 @@ class ImplicitALSEngine:
         backend,
         group=None,
         explicit: bool = False,
+        defer_init: bool = False,
     ):
         self.k = int(k)
         self.backend = backend
@@ -205,6 +219,13 @@ class ImplicitALSEngine:
         n_users, n_items = ui.shape
         self.n_users, self.n_items = n_users, n_items
         on_device = hasattr(ui, "h_indptr")  # a DeviceCSR: the matrix is already in HBM
+        if not on_device and hasattr(backend, "make_plans_on_device"):
+            # product path: ONE upload of the original CSR; everything derived from it (item
+            # counts, relabelling, the other orientation) is computed in HBM
+            ui = sps.csr_array(ui)
+            ui = backend.D.DeviceCSR.from_arrays(ui.indptr, ui.indices, ui.data, ui.shape,
+                                                 backend.dev)
+            on_device = True
         if on_device:
             ulen = np.diff(ui.h_indptr)
             ilen = torch.bincount(ui.indices, minlength=n_items).cpu().numpy()
@@ -234,11 +255,28 @@ class ImplicitALSEngine:
             self.local_nnz = (int(ui_new.indptr[self.u_hi] - ui_new.indptr[self.u_lo]),
                               int(iu_new.indptr[self.i_hi] - iu_new.indptr[self.i_lo]))  # fmt: skip
 
+        self._nu, self._ni = nu, ni
+        self._qtq = None
+        if not defer_init:
+            self.set_initial(user_init, item_init)
+        self.epochs_trained = 0
+
+    def set_initial(self, user_init, item_init):
+        """
+        Initial factors (host arrays in the original labelling, or None for the reference's
+        recipe drawn in HBM).  Separate from the constructor so that a trainer can draw the
+        host random numbers WHILE the matrix is uploaded, relabelled and transposed.
+        """
+        backend, nu, ni = self.backend, self._nu, self._ni
         if user_init is None:
             # bench-scale models (10^7 x 256): the reference's recipe ((N(0,1) * 0.01)^2, items
             # first) drawn in HBM instead of crossing PCIe with 11 GB of host random numbers
             self.Q = backend.random_init(ni, self.i_old, seed=1)
             self.P = backend.random_init(nu, self.u_old, seed=2)
+        elif hasattr(backend, "upload_permuted"):
+            # product path: upload in the original order, permute in HBM
+            self.P = backend.upload_permuted(user_init, self.u_new, nu)
+            self.Q = backend.upload_permuted(item_init, self.i_new, ni)
         else:
             P = np.zeros((nu, self.k), dtype=np.float32)
             Q = np.zeros((ni, self.k), dtype=np.float32)
@@ -250,12 +288,11 @@ class ImplicitALSEngine:
             # every rank must start from the SAME factors (the first user half mixes the local Q
             # with an all-reduced Gramian): rank 0's initialisation wins, whatever the ranks'
             # generators drew (unseeded runs draw differently on every rank)
-            dist.broadcast(self.P, src=_global_rank(group, 0), group=self.group)
-            dist.broadcast(self.Q, src=_global_rank(group, 0), group=self.group)
+            dist.broadcast(self.P, src=_global_rank(self.group, 0), group=self.group)
+            dist.broadcast(self.Q, src=_global_rank(self.group, 0), group=self.group)
         # Gramian of the initial Q (user half of epoch 1 needs it); padding rows are 0
         self._qtq = None if self.explicit else self._gramian(self.Q, self.i_lo, self.i_hi,
                                                              self.user_reg)
-        self.epochs_trained = 0
 
     # -- collectives ---------------------------------------------------------
     def _gramian(self, full: torch.Tensor, lo: int, hi: int, reg: float) -> torch.Tensor:
@@ -329,9 +366,13 @@ class ImplicitALSEngine:
 
     # -- results (host, original labelling) ------------------------------------
     def user_embeddings(self) -> np.ndarray:
+        if hasattr(self.backend, "download_rows"):
+            return self.backend.download_rows(self.P, self.u_new)  # gathered in HBM
         return self.backend.download(self.P)[self.u_new]
 
     def item_embeddings(self) -> np.ndarray:
+        if hasattr(self.backend, "download_rows"):
+            return self.backend.download_rows(self.Q, self.i_new)
         return self.backend.download(self.Q)[self.i_new]
 
     def otor(self) -> np.ndarray:
