@@ -10,6 +10,7 @@ process group.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -201,6 +202,13 @@ class ALSPlan:
                               device=dev)
         self.frob = torch.zeros(1, dtype=torch.float32, device=dev)
         self.solver = int(lib.lk_als_plan_solver(self._h))
+        # rows with <= 16 entries at padded k > 64: Woodbury path (csrc/als_wb.hip) when there
+        # are enough of them to pay for Z = other @ OtOr^-1 (LK_ALS_WB_MIN_ROWS; 0 disables)
+        self.short_rows = int(lib.lk_als_plan_short_rows(self._h))
+        wb_min = int(os.environ.get("LK_ALS_WB_MIN_ROWS", "4096"))
+        self.use_wb = (self.kp > 64 and self.solver == _native.SOLVER_CHOLESKY and wb_min > 0
+                       and self.short_rows >= wb_min)
+        self._z = None
 
     def set_ctl(self, ctl: "TaskCtl | None"):
         "Attach (or detach) a cancel / progress block; check_status then reports a cancel."
@@ -218,6 +226,14 @@ class ALSPlan:
         csr = self.csr
         assert this.shape == (csr.shape[0], self.kp) and other.shape == (csr.shape[1], self.kp)
         assert this.is_contiguous() and other.is_contiguous() and otor.is_contiguous()
+        if self.use_wb:
+            # OtOr^-1 once per half-epoch in float64 (k x k: a library inverse, plumbing), then
+            # Z = other @ OtOr^-1 on the scoring GEMM of this library (f32 MFMA, k-ordered)
+            k, kp = self.k, self.kp
+            ginv = torch.zeros((kp, kp), dtype=torch.float32, device=other.device)
+            ginv[:k, :k] = torch.linalg.inv(otor[:k, :k].to(torch.float64)).to(torch.float32)
+            self._z = score_dense(other, ginv, k)  # [n_cols x KP]; row i of ginv = column i
+            check(_native.load().lk_als_plan_set_z(self._h, _ptr(self._z)), "lk_als_plan_set_z")
         check(
             _native.load().lk_als_implicit_half_epoch(
                 self._h, _ptr(csr.indptr), _ptr(csr.indices), _ptr(csr.values),

@@ -671,12 +671,22 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
         hipLaunchKernelGGL((als_blk_chunk_kernel<NT, EXPL>), dim3((unsigned)p->n_chunks), dim3(256),
                            0, st, indices, values, p->d_chunk_beg, p->d_chunk_len, other, slabs);
     if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
-    if (n_rows > 0) {
-        const dim3 grid((unsigned)n_rows), block(256);
+    // short rows (<= 16 entries) of the implicit model: Woodbury kernel, when the caller
+    // supplied Z = other * OtOr^-1 for this half-epoch (never with a task-control block: the
+    // kernel does not poll it)
+    const bool use_wb = !EXPL && p->d_z != nullptr && !p->ctl && p->t_short < n_rows;
+    const int64_t n_dense = use_wb ? p->t_short : n_rows;
+    if (use_wb) {
+        int rc = als_wb_launch(p, indptr, IS64 ? 1 : 0, indices, values, p->t_short, n_rows,
+                               this_, other, p->d_z, row_delta, status, st);
+        if (rc != LK_OK) return rc;
+    }
+    if (n_dense > 0) {
+        const dim3 grid((unsigned)n_dense), block(256);
         const IT *ip = static_cast<const IT *>(indptr);
 #define LK_BLK_LAUNCH(KERN, CTLV)                                                                \
     hipLaunchKernelGGL((KERN<IS64, EXPL, CTLV>), grid, block, 0, st, ip, indices, values,        \
-                       p->d_order, n_rows, p->d_row_slab, other, this_, notor_p, slabs,          \
+                       p->d_order, n_dense, p->d_row_slab, other, this_, notor_p, slabs,         \
                        row_delta, status, k, reg, (CTLV) ? p->ctl->dev() : TaskCtlDev{})
         if constexpr (NT == 16) {
             if (p->ctl)

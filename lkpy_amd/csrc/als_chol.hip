@@ -1446,6 +1446,18 @@ extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int i
     std::stable_sort(order.begin(), order.end(),
                      [&](int32_t x, int32_t y) { return len(x) > len(y); });
 
+    {
+        // first task whose row has <= 16 entries (the order is longest first)
+        int64_t lo = 0, hi = n_rows;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (len(order[(size_t)mid]) > 16)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        p->t_short = lo;
+    }
     std::vector<int32_t> row_slab((size_t)n_rows, -1);
     std::vector<int32_t> chunk_row;
     std::vector<int64_t> chunk_beg;
@@ -1545,6 +1557,18 @@ extern "C" int lk_als_plan_set_ctl(lk_als_plan *p, lk_task_ctl *ctl)
 {
     LK_REQUIRE(p != nullptr, "lk_als_plan_set_ctl: null plan");
     p->ctl = ctl;
+    return LK_OK;
+}
+
+extern "C" int64_t lk_als_plan_short_rows(const lk_als_plan *p)
+{
+    return p ? p->n_rows - p->t_short : 0;
+}
+
+extern "C" int lk_als_plan_set_z(lk_als_plan *p, const float *d_z)
+{
+    LK_REQUIRE(p != nullptr, "lk_als_plan_set_z: null plan");
+    p->d_z = d_z;
     return LK_OK;
 }
 

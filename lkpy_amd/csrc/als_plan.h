@@ -19,6 +19,11 @@ struct lk_als_plan {
     int32_t is64 = 0;  // width of the CSR offsets the plan was built from
     int64_t n_chunks = 0;
     int64_t n_long = 0;
+    // rows with <= 16 entries are a suffix [t_short, n_rows) of the longest-first order; for
+    // padded k > 64 the implicit model solves them through the Woodbury kernel (als_wb.hip)
+    // when the caller supplied Z = other * OtOr^-1 for this half-epoch (lk_als_plan_set_z)
+    int64_t t_short = 0;
+    mutable const float *d_z = nullptr;
     // device-side schedule
     int32_t *d_order = nullptr;      // [n_rows] rows, longest first
     int32_t *d_row_slab = nullptr;   // [n_rows] first slab of the row or -1
@@ -46,6 +51,11 @@ int als_blk_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const
                        const float *values, int64_t n_rows, int k, float *this_, const float *other,
                        const float *otor, int ld_otor, char *ws, float *out_frob, hipStream_t st,
                        bool expl, float reg);
+// rows [t0, n_rows) of the plan order (<= 16 entries each) through the Woodbury kernel (als_wb.hip)
+int als_wb_launch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
+                  const float *values, int64_t t0, int64_t n_rows, float *this_,
+                  const float *other, const float *z, float *row_delta, int *status,
+                  hipStream_t st);
 // deterministic two-stage sum of the per-row squared deltas -> sqrt (als_chol.hip)
 int launch_delta_reduce(const float *row_delta, int64_t n_rows, float *partial, float *out_frob,
                         hipStream_t st);

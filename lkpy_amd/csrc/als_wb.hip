@@ -1,0 +1,229 @@
+// als_wb.hip -- implicit-ALS row solve for SHORT rows at large k (padded k = 128 / 256) through
+// the Woodbury identity, gfx950.
+//
+// `train_row_solve` (src/accel/als/implicit.rs:87-125) solves, for every row,
+//     A x = y,   A = OtOr + sum_j v_j q_j q_j^T,   y = sum_j (v_j + 1) q_j
+// with a dense k x k Cholesky (sposv, src/accel/als/solve.rs:65-107): k^3/3 flops per row
+// whatever the row's length n.  For n << k (cfg5: mean 10 entries, k = 256 -- 94 % of the user
+// rows have n <= 16) A is a rank-n update of the SAME matrix G = OtOr for every row of the
+// half-epoch, and with G^-1 known the solve collapses to an n x n system:
+//     M' = diag(sqrt v) M (rows sqrt(v_j) q_j^T),   A = G + M'^T M'
+//     A^-1 = G^-1 - G^-1 M'^T (I + M' G^-1 M'^T)^-1 M' G^-1
+// With z_j = G^-1 q_j (rows of Z = Q G^-1, ONE plain GEMM per half-epoch), w_j = v_j + 1 and
+// S0 = [q_i . z_j] (n x n):
+//     S = I + diag(sqrt v) S0 diag(sqrt v),   S u = sqrt(v) o (S0 w),   x = sum_j (w_j - sqrt(v_j) u_j) z_j
+// -- the same x in exact arithmetic (a direct method, no iteration, no tolerance), for
+// O(n^2 k) instead of k^3/3 flops: ~200x fewer at n = 10, k = 256.  G^-1 is computed once per
+// half-epoch in float64 by the host side (`ALSPlan.half_epoch`), so the error of this path is
+// dominated by the f32 dot products, like the reference's.
+//
+// Kernel: ONE WAVE PER ROW, rows with n <= 16 (plan order is longest-first: they are a suffix
+// of it, empty rows included).  Lane (s, c) = (feature quarter s, entry slot c) loads the
+// quarter s of q_c and of z_c (KP/4 contiguous floats each: the 16 lanes of a quarter read 16
+// rows, a row is read by 4 lanes as 4 contiguous pieces).  S0 is ONE 16 x 16 MFMA tile:
+// v_mfma_f32_16x16x4_f32 with A = the lane's q values, B = its z values, summed over the
+// quarter's features (the MFMA's k index is the quarter).  The 16 x 16 system is solved in lanes
+// 0..15 (lane = row, v_readlane multipliers), and x = sum_j g_j z_j is a 16-lane DPP butterfly
+// over the registers that already hold z.  Entry slots >= n carry zero weights.
+//
+// Bound: gather bandwidth (2 n rows of 4 KP bytes per solved row) -- cfg5 user half: 22 M
+// entries x 2 KiB = 45 GB.
+#include "als_plan.h"
+#include "common.h"
+
+namespace lk {
+namespace wb {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x)
+{
+    const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false);
+    return x + __builtin_bit_cast(float, y);
+}
+// sum over the 16 lanes of a row group, result in every lane of the group
+__device__ __forceinline__ float row16_sum(float x)
+{
+    x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]
+    x = dpp_add<0x141>(x);  // row_half_mirror
+    x = dpp_add<0x140>(x);  // row_mirror
+    return x;
+}
+
+constexpr int WB_MAX_N = 16;
+constexpr int WB_LDS = 16 * 16 + 16;  // S (or L) tile + right-hand side, per wave
+
+template <int KP, bool IS64>
+__global__ __launch_bounds__(256) void als_wb_kernel(
+    const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_tasks,
+    const float *__restrict__ other, const float *__restrict__ z, float *__restrict__ this_,
+    float *__restrict__ row_delta, int *__restrict__ status)
+{
+    constexpr int QF = KP / 4;  // features per quarter
+    constexpr int NQ = QF / 4;  // float4 per quarter
+    __shared__ __attribute__((aligned(16))) float lds_all[4][WB_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int s = lane >> 4, c = lane & 15;
+    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    if (t >= n_tasks) return;
+    const int row = order[t];
+    const int64_t beg = indptr[row], end = indptr[row + 1];
+    const int n = (int)(end - beg);
+    float *xrow = this_ + (int64_t)row * KP;
+    float *lds = lds_all[wave];
+
+    if (n == 0) {  // implicit.rs:98-101
+        for (int f = lane; f < KP; f += 64) xrow[f] = 0.f;
+        if (lane == 0) row_delta[row] = 0.f;
+        return;
+    }
+    // entry of slot c (slots >= n re-read the last entry with zero weights)
+    const int64_t e = beg + (c < n ? c : n - 1);
+    const int col = indices[e];
+    const float v = c < n ? values[e] : 0.f;
+    const float w = c < n ? v + 1.0f : 0.f;  // `vals += 1.0` (implicit.rs:116)
+    const float sv = __builtin_sqrtf(v);     // v < 0: NaN -> reported as not positive definite
+
+    f32x4 mq[NQ], zq[NQ];
+    {
+        const f32x4 *mp = reinterpret_cast<const f32x4 *>(other + (int64_t)col * KP + s * QF);
+        const f32x4 *zp = reinterpret_cast<const f32x4 *>(z + (int64_t)col * KP + s * QF);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) mq[q] = mp[q];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) zq[q] = zp[q];
+    }
+    // S0[i][j] = q_i . z_j : lane (s', c') register r = S0[4 s' + r][c']
+    f32x4 S0 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int el = 0; el < 4; ++el)
+            S0 = __builtin_amdgcn_mfma_f32_16x16x4f32(mq[q][el], zq[q][el], S0, 0, 0, 0);
+
+    // r0 = S0 w (row sums weighted by the column's w), S = I + diag(sv) S0 diag(sv)
+    float r0[4], svi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        r0[r] = row16_sum(S0[r] * w);
+        svi[r] = __shfl(sv, 4 * s + r, 64);
+    }
+    f32x4 Sm;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Sm[r] = svi[r] * sv * S0[r] + ((4 * s + r) == c ? 1.0f : 0.f);
+    // column c' of S (= row c': S is symmetric) contiguous in LDS; right-hand side behind it
+    *reinterpret_cast<f32x4 *>(&lds[c * 16 + 4 * s]) = Sm;
+    if (c == 0)
+        *reinterpret_cast<f32x4 *>(&lds[256 + 4 * s]) =
+            f32x4{svi[0] * r0[0], svi[1] * r0[1], svi[2] * r0[2], svi[3] * r0[3]};
+
+    // lane = row (lanes 0..15): right-looking Cholesky with the forward substitution folded in
+    float a[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 tq = *reinterpret_cast<const f32x4 *>(&lds[(lane & 15) * 16 + 4 * q]);
+        a[4 * q + 0] = tq.x;
+        a[4 * q + 1] = tq.y;
+        a[4 * q + 2] = tq.z;
+        a[4 * q + 3] = tq.w;
+    }
+    float b = lds[256 + (lane & 15)];
+    float minpiv = 3.0e38f, dinv = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float piv = bcast(a[j], j);
+        minpiv = fminf(minpiv, piv);
+        const float rinv = __builtin_amdgcn_rsqf(piv);
+        dinv = (lane == j) ? rinv : dinv;
+        const float lj = (lane > j && lane < 16) ? a[j] * rinv : 0.f;
+        const float zj = bcast(b, j) * rinv;
+        b = fmaf(-lj, zj, b);
+#pragma unroll
+        for (int cc = j + 1; cc < 16; ++cc) a[cc] = fmaf(-lj, bcast(lj, cc), a[cc]);
+        a[j] = lj;  // row `lane` of L, strictly lower part
+    }
+    b *= dinv;  // z of L z = rhs
+    // L^T: lane i needs column i of L -- rows of L to LDS, columns back (entries j <= i are
+    // outside the strictly-lower part: cleared on the way in)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 tq;
+        tq.x = (4 * q + 0 < lane) ? a[4 * q + 0] : 0.f;
+        tq.y = (4 * q + 1 < lane) ? a[4 * q + 1] : 0.f;
+        tq.z = (4 * q + 2 < lane) ? a[4 * q + 2] : 0.f;
+        tq.w = (4 * q + 3 < lane) ? a[4 * q + 3] : 0.f;
+        if (lane < 16) *reinterpret_cast<f32x4 *>(&lds[lane * 16 + 4 * q]) = tq;
+    }
+    float lt[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) lt[j] = lds[j * 16 + (lane & 15)];  // L[j][lane], 0 for j <= lane
+#pragma unroll
+    for (int j = 15; j >= 1; --j) {
+        const float xj = bcast(b * dinv, j);
+        b = fmaf(-lt[j], xj, b);
+    }
+    b *= dinv;  // u' of S u' = sv o r0, lane j < 16
+    // g_j = w_j - sv_j u'_j (lanes 0..15 hold entry j = lane), then to every row group
+    float g = w - sv * b;
+    g = __shfl(g, c, 64);
+
+    // x = sum_j g_j z_j: this lane's quarter, summed over the 16 entry slots
+    const bool bad = !(minpiv > 0.f) || !(fabsf(g) <= 3.0e38f);
+    if (__any(bad) && lane == 0) atomicCAS(status, 0, row + 1);
+    float d2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        f32x4 xs;
+        xs.x = row16_sum(g * zq[q].x);
+        xs.y = row16_sum(g * zq[q].y);
+        xs.z = row16_sum(g * zq[q].z);
+        xs.w = row16_sum(g * zq[q].w);
+        if (c == 0) {
+            f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + s * QF + 4 * q);
+            const f32x4 old = *dst;
+            *dst = xs;
+            const f32x4 d = xs - old;
+            d2 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+        }
+    }
+    d2 = wave_sum(d2);
+    if (lane == 0) row_delta[row] = d2;
+}
+
+}  // namespace wb
+
+// rows [t0, n_rows) of the plan order (n <= 16 entries each) through the Woodbury kernel
+int als_wb_launch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
+                  const float *values, int64_t t0, int64_t n_rows, float *this_,
+                  const float *other, const float *z, float *row_delta, int *status,
+                  hipStream_t st)
+{
+    const int64_t n = n_rows - t0;
+    if (n <= 0) return LK_OK;
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+#define LK_WB(KPV, IS)                                                                          \
+    hipLaunchKernelGGL((wb::als_wb_kernel<KPV, IS>), grid, block, 0, st,                        \
+                       static_cast<const typename IndPtr<IS>::type *>(indptr), indices, values, \
+                       p->d_order + t0, n, other, z, this_, row_delta, status)
+    if (p->KP == 256) {
+        if (is64)
+            LK_WB(256, true);
+        else
+            LK_WB(256, false);
+    } else if (p->KP == 128) {
+        if (is64)
+            LK_WB(128, true);
+        else
+            LK_WB(128, false);
+    } else {
+        set_error("Woodbury row solve: unsupported padded embedding size %d", p->KP);
+        return LK_E_INVALID;
+    }
+#undef LK_WB
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+}  // namespace lk

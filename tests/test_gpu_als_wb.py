@@ -1,0 +1,84 @@
+"""
+Woodbury row solve for short rows at large k (csrc/als_wb.hip): the same half-epoch through
+`lk_als_implicit_half_epoch`, rows with <= 16 entries taking the rank-n path, against the
+oracle's dense `sposv` restatement (src/accel/als/implicit.rs:87-125) and against this
+library's own dense kernel.  Tolerance: 1e-4 relative (north star).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _short_csr(rng, n_rows, n_cols, varied_values):
+    lens = np.where(rng.random(n_rows) < 0.8, rng.integers(0, 17, n_rows),
+                    rng.integers(17, 300, n_rows))
+    lens[:40] = np.arange(40) % 17  # every length 0..16 present
+    indptr = np.zeros(n_rows + 1, np.int64)
+    np.cumsum(lens, out=indptr[1:])
+    indices = np.empty(indptr[-1], np.int32)
+    for r in range(n_rows):
+        indices[indptr[r]:indptr[r + 1]] = np.sort(
+            rng.choice(n_cols, lens[r], replace=False)).astype(np.int32)
+    values = np.full(indptr[-1], 40.0, np.float32)
+    if varied_values:  # use_ratings: weight * rating, incl. zero confidence increments
+        values = (rng.integers(0, 11, indptr[-1]) * 4.0).astype(np.float32)
+    return sps.csr_array((values, indices, indptr), shape=(n_rows, n_cols))
+
+
+@pytest.mark.parametrize("is64", [False, True])
+@pytest.mark.parametrize("k,varied", [(100, False), (128, True), (200, False), (256, True)])
+def test_short_rows_vs_oracle_and_dense(gpu, oracle, rng, monkeypatch, k, varied, is64):
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    n_rows, n_cols = 3000, 4000
+    mat = _short_csr(rng, n_rows, n_cols, varied)
+    other = (rng.standard_normal((n_cols, k)) * 0.1).astype(np.float32)
+    this = (rng.standard_normal((n_rows, k)) * 0.1).astype(np.float32)
+    otor = oracle.implicit_otor(other, 0.1)
+    want = this.copy()
+    want_frob = oracle.als_half_epoch(mat, want, other, otor)
+
+    indptr = mat.indptr.astype(np.int64 if is64 else np.int32)
+    csr = D.DeviceCSR.from_arrays(indptr, mat.indices, mat.data, mat.shape, gpu)
+    d_other = D.to_device_padded(other, gpu)
+    d_otor = D.Gramian(k, gpu)(d_other, 0.1)
+
+    def run(min_rows):
+        monkeypatch.setenv("LK_ALS_WB_MIN_ROWS", str(min_rows))
+        plan = D.ALSPlan(csr, k, _native.SOLVER_CHOLESKY)
+        d_this = D.to_device_padded(this, gpu)
+        frob = plan.half_epoch(d_this, d_other, d_otor)
+        plan.check_status()
+        return plan, D.to_host_unpadded(d_this, k), float(frob.item()), d_this
+
+    plan, got, frob, d_this = run(1)
+    assert plan.use_wb and plan.short_rows >= 2000
+    plan0, dense, frob0, _ = run(0)
+    assert not plan0.use_wb
+
+    lens = np.diff(mat.indptr)
+    assert np.all(got[lens == 0] == 0.0)  # implicit.rs:98-101
+    # rows the Woodbury kernel did not touch are bit-identical to the dense run
+    assert np.array_equal(got[lens > 16], dense[lens > 16])
+    for name, ref in (("oracle", want), ("dense kernel", dense)):
+        rn = np.linalg.norm(ref, axis=1)
+        err = np.linalg.norm(got - ref, axis=1)
+        assert np.all(err <= 5 * RTOL * np.maximum(rn, 1e-3)), name
+        assert np.linalg.norm(got - ref) <= RTOL * np.linalg.norm(ref), name
+    assert abs(frob - want_frob) <= 1e-4 * want_frob
+    # closer to (or as close as) the float64 solution as the reference arithmetic
+    exact = oracle.als_half_epoch_f64(mat, other, 0.1)
+    short = (lens > 0) & (lens <= 16)
+    e_gpu = np.linalg.norm((got - exact)[short]) / np.linalg.norm(exact[short])
+    e_ref = np.linalg.norm((want - exact)[short]) / np.linalg.norm(exact[short])
+    assert e_gpu <= max(2 * e_ref, 2e-6), (e_gpu, e_ref)
+    # pad columns stay zero, bit-reproducible
+    if d_this.shape[1] > k:
+        assert float(d_this[:, k:].abs().max().item()) == 0.0
+    _, again, _, _ = run(1)
+    assert np.array_equal(again, got)
