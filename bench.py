@@ -49,22 +49,40 @@ LONG_ROW = int(os.environ.get("LK_BENCH_LONG_ROW", 2048))  # LK_ALS_LONG_ROW (cs
 CHUNK = 1024  # LK_ALS_CHUNK
 
 
-def half_flops(lengths: np.ndarray, k: int):
+WB_MAX_N = 16  # rows this short take the Woodbury kernel at padded k > 64 (csrc/als_wb.hip)
+
+
+def half_flops(lengths: np.ndarray, k: int, wb: bool = False):
     """
     Algorithmic flops of one half-epoch:
     nnz*(2k^2 + 2k) + rows_nonempty*(k^3/3 + 2k^2), split into the part done by the
     solve kernel (short rows + every solve) and by the chunk kernel (long rows' Gram).
+    ``wb``: rows with <= 16 entries are solved through the Woodbury identity -- their flops are
+    that method's (S0 = 2 n^2 k, S0 w and x = 4 n k, the n x n solve n^3/3 + 2 n^2), not the
+    k^3/3 of a dense factorisation nobody performs (`reference_half_flops` keeps that figure).
     """
     lengths = lengths.astype(np.int64)
     per_nnz = 2 * k * k + 2 * k
     per_row = k**3 / 3.0 + 2 * k * k
     long_nnz = int(lengths[lengths > LONG_ROW].sum())
-    short_nnz = int(lengths.sum()) - long_nnz
-    nonempty = int((lengths > 0).sum())
-    return short_nnz * per_nnz + nonempty * per_row, long_nnz * per_nnz
+    if not wb:
+        short_nnz = int(lengths.sum()) - long_nnz
+        nonempty = int((lengths > 0).sum())
+        return short_nnz * per_nnz + nonempty * per_row, long_nnz * per_nnz
+    dense = lengths[lengths > WB_MAX_N]
+    n = lengths[(lengths > 0) & (lengths <= WB_MAX_N)].astype(np.float64)
+    wb_flops = float((2 * n * n * k + 4 * n * k + n**3 / 3.0 + 2 * n * n).sum())
+    return (int(dense.sum()) - long_nnz) * per_nnz + len(dense) * per_row + wb_flops, \
+        long_nnz * per_nnz
 
 
-def half_mfma_flops(lengths: np.ndarray, kp: int):
+def reference_half_flops(lengths: np.ndarray, k: int) -> float:
+    "what the reference's algorithm (a dense sposv per row) costs for this half (SURVEY 8d)"
+    a, b = half_flops(lengths, k, wb=False)
+    return a + b
+
+
+def half_mfma_flops(lengths: np.ndarray, kp: int, wb: bool = False):
     """
     Matrix-core flops the solve kernel actually ISSUES in one half-epoch: v_mfma_f32_16x16x4
     instructions x 2048.  Gram: one instruction per upper tile per group of 4 entries
@@ -72,15 +90,20 @@ def half_mfma_flops(lengths: np.ndarray, kp: int):
     blocked Cholesky's trailing updates, 4 * sum_b (NT-1-b)(NT-b)/2 per row
     (csrc/als_blk.hip).  The k <= 64 kernel factorises in 4-column panels (VALU) with MFMA
     trailing updates (79 instructions per row at k = 64, full tiles): counted as the k^3/3
-    useful flops per row, not as what the matrix cores execute for it.
+    useful flops per row, not as what the matrix cores execute for it.  ``wb``: a Woodbury row
+    issues kp/4 MFMAs (one 16 x 16 tile over all features).
     """
     lengths = lengths.astype(np.int64)
     nt = kp // 16
     tri = nt * (nt + 1) // 2
+    n_wb = 0
+    if wb:
+        n_wb = int(((lengths > 0) & (lengths <= WB_MAX_N)).sum())
+        lengths = lengths[lengths > WB_MAX_N]
     short = lengths[(lengths > 0) & (lengths <= LONG_ROW)]
     groups = int(((short + 3) // 4).sum())
     nonempty = int((lengths > 0).sum())
-    fl = groups * tri * 2048.0
+    fl = groups * tri * 2048.0 + n_wb * (kp // 4) * 2048.0
     if kp > 64:
         chol = 4 * sum((nt - 1 - b) * (nt - b) // 2 for b in range(nt))
         fl += nonempty * chol * 2048.0
@@ -404,12 +427,13 @@ def main_cfg5(args):
     ci, si, ni = eng.i_plan.get_timing()
     ulen = np.diff(eng.u_plan.csr.h_indptr)
     ilen = np.diff(eng.i_plan.csr.h_indptr)
-    fu, fuc = half_flops(ulen, k)
-    fi, fic = half_flops(ilen, k)
+    uwb, iwb = bool(eng.u_plan.use_wb), bool(eng.i_plan.use_wb)
+    fu, fuc = half_flops(ulen, k, uwb)
+    fi, fic = half_flops(ilen, k, iwb)
     # per epoch: both solve launches + both chunk launches
     ep_ms = (su + si + cu + ci) / max(nu, 1)
     ep_flops = fu + fi + fuc + fic
-    ex_flops = half_mfma_flops(ulen, backend.kp) + half_mfma_flops(ilen, backend.kp)
+    ex_flops = half_mfma_flops(ulen, backend.kp, uwb) + half_mfma_flops(ilen, backend.kp, iwb)
     out = {
         "metric": "ALS-implicit epochs/sec (cfg5 synthetic %.3gM x %.3gM x %.3gM, k=%d)"
         % (n_users / 1e6, n_items / 1e6, nnz / 1e6, k),
@@ -437,7 +461,8 @@ def main_cfg5(args):
         "generate_seconds": round(gen_seconds, 3),
         "setup_seconds": round(setup_seconds, 3),
         "roofline": {
-            "kernel": "als_blk_solve_kernel%d + als_blk_chunk_kernel" % (backend.kp // 16),
+            "kernel": "als_blk_solve_kernel%d + als_blk_chunk_kernel" % (backend.kp // 16)
+            + (" + als_wb_kernel (rows <= 16 entries)" if (uwb or iwb) else ""),
             "bound": "mfma",
             "achieved": round(ep_flops / (ep_ms * 1e-3) / 1e12, 3),
             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -449,8 +474,16 @@ def main_cfg5(args):
                                     "user_chunk": round(cu / max(nu, 1), 3),
                                     "item_chunk": round(ci / max(ni, 1), 3)},
             "algorithmic_flops_per_epoch": ep_flops,
+            "reference_flops_per_epoch": reference_half_flops(ulen, k)
+            + reference_half_flops(ilen, k),
+            "woodbury_rows": {"user": int(eng.u_plan.short_rows) if uwb else 0,
+                              "item": int(eng.i_plan.short_rows) if iwb else 0},
             "algorithmic_bytes_per_epoch": half_bytes(ulen, k) + half_bytes(ilen, k),
             "traffic": None,
+            "note": "rows with <= 16 entries are rank-n updates of OtOr and are solved through "
+            "the Woodbury identity (same solution, O(n^2 k) flops): algorithmic_flops counts "
+            "what this path needs for them; reference_flops = a dense k^3/3 solve for every "
+            "row, as the reference does (SURVEY 8d)",
         },
     }
 
@@ -631,15 +664,17 @@ def main():
     eng.i_plan.enable_timing(False)
     ulen = np.diff(eng.u_plan.csr.h_indptr)
     ilen = np.diff(eng.i_plan.csr.h_indptr)
-    fu_solve, fu_chunk = half_flops(ulen, k)
-    fi_solve, fi_chunk = half_flops(ilen, k)
+    uwb = bool(getattr(eng.u_plan, "use_wb", False))
+    iwb = bool(getattr(eng.i_plan, "use_wb", False))
+    fu_solve, fu_chunk = half_flops(ulen, k, uwb)
+    fi_solve, fi_chunk = half_flops(ilen, k, iwb)
     launches = nu + ni
     kname = ("als_solve_kernel<NT=%d>" if backend.kp <= 64 else "als_blk_solve_kernel%d") % (
         backend.kp // 16)
     if launches > 0 and (su + si) > 0:
         flops_per_launch = (fu_solve * nu + fi_solve * ni) / launches
-        exec_per_launch = (half_mfma_flops(ulen, backend.kp) * nu
-                           + half_mfma_flops(ilen, backend.kp) * ni) / launches
+        exec_per_launch = (half_mfma_flops(ulen, backend.kp, uwb) * nu
+                           + half_mfma_flops(ilen, backend.kp, iwb) * ni) / launches
         avg_ms = (su + si) / launches
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         roof = {
@@ -662,7 +697,11 @@ def main():
             "chunk_kernel_ms_per_launch": round((cu + ci) / launches, 4),
             "chunk_kernel_flops_per_launch": (fu_chunk * nu + fi_chunk * ni) / launches,
             "note": "frac = SURVEY 8d algorithmic flops (2k^2 per entry) / time / peak; "
-            "frac_executed = matrix-core work actually issued (upper tiles only)",
+            "frac_executed = matrix-core work actually issued (upper tiles only)"
+            + ("; rows with <= 16 entries take the Woodbury kernel and are counted with that "
+               "method's flops (user %d, item %d rows)"
+               % (eng.u_plan.short_rows if uwb else 0, eng.i_plan.short_rows if iwb else 0)
+               if (uwb or iwb) else ""),
         }
     if roof and world == 1 and args.scale == 1.0:
         roof["traffic"], roof["traffic_source"] = pmc_traffic(

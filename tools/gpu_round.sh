@@ -1,5 +1,12 @@
 mkdir -p gpurun_out
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log; tail -3 gpurun_out/smoke.log
-timeout 600 python bench.py --k 128 --steps 10 --no-knn --no-topk > gpurun_out/bench_k128.log 2> gpurun_out/bench_k128.err; echo "rc=$?" >> gpurun_out/bench_k128.err
-timeout 900 python bench.py --config cfg5 --steps 3 --warmup 1 > gpurun_out/bench_cfg5.log 2> gpurun_out/bench_cfg5.err; echo "rc=$?" >> gpurun_out/bench_cfg5.err
-cut -c1-900 gpurun_out/bench_k128.log; tail -2 gpurun_out/bench_k128.err; cut -c1-1500 gpurun_out/bench_cfg5.log; tail -2 gpurun_out/bench_cfg5.err
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_cfg5
+mkdir -p $OUT
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o cfg5 -- python bench.py --config cfg5 --steps 2 --warmup 1 --no-cpu --no-topk > $OUT/stats.log 2>&1
+tail -2 $OUT/stats.log | cut -c1-300
+python - <<'PY'
+import csv,glob
+f=glob.glob('gpurun_out/prof_cfg5/stats/*kernel_stats.csv')[0]
+for r in list(csv.DictReader(open(f)))[:8]:
+    print(r['Name'][:80], r['Calls'], r['AverageNs'], r['Percentage'])
+PY
