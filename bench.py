@@ -49,7 +49,8 @@ LONG_ROW = int(os.environ.get("LK_BENCH_LONG_ROW", 2048))  # LK_ALS_LONG_ROW (cs
 CHUNK = 1024  # LK_ALS_CHUNK
 
 
-WB_MAX_N = 16  # rows this short take the Woodbury kernel at padded k > 64 (csrc/als_wb.hip)
+WB_MAX_N = 64  # rows this short take the Woodbury kernels at padded k > 64 (csrc/als_wb.hip:
+#               n <= 16, one MFMA tile; als_wb64_kernel in csrc/als_chol.hip: 17 .. 64)
 
 
 def half_flops(lengths: np.ndarray, k: int, wb: bool = False):
@@ -57,7 +58,7 @@ def half_flops(lengths: np.ndarray, k: int, wb: bool = False):
     Algorithmic flops of one half-epoch:
     nnz*(2k^2 + 2k) + rows_nonempty*(k^3/3 + 2k^2), split into the part done by the
     solve kernel (short rows + every solve) and by the chunk kernel (long rows' Gram).
-    ``wb``: rows with <= 16 entries are solved through the Woodbury identity -- their flops are
+    ``wb``: rows with <= 64 entries are solved through the Woodbury identity -- their flops are
     that method's (S0 = 2 n^2 k, S0 w and x = 4 n k, the n x n solve n^3/3 + 2 n^2), not the
     k^3/3 of a dense factorisation nobody performs (`reference_half_flops` keeps that figure).
     """
@@ -91,19 +92,24 @@ def half_mfma_flops(lengths: np.ndarray, kp: int, wb: bool = False):
     (csrc/als_blk.hip).  The k <= 64 kernel factorises in 4-column panels (VALU) with MFMA
     trailing updates (79 instructions per row at k = 64, full tiles): counted as the k^3/3
     useful flops per row, not as what the matrix cores execute for it.  ``wb``: a Woodbury row
-    issues kp/4 MFMAs (one 16 x 16 tile over all features).
+    issues kp/4 MFMAs per 16 x 16 tile of S0 (plus the 64 x 64 solve's for 17 .. 64 entries).
     """
     lengths = lengths.astype(np.int64)
     nt = kp // 16
     tri = nt * (nt + 1) // 2
-    n_wb = 0
+    wb_mfma = 0
     if wb:
-        n_wb = int(((lengths > 0) & (lengths <= WB_MAX_N)).sum())
+        # n <= 16: one S0 tile over all features (kp/4 instructions); 17 .. 64: ceil(n/16)^2
+        # tiles + the 79 trailing-update instructions of the 64 x 64 hybrid solve
+        n16 = int(((lengths > 0) & (lengths <= 16)).sum())
+        mid = lengths[(lengths > 16) & (lengths <= WB_MAX_N)]
+        wb_mfma = n16 * (kp // 4) + int((((mid + 15) // 16) ** 2).sum()) * (kp // 4) \
+            + 79 * len(mid)
         lengths = lengths[lengths > WB_MAX_N]
     short = lengths[(lengths > 0) & (lengths <= LONG_ROW)]
     groups = int(((short + 3) // 4).sum())
     nonempty = int((lengths > 0).sum())
-    fl = groups * tri * 2048.0 + n_wb * (kp // 4) * 2048.0
+    fl = groups * tri * 2048.0 + wb_mfma * 2048.0
     if kp > 64:
         chol = 4 * sum((nt - 1 - b) * (nt - b) // 2 for b in range(nt))
         fl += nonempty * chol * 2048.0
@@ -462,7 +468,7 @@ def main_cfg5(args):
         "setup_seconds": round(setup_seconds, 3),
         "roofline": {
             "kernel": "als_blk_solve_kernel%d + als_blk_chunk_kernel" % (backend.kp // 16)
-            + (" + als_wb_kernel (rows <= 16 entries)" if (uwb or iwb) else ""),
+            + (" + als_wb_kernel / als_wb64_kernel (rows <= 64 entries)" if (uwb or iwb) else ""),
             "bound": "mfma",
             "achieved": round(ep_flops / (ep_ms * 1e-3) / 1e12, 3),
             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -480,7 +486,7 @@ def main_cfg5(args):
                               "item": int(eng.i_plan.short_rows) if iwb else 0},
             "algorithmic_bytes_per_epoch": half_bytes(ulen, k) + half_bytes(ilen, k),
             "traffic": None,
-            "note": "rows with <= 16 entries are rank-n updates of OtOr and are solved through "
+            "note": "rows with <= 64 entries are rank-n updates of OtOr and are solved through "
             "the Woodbury identity (same solution, O(n^2 k) flops): algorithmic_flops counts "
             "what this path needs for them; reference_flops = a dense k^3/3 solve for every "
             "row, as the reference does (SURVEY 8d)",
@@ -698,7 +704,7 @@ def main():
             "chunk_kernel_flops_per_launch": (fu_chunk * nu + fi_chunk * ni) / launches,
             "note": "frac = SURVEY 8d algorithmic flops (2k^2 per entry) / time / peak; "
             "frac_executed = matrix-core work actually issued (upper tiles only)"
-            + ("; rows with <= 16 entries take the Woodbury kernel and are counted with that "
+            + ("; rows with <= 64 entries take the Woodbury kernels and are counted with that "
                "method's flops (user %d, item %d rows)"
                % (eng.u_plan.short_rows if uwb else 0, eng.i_plan.short_rows if iwb else 0)
                if (uwb or iwb) else ""),

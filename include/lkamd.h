@@ -130,13 +130,14 @@ int32_t lk_als_plan_solver(const lk_als_plan *plan);
 int lk_als_plan_set_cg(lk_als_plan *plan, float tol, int32_t max_iter);
 /* Attach a task-control block (cancel / progress) to every half-epoch run with this plan. */
 int lk_als_plan_set_ctl(lk_als_plan *plan, lk_task_ctl *ctl);
-/* Short rows at large k (implicit model, padded k = 128 / 256).  A row with n <= 16 entries
+/* Short rows at large k (implicit model, padded k = 128 / 256).  A row with n <= 64 entries
  * is a rank-n update of OtOr, the same matrix for every row of the half-epoch: with
  * Z = other * OtOr^-1 ([n_cols x lk_padded_dim(k)], pad columns zero) supplied by the caller,
  * lk_als_implicit_half_epoch solves those rows through the Woodbury identity (an n x n
  * system, O(n^2 k) instead of the k^3/3 of `sposv`, src/accel/als/solve.rs:65-107) -- the
- * same solution in exact arithmetic, no iteration.  lk_als_plan_short_rows: how many rows
- * of the plan qualify.  lk_als_plan_set_z: Z for the NEXT half-epoch calls (NULL: every row
+ * same solution in exact arithmetic, no iteration (n <= 16: one 16 x 16 system per wave;
+ * 17 .. 64: a 64 x 64 system on the k = 64 solver).  lk_als_plan_short_rows: how many rows of
+ * the plan have <= 16 entries.  lk_als_plan_set_z: Z for the NEXT half-epoch calls (NULL: every row
  * takes the dense solve); the buffer must stay alive until those calls have finished. */
 int64_t lk_als_plan_short_rows(const lk_als_plan *plan);
 int lk_als_plan_set_z(lk_als_plan *plan, const float *d_z);

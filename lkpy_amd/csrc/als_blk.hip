@@ -643,6 +643,13 @@ __global__ void als_blk_prep_otor_kernel(const float *__restrict__ otor, int ld_
     notor_p[idx] = v;
 }
 
+// LK_ALS_WB64=0: rows with 17 .. 64 entries stay on the dense kernel (A/B timing, tests)
+static bool als_wb64_enabled()
+{
+    const char *e = getenv("LK_ALS_WB64");
+    return !(e && e[0] == '0');
+}
+
 template <int NT, bool IS64, bool EXPL>
 static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *indices,
                       const float *values, int64_t n_rows, int k, float *this_, const float *other,
@@ -675,10 +682,14 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     // supplied Z = other * OtOr^-1 for this half-epoch (never with a task-control block: the
     // kernel does not poll it)
     const bool use_wb = !EXPL && p->d_z != nullptr && !p->ctl && p->t_short < n_rows;
-    const int64_t n_dense = use_wb ? p->t_short : n_rows;
+    const int64_t n_dense = use_wb ? (als_wb64_enabled() ? p->t_mid : p->t_short) : n_rows;
     if (use_wb) {
         int rc = als_wb_launch(p, indptr, IS64 ? 1 : 0, indices, values, p->t_short, n_rows,
                                this_, other, p->d_z, row_delta, status, st);
+        if (rc != LK_OK) return rc;
+        // rows with 17 .. 64 entries: the same identity with a 64 x 64 system
+        rc = als_wb64_launch(p, indptr, IS64 ? 1 : 0, indices, values, n_dense, p->t_short,
+                             this_, other, p->d_z, row_delta, status, st);
         if (rc != LK_OK) return rc;
     }
     if (n_dense > 0) {

@@ -1241,6 +1241,198 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
 #endif
 }
 
+// ---- Woodbury row solve for rows with 17..64 entries at padded k = 128 / 256 -----------------
+//
+// Same identity as csrc/als_wb.hip (see there): x = sum_j (w_j - sqrt(v_j) u_j) z_j with
+// S u = sqrt(v) o (S0 w), S = I + diag(sqrt v) S0 diag(sqrt v), S0 = [q_i . z_j] -- but S is up
+// to 64 x 64 now: exactly the system the k = 64 hybrid solver above factors in accumulator
+// tiles.  One wave per row; entry e = 16 t + c, lane (s, c) = (feature quarter s, slot c) holds
+// the entries t = 0..3 of its slot.  Pass 1 streams the quarter's features four at a time and
+// accumulates ALL 16 tiles of S0 (the lower ones only feed the row sums S0 w); `hybrid_solve<4>`
+// solves; pass 2 re-reads z (L1/L2 hits) for x = sum_e g_e z_e with a 16-lane DPP butterfly.
+template <int CTRL>
+__device__ __forceinline__ float wb_dpp_add(float x)
+{
+    const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false);
+    return x + __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ float wb_row16_sum(float x)
+{
+    x = wb_dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
+    x = wb_dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]
+    x = wb_dpp_add<0x141>(x);  // row_half_mirror
+    x = wb_dpp_add<0x140>(x);  // row_mirror
+    return x;
+}
+
+template <int KP, bool IS64>
+__global__ __launch_bounds__(256) void als_wb64_kernel(
+    const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_tasks,
+    const float *__restrict__ other, const float *__restrict__ z, float *__restrict__ this_,
+    float *__restrict__ row_delta, int *__restrict__ status)
+{
+    constexpr int QF = KP / 4;  // features per quarter
+    constexpr int NQ = QF / 4;  // chunks of 4 features
+    __shared__ __attribute__((aligned(16))) float lds_all[4][hybrid_lds_floats<4>()];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int s = lane >> 4, c = lane & 15;
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    if (task >= n_tasks) return;
+    const int row = order[task];
+    const int64_t beg = indptr[row], end = indptr[row + 1];
+    const int n = (int)(end - beg);  // 17 .. 64 (any 1 .. 64 is handled)
+    float *xrow = this_ + (int64_t)row * KP;
+    float *lds = lds_all[wave];
+    const int nte = __builtin_amdgcn_readfirstlane((n + 15) >> 4);  // entry tiles in use
+
+    // this lane's entries: slot c of every tile (slots past the row end: zero weights)
+    const float *mrow[4], *zrow[4];
+    float w[4], sv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int el = 16 * t + c;
+        const int64_t e = beg + (el < n ? el : n - 1);
+        const int col = indices[e];
+        const float v = el < n ? values[e] : 0.f;
+        w[t] = el < n ? v + 1.0f : 0.f;
+        sv[t] = __builtin_sqrtf(v);
+        mrow[t] = other + (int64_t)col * KP + s * QF;
+        zrow[t] = z + (int64_t)col * KP + s * QF;
+    }
+    // pass 1: S0 tiles, acc[ti][tj] lane (s', c') register r = S0[16 ti + 4 s' + r][16 tj + c']
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < NQ; ++q) {
+        f32x4 mq[4], zq[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            mq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            zq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < nte) {
+                mq[t] = *reinterpret_cast<const f32x4 *>(mrow[t] + 4 * q);
+                zq[t] = *reinterpret_cast<const f32x4 *>(zrow[t] + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+                if (ti < nte && tj < nte) {
+#pragma unroll
+                    for (int el = 0; el < 4; ++el)
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            mq[ti][el], zq[tj][el], acc[ti][tj], 0, 0, 0);
+                }
+    }
+    // S = I + diag(sv) S0 diag(sv) (upper tiles) and the right-hand side sv o (S0 w)
+    Gram<4> G;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+        float svr[4], rhs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            svr[r] = __shfl(sv[ti], 4 * s + r, 64);  // sqrt(v) of row 16 ti + 4 s + r
+            float r0 = 0.f;
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) r0 += wb_row16_sum(acc[ti][tj][r] * w[tj]);
+            rhs[r] = svr[r] * r0;
+        }
+#pragma unroll
+        for (int tj = ti; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                G.t[tidx(ti, tj)][r] = svr[r] * sv[tj] * acc[ti][tj][r] +
+                                       ((ti == tj && (4 * s + r) == c) ? 1.0f : 0.f);
+        // rhs of row 16 ti + c for every lane: it sits in row group c >> 2, register c & 3
+        float sel = rhs[0];
+        sel = (c & 3) == 1 ? rhs[1] : sel;
+        sel = (c & 3) == 2 ? rhs[2] : sel;
+        sel = (c & 3) == 3 ? rhs[3] : sel;
+        G.y[ti] = __shfl(sel, (c >> 2) * 16 + c, 64);
+    }
+    float b;
+#ifdef LK_ALS_PHASES
+    unsigned long long tmid_unused = 0;
+    const float minpiv = hybrid_solve<4>(G, b, lds, &tmid_unused);
+#else
+    const float minpiv = hybrid_solve<4>(G, b, lds);
+#endif
+    // b = u' of entry `lane`;  g_e = w_e - sv_e u'_e for this lane's four entries
+    float g[4];
+    bool bad = !(minpiv > 0.f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        g[t] = w[t] - sv[t] * __shfl(b, 16 * t + c, 64);
+        bad = bad || !(fabsf(g[t]) <= 3.0e38f);
+    }
+    if (__any(bad) && lane == 0) atomicCAS(status, 0, row + 1);
+    // pass 2: x = sum_e g_e z_e
+    float d2 = 0.f;
+    for (int q = 0; q < NQ; ++q) {
+        f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < nte) {
+                const f32x4 zq = *reinterpret_cast<const f32x4 *>(zrow[t] + 4 * q);
+                a4.x = fmaf(g[t], zq.x, a4.x);
+                a4.y = fmaf(g[t], zq.y, a4.y);
+                a4.z = fmaf(g[t], zq.z, a4.z);
+                a4.w = fmaf(g[t], zq.w, a4.w);
+            }
+        f32x4 xs;
+        xs.x = wb_row16_sum(a4.x);
+        xs.y = wb_row16_sum(a4.y);
+        xs.z = wb_row16_sum(a4.z);
+        xs.w = wb_row16_sum(a4.w);
+        if (c == 0) {
+            f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + s * QF + 4 * q);
+            const f32x4 old = *dst;
+            *dst = xs;
+            const f32x4 d = xs - old;
+            d2 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+        }
+    }
+    d2 = wave_sum(d2);
+    if (lane == 0) row_delta[row] = d2;
+}
+
+// rows [t0, t1) of the plan order (17 .. 64 entries each)
+int als_wb64_launch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
+                    const float *values, int64_t t0, int64_t t1, float *this_,
+                    const float *other, const float *z, float *row_delta, int *status,
+                    hipStream_t st)
+{
+    const int64_t n = t1 - t0;
+    if (n <= 0) return LK_OK;
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+#define LK_WB64(KPV, IS)                                                                        \
+    hipLaunchKernelGGL((als_wb64_kernel<KPV, IS>), grid, block, 0, st,                          \
+                       static_cast<const typename IndPtr<IS>::type *>(indptr), indices, values, \
+                       p->d_order + t0, n, other, z, this_, row_delta, status)
+    if (p->KP == 256) {
+        if (is64)
+            LK_WB64(256, true);
+        else
+            LK_WB64(256, false);
+    } else if (p->KP == 128) {
+        if (is64)
+            LK_WB64(128, true);
+        else
+            LK_WB64(128, false);
+    } else {
+        set_error("Woodbury row solve: unsupported padded embedding size %d", p->KP);
+        return LK_E_INVALID;
+    }
+#undef LK_WB64
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
 // OtOr [k x k] -> primed [KP x KP] with identity on the pad features.
 template <int NT>
 __global__ void als_prep_otor_kernel(const float *__restrict__ otor, int ld_otor, int k,
@@ -1457,6 +1649,16 @@ extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int i
                 hi = mid;
         }
         p->t_short = lo;
+        lo = 0;
+        hi = p->t_short;
+        while (lo < hi) {  // first task whose row has <= 64 entries
+            const int64_t mid = (lo + hi) >> 1;
+            if (len(order[(size_t)mid]) > 64)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        p->t_mid = lo;
     }
     std::vector<int32_t> row_slab((size_t)n_rows, -1);
     std::vector<int32_t> chunk_row;

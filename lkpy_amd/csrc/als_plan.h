@@ -23,6 +23,7 @@ struct lk_als_plan {
     // padded k > 64 the implicit model solves them through the Woodbury kernel (als_wb.hip)
     // when the caller supplied Z = other * OtOr^-1 for this half-epoch (lk_als_plan_set_z)
     int64_t t_short = 0;
+    int64_t t_mid = 0;  // rows with 17 .. 64 entries are [t_mid, t_short): als_wb64_kernel
     mutable const float *d_z = nullptr;
     // device-side schedule
     int32_t *d_order = nullptr;      // [n_rows] rows, longest first
@@ -56,6 +57,11 @@ int als_wb_launch(const lk_als_plan *p, const void *indptr, int is64, const int3
                   const float *values, int64_t t0, int64_t n_rows, float *this_,
                   const float *other, const float *z, float *row_delta, int *status,
                   hipStream_t st);
+// rows [t0, t1) of the plan order (17 .. 64 entries each), als_wb64_kernel (als_chol.hip)
+int als_wb64_launch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
+                    const float *values, int64_t t0, int64_t t1, float *this_,
+                    const float *other, const float *z, float *row_delta, int *status,
+                    hipStream_t st);
 // deterministic two-stage sum of the per-row squared deltas -> sqrt (als_chol.hip)
 int launch_delta_reduce(const float *row_delta, int64_t n_rows, float *partial, float *out_frob,
                         hipStream_t st);

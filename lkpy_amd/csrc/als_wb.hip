@@ -50,7 +50,6 @@ __device__ __forceinline__ float row16_sum(float x)
     return x;
 }
 
-constexpr int WB_MAX_N = 16;
 constexpr int WB_LDS = 16 * 16 + 16;  // S (or L) tile + right-hand side, per wave
 
 template <int KP, bool IS64>

@@ -1,6 +1,7 @@
 """
 Woodbury row solve for short rows at large k (csrc/als_wb.hip): the same half-epoch through
-`lk_als_implicit_half_epoch`, rows with <= 16 entries taking the rank-n path, against the
+`lk_als_implicit_half_epoch`, rows with <= 16 (16 x 16 system, csrc/als_wb.hip) and with
+17 .. 64 entries (64 x 64 system, als_wb64_kernel in csrc/als_chol.hip) taking the rank-n path, against the
 oracle's dense `sposv` restatement (src/accel/als/implicit.rs:87-125) and against this
 library's own dense kernel.  Tolerance: 1e-4 relative (north star).
 """
@@ -14,9 +15,10 @@ RTOL = 1e-4
 
 
 def _short_csr(rng, n_rows, n_cols, varied_values):
-    lens = np.where(rng.random(n_rows) < 0.8, rng.integers(0, 17, n_rows),
-                    rng.integers(17, 300, n_rows))
-    lens[:40] = np.arange(40) % 17  # every length 0..16 present
+    u = rng.random(n_rows)
+    lens = np.where(u < 0.6, rng.integers(0, 17, n_rows),
+                    np.where(u < 0.9, rng.integers(17, 65, n_rows), rng.integers(65, 300, n_rows)))
+    lens[:65] = np.arange(65)  # every length 0..64 present
     indptr = np.zeros(n_rows + 1, np.int64)
     np.cumsum(lens, out=indptr[1:])
     indices = np.empty(indptr[-1], np.int32)
@@ -57,14 +59,20 @@ def test_short_rows_vs_oracle_and_dense(gpu, oracle, rng, monkeypatch, k, varied
         return plan, D.to_host_unpadded(d_this, k), float(frob.item()), d_this
 
     plan, got, frob, d_this = run(1)
-    assert plan.use_wb and plan.short_rows >= 2000
+    assert plan.use_wb and plan.short_rows >= 1500
     plan0, dense, frob0, _ = run(0)
     assert not plan0.use_wb
 
     lens = np.diff(mat.indptr)
     assert np.all(got[lens == 0] == 0.0)  # implicit.rs:98-101
-    # rows the Woodbury kernel did not touch are bit-identical to the dense run
-    assert np.array_equal(got[lens > 16], dense[lens > 16])
+    # rows the Woodbury kernels did not touch are bit-identical to the dense run
+    assert np.array_equal(got[lens > 64], dense[lens > 64])
+    # ... and with the 64 x 64 variant switched off, so are the rows with 17 .. 64 entries
+    monkeypatch.setenv("LK_ALS_WB64", "0")
+    _, got16, _, _ = run(1)
+    monkeypatch.delenv("LK_ALS_WB64")
+    assert np.array_equal(got16[lens > 16], dense[lens > 16])
+    assert np.array_equal(got16[lens <= 16], got[lens <= 16])
     for name, ref in (("oracle", want), ("dense kernel", dense)):
         rn = np.linalg.norm(ref, axis=1)
         err = np.linalg.norm(got - ref, axis=1)
@@ -73,7 +81,7 @@ def test_short_rows_vs_oracle_and_dense(gpu, oracle, rng, monkeypatch, k, varied
     assert abs(frob - want_frob) <= 1e-4 * want_frob
     # closer to (or as close as) the float64 solution as the reference arithmetic
     exact = oracle.als_half_epoch_f64(mat, other, 0.1)
-    short = (lens > 0) & (lens <= 16)
+    short = (lens > 0) & (lens <= 64)
     e_gpu = np.linalg.norm((got - exact)[short]) / np.linalg.norm(exact[short])
     e_ref = np.linalg.norm((want - exact)[short]) / np.linalg.norm(exact[short])
     assert e_gpu <= max(2 * e_ref, 2e-6), (e_gpu, e_ref)
