@@ -53,6 +53,11 @@ WB_MAX_N = 64  # rows this short take the Woodbury kernels at padded k > 64 (csr
 #               n <= 16, one MFMA tile; als_wb64_kernel in csrc/als_chol.hip: 17 .. 64)
 
 
+def _wb_max(k: int) -> int:
+    "longest row the Woodbury kernels take: 64 entries at padded k = 256, 16 at padded k = 128"
+    return WB_MAX_N if k > 128 else 16
+
+
 def half_flops(lengths: np.ndarray, k: int, wb: bool = False):
     """
     Algorithmic flops of one half-epoch:
@@ -70,8 +75,8 @@ def half_flops(lengths: np.ndarray, k: int, wb: bool = False):
         short_nnz = int(lengths.sum()) - long_nnz
         nonempty = int((lengths > 0).sum())
         return short_nnz * per_nnz + nonempty * per_row, long_nnz * per_nnz
-    dense = lengths[lengths > WB_MAX_N]
-    n = lengths[(lengths > 0) & (lengths <= WB_MAX_N)].astype(np.float64)
+    dense = lengths[lengths > _wb_max(k)]
+    n = lengths[(lengths > 0) & (lengths <= _wb_max(k))].astype(np.float64)
     wb_flops = float((2 * n * n * k + 4 * n * k + n**3 / 3.0 + 2 * n * n).sum())
     return (int(dense.sum()) - long_nnz) * per_nnz + len(dense) * per_row + wb_flops, \
         long_nnz * per_nnz
@@ -102,10 +107,10 @@ def half_mfma_flops(lengths: np.ndarray, kp: int, wb: bool = False):
         # n <= 16: one S0 tile over all features (kp/4 instructions); 17 .. 64: ceil(n/16)^2
         # tiles + the 79 trailing-update instructions of the 64 x 64 hybrid solve
         n16 = int(((lengths > 0) & (lengths <= 16)).sum())
-        mid = lengths[(lengths > 16) & (lengths <= WB_MAX_N)]
+        mid = lengths[(lengths > 16) & (lengths <= _wb_max(kp))]
         wb_mfma = n16 * (kp // 4) + int((((mid + 15) // 16) ** 2).sum()) * (kp // 4) \
             + 79 * len(mid)
-        lengths = lengths[lengths > WB_MAX_N]
+        lengths = lengths[lengths > _wb_max(kp)]
     short = lengths[(lengths > 0) & (lengths <= LONG_ROW)]
     groups = int(((short + 3) // 4).sum())
     nonempty = int((lengths > 0).sum())
@@ -482,8 +487,8 @@ def main_cfg5(args):
             "algorithmic_flops_per_epoch": ep_flops,
             "reference_flops_per_epoch": reference_half_flops(ulen, k)
             + reference_half_flops(ilen, k),
-            "woodbury_rows": {"user": int(eng.u_plan.short_rows) if uwb else 0,
-                              "item": int(eng.i_plan.short_rows) if iwb else 0},
+            "woodbury_rows": {"user": int(eng.u_plan.woodbury_rows) if uwb else 0,
+                              "item": int(eng.i_plan.woodbury_rows) if iwb else 0},
             "algorithmic_bytes_per_epoch": half_bytes(ulen, k) + half_bytes(ilen, k),
             "traffic": None,
             "note": "rows with <= 64 entries are rank-n updates of OtOr and are solved through "
@@ -706,7 +711,7 @@ def main():
             "frac_executed = matrix-core work actually issued (upper tiles only)"
             + ("; rows with <= 64 entries take the Woodbury kernels and are counted with that "
                "method's flops (user %d, item %d rows)"
-               % (eng.u_plan.short_rows if uwb else 0, eng.i_plan.short_rows if iwb else 0)
+               % (eng.u_plan.woodbury_rows if uwb else 0, eng.i_plan.woodbury_rows if iwb else 0)
                if (uwb or iwb) else ""),
         }
     if roof and world == 1 and args.scale == 1.0:

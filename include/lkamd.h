@@ -140,6 +140,7 @@ int lk_als_plan_set_ctl(lk_als_plan *plan, lk_task_ctl *ctl);
  * the plan have <= 16 entries.  lk_als_plan_set_z: Z for the NEXT half-epoch calls (NULL: every row
  * takes the dense solve); the buffer must stay alive until those calls have finished. */
 int64_t lk_als_plan_short_rows(const lk_als_plan *plan);
+int64_t lk_als_plan_woodbury_rows(const lk_als_plan *plan); /* rows with <= 64 entries */
 int lk_als_plan_set_z(lk_als_plan *plan, const float *d_z);
 
 int lk_als_implicit_half_epoch(const lk_als_plan *plan, const void *d_indptr,

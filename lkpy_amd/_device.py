@@ -202,12 +202,16 @@ class ALSPlan:
                               device=dev)
         self.frob = torch.zeros(1, dtype=torch.float32, device=dev)
         self.solver = int(lib.lk_als_plan_solver(self._h))
-        # rows with <= 16 entries at padded k > 64: Woodbury path (csrc/als_wb.hip) when there
-        # are enough of them to pay for Z = other @ OtOr^-1 (LK_ALS_WB_MIN_ROWS; 0 disables)
-        self.short_rows = int(lib.lk_als_plan_short_rows(self._h))
+        # rows with <= 64 entries at padded k > 64: Woodbury paths (csrc/als_wb.hip, als_wb64_kernel)
+        # when there are enough of them to pay for Z = other @ OtOr^-1 (LK_ALS_WB_MIN_ROWS; 0
+        # disables)
+        self.short_rows = int(lib.lk_als_plan_short_rows(self._h))        # <= 16 entries
+        self.woodbury_rows = int(lib.lk_als_plan_woodbury_rows(self._h))  # <= 64 entries
         wb_min = int(os.environ.get("LK_ALS_WB_MIN_ROWS", "4096"))
+        if self.kp < 256:
+            self.woodbury_rows = self.short_rows  # k = 128: only the 16 x 16 variant pays
         self.use_wb = (self.kp > 64 and self.solver == _native.SOLVER_CHOLESKY and wb_min > 0
-                       and self.short_rows >= wb_min)
+                       and self.woodbury_rows >= wb_min)
         self._z = None
 
     def set_ctl(self, ctl: "TaskCtl | None"):

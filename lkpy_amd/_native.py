@@ -67,6 +67,7 @@ def _declare(lib):
         "lk_als_plan_solver": (c_int32, [vp]),
         "lk_als_plan_set_cg": (c_int, [vp, c_float, c_int32]),
         "lk_als_plan_short_rows": (c_int64, [vp]),
+        "lk_als_plan_woodbury_rows": (c_int64, [vp]),
         "lk_als_plan_set_z": (c_int, [vp, vp]),
         "lk_als_implicit_half_epoch": (
             c_int,

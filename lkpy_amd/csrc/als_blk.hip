@@ -682,7 +682,10 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     // supplied Z = other * OtOr^-1 for this half-epoch (never with a task-control block: the
     // kernel does not poll it)
     const bool use_wb = !EXPL && p->d_z != nullptr && !p->ctl && p->t_short < n_rows;
-    const int64_t n_dense = use_wb ? (als_wb64_enabled() ? p->t_mid : p->t_short) : n_rows;
+    // (17 .. 64 entries: only at padded k = 256 -- at k = 128 the 64 x 64 system costs as much as
+    // the dense solve of this file, measured on the ML-25M shape)
+    const int64_t n_dense =
+        use_wb ? ((NT == 16 && als_wb64_enabled()) ? p->t_mid : p->t_short) : n_rows;
     if (use_wb) {
         int rc = als_wb_launch(p, indptr, IS64 ? 1 : 0, indices, values, p->t_short, n_rows,
                                this_, other, p->d_z, row_delta, status, st);

@@ -1767,6 +1767,11 @@ extern "C" int64_t lk_als_plan_short_rows(const lk_als_plan *p)
     return p ? p->n_rows - p->t_short : 0;
 }
 
+extern "C" int64_t lk_als_plan_woodbury_rows(const lk_als_plan *p)
+{
+    return p ? p->n_rows - p->t_mid : 0;
+}
+
 extern "C" int lk_als_plan_set_z(lk_als_plan *p, const float *d_z)
 {
     LK_REQUIRE(p != nullptr, "lk_als_plan_set_z: null plan");
