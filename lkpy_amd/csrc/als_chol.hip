@@ -55,11 +55,12 @@
 #define LK_ALS_GRAM_FENCE 1
 #endif
 #ifndef LK_ALS_PANEL
-#define LK_ALS_PANEL 2  // 2: hybrid (lane = row panels + MFMA updates); 1: panel; 0: lane = row Cholesky
+#define LK_ALS_PANEL 2  // 2: hybrid Cholesky (panels in lane = row layout + MFMA updates);
+                        // 0: the round-1 lane = row Cholesky (bit-identical results; A/B timing)
 #endif
 #ifndef LK_ALS_SOLVE_ATTR
 #if LK_ALS_PANEL
-// the panel solver keeps the matrix in its 40 accumulator registers: 4 waves per SIMD
+// the hybrid solver keeps the matrix in its 40 accumulator registers: 4 waves per SIMD
 #define LK_ALS_SOLVE_ATTR __attribute__((amdgpu_waves_per_eu(4)))
 #endif
 #endif
@@ -705,157 +706,6 @@ __device__ __forceinline__ float chol_solve(f32x2 (&a)[KP / 2], float &b,
     return minpiv;
 }
 
-// ---- panel Cholesky on the accumulator tiles (LK_ALS_PANEL) -----------------------------------
-//
-// The normal matrix never leaves the MFMA accumulator layout (tile (ti, tj), lane (slot, sub),
-// register r = A'[16 ti + 4 slot + r][16 tj + sub]).  Right-looking Cholesky in panels of FOUR
-// columns J .. J+3 (J = 4m; tile column TJ = m / 4, row group MG = m % 4 of that tile):
-//   1. extraction: by symmetry the panel A'[row][J + s] is register s of row group MG of the
-//      tiles (TJ, t); one masked ds_write_b128 + one ds_read_b32 per tile puts it into the
-//      PANEL layout p[t], lane (s, c) = A'[16 t + c][J + s] -- four row groups, four columns;
-//   2. the four columns are factored in that layout: pivot by v_readlane, the finished column
-//      is broadcast from its row group to the other three (ds_bpermute) and applied to the
-//      columns right of it, to the right-hand side (the forward substitution L z = y rides
-//      along) and written to the strictly-lower L image the back substitution reads;
-//   3. the rank-4 update of everything right of the panel is ONE v_mfma_f32_16x16x4_f32 per
-//      tile: in the panel layout -p[ti] IS the A operand and p[tj] IS the B operand.
-// 80 MFMAs replace the ~1000 v_pk_fma + 500 ds_read_b128 of the lane = row version, the
-// transposition disappears, and the solver needs ~30 registers beside the 40 of the tiles,
-// which is what lets four waves share a SIMD (tools/emul/panel_chol.py is the lane-level
-// NumPy model the index arithmetic was checked with).
-template <int NT>
-__host__ __device__ constexpr int panel_lds_floats()
-{
-    // L image | KP reciprocal pivots | KP z values | extraction scratch (64 floats per tile)
-    return LPack<NT * 16>::SIZE + 2 * NT * 16 + NT * 64;
-}
-
-template <int NT, int M>
-__device__ __forceinline__ void panel_step(Gram<NT> &G, float &minpiv, float *__restrict__ lds,
-                                           const int lane)
-{
-    constexpr int KP = NT * 16, J = 4 * M, TJ = M >> 2, MG = M & 3, JC = 4 * MG;
-    using P = LPack<KP>;
-    const int slot = lane >> 4, sub = lane & 15;
-    float *rinvarr = lds + P::SIZE;
-    float *zarr = rinvarr + KP;
-    float *scr = zarr + KP;
-
-    float p[NT];
-    // 1. extraction into the panel layout
-#pragma unroll
-    for (int t = TJ; t < NT; ++t)
-        if (slot == MG) *reinterpret_cast<f32x4 *>(&scr[(t * 16 + sub) * 4]) = G.t[tidx(TJ, t)];
-#pragma unroll
-    for (int t = TJ; t < NT; ++t) p[t] = scr[(t * 16 + sub) * 4 + slot];
-
-    // 2. the four columns
-#pragma unroll
-    for (int s0 = 0; s0 < 4; ++s0) {
-        const int j = J + s0;
-        const float piv = bcast(p[TJ], 16 * s0 + JC + s0);
-        minpiv = fminf(minpiv, piv);
-        const float rinv = __builtin_amdgcn_rsqf(piv);
-        if (lane == 0) rinvarr[j] = rinv;
-        // finish column s0 (row group s0).  The cells above the diagonal are NOT cleared: they
-        // only ever reach rows / columns that are dead by then (finished rows of the tiles and
-        // of y) -- except in the L image, which stores zeros for them.
-        const float rsel = slot == s0 ? rinv : 1.0f;
-#pragma unroll
-        for (int t = TJ; t < NT; ++t) p[t] *= rsel;
-        // L[16 t + c][j] for every row group
-        float bc[NT];
-#pragma unroll
-        for (int t = TJ; t < NT; ++t) bc[t] = __shfl(p[t], 16 * s0 + sub, 64);
-        if (s0 < 3) {
-            // columns right of it inside the panel: P[row][s] -= L[row][j] * L[J + s][j]
-            const float sc = __shfl(p[TJ], 16 * s0 + JC + slot, 64);
-            const float scm = slot > s0 ? sc : 0.f;
-#pragma unroll
-            for (int t = TJ; t < NT; ++t) p[t] = fmaf(-bc[t], scm, p[t]);
-        }
-        // forward substitution: z_j = y_j / L_jj; y -= L[:, j] z_j
-        const float zj = bcast(G.y[TJ], JC + s0) * rinv;
-        if (lane == 0) zarr[j] = zj;
-#pragma unroll
-        for (int t = TJ; t < NT; ++t) G.y[t] = fmaf(-bc[t], zj, G.y[t]);
-        // strictly-lower L image, column j: rows >= c0(j), zeros on and above the diagonal
-        const int c0j = P::c0(j), lo = c0j - 16 * TJ;
-        float *col = lds + P::off(j) - c0j;
-        if (lo < 16) {
-            const float v = (sub > JC + s0) ? bc[TJ] : 0.f;
-            if (slot == 0 && sub >= lo) col[16 * TJ + sub] = v;
-        }
-#pragma unroll
-        for (int t = TJ + 1; t < NT; ++t)
-            if (slot == 0) col[16 * t + sub] = bc[t];
-    }
-    // 3. rank-4 update of the tiles right of / below the panel (tile row TJ first: the next
-    // panel of this tile column is extracted from it)
-    float np[NT];
-#pragma unroll
-    for (int t = TJ; t < NT; ++t) np[t] = -p[t];
-#pragma unroll
-    for (int ti = TJ; ti < NT; ++ti)
-#pragma unroll
-        for (int t2 = ti; t2 < NT; ++t2)
-            G.t[tidx(ti, t2)] = __builtin_amdgcn_mfma_f32_16x16x4f32(np[ti], p[t2],
-                                                                     G.t[tidx(ti, t2)], 0, 0, 0);
-}
-
-template <int NT, int... Ms>
-__device__ __forceinline__ void panel_steps(Gram<NT> &G, float &minpiv, float *__restrict__ lds,
-                                            const int lane, std::integer_sequence<int, Ms...>)
-{
-    (panel_step<NT, Ms>(G, minpiv, lds, lane), ...);
-}
-
-// G: accumulator tiles of A' and the right-hand side (every lane: y'[16 t + sub]).  Returns
-// the smallest pivot; b = solution for primed row `lane`.
-template <int NT>
-__device__ __forceinline__ float panel_solve(Gram<NT> &G, float &b, float *__restrict__ lds
-#ifdef LK_ALS_PHASES
-                                             ,
-                                             unsigned long long *tmid
-#endif
-)
-{
-    constexpr int KP = NT * 16;
-    using P = LPack<KP>;
-    // the lane number is made opaque here so that nothing derived from it for the solver
-    // (row-group masks, LDS addresses) is kept alive across the normal-matrix loop
-    int lane = lane_id();
-    asm volatile("" : "+v"(lane));
-    float minpiv = 3.0e38f;
-    panel_steps<NT>(G, minpiv, lds, lane, std::make_integer_sequence<int, KP / 4>{});
-#ifdef LK_ALS_PHASES
-    asm volatile("" : "+v"(G.y[0]));
-    *tmid = __builtin_amdgcn_s_memtime();
-#endif
-    // backward: L^T x = z, lane = primed row.  Lane i needs L[j][i] (j > i) = column i of the
-    // LDS image, read four rows at a time (ds_read_b128; rows <= i inside the column are
-    // stored zeros, rows below c0(i) are outside it).
-    const float dinv = (lane < KP) ? lds[P::SIZE + lane] : 0.f;
-    b = (lane < KP) ? lds[P::SIZE + KP + lane] : 0.f;
-    const int my_c0 = (lane + 1) & ~3;
-    const float *mycol = lds + P::off(lane) - my_c0;
-#pragma unroll
-    for (int j4 = KP / 4 - 1; j4 >= 0; --j4) {
-        f32x4 l4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (lane < KP - 1 && 4 * j4 >= my_c0) l4 = *reinterpret_cast<const f32x4 *>(mycol + 4 * j4);
-#pragma unroll
-        for (int u = 3; u >= 0; --u) {
-            const int j = 4 * j4 + u;
-            if (j >= 1) {
-                const float xj = bcast(b * dinv, j);
-                b = fmaf(-l4[u], xj, b);
-            }
-        }
-    }
-    b *= dinv;
-    return minpiv;
-}
-
 // ---- hybrid Cholesky (LK_ALS_PANEL == 2) -------------------------------------------------------
 //
 // The matrix stays in the accumulator tiles; panels of FOUR columns J .. J+3 are
@@ -1026,10 +876,8 @@ struct TPack {
 template <int NT>
 __host__ __device__ constexpr int solve_lds_floats()
 {
-#if LK_ALS_PANEL == 2
+#if LK_ALS_PANEL
     return hybrid_lds_floats<NT>();
-#elif LK_ALS_PANEL
-    return panel_lds_floats<NT>() > GRAM_STAGE_WORDS ? panel_lds_floats<NT>() : GRAM_STAGE_WORDS;
 #endif
     // the L image is followed by the k reciprocal pivots
     return TPack<NT>::SIZE > LPack<NT * 16>::SIZE + NT * 16 ? TPack<NT>::SIZE
@@ -1139,19 +987,11 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
 #ifdef LK_ALS_PHASES
     LK_PHASE_T(ph3);
     unsigned long long ph4 = 0;
-#if LK_ALS_PANEL == 2
     const float minpiv = hybrid_solve<NT>(G, b, lds, &ph4);
-#else
-    const float minpiv = panel_solve<NT>(G, b, lds, &ph4);
-#endif
     asm volatile("" : "+v"(b));
     LK_PHASE_T(ph5);
 #else
-#if LK_ALS_PANEL == 2
     const float minpiv = hybrid_solve<NT>(G, b, lds);
-#else
-    const float minpiv = panel_solve<NT>(G, b, lds);
-#endif
 #endif
 #else
     // tile (ti,tj): lane holds D[i = slot*4+r][j = sub] = A'[ti*16+i][tj*16+j]

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """
-Lane-level NumPy emulation of the panel Cholesky of als_chol.hip (one wave = 64 lanes,
-lane = 16*slot + sub): checks the index arithmetic of the HIP code on the CPU.
+Lane-level NumPy emulation (one wave = 64 lanes, lane = 16*slot + sub) of the FIRST panel
+Cholesky tried for als_chol.hip: everything in the accumulator-tile layout, finished columns
+broadcast with ds_bpermute.  Correct, but measured slower than the lane = row solver (the
+bpermute round trip sits in every column's dependent chain) and removed from the kernel; the
+shipped scheme is tools/emul/hybrid_chol.py, which shares the helpers defined here
+(MFMA / L-image models).
     python tools/emul/panel_chol.py
 """
 import numpy as np
