@@ -31,7 +31,10 @@ namespace lk {
 
 constexpr int SC_UB = 64;   // users per block tile
 constexpr int SC_IB = 256;  // items per block tile
-constexpr int SC_KC = 32;   // features staged per pass (42 KiB of LDS: 3 workgroups per CU)
+#ifndef LK_TOPK_KC
+#define LK_TOPK_KC 32
+#endif
+constexpr int SC_KC = LK_TOPK_KC;   // features staged per pass (42 KiB of LDS: 3 workgroups per CU)
 constexpr int SC_LD = SC_KC + 1;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -200,7 +203,11 @@ __device__ __forceinline__ void score_panel_body(
 #pragma unroll
                     for (int rg = 0; rg < 16; ++rg) {
                         const float x = acc[ut][t][rg];
+#ifdef LK_TOPK_NO_HITS  // experiment: the filter GEMM without its epilogue's candidate traffic
+                        const bool hit = in && x >= th[rg] && x > 3.0e38f;  // never, but not provably
+#else
                         const bool hit = in && x >= th[rg];
+#endif
                         const unsigned long long m = __ballot(hit);
                         if (m) {  // wave-uniform
                             if (hit) {
