@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void cand_select_kernel(
     const unsigned long long *__restrict__ cand, const unsigned *__restrict__ cand_cnt,
     const int64_t *__restrict__ excl_ptr, const int32_t *__restrict__ excl_items,
     int64_t user_base, int n, int32_t *__restrict__ out_idx, float *__restrict__ out_score,
-    int64_t out_ld, int *__restrict__ overflow)
+    int64_t out_ld, int *__restrict__ redo /* [0] = count, [1 ..] = user rows */, int redo_cap)
 {
     __shared__ unsigned long long key[CAP];
     __shared__ int hslot[2 * CAP];  // open addressing: candidate position + 1, 0 = empty
@@ -277,8 +277,15 @@ __global__ __launch_bounds__(256) void cand_select_kernel(
     const unsigned m = cand_cnt[b];
     int32_t *oidx = out_idx + b * out_ld;
     float *osc = out_score ? out_score + b * out_ld : nullptr;
-    if (m > (unsigned)CAP) {  // handled by the caller through the unfused path
-        if (tid == 0) atomicExch(overflow, 1);
+    // rows whose candidate list overflowed, or that end up with fewer than n valid candidates
+    // (the threshold is a rank of the sample chosen so that this is a 1e-5 event per row -- or
+    // the row simply has fewer than n valid items), are listed and redone exactly by the caller
+    auto flag = [&]() {
+        const int pos = atomicAdd(&redo[0], 1);
+        if (pos < redo_cap) redo[1 + pos] = (int)(user_base + b);
+    };
+    if (m > (unsigned)CAP) {
+        if (tid == 0) flag();
         return;
     }
     unsigned p2 = 1;
@@ -339,6 +346,8 @@ __global__ __launch_bounds__(256) void cand_select_kernel(
             if (osc) osc[i] = __builtin_nanf("");
         }
     }
+    // sorted descending, zeros (excluded / padding) last: fewer than n valid candidates?
+    if (tid == 0 && ((unsigned)(n - 1) >= p2 || key[n - 1] == 0ull)) flag();
 }
 
 // tau[b] = the n-th best score of the stage-1 sample (or -inf when the sample holds fewer
@@ -354,19 +363,37 @@ __global__ void tau_from_topn_kernel(const float *__restrict__ sub_scores, int64
     cand_cnt[b] = 0u;
 }
 
-// scores[b][excluded item] = NaN  (NaN is skipped by the selection, like the reference)
+// scores[b][excluded item] = NaN  (NaN is skipped by the selection, like the reference).
+// `stride` > 1: the panel holds the SAMPLE items 0, stride, 2 stride, ... (column = item / stride)
 __global__ void score_mask_kernel(const int64_t *__restrict__ excl_ptr,
                                   const int32_t *__restrict__ excl_items, int64_t user_base,
                                   int64_t n_rows, int64_t n_items, float *__restrict__ scores,
-                                  int64_t ld_s)
+                                  int64_t ld_s, int stride = 1)
 {
     const int64_t b = blockIdx.x;
     if (b >= n_rows) return;
     const int64_t s = excl_ptr[user_base + b], e = excl_ptr[user_base + b + 1];
     for (int64_t q = s + threadIdx.x; q < e; q += blockDim.x) {
         const int it = excl_items[q];
-        if (it >= 0 && it < n_items) scores[b * ld_s + it] = __builtin_nanf("");
+        if (it < 0 || it >= n_items) continue;
+        if (stride == 1)
+            scores[b * ld_s + it] = __builtin_nanf("");
+        else if (it % stride == 0)
+            scores[b * ld_s + it / stride] = __builtin_nanf("");
     }
+}
+
+// sample of the item factors: rows 0, stride, 2 stride, ... (one float4 per thread)
+__global__ void sample_rows_kernel(const float *__restrict__ items, int ld, int64_t n_sample,
+                                   int stride, float *__restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_row = ld / 4;
+    if (e >= n_sample * per_row) return;
+    const int64_t r = e / per_row;
+    const int c4 = (int)(e - r * per_row);
+    reinterpret_cast<f32x4 *>(out)[e] =
+        reinterpret_cast<const f32x4 *>(items + r * stride * (int64_t)ld)[c4];
 }
 
 // Radix-select path (any n <= MAXN, any row): MSB-first 8-bit radix select of the n-th
@@ -641,12 +668,17 @@ static int64_t score_batch()
 static int64_t padded_items(int64_t n_items) { return (n_items + 63) / 64 * 64; }
 
 // ---- fused scoring + selection (never materialises the B x I score matrix) -----------------
-// Stage 1: the first n_sub items are scored into a small panel; the n-th best of those
-// candidates (exclusions applied) is tau_b, a LOWER BOUND of the row's n-th best over all
-// items.  Stage 2: the full GEMM, whose epilogue appends the entries >= tau_b to the row's
-// candidate list (expected n * I / n_sub entries).  Stage 3: exclusions struck out, exact
-// (score desc, index asc) order among the candidates.  Same results as the panel path, bit
-// for bit; rows whose list overflows FUSED_CAP go through the panel path.
+// Stage 1: a strided SAMPLE of the items (every stride-th, about an eighth of the catalogue) is
+// scored into a small panel; tau_b = the r-th best of the row's valid sample scores.  r = n
+// would make tau_b a certain lower bound of the row's n-th best overall (8 n candidates per
+// row); instead r is the smallest rank for which "fewer than n items of the whole catalogue
+// reach tau_b" is a 1e-6 event per row under the sampling (binomial tail, fused_tau_rank):
+// r = 28 for n = 100 -- 3.6x fewer candidates to compact, append, hash and sort.  Stage 2:
+// the full GEMM, whose epilogue appends the entries >= tau_b to the row's candidate list.
+// Stage 3: exclusions struck out, exact (score desc, index asc) order among the candidates;
+// a row that ends up with fewer than n valid candidates (the rare event above, an overflowing
+// list, or a row that simply has fewer than n valid items) is listed and redone EXACTLY
+// through the panel path -- so the results are those of the panel path, bit for bit, always.
 constexpr int FUSED_CAP = 2048;        // candidates per row
 constexpr int64_t FUSED_ROWS = 65536;  // rows per batch: 512 workgroups of 128 users fill the chip twice over
 constexpr int FUSED_MAX_N = 128;       // expected candidates <= 8 n <= FUSED_CAP / 2
@@ -669,7 +701,7 @@ static bool use_fused(int64_t n_users, int64_t n_items, int32_t n)
            n_items >= 64 * (int64_t)n && n_users >= fused_min_users();
 }
 
-// items of the stage-1 sample: an eighth of the catalogue, at least 16 n, a multiple of 256
+// target size of the stage-1 sample: an eighth of the catalogue, at least 16 n, a multiple of 256
 static int64_t fused_sub_items(int64_t n_items, int32_t n)
 {
     int64_t s = n_items / 8;
@@ -677,16 +709,51 @@ static int64_t fused_sub_items(int64_t n_items, int32_t n)
     s = (s + 255) / 256 * 256;
     return s < n_items ? s : n_items;
 }
+// the sample is every stride-th item (item ids often follow popularity or age: a prefix of the
+// catalogue would not be representative)
+static int fused_stride(int64_t n_items, int32_t n)
+{
+    const int64_t st = n_items / fused_sub_items(n_items, n);
+    return (int)(st < 1 ? 1 : st);
+}
+static int64_t fused_sample_items(int64_t n_items, int32_t n)
+{
+    const int st = fused_stride(n_items, n);
+    return (n_items + st - 1) / st;
+}
+// rank of the sample score used as the threshold: smallest r with P[Binomial(n-1, f) >= r] <= 1e-6,
+// f = sample fraction (at least r of the row's n-1 best items would have to be in the sample
+// for fewer than n items to reach the threshold).  LK_TOPK_TAU_EXACT=1: r = n (a certain bound).
+static int fused_tau_rank(int64_t n_items, int32_t n)
+{
+    const char *e = getenv("LK_TOPK_TAU_EXACT");
+    if (e && e[0] == '1') return n;
+    const double f = (double)fused_sample_items(n_items, n) / (double)n_items;
+    const int m = n - 1;
+    // tail[r] = P[X >= r], X ~ Binomial(m, f), from the pmf
+    double pmf = 1.0;
+    for (int i = 0; i < m; ++i) pmf *= (1.0 - f);  // P[X = 0]
+    double cdf = 0.0;
+    for (int r = 0; r <= m; ++r) {
+        // tail of rank r = 1 - P[X <= r-1]
+        if (r >= 1 && 1.0 - cdf <= 1.0e-6) return r;
+        cdf += pmf;
+        pmf = pmf * (double)(m - r) / (double)(r + 1) * f / (1.0 - f);
+    }
+    return n;
+}
+constexpr int FUSED_REDO_CAP = 4096;  // rows redone one by one; more: everything through the panel
 
 struct FusedLayout {
-    size_t off_sub, off_tau, off_cnt, off_cand, off_sidx, off_ssc, off_flags, bytes;
+    size_t off_sub, off_tau, off_cnt, off_cand, off_sidx, off_ssc, off_flags, off_qs, bytes;
 };
 
 static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n)
 {
     const int64_t rows = n_users < FUSED_ROWS ? n_users : FUSED_ROWS;
-    const int64_t nsub = padded_items(fused_sub_items(n_items, n));
+    const int64_t nsub = padded_items(fused_sample_items(n_items, n));
     const int64_t batches = (n_users + FUSED_ROWS - 1) / FUSED_ROWS;
+    (void)batches;
     FusedLayout L;
     size_t off = 0;
     L.off_sub = off;
@@ -701,8 +768,10 @@ static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n)
     off += align_up((size_t)rows * n * 4, 256);
     L.off_ssc = off;
     off += align_up((size_t)rows * n * 4, 256);
-    L.off_flags = off;
-    off += align_up((size_t)(batches > 0 ? batches : 1) * 4, 256);
+    L.off_flags = off;  // redo list: count + rows
+    off += align_up((size_t)(1 + FUSED_REDO_CAP) * 4, 256);
+    L.off_qs = off;     // sample of the item factors, [n_sample x 256 floats at most]
+    off += align_up((size_t)nsub * 256 * 4, 256);
     L.bytes = off;
     return L;
 }
@@ -830,29 +899,39 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
         auto *cand = reinterpret_cast<unsigned long long *>(fw + L.off_cand);
         int32_t *sidx = reinterpret_cast<int32_t *>(fw + L.off_sidx);
         float *ssc = reinterpret_cast<float *>(fw + L.off_ssc);
-        int *flags = reinterpret_cast<int *>(fw + L.off_flags);
-        const int64_t n_sub = lk::fused_sub_items(n_items, n);
+        int *redo = reinterpret_cast<int *>(fw + L.off_flags);
+        float *qs = reinterpret_cast<float *>(fw + L.off_qs);
+        const int stride = lk::fused_stride(n_items, n);
+        const int64_t n_sub = lk::fused_sample_items(n_items, n);
         const int64_t ld_sub = lk::padded_items(n_sub);
+        const int r_tau = lk::fused_tau_rank(n_items, n);
         const int64_t batches = (n_users + lk::FUSED_ROWS - 1) / lk::FUSED_ROWS;
-        LK_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(int) * (size_t)batches, st));
+        LK_HIP_CHECK(hipMemsetAsync(redo, 0, sizeof(int), st));
+        // the sample rows of the item factors, contiguous
+        {
+            const int64_t vec = n_sub * (KP / 4);
+            hipLaunchKernelGGL(lk::sample_rows_kernel, dim3((unsigned)((vec + 255) / 256)),
+                               dim3(256), 0, st, d_items, KP, n_sub, stride, qs);
+        }
         for (int64_t bi = 0; bi < batches; ++bi) {
             const int64_t ub = bi * lk::FUSED_ROWS;
             const int64_t rows = (n_users - ub) < lk::FUSED_ROWS ? (n_users - ub) : lk::FUSED_ROWS;
             const float *ub_users = d_users + ub * ld_users;
             const dim3 ugrid_sub((unsigned)((n_sub + lk::SC_IB - 1) / lk::SC_IB),
                                  (unsigned)((rows + lk::SC_UB - 1) / lk::SC_UB));
-            // stage 1: threshold from the first n_sub items
+            // stage 1: threshold from the sample
             hipLaunchKernelGGL(lk::score_panel_kernel, ugrid_sub, dim3(256), 0, st, ub_users,
-                               ld_users, rows, d_items, ld_items, n_sub, KP, sub, ld_sub,
+                               ld_users, rows, qs, KP, n_sub, KP, sub, ld_sub,
                                (const float *)nullptr, (unsigned long long *)nullptr,
                                (unsigned *)nullptr, 0);
             if (d_excl_ptr)
                 hipLaunchKernelGGL(lk::score_mask_kernel, dim3((unsigned)rows), dim3(64), 0, st,
-                                   d_excl_ptr, d_excl_items, ub, rows, n_sub, sub, ld_sub);
+                                   d_excl_ptr, d_excl_items, ub, rows, n_items, sub, ld_sub,
+                                   stride);
             hipLaunchKernelGGL(lk::row_topn_kernel<lk::TOPN_MAX>, dim3((unsigned)rows), dim3(256),
-                               0, st, sub, ld_sub, n_sub, n, sidx, ssc, (int64_t)n);
+                               0, st, sub, ld_sub, n_sub, r_tau, sidx, ssc, (int64_t)n);
             hipLaunchKernelGGL(lk::tau_from_topn_kernel, dim3((unsigned)((rows + 255) / 256)),
-                               dim3(256), 0, st, ssc, (int64_t)n, n, rows, tau, cnt);
+                               dim3(256), 0, st, ssc, (int64_t)n, r_tau, rows, tau, cnt);
             // stage 2: the full contraction, candidates only
             // one workgroup per 128 users, walking all item tiles (no global atomics)
             const dim3 ugrid((unsigned)((rows + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB)));
@@ -863,23 +942,28 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
             hipLaunchKernelGGL(lk::cand_select_kernel<lk::FUSED_CAP>, dim3((unsigned)rows),
                                dim3(256), 0, st, cand, cnt, d_excl_ptr, d_excl_items, ub, n,
                                d_out_idx + ub * n, d_out_score ? d_out_score + ub * n : nullptr,
-                               (int64_t)n, flags + bi);
+                               (int64_t)n, redo, lk::FUSED_REDO_CAP);
         }
         LK_HIP_CHECK(hipGetLastError());
-        // batches with an overflowing row (heavy ties at the threshold, fewer than n candidates in
-        // the sample, ...) are redone through the panel path: same results by construction
-        std::vector<int> h_flags((size_t)batches, 0);
-        LK_HIP_CHECK(hipMemcpyAsync(h_flags.data(), flags, sizeof(int) * (size_t)batches,
-                                    hipMemcpyDeviceToHost, st));
+        // rows that did not end up with n valid candidates are redone exactly, one by one
+        // (a handful per call); more than the list holds: everything through the panel path
+        std::vector<int> h_redo((size_t)1 + lk::FUSED_REDO_CAP, 0);
+        LK_HIP_CHECK(hipMemcpyAsync(h_redo.data(), redo, sizeof(int), hipMemcpyDeviceToHost, st));
         LK_HIP_CHECK(hipStreamSynchronize(st));
-        for (int64_t bi = 0; bi < batches; ++bi) {
-            if (!h_flags[(size_t)bi]) continue;
-            const int64_t b0 = bi * lk::FUSED_ROWS;
-            const int64_t bn = (n_users - b0) < lk::FUSED_ROWS ? (n_users - b0) : lk::FUSED_ROWS;
-            for (int64_t ub = b0; ub < b0 + bn; ub += lk::score_batch()) {
-                const int64_t rows = (b0 + bn - ub) < lk::score_batch() ? (b0 + bn - ub)
+        const int n_redo = h_redo[0];
+        if (n_redo > lk::FUSED_REDO_CAP) {
+            for (int64_t ub = 0; ub < n_users; ub += lk::score_batch()) {
+                const int64_t rows = (n_users - ub) < lk::score_batch() ? (n_users - ub)
                                                                         : lk::score_batch();
                 int rc = run_panel(ub, rows);
+                if (rc != LK_OK) return rc;
+            }
+        } else if (n_redo > 0) {
+            LK_HIP_CHECK(hipMemcpyAsync(h_redo.data() + 1, redo + 1, sizeof(int) * (size_t)n_redo,
+                                        hipMemcpyDeviceToHost, st));
+            LK_HIP_CHECK(hipStreamSynchronize(st));
+            for (int i = 0; i < n_redo; ++i) {
+                int rc = run_panel((int64_t)h_redo[(size_t)1 + i], 1);
                 if (rc != LK_OK) return rc;
             }
         }

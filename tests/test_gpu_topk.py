@@ -175,3 +175,40 @@ def test_score_topk_fused_no_overflow_rows(gpu, oracle, rng, monkeypatch):
     for b in range(0, B, 7):
         s, want = _oracle_topn(oracle, Q, U[b], np.zeros(0, np.int64), n)
         assert np.array_equal(idx[b], want) and np.array_equal(sc[b], s[want])
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_score_topk_fused_threshold_misses_are_redone(gpu, oracle, rng, monkeypatch, exact):
+    """
+    The fused path's threshold is a RANK of the strided item sample chosen so that "fewer than n
+    items reach it" is a 1e-6 event -- under random sampling.  An adversarial catalogue (every
+    high-scoring item sits at an id that is a multiple of the stride, i.e. IN the sample) makes
+    the event certain: such rows must be detected and redone exactly.  LK_TOPK_TAU_EXACT=1
+    (threshold = n-th best of the sample, a certain bound) gives the same lists.
+    """
+    from lkpy_amd import _device as D
+
+    monkeypatch.setenv("LK_TOPK_FUSED_MIN_USERS", "1")
+    if exact:
+        monkeypatch.setenv("LK_TOPK_TAU_EXACT", "1")
+    B, I, k, n = 96, 40000, 32, 100
+    U = np.abs(rng.standard_normal((B, k))).astype(np.float32)
+    Q = (rng.standard_normal((I, k)) * 0.01).astype(np.float32)
+    # the sample is every (I // sub)-th item with sub = max(I / 8, 16 n) rounded up to 256
+    sub = max(I // 8, 16 * n)
+    sub = (sub + 255) // 256 * 256
+    stride = I // sub
+    hot = np.arange(0, I, stride)[:400]
+    Q[hot] = np.abs(rng.standard_normal((len(hot), k))).astype(np.float32) + 1.0
+    U[5] = -U[5]  # one row whose best items are NOT the hot ones
+    lens = rng.integers(0, 200, B)
+    ptr = np.zeros(B + 1, np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    ex = np.concatenate([rng.choice(I, l, replace=False) for l in lens]).astype(np.int32)
+    dU, dQ = D.to_device_padded(U, gpu), D.to_device_padded(Q, gpu)
+    idx, sc = D.score_topk(dU, dQ, k, n, torch.from_numpy(ptr).to(gpu), torch.from_numpy(ex).to(gpu))
+    idx, sc = idx.cpu().numpy(), sc.cpu().numpy()
+    for b in range(0, B, 5):
+        s, want = _oracle_topn(oracle, Q, U[b], ex[ptr[b] : ptr[b + 1]], n)
+        assert np.array_equal(idx[b], want), b
+        assert np.array_equal(sc[b].view(np.uint32), s[want].view(np.uint32)), b
