@@ -668,17 +668,20 @@ static int64_t score_batch()
 static int64_t padded_items(int64_t n_items) { return (n_items + 63) / 64 * 64; }
 
 // ---- fused scoring + selection (never materialises the B x I score matrix) -----------------
-// Stage 1: a strided SAMPLE of the items (every stride-th, about an eighth of the catalogue) is
+// Stage 1: a strided SAMPLE of the items (every stride-th, about a sixteenth of the catalogue) is
 // scored into a small panel; tau_b = the r-th best of the row's valid sample scores.  r = n
-// would make tau_b a certain lower bound of the row's n-th best overall (8 n candidates per
+// would make tau_b a certain lower bound of the row's n-th best overall (16 n candidates per
 // row); instead r is the smallest rank for which "fewer than n items of the whole catalogue
 // reach tau_b" is a 1e-6 event per row under the sampling (binomial tail, fused_tau_rank):
-// r = 28 for n = 100 -- 3.6x fewer candidates to compact, append, hash and sort.  Stage 2:
+// r = 21 for n = 100 -- ~330 candidates per row to compact, append, hash and sort.  Stage 2:
 // the full GEMM, whose epilogue appends the entries >= tau_b to the row's candidate list.
 // Stage 3: exclusions struck out, exact (score desc, index asc) order among the candidates;
 // a row that ends up with fewer than n valid candidates (the rare event above, an overflowing
 // list, or a row that simply has fewer than n valid items) is listed and redone EXACTLY
 // through the panel path -- so the results are those of the panel path, bit for bit, always.
+#ifndef LK_TOPK_SAMPLE_DIV_DEFAULT
+#define LK_TOPK_SAMPLE_DIV_DEFAULT 16  // measured: 8 -> 23.5 ms, 16 -> 22.5, 32 -> 23.6 (ML-25M, k = 64)
+#endif
 constexpr int FUSED_CAP = 2048;        // candidates per row
 constexpr int64_t FUSED_ROWS = 65536;  // rows per batch: 512 workgroups of 128 users fill the chip twice over
 constexpr int FUSED_MAX_N = 128;       // expected candidates <= 8 n <= FUSED_CAP / 2
@@ -701,10 +704,12 @@ static bool use_fused(int64_t n_users, int64_t n_items, int32_t n)
            n_items >= 64 * (int64_t)n && n_users >= fused_min_users();
 }
 
-// target size of the stage-1 sample: an eighth of the catalogue, at least 16 n, a multiple of 256
+// target size of the stage-1 sample: a sixteenth of the catalogue, at least 16 n, a multiple of 256
 static int64_t fused_sub_items(int64_t n_items, int32_t n)
 {
-    int64_t s = n_items / 8;
+    const char *e = getenv("LK_TOPK_SAMPLE_DIV");  // tuning knob: catalogue / sample size
+    const long div = e ? atol(e) : 0;
+    int64_t s = n_items / ((div >= 2 && div <= 64) ? div : LK_TOPK_SAMPLE_DIV_DEFAULT);
     if (s < 16 * (int64_t)n) s = 16 * (int64_t)n;
     s = (s + 255) / 256 * 256;
     return s < n_items ? s : n_items;

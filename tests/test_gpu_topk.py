@@ -194,8 +194,8 @@ def test_score_topk_fused_threshold_misses_are_redone(gpu, oracle, rng, monkeypa
     B, I, k, n = 96, 40000, 32, 100
     U = np.abs(rng.standard_normal((B, k))).astype(np.float32)
     Q = (rng.standard_normal((I, k)) * 0.01).astype(np.float32)
-    # the sample is every (I // sub)-th item with sub = max(I / 8, 16 n) rounded up to 256
-    sub = max(I // 8, 16 * n)
+    # the sample is every (I // sub)-th item with sub = max(I / 16, 16 n) rounded up to 256
+    sub = max(I // 16, 16 * n)
     sub = (sub + 255) // 256 * 256
     stride = I // sub
     hot = np.arange(0, I, stride)[:400]
