@@ -234,10 +234,17 @@ class ALSPlan:
             # OtOr^-1 once per half-epoch in float64 (k x k: a library inverse, plumbing), then
             # Z = other @ OtOr^-1 on the scoring GEMM of this library (f32 MFMA, k-ordered)
             k, kp = self.k, self.kp
-            ginv = torch.zeros((kp, kp), dtype=torch.float32, device=other.device)
-            ginv[:k, :k] = torch.linalg.inv(otor[:k, :k].to(torch.float64)).to(torch.float32)
-            self._z = score_dense(other, ginv, k)  # [n_cols x KP]; row i of ginv = column i
-            check(_native.load().lk_als_plan_set_z(self._h, _ptr(self._z)), "lk_als_plan_set_z")
+            chol, info = torch.linalg.cholesky_ex(otor[:k, :k].to(torch.float64))
+            if int(info.item()) == 0:
+                ginv = torch.zeros((kp, kp), dtype=torch.float32, device=other.device)
+                ginv[:k, :k] = torch.cholesky_inverse(chol).to(torch.float32)
+                self._z = score_dense(other, ginv, k)  # [n_cols x KP]; row i of ginv = column i
+                z_ptr = _ptr(self._z)
+            else:
+                # OtOr itself is not positive definite (reg = 0 with rank-deficient factors):
+                # the rows' own matrices may still be -- every row takes the dense solve
+                self._z, z_ptr = None, None
+            check(_native.load().lk_als_plan_set_z(self._h, z_ptr), "lk_als_plan_set_z")
         check(
             _native.load().lk_als_implicit_half_epoch(
                 self._h, _ptr(csr.indptr), _ptr(csr.indices), _ptr(csr.values),
