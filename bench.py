@@ -582,8 +582,10 @@ def main_cfg5(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed epochs (default 50; cfg5: 3, SURVEY 8d).  BASELINE's 20-epoch "
+                    "fit is the `fit` leg; more timed epochs only steady the epochs/s figure")
+    ap.add_argument("--warmup", type=int, default=None, help="default 3 (cfg5: 1)")
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the dataset (debug only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the parity + cpu_baseline legs")
@@ -600,6 +602,10 @@ def main():
     ap.add_argument("--topk-users", type=int, default=0,
                     help="cfg5: users of the dense top-K leg (default: 1/8 of the users)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 3 if args.config == "cfg5" else 50
+    if args.warmup is None:
+        args.warmup = 1 if args.config == "cfg5" else 3
     if args.config == "cfg5":
         return main_cfg5(args)
 
@@ -870,7 +876,7 @@ def main():
         del eng  # free the engine's HBM before the other legs
         torch.cuda.empty_cache()
     if single and not args.no_fit:
-        leg("fit", lambda: fit_leg(ratings, k, args.steps, weight))
+        leg("fit", lambda: fit_leg(ratings, k, 20, weight))  # configs[1]: 20 epochs
     if single and not args.no_knn:
         leg("knn", knn_leg)
         if isinstance(out.get("parity"), dict) and isinstance(out["knn"], dict):
