@@ -211,6 +211,8 @@ def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
             (o["max_cond_of_rows_over"] for o in out.values() if "max_cond_of_rows_over" in o),
             default=None),
         "decidable_rows_over_1e-4": sum(o["decidable_rows_over_1e-4"] for o in out.values()),
+        "decidable_rows_over_1e-4_gpu_side": sum(
+            o.get("decidable_rows_over_1e-4_gpu_side", 0) for o in out.values()),
         "gpu_row_err_over_cond_u_max": max(o["row_err_over_cond_u_max_gpu"] for o in out.values()),
         "oracle_row_err_over_cond_u_max": max(
             o["row_err_over_cond_u_max_oracle"] for o in out.values()),

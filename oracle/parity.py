@@ -12,7 +12,11 @@ from IDENTICAL inputs on both sides:
 * the matrix-level relative error GPU vs oracle (Frobenius),
 * how many rows exceed 1e-4 (row-wise ``||x_gpu - x_oracle|| / ||x_oracle||``) and the
   condition numbers of exactly those rows (lower-bound estimates from the float64 referee),
-* the claims that are asserted: EVERY row with ``cond * 2^-24 < 1e-5`` is within 1e-4; the
+* the claims that are asserted: EVERY row with ``cond * 2^-24 < 1e-5`` is within 1e-4 of the
+  oracle -- or, where it is not, the float64 referee shows that the gap is the REFERENCE
+  arithmetic's own (the GPU row is within 0.5e-4 of the exact answer; such rows are listed with
+  all three distances: they are rows of tens of thousands of entries whose sequential float32
+  accumulation in the reference drifts by ~1e-4); the
   GPU is no further from the float64 referee than the reference arithmetic is (matrix level,
   factor 2 slack); and -- the statement that is not vacuous on real data, where
   ``cond(A) >= 100`` for every non-empty row because ``cond(OtOr)`` already is -- EVERY row of
@@ -77,7 +81,21 @@ def als_half_accounting(got: np.ndarray, want: np.ndarray, exact: np.ndarray | N
         decidable = cu < 1.0e-5
         res["rows_decidable"] = int(decidable.sum())  # cond * 2^-24 < 1e-5
         res["decidable_rows_over_1e-4"] = int((over & decidable).sum())
-        ok &= res["decidable_rows_over_1e-4"] == 0
+        if exact is None:
+            ok &= res["decidable_rows_over_1e-4"] == 0
+        else:
+            # a decidable row over 1e-4 counts against the GPU only if the GPU row itself is
+            # more than half the tolerance from the float64 answer; otherwise the gap is the
+            # reference arithmetic's own deviation, and the row is listed with all distances
+            e_gx = _row_rel(got, exact)
+            e_ox = _row_rel(want, exact)
+            mine = over & decidable & (e_gx > 0.5 * RTOL)
+            res["decidable_rows_over_1e-4_gpu_side"] = int(mine.sum())
+            ok &= not mine.any()
+            res["rows_over_detail"] = [
+                {"row": int(r), "cond": float(cond[r]), "gpu_vs_oracle": float(e_go[r]),
+                 "gpu_vs_f64": float(e_gx[r]), "oracle_vs_f64": float(e_ox[r])}
+                for r in np.flatnonzero(over)[:10]]
         if over.any():
             res["min_cond_of_rows_over"] = float(cond[over].min())
             res["max_cond_of_rows_over"] = float(cond[over].max())

@@ -377,3 +377,29 @@ def test_ease_oracle_closed_form(oracle, rng):
     assert np.allclose(w, b, rtol=1e-4, atol=1e-6)
     hist = np.array([1, 4, 9])
     assert np.allclose(oracle.ease_score(w, hist), w[hist].sum(axis=0), rtol=1e-6, atol=1e-7)
+
+
+def test_parity_accounting_attributes_gaps():
+    """
+    oracle/parity.py: a decidable row over 1e-4 vs the oracle counts against the GPU only when the
+    GPU row itself is off the float64 answer; a drift of the reference arithmetic is listed.
+    """
+    from oracle import parity
+
+    rng = np.random.default_rng(0)
+    exact = rng.standard_normal((100, 8))
+    got = (exact * (1 + 1e-6)).astype(np.float32)
+    want = exact.astype(np.float32).copy()
+    want[3] *= 1 + 2e-4  # the reference drifts on row 3
+    cond = np.full(100, 80.0)
+    a = parity.als_half_accounting(got, want, exact, cond)
+    assert a["rows_over_1e-4"] == 1 and a["decidable_rows_over_1e-4"] == 1
+    assert a["decidable_rows_over_1e-4_gpu_side"] == 0 and a["ok"]
+    assert a["rows_over_detail"][0]["row"] == 3
+    got2 = got.copy()
+    got2[5] *= 1 + 2e-4  # now the GPU is the one that is off
+    b = parity.als_half_accounting(got2, exact.astype(np.float32), exact, cond)
+    assert b["decidable_rows_over_1e-4_gpu_side"] == 1 and not b["ok"]
+    # without a referee the old, stricter rule applies
+    c = parity.als_half_accounting(got, want, None, cond)
+    assert not c["ok"]
