@@ -1,5 +1,3 @@
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gputest.log
-tail -3 gpurun_out/gputest.log
-timeout 600 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?" >> gpurun_out/bench.err
-tail -1 gpurun_out/bench.err
+PROF_CMD="python bench.py --config cfg5 --steps 2 --warmup 1 --no-cpu --no-topk" timeout 1500 bash tools/prof_als.sh r02_cfg5b > gpurun_out/prof_cfg5b.log 2>&1
+tail -3 gpurun_out/prof_cfg5b.log
