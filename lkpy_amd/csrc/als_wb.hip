@@ -28,6 +28,8 @@
 //
 // Bound: gather bandwidth (2 n rows of 4 KP bytes per solved row) -- cfg5 user half: 22 M
 // entries x 2 KiB = 45 GB.
+#include <type_traits>
+
 #include "als_plan.h"
 #include "common.h"
 
@@ -40,13 +42,16 @@ __device__ __forceinline__ float dpp_add(float x)
     const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false);
     return x + __builtin_bit_cast(float, y);
 }
-// sum over the 16 lanes of a row group, result in every lane of the group
-__device__ __forceinline__ float row16_sum(float x)
+// sum over the first 4 / 8 / 16 lanes of a row group (DEPTH = 2 / 3 / 4 butterfly steps): the
+// result is in lane 0 of the group (DEPTH = 4: in every lane).  Entry slots >= n carry zeros,
+// so a row with n <= 4 (82 % of the cfg5 user rows) needs two steps, not four.
+template <int DEPTH>
+__device__ __forceinline__ float row_sum(float x)
 {
-    x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
-    x = dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]
-    x = dpp_add<0x141>(x);  // row_half_mirror
-    x = dpp_add<0x140>(x);  // row_mirror
+    x = dpp_add<0xB1>(x);  // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E>(x);  // quad_perm [2,3,0,1]
+    if constexpr (DEPTH >= 3) x = dpp_add<0x141>(x);  // row_half_mirror
+    if constexpr (DEPTH >= 4) x = dpp_add<0x140>(x);  // row_mirror
     return x;
 }
 
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256) void als_wb_kernel(
     if (t >= n_tasks) return;
     const int row = order[t];
     const int64_t beg = indptr[row], end = indptr[row + 1];
-    const int n = (int)(end - beg);
+    const int n = __builtin_amdgcn_readfirstlane((int)(end - beg));  // 0 .. 16, wave-uniform
     float *xrow = this_ + (int64_t)row * KP;
     float *lds = lds_all[wave];
 
@@ -106,7 +111,9 @@ __global__ __launch_bounds__(256) void als_wb_kernel(
     float r0[4], svi[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        r0[r] = row16_sum(S0[r] * w);
+        // (only lane c == 0 of a group uses r0: the butterfly depth follows n)
+        const float pr = S0[r] * w;
+        r0[r] = n <= 4 ? row_sum<2>(pr) : (n <= 8 ? row_sum<3>(pr) : row_sum<4>(pr));
         svi[r] = __shfl(sv, 4 * s + r, 64);
     }
     f32x4 Sm;
@@ -130,17 +137,22 @@ __global__ __launch_bounds__(256) void als_wb_kernel(
     }
     float b = lds[256 + (lane & 15)];
     float minpiv = 3.0e38f, dinv = 0.f;
+    // (rows / columns >= n of S are the identity: their steps are skipped, wave-uniformly)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const float piv = bcast(a[j], j);
-        minpiv = fminf(minpiv, piv);
-        const float rinv = __builtin_amdgcn_rsqf(piv);
-        dinv = (lane == j) ? rinv : dinv;
-        const float lj = (lane > j && lane < 16) ? a[j] * rinv : 0.f;
-        const float zj = bcast(b, j) * rinv;
-        b = fmaf(-lj, zj, b);
+        float lj = 0.f;
+        if (j < n) {
+            const float piv = bcast(a[j], j);
+            minpiv = fminf(minpiv, piv);
+            const float rinv = __builtin_amdgcn_rsqf(piv);
+            dinv = (lane == j) ? rinv : dinv;
+            lj = (lane > j && lane < 16) ? a[j] * rinv : 0.f;
+            const float zj = bcast(b, j) * rinv;
+            b = fmaf(-lj, zj, b);
 #pragma unroll
-        for (int cc = j + 1; cc < 16; ++cc) a[cc] = fmaf(-lj, bcast(lj, cc), a[cc]);
+            for (int cc = j + 1; cc < 16; ++cc)
+                if (cc < n) a[cc] = fmaf(-lj, bcast(lj, cc), a[cc]);
+        }
         a[j] = lj;  // row `lane` of L, strictly lower part
     }
     b *= dinv;  // z of L z = rhs
@@ -159,10 +171,11 @@ __global__ __launch_bounds__(256) void als_wb_kernel(
 #pragma unroll
     for (int j = 0; j < 16; ++j) lt[j] = lds[j * 16 + (lane & 15)];  // L[j][lane], 0 for j <= lane
 #pragma unroll
-    for (int j = 15; j >= 1; --j) {
-        const float xj = bcast(b * dinv, j);
-        b = fmaf(-lt[j], xj, b);
-    }
+    for (int j = 15; j >= 1; --j)
+        if (j < n) {
+            const float xj = bcast(b * dinv, j);
+            b = fmaf(-lt[j], xj, b);
+        }
     b *= dinv;  // u' of S u' = sv o r0, lane j < 16
     // g_j = w_j - sv_j u'_j (lanes 0..15 hold entry j = lane), then to every row group
     float g = w - sv * b;
@@ -172,21 +185,30 @@ __global__ __launch_bounds__(256) void als_wb_kernel(
     const bool bad = !(minpiv > 0.f) || !(fabsf(g) <= 3.0e38f);
     if (__any(bad) && lane == 0) atomicCAS(status, 0, row + 1);
     float d2 = 0.f;
+    auto finish = [&](auto depth_c) {
+        constexpr int DEPTH = decltype(depth_c)::value;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        f32x4 xs;
-        xs.x = row16_sum(g * zq[q].x);
-        xs.y = row16_sum(g * zq[q].y);
-        xs.z = row16_sum(g * zq[q].z);
-        xs.w = row16_sum(g * zq[q].w);
-        if (c == 0) {
-            f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + s * QF + 4 * q);
-            const f32x4 old = *dst;
-            *dst = xs;
-            const f32x4 d = xs - old;
-            d2 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+        for (int q = 0; q < NQ; ++q) {
+            f32x4 xs;
+            xs.x = row_sum<DEPTH>(g * zq[q].x);
+            xs.y = row_sum<DEPTH>(g * zq[q].y);
+            xs.z = row_sum<DEPTH>(g * zq[q].z);
+            xs.w = row_sum<DEPTH>(g * zq[q].w);
+            if (c == 0) {
+                f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + s * QF + 4 * q);
+                const f32x4 old = *dst;
+                *dst = xs;
+                const f32x4 d = xs - old;
+                d2 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+            }
         }
-    }
+    };
+    if (n <= 4)
+        finish(std::integral_constant<int, 2>{});
+    else if (n <= 8)
+        finish(std::integral_constant<int, 3>{});
+    else
+        finish(std::integral_constant<int, 4>{});
     d2 = wave_sum(d2);
     if (lane == 0) row_delta[row] = d2;
 }
