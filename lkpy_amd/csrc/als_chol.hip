@@ -296,8 +296,10 @@ __device__ __forceinline__ void dma_issue(const unsigned ring_lds, const int slo
                                           const float *__restrict__ other)
 {
     const int lane = lane_id();
-    const int col = __builtin_bit_cast(int, stage_slot[g * 4]);
-    const float *src = other + (int64_t)col * 64 + (lane & 15) * 4;
+    const unsigned col = __builtin_bit_cast(unsigned, stage_slot[g * 4]);
+    // one v_mad_u64_u32: (this lane's 16 bytes of row 0) + col * 256
+    const uint64_t lane_base = (uint64_t)(uintptr_t)(other + (lane & 15) * 4);
+    const float *src = reinterpret_cast<const float *>(lane_base + (uint64_t)col * 256ull);
     const unsigned dst = ring_lds + slot_idx * 1024;
     unsigned keep;
     asm volatile(
