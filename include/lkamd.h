@@ -345,6 +345,14 @@ int lk_csr_rows_dot(const void *d_indptr, int indptr_is_64, const int32_t *d_ind
                     const float *d_values, int64_t n_rows, const float *d_x, int64_t ld_x,
                     int64_t n_queries, float *d_out, int64_t ld_out, void *stream);
 
+/* Device -> pageable host memory at PCIe speed: chunks through a ring of pinned staging slots,
+ * a team of `n_threads` host threads (<= 14; 0 = 8) copies the landed chunks to `h_dst` in
+ * parallel (first-touching its pages on many cores).  Used for results the reference hands
+ * back as host arrays -- e.g. the similarity matrix of `compute_similarities`
+ * (src/accel/knn/item_train.rs:86-91): SURVEY.md section 8d counts the kNN build "to CSR sim
+ * matrix on host".  Blocking; waits for `stream` (the producer of `d_src`) first. */
+int lk_download(void *h_dst, const void *d_src, size_t bytes, int32_t n_threads, void *stream);
+
 /* ------------------------------------------------------------------------
  * EASE (`EASEScorer`, src/lenskit/knn/ease.py:88-147).
  * lk_ease_gram: the dense matrix the model inverts, G = X^T X + reg I for the binary

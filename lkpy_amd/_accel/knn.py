@@ -51,8 +51,8 @@ def compute_similarities(ui_ratings, iu_ratings, shape, min_sim: float,
         task.attach(ctl)  # cancel() / current_progress() reach the running build kernel
         out = D.iknn_build(ui, iu, min_sim, save_nbrs, ctl=ctl)
         task.set_progress(ni)
-        return [_sim_chunk(out.indptr.cpu().numpy(), out.indices.cpu().numpy(),
-                           out.values.cpu().numpy(), ni)]
+        return [_sim_chunk(out.indptr.cpu().numpy(), D.to_host(out.indices),
+                           D.to_host(out.values), ni)]
 
     return AccelTask(run, total=ni)
 

@@ -116,6 +116,7 @@ def _declare(lib):
         "lk_csr_rows_dot": (
             c_int, [vp, c_int, vp, vp, c_int64, vp, c_int64, c_int64, vp, c_int64, vp]
         ),
+        "lk_download": (c_int, [vp, vp, c_size_t, c_int32, vp]),
         "lk_ease_gram": (c_int, [vp, vp, vp, vp, c_int64, c_float, vp, c_int64, vp]),
         "lk_ease_score_batch": (
             c_int, [vp, vp, c_int64, vp, c_int64, c_int64, vp, c_int64, vp]

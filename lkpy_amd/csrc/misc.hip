@@ -179,3 +179,123 @@ extern "C" int lk_task_ctl_progress(const lk_task_ctl *c, int64_t *rows_done, in
                      : 0;
     return LK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// lk_download: device -> PAGEABLE host memory at PCIe speed.
+//
+// The reference hands its results to Python as host Arrow arrays (e.g. the similarity matrix of
+// `compute_similarities`, src/accel/knn/item_train.rs:86-91; SURVEY.md section 8d counts the kNN
+// build "to CSR sim matrix on host").  An unbounded ML-25M model is 9.2 GB: hipMemcpy into a
+// fresh pageable buffer runs at ~12 GB/s -- one thread paying the page faults of 2.3 M fresh
+// pages and the copy out of the driver's bounce buffer.  Here the transfer is chunked through a
+// small ring of PINNED staging slots (DMA at link speed, hipMemcpyAsync) and a team of host
+// threads copies the landed chunks to their final place in parallel, first-touching the
+// destination pages on many cores at once.
+// ---------------------------------------------------------------------------------------------
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <string.h>
+
+namespace lk {
+namespace {
+constexpr size_t DL_CHUNK = (size_t)16 << 20;  // bytes per staging slot
+constexpr int DL_SLOTS = 16;
+
+struct DownloadRing {
+    char *slot[DL_SLOTS] = {};
+    hipEvent_t done[DL_SLOTS] = {};
+    hipStream_t stream = nullptr;
+    bool ok = false;
+    std::mutex mu;
+    int init()
+    {
+        if (ok) return LK_OK;
+        for (int i = 0; i < DL_SLOTS; ++i) {
+            LK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&slot[i]), DL_CHUNK, hipHostMallocDefault));
+            LK_HIP_CHECK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        }
+        LK_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        ok = true;
+        return LK_OK;
+    }
+};
+DownloadRing g_ring;  // one transfer at a time (guarded by its mutex); slots stay pinned
+}  // namespace
+}  // namespace lk
+
+extern "C" int lk_download(void *h_dst, const void *d_src, size_t bytes, int32_t n_threads,
+                           void *stream)
+{
+    LK_REQUIRE(bytes == 0 || (h_dst && d_src), "lk_download: null pointer");
+    if (bytes == 0) return LK_OK;
+    // the producer of d_src ran on `stream`
+    LK_HIP_CHECK(hipStreamSynchronize(lk::as_stream(stream)));
+    if (bytes < 4 * lk::DL_CHUNK) {  // small: a plain copy
+        LK_HIP_CHECK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+        return LK_OK;
+    }
+    std::lock_guard<std::mutex> guard(lk::g_ring.mu);
+    int rc = lk::g_ring.init();
+    if (rc != LK_OK) return rc;
+    if (n_threads < 1) n_threads = 8;
+    if (n_threads > lk::DL_SLOTS - 2) n_threads = lk::DL_SLOTS - 2;
+    const size_t n_chunks = (bytes + lk::DL_CHUNK - 1) / lk::DL_CHUNK;
+    // chunk c lives in slot c % DL_SLOTS; issued[c] / copied[c] hand the slots over
+    std::atomic<size_t> issued{0}, copied_upto{0};
+    std::vector<std::atomic<int>> copied(n_chunks);
+    for (auto &x : copied) x.store(0, std::memory_order_relaxed);
+    std::atomic<int> failed{0};
+    char *dst = static_cast<char *>(h_dst);
+    const char *src = static_cast<const char *>(d_src);
+
+    auto worker = [&](int t) {
+        for (size_t c = (size_t)t; c < n_chunks; c += (size_t)n_threads) {
+            while (issued.load(std::memory_order_acquire) <= c) {
+                if (failed.load()) return;
+                std::this_thread::yield();
+            }
+            const int s = (int)(c % lk::DL_SLOTS);
+            if (hipEventSynchronize(lk::g_ring.done[s]) != hipSuccess) {
+                failed.store(1);
+                return;
+            }
+            const size_t off = c * lk::DL_CHUNK;
+            const size_t n = bytes - off < lk::DL_CHUNK ? bytes - off : lk::DL_CHUNK;
+            memcpy(dst + off, lk::g_ring.slot[s], n);
+            copied[c].store(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> team;
+    team.reserve((size_t)n_threads);
+    for (int t = 0; t < n_threads; ++t) team.emplace_back(worker, t);
+    hipError_t err = hipSuccess;
+    for (size_t c = 0; c < n_chunks && !failed.load(); ++c) {
+        if (c >= (size_t)lk::DL_SLOTS) {  // the slot's previous chunk must have been copied out
+            const size_t prev = c - lk::DL_SLOTS;
+            while (!copied[prev].load(std::memory_order_acquire)) {
+                if (failed.load()) break;
+                std::this_thread::yield();
+            }
+        }
+        const int s = (int)(c % lk::DL_SLOTS);
+        const size_t off = c * lk::DL_CHUNK;
+        const size_t n = bytes - off < lk::DL_CHUNK ? bytes - off : lk::DL_CHUNK;
+        err = hipMemcpyAsync(lk::g_ring.slot[s], src + off, n, hipMemcpyDeviceToHost,
+                             lk::g_ring.stream);
+        if (err == hipSuccess) err = hipEventRecord(lk::g_ring.done[s], lk::g_ring.stream);
+        if (err != hipSuccess) {
+            failed.store(1);
+            break;
+        }
+        issued.store(c + 1, std::memory_order_release);
+    }
+    for (auto &th : team) th.join();
+    (void)copied_upto;
+    if (failed.load()) {
+        lk::set_error("lk_download: transfer failed: %s", hipGetErrorString(err));
+        return LK_E_HIP;
+    }
+    return LK_OK;
+}

@@ -81,9 +81,10 @@ class ItemKNNScorer(Component):
         self.item_means = None if means is None else np.asarray(means)
         offsets = out.indptr.cpu().numpy()
         self.item_counts = np.diff(offsets)
-        # Arrow extension array, int64 offsets (item.py:176-177: LargeList -> from_array)
+        # Arrow extension array, int64 offsets (item.py:176-177: LargeList -> from_array); an
+        # unbounded ML-25M model is 9.2 GB: D.to_host moves it at PCIe speed (lk_download)
         self.sim_matrix = SparseRowArray.from_arrays(
-            offsets, out.indices.cpu().numpy(), out.values.cpu().numpy(),
+            offsets, D.to_host(out.indices), D.to_host(out.values),
             shape=(n_items, n_items))
         import pyarrow as pa
 

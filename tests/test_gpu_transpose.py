@@ -52,3 +52,24 @@ def test_transpose_empty_and_structure_only(gpu, oracle):
     assert np.array_equal(tr.values.to_numpy(), want.data)
     s_only = SparseRowArray.from_scipy(m, values=False).transpose()
     assert s_only.values is None and np.array_equal(s_only.indices.to_numpy(), want.indices)
+
+
+@pytest.mark.parametrize("dtype,n", [("int32", 50_000_003), ("float32", 16_777_216 + 5), ("int64", 1000)])
+def test_to_host_staged_download(gpu, dtype, n):
+    "D.to_host: the pinned-ring / thread-team download returns exactly what .cpu() does"
+    import torch
+
+    from lkpy_amd import _device as D
+
+    g = torch.Generator(device=gpu).manual_seed(3)
+    if dtype == "float32":
+        t = torch.randn(n, device=gpu, generator=g)
+    else:
+        t = torch.randint(-2**31 + 1, 2**31 - 1, (n,), device=gpu, generator=g,
+                          dtype=getattr(torch, dtype))
+    got = D.to_host(t, threads=6)
+    assert got.dtype == np.dtype(dtype) and got.shape == (n,)
+    assert np.array_equal(got, t.cpu().numpy())
+    # a second transfer reuses the ring; a 2-D view keeps its shape
+    t2 = t[: (n // 7) * 7].reshape(-1, 7)
+    assert np.array_equal(D.to_host(t2), t2.cpu().numpy())
