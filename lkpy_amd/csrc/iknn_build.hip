@@ -63,6 +63,12 @@ struct lk_iknn_plan {
     size_t off_pack = 0, off_seg = 0, off_cnt = 0, off_off = 0, off_rows = 0, ws_bytes = 0;
     // single-pass build through a dense-bound staging area (n_items^2 entries) when it fits
     int32_t staged = 0;
+    // symmetric build (staged, whole matrix): only the windows on / right of the diagonal are
+    // accumulated, the blocks left of it are MIRRORED from their transposes (iknn_mirror_kernel)
+    int32_t symmetric = 0;
+    int64_t n_sym_tasks = 0;  // (row, window) tasks actually accumulated
+    size_t off_strip = 0;     // symmetric: [n_tasks][W/64 + 1] u16 survivor counts before each
+                              // 64-column strip of a task's window (written at extraction)
     size_t off_st_idx = 0, off_st_val = 0;
     lk_task_ctl *ctl = nullptr;  // optional cancel / progress block (lk_iknn_plan_set_ctl)
     // optional timing of the build kernel (HIP events on the launch stream; bench.py roofline)
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
     const typename IndPtr<IS64>::type *__restrict__ iu_ptr, const int32_t *__restrict__ iu_idx,
     const float *__restrict__ iu_val, const int2 *__restrict__ desc,
     const int32_t *__restrict__ tasks, int64_t n_btasks, int64_t n_items, int64_t row_lo, int P,
-    int Q, int W,
+    int Q, int W, int symmetric, uint16_t *__restrict__ strip_tab,
     float min_sim, int32_t *__restrict__ task_cnt,
     const int64_t *__restrict__ task_off, int32_t *__restrict__ out_idx,
     float *__restrict__ out_val, TaskCtlDev ctl)
@@ -147,6 +153,9 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
         const int row = (int)row_lo + lrow;  // item id
         const int p = (code - lrow * Q) * 4 + wave;
         if (p >= P) continue;
+        // symmetric build: sim(i, j) and sim(j, i) are the same sums of the same products in
+        // the same order -- windows left of the row's own are mirrored, not accumulated
+        if (symmetric && p < row / W) continue;
         if (ctl.d_cancel) {  // AccelTask.cancel: tasks not started keep their zero count
             int c = 0;
             if (lane == 0) c = ctl_cancelled(ctl, wave == 0 && (bt & 63) == 0) ? 1 : 0;
@@ -278,7 +287,11 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
         // staged: window p of (local) row r is compacted at r * n_items + p * W
         int64_t wpos = !WRITE ? 0 : COUNT ? (int64_t)lrow * n_items + c_lo : task_off[task];
         int count = 0;
+        uint16_t *strip = (COUNT && strip_tab) ? strip_tab + (size_t)task * (W / 64 + 1) : nullptr;
         for (int c0 = 0; c0 < wlen; c0 += 64) {
+            // (symmetric build: where the 64-column strip starts inside the compacted segment --
+            // the mirror kernel reads strips of this segment without searching)
+            if (strip && lane == 0) strip[c0 >> 6] = (uint16_t)count;
             const int c = c0 + lane;
             float s = 0.f;
             if (c < wlen) {
@@ -299,9 +312,97 @@ __global__ __launch_bounds__(256) void iknn_build_kernel(
             }
             if (COUNT) count += __popcll(m);
         }
+        if (strip && lane == 0) strip[(wlen + 63) >> 6] = (uint16_t)count;
         if (COUNT && lane == 0) task_cnt[task] = count;
         if (ctl.d_done && lane == 0) ctl_advance(ctl, 1);  // unit: one (row, window) task
     }
+}
+
+// ---- symmetric build: the blocks left of the diagonal, from their transposes -----------------
+//
+// sim(i, j) = sim(j, i) BIT FOR BIT: both are the sum, over the common users in ascending order,
+// of the same rounded products.  So only the windows p >= window(i) of row i are accumulated
+// (iknn_build_kernel with `symmetric`), and segment (row j, window q < window(j)) is the
+// transpose of what the rows i of window q found in window p = window(j).  One workgroup per
+// (block (q, p), strip of 64 columns j): the rows i of window q are taken 256 at a time; every
+// thread finds its row's entries inside the strip (binary search in the sorted, compacted
+// segment (i, p)) and drops their values into a dense 256 x 64 tile in LDS; the tile is then
+// read out column by column -- lane = column j, rows in ascending order, the four waves owning
+// consecutive 64-row ranges whose per-column counts are prefixed -- and appended to the segment
+// (j, q) of the staging area: compacted, ascending i, exactly what an accumulation would have
+// written.  Similarities are >= min_sim > 0, so 0.0f marks an empty cell.
+constexpr int MIRROR_ROWS = 256;
+
+__global__ __launch_bounds__(256) void iknn_mirror_kernel(int32_t *__restrict__ cnt,
+                                                          const uint16_t *__restrict__ strip_tab,
+                                                          int64_t n_items, int P, int W,
+                                                          int32_t *__restrict__ st_idx,
+                                                          float *__restrict__ st_val)
+{
+    // tile[column of the strip][row of the group]: the scatter writes (thread = row) and the
+    // read-out (lane = row, one column at a time) are both conflict-free
+    __shared__ float tile[64][MIRROR_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = W / 64;  // strips per window
+    int pair = blockIdx.x / S;
+    const int strip = blockIdx.x - pair * S;
+    int p = 1;
+    while (pair >= p) {  // pair index -> (q < p)
+        pair -= p;
+        ++p;
+    }
+    const int q = pair;
+    const int64_t j0 = (int64_t)p * W + (int64_t)strip * 64;
+    if (j0 >= n_items) return;
+    const int ncols = (int)((n_items - j0) < 64 ? (n_items - j0) : 64);
+    const int64_t i_lo = (int64_t)q * W;
+    const int64_t i_hi = (i_lo + W) < n_items ? (i_lo + W) : n_items;
+    for (int e = tid; e < 64 * MIRROR_ROWS; e += 256) (&tile[0][0])[e] = 0.f;
+    // wave w owns the columns 16 w .. 16 w + 15 of the strip for ALL rows: the write position
+    // of a column is a wave-private running count (lane c & 15 of the wave keeps column c's)
+    int pos_mine = 0;  // lane l < 16: entries written so far to column 16 * wave + l
+    __syncthreads();
+    for (int64_t g0 = i_lo; g0 < i_hi; g0 += MIRROR_ROWS) {
+        {
+            // this row's entries inside the strip: a run of its compacted segment (i, p) whose
+            // ends the build kernel recorded at extraction
+            const int64_t i = g0 + tid;
+            if (i < i_hi) {
+                const int64_t base = i * n_items + (int64_t)p * W;
+                const uint16_t *tab = strip_tab + (size_t)(i * P + p) * (S + 1) + strip;
+                const int lo = tab[0], hi = tab[1];
+                for (int k = lo; k < hi; ++k)
+                    tile[st_idx[base + k] - j0][tid] = st_val[base + k];
+            }
+        }
+        __syncthreads();
+        for (int cl = 0; cl < 16; ++cl) {
+            const int c = wave * 16 + cl;
+            if (c >= ncols) break;  // wave-uniform
+            int pos = __builtin_amdgcn_readlane(pos_mine, cl);
+            const int64_t obase = (j0 + c) * n_items + (int64_t)q * W;
+#pragma unroll
+            for (int ch = 0; ch < MIRROR_ROWS / 64; ++ch) {
+                const float v = tile[c][ch * 64 + lane];
+                const bool nz = v != 0.f;
+                const unsigned long long m = __ballot(nz);
+                if (m) {  // wave-uniform
+                    if (nz) {
+                        const int rank = __builtin_amdgcn_mbcnt_hi(
+                            (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                        tile[c][ch * 64 + lane] = 0.f;  // leave the tile clean for the next group
+                        st_idx[obase + pos + rank] = (int32_t)(g0 + ch * 64 + lane);
+                        st_val[obase + pos + rank] = v;
+                    }
+                    pos += __popcll(m);
+                }
+            }
+            if (lane == cl) pos_mine = pos;
+        }
+        __syncthreads();
+    }
+    if (lane < 16 && wave * 16 + lane < ncols) cnt[(j0 + wave * 16 + lane) * P + q] = pos_mine;
 }
 
 // Exclusive scan of the int32 task counts into int64 offsets (n_rows*P + 1 outputs) in three
@@ -450,11 +551,43 @@ extern "C" int lk_iknn_plan_create_rows(lk_iknn_plan **out, const void *h_ui_ind
         const int32_t *ip = static_cast<const int32_t *>(h_iu_indptr);
         return (int64_t)ip[r + 1] - ip[r];
     };
+    // single-pass (staged) build?  288 GB of HBM: when n_items^2 (index, value) pairs fit
+    // comfortably, every task writes its survivors straight into a row-strided staging area in
+    // ONE pass over the data and a copy kernel compacts them; otherwise count and fill are two
+    // full passes.
+    const size_t stage = (size_t)n_rows * (size_t)n_items * sizeof(int32_t);
+    {
+        size_t cap = (size_t)64 << 30, free_b = 0, total_b = 0;
+        if (const char *env = getenv("LK_IKNN_STAGE_GB")) cap = (size_t)atol(env) << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap = std::min(cap, free_b / 3);
+        if (n_rows > 0 && 2 * stage <= cap) p->staged = 1;
+    }
+    // symmetric build: staged, the whole matrix, more than one window (LK_IKNN_SYMMETRIC=0: off)
+    {
+        const char *env = getenv("LK_IKNN_SYMMETRIC");
+        p->symmetric = (p->staged && row_begin == 0 && row_end == n_items && p->P > 1 &&
+                        p->W % 64 == 0 && !(env && env[0] == '0'))
+                           ? 1
+                           : 0;
+    }
     std::vector<int32_t> rows((size_t)n_rows);  // LOCAL row numbers, heaviest first
     for (int64_t r = 0; r < n_rows; ++r) rows[(size_t)r] = (int32_t)r;
     std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) {
         return len(row_begin + a) > len(row_begin + b);
     });
+    // (row, quad of four adjacent windows) tasks of the weight-sorted rows; the symmetric build
+    // drops the quads that lie entirely left of the row's own window
+    std::vector<int32_t> sorted_tasks;
+    sorted_tasks.reserve((size_t)p->n_btasks);
+    p->n_sym_tasks = 0;
+    for (int64_t i = 0; i < n_rows; ++i) {
+        const int32_t r = rows[(size_t)i];
+        const int qrow = p->symmetric ? (int)((row_begin + r) / W) : 0;
+        for (int qd = 0; qd < p->Q; ++qd)
+            if (4 * qd + 3 >= qrow) sorted_tasks.push_back(r * p->Q + qd);
+        p->n_sym_tasks += p->P - qrow;
+    }
+    p->n_btasks = (int64_t)sorted_tasks.size();
     // Workgroup b of G takes tasks b, b+G, b+2G, ...: deal the weight-sorted list
     // serpentine (every other round reversed) so the per-workgroup totals stay level.
     std::vector<int32_t> tasks((size_t)p->n_btasks);
@@ -463,7 +596,7 @@ extern "C" int lk_iknn_plan_create_rows(lk_iknn_plan **out, const void *h_ui_ind
         const int64_t round = i / G, pos = i - round * G;
         const int64_t cnt_in_round = std::min<int64_t>(G, p->n_btasks - round * G);
         const int64_t src = round * G + ((round & 1) ? cnt_in_round - 1 - pos : pos);
-        tasks[(size_t)i] = rows[(size_t)(src / p->Q)] * p->Q + (int32_t)(src % p->Q);
+        tasks[(size_t)i] = sorted_tasks[(size_t)src];
     }
     size_t bytes = std::max<size_t>(tasks.size(), 1) * sizeof(int32_t);
     if (hipMalloc(reinterpret_cast<void **>(&p->d_task), bytes) != hipSuccess) {
@@ -489,21 +622,15 @@ extern "C" int lk_iknn_plan_create_rows(lk_iknn_plan **out, const void *h_ui_ind
     off += lk::align_up((size_t)(p->n_tasks + 1) * sizeof(int64_t), 256);
     p->off_rows = off;
     off += lk::align_up((size_t)(n_rows + 1) * sizeof(int64_t), 256);
-    // 288 GB of HBM: when n_items^2 (index, value) pairs fit comfortably, every task writes
-    // its survivors straight into a row-strided staging area in ONE pass over the data and
-    // a copy kernel compacts them; otherwise count and fill are two full passes.
-    {
-        const size_t stage = (size_t)n_rows * (size_t)n_items * sizeof(int32_t);
-        size_t cap = (size_t)64 << 30, free_b = 0, total_b = 0;
-        if (const char *env = getenv("LK_IKNN_STAGE_GB")) cap = (size_t)atol(env) << 30;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap = std::min(cap, free_b / 3);
-        if (n_rows > 0 && 2 * stage <= cap) {
-            p->staged = 1;
-            p->off_st_idx = off;
-            off += lk::align_up(stage, 256);
-            p->off_st_val = off;
-            off += lk::align_up(stage, 256);
-        }
+    if (p->symmetric) {
+        p->off_strip = off;
+        off += lk::align_up((size_t)p->n_tasks * (size_t)(p->W / 64 + 1) * sizeof(uint16_t), 256);
+    }
+    if (p->staged) {
+        p->off_st_idx = off;
+        off += lk::align_up(stage, 256);
+        p->off_st_val = off;
+        off += lk::align_up(stage, 256);
     }
     p->ws_bytes = off;
     *out = p;
@@ -591,7 +718,7 @@ static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t 
     int64_t blocks = std::min<int64_t>(p->n_btasks, iknn_grid(p->W));
     if (p->ctl) {
         if (COUNT) LK_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)p->n_tasks, st));
-        int rc = ctl_begin(p->ctl, p->n_rows, p->n_tasks, st);
+        int rc = ctl_begin(p->ctl, p->n_rows, p->symmetric ? p->n_sym_tasks : p->n_tasks, st);
         if (rc != LK_OK) return rc;
     }
     const bool tm = p->timing && p->timing_n < 4;
@@ -599,9 +726,18 @@ static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t 
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st,
                        static_cast<const IT *>(ui_ptr), pack, static_cast<const IT *>(iu_ptr),
                        iu_idx, iu_val, desc, p->d_task, p->n_btasks, p->n_items, p->row_lo, p->P, p->Q,
-                       p->W,
+                       p->W, p->symmetric,
+                       p->symmetric ? reinterpret_cast<uint16_t *>(ws + p->off_strip) : nullptr,
                        min_sim, cnt, off, out_idx, out_val,
                        p->ctl ? p->ctl->dev() : TaskCtlDev{});
+    if (p->symmetric && WRITE && COUNT) {
+        // the windows left of the diagonal: transposes of the accumulated blocks
+        const int64_t pairs = (int64_t)p->P * (p->P - 1) / 2;
+        const int64_t strips = p->W / 64;
+        hipLaunchKernelGGL(iknn_mirror_kernel, dim3((unsigned)(pairs * strips)), dim3(256), 0, st,
+                           cnt, reinterpret_cast<const uint16_t *>(ws + p->off_strip), p->n_items,
+                           p->P, p->W, out_idx, out_val);
+    }
     if (tm) {
         LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
         p->timing_n++;

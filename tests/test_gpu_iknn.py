@@ -175,3 +175,35 @@ def test_save_nbrs_rejected_by_raw_build(gpu, oracle, ml_small):
     lib = _native.load()
     assert lib.lk_iknn_truncate_count(None, None, None, None, 0, None, 5, 0, 5, 0, None, None,
                                       ctypes.byref(ctypes.c_int64(0)), None) == _native.LK_E_INVALID
+
+
+def test_symmetric_build_equals_full_build(gpu, rng, monkeypatch):
+    """
+    The symmetric build (windows on / right of the diagonal accumulated, the others mirrored
+    from their transposes) and the full build give the same CSR, bit for bit: multi-window
+    matrix with a partial last window, empty items, heavy items.
+    """
+    from lkpy_amd import _device as D
+
+    monkeypatch.setenv("LK_IKNN_W", "1024")
+    n_users, n_items = 3000, 5 * 1024 + 333
+    lens = np.clip(rng.geometric(1 / 25.0, n_users), 1, 400)
+    rows = np.repeat(np.arange(n_users), lens)
+    pop = rng.zipf(1.3, len(rows)) % n_items
+    cols = (pop * 7919) % n_items
+    m = sps.csr_array((np.ones(len(rows), np.float32), (rows, cols)), shape=(n_users, n_items))
+    m.sum_duplicates()
+    m.data = rng.random(m.nnz).astype(np.float32) + 0.1
+    m.sort_indices()
+    iu = sps.csr_array(m.T)
+    iu.sort_indices()
+    dui, diu = D.DeviceCSR.from_scipy(m, gpu), D.DeviceCSR.from_scipy(iu, gpu)
+    outs = {}
+    for sym in ("1", "0"):
+        monkeypatch.setenv("LK_IKNN_SYMMETRIC", sym)
+        o = D.iknn_build(dui, diu, 1.0e-6, None)
+        outs[sym] = (o.indptr.cpu().numpy(), o.indices.cpu().numpy(), o.values.cpu().numpy())
+    assert outs["1"][0][-1] > 100000
+    for a, b in zip(outs["1"], outs["0"]):
+        assert np.array_equal(a.view(np.uint8) if a.dtype == np.float32 else a,
+                              b.view(np.uint8) if b.dtype == np.float32 else b)
