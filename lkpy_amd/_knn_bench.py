@@ -1,6 +1,7 @@
 """Item-kNN model-build leg of bench.py (BASELINE.json metric, second half)."""
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -111,8 +112,12 @@ def run(ratings: sps.csr_array, dev, reps: int = 2, checker=None) -> dict:
         "frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / 8000.0, 4),
         "avg_launch_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
         "traffic": None,
+        "symmetric": os.environ.get("LK_IKNN_SYMMETRIC", "1") != "0",
         "note": "the packed user rows (200 MB) are L2/MALL resident: reported against the HBM "
-        "peak, flagged cache-resident (SURVEY 8d)",
+        "peak, flagged cache-resident (SURVEY 8d).  Symmetric build: algorithmic bytes count the "
+        "whole product stream (SURVEY 8d) although only the windows on / right of the diagonal "
+        "(about 53 % of the multiply-accumulates) are accumulated, the rest is mirrored; "
+        "avg_launch_ms = build kernel + mirror kernel",
     }
     cpu = par = None
     if checker is not None:

@@ -1,9 +1,6 @@
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out/prof_knn_sym
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_knn_sym/stats -o knn -- python tools/knn_only.py > gpurun_out/prof_knn_sym/stats.log 2>&1
-python - <<'PY'
-import csv,glob
-f=glob.glob('gpurun_out/prof_knn_sym/stats/*kernel_stats.csv')[0]
-for r in list(csv.DictReader(open(f)))[:8]:
-    print(r['Name'][:70], r['Calls'], r['AverageNs'], r['Percentage'])
-PY
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gputest.log
+tail -3 gpurun_out/gputest.log
+timeout 600 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?" >> gpurun_out/bench.err
+tail -1 gpurun_out/bench.err
+timeout 600 bash tools/prof_knn.sh r02b > gpurun_out/prof_knn.log 2>&1
