@@ -198,6 +198,29 @@ def test_engine_single_process_relabelling_round_trip(oracle, explicit):
         assert np.allclose(eng.otor(), oracle.implicit_otor(Q, 0.1), rtol=1e-3, atol=1e-5)
 
 
+def test_engine_deferred_initial_factors(oracle):
+    """
+    ``defer_init=True`` + ``set_initial`` (the trainer draws the host random numbers while the
+    engine uploads / relabels the matrix) is the same engine as passing the factors up front.
+    """
+    from lkpy_amd._als_engine import ImplicitALSEngine
+
+    rng = np.random.default_rng(4)
+    n_users, n_items, k = 90, 50, 4
+    ui = sps.csr_array(np.where(rng.random((n_users, n_items)) < 0.12, 40.0, 0).astype(np.float32))
+    ui.eliminate_zeros()
+    Q0, P0 = oracle.als_initial_params(rng, n_items, k), oracle.als_initial_params(rng, n_users, k)
+    a = ImplicitALSEngine(ui, k, 0.1, 0.2, P0, Q0, OracleBackend(k))
+    b = ImplicitALSEngine(ui, k, 0.1, 0.2, None, None, OracleBackend(k), defer_init=True)
+    assert b._qtq is None
+    b.set_initial(P0, Q0)
+    for eng in (a, b):
+        eng.train_epoch()
+    assert np.array_equal(a.user_embeddings(), b.user_embeddings())
+    assert np.array_equal(a.item_embeddings(), b.item_embeddings())
+    assert np.array_equal(np.asarray(a.otor()), np.asarray(b.otor()))
+
+
 # ---------------------------------------------------------------------------------------
 # item-kNN build / dense top-N sharded over ranks (lkpy_amd/_sharded.py), oracle standing in
 # ---------------------------------------------------------------------------------------
