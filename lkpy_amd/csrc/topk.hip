@@ -35,9 +35,21 @@ constexpr int SC_IB = 256;  // items per block tile
 #define LK_TOPK_KC 32
 #endif
 constexpr int SC_KC = LK_TOPK_KC;   // features staged per pass (42 KiB of LDS: 3 workgroups per CU)
-constexpr int SC_LD = SC_KC + 1;
+constexpr int SC_LD = SC_KC + 1;    // conflict-free ds_read_b32 operand fetches
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifdef LK_TOPK_PHASES
+// Diagnostic build only (tools/topk_variants.py): shader-clock cycles of the filter kernel per
+// wave, 8 words: [0] operand wait + staging + barrier, [1] MFMA loop, [2] barrier after the loop,
+// [3] flags + records, [4] flush, [5] barrier after the epilogue, [6] tiles, [7] whole
+__device__ unsigned long long *lk_topk_phase_buf;
+#define LK_TP_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define LK_TP_ADD(i, a, b) ph[i] += (b) - (a)
+#else
+#define LK_TP_T(var)
+#define LK_TP_ADD(i, a, b)
+#endif
 
 // FILTER = false: write the score tile to `scores`.  FILTER = true (fused selection, stage 2):
 // nothing is written but the entries that reach the row's threshold tau[u] (a lower bound of
@@ -76,6 +88,10 @@ __device__ __forceinline__ void score_panel_body(
             s_cnt[r] = 0u;
         }
     }
+#ifdef LK_TOPK_PHASES
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    LK_TP_T(tp_begin);
+#endif
 
     constexpr int UV = UB * (SC_KC / 4) / 256;     // float4 per thread, user panel
     constexpr int IV = SC_IB * (SC_KC / 4) / 256;  // float4 per thread, item panel
@@ -96,7 +112,34 @@ __device__ __forceinline__ void score_panel_body(
 
         // Software pipeline: the next 32-feature slab of both panels is fetched into registers
         // (coalesced float4 reads) while the MFMAs of the current slab run out of LDS.
-        auto fetch = [&](int kc) {
+        auto fetch = [&](int64_t t0, int kc) {  // t0: first item of the tile
+            if constexpr (FILTER) {
+                // the fused path runs with kp % SC_KC == 0 (use_fused): no feature predicate; rows
+                // past the end are clamped to the last one (their scores are never taken: tau =
+                // +inf for such users, the `in` test for such items) -- unpredicated loads, one
+                // 32-bit lane offset against a scalar tile base instead of a 64-bit address each
+                constexpr int RPQ = 256 / (SC_KC / 4);  // rows per q step
+                const int r0 = tid / (SC_KC / 4);
+                const unsigned cb = (unsigned)(tid % (SC_KC / 4)) * 16u;
+                const char *ubase = reinterpret_cast<const char *>(users + u0 * ld_u + kc);
+                const char *ibase = reinterpret_cast<const char *>(items + t0 * ld_i + kc);
+                const int64_t nu64 = n_users - u0, ni64 = n_items - t0;
+                const int nu = (int)(nu64 < UB ? nu64 : UB) - 1;
+                const int ni = (int)(ni64 < SC_IB ? ni64 : SC_IB) - 1;
+#pragma unroll
+                for (int q = 0; q < UV; ++q) {
+                    const int r = min(r0 + q * RPQ, nu);
+                    ru[q] = *reinterpret_cast<const f32x4 *>(
+                        ubase + ((unsigned)r * (unsigned)ld_u * 4u + cb));
+                }
+#pragma unroll
+                for (int q = 0; q < IV; ++q) {
+                    const int r = min(r0 + q * RPQ, ni);
+                    ri[q] = *reinterpret_cast<const f32x4 *>(
+                        ibase + ((unsigned)r * (unsigned)ld_i * 4u + cb));
+                }
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < UV; ++q) {
                 const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
@@ -108,8 +151,8 @@ __device__ __forceinline__ void score_panel_body(
             for (int q = 0; q < IV; ++q) {
                 const int e = tid + q * 256, r = e / (SC_KC / 4), c4 = e % (SC_KC / 4);
                 ri[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (i0 + r < n_items && kc + c4 * 4 < kp)
-                    ri[q] = *reinterpret_cast<const f32x4 *>(items + (i0 + r) * ld_i + kc + c4 * 4);
+                if (t0 + r < n_items && kc + c4 * 4 < kp)
+                    ri[q] = *reinterpret_cast<const f32x4 *>(items + (t0 + r) * ld_i + kc + c4 * 4);
             }
         };
         auto stage = [&]() {
@@ -126,11 +169,16 @@ __device__ __forceinline__ void score_panel_body(
                 d[0] = ri[q].x; d[1] = ri[q].y; d[2] = ri[q].z; d[3] = ri[q].w;
             }
         };
-        fetch(0);
+        LK_TP_T(tp0);
+        // filter: the first slab of every tile but the first was requested in the previous
+        // tile's epilogue
+        if (!FILTER || itile == it_begin) fetch(i0, 0);
         for (int kc = 0; kc < kp; kc += SC_KC) {
+            LK_TP_T(tp1);
             stage();
             __syncthreads();
-            if (kc + SC_KC < kp) fetch(kc + SC_KC);
+            if (kc + SC_KC < kp) fetch(i0, kc + SC_KC);
+            LK_TP_T(tp2);
             // v_mfma_f32_32x32x2_f32: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]
             const int r = lane & 31, h = lane >> 5;
 #pragma unroll 4
@@ -147,7 +195,15 @@ __device__ __forceinline__ void score_panel_body(
                             __builtin_amdgcn_mfma_f32_32x32x2f32(a[ut], b, acc[ut][t], 0, 0, 0);
                 }
             }
+#ifdef LK_TOPK_PHASES
+            asm volatile("" : "+v"(acc[0][0]), "+v"(acc[UT - 1][3]));
+#endif
+            LK_TP_T(tp3);
             __syncthreads();  // everyone is done reading before the next slab is staged
+            LK_TP_T(tp4);
+            LK_TP_ADD(0, kc == 0 ? tp0 : tp1, tp2);
+            LK_TP_ADD(1, tp2, tp3);
+            LK_TP_ADD(2, tp3, tp4);
         }
         // C/D: col (item) = lane&31, row (user) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
         if constexpr (!FILTER) {
@@ -164,27 +220,45 @@ __device__ __forceinline__ void score_panel_body(
                     }
                 }
         } else {
-            // Hits (score >= tau of its row; NaN fails) are rare after stage 1 -- a few per row
-            // and tile.  A memory operation per hit inside 64 * UT divergent branches would
-            // serialise the wave on latency, so the hits are first compacted wave-wide into this
-            // wave's share of the (idle until the next tile is staged) operand LDS; then a lane
-            // per hit takes its slot from the row's LDS counter and writes the candidate.
-            constexpr int STAGE = 2048;  // entries per wave: key (u32) + row << 8 | column (u16)
-            static_assert(4 * STAGE * 6 <= (UB + SC_IB) * SC_LD * 4, "staging must fit the operand LDS");
-            unsigned *skey = reinterpret_cast<unsigned *>(lds_all) + wave * STAGE;
-            unsigned short *src = reinterpret_cast<unsigned short *>(
-                                      reinterpret_cast<unsigned *>(lds_all) + 4 * STAGE) + wave * STAGE;
+            // Hits (score >= tau of its row; NaN fails) are rare after stage 1: 0.5 % of the
+            // scores, 30 % of the accumulator registers of a wave hold one.  A branch per
+            // register (taken when nothing hit) and a handler per hit cost a wave as much as
+            // the tile's MFMAs (measured: 14.6 k cycles of a 41 k-cycle tile), so the epilogue is
+            // straight-line code per 32 x 32 tile instead: 16 flag bits per lane (compare +
+            // add-with-carry on the VALU alone), and a lane with any flag stores its 16
+            // accumulators as one RECORD (4 ds_write_b128 + an id word with the flags) in this
+            // wave's share of the operand LDS, which is idle until the next tile is staged.  The
+            // flush takes a lane per record, walks its flagged values (1.1 on average), tests
+            // x >= tau itself, takes the slot from the row's LDS counter and writes the candidate.
+            constexpr int REC_CAP = 128;  // records per wave
+            static_assert((4 * REC_CAP * 16 + 4 * REC_CAP) * 4 <= (UB + SC_IB) * SC_LD * 4,
+                          "records must fit the operand LDS");
+            float *rvals = lds_all + wave * (REC_CAP * 16);
+            unsigned *rids = reinterpret_cast<unsigned *>(lds_all + 4 * REC_CAP * 16) + wave * REC_CAP;
             const unsigned long long lt_mask = (1ull << lane) - 1ull;
-            int base = 0;  // wave-uniform
+            int base = 0;  // records held, wave-uniform
+            LK_TP_T(tp5);
             auto flush = [&]() {
-                for (int i = lane; i < base; i += 64) {
-                    const unsigned key = skey[i], rc = src[i];
-                    const unsigned row = rc >> 8;
-                    const unsigned it = (unsigned)(i0 + (rc & 0xffu));
-                    const unsigned pos = atomicAdd(&s_cnt[row], 1u);  // LDS
-                    if (pos < (unsigned)cand_cap)
-                        cand[(u0 + row) * cand_cap + pos] =
-                            ((unsigned long long)key << 32) | (0xffffffffu - it);
+                for (int r0 = 0; r0 < base; r0 += 64) {
+                    const int rec = r0 + lane;
+                    const unsigned id = rec < base ? rids[rec] : 0u;
+                    unsigned lm = id >> 16;
+                    const unsigned ls = id & 63u;
+                    const unsigned rowb = wu + ((id >> 8) & 0xffu) * 32 + 4 * (ls >> 5);
+                    const unsigned it = (unsigned)(i0 + wi + ((id >> 6) & 3u) * 32 + (ls & 31u));
+                    while (lm) {
+                        const int b = 31 - __clz(lm);
+                        lm &= ~(1u << b);
+                        const int rg = 15 - b;
+                        const float x = rvals[rec * 16 + rg];
+                        const unsigned row = rowb + (rg & 3) + 8 * (rg >> 2);
+                        if (x >= s_tau[row]) {  // the flag is "not below": NaN ends here
+                            const unsigned pos = atomicAdd(&s_cnt[row], 1u);  // LDS
+                            if (pos < (unsigned)cand_cap)
+                                cand[(u0 + row) * cand_cap + pos] =
+                                    ((unsigned long long)f2key(x) << 32) | (0xffffffffu - it);
+                        }
+                    }
                 }
                 base = 0;
             };
@@ -196,33 +270,48 @@ __device__ __forceinline__ void score_panel_body(
                     th[rg] = s_tau[wu + ut * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5)];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    // a group of 16 sites appends at most 1024 entries: one capacity check
-                    if (base > STAGE - 1024) flush();
                     const int col = wi + t * 32 + (lane & 31);
                     const bool in = i0 + col < n_items;
+                    // lm: bit 15 - rg = !(x[rg] < th[rg]), shifted in through the carry; two
+                    // chains, a scalar mask pair each
+                    unsigned lma = 0u, lmb = 0u;
 #pragma unroll
-                    for (int rg = 0; rg < 16; ++rg) {
-                        const float x = acc[ut][t][rg];
-#ifdef LK_TOPK_NO_HITS  // experiment: the filter GEMM without its epilogue's candidate traffic
-                        const bool hit = in && x >= th[rg] && x > 3.0e38f;  // never, but not provably
-#else
-                        const bool hit = in && x >= th[rg];
-#endif
-                        const unsigned long long m = __ballot(hit);
-                        if (m) {  // wave-uniform
-                            if (hit) {
-                                const int slot = base + __popcll(m & lt_mask);
-                                const int row = wu + ut * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
-                                skey[slot] = f2key(x);
-                                src[slot] = (unsigned short)((row << 8) | col);
-                            }
-                            base += __popcll(m);
-                        }
+                    for (int rg = 0; rg < 8; ++rg) {
+                        unsigned long long ca, cb;
+                        asm("v_cmp_nlt_f32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, %0, %0, %1"
+                            : "+v"(lma), "=&s"(ca) : "v"(acc[ut][t][rg]), "v"(th[rg]));
+                        asm("v_cmp_nlt_f32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, %0, %0, %1"
+                            : "+v"(lmb), "=&s"(cb) : "v"(acc[ut][t][rg + 8]), "v"(th[rg + 8]));
                     }
+                    const unsigned lm = (lma << 8) | lmb;
+                    const bool h = in && lm != 0u;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(h);
+                    if (base + __popcll(m) > REC_CAP) flush();  // wave-uniform
+                    if (h) {
+                        const int slot = base + __popcll(m & lt_mask);
+                        f32x4 *dst = reinterpret_cast<f32x4 *>(rvals + slot * 16);
+                        const f32x16 a = acc[ut][t];
+                        dst[0] = f32x4{a[0], a[1], a[2], a[3]};
+                        dst[1] = f32x4{a[4], a[5], a[6], a[7]};
+                        dst[2] = f32x4{a[8], a[9], a[10], a[11]};
+                        dst[3] = f32x4{a[12], a[13], a[14], a[15]};
+                        rids[slot] = (lm << 16) | (unsigned)((ut << 8) | (t << 6)) | (unsigned)lane;
+                    }
+                    base += __popcll(m);
                 }
+                // the next tile's first slab: requested once the first half of the accumulators
+                // is dead (its registers take the data), in flight behind the rest of the epilogue
+                if (ut == 0 && itile + 1 < it_end) fetch(i0 + SC_IB, 0);
             }
+            LK_TP_T(tp6);
             flush();
-            __syncthreads();  // the staging area is the next tile's operand slab
+            LK_TP_T(tp7);
+            __syncthreads();  // the records lie in the next tile's operand slab
+            LK_TP_T(tp8);
+            LK_TP_ADD(3, tp5, tp6);
+            LK_TP_ADD(4, tp6, tp7);
+            LK_TP_ADD(5, tp7, tp8);
+            LK_TP_ADD(6, 0, 1);
         }
         if constexpr (!FILTER) break;  // one tile per workgroup: no loop at all for the compiler
         ++itile;
@@ -231,6 +320,13 @@ __device__ __forceinline__ void score_panel_body(
         __syncthreads();
         for (int r = tid; r < UB; r += 256)
             if (u0 + r < n_users) cand_cnt[u0 + r] = s_cnt[r];
+#ifdef LK_TOPK_PHASES
+        LK_TP_T(tp_end);
+        ph[7] = tp_end - tp_begin;
+        if (lane == 0 && lk_topk_phase_buf)
+            for (int i = 0; i < 8; ++i)
+                lk_topk_phase_buf[((size_t)blockIdx.x * 4 + wave) * 8 + i] = ph[i];
+#endif
     }
 }
 
@@ -698,10 +794,11 @@ static int64_t fused_min_users()
     return e ? (int64_t)atol(e) : (int64_t)8192;  // fewer rows: too few workgroups, panel path
 }
 
-static bool use_fused(int64_t n_users, int64_t n_items, int32_t n)
+static bool use_fused(int64_t n_users, int64_t n_items, int32_t n, int kp = SC_KC)
 {
+    // kp: whole SC_KC-feature slabs only (the filter kernel loads them without a feature predicate)
     return n >= 1 && n <= FUSED_MAX_N && n_items >= fused_min_items() &&
-           n_items >= 64 * (int64_t)n && n_users >= fused_min_users();
+           n_items >= 64 * (int64_t)n && n_users >= fused_min_users() && kp % SC_KC == 0;
 }
 
 // target size of the stage-1 sample: a sixteenth of the catalogue, at least 16 n, a multiple of 256
@@ -782,6 +879,14 @@ static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n)
 }
 
 }  // namespace lk
+
+#ifdef LK_TOPK_PHASES
+extern "C" int lk_topk_phase_set(unsigned long long *d_buf)
+{
+    LK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(lk::lk_topk_phase_buf), &d_buf, sizeof(d_buf)));
+    return LK_OK;
+}
+#endif
 
 extern "C" size_t lk_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t n)
 {
@@ -895,7 +1000,7 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
         return LK_OK;
     };
 
-    if (!full && lk::use_fused(n_users, n_items, n)) {
+    if (!full && lk::use_fused(n_users, n_items, n, KP)) {
         const lk::FusedLayout L = lk::fused_layout(n_users, n_items, n);
         char *fw = static_cast<char *>(d_ws) + panel_bytes;
         float *sub = reinterpret_cast<float *>(fw + L.off_sub);
