@@ -354,6 +354,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 }
 #undef LK_SCORE_ARGS
 
+// Bitonic sort of p2 (a power of two >= 2) LDS elements, descending, by the 256 threads of a
+// workgroup.  Thread q of a stage owns the PAIR (i, i | j), i = q with a zero inserted at bit
+// log2 j -- no idle half -- and the 64 pairs of a wave then cover exactly 128 consecutive
+// elements whenever j <= 64: those stages need no workgroup barrier (a wave's LDS operations
+// execute in order), so a 512-element sort takes 6 barriers instead of 45.  Callers
+// synchronise before (data in place) and may read after the final barrier.
+template <typename T>
+__device__ __forceinline__ void bitonic_desc_lds(T *a, unsigned p2, int tid)
+{
+    const unsigned npair = p2 >> 1;
+    auto cx = [&](unsigned q, unsigned k, unsigned j) {
+        const unsigned i = ((q & ~(j - 1u)) << 1) | (q & (j - 1u)), p = i | j;
+        const T x = a[i], y = a[p];
+        const bool desc = (i & k) == 0;
+        if (desc ? (x < y) : (x > y)) {
+            a[i] = y;
+            a[p] = x;
+        }
+    };
+    const unsigned klocal = p2 < 128u ? p2 : 128u;
+    for (unsigned q = tid; q < npair; q += 256)
+        for (unsigned k = 2; k <= klocal; k <<= 1)
+            for (unsigned j = k >> 1; j > 0; j >>= 1) {
+                cx(q, k, j);
+                __builtin_amdgcn_wave_barrier();
+            }
+    __syncthreads();
+    for (unsigned k = 256; k <= p2; k <<= 1) {
+        for (unsigned j = k >> 1; j >= 128; j >>= 1) {
+            for (unsigned q = tid; q < npair; q += 256) cx(q, k, j);
+            __syncthreads();
+        }
+        for (unsigned q = tid; q < npair; q += 256)
+            for (unsigned j = 64; j > 0; j >>= 1) {
+                cx(q, k, j);
+                __builtin_amdgcn_wave_barrier();
+            }
+        __syncthreads();
+    }
+}
+
 // stage 3 of the fused selection: one workgroup per row.  The candidates (every entry >= tau)
 // are loaded, the row's excluded items are struck out through a small LDS hash of the
 // candidates' item numbers (the exclusion list may be in any order and of any length: it is
@@ -388,20 +429,21 @@ __global__ __launch_bounds__(256) void cand_select_kernel(
     while (p2 < m) p2 <<= 1;
     if (p2 < 2) p2 = 2;
     for (unsigned i = tid; i < p2; i += 256) key[i] = i < m ? cand[b * CAP + i] : 0ull;
-    for (int i = tid; i < 2 * CAP; i += 256) hslot[i] = 0;
+    const unsigned hmask = 2 * p2 - 1;  // table of 2 p2 >= 2 m slots
+    for (unsigned i = tid; i <= hmask; i += 256) hslot[i] = 0;
     __syncthreads();
     if (excl_ptr) {
         const int64_t eb = excl_ptr[user_base + b], ee = excl_ptr[user_base + b + 1];
         if (ee > eb) {
             for (unsigned i = tid; i < m; i += 256) {
                 const unsigned it = 0xffffffffu - (unsigned)(key[i] & 0xffffffffu);
-                unsigned h = (it * 2654435761u) & (2 * CAP - 1);
-                while (atomicCAS(&hslot[h], 0, (int)i + 1) != 0) h = (h + 1) & (2 * CAP - 1);
+                unsigned h = (it * 2654435761u) & hmask;
+                while (atomicCAS(&hslot[h], 0, (int)i + 1) != 0) h = (h + 1) & hmask;
             }
             __syncthreads();
             for (int64_t e = eb + tid; e < ee; e += 256) {
                 const unsigned it = (unsigned)excl_items[e];
-                unsigned h = (it * 2654435761u) & (2 * CAP - 1);
+                unsigned h = (it * 2654435761u) & hmask;
                 for (;;) {
                     const int s = hslot[h];
                     if (s == 0) break;
@@ -410,28 +452,13 @@ __global__ __launch_bounds__(256) void cand_select_kernel(
                         key[s - 1] = 0ull;  // excluded: sorts to the end, never emitted
                         break;
                     }
-                    h = (h + 1) & (2 * CAP - 1);
+                    h = (h + 1) & hmask;
                 }
             }
             __syncthreads();
         }
     }
-    for (unsigned k = 2; k <= p2; k <<= 1) {
-        for (unsigned j = k >> 1; j > 0; j >>= 1) {
-            for (unsigned i = tid; i < p2; i += 256) {
-                const unsigned ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = key[i], c = key[ixj];
-                    const bool desc = ((i & k) == 0);
-                    if (desc ? (a < c) : (a > c)) {
-                        key[i] = c;
-                        key[ixj] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
+    bitonic_desc_lds(key, p2, tid);
     for (int i = tid; i < n; i += 256) {
         const unsigned long long c = (unsigned)i < p2 ? key[i] : 0ull;
         if (c != 0ull) {
@@ -446,17 +473,56 @@ __global__ __launch_bounds__(256) void cand_select_kernel(
     if (tid == 0 && ((unsigned)(n - 1) >= p2 || key[n - 1] == 0ull)) flag();
 }
 
-// tau[b] = the n-th best score of the stage-1 sample (or -inf when the sample holds fewer
-// than n candidates: everything then passes and the row falls back through the overflow flag)
-__global__ void tau_from_topn_kernel(const float *__restrict__ sub_scores, int64_t ld, int n,
-                                     int64_t n_rows, float *__restrict__ tau,
-                                     unsigned *__restrict__ cand_cnt)
+// Stage 1 of the fused selection, a wave per row: tau[b] = the r-th largest of 256 class maxima
+// of the row's sample scores (class = float4 index mod 256; NaN -- excluded items -- skipped).
+// At least r sample scores reach it, so it is a lower bound of the r-th largest sample score
+// (the two coincide unless two of the r best share a class: tau is then the next class
+// maximum down, a few per cent more candidates) -- one sweep of the row, no sort: the r-th
+// largest of the 256 keys, four per lane, comes from a bitwise search with wave ballots.
+// Fewer than r classes with a valid score: tau = -inf (everything passes, the row overflows and
+// is redone through the panel path).
+__global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict__ sub, int64_t ld,
+                                                         int64_t n_sub, int r, int64_t n_rows,
+                                                         float *__restrict__ tau,
+                                                         unsigned *__restrict__ cand_cnt)
 {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_rows) return;
-    const float x = sub_scores[b * ld + n - 1];
-    tau[b] = (x == x) ? x : -__builtin_inff();
-    cand_cnt[b] = 0u;
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_rows) return;  // wave-uniform
+    const float *row = sub + b * ld;
+    const f32x4 *row4 = reinterpret_cast<const f32x4 *>(row);  // ld % 64 == 0, 256-byte aligned base
+    const int64_t n4 = n_sub / 4;
+    unsigned v[4] = {0u, 0u, 0u, 0u};  // valid keys are >= f2key(-inf) > 0
+    for (int64_t j0 = 0; j0 < n4; j0 += 256) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t i = j0 + 64 * c + lane;
+            if (i < n4) {
+                const f32x4 x = row4[i];
+                if (x.x == x.x) v[c] = max(v[c], f2key(x.x));
+                if (x.y == x.y) v[c] = max(v[c], f2key(x.y));
+                if (x.z == x.z) v[c] = max(v[c], f2key(x.z));
+                if (x.w == x.w) v[c] = max(v[c], f2key(x.w));
+            }
+        }
+    }
+    for (int64_t i = n4 * 4 + lane; i < n_sub; i += 64) {
+        const float x = row[i];
+        if (x == x) v[0] = max(v[0], f2key(x));
+    }
+    // largest t with #{v >= t} >= r
+    unsigned cur = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned trial = cur | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cnt += __popcll(__builtin_amdgcn_ballot_w64(v[c] >= trial));
+        if (cnt >= r) cur = trial;  // wave-uniform
+    }
+    if (lane == 0) {
+        tau[b] = cur ? key2f(cur) : -__builtin_inff();
+        cand_cnt[b] = 0u;
+    }
 }
 
 // scores[b][excluded item] = NaN  (NaN is skipped by the selection, like the reference).
@@ -654,20 +720,7 @@ __global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__
         tmax[tid] = best;
         if (tid == 0) f_count = 0;
         __syncthreads();
-        for (unsigned k = 2; k <= 256; k <<= 1) {
-            for (unsigned j = k >> 1; j > 0; j >>= 1) {
-                const unsigned i = tid, ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned a = tmax[i], b = tmax[ixj];
-                    const bool desc = ((i & k) == 0);
-                    if (desc ? (a < b) : (a > b)) {
-                        tmax[i] = b;
-                        tmax[ixj] = a;
-                    }
-                }
-                __syncthreads();
-            }
-        }
+        bitonic_desc_lds(tmax, 256u, tid);
         const unsigned tau = tmax[n - 1];
         if (tau > 0) {
             const int lane = tid & 63;
@@ -719,22 +772,7 @@ __global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__
     while (p2 < m) p2 <<= 1;
     for (unsigned i = m + tid; i < p2; i += 256) cand[i] = 0ull;
     __syncthreads();
-    for (unsigned k = 2; k <= p2; k <<= 1) {
-        for (unsigned j = k >> 1; j > 0; j >>= 1) {
-            for (unsigned i = tid; i < p2; i += 256) {
-                const unsigned ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = cand[i], b = cand[ixj];
-                    const bool desc = ((i & k) == 0);
-                    if (desc ? (a < b) : (a > b)) {
-                        cand[i] = b;
-                        cand[ixj] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
+    if (p2 >= 2) bitonic_desc_lds(cand, p2, tid);
     for (int i = tid; i < n; i += 256) {
         if ((unsigned)i < m) {
             const unsigned long long c = cand[i];
@@ -847,7 +885,7 @@ static int fused_tau_rank(int64_t n_items, int32_t n)
 constexpr int FUSED_REDO_CAP = 4096;  // rows redone one by one; more: everything through the panel
 
 struct FusedLayout {
-    size_t off_sub, off_tau, off_cnt, off_cand, off_sidx, off_ssc, off_flags, off_qs, bytes;
+    size_t off_sub, off_tau, off_cnt, off_cand, off_flags, off_qs, bytes;
 };
 
 static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n)
@@ -866,10 +904,6 @@ static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n)
     off += align_up((size_t)rows * 4, 256);
     L.off_cand = off;
     off += align_up((size_t)rows * FUSED_CAP * 8, 256);
-    L.off_sidx = off;
-    off += align_up((size_t)rows * n * 4, 256);
-    L.off_ssc = off;
-    off += align_up((size_t)rows * n * 4, 256);
     L.off_flags = off;  // redo list: count + rows
     off += align_up((size_t)(1 + FUSED_REDO_CAP) * 4, 256);
     L.off_qs = off;     // sample of the item factors, [n_sample x 256 floats at most]
@@ -1007,8 +1041,6 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
         float *tau = reinterpret_cast<float *>(fw + L.off_tau);
         unsigned *cnt = reinterpret_cast<unsigned *>(fw + L.off_cnt);
         auto *cand = reinterpret_cast<unsigned long long *>(fw + L.off_cand);
-        int32_t *sidx = reinterpret_cast<int32_t *>(fw + L.off_sidx);
-        float *ssc = reinterpret_cast<float *>(fw + L.off_ssc);
         int *redo = reinterpret_cast<int *>(fw + L.off_flags);
         float *qs = reinterpret_cast<float *>(fw + L.off_qs);
         const int stride = lk::fused_stride(n_items, n);
@@ -1038,10 +1070,8 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
                 hipLaunchKernelGGL(lk::score_mask_kernel, dim3((unsigned)rows), dim3(64), 0, st,
                                    d_excl_ptr, d_excl_items, ub, rows, n_items, sub, ld_sub,
                                    stride);
-            hipLaunchKernelGGL(lk::row_topn_kernel<lk::TOPN_MAX>, dim3((unsigned)rows), dim3(256),
-                               0, st, sub, ld_sub, n_sub, r_tau, sidx, ssc, (int64_t)n);
-            hipLaunchKernelGGL(lk::tau_from_topn_kernel, dim3((unsigned)((rows + 255) / 256)),
-                               dim3(256), 0, st, ssc, (int64_t)n, r_tau, rows, tau, cnt);
+            hipLaunchKernelGGL(lk::sample_tau_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                               st, sub, ld_sub, n_sub, r_tau, rows, tau, cnt);
             // stage 2: the full contraction, candidates only
             // one workgroup per 128 users, walking all item tiles (no global atomics)
             const dim3 ugrid((unsigned)((rows + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB)));
