@@ -20,8 +20,12 @@
 // largest key, equal keys are taken by LOWEST index, the <= n winners are bitonic-sorted in
 // LDS by (score desc, index asc).  Deterministic.
 //
-// Roofline: scoring is f32-MFMA bound (2*B*I*k flop); this first version writes the
-// B_tile x I score panel to HBM and reads it back for the selection (not yet fused).
+// Roofline: scoring is f32-MFMA bound (2*B*I*k flop).  Large calls take the FUSED path (no
+// score matrix): stage 1 scores a strided sample of the catalogue and takes a per-row threshold
+// from it (sample_tau_kernel), stage 2 is the full GEMM whose epilogue keeps only the scores
+// that reach the threshold (score_filter_kernel), stage 3 sorts each row's few hundred
+// candidates exactly (cand_select_kernel); rows the threshold fails on are redone through the
+// panel path (GEMM panel written once, row_topn_kernel), which also serves small calls.
 #include <cstdlib>
 #include <vector>
 

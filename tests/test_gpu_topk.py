@@ -120,14 +120,15 @@ def _oracle_topn(oracle, Q, u, excl, n):
     return s, want
 
 
-@pytest.mark.parametrize("k,n", [(64, 100), (25, 10), (128, 128)])
+@pytest.mark.parametrize("k,n", [(64, 100), (25, 10), (128, 128), (10, 10)])
 def test_score_topk_fused_path(gpu, oracle, rng, k, n, monkeypatch):
     """
     The fused scoring + selection path (catalogues >= 16 384 items: stage-1 threshold from an
     item sample, stage-2 GEMM emitting candidates only, stage-3 exact order) gives the SAME
     lists as the panel path and as the oracle: exclusion lists in any order and of any length,
     exact ties across the threshold, rows with fewer than n candidates, rows that overflow the
-    candidate buffer (all scores equal) and fall back.
+    candidate buffer (all scores equal) and fall back.  (k = 10 pads to 16 features, less than a
+    staged slab: such calls take the panel path whatever the sizes.)
     """
     from lkpy_amd import _device as D
 
@@ -212,3 +213,31 @@ def test_score_topk_fused_threshold_misses_are_redone(gpu, oracle, rng, monkeypa
         s, want = _oracle_topn(oracle, Q, U[b], ex[ptr[b] : ptr[b + 1]], n)
         assert np.array_equal(idx[b], want), b
         assert np.array_equal(sc[b].view(np.uint32), s[want].view(np.uint32)), b
+
+
+def test_score_topk_fused_non_finite_scores(gpu, rng, monkeypatch):
+    """
+    NaN and infinite scores through the fused path: its epilogue flags "not below the threshold"
+    (true for NaN), stores the lane's accumulators and tests them again in the flush -- NaN must
+    drop out there, +inf must be kept, -inf must lose, and rows whose threshold itself is
+    infinite must still give the panel path's lists, bit for bit.
+    """
+    from lkpy_amd import _device as D
+
+    monkeypatch.setenv("LK_TOPK_FUSED_MIN_USERS", "1")
+    B, I, k, n = 150, 17000, 64, 50
+    U = rng.standard_normal((B, k)).astype(np.float32)
+    Q = rng.standard_normal((I, k)).astype(np.float32)
+    Q[rng.choice(I, 300, replace=False), 3] = np.nan   # NaN score for every user
+    Q[rng.choice(I, 40, replace=False), 5] = np.inf    # +inf or -inf by the sign of U[:, 5]
+    Q[::16][:200, 7] = np.inf                          # many infinite scores inside the sample
+    U[4] = 0.0
+    U[4, 5] = 1.0   # inf * 0 = NaN elsewhere; +inf scores only
+    dU, dQ = D.to_device_padded(U, gpu), D.to_device_padded(Q, gpu)
+    idx, sc = D.score_topk(dU, dQ, k, n)
+    monkeypatch.setenv("LK_TOPK_FUSED_MIN_ITEMS", "1000000000")
+    idx2, sc2 = D.score_topk(dU, dQ, k, n)
+    assert np.array_equal(idx2.cpu().numpy(), idx.cpu().numpy())
+    assert np.array_equal(sc2.cpu().numpy().view(np.uint32), sc.cpu().numpy().view(np.uint32))
+    sc = sc.cpu().numpy()
+    assert not np.isnan(sc[idx.cpu().numpy() >= 0]).any()

@@ -3,4 +3,4 @@ timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/gputest.log 2>&1; 
 tail -3 gpurun_out/gputest.log
 timeout 600 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?" >> gpurun_out/bench.err
 tail -1 gpurun_out/bench.err
-timeout 600 bash tools/prof_knn.sh r02b > gpurun_out/prof_knn.log 2>&1
+timeout 400 bash tools/prof_topk.sh r02d > gpurun_out/prof_topk.log 2>&1
