@@ -358,6 +358,213 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 }
 #undef LK_SCORE_ARGS
 
+#ifndef LK_TOPK_DMA
+#define LK_TOPK_DMA 1  // k = 64 takes score_filter64_kernel (operands by global_load_lds); 0: never
+#endif
+// ---- the fused filter for 64 features: operands straight into LDS ------------------------------
+//
+// Same tile (128 users x 256 items per workgroup, 64 x 128 per wave, 128 accumulators), same
+// arithmetic (every score the k-ordered fmaf chain) and the same record epilogue as
+// score_filter_kernel, but no operand passes through a register on its way to LDS:
+//   * the workgroup's 128 x 64 user panel is loaded ONCE (32 KiB, resident for all item tiles),
+//   * the item tiles arrive as 16-feature slabs (256 x 16 floats = 16 KiB) in two buffers:
+//     slab g + 1 is requested (`global_load_lds_dwordx4`: a wave's instruction moves 1 KiB, lane l
+//     -> LDS bytes [16 l, 16 l + 16) of the block M0 names) before the MFMAs of slab g start, and
+//     one `s_waitcnt vmcnt(0)` + barrier per slab publishes it -- no staging registers, no
+//     ds_write, one barrier per slab instead of two.
+// The LDS side of such a load is linear in the lane, so the bank swizzle sits on the GLOBAL side:
+// position p of row r holds chunk p ^ f(r) of the row (f = r & 15 for the 16-chunk user rows,
+// (r >> 2) & 3 for the 4-chunk slab rows); the 32 rows of an MFMA operand fetch then hit 16
+// different 4-bank groups, two rows each (the unpadded pitch allows no better).
+// The records of the epilogue live in item buffer 1 (idle between a tile's last slab and the
+// next tile's first prefetch into it) -- wave w's 64 records are exactly the 4 KiB its own DMA
+// instructions write, so no barrier separates the flush from the next tile.
+constexpr int F64_U_FLOATS = 128 * 64;
+constexpr int F64_I_FLOATS = 256 * 16;  // one slab buffer
+constexpr int F64_LDS_FLOATS = F64_U_FLOATS + 2 * F64_I_FLOATS + 4 * 64 /* record ids */ + 2 * 128;
+
+__device__ __forceinline__ void lds_dma16(const void *src, unsigned lds_byte_addr)
+{
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_byte_addr)
+        : "memory");
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void score_filter64_kernel(
+    const float *__restrict__ users, int64_t n_users, const float *__restrict__ items,
+    int64_t n_items, const float *__restrict__ tau, unsigned long long *__restrict__ cand,
+    unsigned *__restrict__ cand_cnt, int cand_cap)
+{
+    constexpr int UT = 2, UB = 128;
+    __shared__ __attribute__((aligned(1024))) float lds_all[F64_LDS_FLOATS];
+    float *lu = lds_all;
+    float *li = lds_all + F64_U_FLOATS;
+    unsigned *rids_all = reinterpret_cast<unsigned *>(li + 2 * F64_I_FLOATS);
+    float *s_tau = reinterpret_cast<float *>(rids_all + 4 * 64);
+    unsigned *s_cnt = reinterpret_cast<unsigned *>(s_tau + UB);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t u0 = (int64_t)blockIdx.x * UB;
+    const int wu = (wave & 1) * 64, wi = (wave >> 1) * 128;
+    const int64_t n_itiles = (n_items + SC_IB - 1) / SC_IB;
+    const unsigned lds_u = (unsigned)(uintptr_t)lu, lds_i = (unsigned)(uintptr_t)li;
+
+    for (int r = tid; r < UB; r += 256) {
+        s_tau[r] = (u0 + r < n_users) ? tau[u0 + r] : __builtin_inff();
+        s_cnt[r] = 0u;
+    }
+    // user panel: instruction n = 8 wave + q moves rows 4 n .. 4 n + 3 (lane: row l >> 4,
+    // position l & 15 <- chunk (l & 15) ^ (row & 15))
+    {
+        const int64_t nu64 = n_users - u0;
+        const int nu = (int)(nu64 < UB ? nu64 : UB) - 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = wave * 8 + q;
+            const int row = n * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (row & 15);
+            const float *src = users + (u0 + min(row, nu)) * 64 + c * 4;
+            lds_dma16(src, lds_u + (unsigned)n * 1024u);
+        }
+    }
+    // item slab (tile origin t0, features 16 s ..) -> buffer s & 1: instruction n = 4 wave + q
+    // moves rows 16 n .. 16 n + 15 (lane: row l >> 2, position l & 3 <- chunk (l & 3) ^ ((row >> 2) & 3))
+    auto slab_dma = [&](int64_t t0, int s) {
+        const int64_t ni64 = n_items - t0;
+        const int ni = (int)(ni64 < SC_IB ? ni64 : SC_IB) - 1;
+        const float *base = items + t0 * 64 + 16 * s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = wave * 4 + q;
+            const int row = n * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((lane >> 4) & 3);  // (row >> 2) & 3 == (lane >> 4) & 3
+            const float *src = base + (int64_t)min(row, ni) * 64 + c * 4;
+            lds_dma16(src, lds_i + (unsigned)(s & 1) * (F64_I_FLOATS * 4u) + (unsigned)n * 1024u);
+        }
+    };
+    slab_dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // operand addresses (floats).  A: row wu + 32 ut + r, feature k: chunk (k >> 2) ^ (r & 15);
+    // B: row wi + 32 t + r of the slab, feature k' < 16: chunk (k' >> 2) ^ ((r >> 2) & 3)
+    const int r = lane & 31, h = lane >> 5;
+    int offa[16], offb[4];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) offa[c] = (wu + r) * 64 + ((c ^ (r & 15)) << 2) + h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) offb[c] = (wi + r) * 16 + ((c ^ ((r >> 2) & 3)) << 2) + h;
+
+    float *rvals = li + F64_I_FLOATS + wave * (64 * 16);  // 64 records of 16 floats: this wave's 4 KiB of buffer 1
+    unsigned *rids = rids_all + wave * 64;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    for (int64_t itile = 0; itile < n_itiles; ++itile) {
+        const int64_t i0 = itile * SC_IB;
+        f32x16 acc[UT][4];
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[ut][t][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // request the next slab (of this tile, or the first of the next one)
+            if (s < 3) slab_dma(i0, s + 1);
+            else if (itile + 1 < n_itiles) slab_dma(i0 + SC_IB, 0);
+            const float *ib = li + (s & 1) * F64_I_FLOATS;
+#pragma unroll
+            for (int kk = 0; kk < 16; kk += 2) {
+                float a[UT], b[4];
+#pragma unroll
+                for (int ut = 0; ut < UT; ++ut)
+                    a[ut] = lu[offa[4 * s + (kk >> 2)] + ut * (32 * 64) + (kk & 2)];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = ib[offb[kk >> 2] + t * (32 * 16) + (kk & 2)];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int ut = 0; ut < UT; ++ut)
+                        acc[ut][t] =
+                            __builtin_amdgcn_mfma_f32_32x32x2f32(a[ut], b[t], acc[ut][t], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next slab
+            __syncthreads();  // everyone's share; everyone done reading this slab
+        }
+        // epilogue: see score_panel_body (records; here in this wave's 4 KiB of item buffer 1)
+        int base = 0;
+        auto flush = [&]() {
+            const int rec = lane;  // base <= 64
+            const unsigned id = rec < base ? rids[rec] : 0u;
+            unsigned lm = id >> 16;
+            const unsigned ls = id & 63u;
+            const unsigned rowb = wu + ((id >> 8) & 0xffu) * 32 + 4 * (ls >> 5);
+            const unsigned it = (unsigned)(i0 + wi + ((id >> 6) & 3u) * 32 + (ls & 31u));
+            while (lm) {
+                const int bt = 31 - __clz(lm);
+                lm &= ~(1u << bt);
+                const int rg = 15 - bt;
+                const float x = rvals[rec * 16 + rg];
+                const unsigned row = rowb + (rg & 3) + 8 * (rg >> 2);
+                if (x >= s_tau[row]) {  // the flag is "not below": NaN ends here
+                    const unsigned pos = atomicAdd(&s_cnt[row], 1u);  // LDS
+                    if (pos < (unsigned)cand_cap)
+                        cand[(u0 + row) * cand_cap + pos] =
+                            ((unsigned long long)f2key(x) << 32) | (0xffffffffu - it);
+                }
+            }
+            base = 0;
+        };
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+            float th[16];
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg)
+                th[rg] = s_tau[wu + ut * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5)];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int col = wi + t * 32 + (lane & 31);
+                const bool in = i0 + col < n_items;
+                unsigned lma = 0u, lmb = 0u;
+#pragma unroll
+                for (int rg = 0; rg < 8; ++rg) {
+                    unsigned long long ca, cb;
+                    asm("v_cmp_nlt_f32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, %0, %0, %1"
+                        : "+v"(lma), "=&s"(ca) : "v"(acc[ut][t][rg]), "v"(th[rg]));
+                    asm("v_cmp_nlt_f32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, %0, %0, %1"
+                        : "+v"(lmb), "=&s"(cb) : "v"(acc[ut][t][rg + 8]), "v"(th[rg + 8]));
+                }
+                const unsigned lm = (lma << 8) | lmb;
+                const bool hh = in && lm != 0u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hh);
+                if (base + __popcll(m) > 64) flush();  // wave-uniform
+                if (hh) {
+                    const int slot = base + __popcll(m & lt_mask);
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(rvals + slot * 16);
+                    const f32x16 a = acc[ut][t];
+                    dst[0] = f32x4{a[0], a[1], a[2], a[3]};
+                    dst[1] = f32x4{a[4], a[5], a[6], a[7]};
+                    dst[2] = f32x4{a[8], a[9], a[10], a[11]};
+                    dst[3] = f32x4{a[12], a[13], a[14], a[15]};
+                    rids[slot] = (lm << 16) | (unsigned)((ut << 8) | (t << 6)) | (unsigned)lane;
+                }
+                base += __popcll(m);
+            }
+        }
+        flush();
+    }
+    __syncthreads();
+    for (int rr = tid; rr < UB; rr += 256)
+        if (u0 + rr < n_users) cand_cnt[u0 + rr] = s_cnt[rr];
+}
+
+
+
 // Bitonic sort of p2 (a power of two >= 2) LDS elements, descending, by the 256 threads of a
 // workgroup.  Thread q of a stage owns the PAIR (i, i | j), i = q with a zero inserted at bit
 // log2 j -- no idle half -- and the 64 pairs of a wave then cover exactly 128 consecutive
@@ -1079,9 +1286,13 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
             // stage 2: the full contraction, candidates only
             // one workgroup per 128 users, walking all item tiles (no global atomics)
             const dim3 ugrid((unsigned)((rows + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB)));
-            hipLaunchKernelGGL(lk::score_filter_kernel, ugrid, dim3(256), 0, st, ub_users,
-                               ld_users, rows, d_items, ld_items, n_items, KP, (float *)nullptr,
-                               (int64_t)0, tau, cand, cnt, lk::FUSED_CAP);
+            if (LK_TOPK_DMA && KP == 64)
+                hipLaunchKernelGGL(lk::score_filter64_kernel, ugrid, dim3(256), 0, st, ub_users, rows,
+                                   d_items, n_items, tau, cand, cnt, lk::FUSED_CAP);
+            else
+                hipLaunchKernelGGL(lk::score_filter_kernel, ugrid, dim3(256), 0, st, ub_users,
+                                   ld_users, rows, d_items, ld_items, n_items, KP, (float *)nullptr,
+                                   (int64_t)0, tau, cand, cnt, lk::FUSED_CAP);
             // stage 3: exclusions, exact order
             hipLaunchKernelGGL(lk::cand_select_kernel<lk::FUSED_CAP>, dim3((unsigned)rows),
                                dim3(256), 0, st, cand, cnt, d_excl_ptr, d_excl_items, ub, n,
