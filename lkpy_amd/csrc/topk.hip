@@ -256,7 +256,9 @@ __device__ __forceinline__ void score_panel_body(
                         const int rg = 15 - b;
                         const float x = rvals[rec * 16 + rg];
                         const unsigned row = rowb + (rg & 3) + 8 * (rg >> 2);
-                        if (x >= s_tau[row]) {  // the flag is "not below": NaN ends here
+                        // the flag is "not below": NaN ends here; so does a +inf score of a
+                        // row past the end (tau = +inf, clamped operands): no list to write to
+                        if (x >= s_tau[row] && (int64_t)(u0 + row) < n_users) {
                             const unsigned pos = atomicAdd(&s_cnt[row], 1u);  // LDS
                             if (pos < (unsigned)cand_cap)
                                 cand[(u0 + row) * cand_cap + pos] =
@@ -511,7 +513,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                 const int rg = 15 - bt;
                 const float x = rvals[rec * 16 + rg];
                 const unsigned row = rowb + (rg & 3) + 8 * (rg >> 2);
-                if (x >= s_tau[row]) {  // the flag is "not below": NaN ends here
+                // the flag is "not below": NaN ends here, and so does a +inf score of a row past
+                // the end (tau = +inf, clamped operands)
+                if (x >= s_tau[row] && (int64_t)(u0 + row) < n_users) {
                     const unsigned pos = atomicAdd(&s_cnt[row], 1u);  // LDS
                     if (pos < (unsigned)cand_cap)
                         cand[(u0 + row) * cand_cap + pos] =

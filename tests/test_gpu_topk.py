@@ -233,6 +233,8 @@ def test_score_topk_fused_non_finite_scores(gpu, rng, monkeypatch):
     Q[::16][:200, 7] = np.inf                          # many infinite scores inside the sample
     U[4] = 0.0
     U[4, 5] = 1.0   # inf * 0 = NaN elsewhere; +inf scores only
+    U[B - 1, 5] = 2.0  # the last row stands in for the 106 rows past the end of its tile: their
+    U[B - 1, 7] = 3.0  # +inf scores must not be written anywhere
     dU, dQ = D.to_device_padded(U, gpu), D.to_device_padded(Q, gpu)
     idx, sc = D.score_topk(dU, dQ, k, n)
     monkeypatch.setenv("LK_TOPK_FUSED_MIN_ITEMS", "1000000000")
