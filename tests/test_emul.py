@@ -1,7 +1,8 @@
 """
 The lane-level NumPy models of the ALS Cholesky kernels (tools/emul) stay runnable: they are
 how the index arithmetic of csrc/als_chol.hip (accumulator-tile layout, L image, permlane
-transposition) is checked without a GPU.
+transposition) is checked without a GPU.  Likewise the LDS placement of the DMA-staged top-K
+filter kernel (csrc/topk.hip::score_filter64_kernel).
 """
 import sys
 from pathlib import Path
@@ -36,3 +37,10 @@ def test_permlane_transposition_model():
         # y[r] at row group g = x[g] at row group r
         want = 100 * (lanes >> 4) + (16 * r + (lanes & 15))
         assert np.array_equal(y[r], want.astype(np.float32))
+
+
+def test_filter64_lds_layout_model():
+    "every operand fetch of score_filter64_kernel reads what the LDS DMA placed; 2-way banks"
+    import filter64_layout as f
+
+    assert f.check() == (2, 2)
