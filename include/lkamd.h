@@ -249,12 +249,13 @@ int lk_iknn_build_fill(const lk_iknn_plan *plan, const void *d_ui_indptr,
  *   lower index; out_score likewise; rows with fewer than n candidates are
  *   padded with index -1 / score NaN.
  * Two implementations, identical results bit for bit:
- *   - fused (n <= 128, >= 16384 items, >= 8192 users; env LK_TOPK_FUSED_MIN_ITEMS /
+ *   - fused (n <= 128, >= 16384 items, >= 8192 users, k > 16; env LK_TOPK_FUSED_MIN_ITEMS /
  *     LK_TOPK_FUSED_MIN_USERS): a threshold per user from an item sample, then ONE pass of
- *     the contraction whose epilogue keeps only the entries above it, then the exact order
+ *     the contraction whose epilogue keeps only the entries that reach it, then the exact order
  *     among those candidates -- the n_users x n_items score matrix never exists in memory;
- *     this path synchronises the stream before returning (it checks an overflow flag and
- *     redoes the rare overflowing batches through the panel path);
+ *     this path synchronises the stream before returning (it reads the list of rows that did
+ *     not end up with n valid candidates -- overflowing lists, thresholds that proved too
+ *     high -- and redoes exactly those rows through the panel path);
  *   - panel: 2048 users at a time are scored into the workspace and selected from there.
  * ---------------------------------------------------------------------- */
 size_t lk_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t n);
