@@ -567,6 +567,180 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         if (u0 + rr < n_users) cand_cnt[u0 + rr] = s_cnt[rr];
 }
 
+#if LK_TOPK_DMA >= 2
+// ---- PREPARED, NOT YET RUN ON A GPU (build with -DLK_TOPK_DMA=2; tools/topk_variants.py) -------
+// The same DMA staging for the other feature counts (KP = 32, 128, 256): the user panel does not
+// stay resident (64 / 128 KiB at KP = 128 / 256), so a slab buffer holds the 16-feature slab of
+// BOTH operands (128 x 16 user floats + 256 x 16 item floats = 24 KiB; two buffers), six DMA
+// instructions per wave and slab.  KP / 16 slabs per tile (even, so slab s sits in buffer
+// s & 1), walked two per loop iteration; records in the item half of buffer 1 as in
+// score_filter64_kernel.  Layout model: tools/emul/filter64_layout.py (slab rows are placed the
+// same way for both operands).
+template <int KP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void score_filter_slab_kernel(
+    const float *__restrict__ users, int64_t n_users, const float *__restrict__ items,
+    int64_t n_items, const float *__restrict__ tau, unsigned long long *__restrict__ cand,
+    unsigned *__restrict__ cand_cnt, int cand_cap)
+{
+    constexpr int UT = 2, UB = 128, NS = KP / 16;
+    static_assert(NS >= 2 && NS % 2 == 0, "an even number of 16-feature slabs");
+    constexpr int US = UB * 16, IS = SC_IB * 16, BUF = US + IS;  // floats
+    __shared__ __attribute__((aligned(1024))) float lds_all[2 * BUF + 4 * 64 + 2 * UB];
+    unsigned *rids_all = reinterpret_cast<unsigned *>(lds_all + 2 * BUF);
+    float *s_tau = reinterpret_cast<float *>(rids_all + 4 * 64);
+    unsigned *s_cnt = reinterpret_cast<unsigned *>(s_tau + UB);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t u0 = (int64_t)blockIdx.x * UB;
+    const int wu = (wave & 1) * 64, wi = (wave >> 1) * 128;
+    const int64_t n_itiles = (n_items + SC_IB - 1) / SC_IB;
+    const unsigned lds0 = (unsigned)(uintptr_t)lds_all;
+
+    for (int r = tid; r < UB; r += 256) {
+        s_tau[r] = (u0 + r < n_users) ? tau[u0 + r] : __builtin_inff();
+        s_cnt[r] = 0u;
+    }
+    const int64_t nu64 = n_users - u0;
+    const int nu = (int)(nu64 < UB ? nu64 : UB) - 1;
+    // slab s of both operands (item tile origin t0) -> buffer s & 1.  A DMA instruction moves 16
+    // rows of 16 floats: lane -> row l >> 2, position l & 3 <- chunk (l & 3) ^ ((row >> 2) & 3).
+    auto slab_dma = [&](int64_t t0, int s) {
+        const int64_t ni64 = n_items - t0;
+        const int ni = (int)(ni64 < SC_IB ? ni64 : SC_IB) - 1;
+        const int c = (lane & 3) ^ ((lane >> 4) & 3);
+        const unsigned buf = lds0 + (unsigned)(s & 1) * (BUF * 4u);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {  // user rows 16 n .., n = 2 wave + q
+            const int n = wave * 2 + q;
+            const int row = n * 16 + (lane >> 2);
+            const float *src = users + (u0 + min(row, nu)) * KP + 16 * s + c * 4;
+            lds_dma16(src, buf + (unsigned)n * 1024u);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // item rows 16 n .., n = 4 wave + q
+            const int n = wave * 4 + q;
+            const int row = n * 16 + (lane >> 2);
+            const float *src = items + (t0 + min(row, ni)) * KP + 16 * s + c * 4;
+            lds_dma16(src, buf + (unsigned)(US * 4) + (unsigned)n * 1024u);
+        }
+    };
+    slab_dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int r = lane & 31, h = lane >> 5;
+    int offa[4], offb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        offa[c] = (wu + r) * 16 + ((c ^ ((r >> 2) & 3)) << 2) + h;
+        offb[c] = US + (wi + r) * 16 + ((c ^ ((r >> 2) & 3)) << 2) + h;
+    }
+    float *rvals = lds_all + BUF + US + wave * (64 * 16);  // this wave's 4 KiB of buffer 1's item half
+    unsigned *rids = rids_all + wave * 64;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    for (int64_t itile = 0; itile < n_itiles; ++itile) {
+        const int64_t i0 = itile * SC_IB;
+        f32x16 acc[UT][4];
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[ut][t][e] = 0.f;
+        for (int sp = 0; sp < NS / 2; ++sp) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const int s = 2 * sp + par;
+                if (s + 1 < NS) slab_dma(i0, s + 1);
+                else if (itile + 1 < n_itiles) slab_dma(i0 + SC_IB, 0);
+                const float *bb = lds_all + par * BUF;
+#pragma unroll
+                for (int kk = 0; kk < 16; kk += 2) {
+                    float a[UT], b[4];
+#pragma unroll
+                    for (int ut = 0; ut < UT; ++ut)
+                        a[ut] = bb[offa[kk >> 2] + ut * (32 * 16) + (kk & 2)];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b[t] = bb[offb[kk >> 2] + t * (32 * 16) + (kk & 2)];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int ut = 0; ut < UT; ++ut)
+                            acc[ut][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ut], b[t], acc[ut][t],
+                                                                              0, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+        int base = 0;
+        auto flush = [&]() {
+            const int rec = lane;  // base <= 64
+            const unsigned id = rec < base ? rids[rec] : 0u;
+            unsigned lm = id >> 16;
+            const unsigned ls = id & 63u;
+            const unsigned rowb = wu + ((id >> 8) & 0xffu) * 32 + 4 * (ls >> 5);
+            const unsigned it = (unsigned)(i0 + wi + ((id >> 6) & 3u) * 32 + (ls & 31u));
+            while (lm) {
+                const int bt = 31 - __clz(lm);
+                lm &= ~(1u << bt);
+                const int rg = 15 - bt;
+                const float x = rvals[rec * 16 + rg];
+                const unsigned row = rowb + (rg & 3) + 8 * (rg >> 2);
+                if (x >= s_tau[row] && (int64_t)(u0 + row) < n_users) {
+                    const unsigned pos = atomicAdd(&s_cnt[row], 1u);  // LDS
+                    if (pos < (unsigned)cand_cap)
+                        cand[(u0 + row) * cand_cap + pos] =
+                            ((unsigned long long)f2key(x) << 32) | (0xffffffffu - it);
+                }
+            }
+            base = 0;
+        };
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+            float th[16];
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg)
+                th[rg] = s_tau[wu + ut * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5)];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int col = wi + t * 32 + (lane & 31);
+                const bool in = i0 + col < n_items;
+                unsigned lma = 0u, lmb = 0u;
+#pragma unroll
+                for (int rg = 0; rg < 8; ++rg) {
+                    unsigned long long ca, cb;
+                    asm("v_cmp_nlt_f32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, %0, %0, %1"
+                        : "+v"(lma), "=&s"(ca) : "v"(acc[ut][t][rg]), "v"(th[rg]));
+                    asm("v_cmp_nlt_f32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, %0, %0, %1"
+                        : "+v"(lmb), "=&s"(cb) : "v"(acc[ut][t][rg + 8]), "v"(th[rg + 8]));
+                }
+                const unsigned lm = (lma << 8) | lmb;
+                const bool hh = in && lm != 0u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hh);
+                if (base + __popcll(m) > 64) flush();  // wave-uniform
+                if (hh) {
+                    const int slot = base + __popcll(m & lt_mask);
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(rvals + slot * 16);
+                    const f32x16 a = acc[ut][t];
+                    dst[0] = f32x4{a[0], a[1], a[2], a[3]};
+                    dst[1] = f32x4{a[4], a[5], a[6], a[7]};
+                    dst[2] = f32x4{a[8], a[9], a[10], a[11]};
+                    dst[3] = f32x4{a[12], a[13], a[14], a[15]};
+                    rids[slot] = (lm << 16) | (unsigned)((ut << 8) | (t << 6)) | (unsigned)lane;
+                }
+                base += __popcll(m);
+            }
+        }
+        flush();
+    }
+    __syncthreads();
+    for (int rr = tid; rr < UB; rr += 256)
+        if (u0 + rr < n_users) cand_cnt[u0 + rr] = s_cnt[rr];
+}
+#endif  // LK_TOPK_DMA >= 2
+
 
 
 // Bitonic sort of p2 (a power of two >= 2) LDS elements, descending, by the 256 threads of a
@@ -1293,6 +1467,17 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
             if (LK_TOPK_DMA && KP == 64)
                 hipLaunchKernelGGL(lk::score_filter64_kernel, ugrid, dim3(256), 0, st, ub_users, rows,
                                    d_items, n_items, tau, cand, cnt, lk::FUSED_CAP);
+#if LK_TOPK_DMA >= 2
+            else if (KP == 32)
+                hipLaunchKernelGGL(lk::score_filter_slab_kernel<32>, ugrid, dim3(256), 0, st, ub_users,
+                                   rows, d_items, n_items, tau, cand, cnt, lk::FUSED_CAP);
+            else if (KP == 128)
+                hipLaunchKernelGGL(lk::score_filter_slab_kernel<128>, ugrid, dim3(256), 0, st, ub_users,
+                                   rows, d_items, n_items, tau, cand, cnt, lk::FUSED_CAP);
+            else if (KP == 256)
+                hipLaunchKernelGGL(lk::score_filter_slab_kernel<256>, ugrid, dim3(256), 0, st, ub_users,
+                                   rows, d_items, n_items, tau, cand, cnt, lk::FUSED_CAP);
+#endif
             else
                 hipLaunchKernelGGL(lk::score_filter_kernel, ugrid, dim3(256), 0, st, ub_users,
                                    ld_users, rows, d_items, ld_items, n_items, KP, (float *)nullptr,

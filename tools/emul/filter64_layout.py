@@ -23,9 +23,12 @@ def place_users(U):
 
 
 def place_slab(I, s):
-    "I: [256, 64], features 16 s .. 16 s + 15 -> LDS image [4096]; instruction n: rows 16 n .."
-    lds = np.full(256 * 16, -1, dtype=I.dtype)
-    for n in range(16):
+    """
+    I: [rows, KP], features 16 s .. 16 s + 15 -> LDS image [rows * 16]; instruction n moves rows
+    16 n ..  (256 item rows; also the 128 user rows of score_filter_slab_kernel, -DLK_TOPK_DMA=2)
+    """
+    lds = np.full(I.shape[0] * 16, -1, dtype=I.dtype)
+    for n in range(I.shape[0] // 16):
         for lane in range(64):
             row = n * 16 + (lane >> 2)
             c = (lane & 3) ^ ((lane >> 4) & 3)  # == (row >> 2) & 3
@@ -37,6 +40,12 @@ def a_address(wave, lane, ut, s, kk):
     "float address of A[i = lane & 31][k = lane >> 5] for step kk of slab s"
     wu, r, h = (wave & 1) * 64, lane & 31, lane >> 5
     return (wu + r) * 64 + (((4 * s + (kk >> 2)) ^ (r & 15)) << 2) + h + ut * 32 * 64 + (kk & 2)
+
+
+def a_slab_address(wave, lane, ut, kk):
+    "score_filter_slab_kernel: the user slab is laid out like the item slab"
+    wu, r, h = (wave & 1) * 64, lane & 31, lane >> 5
+    return (wu + r) * 16 + (((kk >> 2) ^ ((r >> 2) & 3)) << 2) + h + ut * 32 * 16 + (kk & 2)
 
 
 def b_address(wave, lane, t, kk):
@@ -65,6 +74,16 @@ def check():
                     for kk in range(0, 16, 2):
                         row = (wave >> 1) * 128 + t * 32 + (lane & 31)
                         assert li[b_address(wave, lane, t, kk)] == I[row, 16 * s + kk + (lane >> 5)]
+    U2 = np.arange(128 * 256, dtype=np.int64).reshape(128, 256)  # KP = 256: 16 slabs
+    for s in (0, 7, 15):
+        lus = place_slab(U2, s)
+        assert (lus >= 0).all()
+        for wave in range(4):
+            for lane in range(64):
+                for ut in range(2):
+                    for kk in range(0, 16, 2):
+                        row = (wave & 1) * 64 + ut * 32 + (lane & 31)
+                        assert lus[a_slab_address(wave, lane, ut, kk)] == U2[row, 16 * s + kk + (lane >> 5)]
     # worst bank multiplicity of one operand fetch (64 banks of 4 bytes)
     worst_a = max(max(Counter(a_address(0, l, 0, s, kk) % 64 for l in range(64)).values())
                   for s in range(4) for kk in range(0, 16, 2))
