@@ -54,12 +54,67 @@ int lko_num_threads(void)
 /* Implicit ALS: src/accel/als/implicit.rs:56-125                              */
 /* ------------------------------------------------------------------------- */
 
+/* `mtl.dot(&o_picked)` (implicit.rs:112) / `mt.dot(&o_picked)` (explicit.rs:103): ndarray 0.17.2
+ * built WITHOUT its blas feature (Cargo.toml:38) sends an f32 matrix product to
+ * matrixmultiply 0.3.11 (Cargo.lock:701-702) `sgemm`.  That crate is not under /root/reference;
+ * its published algorithm (Goto-style packing, src/gemm.rs `gemm_loop`; block sizes
+ * src/archparam.rs S_MC = 64, S_KC = 256, S_NC = 1024; x86-64 kernels chosen at run time,
+ * `fma` feature -> 8x8 `_mm256_fmadd_ps` micro-kernel, src/sgemm_kernel.rs) fixes the order in
+ * which the inner dimension -- here the row's entries -- is summed:
+ *
+ *   for each chunk of KC = 256 entries, in order:
+ *       ab = 0;  for j in chunk, in order:  ab = fma(l[j][f], m[j][g], ab)
+ *       c[f][g] = (first chunk) ? ab : c[f][g] + ab          (beta = 0 / 1, alpha = 1)
+ *
+ * (one accumulator per output element per chunk; MC / NC blocking only reorders *which*
+ * elements are worked on, not the sums).  lko_gemm_mode 0 keeps the round-1/2 restatement --
+ * one unblocked sequential f32 sum with separately rounded multiply and add -- for A/B
+ * comparisons (tests/test_oracle_pinned.py reports both against the reference's own Python row
+ * solve).  `l` = m[j][f] * v[j] rounded to f32 (the materialised `mtl`); v == NULL: l = m. */
+#define LKO_SGEMM_KC 256
+static int lko_gemm_mode = 1;
+void lko_set_gemm_mode(int mode) { lko_gemm_mode = mode; }
+int lko_get_gemm_mode(void) { return lko_gemm_mode; }
+
+static void lko_gram_mtl_m(const float *m, const float *v, int64_t n, int k, float *a, float *ab)
+{
+    if (lko_gemm_mode == 0) {
+        memset(a, 0, sizeof(float) * k * k);
+        for (int64_t j = 0; j < n; j++) {
+            const float *mj = m + j * k;
+            float vj = v ? v[j] : 1.0f;
+            for (int f = 0; f < k; f++) {
+                float l = v ? mj[f] * vj : mj[f];
+                float *af = a + (int64_t)f * k;
+                for (int g = 0; g < k; g++) af[g] += l * mj[g];
+            }
+        }
+        return;
+    }
+    for (int64_t j0 = 0; j0 < n; j0 += LKO_SGEMM_KC) {
+        int64_t j1 = j0 + LKO_SGEMM_KC < n ? j0 + LKO_SGEMM_KC : n;
+        float *dst = j0 == 0 ? a : ab;
+        memset(dst, 0, sizeof(float) * k * k);
+        for (int64_t j = j0; j < j1; j++) {
+            const float *mj = m + j * k;
+            float vj = v ? v[j] : 1.0f;
+            for (int f = 0; f < k; f++) {
+                float l = v ? mj[f] * vj : mj[f];
+                float *df = dst + (int64_t)f * k;
+                for (int g = 0; g < k; g++) df[g] = fmaf(l, mj[g], df[g]);
+            }
+        }
+        if (j0 != 0)
+            for (int i = 0; i < k * k; i++) a[i] = a[i] + ab[i];
+    }
+}
+
 /* One row: train_row_solve, implicit.rs:87-125.  Scratch: m (n*k), a (k*k),
  * y (k).  Returns the squared delta, or a negative LAPACK info code -> err. */
 static float lko_als_row(lko_sposv_fn sposv, const int64_t *indptr, const int32_t *indices,
                          const float *values, int64_t row, int k, float *row_data,
                          const float *other, const float *otor, float *m, float *vbuf, float *a,
-                         float *y, int *err)
+                         float *ab, float *y, int *err)
 {
     int64_t sp = indptr[row], ep = indptr[row + 1];
     int64_t n = ep - sp;
@@ -75,16 +130,7 @@ static float lko_als_row(lko_sposv_fn sposv, const int64_t *indptr, const int32_
     /* mtl = mt * vals; mtm = mtl.dot(o_picked)  (implicit.rs:110-112):
      * A[f][g] = sum_j (M[j][f]*v_j) * M[j][g]; the product M*v is rounded to
      * f32 first (it is materialised as `mtl`), accumulation in f32. */
-    memset(a, 0, sizeof(float) * k * k);
-    for (int64_t j = 0; j < n; j++) {
-        const float *mj = m + j * k;
-        float v = vbuf[j];
-        for (int f = 0; f < k; f++) {
-            float l = mj[f] * v;
-            float *af = a + (int64_t)f * k;
-            for (int g = 0; g < k; g++) af[g] += l * mj[g];
-        }
-    }
+    lko_gram_mtl_m(m, vbuf, n, k, a, ab);
     /* a = otor + mtm (implicit.rs:115) */
     for (int i = 0; i < k * k; i++) a[i] = otor[i] + a[i];
     /* vals += 1; y = mt.dot(vals) (implicit.rs:116-117) */
@@ -155,13 +201,14 @@ int lko_als_implicit_half_epoch(void *sposv_ptr, const int64_t *indptr, const in
         float *m = (float *)malloc(sizeof(float) * (size_t)(max_n > 0 ? max_n : 1) * k);
         float *vb = (float *)malloc(sizeof(float) * (size_t)(max_n > 0 ? max_n : 1));
         float *a = (float *)malloc(sizeof(float) * (size_t)k * k);
+        float *ab = (float *)malloc(sizeof(float) * (size_t)k * k);
         float *y = (float *)malloc(sizeof(float) * (size_t)k);
         float acc = 0.0f;
 #pragma omp for schedule(dynamic, 64)
         for (int64_t r = 0; r < n_rows; r++) {
             int err = 0;
             float d2 = lko_als_row(sposv, indptr, indices, values, r, k, this_ + r * k, other,
-                                   otor, m, vb, a, y, &err);
+                                   otor, m, vb, a, ab, y, &err);
             if (err) {
 #pragma omp critical
                 if (!failed) failed = err;
@@ -172,6 +219,7 @@ int lko_als_implicit_half_epoch(void *sposv_ptr, const int64_t *indptr, const in
         free(m);
         free(vb);
         free(a);
+        free(ab);
         free(y);
     }
     float frob = 0.0f;
@@ -191,7 +239,7 @@ int lko_als_implicit_half_epoch(void *sposv_ptr, const int64_t *indptr, const in
 static float lko_als_explicit_row(lko_sposv_fn sposv, const int64_t *indptr,
                                   const int32_t *indices, const float *values, int64_t row, int k,
                                   float *row_data, const float *other, float reg, float *m,
-                                  float *a, float *y, int *err)
+                                  float *a, float *ab, float *y, int *err)
 {
     int64_t sp = indptr[row], ep = indptr[row + 1];
     int64_t n = ep - sp;
@@ -201,15 +249,7 @@ static float lko_als_explicit_row(lko_sposv_fn sposv, const int64_t *indptr,
     }
     for (int64_t j = 0; j < n; j++)
         memcpy(m + j * k, other + (int64_t)indices[sp + j] * k, sizeof(float) * k);
-    memset(a, 0, sizeof(float) * k * k);
-    for (int64_t j = 0; j < n; j++) { /* mtm = mt.dot(&o_picked)  (explicit.rs:103) */
-        const float *mj = m + j * k;
-        for (int f = 0; f < k; f++) {
-            float l = mj[f];
-            float *af = a + (int64_t)f * k;
-            for (int g = 0; g < k; g++) af[g] += l * mj[g];
-        }
-    }
+    lko_gram_mtl_m(m, NULL, n, k, a, ab); /* mtm = mt.dot(&o_picked)  (explicit.rs:103) */
     {
         float dg = reg * (float)n; /* reg * cols.len() as f32 */
         for (int f = 0; f < k; f++) a[(int64_t)f * k + f] += dg;
@@ -269,13 +309,14 @@ int lko_als_explicit_half_epoch(void *sposv_ptr, const int64_t *indptr, const in
 #endif
         float *m = (float *)malloc(sizeof(float) * (size_t)(max_n > 0 ? max_n : 1) * k);
         float *a = (float *)malloc(sizeof(float) * (size_t)k * k);
+        float *ab = (float *)malloc(sizeof(float) * (size_t)k * k);
         float *y = (float *)malloc(sizeof(float) * (size_t)k);
         float acc = 0.0f;
 #pragma omp for schedule(dynamic, 64)
         for (int64_t r = 0; r < n_rows; r++) {
             int err = 0;
             float d2 = lko_als_explicit_row(sposv, indptr, indices, values, r, k, this_ + r * k,
-                                            other, reg, m, a, y, &err);
+                                            other, reg, m, a, ab, y, &err);
             if (err) {
 #pragma omp critical
                 if (!failed) failed = err;
@@ -285,6 +326,7 @@ int lko_als_explicit_half_epoch(void *sposv_ptr, const int64_t *indptr, const in
         partials[tid] = acc;
         free(m);
         free(a);
+        free(ab);
         free(y);
     }
     float frob = 0.0f;

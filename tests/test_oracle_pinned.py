@@ -1,0 +1,167 @@
+"""
+The ALS oracle pinned to the REFERENCE ITSELF.
+
+``tests/golden/make_als_fixtures.py`` executed the reference's own ``_train_new_row`` /
+``solve_cholesky`` / ``_implicit_otor`` / ``initial_params`` (``src/lenskit/als/_implicit.py:97-130,
+152-155,177-184``, ``src/lenskit/math/solve.py:17-41``; taken from ``/root/reference`` by ``ast``
+at generation time) and committed their outputs.  Here the oracle -- ``oracle/lk_oracle.c``, the
+restatement of the Rust kernel (``src/accel/als/implicit.rs:56-125``) that the GPU is compared
+with, and the NumPy half in ``oracle/lk_oracle.py`` -- is checked against those vectors from
+IDENTICAL inputs.
+
+Tolerances.  The reference's Python row solve and its Rust row solve are two different float32
+evaluations of the same ``x = A^-1 y`` (BLAS ``sgemm``/``gemv`` + ``spotrf`` vs matrixmultiply +
+a sequential ``mt.dot(vals)`` + ``sposv``), so they can agree only to the forward error of a
+float32 solve: ``c * cond(A) * 2^-24 * sqrt(n)``.  Asserted: every synthetic row within
+``0.5 * cond * u * sqrt(n) + 5e-7`` (measured constant <= 0.27) and within the north-star 1e-4
+wherever that bound allows it (all rows of <= 1000 entries, any k); ml-latest-small rows within
+``4 * cond * u + 2e-6`` (measured <= 2.1) and within 1e-4 wherever ``cond * u < 1e-5``.
+The NumPy restatements (``implicit_otor``, ``als_initial_params``, ``als_fold_in``) are
+BIT-IDENTICAL to the reference functions.
+"""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+GOLD = Path(__file__).resolve().parent / "golden"
+sys.path.insert(0, str(GOLD))
+import als_fixture_inputs as fx  # noqa: E402
+
+from oracle import lk_oracle as lko  # noqa: E402
+
+U32 = 2.0**-24
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def _row_rel(a, b):
+    num = np.linalg.norm(a.astype(np.float64) - b.astype(np.float64), axis=1)
+    den = np.linalg.norm(b.astype(np.float64), axis=1)
+    out = np.zeros_like(num)
+    nz = den > 0
+    out[nz] = num[nz] / den[nz]
+    assert not (num[~nz] > 0).any(), "non-zero row where the reference has a zero row"
+    return out
+
+
+@pytest.fixture(scope="module")
+def rows():
+    return np.load(GOLD / "als_ref_rows.npz")
+
+
+@pytest.fixture(scope="module")
+def mlsmall():
+    return np.load(GOLD / "als_ref_mlsmall.npz")
+
+
+@pytest.mark.parametrize("kind", ["centered", "skewed"])
+@pytest.mark.parametrize("k", fx.ROW_K)
+def test_rows_against_reference_train_new_row(rows, kind, k):
+    worst_ratio, within = 0.0, 0
+    cases = [c for c in fx.row_cases() if c.kind == kind and c.k == k]
+    for c in cases:
+        emb = fx.embeddings(c)
+        items, vals = fx.row_entries(c)
+        want = rows[f"x_{c.name}"]
+        otor_ref = rows[f"otor_{c.kind}_k{c.k}"]
+        # NumPy half: same calls as the reference -> same bits
+        otor = lko.implicit_otor(emb, np.float32(c.reg))
+        assert otor.dtype == np.float32 and np.array_equal(otor, otor_ref)
+        assert np.array_equal(lko.als_fold_in(items, vals, emb, otor), want)
+        # C half (the Rust restatement): a one-row half-epoch from the same inputs
+        m = sps.csr_array((vals, items, np.array([0, len(items)])), shape=(1, fx.N_CATALOGUE))
+        this = np.zeros((1, c.k), np.float32)
+        frob = lko.als_half_epoch(m, this, emb, otor_ref)
+        M = emb[items].astype(np.float64)
+        A = otor_ref.astype(np.float64) + (M.T * vals.astype(np.float64)) @ M
+        cond = float(np.linalg.cond(A))
+        e = _rel(this[0], want)
+        bound = 0.5 * cond * U32 * np.sqrt(c.n) + 5e-7
+        assert e <= bound, (c.name, e, bound, cond)
+        worst_ratio = max(worst_ratio, e / (cond * U32 * np.sqrt(c.n)))
+        if c.n <= 1000:
+            assert e <= 1.0e-4, (c.name, e)
+        within += e <= 1.0e-4
+        # the returned delta: ||x - 0||
+        assert frob == pytest.approx(float(np.linalg.norm(want.astype(np.float64))), rel=1e-3)
+    print(f"{kind} k={k}: {within}/{len(cases)} rows within 1e-4 of the reference; "
+          f"max err / (cond u sqrt n) = {worst_ratio:.3f}")
+
+
+def test_initial_params_are_the_reference_draws(mlsmall):
+    ui, _ = fx.ml_small_matrices()
+    U, I = ui.shape
+    rng = np.random.default_rng(fx.ML_SEED)
+    Q0 = lko.als_initial_params(rng, I, fx.ML_K)  # items first
+    P0 = lko.als_initial_params(rng, U, fx.ML_K)
+    assert np.array_equal(Q0[:8], mlsmall["Q0_head"]) and np.array_equal(P0[:8], mlsmall["P0_head"])
+    assert float(Q0.astype(np.float64).sum()) == float(mlsmall["Q0_sum"])
+    assert float(P0.astype(np.float64).sum()) == float(mlsmall["P0_sum"])
+
+
+@pytest.mark.parametrize("half", ["P1", "Q1", "P3", "Q3"])
+def test_ml_small_half_epochs_from_identical_inputs(mlsmall, half):
+    ui, iu = fx.ml_small_matrices()
+    U, I = ui.shape
+    rng = np.random.default_rng(fx.ML_SEED)
+    Q0 = lko.als_initial_params(rng, I, fx.ML_K)
+    csr, other = {"P1": (ui, Q0), "Q1": (iu, mlsmall["P1"]), "P3": (ui, mlsmall["Q2"]),
+                  "Q3": (iu, mlsmall["P3"])}[half]
+    want = mlsmall[half]
+    this = np.zeros_like(want)
+    otor = lko.implicit_otor(other, np.float32(fx.ML_REG))
+    lko.als_half_epoch(csr, this, other, otor)
+    _x64, cond = lko.als_referee_f64(csr, other, fx.ML_REG)
+    e = _row_rel(this, want)
+    empty = np.diff(csr.indptr) == 0
+    assert not this[empty].any() and not want[empty].any()  # implicit.rs:98-101
+    cu = cond * U32
+    assert (e <= 4.0 * cu + 2.0e-6).all(), float((e / np.maximum(cu, 1e-30)).max())
+    decidable = cu < 1.0e-5
+    assert (e[decidable] <= 1.0e-4).all()
+    print(f"{half}: rel {_rel(this, want):.2e}, rows {len(e)}, decidable {int(decidable.sum())}, "
+          f"max err/(cond u) {float((e[cond > 0] / cu[cond > 0]).max()):.2f}")
+
+
+def test_ml_small_three_epochs_track_the_reference(mlsmall):
+    """The whole oracle training loop (``als_train``: init order, epoch order, OtOr per half,
+    deltas) against three epochs solved by the reference's row function."""
+    d = lko.load_ml_small()
+    rmat = d["rmat"].copy()
+    rmat.data[:] = 1.0  # implicit: prepare_matrix multiplies by the weight
+    st = lko.als_train(rmat, fx.ML_K, 3, fx.ML_SEED, reg=fx.ML_REG, weight=fx.ML_WEIGHT)
+    # deltas are norms of well-determined quantities: tight
+    assert np.allclose(np.asarray(st.deltas, np.float64), mlsmall["deltas"], rtol=2e-3)
+    # the factors themselves drift with the conditioning (1e3 ... 2e5) over three epochs
+    assert _rel(st.user_embeddings, mlsmall["P3"]) < 2e-2
+    assert _rel(st.item_embeddings, mlsmall["Q3"]) < 2e-2
+    assert _rel(st.OtOr, mlsmall["OtOr3"]) < 1e-3
+
+
+def test_gemm_mode_switch():
+    "mode 0 = the unblocked sequential sum of rounds 1-2 is still there for A/B comparisons"
+    L = lko.lib()
+    assert L.lko_get_gemm_mode() == 1
+    c = fx.RowCase("skewed", 64, 2049)
+    emb, (items, vals) = fx.embeddings(c), fx.row_entries(c)
+    otor = lko.implicit_otor(emb, np.float32(c.reg))
+    m = sps.csr_array((vals, items, np.array([0, len(items)])), shape=(1, fx.N_CATALOGUE))
+    out = []
+    try:
+        for mode in (1, 0):
+            L.lko_set_gemm_mode(mode)
+            this = np.zeros((1, c.k), np.float32)
+            lko.als_half_epoch(m, this, emb, otor)
+            out.append(this.copy())
+    finally:
+        L.lko_set_gemm_mode(1)
+    assert not np.array_equal(out[0], out[1]) and _rel(out[0], out[1]) < 1e-4
