@@ -198,25 +198,26 @@ def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
         acc = parity.als_half_accounting(got_, want, exact, cond)
         acc.pop("by_cond_decade", None)
         out[name] = acc
+    exceptions = [dict(e, half=name) for name, o in out.items() for e in o.get("exceptions", [])]
     par = {
         "what": "one epoch from the trained state, GPU vs oracle from identical inputs, "
         + ("every row" if row_frac >= 1.0 else f"a {row_frac:.3f} row sample"),
+        "criterion": "ok = no row further than 1e-4 (relative) from the oracle's row -- the raw "
+        "north-star tolerance, nothing folded in; rows over it are listed in `exceptions` with "
+        "cond(A) and their distances to the float64 referee; `accounted` is the separate "
+        "statement that each exception is the reference arithmetic's own deviation",
         "als_rel_P": out["user"]["rel_gpu_vs_oracle"],
         "als_rel_Q": out["item"]["rel_gpu_vs_oracle"],
+        "rows_checked": out["user"]["rows"] + out["item"]["rows"],
         "rows_over_1e-4": out["user"]["rows_over_1e-4"] + out["item"]["rows_over_1e-4"],
-        "min_cond_of_those": min(
-            (o["min_cond_of_rows_over"] for o in out.values() if "min_cond_of_rows_over" in o),
-            default=None),
-        "max_cond_of_those": max(
-            (o["max_cond_of_rows_over"] for o in out.values() if "max_cond_of_rows_over" in o),
-            default=None),
-        "decidable_rows_over_1e-4": sum(o["decidable_rows_over_1e-4"] for o in out.values()),
-        "decidable_rows_over_1e-4_gpu_side": sum(
-            o.get("decidable_rows_over_1e-4_gpu_side", 0) for o in out.values()),
+        "row_rel_max": max(out["user"]["row_rel_max"], out["item"]["row_rel_max"]),
+        "ok": bool(all(o["ok"] for o in out.values())),
+        "exceptions": exceptions,
+        "accounted": bool(all(o["accounted"] for o in out.values())),
+        "rows_decidable": sum(o.get("rows_decidable", 0) for o in out.values()),
         "gpu_row_err_over_cond_u_max": max(o["row_err_over_cond_u_max_gpu"] for o in out.values()),
         "oracle_row_err_over_cond_u_max": max(
             o["row_err_over_cond_u_max_oracle"] for o in out.values()),
-        "ok": bool(all(o["ok"] for o in out.values())),
         "user": out["user"],
         "item": out["item"],
     }
@@ -287,31 +288,66 @@ def fit_leg(ratings, k, epochs, weight):
     }
 
 
-def topk_cpu_baseline(P, Q, excl, n, budget_s=10.0):
+def topk_cpu_and_parity(P, Q, ex_ptr, ex_idx, gpu_idx, gpu_sc, n, budget_s=10.0,
+                        max_users=32768):
     """
-    The reference's path for one user -- scores = Q @ u (``ALSBase.__call__``), candidates =
-    all items minus the user's own, heap top-N -- through the oracle's restatement, on a user
-    sample, extrapolated to all users.
+    bench.py's checker leg for the dense top-N call.  The reference's path for one user --
+    scores = Q @ u (``ALSBase.__call__``), candidates = all items minus the user's own, heap
+    top-N -- through the oracle's restatement (``lko_score_topn_batch``: the per-query loop on
+    all host threads, as the reference's batch runner spreads queries over workers), on a seeded
+    user sample: TIMED (cpu_baseline, extrapolated by users) and COMPARED with the lists the GPU
+    produced for the same users from the same factors (parity: index lists and score bits).
+    ``P``/``Q``/exclusions are in the engine's (relabelled) row order on both sides.
     """
     from oracle import lk_oracle as lko
 
     rng = np.random.default_rng(7)
     n_users = P.shape[0]
-    users = rng.choice(n_users, min(n_users, 16384), replace=False)
-    lko.argtopn(lko.score_dense(Q, P[users[0]]), n)  # first call: library load, page-in
+    users = rng.choice(n_users, min(n_users, max_users), replace=False)
+    threads = lko.num_threads()
+    ex_ptr = np.asarray(ex_ptr, dtype=np.int64)
+
+    def run(us):
+        lens = ex_ptr[us + 1] - ex_ptr[us]
+        ptr = np.zeros(len(us) + 1, np.int64)
+        np.cumsum(lens, out=ptr[1:])
+        idx = np.concatenate([ex_idx[ex_ptr[u]:ex_ptr[u + 1]] for u in us]) if len(us) else \
+            np.empty(0, np.int32)
+        return lko.score_topn_batch(Q, P[us], n, ptr, idx, threads)
+
+    run(users[:threads])  # first call: library load, page-in
+    done, blocks = 0, []
     t0 = time.perf_counter()
-    done = 0
-    for u in users:
-        sc = lko.score_dense(Q, P[u])
-        sc[excl.indices[excl.indptr[u]:excl.indptr[u + 1]]] = np.nan
-        lko.argtopn(sc, n)
-        done += 1
+    while done < len(users):
+        us = users[done:done + 1024]
+        blocks.append(run(us))
+        done += len(us)
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": round(dt / done * n_users, 2), "unit": "s", "cores": 1, "kind": "port",
-            "sample": f"{done} of {n_users} users in {dt:.2f}s (score_dense + exclusion + "
-            "heap top-N per user, the reference's per-query loop), extrapolated by users"}
+    users = users[:done]
+    want_i = np.concatenate([b[0] for b in blocks])
+    want_s = np.concatenate([b[1] for b in blocks])
+    cpu = {"value": round(dt / done * n_users, 2), "unit": "s", "cores": threads, "kind": "port",
+           "sample": f"{done} of {n_users} users in {dt:.2f}s (score_dense + exclusion + heap "
+           f"top-N per user, the reference's per-query path, queries spread over {threads} "
+           "threads), extrapolated by users"}
+    got_i, got_s = gpu_idx[users], gpu_sc[users]
+    same = (got_i == want_i).all(axis=1)
+    # a list that differs only where neighbouring scores are EQUAL is a tie, not an error
+    near = 0
+    for r in np.flatnonzero(~same):
+        d = got_i[r] != want_i[r]
+        if np.array_equal(got_s[r][d].view(np.uint32), want_s[r][d].view(np.uint32)):
+            near += 1
+    par = {"users_checked": int(done), "list_length": int(n),
+           "lists_identical": int(same.sum()),
+           "near_ties": int(near),
+           "mismatched_users": int((~same).sum() - near),
+           "score_bits_identical": bool(np.array_equal(
+               got_s.view(np.uint32)[same], want_s.view(np.uint32)[same])),
+           "ok": bool(same.all())}
+    return cpu, par
 
 
 def _gather_rows(out, rows):
@@ -372,14 +408,50 @@ def knn_cpu_and_parity(dui, diu, out):
 
 
 
-def main_cfg5(args):
+def knn_score_cpu_and_parity(sims, r_ptr, r_idx, r_val, t_ptr, t_idx, got_s, got_c):
+    """
+    The cfg3 batch-scoring call (10 000 queries x 100 targets, ``max_nbrs`` 100, ``min_nbrs`` 1)
+    through the oracle's ``score_explicit`` restatement (src/accel/knn/item_score.rs:23-111,
+    accum.rs) for EVERY query, timed, and compared with the GPU's scores / neighbour counts.
+    Counts and the null pattern must be identical; scores within 1e-5 relative (the accumulator
+    sums the same <= 100 terms in heap order on the CPU, in selection order on the GPU).
+    """
+    import scipy.sparse as sps
+
+    from oracle import lk_oracle as lko
+
+    h = sps.csr_array((sims.values.cpu().numpy(), sims.indices.cpu().numpy(),
+                       sims.indptr.cpu().numpy()), shape=sims.shape)
+    threads = lko.num_threads()
+    t0 = time.perf_counter()
+    want_s, want_c = lko.iknn_score_batch(h, r_ptr, r_idx, r_val, t_ptr, t_idx, 100, 1, threads)
+    dt = time.perf_counter() - t0
+    nan_same = bool(np.array_equal(np.isnan(got_s), np.isnan(want_s)))
+    fin = ~np.isnan(want_s) & ~np.isnan(got_s)
+    rel = np.abs(got_s[fin].astype(np.float64) - want_s[fin]) / np.maximum(np.abs(want_s[fin]), 1e-6)
+    return {
+        "cpu_baseline": {"value": round(dt, 3), "unit": "s", "cores": threads, "kind": "port",
+                         "sample": f"all {len(r_ptr) - 1} queries (score_explicit per query, "
+                         f"queries spread over {threads} threads)"},
+        "parity": {"queries_checked": int(len(r_ptr) - 1), "targets_checked": int(len(t_idx)),
+                   "counts_identical": bool(np.array_equal(got_c, want_c)),
+                   "null_pattern_identical": nan_same,
+                   "score_rel_max": float(rel.max()) if len(rel) else 0.0,
+                   "scores_over_1e-5": int((rel > 1e-5).sum()),
+                   "ok": bool(nan_same and np.array_equal(got_c, want_c)
+                              and (len(rel) == 0 or rel.max() <= 1e-5))},
+    }
+
+
+def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
     """
     BASELINE.json configs[4] / SURVEY.md 8d "cfg5 concrete input": U = 10^7, I = 10^6,
     nnz = 10^8 generated in HBM from seed 5 (Philox; csrc/synth.hip), values 40, als-implicit
-    k = 256 (exact solver), `--steps` timed epochs after `--warmup`; dense top-100 for a user
-    slice x ALL items with the history excluded.  `--scale` shrinks users, items and nnz
-    together.  With --gpus N (torch.distributed.run) the users / items are row-sharded as for
-    cfg2; on one GPU the whole problem runs on that GPU.
+    k = 256 (exact solver), ``steps`` timed epochs after ``warmup``; dense top-100 for a user
+    slice x ALL items with the history excluded.  ``args.scale`` shrinks users, items and nnz
+    together.  With world > 1 the users / items are row-sharded as for cfg2; on one GPU the
+    whole problem runs on that GPU.  Returns the result object (a bench line of its own under
+    ``--config cfg5``, the ``cfg5`` leg of the default line otherwise).
     """
     import torch
     import torch.distributed as dist
@@ -388,18 +460,7 @@ def main_cfg5(args):
     from lkpy_amd import _native, synth
     from lkpy_amd._als_engine import HipBackend, ImplicitALSEngine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    _native.require_gpu()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-    k = args.k if args.k != 64 else 256
+    k = args.k if args.k not in (64, 128) else 256
     reg = 0.1
     c = synth.CFG5
     n_users = max(1024, int(c["n_users"] * args.scale))
@@ -420,14 +481,14 @@ def main_cfg5(args):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         eng.train_epoch()
     eng.check()
     eng.u_plan.enable_timing(True)
     eng.i_plan.enable_timing(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         du, di = eng.train_epoch()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -450,12 +511,12 @@ def main_cfg5(args):
     out = {
         "metric": "ALS-implicit epochs/sec (cfg5 synthetic %.3gM x %.3gM x %.3gM, k=%d)"
         % (n_users / 1e6, n_items / 1e6, nnz / 1e6, k),
-        "value": round(args.steps / elapsed, 4),
+        "value": round(steps / elapsed, 4),
         "unit": "epochs/s",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 3),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -464,7 +525,7 @@ def main_cfg5(args):
         "degrees truncated-Zipf mean %.1f, items ~ Zipf(1.0))" % (c["seed"], nnz / n_users),
         "config": {
             "workload": "cfg5: %d users x %d items x %d interactions, als-implicit k=%d, "
-            "%d timed epochs, %d x MI355X" % (n_users, n_items, nnz, k, args.steps, world),
+            "%d timed epochs, %d x MI355X" % (n_users, n_items, nnz, k, steps, world),
             "solver": "cholesky" if eng.u_plan.solver == 0 else "cg",
             "reg": reg, "weight": 40.0,
             "longest_user_row": int(ulen.max()), "busiest_item": int(ilen.max()),
@@ -507,52 +568,78 @@ def main_cfg5(args):
             out[name] = {"error": f"{type(exc).__name__}: {exc}"}
 
     def parity_leg():
-        # "cfg5 on CPU: time 1 half-epoch on a 1 % row sample and extrapolate";
-        # the same sample is the parity check (user half from identical inputs)
+        # "cfg5 on CPU: time 1 half-epoch on a 1 % row sample and extrapolate"; the
+        # same samples are the parity check -- BOTH halves from identical inputs: sampled user
+        # rows, and sampled item rows that always include the BUSIEST item (1.5 M entries at full
+        # scale: the chunk path's hardest case; relabelled row 0)
         import scipy.sparse as sps
 
         from oracle import lk_oracle as lko
         from oracle import parity
 
-        Qh = eng.backend.download(eng.Q)  # relabelled order on both sides
-        plan = eng.u_plan
-        rng = np.random.default_rng(3)
-        rows = np.sort(rng.choice(plan.csr.shape[0], max(256, plan.csr.shape[0] // 400),
-                                  replace=False))
-        hp = plan.csr.h_indptr.astype(np.int64)
-        lens = (hp[rows + 1] - hp[rows])
-        ptr = np.zeros(len(rows) + 1, np.int64)
-        np.cumsum(lens, out=ptr[1:])
-        take = torch.from_numpy(np.concatenate(
-            [np.arange(hp[r], hp[r + 1]) for r in rows]).astype(np.int64)).to(dev)
-        idx = plan.csr.indices[take].cpu().numpy()
-        val = plan.csr.values[take].cpu().numpy()
-        sub = sps.csr_array((val, idx, ptr), shape=(len(rows), Qh.shape[0]))
-        # the GPU's user half from this Q: one more user half-epoch, rows read back
-        otor = eng._qtq
-        eng.backend.half_epoch(plan, eng.P[eng.u_lo:eng.u_hi], eng.Q, otor)
-        plan.check_status()
-        got = eng.backend.download(eng.P[torch.from_numpy(rows).to(dev)])
-        want = np.zeros_like(got)
         threads = lko.num_threads()
-        t0 = time.perf_counter()
-        lko.als_half_epoch(sub, want, Qh, lko.implicit_otor(Qh, reg), threads)
-        dt = time.perf_counter() - t0
-        exact, cond = lko.als_referee_f64(sub, Qh, reg)
-        acc = parity.als_half_accounting(got, want, exact, cond)
-        acc.pop("by_cond_decade", None)
-        fl_s, _ = half_flops(lens, k)
-        est = dt * (fu + fuc + fi + fic) / max(fl_s, 1.0)
+        rng = np.random.default_rng(3)
+        res, cpu_s, cpu_fl, desc = {}, 0.0, 0.0, []
+
+        def half(name, plan, this_full, lo, hi, other_full, otor_reg, n_sample, must=()):
+            nonlocal cpu_s, cpu_fl
+            other_h = eng.backend.download(other_full)  # relabelled order on both sides
+            n_rows = plan.csr.shape[0]
+            rows = rng.choice(n_rows, min(n_rows, n_sample), replace=False)
+            rows = np.unique(np.concatenate([rows, np.asarray(must, dtype=rows.dtype)]))
+            hp = plan.csr.h_indptr.astype(np.int64)
+            lens = hp[rows + 1] - hp[rows]
+            ptr = np.zeros(len(rows) + 1, np.int64)
+            np.cumsum(lens, out=ptr[1:])
+            # (plans are views into the full arrays: offsets are not rebased)
+            take = torch.from_numpy(np.concatenate(
+                [np.arange(hp[r], hp[r + 1]) for r in rows]).astype(np.int64)).to(dev)
+            idx = plan.csr.indices[take].cpu().numpy()
+            val = plan.csr.values[take].cpu().numpy()
+            sub = sps.csr_array((val, idx, ptr), shape=(len(rows), other_h.shape[0]))
+            # the GPU's half from these inputs: one more half-epoch, sampled rows read back
+            otor = eng.backend.gramian(other_full, otor_reg)
+            eng.backend.half_epoch(plan, this_full[lo:hi], other_full, otor)
+            plan.check_status()
+            got = eng.backend.download(this_full[lo:hi][torch.from_numpy(rows).to(dev)])
+            want = np.zeros_like(got)
+            t0 = time.perf_counter()
+            lko.als_half_epoch(sub, want, other_h, lko.implicit_otor(other_h, otor_reg), threads)
+            dt = time.perf_counter() - t0
+            exact, cond = lko.als_referee_f64(sub, other_h, otor_reg)
+            acc = parity.als_half_accounting(got, want, exact, cond)
+            acc.pop("by_cond_decade", None)
+            acc["longest_row_checked"] = int(lens.max())
+            cpu_s += dt
+            cpu_fl += reference_half_flops(lens, k)
+            desc.append(f"{name} half: {len(rows)} of {n_rows} rows ({sub.nnz} nnz, longest "
+                        f"{int(lens.max())}) in {dt:.2f}s")
+            res[name] = acc
+
+        n_u = max(256, eng.u_plan.csr.shape[0] // 400)
+        n_i = max(256, eng.i_plan.csr.shape[0] // 400)
+        half("user", eng.u_plan, eng.P, eng.u_lo, eng.u_hi, eng.Q, reg, n_u)
+        half("item", eng.i_plan, eng.Q, eng.i_lo, eng.i_hi, eng.P, reg, n_i, must=(0,))
+        # keep the engine consistent for the legs that follow (the scorer's Q^T Q)
+        eng._qtq = eng.backend.gramian(eng.Q, reg)
+        est = cpu_s * (reference_half_flops(ulen, k) + reference_half_flops(ilen, k)) \
+            / max(cpu_fl, 1.0)
         out["cpu_baseline"] = {
             "value": 1.0 / est, "unit": "epochs/s", "cores": threads, "kind": "port",
-            "sample": f"user half on {len(rows)} of {plan.csr.shape[0]} rows ({sub.nnz} nnz) in "
-            f"{dt:.2f}s, extrapolated to an epoch by algorithmic flops",
+            "sample": "; ".join(desc) + "; extrapolated to an epoch by algorithmic flops "
+            "(reference's dense k^3/3 per row)",
             "host_cpus": os.cpu_count()}
-        return {"what": "user half-epoch, GPU vs oracle from identical inputs, sampled rows",
-                **acc}
+        return {"what": "user AND item half-epoch, GPU vs oracle from identical inputs, sampled "
+                "rows (the item sample always contains the busiest item)",
+                "rows_checked": res["user"]["rows"] + res["item"]["rows"],
+                "rows_over_1e-4": res["user"]["rows_over_1e-4"] + res["item"]["rows_over_1e-4"],
+                "ok": bool(res["user"]["ok"] and res["item"]["ok"]),
+                "accounted": bool(res["user"]["accounted"] and res["item"]["accounted"]),
+                "exceptions": [dict(e, half=h) for h in res for e in res[h].get("exceptions", [])],
+                "user": res["user"], "item": res["item"]}
 
     def topk_leg():
-        B = args.topk_users or max(64, eng.P.shape[0] // 8)
+        B = topk_users or max(64, eng.P.shape[0] // 8)
         B = min(B, eng.P.shape[0])
         hp = eng.u_plan.csr.h_indptr.astype(np.int64)
         excl_ptr = torch.from_numpy(hp[: B + 1]).to(dev)
@@ -574,6 +661,30 @@ def main_cfg5(args):
         leg("parity", parity_leg)
     if rank == 0 and world == 1 and not args.no_topk:
         leg("topk", topk_leg)
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
+def main_cfg5(args):
+    "``--config cfg5``: the cfg5 run as a bench line of its own."
+    import torch
+    import torch.distributed as dist
+
+    from lkpy_amd import _native
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    _native.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    out = cfg5_run(args, dev, world, rank, args.steps, args.warmup, args.topk_users)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -581,69 +692,19 @@ def main_cfg5(args):
         dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None,
-                    help="timed epochs (default 50; cfg5: 3, SURVEY 8d).  BASELINE's 20-epoch "
-                    "fit is the `fit` leg; more timed epochs only steady the epochs/s figure")
-    ap.add_argument("--warmup", type=int, default=None, help="default 3 (cfg5: 1)")
-    ap.add_argument("--k", type=int, default=64)
-    ap.add_argument("--scale", type=float, default=1.0, help="shrink the dataset (debug only)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the parity + cpu_baseline legs")
-    ap.add_argument("--no-knn", action="store_true", help="skip the item-kNN build leg")
-    ap.add_argument("--no-topk", action="store_true", help="skip the dense top-N scoring leg")
-    ap.add_argument("--no-fit", action="store_true", help="skip the end-to-end fit leg")
-    ap.add_argument("--sharded-legs", action="store_true",
-                    help="N > 1: also time the sharded item-kNN build and dense top-N (off by "
-                    "default: the scaling run's headline must not depend on legs that no "
-                    "multi-GPU box has exercised yet)")
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg5"],
-                    help="cfg2: ML-25M-shaped (the default, BASELINE.json configs[1..3]); "
-                    "cfg5: synthetic 10M x 1M x 100M generated in HBM, k = 256 (configs[4])")
-    ap.add_argument("--topk-users", type=int, default=0,
-                    help="cfg5: users of the dense top-K leg (default: 1/8 of the users)")
-    args = ap.parse_args()
-    if args.steps is None:
-        args.steps = 3 if args.config == "cfg5" else 50
-    if args.warmup is None:
-        args.warmup = 1 if args.config == "cfg5" else 3
-    if args.config == "cfg5":
-        return main_cfg5(args)
-
+def als_timed(ui, P0, Q0, k, reg, steps, warmup, dev, world, scale):
+    """
+    Set up the engine (one upload, relabel + transpose in HBM), run ``warmup`` untimed and
+    ``steps`` timed epochs bracketed by barrier + synchronize (maximum over ranks), and build the
+    roofline object of the solve kernel from the HIP-event launch durations recorded on the
+    launch stream inside the library.  Returns (engine, backend, seconds, roofline, set-up
+    seconds, final deltas).
+    """
     import torch
     import torch.distributed as dist
 
-    from lkpy_amd import _native, synth
+    from lkpy_amd import _native
     from lkpy_amd._als_engine import HipBackend, ImplicitALSEngine
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    _native.require_gpu()  # no CPU fallback: fail loudly without the HIP path
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    k, reg, weight = args.k, 0.1, 40.0
-    ratings = synth.ml25m_like(scale=args.scale)
-    info = synth.describe(ratings)
-    import scipy.sparse as sps
-
-    ui = sps.csr_array(
-        (np.full(ratings.nnz, weight, dtype=np.float32), ratings.indices, ratings.indptr),
-        shape=ratings.shape,
-    )
-    # the reference's init: item matrix first, then users, (N(0,1)*0.01)^2
-    rng = np.random.default_rng(42)
-    Q0 = rng.standard_normal((ui.shape[1], k), dtype=np.float32) * 0.01
-    Q0 *= Q0
-    P0 = rng.standard_normal((ui.shape[0], k), dtype=np.float32) * 0.01
-    P0 *= P0
 
     backend = HipBackend(k, dev, _native.SOLVER_AUTO)
     torch.cuda.synchronize(dev)
@@ -657,14 +718,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         eng.train_epoch()
     eng.check()
     eng.u_plan.enable_timing(True)
     eng.i_plan.enable_timing(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         du, di = eng.train_epoch()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -673,7 +734,6 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
 
     # ---- roofline of the dominant kernel (local shard of this rank) ----
     roof = None
@@ -722,10 +782,112 @@ def main():
                % (eng.u_plan.woodbury_rows if uwb else 0, eng.i_plan.woodbury_rows if iwb else 0)
                if (uwb or iwb) else ""),
         }
-    if roof and world == 1 and args.scale == 1.0:
+    if roof and world == 1 and scale == 1.0:
         roof["traffic"], roof["traffic_source"] = pmc_traffic(
-            "r*_als_k%d_counters.csv" % k if k != 64 else "r*_als_*_counters.csv",
+            "r*_k%d_counters.csv" % k if k != 64 else "r*_als_*_counters.csv",
             kname.split("<")[0])
+    return eng, backend, elapsed, roof, setup_seconds, (float(du.item()), float(di.item()))
+
+
+def maybe_self_launch(args):
+    """
+    ``python bench.py --gpus N`` with N > 1 and no launcher environment: re-execute under
+    ``torch.distributed.run`` (one process per GPU, rendezvous on 127.0.0.1 and a free port) --
+    the same command line the driver uses when it launches the ranks itself, in which case
+    WORLD_SIZE is already set and this is a no-op.
+    """
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed epochs (default 50; cfg5: 3, SURVEY 8d).  BASELINE's 20-epoch "
+                    "fit is the `fit` leg; more timed epochs only steady the epochs/s figure")
+    ap.add_argument("--warmup", type=int, default=None, help="default 3 (cfg5: 1)")
+    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the dataset (debug only)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the parity + cpu_baseline legs")
+    ap.add_argument("--no-knn", action="store_true", help="skip the item-kNN build leg")
+    ap.add_argument("--no-topk", action="store_true", help="skip the dense top-N scoring leg")
+    ap.add_argument("--no-fit", action="store_true", help="skip the end-to-end fit leg")
+    ap.add_argument("--no-k128", action="store_true", help="skip the k = 128 leg (configs[3])")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg5 leg (configs[4])")
+    ap.add_argument("--k128-steps", type=int, default=10, help="timed epochs of the k128 leg")
+    ap.add_argument("--sharded-legs", action="store_true",
+                    help="N > 1: also time the sharded item-kNN build and dense top-N (off by "
+                    "default: the scaling run's headline must not depend on legs that no "
+                    "multi-GPU box has exercised yet)")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg5"],
+                    help="cfg2: ML-25M-shaped (the default, BASELINE.json configs[1..3]); "
+                    "cfg5: synthetic 10M x 1M x 100M generated in HBM, k = 256 (configs[4])")
+    ap.add_argument("--topk-users", type=int, default=0,
+                    help="cfg5: users of the dense top-K leg (default: 1/8 of the users)")
+    args = ap.parse_args()
+    maybe_self_launch(args)
+    if args.steps is None:
+        args.steps = 3 if args.config == "cfg5" else 50
+    if args.warmup is None:
+        args.warmup = 1 if args.config == "cfg5" else 3
+    if args.config == "cfg5":
+        return main_cfg5(args)
+
+    import torch
+    import torch.distributed as dist
+
+    from lkpy_amd import _native, synth
+    from lkpy_amd._als_engine import HipBackend, ImplicitALSEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    _native.require_gpu()  # no CPU fallback: fail loudly without the HIP path
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    k, reg, weight = args.k, 0.1, 40.0
+    ratings = synth.ml25m_like(scale=args.scale)
+    info = synth.describe(ratings)
+    import scipy.sparse as sps
+
+    ui = sps.csr_array(
+        (np.full(ratings.nnz, weight, dtype=np.float32), ratings.indices, ratings.indptr),
+        shape=ratings.shape,
+    )
+    # the reference's init: item matrix first, then users, (N(0,1)*0.01)^2
+    rng = np.random.default_rng(42)
+    Q0 = rng.standard_normal((ui.shape[1], k), dtype=np.float32) * 0.01
+    Q0 *= Q0
+    P0 = rng.standard_normal((ui.shape[0], k), dtype=np.float32) * 0.01
+    P0 *= P0
+
+    eng, backend, elapsed, roof, setup_seconds, deltas = als_timed(
+        ui, P0, Q0, k, reg, args.steps, args.warmup, dev, world, args.scale)
+    ms_per_step = elapsed / args.steps * 1e3
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
     out = {
         "metric": "ALS-implicit epochs/sec (ML-25M-shaped, k=%d)" % k,
         "value": round(args.steps / elapsed, 3),
@@ -753,7 +915,7 @@ def main():
             "weight": weight,
             "parallelism": "row-sharded x%d" % world if world > 1 else "single GPU",
         },
-        "final_deltas": [float(du.item()), float(di.item())],
+        "final_deltas": list(deltas),
         "setup_seconds": round(setup_seconds, 4),
     }
     if roof:
@@ -777,12 +939,13 @@ def main():
         # "batched dense top-K scoring", f32 MFMA); exclusion of the users' own items included
         from lkpy_amd import _device as D
 
-        excl_ptr = torch.from_numpy(eng.u_plan.csr.h_indptr.astype(np.int64)).to(dev)
+        h_ptr = eng.u_plan.csr.h_indptr.astype(np.int64)
+        excl_ptr = torch.from_numpy(h_ptr).to(dev)
         ts = []
         for _ in range(3):
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            D.score_topk(eng.P, eng.Q, k, 100, excl_ptr, eng.u_plan.csr.indices)
+            g_idx, g_sc = D.score_topk(eng.P, eng.Q, k, 100, excl_ptr, eng.u_plan.csr.indices)
             torch.cuda.synchronize(dev)
             ts.append(time.perf_counter() - t0)
         tb = min(ts)
@@ -804,8 +967,10 @@ def main():
         }
         if not args.no_cpu:
             try:
-                res["cpu_baseline"] = topk_cpu_baseline(
-                    eng.user_embeddings(), eng.item_embeddings(), sps.csr_array(ratings), 100)
+                res["cpu_baseline"], res["parity"] = topk_cpu_and_parity(
+                    backend.download(eng.P), backend.download(eng.Q), h_ptr,
+                    eng.u_plan.csr.indices.cpu().numpy(), g_idx.cpu().numpy(),
+                    g_sc.cpu().numpy(), 100)
             except Exception as exc:  # noqa: BLE001
                 res["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
         return res
@@ -813,7 +978,8 @@ def main():
     def knn_leg():
         from lkpy_amd import _knn_bench
 
-        res = _knn_bench.run(ratings, dev, checker=None if args.no_cpu else knn_cpu_and_parity)
+        res = _knn_bench.run(ratings, dev, checker=None if args.no_cpu else knn_cpu_and_parity,
+                             score_checker=None if args.no_cpu else knn_score_cpu_and_parity)
         if isinstance(res.get("roofline"), dict) and args.scale == 1.0:
             # HBM bytes of the build kernel from the committed PMC summary of the same workload
             res["roofline"]["traffic"], res["roofline"]["traffic_source"] = pmc_traffic(
@@ -869,6 +1035,35 @@ def main():
             extra = {"sharded_legs_error": f"{type(exc).__name__}: {exc}"}
         out.update(extra)
 
+    def k128_leg():
+        """BASELINE.json configs[3] on ONE GPU: the same data at k = 128 (``als_blk.hip``): a few
+        timed epochs, roofline, and the parity / cpu_baseline pair on a row sample."""
+        k2 = 128
+        rng2 = np.random.default_rng(42)
+        Q2 = rng2.standard_normal((ui.shape[1], k2), dtype=np.float32) * 0.01
+        Q2 *= Q2
+        P2 = rng2.standard_normal((ui.shape[0], k2), dtype=np.float32) * 0.01
+        P2 *= P2
+        eng2, _b2, el2, roof2, setup2, deltas2 = als_timed(
+            ui, P2, Q2, k2, reg, args.k128_steps, 3, dev, world, args.scale)
+        res = {
+            "metric": "ALS-implicit epochs/sec (ML-25M-shaped, k=128), 1 x MI355X",
+            "value": round(args.k128_steps / el2, 3), "unit": "epochs/s",
+            "steps": args.k128_steps, "warmup": 3,
+            "ms_per_step": round(el2 / args.k128_steps * 1e3, 4),
+            "setup_seconds": round(setup2, 4), "final_deltas": list(deltas2),
+            "config": {"workload": "MovieLens-25M-shaped, als-implicit k=128 (BASELINE configs[3] "
+                       "on one GPU), %d timed epochs" % args.k128_steps},
+            "roofline": roof2,
+        }
+        if not args.no_cpu:
+            res["parity"], res["cpu_baseline"] = als_parity_and_cpu(eng2, ui, k2, reg, 0.05)
+        return res
+
+    def cfg5_leg():
+        "BASELINE.json configs[4] on ONE GPU: 3 timed epochs + parity sample + a top-K slice"
+        return cfg5_run(args, dev, world, rank, 3, 1, args.topk_users)
+
     single = rank == 0 and world == 1
     if single and not args.no_cpu:
         leg("parity", als_parity_leg)
@@ -883,6 +1078,11 @@ def main():
         leg("knn", knn_leg)
         if isinstance(out.get("parity"), dict) and isinstance(out["knn"], dict):
             out["parity"]["knn"] = out["knn"].pop("parity", None)
+    if single and not args.no_k128 and k == 64:
+        leg("k128", k128_leg)
+        torch.cuda.empty_cache()
+    if single and not args.no_cfg5 and k == 64:
+        leg("cfg5", cfg5_leg)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

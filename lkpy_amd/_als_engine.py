@@ -31,6 +31,8 @@ the product backend is :class:`HipBackend` and there is no fallback.
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import scipy.sparse as sps
 import torch
@@ -216,6 +218,13 @@ class ImplicitALSEngine:
         self.group = group
         self.world = dist.get_world_size(group) if (group is not None or _dist_on()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # collectives run whenever there is more than one rank; LK_ALS_FORCE_COLLECTIVES=1 makes
+        # a single rank with an initialised process group issue them too (the in-place
+        # all-gather on the slice view, the k*k + 1 all-reduce, the init broadcast): the way to
+        # execute the RCCL path on device tensors on a one-GPU box (tests/test_gpu_rccl.py)
+        self.collective = self.world > 1 or (
+            os.environ.get("LK_ALS_FORCE_COLLECTIVES", "0") == "1" and dist.is_available()
+            and dist.is_initialized())
         n_users, n_items = ui.shape
         self.n_users, self.n_items = n_users, n_items
         on_device = hasattr(ui, "h_indptr")  # a DeviceCSR: the matrix is already in HBM
@@ -284,7 +293,7 @@ class ImplicitALSEngine:
             Q[self.i_new] = item_init
             self.P = backend.upload(P)
             self.Q = backend.upload(Q)
-        if self.world > 1:
+        if self.collective:
             # every rank must start from the SAME factors (the first user half mixes the local Q
             # with an all-reduced Gramian): rank 0's initialisation wins, whatever the ranks'
             # generators drew (unseeded runs draw differently on every rank)
@@ -297,14 +306,14 @@ class ImplicitALSEngine:
     # -- collectives ---------------------------------------------------------
     def _gramian(self, full: torch.Tensor, lo: int, hi: int, reg: float) -> torch.Tensor:
         "M^T M + reg I from slice Gramians (k x k all-reduce when sharded)."
-        if self.world == 1:
+        if not self.collective:
             return self.backend.gramian(full, reg)
         g = self.backend.gramian(full[lo:hi], reg if self.rank == 0 else 0.0)
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
         return g
 
     def _exchange(self, full: torch.Tensor, lo: int, hi: int):
-        if self.world > 1:
+        if self.collective:
             dist.all_gather_into_tensor(full, full[lo:hi], group=self.group)
 
     # -- training ------------------------------------------------------------
@@ -342,7 +351,7 @@ class ImplicitALSEngine:
         (k*k + 1 floats: latency-bound on xGMI, so one message instead of two); returns
         (M^T M + reg I, sqrt(sum of squared row deltas)).
         """
-        if self.world == 1:
+        if not self.collective:
             return self.backend.gramian(full, reg), d.clone()
         g = self.backend.gramian(full[lo:hi], reg if self.rank == 0 else 0.0)
         kk = self.k * self.k
@@ -353,7 +362,7 @@ class ImplicitALSEngine:
         return buf[:kk].reshape(self.k, self.k).contiguous(), buf[kk:].sqrt()
 
     def _delta(self, d: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if not self.collective:
             return d.clone()
         sq = d * d
         dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)

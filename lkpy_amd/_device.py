@@ -232,6 +232,12 @@ class ALSPlan:
             self.woodbury_rows = self.short_rows  # k = 128: only the 16 x 16 variant pays
         self.use_wb = (self.kp > 64 and self.solver == _native.SOLVER_CHOLESKY and wb_min > 0
                        and self.woodbury_rows >= wb_min)
+        if self.use_wb and csr.values is not None and csr.values.numel() > 0 \
+                and float(csr.values.min()) < 0.0:
+            # the Woodbury kernels take sqrt(v) of every confidence increment: with negative
+            # values (use_ratings=True and negative ratings) they would flag rows the dense
+            # sposv path still solves -- such matrices keep the dense kernels for every row
+            self.use_wb = False
         self._z = None
 
     def set_ctl(self, ctl: "TaskCtl | None"):

@@ -30,7 +30,8 @@ def prepare_explicit(ratings: sps.csr_array):
     return ui, iu, means
 
 
-def _score_batch_leg(D, ratings, means, sims, dev, n_users=10_000, n_targets=100) -> dict:
+def _score_batch_leg(D, ratings, means, sims, dev, n_users=10_000, n_targets=100,
+                     checker=None) -> dict:
     """rating prediction (max_nbrs = 100, min_nbrs = 1) for 10 000 sampled
     users x 100 sampled items through one ``lk_iknn_score_batch`` call."""
     csr = sps.csr_array(ratings)
@@ -56,14 +57,23 @@ def _score_batch_leg(D, ratings, means, sims, dev, n_users=10_000, n_targets=100
     s, _c = D.iknn_score_batch(*args)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    return {"queries": int(len(users)), "targets_per_query": n_targets, "seconds": round(dt, 4),
-            "queries_per_s": round(len(users) / dt, 1), "scored": int(torch.isfinite(s).sum())}
+    res = {"queries": int(len(users)), "targets_per_query": n_targets, "seconds": round(dt, 4),
+           "queries_per_s": round(len(users) / dt, 1), "scored": int(torch.isfinite(s).sum())}
+    if checker is not None:
+        try:
+            res.update(checker(sims, r_ptr, r_idx, r_val, t_ptr, t_idx, s.cpu().numpy(),
+                               _c.cpu().numpy()))
+        except Exception as exc:  # noqa: BLE001 -- reported in place
+            res["parity"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return res
 
 
-def run(ratings: sps.csr_array, dev, reps: int = 2, checker=None) -> dict:
+def run(ratings: sps.csr_array, dev, reps: int = 2, checker=None, score_checker=None) -> dict:
     """
     ``checker(dui, diu, out) -> (cpu_baseline, parity)``: bench.py's oracle leg, called while the
     full similarity matrix is still resident (this package itself never touches ``oracle/``).
+    ``score_checker(sims, r_ptr, r_idx, r_val, t_ptr, t_idx, scores, counts) -> dict``: the same
+    for the batch-scoring call (host copies of the query lists and of the GPU's answers).
     """
     from . import _device as D
 
@@ -136,7 +146,7 @@ def run(ratings: sps.csr_array, dev, reps: int = 2, checker=None) -> dict:
         sims = D.iknn_build(dui, diu, 1.0e-6, 100)
         torch.cuda.synchronize(dev)
         t100.append(time.perf_counter() - t0)
-    score = _score_batch_leg(D, ratings, means, sims, dev)
+    score = _score_batch_leg(D, ratings, means, sims, dev, checker=score_checker)
     res = {
         "metric": "item-kNN model build seconds (ML-25M-shaped, cosine, min_sim=1e-6, unbounded)",
         "value": round(best, 4),

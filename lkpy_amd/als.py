@@ -64,6 +64,22 @@ def _scorer_state(obj) -> dict:
     return st
 
 
+def _restore_scorer_state(obj, state: dict):
+    """
+    ``__setstate__`` of the ALS scorers.  Pickles written before the learned arrays became
+    lazily-synchronised descriptors hold them under their plain names (``user_embeddings``,
+    ``item_embeddings``, ``_OtOr``); they are moved to the descriptors' ``_h_`` slots so that an
+    old model file scores as before instead of failing later inside ``_device_state``.
+    """
+    state = dict(state)
+    for name in ("user_embeddings", "item_embeddings", "_OtOr"):
+        if name in state and isinstance(getattr(type(obj), name, None), _DeviceBacked):
+            state.setdefault("_h_" + name, state.pop(name))
+    state.pop("_dev", None)
+    state.pop("_pending_sync", None)
+    obj.__dict__.update(state)
+
+
 class UIPair(BaseModel):
     user: PositiveFloat
     item: PositiveFloat
@@ -136,6 +152,9 @@ class ImplicitMFScorer(UsesTrainer, Component):
     # -- device-side caches (never pickled) ---------------------------------------
     def __getstate__(self):
         return _scorer_state(self)
+
+    def __setstate__(self, state):
+        _restore_scorer_state(self, state)
 
     def _device_state(self):
         dev = getattr(self, "_dev", None)
@@ -298,14 +317,21 @@ class ImplicitMFTrainer(ModelTrainer):
         """
         _implicit.py:141-149 + the ``from_scipy(ui_rates)`` of _common.py:218: confidence values
         ``weight`` (or ``weight * rating``) in CSR.  The reference goes through COO and lets
-        SciPy convert; the dataset already holds (user, item)-sorted, duplicate-free
-        interactions, so the CSR arrays are taken as they are -- same matrix, no host sort.
+        SciPy convert; the dataset already holds (user, item)-sorted interactions, so the CSR
+        arrays are taken as they are -- same matrix, no host sort -- unless the dataset reports
+        repeated pairs, which are summed as SciPy's conversion would.
         """
         ints = data.interactions().matrix()
         rmat = ints.scipy(attribute="rating", layout="csr") if self.scorer.config.use_ratings \
             else ints.scipy(layout="csr")
         vals = np.require(rmat.data, dtype=np.float32) * np.float32(self.scorer.config.weight)
-        return sps.csr_array((vals, rmat.indices, rmat.indptr), shape=rmat.shape)
+        out = sps.csr_array((vals, rmat.indices, rmat.indptr), shape=rmat.shape)
+        if getattr(data, "has_duplicates", True):
+            # repeated (user, item) pairs: ONE entry with the summed confidence, exactly what
+            # the reference's COO -> CSR conversion produces (y gets (2v + 1) once, not (v + 1)
+            # twice)
+            out.sum_duplicates()
+        return out
 
     def initial_params(self, nrows: int, ncols: int) -> np.ndarray:
         "_implicit.py:152-155"
@@ -373,6 +399,12 @@ class BiasedMFScorer(UsesTrainer, Component):
 
     def __getstate__(self):
         return _scorer_state(self)
+
+    def __setstate__(self, state):
+        _restore_scorer_state(self, state)
+
+    def __setstate__(self, state):
+        _restore_scorer_state(self, state)
 
     def _device_state(self):
         dev = getattr(self, "_dev", None)

@@ -371,9 +371,16 @@ __global__ __launch_bounds__(256) void iknn_mirror_kernel(int32_t *__restrict__ 
             if (i < i_hi) {
                 const int64_t base = i * n_items + (int64_t)p * W;
                 const uint16_t *tab = strip_tab + (size_t)(i * P + p) * (S + 1) + strip;
-                const int lo = tab[0], hi = tab[1];
-                for (int k = lo; k < hi; ++k)
-                    tile[st_idx[base + k] - j0][tid] = st_val[base + k];
+                // (a cancelled build leaves tasks without their strip counts: the table is
+                // zeroed beforehand when a cancel block is attached, and whatever is read is
+                // clamped to the segment and to the strip, so a discarded result can never
+                // turn into an out-of-bounds access)
+                int hi = tab[1] < W ? tab[1] : W;
+                const int lo = tab[0] < hi ? tab[0] : hi;
+                for (int k = lo; k < hi; ++k) {
+                    const unsigned col = (unsigned)(st_idx[base + k] - j0);
+                    if (col < 64u) tile[col][tid] = st_val[base + k];
+                }
             }
         }
         __syncthreads();
@@ -718,6 +725,12 @@ static int launch_iknn(const lk_iknn_plan *p, const void *ui_ptr, const int32_t 
     int64_t blocks = std::min<int64_t>(p->n_btasks, iknn_grid(p->W));
     if (p->ctl) {
         if (COUNT) LK_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)p->n_tasks, st));
+        // tasks that stop at a cancel never write their strip counts: the mirror kernel below
+        // must not read stale workspace for them
+        if (COUNT && p->symmetric)
+            LK_HIP_CHECK(hipMemsetAsync(ws + p->off_strip, 0,
+                                        (size_t)p->n_tasks * (size_t)(p->W / 64 + 1) *
+                                            sizeof(uint16_t), st));
         int rc = ctl_begin(p->ctl, p->n_rows, p->symmetric ? p->n_sym_tasks : p->n_tasks, st);
         if (rc != LK_OK) return rc;
     }

@@ -304,6 +304,11 @@ class Dataset:
         self._rows = np.require(rows, dtype=np.int32)[order]
         self._cols = np.require(cols, dtype=np.int32)[order]
         self._attrs = {k: np.asarray(v)[order] for k, v in attrs.items()}
+        # repeated (user, item) pairs are kept as separate interactions (as the reference's
+        # interaction tables do); consumers that need a MATRIX sum them, as SciPy's COO -> CSR
+        # conversion does on the reference's path (src/lenskit/als/_implicit.py:141-149)
+        self.has_duplicates = bool(len(self._rows) > 1 and np.any(
+            (self._rows[1:] == self._rows[:-1]) & (self._cols[1:] == self._cols[:-1])))
         # int32 offsets like Arrow List; int64 once the interaction count needs it
         # (src/lenskit/data/matrix.py:411-419)
         dt = np.int32 if len(self._rows) < np.iinfo(np.int32).max else np.int64

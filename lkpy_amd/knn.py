@@ -421,7 +421,9 @@ class EASEScorer(Component):
             good = np.empty(0, np.int32)
             if q_items is not None:
                 q_inos = q_items.numbers(vocabulary=self.items, missing="negative")
-                good = q_inos[q_inos >= 0].astype(np.int32)
+                # a repeated history item counts ONCE: the reference sets q_vec[q_good] = 1.0
+                # (src/lenskit/knn/ease.py), it does not add per occurrence
+                good = np.unique(q_inos[q_inos >= 0]).astype(np.int32)
             hists.append(good)
             ok.append(len(good) > 0)  # ease.py:150-158: no usable history => all NaN
         ptr = np.zeros(len(hists) + 1, dtype=np.int64)

@@ -32,72 +32,114 @@ SPARSE_ROW_EXT_NAME = "lenskit.sparse_row"
 
 
 class SparseIndexType(pa.ExtensionType):
-    "``int32`` column numbers + the row dimension (matrix.py:104-143)."
+    """
+    Wire schema (category: interchange format, src/lenskit/data/matrix.py:104-143): ``int32``
+    storage under the name ``lenskit.sparse_index``; the column count travels as the JSON
+    metadata ``{"dimension": n}``.
+    """
 
     def __init__(self, dimension: int):
         self.dimension = int(dimension)
         super().__init__(pa.int32(), SPARSE_IDX_EXT_NAME)
 
     def check_dimension(self, expected: int | None) -> int:
-        if expected is not None and expected != self.dimension:
-            raise ValueError(f"dimension mismatch: expected {expected}, found {self.dimension}")
-        return self.dimension
+        "the column count, after confirming it is ``expected`` when the caller states one"
+        if expected is None or int(expected) == self.dimension:
+            return self.dimension
+        raise ValueError(f"sparse index declares {self.dimension} columns, caller expects {expected}")
 
     def __arrow_ext_serialize__(self) -> bytes:
         return json.dumps({"dimension": self.dimension}).encode()
 
     @classmethod
     def __arrow_ext_deserialize__(cls, storage_type, serialized):
-        data = json.loads(serialized.decode())
-        if not pa.types.is_int32(storage_type):
-            raise TypeError("sparse index must be int32")
-        return cls(data["dimension"])
+        if storage_type != pa.int32():
+            raise TypeError(f"{SPARSE_IDX_EXT_NAME} is stored as int32, not {storage_type}")
+        return cls(json.loads(serialized)["dimension"])
 
     def __reduce__(self):
         return SparseIndexType, (self.dimension,)
 
 
-def _check_index_type(index_type: pa.DataType, dimension: int | None) -> int:
-    "matrix.py:543-555"
-    if isinstance(index_type, SparseIndexType):
-        return index_type.check_dimension(dimension)
-    if not pa.types.is_int32(index_type):
-        raise TypeError(f"index field must be int32, found {index_type}")
-    if dimension is None:
-        raise TypeError("legacy sparse rows need an explicit dimension")
-    return dimension
+class _RowLayout:
+    """
+    What one look at an Arrow type tells about a sparse-row array: how many columns, whether
+    offsets are 64-bit, and the value type (``None`` = structure only).  Both extension types
+    below are thin labels around this description; ``read`` is the single place that decides
+    whether a storage type is an acceptable sparse-row layout (the checks the Rust view makes in
+    ``CSRMatrix::from_arrow``, src/accel/sparse/csr.rs:160-204, and ``from_type`` of
+    src/lenskit/data/matrix.py:175-199,255-293, stated once).
+    """
+
+    __slots__ = ("dimension", "large", "value_type")
+
+    def __init__(self, dimension: int, large: bool, value_type):
+        self.dimension, self.large, self.value_type = int(dimension), bool(large), value_type
+
+    @staticmethod
+    def _columns(index_type: pa.DataType, stated: int | None) -> int:
+        if isinstance(index_type, SparseIndexType):
+            return index_type.check_dimension(stated)
+        if index_type != pa.int32():
+            raise TypeError(f"column numbers must be int32 (or {SPARSE_IDX_EXT_NAME}), "
+                            f"found {index_type}")
+        if stated is None:  # plain int32 indices (pre-extension files) carry no column count
+            raise TypeError("plain int32 column numbers need the dimension from the caller")
+        return int(stated)
+
+    @classmethod
+    def read(cls, data_type: pa.DataType, stated: int | None, want_values: bool) -> "_RowLayout":
+        if pa.types.is_large_list(data_type):
+            large = True
+        elif pa.types.is_list(data_type):
+            large = False
+        else:
+            raise TypeError(f"sparse rows are List or LargeList arrays, found {data_type}")
+        elem = data_type.value_type
+        if not want_values:
+            return cls(cls._columns(elem, stated), large, None)
+        if not pa.types.is_struct(elem):
+            raise TypeError(f"row elements must be Struct{{index, value}}, found {elem}")
+        names = [elem.field(i).name for i in range(elem.num_fields)]
+        if names != ["index", "value"]:
+            raise TypeError(f"row element fields must be ['index', 'value'], found {names}")
+        return cls(cls._columns(elem.field(0).type, stated), large, elem.field(1).type)
+
+    def storage(self, index_type: SparseIndexType) -> pa.DataType:
+        elem = index_type if self.value_type is None else \
+            pa.struct([("index", index_type), ("value", self.value_type)])
+        return pa.large_list(elem) if self.large else pa.list_(elem)
 
 
-class SparseIndexListType(pa.ExtensionType):
-    "Structure-only rows: ``(Large)List<sparse_index>`` (matrix.py:146-214)."
+class _SparseRowsBase(pa.ExtensionType):
+    "shared behaviour of the two row types: empty metadata, layout recovered from the storage"
 
-    value_type = None
+    _with_values: bool
+    _ext_name: str
 
-    def __init__(self, dimension: int, large: bool = False):
-        self.index_type = SparseIndexType(dimension)
-        ctor = pa.large_list if large else pa.list_
-        super().__init__(ctor(self.index_type), SPARSE_IDX_LIST_EXT_NAME)
+    def _setup(self, layout: _RowLayout):
+        self.index_type = SparseIndexType(layout.dimension)
+        self.value_type = layout.value_type
+        pa.ExtensionType.__init__(self, layout.storage(self.index_type), self._ext_name)
 
     @classmethod
     def from_type(cls, data_type: pa.DataType, dimension: int | None = None):
-        if isinstance(data_type, SparseIndexListType):
+        if isinstance(data_type, cls):
             data_type.index_type.check_dimension(dimension)
             return data_type
-        if pa.types.is_list(data_type):
-            large = False
-        elif pa.types.is_large_list(data_type):
-            large = True
-        else:
-            raise TypeError(f"expected list type, found {data_type}")
-        dimension = _check_index_type(data_type.value_type, dimension)
-        return cls(dimension, large=large)
+        lay = _RowLayout.read(data_type, dimension, cls._with_values)
+        return cls._from_layout(lay)
 
     @property
     def dimension(self) -> int:
         return self.index_type.dimension
 
+    @property
+    def large(self) -> bool:
+        return pa.types.is_large_list(self.storage_type)
+
     def __arrow_ext_serialize__(self) -> bytes:
-        return b""
+        return b""  # wire schema: everything is in the storage type
 
     @classmethod
     def __arrow_ext_deserialize__(cls, storage_type, serialized):
@@ -106,66 +148,40 @@ class SparseIndexListType(pa.ExtensionType):
     def __arrow_ext_class__(self):
         return SparseRowArray
 
+
+class SparseIndexListType(_SparseRowsBase):
+    "``lenskit.sparse_index_list``: ``(Large)List<sparse_index>``, structure only."
+
+    _with_values = False
+    _ext_name = SPARSE_IDX_LIST_EXT_NAME
+
+    def __init__(self, dimension: int, large: bool = False):
+        self._setup(_RowLayout(dimension, large, None))
+
+    @classmethod
+    def _from_layout(cls, lay: _RowLayout):
+        return cls(lay.dimension, lay.large)
+
     def __reduce__(self):
-        return SparseIndexListType, (self.dimension, pa.types.is_large_list(self.storage_type))
+        return SparseIndexListType, (self.dimension, self.large)
 
 
-class SparseRowType(pa.ExtensionType):
-    "Rows with values: ``(Large)List<Struct{index, value}>`` (matrix.py:217-315)."
+class SparseRowType(_SparseRowsBase):
+    "``lenskit.sparse_row``: ``(Large)List<Struct{index: sparse_index, value: T}>``."
+
+    _with_values = True
+    _ext_name = SPARSE_ROW_EXT_NAME
 
     def __init__(self, dimension: int, value_type: pa.DataType | None = pa.float32(),
                  large: bool = False):
-        self.value_type = value_type
-        self.index_type = SparseIndexType(dimension)
-        ctor = pa.large_list if large else pa.list_
-        if value_type is None:
-            element = self.index_type
-        else:
-            element = pa.struct([("index", self.index_type), ("value", value_type)])
-        super().__init__(ctor(element), SPARSE_ROW_EXT_NAME)
+        self._setup(_RowLayout(dimension, large, value_type))
 
     @classmethod
-    def from_type(cls, data_type: pa.DataType, dimension: int | None = None) -> "SparseRowType":
-        if isinstance(data_type, SparseRowType):
-            data_type.index_type.check_dimension(dimension)
-            return data_type
-        if pa.types.is_list(data_type):
-            large = False
-        elif pa.types.is_large_list(data_type):
-            large = True
-        else:
-            raise TypeError(f"expected list type, found {data_type}")
-        inner = data_type.value_type
-        if not pa.types.is_struct(inner):
-            raise TypeError(f"expected struct type, found {inner}")
-        if inner.num_fields != 2:
-            raise TypeError(f"element struct must have 2 elements, found {inner.num_fields}")
-        idx_f = inner.field(0)
-        if idx_f.name != "index":
-            raise TypeError(f"first field of element struct must be 'index', found {idx_f.name}")
-        dimension = _check_index_type(idx_f.type, dimension)
-        val_f = inner.field(1)
-        if val_f.name != "value":
-            raise TypeError(f"second field of element struct must be 'value', found {val_f.name}")
-        return cls(dimension, val_f.type, large=large)
-
-    @property
-    def dimension(self) -> int:
-        return self.index_type.dimension
-
-    def __arrow_ext_serialize__(self) -> bytes:
-        return b""
-
-    @classmethod
-    def __arrow_ext_deserialize__(cls, storage_type, serialized):
-        return cls.from_type(storage_type)
-
-    def __arrow_ext_class__(self):
-        return SparseRowArray
+    def _from_layout(cls, lay: _RowLayout):
+        return cls(lay.dimension, lay.value_type, lay.large)
 
     def __reduce__(self):
-        return SparseRowType, (self.dimension, self.value_type,
-                               pa.types.is_large_list(self.storage_type))
+        return SparseRowType, (self.dimension, self.value_type, self.large)
 
 
 class SparseRowArray(pa.ExtensionArray):
@@ -217,11 +233,10 @@ class SparseRowArray(pa.ExtensionArray):
         if isinstance(array.type, (SparseRowType, SparseIndexListType)):
             array.type.index_type.check_dimension(dimension)
             return pa.ExtensionArray.from_storage(array.type, array)
-        vt = getattr(array.type, "value_type", None)
-        if vt is not None and not pa.types.is_struct(vt):
-            et = SparseIndexListType.from_type(array.type, dimension)
-        else:
-            et = SparseRowType.from_type(array.type, dimension)
+        elem = getattr(array.type, "value_type", None)
+        structure_only = elem is not None and not pa.types.is_struct(elem)
+        et = (SparseIndexListType if structure_only else SparseRowType).from_type(
+            array.type, dimension)
         return pa.ExtensionArray.from_storage(et, array.cast(et.storage_type))
 
     @classmethod

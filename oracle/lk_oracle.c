@@ -999,3 +999,76 @@ void lko_score_dense(const float *q, int64_t n_items, int k, const float *u, flo
         out[i] = acc;
     }
 }
+
+/* ------------------------------------------------------------------------- */
+/* Batches of queries (bench.py's cpu_baseline / at-scale parity legs)          */
+/* ------------------------------------------------------------------------- */
+
+/* n_q recommend queries, each the reference's per-query path: scores = Q @ u
+ * (ALSBase.__call__, src/lenskit/als/_common.py:163-170; here the fixed k-ordered chain of
+ * lko_score_dense), the query's own items struck out (candidates = all items minus the
+ * user's, src/lenskit/basic/candidates.py:77-94), heap top-n (lko_argtopn).  Queries are
+ * independent and run on OpenMP threads, as the reference's batch runner spreads them over
+ * worker processes (src/lenskit/batch/_runner.py:259-345).  out_idx [n_q x n] is padded with
+ * -1, out_scores with NaN. */
+int lko_score_topn_batch(const float *q, int64_t n_items, int k, const float *users, int64_t n_q,
+                         const int64_t *ex_ptr, const int32_t *ex_idx, int n, int32_t *out_idx,
+                         float *out_scores, int n_threads)
+{
+#ifdef _OPENMP
+    if (n_threads <= 0 || n_threads > LKO_MAX_THREADS) n_threads = lko_num_threads();
+#else
+    n_threads = 1;
+#endif
+#pragma omp parallel num_threads(n_threads)
+    {
+        float *sc = (float *)malloc(sizeof(float) * (size_t)n_items);
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t b = 0; b < n_q; b++) {
+            const float *u = users + b * k;
+            for (int64_t i = 0; i < n_items; i++) {
+                const float *qi = q + i * k;
+                float acc = 0.0f;
+                for (int f = 0; f < k; f++) acc = fmaf(qi[f], u[f], acc);
+                sc[i] = acc;
+            }
+            if (ex_ptr)
+                for (int64_t e = ex_ptr[b]; e < ex_ptr[b + 1]; e++)
+                    if (ex_idx[e] >= 0 && ex_idx[e] < n_items) sc[ex_idx[e]] = NAN;
+            int32_t *oi = out_idx + b * n;
+            int64_t m = lko_argtopn(sc, NULL, n_items, n, oi);
+            for (int64_t j = 0; j < n; j++) {
+                out_scores[b * n + j] = j < m ? sc[oi[j]] : NAN;
+                if (j >= m) oi[j] = -1;
+            }
+        }
+        free(sc);
+    }
+    return 0;
+}
+
+/* n_q item-kNN score queries (lko_iknn_score each), CSR-style history / target lists. */
+int lko_iknn_score_batch(const int64_t *s_ptr, const int32_t *s_idx, const float *s_val,
+                         int64_t n_items, int64_t n_q, const int64_t *ref_ptr,
+                         const int32_t *ref_items, const float *ref_rates, const int64_t *tgt_ptr,
+                         const int32_t *tgt_items, int max_nbrs, int min_nbrs, int explicit_,
+                         float *out_scores, uint8_t *out_valid, int32_t *out_counts,
+                         int n_threads)
+{
+    int bad = 0;
+#ifdef _OPENMP
+    if (n_threads <= 0 || n_threads > LKO_MAX_THREADS) n_threads = lko_num_threads();
+#else
+    n_threads = 1;
+#endif
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads) reduction(| : bad)
+    for (int64_t b = 0; b < n_q; b++) {
+        bad |= lko_iknn_score(s_ptr, s_idx, s_val, n_items, ref_items + ref_ptr[b],
+                              explicit_ ? ref_rates + ref_ptr[b] : ref_rates,
+                              ref_ptr[b + 1] - ref_ptr[b], tgt_items + tgt_ptr[b],
+                              tgt_ptr[b + 1] - tgt_ptr[b], max_nbrs, min_nbrs, explicit_,
+                              out_scores + tgt_ptr[b], out_valid + tgt_ptr[b],
+                              out_counts + tgt_ptr[b]);
+    }
+    return bad;
+}

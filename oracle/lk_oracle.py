@@ -372,6 +372,30 @@ def argsort_descending(scores: np.ndarray) -> np.ndarray:
     return idx[order]
 
 
+def score_topn_batch(q: np.ndarray, users: np.ndarray, n: int, ex_ptr=None, ex_idx=None,
+                     n_threads: int = 0):
+    """
+    A batch of recommend queries, each the reference's per-query path (dense scores, the
+    query's own items struck out, heap top-n; ``lko_score_topn_batch``).  Returns
+    (indices int32 [B x n] padded with -1, scores f32 [B x n] padded with NaN).
+    """
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    users = np.ascontiguousarray(users, dtype=np.float32)
+    B = users.shape[0]
+    out_i = np.empty((B, n), dtype=np.int32)
+    out_s = np.empty((B, n), dtype=np.float32)
+    pp = pi = None
+    if ex_ptr is not None:
+        ex_ptr = np.ascontiguousarray(ex_ptr, dtype=np.int64)
+        ex_idx = np.ascontiguousarray(ex_idx, dtype=np.int32)
+        pp, pi = _p(ex_ptr, _i64p), _p(ex_idx, _i32p)
+    lib().lko_score_topn_batch(
+        _p(q, _f32p), ctypes.c_int64(q.shape[0]), ctypes.c_int(q.shape[1]), _p(users, _f32p),
+        ctypes.c_int64(B), pp, pi, ctypes.c_int(n), _p(out_i, _i32p), _p(out_s, _f32p),
+        ctypes.c_int(n_threads))
+    return out_i, out_s
+
+
 # --------------------------------------------------------------------------
 # item-kNN
 # --------------------------------------------------------------------------
@@ -526,6 +550,33 @@ def iknn_score(
     )  # fmt: skip
     if rc:
         raise ValueError("similarity is null")  # accum.rs:146-151
+    scores[valid == 0] = np.nan
+    return scores, counts
+
+
+def iknn_score_batch(sims: sps.csr_array, ref_ptr, ref_items, ref_rates, tgt_ptr, tgt_items,
+                     max_nbrs: int, min_nbrs: int, n_threads: int = 0):
+    "``iknn_score`` for a batch of queries given as CSR-style lists (``lko_iknn_score_batch``)."
+    sp = np.ascontiguousarray(sims.indptr, dtype=np.int64)
+    si = np.ascontiguousarray(sims.indices, dtype=np.int32)
+    sv = np.ascontiguousarray(sims.data, dtype=np.float32)
+    rp = np.ascontiguousarray(ref_ptr, dtype=np.int64)
+    ri = np.ascontiguousarray(ref_items, dtype=np.int32)
+    explicit = ref_rates is not None
+    rr = np.ascontiguousarray(ref_rates, dtype=np.float32) if explicit else None
+    tp = np.ascontiguousarray(tgt_ptr, dtype=np.int64)
+    ti = np.ascontiguousarray(tgt_items, dtype=np.int32)
+    scores = np.empty(len(ti), dtype=np.float32)
+    valid = np.empty(len(ti), dtype=np.uint8)
+    counts = np.empty(len(ti), dtype=np.int32)
+    rc = lib().lko_iknn_score_batch(
+        _p(sp, _i64p), _p(si, _i32p), _p(sv, _f32p), ctypes.c_int64(sims.shape[0]),
+        ctypes.c_int64(len(rp) - 1), _p(rp, _i64p), _p(ri, _i32p),
+        _p(rr, _f32p) if explicit else None, _p(tp, _i64p), _p(ti, _i32p),
+        ctypes.c_int(max_nbrs), ctypes.c_int(min_nbrs), ctypes.c_int(1 if explicit else 0),
+        _p(scores, _f32p), _p(valid, _u8p), _p(counts, _i32p), ctypes.c_int(n_threads))
+    if rc:
+        raise ValueError("similarity is null")
     scores[valid == 0] = np.nan
     return scores, counts
 

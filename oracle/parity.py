@@ -58,7 +58,14 @@ def als_half_accounting(got: np.ndarray, want: np.ndarray, exact: np.ndarray | N
     """
     ``got``: GPU rows, ``want``: oracle (reference arithmetic) rows, ``exact``: float64 referee
     rows, ``cond``: per-row condition estimates -- all for the same half-epoch from the same
-    inputs.  Returns the accounting dict; ``ok`` is the asserted claim.
+    inputs.  Returns the accounting dict.
+
+    ``ok`` is the RAW north-star criterion and nothing else: no row further than 1e-4 (relative)
+    from the oracle's row.  Rows that fail it are listed in ``exceptions`` with their condition
+    number and all three distances (GPU-oracle, GPU-float64, oracle-float64).  ``accounted`` is
+    the separate, weaker statement used where the data cannot meet the raw criterion
+    (ml-latest-small, a first epoch from the tiny init: cond 1e3 ... 1e6): every row over 1e-4 is
+    explained by its conditioning or by the reference arithmetic's own distance from float64.
     """
     e_go = _row_rel(got, want)
     over = e_go > RTOL
@@ -70,6 +77,7 @@ def als_half_accounting(got: np.ndarray, want: np.ndarray, exact: np.ndarray | N
         "row_rel_p999": float(np.quantile(e_go, 0.999)) if len(e_go) else 0.0,
         "rows_over_1e-4": int(over.sum()),
     }
+    res["ok"] = bool(not over.any())
     ok = True
     if exact is not None:
         res["rel_gpu_vs_f64"] = _rel(got, exact)
@@ -92,7 +100,7 @@ def als_half_accounting(got: np.ndarray, want: np.ndarray, exact: np.ndarray | N
             mine = over & decidable & (e_gx > 0.5 * RTOL)
             res["decidable_rows_over_1e-4_gpu_side"] = int(mine.sum())
             ok &= not mine.any()
-            res["rows_over_detail"] = [
+            res["exceptions"] = [
                 {"row": int(r), "cond": float(cond[r]), "gpu_vs_oracle": float(e_go[r]),
                  "gpu_vs_f64": float(e_gx[r]), "oracle_vs_f64": float(e_ox[r])}
                 for r in np.flatnonzero(over)[:10]]
@@ -124,7 +132,7 @@ def als_half_accounting(got: np.ndarray, want: np.ndarray, exact: np.ndarray | N
             viol = e_g[nzc] > NORM_BOUND * cu[nzc] + FLOOR
             res["rows_beyond_forward_bound"] = int(viol.sum())
             ok &= not viol.any()
-    res["ok"] = bool(ok)
+    res["accounted"] = bool(ok)
     return res
 
 

@@ -51,22 +51,46 @@ def test_als_implicit_toml_trains_like_the_reference(gpu, oracle, ml_small, ml_d
     # SAME factors: history lookup, candidates minus history, fold-in, scores, top-N
     csr = sps.csr_array(ind)
     Q, OtOr = scorer.item_embeddings, scorer._OtOr
-    same = 0
+    from lkpy_amd.data import ItemList as _IL
+
     users = ml_small["user_ids"][::29]
+    same_cpu_foldin, near_ties, fold_err = 0, 0, 0.0
     for uid in users:
         recs = pipe.run("recommender", query=int(uid), n=10)
         assert len(recs) == 10 and recs.ordered
         u = int(np.searchsorted(ml_small["user_ids"], uid))
         hist = csr.indices[csr.indptr[u] : csr.indptr[u + 1]]
-        x = oracle.als_fold_in(hist, np.full(len(hist), 40.0, np.float32), Q, OtOr)
-        s = oracle.score_dense(Q, x.astype(np.float32))
-        s[hist] = np.nan
-        top = oracle.argtopn(s, 10)
         got = recs.numbers(vocabulary=scorer.items)
         assert not np.isin(got, hist).any()
-        assert np.allclose(recs.scores(), s[got], rtol=2e-4, atol=2e-5)
-        same += int(np.array_equal(got, top))
-    assert same >= 0.9 * len(users)  # fold-in differs at ~1e-6: only near-ties may swap
+        # (1) index sets BIT-EXACT: from the SAME query vector (the GPU's fold-in) the reference's
+        # scoring + candidate exclusion + heap top-N give exactly the GPU's list and score bits
+        x_gpu, _ = scorer.new_user_embedding(None, _IL(item_nums=hist, vocabulary=scorer.items))
+        s = oracle.score_dense(Q, x_gpu.astype(np.float32))
+        s[hist] = np.nan
+        top = oracle.argtopn(s, 10)
+        assert np.array_equal(got, top), (int(uid), got, top)
+        assert np.array_equal(np.asarray(recs.scores(), np.float32).view(np.uint32),
+                              s[top].view(np.uint32))
+        # (2) the fold-in vector itself vs the reference's _train_new_row restatement: this
+        # system is ill-conditioned on ml-latest-small (cond 1e3..2e5, test_gpu_als_reference.py)
+        x_cpu = oracle.als_fold_in(hist, np.full(len(hist), 40.0, np.float32), Q, OtOr)
+        fold_err = max(fold_err, _rel(x_gpu, x_cpu))
+        # (3) with the CPU fold-in vector instead, lists may differ only at NEAR-TIES: wherever
+        # they differ, the two scores involved are closer than the fold-in difference explains
+        s2 = oracle.score_dense(Q, x_cpu.astype(np.float32))
+        s2[hist] = np.nan
+        top2 = oracle.argtopn(s2, 10)
+        if np.array_equal(got, top2):
+            same_cpu_foldin += 1
+        else:
+            d = got != top2
+            gap = np.abs(s2[got[d]] - s2[top2[d]]) / np.maximum(np.abs(s2[top2[d]]), 1e-12)
+            assert gap.max() < 1e-3, (int(uid), gap)
+            near_ties += 1
+    print(f"\nrecommend parity over {len(users)} users: lists bit-identical given the same query "
+          f"vector: {len(users)}/{len(users)}; with the CPU fold-in vector: {same_cpu_foldin} "
+          f"identical, {near_ties} differ at near-ties only; fold-in rel err max {fold_err:.2e}")
+    assert fold_err < 5e-3
 
     # NaN semantics (tests/models/test_als_implicit.py:277-298, _common.py:145-170)
     from lkpy_amd.data import ItemList
@@ -286,3 +310,32 @@ def test_als_explicit_toml_trains_like_the_reference(gpu, oracle, ml_small, ml_d
     clone = pickle.loads(pickle.dumps(pipe))
     r2 = clone.run("scorer", query=uid, items=items)
     assert np.allclose(stored, r2.scores(), atol=1e-3)
+
+
+def test_repeated_pairs_are_summed_like_the_reference(gpu):
+    """``prepare_matrix`` sums repeated (user, item) pairs as the reference's
+    COO -> CSR conversion does; a dataset with a pair split in two trains to the same factors
+    as the dataset holding the summed rating once."""
+    from lkpy_amd.als import ImplicitMFScorer
+    from lkpy_amd.data import Dataset
+    from lkpy_amd.training import TrainingOptions
+
+    rng = np.random.default_rng(5)
+    u = rng.integers(0, 200, 6000)
+    i = rng.integers(0, 300, 6000)
+    key = np.unique(u * 1000 + i)
+    u, i = key // 1000, key % 1000
+    r = rng.integers(1, 6, len(u)).astype(np.float32)
+    # split the first 500 pairs into two interactions carrying half the rating each
+    u2, i2 = np.concatenate([u, u[:500]]), np.concatenate([i, i[:500]])
+    r2 = np.concatenate([r, r[:500] / 2])
+    r2[:500] /= 2
+    all_items = np.arange(300)
+    a = ImplicitMFScorer(features=16, epochs=3, use_ratings=True)
+    a.train(Dataset.from_arrays(u, i, r, all_item_ids=all_items), TrainingOptions(rng=7))
+    b = ImplicitMFScorer(features=16, epochs=3, use_ratings=True)
+    dsb = Dataset.from_arrays(u2, i2, r2, all_item_ids=all_items)
+    assert dsb.has_duplicates
+    b.train(dsb, TrainingOptions(rng=7))
+    assert np.array_equal(a.item_embeddings, b.item_embeddings)
+    assert np.array_equal(a.user_embeddings, b.user_embeddings)

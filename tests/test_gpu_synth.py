@@ -61,4 +61,4 @@ def test_engine_on_device_resident_matrix(gpu, oracle):
         exact, cond = oracle.als_referee_f64(mat, other, 0.1)
         acc = parity.als_half_accounting(got, want, exact, cond)
         print({k_: v for k_, v in acc.items() if k_ != "by_cond_decade"})
-        assert acc["ok"], acc
+        assert acc["accounted"], acc

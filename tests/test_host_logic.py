@@ -280,3 +280,44 @@ def test_user_knn_component_constructs_and_validates():
     assert UserKNNConfig(min_sim=1e-320).min_sim >= float(np.finfo(np.float64).smallest_normal)
     with pytest.raises(Exception):
         UserKNNConfig(bogus=1)
+
+
+def test_legacy_pickle_state_is_migrated():
+    """Scorers pickled before the learned arrays became lazily-synchronised descriptors keep them
+    under their plain names; ``__setstate__`` moves them to the descriptor slots."""
+    import pickle
+
+    from lkpy_amd.als import BiasedMFScorer, ImplicitMFScorer
+    from lkpy_amd.data import Vocabulary
+
+    sc = ImplicitMFScorer(features=4)
+    legacy = dict(sc.__getstate__())
+    for k_ in ("_h_user_embeddings", "_h_item_embeddings", "_h__OtOr"):
+        legacy.pop(k_, None)
+    legacy.update(user_embeddings=np.ones((3, 4), np.float32),
+                  item_embeddings=np.full((5, 4), 2.0, np.float32),
+                  _OtOr=np.eye(4, dtype=np.float32), items=Vocabulary(np.arange(5), "item"))
+    new = ImplicitMFScorer.__new__(ImplicitMFScorer)
+    new.__setstate__(legacy)
+    assert new.user_embeddings.shape == (3, 4) and new.item_embeddings[0, 0] == 2.0
+    assert np.array_equal(new._OtOr, np.eye(4, dtype=np.float32))
+    # and the current format still round-trips
+    again = pickle.loads(pickle.dumps(new))
+    assert np.array_equal(again.item_embeddings, new.item_embeddings)
+    b = BiasedMFScorer.__new__(BiasedMFScorer)
+    b.__setstate__({"config": BiasedMFScorer(features=4).config,
+                    "user_embeddings": None, "item_embeddings": np.zeros((2, 4), np.float32)})
+    assert b.user_embeddings is None and b.item_embeddings.shape == (2, 4)
+
+
+def test_dataset_reports_repeated_pairs():
+    "ADVICE r2: repeated (user, item) pairs must reach the kernels as ONE summed entry"
+    from lkpy_amd.data import Dataset
+
+    ds = Dataset.from_arrays([1, 1, 2, 1], [10, 11, 10, 10], [1.0, 2.0, 3.0, 4.0])
+    assert ds.has_duplicates
+    assert not Dataset.from_arrays([1, 1, 2], [10, 11, 10], [1.0, 2.0, 3.0]).has_duplicates
+    m = ds.interactions().matrix().scipy(attribute="rating", layout="csr")
+    m = m.copy()
+    m.sum_duplicates()
+    assert m.nnz == 3 and m[0, 0] == 5.0

@@ -394,12 +394,15 @@ def test_parity_accounting_attributes_gaps():
     cond = np.full(100, 80.0)
     a = parity.als_half_accounting(got, want, exact, cond)
     assert a["rows_over_1e-4"] == 1 and a["decidable_rows_over_1e-4"] == 1
-    assert a["decidable_rows_over_1e-4_gpu_side"] == 0 and a["ok"]
-    assert a["rows_over_detail"][0]["row"] == 3
+    assert a["decidable_rows_over_1e-4_gpu_side"] == 0 and a["accounted"]
+    assert not a["ok"]  # the raw criterion (no row over 1e-4) is reported as it is
+    assert a["exceptions"][0]["row"] == 3
     got2 = got.copy()
     got2[5] *= 1 + 2e-4  # now the GPU is the one that is off
     b = parity.als_half_accounting(got2, exact.astype(np.float32), exact, cond)
-    assert b["decidable_rows_over_1e-4_gpu_side"] == 1 and not b["ok"]
+    assert b["decidable_rows_over_1e-4_gpu_side"] == 1 and not b["accounted"] and not b["ok"]
     # without a referee the old, stricter rule applies
     c = parity.als_half_accounting(got, want, None, cond)
-    assert not c["ok"]
+    assert not c["accounted"] and not c["ok"]
+    d = parity.als_half_accounting(got, exact.astype(np.float32), exact, cond)
+    assert d["ok"] and d["accounted"] and d["rows_over_1e-4"] == 0
