@@ -142,6 +142,21 @@ int lk_als_plan_set_ctl(lk_als_plan *plan, lk_task_ctl *ctl);
 int64_t lk_als_plan_short_rows(const lk_als_plan *plan);
 int64_t lk_als_plan_woodbury_rows(const lk_als_plan *plan); /* rows with <= 64 entries */
 int lk_als_plan_set_z(lk_als_plan *plan, const float *d_z);
+/* The same path with NOTHING computed on the caller's side: hand the plan a device buffer of
+ * n_cols x lk_padded_dim(k) floats and every lk_als_implicit_half_epoch run with it forms Z
+ * itself on the launch stream -- OtOr^-1 to float64 accuracy by an in-register sweep + two
+ * Newton-Schulz steps (csrc/spd_inverse.hip), then Z = other * OtOr^-1 on the scoring GEMM.  If
+ * OtOr turns out not to be positive definite (reg = 0 with rank-deficient factors) the decision
+ * is taken ON THE DEVICE: the Woodbury kernels stand down and a dense fallback launch solves
+ * their rows exactly as `sposv` would (and reports a row whose own matrix is not positive
+ * definite the same way).  No library call, no host synchronisation.  NULL detaches the buffer. */
+int lk_als_plan_set_z_workspace(lk_als_plan *plan, float *d_zbuf);
+/* OtOr^-1 alone (diagnostics / tests): d_out [KP x KP] floats zero padded, *d_flag = 0 or != 0
+ * when d_a is not positive definite, d_ws lk_spd_inverse_workspace_bytes(k) bytes; padded
+ * k = 128 / 256 only. */
+size_t lk_spd_inverse_workspace_bytes(int32_t k);
+int lk_spd_inverse(const float *d_a, int32_t lda, int32_t k, float *d_out, int32_t *d_flag,
+                   void *d_ws, void *stream);
 
 int lk_als_implicit_half_epoch(const lk_als_plan *plan, const void *d_indptr,
                                const int32_t *d_indices, const float *d_values, int64_t n_rows,

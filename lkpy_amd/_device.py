@@ -256,21 +256,14 @@ class ALSPlan:
         csr = self.csr
         assert this.shape == (csr.shape[0], self.kp) and other.shape == (csr.shape[1], self.kp)
         assert this.is_contiguous() and other.is_contiguous() and otor.is_contiguous()
-        if self.use_wb:
-            # OtOr^-1 once per half-epoch in float64 (k x k: a library inverse, plumbing), then
-            # Z = other @ OtOr^-1 on the scoring GEMM of this library (f32 MFMA, k-ordered)
-            k, kp = self.k, self.kp
-            chol, info = torch.linalg.cholesky_ex(otor[:k, :k].to(torch.float64))
-            if int(info.item()) == 0:
-                ginv = torch.zeros((kp, kp), dtype=torch.float32, device=other.device)
-                ginv[:k, :k] = torch.cholesky_inverse(chol).to(torch.float32)
-                self._z = score_dense(other, ginv, k)  # [n_cols x KP]; row i of ginv = column i
-                z_ptr = _ptr(self._z)
-            else:
-                # OtOr itself is not positive definite (reg = 0 with rank-deficient factors):
-                # the rows' own matrices may still be -- every row takes the dense solve
-                self._z, z_ptr = None, None
-            check(_native.load().lk_als_plan_set_z(self._h, z_ptr), "lk_als_plan_set_z")
+        if self.use_wb and self._z is None:
+            # the library forms Z = other @ OtOr^-1 itself at every half-epoch (OtOr^-1 to float64
+            # accuracy on the device, csrc/spd_inverse.hip; Z on the scoring GEMM): this side only
+            # lends it the [n_cols x KP] buffer -- no library factorisation, no host round trip
+            self._z = torch.empty((csr.shape[1], self.kp), dtype=torch.float32,
+                                  device=other.device)
+            check(_native.load().lk_als_plan_set_z_workspace(self._h, _ptr(self._z)),
+                  "lk_als_plan_set_z_workspace")
         check(
             _native.load().lk_als_implicit_half_epoch(
                 self._h, _ptr(csr.indptr), _ptr(csr.indices), _ptr(csr.values),

@@ -474,7 +474,7 @@ __device__ __forceinline__ void als_blk_solve_body(
     const int32_t *__restrict__ row_slab, const float *__restrict__ other,
     float *__restrict__ this_, const float *__restrict__ notor_p,
     const float *__restrict__ slabs, float *__restrict__ row_delta, int *__restrict__ status,
-    int k, float reg, TaskCtlDev ctl, float *lds)
+    int k, float reg, TaskCtlDev ctl, float *lds, const int64_t t)
 {
     using C = Cfg<NT>;
     constexpr int KP = C::KP, NL = C::NL;
@@ -484,7 +484,6 @@ __device__ __forceinline__ void als_blk_solve_body(
     const int wr = wave & 1, wc = wave >> 1;
     const int sub = lane & 15, slot = lane >> 4;
     const bool phantom = wr > wc;
-    const int64_t t = blockIdx.x;
     if (t >= n_rows) return;
     if constexpr (CTL) {  // AccelTask.cancel: rows not started yet are skipped
         // one decision per WORKGROUP (the waves meet at barriers later: they must agree)
@@ -617,12 +616,36 @@ __device__ __forceinline__ void als_blk_solve_body(
         __shared__ __attribute__((aligned(16))) float lds[Cfg<NTV>::LDS_FLOATS];                \
         als_blk_solve_body<NTV, IS64, EXPL, CTL>(indptr, indices, values, order, n_rows,        \
                                                  row_slab, other, this_, notor_p, slabs,        \
-                                                 row_delta, status, k, reg, ctl, lds);          \
+                                                 row_delta, status, k, reg, ctl, lds,           \
+                                                 (int64_t)blockIdx.x);                          \
     }
 
 LK_BLK_KERNEL(als_blk_solve_kernel16, 16, LK_ALS_BLK_ATTR16)
 LK_BLK_KERNEL(als_blk_solve_kernel8, 8, LK_ALS_BLK_ATTR8)
 #undef LK_BLK_KERNEL
+
+// Dense solve of the rows [t_begin, t_end) of the plan order IF status[1] != 0, i.e. when the
+// Woodbury kernels that normally take them had to stand down because OtOr^-1 does not exist
+// (spd_inverse.hip set the flag ON THE DEVICE: no host round trip decides this).  A small fixed
+// grid that strides over the rows: with the flag clear -- always, unless reg = 0 meets
+// rank-deficient factors -- every workgroup returns after one scalar load.
+template <int NT, bool IS64>
+__global__ __launch_bounds__(256) void als_blk_fallback_kernel(
+    const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ values, const int32_t *__restrict__ order, int64_t t_begin,
+    int64_t t_end, const int32_t *__restrict__ row_slab, const float *__restrict__ other,
+    float *__restrict__ this_, const float *__restrict__ notor_p, const float *__restrict__ slabs,
+    float *__restrict__ row_delta, int *__restrict__ status, int k)
+{
+    __shared__ __attribute__((aligned(16))) float lds[Cfg<NT>::LDS_FLOATS];
+    if (status[1] == 0) return;
+    for (int64_t t = t_begin + blockIdx.x; t < t_end; t += gridDim.x) {
+        als_blk_solve_body<NT, IS64, false, false>(indptr, indices, values, order, t_end, row_slab,
+                                                   other, this_, notor_p, slabs, row_delta,
+                                                   status, k, 0.f, TaskCtlDev{}, lds, t);
+        __syncthreads();
+    }
+}
 
 // -OtOr [k x k] -> primed [KP x KP] of this file's feature order, -1 on the pad diagonal
 template <int NT>
@@ -652,9 +675,9 @@ static bool als_wb64_enabled()
 
 template <int NT, bool IS64, bool EXPL>
 static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *indices,
-                      const float *values, int64_t n_rows, int k, float *this_, const float *other,
-                      const float *otor, int ld_otor, char *ws, float *out_frob, hipStream_t st,
-                      float reg)
+                      const float *values, int64_t n_rows, int64_t n_cols, int k, float *this_,
+                      const float *other, const float *otor, int ld_otor, char *ws,
+                      float *out_frob, hipStream_t st, float reg)
 {
     using C = Cfg<NT>;
     using IT = typename IndPtr<IS64>::type;
@@ -681,19 +704,38 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     // short rows (<= 16 entries) of the implicit model: Woodbury kernel, when the caller
     // supplied Z = other * OtOr^-1 for this half-epoch (never with a task-control block: the
     // kernel does not poll it)
-    const bool use_wb = !EXPL && p->d_z != nullptr && !p->ctl && p->t_short < n_rows;
+    const float *z = p->d_z;
+    const bool own_z = !EXPL && p->d_zbuf != nullptr && !p->ctl && p->t_short < n_rows &&
+                       n_cols > 0;
+    if (own_z) {
+        // Z = other * OtOr^-1 for this half-epoch, all on this stream: the inverse to float64
+        // accuracy (spd_inverse.hip; status[1] = its flag, tested by the Woodbury kernels and by
+        // the fallback launch below), then one scoring GEMM (k-ordered f32 MFMA, topk.hip)
+        float *ginv = reinterpret_cast<float *>(ws + p->off_ginv);
+        int rc = spd_inverse(otor, ld_otor, k, C::KP, ginv, status + 1, ws + p->off_invws, st);
+        if (rc != LK_OK) return rc;
+        rc = lk_score_dense(other, C::KP, n_cols, ginv, C::KP, C::KP, k, p->d_zbuf, C::KP, st);
+        if (rc != LK_OK) return rc;
+        z = p->d_zbuf;
+    }
+    const bool use_wb = !EXPL && z != nullptr && !p->ctl && p->t_short < n_rows;
     // (17 .. 64 entries: only at padded k = 256 -- at k = 128 the 64 x 64 system costs as much as
     // the dense solve of this file, measured on the ML-25M shape)
     const int64_t n_dense =
         use_wb ? ((NT == 16 && als_wb64_enabled()) ? p->t_mid : p->t_short) : n_rows;
     if (use_wb) {
         int rc = als_wb_launch(p, indptr, IS64 ? 1 : 0, indices, values, p->t_short, n_rows,
-                               this_, other, p->d_z, row_delta, status, st);
+                               this_, other, z, row_delta, status, st);
         if (rc != LK_OK) return rc;
         // rows with 17 .. 64 entries: the same identity with a 64 x 64 system
         rc = als_wb64_launch(p, indptr, IS64 ? 1 : 0, indices, values, n_dense, p->t_short,
-                             this_, other, p->d_z, row_delta, status, st);
+                             this_, other, z, row_delta, status, st);
         if (rc != LK_OK) return rc;
+        if (own_z)  // no-op unless spd_inverse raised its flag
+            hipLaunchKernelGGL((als_blk_fallback_kernel<NT, IS64>), dim3(1024), dim3(256), 0, st,
+                               static_cast<const IT *>(indptr), indices, values, p->d_order,
+                               n_dense, n_rows, p->d_row_slab, other, this_, notor_p, slabs,
+                               row_delta, status, k);
     }
     if (n_dense > 0) {
         const dim3 grid((unsigned)n_dense), block(256);
@@ -735,28 +777,22 @@ size_t als_blk_slab_floats(int NT)
 // Exact half-epoch for KP = 128 / 256 (dispatch target of lk_als_implicit_half_epoch /
 // lk_als_explicit_half_epoch); `otor` null = explicit model.
 int als_blk_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
-                       const float *values, int64_t n_rows, int k, float *this_, const float *other,
-                       const float *otor, int ld_otor, char *ws, float *out_frob, hipStream_t st,
-                       bool expl, float reg)
+                       const float *values, int64_t n_rows, int64_t n_cols, int k, float *this_,
+                       const float *other, const float *otor, int ld_otor, char *ws,
+                       float *out_frob, hipStream_t st, bool expl, float reg)
 {
+#define LK_BLK_ARGS p, indptr, indices, values, n_rows, n_cols, k, this_, other, otor, ld_otor, ws, out_frob, st, reg
 #define LK_BLK_CASE(NTV)                                                                      \
     do {                                                                                      \
         if (expl)                                                                             \
-            return is64 ? blk::launch_blk<NTV, true, true>(p, indptr, indices, values, n_rows, \
-                                                           k, this_, other, otor, ld_otor, ws, \
-                                                           out_frob, st, reg)                 \
-                        : blk::launch_blk<NTV, false, true>(p, indptr, indices, values, n_rows, \
-                                                            k, this_, other, otor, ld_otor,   \
-                                                            ws, out_frob, st, reg);           \
-        return is64 ? blk::launch_blk<NTV, true, false>(p, indptr, indices, values, n_rows, k, \
-                                                        this_, other, otor, ld_otor, ws,      \
-                                                        out_frob, st, reg)                    \
-                    : blk::launch_blk<NTV, false, false>(p, indptr, indices, values, n_rows,  \
-                                                         k, this_, other, otor, ld_otor, ws,  \
-                                                         out_frob, st, reg);                  \
+            return is64 ? blk::launch_blk<NTV, true, true>(LK_BLK_ARGS)                       \
+                        : blk::launch_blk<NTV, false, true>(LK_BLK_ARGS);                     \
+        return is64 ? blk::launch_blk<NTV, true, false>(LK_BLK_ARGS)                          \
+                    : blk::launch_blk<NTV, false, false>(LK_BLK_ARGS);                        \
     } while (0)
     if (p->KP == 256) LK_BLK_CASE(16);
     if (p->KP == 128) LK_BLK_CASE(8);
+#undef LK_BLK_ARGS
 #undef LK_BLK_CASE
     set_error("blocked Cholesky: unsupported padded embedding size %d", p->KP);
     return LK_E_INVALID;

@@ -1122,6 +1122,7 @@ __global__ __launch_bounds__(256) void als_wb64_kernel(
     const int s = lane >> 4, c = lane & 15;
     const int64_t task = (int64_t)blockIdx.x * 4 + wave;
     if (task >= n_tasks) return;
+    if (status[1] != 0) return;  // Z unavailable (OtOr not positive definite): dense fallback
     const int row = order[task];
     const int64_t beg = indptr[row], end = indptr[row + 1];
     const int n = (int)(end - beg);  // 17 .. 64 (any 1 .. 64 is handled)
@@ -1544,6 +1545,12 @@ extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int i
     size_t slab_f = KP > 64 ? lk::als_blk_slab_floats(p->NT)
                             : (size_t)(lk::als_tiles(p->NT) * 4 + p->NT) * 64;
     off += lk::align_up((size_t)std::max<int64_t>(p->n_chunks, 1) * slab_f * sizeof(float), 256);
+    if (KP > 64) {  // OtOr^-1 for the Woodbury rows (lk_als_plan_set_z_workspace)
+        p->off_ginv = off;
+        off += lk::align_up((size_t)KP * KP * sizeof(float), 256);
+        p->off_invws = off;
+        off += lk::align_up(lk::spd_inverse_workspace_bytes(KP), 256);
+    }
     p->ws_bytes = off;
     *out = p;
     return LK_OK;
@@ -1621,6 +1628,16 @@ extern "C" int lk_als_plan_set_z(lk_als_plan *p, const float *d_z)
     return LK_OK;
 }
 
+extern "C" int lk_als_plan_set_z_workspace(lk_als_plan *p, float *d_zbuf)
+{
+    LK_REQUIRE(p != nullptr, "lk_als_plan_set_z_workspace: null plan");
+    LK_REQUIRE(d_zbuf == nullptr || p->KP > 64,
+               "lk_als_plan_set_z_workspace: the Woodbury kernels serve padded k = 128 / 256 only");
+    p->d_zbuf = d_zbuf;
+    if (d_zbuf) p->d_z = nullptr;
+    return LK_OK;
+}
+
 extern "C" int lk_als_plan_set_cg(lk_als_plan *p, float tol, int32_t max_iter)
 {
     LK_REQUIRE(p != nullptr, "lk_als_plan_set_cg: null plan");
@@ -1656,9 +1673,9 @@ extern "C" int lk_als_implicit_half_epoch(const lk_als_plan *plan, const void *d
                                      d_this, ld_this, d_other, ld_other, d_otor, ld_otor, ws,
                                      d_out_frob, st);
     if (plan->KP > 64)
-        return lk::als_blk_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows, k,
-                                      d_this, d_other, d_otor, ld_otor, ws, d_out_frob, st, false,
-                                      0.f);
+        return lk::als_blk_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows,
+                                      n_cols, k, d_this, d_other, d_otor, ld_otor, ws, d_out_frob,
+                                      st, false, 0.f);
 #define LK_CHOL_CASE(NT)                                                                        \
     return plan->is64 ? lk::launch_chol<NT, true>(plan, d_indptr, d_indices, d_values, n_rows, \
                                                   k, d_this, ld_this, d_other, ld_other,       \
@@ -1701,8 +1718,9 @@ extern "C" int lk_als_explicit_half_epoch(const lk_als_plan *plan, const void *d
     hipStream_t st = lk::as_stream(stream);
     char *ws = static_cast<char *>(d_ws);
     if (plan->KP > 64)
-        return lk::als_blk_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows, k,
-                                      d_this, d_other, nullptr, 0, ws, d_out_frob, st, true, reg);
+        return lk::als_blk_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows,
+                                      n_cols, k, d_this, d_other, nullptr, 0, ws, d_out_frob, st,
+                                      true, reg);
 #define LK_CHOL_CASE(NT)                                                                         \
     return plan->is64                                                                            \
                ? lk::launch_chol<NT, true, true>(plan, d_indptr, d_indices, d_values, n_rows, k, \

@@ -25,6 +25,10 @@ struct lk_als_plan {
     int64_t t_short = 0;
     int64_t t_mid = 0;  // rows with 17 .. 64 entries are [t_mid, t_short): als_wb64_kernel
     mutable const float *d_z = nullptr;
+    // ... or a caller-owned [n_cols x KP] buffer the LIBRARY fills with Z at every implicit
+    // half-epoch (lk_als_plan_set_z_workspace): OtOr^-1 by spd_inverse.hip, Z by the scoring GEMM
+    float *d_zbuf = nullptr;
+    size_t off_ginv = 0, off_invws = 0;  // [KP x KP] float inverse, spd_inverse scratch
     // device-side schedule
     int32_t *d_order = nullptr;      // [n_rows] rows, longest first
     int32_t *d_row_slab = nullptr;   // [n_rows] first slab of the row or -1
@@ -49,19 +53,26 @@ namespace lk {
 // exact half-epoch for padded k = 128 / 256: one workgroup per row (als_blk.hip)
 size_t als_blk_slab_floats(int NT);
 int als_blk_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
-                       const float *values, int64_t n_rows, int k, float *this_, const float *other,
-                       const float *otor, int ld_otor, char *ws, float *out_frob, hipStream_t st,
-                       bool expl, float reg);
+                       const float *values, int64_t n_rows, int64_t n_cols, int k, float *this_,
+                       const float *other, const float *otor, int ld_otor, char *ws,
+                       float *out_frob, hipStream_t st, bool expl, float reg);
 // rows [t0, n_rows) of the plan order (<= 16 entries each) through the Woodbury kernel (als_wb.hip)
 int als_wb_launch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
                   const float *values, int64_t t0, int64_t n_rows, float *this_,
                   const float *other, const float *z, float *row_delta, int *status,
                   hipStream_t st);
+// (both Woodbury kernels return at once when status[1] != 0: Z is not available -- OtOr was not
+// positive definite -- and the dense fallback launch of als_blk.hip solves their rows)
 // rows [t0, t1) of the plan order (17 .. 64 entries each), als_wb64_kernel (als_chol.hip)
 int als_wb64_launch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
                     const float *values, int64_t t0, int64_t t1, float *this_,
                     const float *other, const float *z, float *row_delta, int *status,
                     hipStream_t st);
+// out[KP x KP] = a[k x k]^-1 (float64 accuracy, zero padded), *flag != 0 when a is not positive
+// definite (spd_inverse.hip); ws: spd_inverse_workspace_bytes(KP)
+size_t spd_inverse_workspace_bytes(int KP);
+int spd_inverse(const float *a, int lda, int k, int KP, float *out, int *flag, void *ws,
+                hipStream_t st);
 // deterministic two-stage sum of the per-row squared deltas -> sqrt (als_chol.hip)
 int launch_delta_reduce(const float *row_delta, int64_t n_rows, float *partial, float *out_frob,
                         hipStream_t st);

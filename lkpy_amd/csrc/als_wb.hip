@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void als_wb_kernel(
     const int s = lane >> 4, c = lane & 15;
     const int64_t t = (int64_t)blockIdx.x * 4 + wave;
     if (t >= n_tasks) return;
+    if (status[1] != 0) return;  // Z unavailable (OtOr not positive definite): dense fallback
     const int row = order[t];
     const int64_t beg = indptr[row], end = indptr[row + 1];
     const int n = __builtin_amdgcn_readfirstlane((int)(end - beg));  // 0 .. 16, wave-uniform

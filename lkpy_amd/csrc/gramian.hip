@@ -24,6 +24,7 @@
 namespace lk {
 
 constexpr int GRAM_WAVES = 4;
+constexpr int GRAM_SEG = 256;  // row groups (of 4 rows) per f32 MFMA chain, see gram_wave
 
 __host__ __device__ constexpr int gram_tiles(int NT) { return NT * (NT + 1) / 2; }
 
@@ -74,9 +75,18 @@ __device__ __forceinline__ void gram_wave(const float *__restrict__ m, int64_t r
     const int lane = lane_id();
     const int sub = lane & 15, slot = lane >> 4;
 
-    f32x4 acc[NLOC > 0 ? NLOC : 1];
+    // Two-level sum: `acc` is the f32 MFMA chain of at most GRAM_SEG row groups (4 rows each);
+    // it is folded into `tot` and restarted every GRAM_SEG groups.  A single chain over the
+    // 78 000 rows a block used to take at n = 10^7 is ~sqrt(19 500) roundings deep (relative
+    // error ~8e-6 -- times cond(A) ~ 250 that alone put ALS rows 1e-4 from float64 at cfg5);
+    // chains of 256 steps + a short sum of chains stay at ~20 roundings.  Fixed order, so still
+    // bit-reproducible.
+    f32x4 acc[NLOC > 0 ? NLOC : 1], tot[NLOC > 0 ? NLOC : 1];
 #pragma unroll
-    for (int l = 0; l < NLOC; ++l) acc[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < NLOC; ++l) {
+        acc[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tot[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     constexpr int PF = (NT >= 8) ? 2 : 4;  // groups in flight
     QVec<NT> qn[PF];
@@ -109,7 +119,16 @@ __device__ __forceinline__ void gram_wave(const float *__restrict__ m, int64_t r
                 acc[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.v[ti], q.v[tj], acc[l], 0, 0, 0);
             }
         }
+        if (((g0 + PF) & (GRAM_SEG - 1)) == 0) {  // wave-uniform; PF divides GRAM_SEG
+#pragma unroll
+            for (int l = 0; l < NLOC; ++l) {
+                tot[l] += acc[l];
+                acc[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
     }
+#pragma unroll
+    for (int l = 0; l < NLOC; ++l) acc[l] += tot[l];
     // D[i = slot*4 + r][j = sub]  ->  slab[(ti*16 + i) * KP + tj*16 + j]
 #pragma unroll
     for (int l = 0; l < NLOC; ++l) {
@@ -152,27 +171,29 @@ __global__ __launch_bounds__(256) void gramian_finish_kernel(const float *__rest
                                                              float *__restrict__ out, int ld_out)
 {
     constexpr int KP = NT * 16;
-    __shared__ float part[4][64];
+    __shared__ double part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + lane;
     const int pr = idx / KP, pc = idx % KP;
     const int ti = pr >> 4, tj = pc >> 4;
-    float s = 0.f;
+    double sd = 0.0;
     if (ti <= tj) {  // lower tiles are never written by the partial kernel
+        // the slabs are summed in float64 (up to 512 of them: a float32 sum would add another
+        // ~sqrt(512 / 8) roundings on top of the chains'); one rounding to float32 at the end
         const float *src = ws + idx;
-        float s0 = 0.f, s1 = 0.f;
+        double s0 = 0.0, s1 = 0.0;
         int b = wave;
         for (; b + 4 < nblocks; b += 8) {
-            s0 += src[(size_t)b * KP * KP];
-            s1 += src[(size_t)(b + 4) * KP * KP];
+            s0 += (double)src[(size_t)b * KP * KP];
+            s1 += (double)src[(size_t)(b + 4) * KP * KP];
         }
-        if (b < nblocks) s0 += src[(size_t)b * KP * KP];
-        s = s0 + s1;
+        if (b < nblocks) s0 += (double)src[(size_t)b * KP * KP];
+        sd = s0 + s1;
     }
-    part[wave][lane] = s;
+    part[wave][lane] = sd;
     __syncthreads();
     if (wave != 0 || ti > tj) return;
-    s = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    float s = (float)(((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
     const int fr = (pr & 15) * NT + ti, fc = (pc & 15) * NT + tj;
     if (fr >= k || fc >= k) return;
     // within a diagonal tile both (fr,fc) and (fc,fr) are present and bitwise equal
@@ -185,9 +206,10 @@ __global__ __launch_bounds__(256) void gramian_finish_kernel(const float *__rest
 
 static int gram_blocks(int64_t n, int KP)
 {
-    // enough blocks to fill 256 CUs, fewer slabs for wide k (slab = KP*KP*4 bytes)
-    int64_t maxb = (KP >= 256) ? 128 : 256;
-    int64_t b = (n + 63) / 64;  // at least 64 rows (16 groups) per block
+    // enough blocks to fill 256 CUs twice over (the workspace holds 512 slabs of KP*KP floats)
+    (void)KP;
+    int64_t maxb = 512;
+    int64_t b = (n + 255) / 256;  // at least 256 rows (64 groups) per block
     if (b > maxb) b = maxb;
     if (b < 1) b = 1;
     return (int)b;
@@ -199,8 +221,10 @@ static int launch_gramian(const float *m, int64_t n, int k, int ld, float reg, f
 {
     constexpr int KP = NT * 16;
     int nb = gram_blocks(n, KP);
-    int64_t rpb = ((n + nb - 1) / nb + 3) / 4 * 4;
-    if (rpb < 4) rpb = 4;
+    // rows per block: a multiple of 4 * PF groups so that every block's chains break at the
+    // same places whatever n is
+    int64_t rpb = ((n + nb - 1) / nb + 15) / 16 * 16;
+    if (rpb < 16) rpb = 16;
     hipLaunchKernelGGL(gramian_partial_kernel<NT>, dim3(nb), dim3(256), 0, st, m, n, ld, rpb, ws);
     hipLaunchKernelGGL(gramian_finish_kernel<NT>, dim3(KP * KP / 64), dim3(256), 0, st, ws, nb, k,
                        reg, out, ld_out);

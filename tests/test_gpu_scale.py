@@ -125,3 +125,54 @@ def test_knn_build_cfg3_sampled_rows(gpu, oracle, ml25m, staged, monkeypatch):
     assert int(ptr[0].item()) == 0 and int(ptr[-1].item()) == nnz
     assert bool((ptr[1:] >= ptr[:-1]).all())
     assert float(out.values.min().item()) >= 1.0e-6  # item_train.rs:135
+
+
+def test_topk_cfg2_all_users_with_exclusions(gpu, oracle, ml25m):
+    """The fused dense top-N call at its bench shape: ALL 162 541 users x 62 423 items, n = 100,
+    every user's own items excluded, factors from real epochs (3 launches x 512 workgroups, LDS
+    candidate counters, redo list) -- a seeded sample of users against the oracle's per-query
+    path (scores = Q u in the k-ordered chain, candidates minus history, heap top-N) FROM THE
+    SAME FACTORS: index sets and score bits identical; the order inside the list may differ only
+    among items whose scores are bit-equal (the reference leaves it unspecified)."""
+    import torch
+
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+    from lkpy_amd._als_engine import HipBackend, ImplicitALSEngine
+
+    k, reg = 64, 0.1
+    ui = sps.csr_array((np.full(ml25m.nnz, 40.0, dtype=np.float32), ml25m.indices, ml25m.indptr),
+                       shape=ml25m.shape)
+    rng = np.random.default_rng(42)
+    Q0 = oracle.als_initial_params(rng, ui.shape[1], k)
+    P0 = oracle.als_initial_params(rng, ui.shape[0], k)
+    backend = HipBackend(k, gpu, _native.SOLVER_CHOLESKY)
+    eng = ImplicitALSEngine(ui, k, reg, reg, P0, Q0, backend)
+    for _ in range(4):
+        eng.train_epoch()
+    eng.check()
+    h_ptr = eng.u_plan.csr.h_indptr.astype(np.int64)
+    excl_ptr = torch.from_numpy(h_ptr).to(gpu)
+    g_idx, g_sc = D.score_topk(eng.P, eng.Q, k, 100, excl_ptr, eng.u_plan.csr.indices)
+    torch.cuda.synchronize()
+    P, Q = backend.download(eng.P), backend.download(eng.Q)  # the engine's row order, both sides
+    ex_idx = eng.u_plan.csr.indices.cpu().numpy()
+    users = np.sort(np.random.default_rng(9).choice(P.shape[0], 4096, replace=False))
+    # always include the heaviest users (longest exclusion lists: relabelled rows 0..15)
+    users = np.unique(np.concatenate([users, np.arange(16)]))
+    lens = h_ptr[users + 1] - h_ptr[users]
+    ptr = np.zeros(len(users) + 1, np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    idx = np.concatenate([ex_idx[h_ptr[u]:h_ptr[u + 1]] for u in users])
+    want_i, want_s = oracle.score_topn_batch(Q, P[users], 100, ptr, idx)
+    got_i, got_s = g_idx.cpu().numpy()[users], g_sc.cpu().numpy()[users]
+    assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))  # sorted score rows
+    assert np.array_equal(np.sort(got_i, axis=1), np.sort(want_i, axis=1))  # index SETS
+    differ = np.flatnonzero((got_i != want_i).any(axis=1))
+    for r in differ:  # only among bit-equal scores
+        d = got_i[r] != want_i[r]
+        assert np.array_equal(got_s[r][d].view(np.uint32), want_s[r][d].view(np.uint32))
+    for r in range(len(users)):
+        assert not np.isin(got_i[r], idx[ptr[r]:ptr[r + 1]]).any()
+    print(f"\ncfg2 top-100 with exclusions: {len(users)} users, index sets + score bits identical; "
+          f"{len(differ)} lists order equal-score items differently")
