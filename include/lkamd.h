@@ -368,6 +368,12 @@ int lk_csr_rows_dot(const void *d_indptr, int indptr_is_64, const int32_t *d_ind
  * (src/accel/knn/item_train.rs:86-91): SURVEY.md section 8d counts the kNN build "to CSR sim
  * matrix on host".  Blocking; waits for `stream` (the producer of `d_src`) first. */
 int lk_download(void *h_dst, const void *d_src, size_t bytes, int32_t n_threads, void *stream);
+/* The same for int32 values known to lie in [0, 65536) -- the column indices of a matrix with at
+ * most 65 536 columns (ML-25M: 62 423 items): they cross PCIe as uint16 (narrowed on the device
+ * into d_tmp_u16, n * 2 bytes) and the host team widens them back while it copies them into
+ * h_dst, so the index half of a similarity matrix costs half the link time. */
+int lk_download_i32_narrow(int32_t *h_dst, const int32_t *d_src, int64_t n, void *d_tmp_u16,
+                           int32_t n_threads, void *stream);
 
 /* ------------------------------------------------------------------------
  * EASE (`EASEScorer`, src/lenskit/knn/ease.py:88-147).

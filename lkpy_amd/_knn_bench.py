@@ -105,7 +105,9 @@ def run(ratings: sps.csr_array, dev, reps: int = 2, checker=None, score_checker=
     # download of the result (what ItemKNNScorer.train does next) into pageable host memory:
     # lk_download (pinned staging ring + host thread team); the plain copy beside it
     t0 = time.perf_counter()
-    h_ptr, h_idx, h_val = out.indptr.cpu().numpy(), D.to_host(out.indices), D.to_host(out.values)
+    h_ptr = out.indptr.cpu().numpy()
+    h_idx = D.to_host(out.indices, index_bound=out.shape[1])
+    h_val = D.to_host(out.values)
     t_down = time.perf_counter() - t0
     del h_ptr, h_idx, h_val
     t0 = time.perf_counter()

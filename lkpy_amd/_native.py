@@ -120,6 +120,7 @@ def _declare(lib):
             c_int, [vp, c_int, vp, vp, c_int64, vp, c_int64, c_int64, vp, c_int64, vp]
         ),
         "lk_download": (c_int, [vp, vp, c_size_t, c_int32, vp]),
+        "lk_download_i32_narrow": (c_int, [vp, vp, c_int64, vp, c_int32, vp]),
         "lk_ease_gram": (c_int, [vp, vp, vp, vp, c_int64, c_float, vp, c_int64, vp]),
         "lk_ease_score_batch": (
             c_int, [vp, vp, c_int64, vp, c_int64, c_int64, vp, c_int64, vp]
@@ -168,6 +169,14 @@ def load(build_if_missing: bool = False):
                 f"{LIB_PATH} not found: build it with `python -m lkpy_amd.csrc.build` "
                 "(or __graft_entry__.build()); lkpy_amd has no CPU fallback"
             )
+    # ONE HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64 /
+    # libhsa-runtime64, and whichever copy is mapped first serves everybody (same sonames).  If
+    # this library came first it would pull /opt/rocm's copy and torch's bundled HSA runtime would
+    # then find no device ("No HIP GPUs are available": seen when __graft_entry__.build() loaded
+    # the library before smoke() imported torch).  torch is the device-memory plumbing of this
+    # package anyway, so it is imported here, before the dlopen.
+    import torch  # noqa: F401
+
     try:
         lib = ctypes.CDLL(str(LIB_PATH))
     except OSError as e:  # pragma: no cover

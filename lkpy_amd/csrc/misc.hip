@@ -201,7 +201,7 @@ extern "C" int lk_task_ctl_progress(const lk_task_ctl *c, int64_t *rows_done, in
 namespace lk {
 namespace {
 constexpr size_t DL_CHUNK = (size_t)16 << 20;  // bytes per staging slot
-constexpr int DL_SLOTS = 16;
+constexpr int DL_SLOTS = 32;
 
 struct DownloadRing {
     char *slot[DL_SLOTS] = {};
@@ -225,30 +225,50 @@ DownloadRing g_ring;  // one transfer at a time (guarded by its mutex); slots st
 }  // namespace
 }  // namespace lk
 
-extern "C" int lk_download(void *h_dst, const void *d_src, size_t bytes, int32_t n_threads,
-                           void *stream)
+namespace lk {
+// WIDEN = 0: plain bytes.  WIDEN = 1: the source is uint16, the destination int32 (twice the
+// bytes): the host team widens while it copies out of the staging slot, so half the bytes cross
+// PCIe (lk_download_u16_as_i32: column indices of a matrix with <= 65 536 columns).
+template <int WIDEN>
+static int download_impl(void *h_dst, const void *d_src, size_t bytes, int32_t n_threads,
+                         void *stream)
 {
-    LK_REQUIRE(bytes == 0 || (h_dst && d_src), "lk_download: null pointer");
     if (bytes == 0) return LK_OK;
     // the producer of d_src ran on `stream`
     LK_HIP_CHECK(hipStreamSynchronize(lk::as_stream(stream)));
+    char *dst = static_cast<char *>(h_dst);
+    const char *src = static_cast<const char *>(d_src);
+    auto put = [&](size_t off, const char *from, size_t n) {
+        if (WIDEN) {
+            const uint16_t *a = reinterpret_cast<const uint16_t *>(from);
+            int32_t *b = reinterpret_cast<int32_t *>(dst + 2 * off);
+            const size_t cnt = n / 2;
+            for (size_t i = 0; i < cnt; ++i) b[i] = (int32_t)a[i];
+        } else {
+            memcpy(dst + off, from, n);
+        }
+    };
     if (bytes < 4 * lk::DL_CHUNK) {  // small: a plain copy
-        LK_HIP_CHECK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+        if (!WIDEN) {
+            LK_HIP_CHECK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+            return LK_OK;
+        }
+        std::vector<char> tmp(bytes);
+        LK_HIP_CHECK(hipMemcpy(tmp.data(), d_src, bytes, hipMemcpyDeviceToHost));
+        put(0, tmp.data(), bytes);
         return LK_OK;
     }
     std::lock_guard<std::mutex> guard(lk::g_ring.mu);
     int rc = lk::g_ring.init();
     if (rc != LK_OK) return rc;
-    if (n_threads < 1) n_threads = 8;
+    if (n_threads < 1) n_threads = 16;
     if (n_threads > lk::DL_SLOTS - 2) n_threads = lk::DL_SLOTS - 2;
     const size_t n_chunks = (bytes + lk::DL_CHUNK - 1) / lk::DL_CHUNK;
-    // chunk c lives in slot c % DL_SLOTS; issued[c] / copied[c] hand the slots over
-    std::atomic<size_t> issued{0}, copied_upto{0};
+    // chunk c lives in slot c % DL_SLOTS; issued / copied[c] hand the slots over
+    std::atomic<size_t> issued{0};
     std::vector<std::atomic<int>> copied(n_chunks);
     for (auto &x : copied) x.store(0, std::memory_order_relaxed);
     std::atomic<int> failed{0};
-    char *dst = static_cast<char *>(h_dst);
-    const char *src = static_cast<const char *>(d_src);
 
     auto worker = [&](int t) {
         for (size_t c = (size_t)t; c < n_chunks; c += (size_t)n_threads) {
@@ -263,7 +283,7 @@ extern "C" int lk_download(void *h_dst, const void *d_src, size_t bytes, int32_t
             }
             const size_t off = c * lk::DL_CHUNK;
             const size_t n = bytes - off < lk::DL_CHUNK ? bytes - off : lk::DL_CHUNK;
-            memcpy(dst + off, lk::g_ring.slot[s], n);
+            put(off, lk::g_ring.slot[s], n);
             copied[c].store(1, std::memory_order_release);
         }
     };
@@ -292,10 +312,37 @@ extern "C" int lk_download(void *h_dst, const void *d_src, size_t bytes, int32_t
         issued.store(c + 1, std::memory_order_release);
     }
     for (auto &th : team) th.join();
-    (void)copied_upto;
     if (failed.load()) {
         lk::set_error("lk_download: transfer failed: %s", hipGetErrorString(err));
         return LK_E_HIP;
     }
     return LK_OK;
+}
+
+__global__ void narrow_i32_u16_kernel(const int32_t *__restrict__ src, int64_t n,
+                                      uint16_t *__restrict__ dst)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (uint16_t)src[i];
+}
+}  // namespace lk
+
+extern "C" int lk_download(void *h_dst, const void *d_src, size_t bytes, int32_t n_threads,
+                           void *stream)
+{
+    LK_REQUIRE(bytes == 0 || (h_dst && d_src), "lk_download: null pointer");
+    return lk::download_impl<0>(h_dst, d_src, bytes, n_threads, stream);
+}
+
+extern "C" int lk_download_i32_narrow(int32_t *h_dst, const int32_t *d_src, int64_t n,
+                                      void *d_tmp_u16, int32_t n_threads, void *stream)
+{
+    LK_REQUIRE(n >= 0 && (n == 0 || (h_dst && d_src && d_tmp_u16)),
+               "lk_download_i32_narrow: null pointer");
+    if (n == 0) return LK_OK;
+    hipLaunchKernelGGL(lk::narrow_i32_u16_kernel, dim3(4096), dim3(256), 0, lk::as_stream(stream),
+                       d_src, n, static_cast<uint16_t *>(d_tmp_u16));
+    LK_HIP_CHECK(hipGetLastError());
+    return lk::download_impl<1>(h_dst, d_tmp_u16, (size_t)n * 2, n_threads, stream);
 }

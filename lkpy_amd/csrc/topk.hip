@@ -785,29 +785,35 @@ __device__ __forceinline__ void bitonic_desc_lds(T *a, unsigned p2, int tid)
 }
 
 // stage 3 of the fused selection: one workgroup per row.  The candidates (every entry >= tau)
-// are loaded into registers, the row's excluded items are struck out by comparing every
-// candidate with every entry of the exclusion list (staged in LDS 1024 at a time and read as
-// broadcasts; the list may be in any order and of any length), and the survivors are
-// bitonic-sorted by (score desc, index asc).  Rows whose candidate list overflowed are flagged
-// for the unfused path.
-template <int CAP>
+// are loaded, the row's excluded items are struck out through a small LDS hash of the
+// candidates' item numbers (the exclusion list may be in any order and of any length: it is
+// only walked once), and the survivors are bitonic-sorted by (score desc, index asc).  Rows
+// whose candidate list overflowed are flagged for the unfused path.
+// Two tiers: the kernel is latency-bound (a chain of dependent global loads, LDS atomics and
+// barriers per row), so what counts is how many rows a CU holds at once.  The first launch keeps
+// LCAP = 1024 keys in LDS (16 KiB: 8 workgroups per CU instead of 5 with room for 2048) and
+// hands the few rows with more candidates to a second launch with LCAP = STRIDE = 2048.
+// (Measured and dropped: striking exclusions out by comparing every candidate with every entry
+// read as LDS broadcasts -- no hash, no atomics, but O(candidates x exclusions / 64): 20.7 ms
+// per call against 17.0 with the hash.)
+template <int LCAP, int STRIDE>
 __global__ __launch_bounds__(256) void cand_select_kernel(
     const unsigned long long *__restrict__ cand, const unsigned *__restrict__ cand_cnt,
     const int64_t *__restrict__ excl_ptr, const int32_t *__restrict__ excl_items,
     int64_t user_base, int n, int32_t *__restrict__ out_idx, float *__restrict__ out_score,
-    int64_t out_ld, int *__restrict__ redo /* [0] = count, [1 ..] = user rows */, int redo_cap)
+    int64_t out_ld, int *__restrict__ redo /* [0] = count, [1 ..] = user rows */, int redo_cap,
+    int *__restrict__ big /* [0] = count, [1 ..] = batch rows with more than LCAP candidates */,
+    int big_cap, const int *__restrict__ row_list /* second tier: the rows to take, or null */)
 {
-    __shared__ unsigned long long key[CAP];
-    // one chunk of the row's exclusion list: every thread compares ITS candidates (registers)
-    // with every entry, read as LDS broadcasts (same address in all lanes: conflict-free) --
-    // no hash table, no LDS atomics (ds_cmpst round trips were the slow half of this kernel:
-    // 1.16 ms per 54 k rows with the hash, 0.5 ms for the same rows without exclusions), and
-    // the list needs no particular order
-    constexpr int XCH = 1024;
-    __shared__ __attribute__((aligned(16))) int exl[XCH];
+    __shared__ unsigned long long key[LCAP];
+    __shared__ int hslot[2 * LCAP];  // open addressing: candidate position + 1, 0 = empty
     const int tid = threadIdx.x;
-    const int64_t b = blockIdx.x;
-    // all three scalars of the row are requested before anything waits on them
+    int64_t b = blockIdx.x;
+    if (row_list) {  // second tier: one workgroup per listed row
+        if ((int)blockIdx.x >= min(row_list[0], big_cap)) return;
+        b = row_list[1 + blockIdx.x];
+    }
+    // the row's three scalars are requested together, before anything waits on them
     const unsigned m = cand_cnt[b];
     int64_t eb = 0, ee = 0;
     if (excl_ptr) {
@@ -823,53 +829,50 @@ __global__ __launch_bounds__(256) void cand_select_kernel(
         const int pos = atomicAdd(&redo[0], 1);
         if (pos < redo_cap) redo[1 + pos] = (int)(user_base + b);
     };
-    if (m > (unsigned)CAP) {
+    if (m > (unsigned)STRIDE) {
         if (tid == 0) flag();
+        return;
+    }
+    if (m > (unsigned)LCAP) {
+        // more candidates than this tier's LDS holds (a few rows in a hundred): the second-tier
+        // launch (LCAP = STRIDE) takes the row; beyond its list: the exact redo path
+        if (tid == 0) {
+            const int pos = big ? atomicAdd(&big[0], 1) : big_cap;
+            if (pos < big_cap)
+                big[1 + pos] = (int)b;
+            else
+                flag();
+        }
         return;
     }
     unsigned p2 = 1;
     while (p2 < m) p2 <<= 1;
     if (p2 < 2) p2 = 2;
-    constexpr int PER = CAP / 256;  // candidates per thread at most
-    unsigned long long mine[PER];
-#pragma unroll
-    for (int r = 0; r < PER; ++r) {
-        const unsigned i = tid + 256u * r;
-        mine[r] = i < m ? cand[b * CAP + i] : 0ull;
-    }
+    for (unsigned i = tid; i < p2; i += 256) key[i] = i < m ? cand[b * STRIDE + i] : 0ull;
     if (ee > eb) {
-        const unsigned rounds = (m + 255u) >> 8;  // wave-uniform: registers that hold candidates
-        int item[PER];
-#pragma unroll
-        for (int r = 0; r < PER; ++r) item[r] = (int)(0xffffffffu - (unsigned)(mine[r] & 0xffffffffu));
-        bool hit[PER];
-#pragma unroll
-        for (int r = 0; r < PER; ++r) hit[r] = false;
-        for (int64_t c0 = eb; c0 < ee; c0 += XCH) {
-            const int len = (int)((ee - c0) < XCH ? (ee - c0) : XCH);
-            if (c0 != eb) __syncthreads();  // the previous chunk has been read by everybody
-            for (int e = tid; e < XCH; e += 256) exl[e] = e < len ? excl_items[c0 + e] : -1;
-            __syncthreads();
-            const int len4 = (len + 3) >> 2;
-            for (int e4 = 0; e4 < len4; ++e4) {
-                const int4 x = reinterpret_cast<const int4 *>(exl)[e4];  // broadcast read
-#pragma unroll
-                for (int r = 0; r < PER; ++r) {
-                    if ((unsigned)r < rounds) {
-                        hit[r] |= (item[r] == x.x) | (item[r] == x.y) | (item[r] == x.z) |
-                                  (item[r] == x.w);
-                    }
+        const unsigned hmask = 2 * p2 - 1;  // table of 2 p2 >= 2 m slots
+        for (unsigned i = tid; i <= hmask; i += 256) hslot[i] = 0;
+        __syncthreads();
+        for (unsigned i = tid; i < m; i += 256) {
+            const unsigned it = 0xffffffffu - (unsigned)(key[i] & 0xffffffffu);
+            unsigned h = (it * 2654435761u) & hmask;
+            while (atomicCAS(&hslot[h], 0, (int)i + 1) != 0) h = (h + 1) & hmask;
+        }
+        __syncthreads();
+        for (int64_t e = eb + tid; e < ee; e += 256) {
+            const unsigned it = (unsigned)excl_items[e];
+            unsigned h = (it * 2654435761u) & hmask;
+            for (;;) {
+                const int s = hslot[h];
+                if (s == 0) break;
+                const unsigned ci = 0xffffffffu - (unsigned)(key[s - 1] & 0xffffffffu);
+                if (ci == it) {
+                    key[s - 1] = 0ull;  // excluded: sorts to the end, never emitted
+                    break;
                 }
+                h = (h + 1) & hmask;
             }
         }
-#pragma unroll
-        for (int r = 0; r < PER; ++r)
-            if (hit[r]) mine[r] = 0ull;  // excluded: sorts to the end, never emitted
-    }
-#pragma unroll
-    for (int r = 0; r < PER; ++r) {
-        const unsigned i = tid + 256u * r;
-        if (i < p2) key[i] = mine[r];
     }
     __syncthreads();
     bitonic_desc_lds(key, p2, tid);
@@ -1311,6 +1314,8 @@ static int fused_tau_rank(int64_t n_items, int32_t n)
     return n;
 }
 constexpr int FUSED_REDO_CAP = 4096;  // rows redone one by one; more: everything through the panel
+constexpr int FUSED_LCAP = 1024;      // candidates the first selection tier holds in LDS
+constexpr int FUSED_BIG_CAP = 32768;  // rows per batch the second tier takes (more: redo path)
 
 struct FusedLayout {
     size_t off_sub, off_tau, off_cnt, off_cand, off_flags, off_qs, bytes;
@@ -1332,7 +1337,7 @@ static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n)
     L.off_cand = off;
     off += align_up((size_t)rows * FUSED_CAP * 8, 256);
     L.off_flags = off;  // redo list: count + rows
-    off += align_up((size_t)(1 + FUSED_REDO_CAP) * 4, 256);
+    off += align_up((size_t)(1 + FUSED_REDO_CAP + 1 + FUSED_BIG_CAP) * 4, 256);
     L.off_qs = off;     // sample of the item factors, [n_sample x 256 floats at most]
     off += align_up((size_t)nsub * 256 * 4, 256);
     L.bytes = off;
@@ -1522,10 +1527,19 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
                                    ld_users, rows, d_items, ld_items, n_items, KP, (float *)nullptr,
                                    (int64_t)0, tau, cand, cnt, lk::FUSED_CAP);
             // stage 3: exclusions, exact order
-            hipLaunchKernelGGL(lk::cand_select_kernel<lk::FUSED_CAP>, dim3((unsigned)rows),
+            int *big = redo + 1 + lk::FUSED_REDO_CAP;  // [0] = count, [1 ..] = rows
+            LK_HIP_CHECK(hipMemsetAsync(big, 0, sizeof(int), st));
+            hipLaunchKernelGGL((lk::cand_select_kernel<lk::FUSED_LCAP, lk::FUSED_CAP>),
+                               dim3((unsigned)rows), dim3(256), 0, st, cand, cnt, d_excl_ptr,
+                               d_excl_items, ub, n, d_out_idx + ub * n,
+                               d_out_score ? d_out_score + ub * n : nullptr, (int64_t)n, redo,
+                               lk::FUSED_REDO_CAP, big, lk::FUSED_BIG_CAP, (const int *)nullptr);
+            hipLaunchKernelGGL((lk::cand_select_kernel<lk::FUSED_CAP, lk::FUSED_CAP>),
+                               dim3((unsigned)(rows < lk::FUSED_BIG_CAP ? rows : lk::FUSED_BIG_CAP)),
                                dim3(256), 0, st, cand, cnt, d_excl_ptr, d_excl_items, ub, n,
                                d_out_idx + ub * n, d_out_score ? d_out_score + ub * n : nullptr,
-                               (int64_t)n, redo, lk::FUSED_REDO_CAP);
+                               (int64_t)n, redo, lk::FUSED_REDO_CAP, (int *)nullptr,
+                               lk::FUSED_BIG_CAP, (const int *)big);
         }
         LK_HIP_CHECK(hipGetLastError());
         // rows that did not end up with n valid candidates are redone exactly, one by one

@@ -84,7 +84,7 @@ class ItemKNNScorer(Component):
         # Arrow extension array, int64 offsets (item.py:176-177: LargeList -> from_array); an
         # unbounded ML-25M model is 9.2 GB: D.to_host moves it at PCIe speed (lk_download)
         self.sim_matrix = SparseRowArray.from_arrays(
-            offsets, D.to_host(out.indices), D.to_host(out.values),
+            offsets, D.to_host(out.indices, index_bound=out.shape[1]), D.to_host(out.values),
             shape=(n_items, n_items))
         import pyarrow as pa
 
