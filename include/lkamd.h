@@ -372,6 +372,8 @@ int lk_download(void *h_dst, const void *d_src, size_t bytes, int32_t n_threads,
  * most 65 536 columns (ML-25M: 62 423 items): they cross PCIe as uint16 (narrowed on the device
  * into d_tmp_u16, n * 2 bytes) and the host team widens them back while it copies them into
  * h_dst, so the index half of a similarity matrix costs half the link time. */
+/* Pin the staging ring of lk_download now (idempotent; otherwise the first large download pays). */
+int lk_download_warmup(void);
 int lk_download_i32_narrow(int32_t *h_dst, const int32_t *d_src, int64_t n, void *d_tmp_u16,
                            int32_t n_threads, void *stream);
 

@@ -120,6 +120,7 @@ def _declare(lib):
             c_int, [vp, c_int, vp, vp, c_int64, vp, c_int64, c_int64, vp, c_int64, vp]
         ),
         "lk_download": (c_int, [vp, vp, c_size_t, c_int32, vp]),
+        "lk_download_warmup": (c_int, []),
         "lk_download_i32_narrow": (c_int, [vp, vp, c_int64, vp, c_int32, vp]),
         "lk_ease_gram": (c_int, [vp, vp, vp, vp, c_int64, c_float, vp, c_int64, vp]),
         "lk_ease_score_batch": (

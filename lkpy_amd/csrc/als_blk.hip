@@ -57,6 +57,23 @@
 namespace lk {
 namespace blk {
 
+#ifdef LK_BLK_PHASES
+// Diagnostic build only (tools/blk_phases.py): shader-clock cycles per row and phase, as seen by
+// wave 0 -- 8 words per row: [0] Gram (or slab sum), [1] panel publish + barrier, [2] diagonal
+// block + panel rows (the v_readlane chain), [3] panel write-back + barrier, [4] forward step +
+// trailing MFMA update, [5] back substitution, [6] row length, [7] whole row
+__device__ unsigned *lk_blk_phase_buf;
+#define LK_BP_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define LK_BP_ADD(i, a, b) ph[i] += (unsigned)((b) - (a))
+#define LK_BP_ARG , unsigned(&ph)[8]
+#define LK_BP_PASS , ph
+#else
+#define LK_BP_T(var)
+#define LK_BP_ADD(i, a, b)
+#define LK_BP_ARG
+#define LK_BP_PASS
+#endif
+
 template <int B, int E, class F>
 __device__ __forceinline__ void sfor(F &&f)
 {
@@ -231,8 +248,9 @@ __global__ __launch_bounds__(256) void als_blk_chunk_kernel(
 template <int NT, int b>
 __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__restrict__ lds,
                                           int tid, int lane, int wave, int wr, int wc,
-                                          float &minpiv)
+                                          float &minpiv LK_BP_ARG)
 {
+    LK_BP_T(bp0);
     using C = Cfg<NT>;
     constexpr int NL = C::NL;
     constexpr int R = C::KP - 16 * b;  // panel rows: block row b and everything below
@@ -257,6 +275,8 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
         });
     }
     __syncthreads();
+    LK_BP_T(bp1);
+    LK_BP_ADD(1, bp0, bp1);
 
     // (2) lane = panel row.  a: this thread's own row (16 columns of the block); d: diagonal
     // block row (lane & 15), replicated in every wave so that the multipliers are v_readlane
@@ -300,6 +320,8 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
         });
     });
 
+    LK_BP_T(bp2);
+    LK_BP_ADD(2, bp1, bp2);
     // (3) L panel rows back in place (MFMA-operand layout), diagonal block + 1/L_jj to their
     // permanent home, z_b = L_bb^-1 (y_b - ...) from thread 0
     if (tid >= 16 && tid < R) {
@@ -324,6 +346,8 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
         }
     }
     __syncthreads();
+    LK_BP_T(bp3);
+    LK_BP_ADD(3, bp2, bp3);
 
     if constexpr (b + 1 < NT) {
         // (4) forward substitution of the rows below: y_r -= L[r][b-block] . z_b
@@ -390,6 +414,8 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
             }
         });
     }
+    LK_BP_T(bp4);
+    LK_BP_ADD(4, bp3, bp4);
 }
 
 // ---- one block of the back substitution  L^T x = z ---------------------------------------
@@ -446,10 +472,10 @@ __device__ __forceinline__ void back_step(const f32x4 (&acc)[Cfg<NT>::T], float 
 
 template <int NT, int... Bs>
 __device__ __forceinline__ void chol_all(f32x4 (&acc)[Cfg<NT>::T], float *lds, int tid, int lane,
-                                         int wave, int wr, int wc, float &minpiv,
+                                         int wave, int wr, int wc, float &minpiv LK_BP_ARG,
                                          std::integer_sequence<int, Bs...>)
 {
-    (chol_step<NT, Bs>(acc, lds, tid, lane, wave, wr, wc, minpiv), ...);
+    (chol_step<NT, Bs>(acc, lds, tid, lane, wave, wr, wc, minpiv LK_BP_PASS), ...);
 }
 
 template <int NT, int... Bs>
@@ -505,6 +531,10 @@ __device__ __forceinline__ void als_blk_solve_body(
         return;
     }
 
+#ifdef LK_BLK_PHASES
+    unsigned ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    LK_BP_T(bp_begin);
     // -- phase 1: -A' = -OtOr' - sum v q q^T in the accumulators ------------------------------
     f32x4 acc[C::T];
     float yacc[NL];
@@ -571,10 +601,16 @@ __device__ __forceinline__ void als_blk_solve_body(
 
     // -- phase 2: blocked Cholesky with the forward substitution riding along ------------------
     float minpiv = 3.0e38f;
-    chol_all<NT>(acc, lds, tid, lane, wave, wr, wc, minpiv, std::make_integer_sequence<int, NT>{});
+    LK_BP_T(bp_gram);
+    LK_BP_ADD(0, bp_begin, bp_gram);
+    chol_all<NT>(acc, lds, tid, lane, wave, wr, wc, minpiv LK_BP_PASS,
+                 std::make_integer_sequence<int, NT>{});
+    LK_BP_T(bp_chol);
 
     // -- phase 3: back substitution ----------------------------------------------------------
     back_all<NT>(acc, lds, lane, wave, wr, wc, std::make_integer_sequence<int, NT>{});
+    LK_BP_T(bp_back);
+    LK_BP_ADD(5, bp_chol, bp_back);
 
     // -- output: un-prime through LDS so that the row is written coalesced --------------------
     if (tid < KP) {
@@ -600,6 +636,14 @@ __device__ __forceinline__ void als_blk_solve_body(
                          lds[C::OFF_RED + 3];
         if constexpr (CTL) ctl_advance(ctl, 1);
     }
+#ifdef LK_BLK_PHASES
+    if (tid == 0 && lk_blk_phase_buf) {
+        LK_BP_T(bp_end);
+        ph[6] = (unsigned)(end - beg);
+        ph[7] = (unsigned)(bp_end - bp_begin);
+        for (int i = 0; i < 8; ++i) lk_blk_phase_buf[(size_t)row * 8 + i] = ph[i];
+    }
+#endif
 }
 
 #define LK_BLK_KERNEL(NAME, NTV, ATTR)                                                          \
@@ -799,3 +843,11 @@ int als_blk_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const
 }
 
 }  // namespace lk
+
+#ifdef LK_BLK_PHASES
+extern "C" int lk_blk_phase_set(unsigned *d_buf)
+{
+    LK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(lk::blk::lk_blk_phase_buf), &d_buf, sizeof(d_buf)));
+    return LK_OK;
+}
+#endif

