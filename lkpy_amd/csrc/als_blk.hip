@@ -186,9 +186,24 @@ __device__ __forceinline__ void ops_consume(f32x4 (&acc)[Cfg<NT>::T], float (&ya
 }
 
 // CSR entries [beg, end) of one row (or chunk) into acc / yacc.  Entries are taken in batches
-// of 64 (one coalesced load of indices + values per wave), four per MFMA step; the operands of
-// the next step are in flight while the current one runs.  Every load is unconditional
-// (lanes / groups past the end re-read the last entry and are masked at use).
+// of 64 (one coalesced load of indices + values per wave), four per MFMA step.  Every load is
+// unconditional (lanes / groups past the end re-read the last entry and are masked at use).
+//
+// The gathered factor rows come from L2 / MALL / HBM with 1-2 k cycles of latency, a step's
+// MFMAs take 0.3 k (k = 128) .. 1.2 k (k = 256): with the operands of ONE step in flight (rounds
+// 1-2) the phase ran at the gather latency -- 2.0-2.6 k cycles per step whatever the row length
+// (LK_BLK_PHASES: 48 % of a k = 128 row, 33 % at k = 256).  LK_BLK_RING = D keeps the operands
+// of D steps in flight in a register ring that runs on across batch boundaries (the next
+// batch's indices / values are loaded one batch ahead); D = 0 is the old single-lookahead loop.
+// Measured per ML-25M-shaped epoch (tools/blk_variants.py): k = 256: D = 0 81.8 ms, 1: 80.8,
+// 2: 75.5, 4: 80.9 (spills); k = 128: D = 0 19.15, 2: 18.80, 4: 19.29, 8 at 3 waves/SIMD: 20.4
+// -- at k = 128 the four resident workgroups already cover most of each other's gather latency.
+#ifndef LK_BLK_RING8
+#define LK_BLK_RING8 2   // k = 128: 9 registers per step (4 spills 150 B more and gains nothing)
+#endif
+#ifndef LK_BLK_RING16
+#define LK_BLK_RING16 2  // k = 256: 17 registers per step, the register file is full
+#endif
 template <int NT, bool EXPL>
 __device__ __forceinline__ void gram_accumulate(f32x4 (&acc)[Cfg<NT>::T], float (&yacc)[NT / 2],
                                                 const int32_t *__restrict__ cols,
@@ -196,20 +211,61 @@ __device__ __forceinline__ void gram_accumulate(f32x4 (&acc)[Cfg<NT>::T], float 
                                                 int64_t end, const float *__restrict__ other,
                                                 int lane, int wr, int wc)
 {
+    constexpr int D = NT == 16 ? LK_BLK_RING16 : LK_BLK_RING8;
     const int64_t last = end - 1;  // end > beg
-    for (int64_t base = beg; base < end; base += 64) {
-        const int64_t e = (base + lane < end) ? base + lane : last;
-        const int col_reg = cols[e];
-        const float val_reg = vals[e];
-        const int nb = (end - base) < 64 ? (int)(end - base) : 64;
-        const int ng = (nb + 3) >> 2;
-        Ops<NT> cur, nxt;
-        ops_issue<NT>(cur, 0, col_reg, val_reg, other, lane, wr, wc);
-        for (int g = 0; g < ng; ++g) {
-            const int gn = (g + 1 < ng) ? g + 1 : g;
-            ops_issue<NT>(nxt, gn, col_reg, val_reg, other, lane, wr, wc);
-            ops_consume<NT, EXPL>(acc, yacc, cur, (g * 4 + (lane >> 4)) < nb);
-            cur = nxt;
+    if constexpr (D == 0) {
+        for (int64_t base = beg; base < end; base += 64) {
+            const int64_t e = (base + lane < end) ? base + lane : last;
+            const int col_reg = cols[e];
+            const float val_reg = vals[e];
+            const int nb = (end - base) < 64 ? (int)(end - base) : 64;
+            const int ng = (nb + 3) >> 2;
+            Ops<NT> cur, nxt;
+            ops_issue<NT>(cur, 0, col_reg, val_reg, other, lane, wr, wc);
+            for (int g = 0; g < ng; ++g) {
+                const int gn = (g + 1 < ng) ? g + 1 : g;
+                ops_issue<NT>(nxt, gn, col_reg, val_reg, other, lane, wr, wc);
+                ops_consume<NT, EXPL>(acc, yacc, cur, (g * 4 + (lane >> 4)) < nb);
+                cur = nxt;
+            }
+        }
+    } else {
+        static_assert(D == 0 || 16 % (D ? D : 1) == 0, "the ring depth divides the 16 steps of a batch");
+        auto load_batch = [&](int64_t base, int &c, float &v) {
+            const int64_t e = (base + lane < end) ? base + lane : last;
+            c = cols[e];
+            v = vals[e];
+        };
+        int colA, colB;
+        float valA, valB;
+        load_batch(beg, colA, valA);
+        load_batch(beg + 64, colB, valB);
+        Ops<NT> ring[D];
+        sfor<0, D>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            ops_issue<NT>(ring[d], d, colA, valA, other, lane, wr, wc);
+        });
+        for (int64_t base = beg; base < end; base += 64) {
+            const int nb = (end - base) < 64 ? (int)(end - base) : 64;
+            const int ng = (nb + 3) >> 2;
+            int colC;
+            float valC;
+            load_batch(base + 128, colC, valC);  // two batches ahead
+            for (int g0 = 0; g0 < ng; g0 += D) {
+                sfor<0, D>([&](auto dc) {
+                    constexpr int d = decltype(dc)::value;
+                    ops_consume<NT, EXPL>(acc, yacc, ring[d], ((g0 + d) * 4 + (lane >> 4)) < nb);
+                    // step g0 + d + D: of this batch, or already of the next one
+                    const int sn = g0 + d + D;
+                    const bool nx = sn >= 16;  // wave-uniform
+                    ops_issue<NT>(ring[d], nx ? sn - 16 : sn, nx ? colB : colA, nx ? valB : valA,
+                                  other, lane, wr, wc);
+                });
+            }
+            colA = colB;
+            valA = valB;
+            colB = colC;
+            valB = valC;
         }
     }
 }

@@ -793,9 +793,13 @@ __device__ __forceinline__ void bitonic_desc_lds(T *a, unsigned p2, int tid)
 // barriers per row), so what counts is how many rows a CU holds at once.  The first launch keeps
 // LCAP = 1024 keys in LDS (16 KiB: 8 workgroups per CU instead of 5 with room for 2048) and
 // hands the few rows with more candidates to a second launch with LCAP = STRIDE = 2048.
-// (Measured and dropped: striking exclusions out by comparing every candidate with every entry
-// read as LDS broadcasts -- no hash, no atomics, but O(candidates x exclusions / 64): 20.7 ms
-// per call against 17.0 with the hash.)
+// (Measured and dropped, lists identical in both: (i) striking exclusions out by comparing every
+// candidate with every entry read as LDS broadcasts -- no hash, no atomics, but
+// O(candidates x exclusions / 64): 20.7 ms per call against 17.0 with the hash; (ii) running
+// this selection as an epilogue of score_filter64_kernel, each workgroup sorting its own 128
+// rows while its co-resident partner multiplies: 20.7 ms against 15.4 -- a row is a ~20 us chain
+// of dependent loads, LDS atomics and barriers, tolerable only with 8 rows in flight per CU; two
+// 256-register workgroups per CU give it one.)
 template <int LCAP, int STRIDE>
 __global__ __launch_bounds__(256) void cand_select_kernel(
     const unsigned long long *__restrict__ cand, const unsigned *__restrict__ cand_cnt,

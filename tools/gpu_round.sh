@@ -1,11 +1,8 @@
-# one gpurun call: GPU tests, smoke, bench line, A/B runs (results under gpurun_out/)
 mkdir -p gpurun_out
-timeout 1800 python -m pytest tests -m gpu -q -s > gpurun_out/gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gputest.log
+timeout 900 python -m pytest tests/test_gpu_topk.py tests/test_gpu_scale.py tests/test_gpu_pipeline.py tests/test_gpu_seam.py -m gpu -q -s > gpurun_out/gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gputest.log
 tail -n 3 gpurun_out/gputest.log
-timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke_main.log 2>&1; echo "smoke(main) rc=$?" >> gpurun_out/smoke_main.log
-tail -n 2 gpurun_out/smoke_main.log
-timeout 900 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?" >> gpurun_out/bench.err
-tail -n 1 gpurun_out/bench.err
-timeout 300 python tools/download_bench.py > gpurun_out/download.log 2>&1
-tail -n 12 gpurun_out/download.log
-du -sh gpurun_out
+timeout 300 python bench.py --no-knn --no-fit --no-k128 --no-cfg5 --steps 5 > gpurun_out/bench_fused.log 2>&1
+LK_TOPK_FUSE_SELECT=0 timeout 300 python bench.py --no-knn --no-fit --no-k128 --no-cfg5 --no-cpu --steps 5 > gpurun_out/bench_unfused.log 2>&1
+timeout 400 python tools/blk_variants.py 128 tools/_variants/lkamd_r0.so tools/_variants/lkamd_r2_1.so tools/_variants/lkamd_r4w3_4.so tools/_variants/lkamd_r8w3.so > gpurun_out/blk128.log 2>&1
+timeout 400 python tools/blk_variants.py 256 tools/_variants/lkamd_r0.so tools/_variants/lkamd_r2_1.so tools/_variants/lkamd_r4w3_4.so > gpurun_out/blk256.log 2>&1
+grep "^{" gpurun_out/blk128.log gpurun_out/blk256.log
