@@ -198,6 +198,9 @@ __device__ __forceinline__ void ops_consume(f32x4 (&acc)[Cfg<NT>::T], float (&ya
 // Measured per ML-25M-shaped epoch (tools/blk_variants.py): k = 256: D = 0 81.8 ms, 1: 80.8,
 // 2: 75.5, 4: 80.9 (spills); k = 128: D = 0 19.15, 2: 18.80, 4: 19.29, 8 at 3 waves/SIMD: 20.4
 // -- at k = 128 the four resident workgroups already cover most of each other's gather latency.
+#ifndef LK_BLK_SOLVE_PRIO
+#define LK_BLK_SOLVE_PRIO 0
+#endif
 #ifndef LK_BLK_RING8
 #define LK_BLK_RING8 2   // k = 128: 9 registers per step (4 spills 150 B more and gains nothing)
 #endif
@@ -613,7 +616,9 @@ __device__ __forceinline__ void als_blk_solve_body(
     if (first_slab >= 0) {
         const int64_t n = end - beg;
         const int ns = (int)((n + LK_ALS_CHUNK_BLK - 1) / LK_ALS_CHUNK_BLK);
-        for (int s = 0; s < ns; ++s) {
+        // many chunks: the groups were pre-summed into their heads (slab_group_reduce_kernel)
+        const int step = ns > LK_ALS_SLAB_GROUP ? LK_ALS_SLAB_GROUP : 1;
+        for (int s = 0; s < ns; s += step) {
             const float *slab =
                 slabs + (size_t)(first_slab + s) * C::SLAB + (size_t)wave * C::SLAB_WAVE;
             sfor<0, C::T>([&](auto tc) {
@@ -659,12 +664,18 @@ __device__ __forceinline__ void als_blk_solve_body(
     float minpiv = 3.0e38f;
     LK_BP_T(bp_gram);
     LK_BP_ADD(0, bp_begin, bp_gram);
+#if LK_BLK_SOLVE_PRIO
+    __builtin_amdgcn_s_setprio(LK_BLK_SOLVE_PRIO);  // see als_chol.hip, LK_ALS_SOLVE_PRIO
+#endif
     chol_all<NT>(acc, lds, tid, lane, wave, wr, wc, minpiv LK_BP_PASS,
                  std::make_integer_sequence<int, NT>{});
     LK_BP_T(bp_chol);
 
     // -- phase 3: back substitution ----------------------------------------------------------
     back_all<NT>(acc, lds, lane, wave, wr, wc, std::make_integer_sequence<int, NT>{});
+#if LK_BLK_SOLVE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     LK_BP_T(bp_back);
     LK_BP_ADD(5, bp_chol, bp_back);
 
@@ -800,6 +811,10 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     if (p->n_chunks > 0)
         hipLaunchKernelGGL((als_blk_chunk_kernel<NT, EXPL>), dim3((unsigned)p->n_chunks), dim3(256),
                            0, st, indices, values, p->d_chunk_beg, p->d_chunk_len, other, slabs);
+    {
+        int rc = launch_slab_group_reduce(p, slabs, (size_t)C::SLAB, st);
+        if (rc != LK_OK) return rc;
+    }
     if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
     // short rows (<= 16 entries) of the implicit model: Woodbury kernel, when the caller
     // supplied Z = other * OtOr^-1 for this half-epoch (never with a task-control block: the

@@ -54,6 +54,9 @@
 #ifndef LK_ALS_GRAM_FENCE
 #define LK_ALS_GRAM_FENCE 1
 #endif
+#ifndef LK_ALS_SOLVE_PRIO
+#define LK_ALS_SOLVE_PRIO 0  // s_setprio level of a wave while it factors / substitutes (0: unchanged)
+#endif
 #ifndef LK_ALS_PANEL
 #define LK_ALS_PANEL 2  // 2: hybrid Cholesky (panels in lane = row layout + MFMA updates);
                         // 0: the round-1 lane = row Cholesky (bit-identical results; A/B timing)
@@ -513,6 +516,35 @@ __device__ __forceinline__ void slab_add(Gram<NT> &G, const float *__restrict__ 
     for (int t = 0; t < NT; ++t) G.y[t] += slab[(als_tiles(NT) * 4 + t) * 64 + lane];
 }
 
+// ---- slab groups: slab[head] += slab[head + 1] + ... + slab[head + cnt - 1] ------------------
+// (grid: groups x ceil(slab_floats / 1024); float4 per thread; chunk order inside the group)
+__global__ __launch_bounds__(256) void slab_group_reduce_kernel(float *__restrict__ slabs,
+                                                                int64_t slab_floats,
+                                                                const int32_t *__restrict__ grp_head,
+                                                                const int32_t *__restrict__ grp_cnt,
+                                                                int parts)
+{
+    const int g = blockIdx.x / parts;
+    const int64_t e = ((int64_t)(blockIdx.x - g * parts) * 256 + threadIdx.x) * 4;
+    if (e >= slab_floats) return;
+    float *head = slabs + (size_t)grp_head[g] * slab_floats + e;
+    const int cnt = grp_cnt[g];
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(head);
+    for (int c = 1; c < cnt; ++c)
+        acc += *reinterpret_cast<const f32x4 *>(head + (size_t)c * slab_floats);
+    *reinterpret_cast<f32x4 *>(head) = acc;
+}
+
+int launch_slab_group_reduce(const lk_als_plan *p, float *slabs, size_t slab_floats, hipStream_t st)
+{
+    if (p->n_groups <= 0) return LK_OK;
+    const int parts = (int)((slab_floats / 4 + 255) / 256);
+    hipLaunchKernelGGL(slab_group_reduce_kernel, dim3((unsigned)(p->n_groups * parts)), dim3(256),
+                       0, st, slabs, (int64_t)slab_floats, p->d_grp_head, p->d_grp_cnt, parts);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
 // ---- chunk kernel: one wave per chunk of a long row ------------------------
 template <int NT, bool EXPL>
 __global__ __launch_bounds__(256) void als_chunk_kernel(
@@ -949,7 +981,9 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     if (first_slab >= 0) {
         const int64_t n = end - beg;
         const int ns = (int)((n + LK_ALS_CHUNK - 1) / LK_ALS_CHUNK);
-        for (int s = 0; s < ns; ++s)
+        // many chunks: the groups were pre-summed into their heads (slab_group_reduce_kernel)
+        const int step = ns > LK_ALS_SLAB_GROUP ? LK_ALS_SLAB_GROUP : 1;
+        for (int s = 0; s < ns; s += step)
             slab_add<NT>(G, slabs + (size_t)(first_slab + s) * slab_floats<NT>());
     } else {
         // (the solver's LDS is idle while the normal matrix is built: it stages the CSR
@@ -993,7 +1027,17 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     asm volatile("" : "+v"(b));
     LK_PHASE_T(ph5);
 #else
+    // The factorisation is one long dependent chain (v_readlane -> rsq -> mul -> fma per column):
+    // a wave in it has ONE ready instruction at a time, while the co-resident waves in their
+    // normal-matrix loops always have several.  LK_ALS_SOLVE_PRIO > 0 lets the chain win the
+    // SIMD's issue arbitration for its duration.
+#if LK_ALS_SOLVE_PRIO
+    __builtin_amdgcn_s_setprio(LK_ALS_SOLVE_PRIO);
+#endif
     const float minpiv = hybrid_solve<NT>(G, b, lds);
+#if LK_ALS_SOLVE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
 #else
     // tile (ti,tj): lane holds D[i = slot*4+r][j = sub] = A'[ti*16+i][tj*16+j]
@@ -1370,6 +1414,8 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
         hipLaunchKernelGGL((als_chunk_kernel<NT, EXPL>), dim3((unsigned)((p->n_chunks + 3) / 4)),
                            dim3(256), 0, st, indices, values, p->d_chunk_beg, p->d_chunk_len,
                            p->n_chunks, other, ld_other, slabs);
+        int rc = launch_slab_group_reduce(p, slabs, slab_floats<NT>(), st);
+        if (rc != LK_OK) return rc;
     }
     if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
     if (n_rows > 0) {
@@ -1522,10 +1568,26 @@ extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int i
         }
     }
     p->n_chunks = (int64_t)chunk_row.size();
+    // slab groups of the rows with many chunks (LK_ALS_SLAB_GROUP, als_plan.h)
+    std::vector<int32_t> grp_head, grp_cnt;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        if (row_slab[(size_t)r] < 0) continue;
+        const int64_t ns = (len(r) + LK_ALS_CHUNK - 1) / LK_ALS_CHUNK;
+        if (ns <= LK_ALS_SLAB_GROUP) continue;
+        for (int64_t s0 = 0; s0 < ns; s0 += LK_ALS_SLAB_GROUP) {
+            const int64_t c = std::min<int64_t>(LK_ALS_SLAB_GROUP, ns - s0);
+            if (c >= 2) {
+                grp_head.push_back((int32_t)(row_slab[(size_t)r] + s0));
+                grp_cnt.push_back((int32_t)c);
+            }
+        }
+    }
+    p->n_groups = (int64_t)grp_head.size();
 
     int rc;
     if ((rc = upload(&p->d_order, order)) != LK_OK || (rc = upload(&p->d_row_slab, row_slab)) ||
         (rc = upload(&p->d_chunk_row, chunk_row)) || (rc = upload(&p->d_chunk_beg, chunk_beg)) ||
+        (rc = upload(&p->d_grp_head, grp_head)) || (rc = upload(&p->d_grp_cnt, grp_cnt)) ||
         (rc = upload(&p->d_chunk_len, chunk_len))) {
         lk_als_plan_destroy(p);
         return rc;
@@ -1598,6 +1660,8 @@ extern "C" void lk_als_plan_destroy(lk_als_plan *p)
     if (p->d_chunk_row) (void)hipFree(p->d_chunk_row);
     if (p->d_chunk_beg) (void)hipFree(p->d_chunk_beg);
     if (p->d_chunk_len) (void)hipFree(p->d_chunk_len);
+    if (p->d_grp_head) (void)hipFree(p->d_grp_head);
+    if (p->d_grp_cnt) (void)hipFree(p->d_grp_cnt);
     delete p;
 }
 

@@ -12,6 +12,14 @@
 #define LK_ALS_LONG_ROW 2048  // rows longer than this are chunked
 #endif
 #define LK_ALS_CHUNK_BLK LK_ALS_CHUNK  // same chunking for the workgroup-per-row kernel (als_blk.hip)
+// Rows with more than LK_ALS_SLAB_GROUP chunks get their slabs pre-summed in groups of that many
+// (slab_group_reduce_kernel: every group in parallel, chunk order inside a group), and the solve
+// kernel adds the group heads only.  Two short float32 sums instead of one long one: the
+// busiest cfg5 item (1.54 M entries = 1505 slabs) was 1.07e-4 from the float64 solution with the
+// single sequential sum; and the 209 MB of its slabs are no longer read by ONE workgroup.
+#ifndef LK_ALS_SLAB_GROUP
+#define LK_ALS_SLAB_GROUP 16
+#endif
 
 struct lk_als_plan {
     int64_t n_rows = 0;
@@ -35,6 +43,9 @@ struct lk_als_plan {
     int32_t *d_chunk_row = nullptr;  // [n_chunks]
     int64_t *d_chunk_beg = nullptr;  // [n_chunks] CSR entry range
     int32_t *d_chunk_len = nullptr;
+    int64_t n_groups = 0;           // slab groups of the rows with more than LK_ALS_SLAB_GROUP chunks
+    int32_t *d_grp_head = nullptr;  // [n_groups] first slab of the group
+    int32_t *d_grp_cnt = nullptr;   // [n_groups] slabs in the group (2 .. LK_ALS_SLAB_GROUP)
     // workspace layout (byte offsets)
     size_t off_status = 0, off_otor = 0, off_delta = 0, off_partial = 0, off_slabs = 0,
            ws_bytes = 0;
@@ -73,6 +84,8 @@ int als_wb64_launch(const lk_als_plan *p, const void *indptr, int is64, const in
 size_t spd_inverse_workspace_bytes(int KP);
 int spd_inverse(const float *a, int lda, int k, int KP, float *out, int *flag, void *ws,
                 hipStream_t st);
+// slab[head] += slab[head + 1] + ... (chunk order) for every group of the plan (als_chol.hip)
+int launch_slab_group_reduce(const lk_als_plan *p, float *slabs, size_t slab_floats, hipStream_t st);
 // deterministic two-stage sum of the per-row squared deltas -> sqrt (als_chol.hip)
 int launch_delta_reduce(const float *row_delta, int64_t n_rows, float *partial, float *out_frob,
                         hipStream_t st);

@@ -12,12 +12,15 @@
  * reference's golden vector tests/models/item-item-preds.csv and the closed
  * forms in tests/models/test_knn_item_item.py; top-N against the Rust unit
  * tests in src/accel/indirect/heap.rs:105-162 and the properties in
- * tests/accel/test_argsort.py.  The ALS factors have NO golden values in the
- * reference and the arithmetic inside LAPACK sposv /
- * ndarray `dot` is third-party: for ALS factors the parity is "unpinned at bit
- * level"; it is pinned only through scipy's own sposv (the very function
- * pointer the reference resolves, src/accel/als/solve.rs:47-59) and the
- * behavioural tests of tests/models/test_als_implicit.py.
+ * tests/accel/test_argsort.py.  The implicit-ALS row solve is pinned against
+ * the REFERENCE'S OWN Python row functions executed in this container
+ * (tests/golden/make_als_fixtures.py -> als_ref_*.npz, checked by
+ * tests/test_oracle_pinned.py): the reference holds no golden factors, but its
+ * _train_new_row / solve_cholesky / _implicit_otor / initial_params run here.
+ * What remains third party is the summation order inside ndarray's `dot`
+ * (matrixmultiply 0.3.11, restated from its published algorithm below) and
+ * LAPACK sposv (the very function pointer the reference resolves,
+ * src/accel/als/solve.rs:47-59).
  *
  * All citations are relative to /root/reference.
  */

@@ -16,12 +16,11 @@ Pinning status (details in oracle/README.md):
   ``tests/models/test_knn_item_item.py:106-162``.
 * top-N: PINNED by the Rust unit tests ``src/accel/indirect/heap.rs:105-162`` and
   the properties of ``tests/accel/test_argsort.py:60-211``.
-* implicit-ALS factors: **parity unpinned at bit level** -- the reference holds no
-  golden factors and the arithmetic inside LAPACK
-  ``sposv`` (SciPy's bundled OpenBLAS) and ndarray's ``dot`` is third-party.  The
-  oracle calls the *same* ``sposv`` function pointer the reference resolves
-  (``src/accel/als/solve.rs:47-59``), and is checked against the behavioural
-  tests of ``tests/models/test_als_implicit.py``.
+* implicit-ALS row solve: PINNED to the reference's own ``_train_new_row`` / ``solve_cholesky`` /
+  ``_implicit_otor`` / ``initial_params`` executed here (``tests/golden/make_als_fixtures.py``,
+  ``tests/test_oracle_pinned.py``).  Third party and restated from published algorithms: the
+  summation order of ndarray's ``dot`` (matrixmultiply 0.3.11, KC = 256 blocks); LAPACK ``sposv``
+  is the *same* function pointer the reference resolves (``src/accel/als/solve.rs:47-59``).
 
 All ``file:line`` citations are relative to ``/root/reference``.
 """

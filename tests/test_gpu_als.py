@@ -303,3 +303,45 @@ def test_large_k_not_spd_and_tiny_rows(gpu, oracle, rng):
     p2.half_epoch(d_this, d_other, D.Gramian(k, gpu)(d_other, 0.1))
     p2.check_status()
     assert _rel(D.to_host_unpadded(d_this, k), want) < RTOL
+
+
+@pytest.mark.parametrize("k", [32, 64, 128, 256])
+def test_rows_with_many_chunks_use_grouped_slab_sums(gpu, oracle, rng, k):
+    """Rows with more than LK_ALS_SLAB_GROUP = 16 chunks of 1024 entries: their slabs are summed in
+    groups of 16 (``slab_group_reduce_kernel``) and the solve kernel adds the group heads --
+    17 chunks (one full group + a single), 33, and 40 000 entries (40 chunks), next to ordinary
+    rows; against the oracle and the float64 referee."""
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    n_cols = 60_000
+    lens = [16 * 1024 + 1, 33 * 1024 - 5, 40_000, 16 * 1024, 2049, 300, 0, 17]
+    indptr = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=indptr[1:])
+    indices = np.concatenate([np.sort(rng.choice(n_cols, ln, replace=False)) for ln in lens])
+    mat = sps.csr_array((np.full(indptr[-1], 40.0, np.float32), indices.astype(np.int32), indptr),
+                        shape=(len(lens), n_cols))
+    other = ((rng.random((n_cols, k)) - 0.5) * (2.0 / np.sqrt(k))).astype(np.float32)
+    this = np.zeros((len(lens), k), np.float32)
+    otor = oracle.implicit_otor(other, 0.1)
+    want = this.copy()
+    oracle.als_half_epoch(mat, want, other, otor)
+    exact = oracle.als_half_epoch_f64(mat, other, 0.1)
+    csr = D.DeviceCSR.from_arrays(mat.indptr.astype(np.int32), mat.indices, mat.data, mat.shape, gpu)
+    plan = D.ALSPlan(csr, k, _native.SOLVER_CHOLESKY)
+    d_this = D.to_device_padded(this, gpu)
+    d_other = D.to_device_padded(other, gpu)
+    plan.half_epoch(d_this, d_other, D.Gramian(k, gpu)(d_other, 0.1))
+    plan.check_status()
+    got = D.to_host_unpadded(d_this, k)
+    for r, ln in enumerate(lens):
+        if ln == 0:
+            assert not got[r].any()
+            continue
+        e_o = np.linalg.norm(got[r] - want[r]) / np.linalg.norm(want[r])
+        e_x = np.linalg.norm(got[r] - exact[r]) / np.linalg.norm(exact[r])
+        assert e_o < RTOL and e_x < RTOL, (ln, e_o, e_x)
+    # deterministic
+    d2 = D.to_device_padded(this, gpu)
+    plan.half_epoch(d2, d_other, D.Gramian(k, gpu)(d_other, 0.1))
+    assert np.array_equal(D.to_host_unpadded(d2, k), got)

@@ -406,3 +406,41 @@ def test_parity_accounting_attributes_gaps():
     assert not c["accounted"] and not c["ok"]
     d = parity.als_half_accounting(got, exact.astype(np.float32), exact, cond)
     assert d["ok"] and d["accounted"] and d["rows_over_1e-4"] == 0
+
+
+def test_batch_query_entry_points_equal_the_per_query_functions(oracle, rng):
+    "lko_score_topn_batch / lko_iknn_score_batch = the per-query restatements, query by query"
+    Q = rng.standard_normal((3000, 24)).astype(np.float32)
+    P = rng.standard_normal((40, 24)).astype(np.float32)
+    lens = rng.integers(0, 30, 40)
+    ptr = np.zeros(41, np.int64)
+    ptr[1:] = np.cumsum(lens)
+    ex = rng.integers(0, 3000, ptr[-1]).astype(np.int32)
+    gi, gs = oracle.score_topn_batch(Q, P, 50, ptr, ex)
+    for b in range(40):
+        sc = oracle.score_dense(Q, P[b])
+        sc[ex[ptr[b]:ptr[b + 1]]] = np.nan
+        w = oracle.argtopn(sc, 50)
+        assert np.array_equal(gi[b], w) and np.array_equal(gs[b], sc[w])
+    # a catalogue smaller than n: padded with -1 / NaN
+    gi2, gs2 = oracle.score_topn_batch(Q[:20], P[:3], 50)
+    assert (gi2[:, 20:] == -1).all() and np.isnan(gs2[:, 20:]).all() and (gi2[:, :20] >= 0).all()
+
+    sims = sps.random_array((200, 200), density=0.2, format="csr", dtype=np.float32,
+                            rng=np.random.default_rng(1))
+    sims.sort_indices()
+    rl = rng.integers(0, 25, 30)
+    rp = np.zeros(31, np.int64)
+    rp[1:] = np.cumsum(rl)
+    ri = rng.integers(0, 200, rp[-1]).astype(np.int32)
+    rr = rng.standard_normal(rp[-1]).astype(np.float32)
+    tp = np.arange(31, dtype=np.int64) * 12
+    ti = rng.integers(0, 200, 30 * 12).astype(np.int32)
+    bs, bc = oracle.iknn_score_batch(sims, rp, ri, rr, tp, ti, 10, 2)
+    for q in range(30):
+        s1, c1 = oracle.iknn_score(sims, ri[rp[q]:rp[q + 1]], rr[rp[q]:rp[q + 1]],
+                                   ti[tp[q]:tp[q + 1]], 10, 2)
+        assert np.array_equal(bc[tp[q]:tp[q + 1]], c1)
+        assert np.array_equal(np.isnan(bs[tp[q]:tp[q + 1]]), np.isnan(s1))
+        ok = ~np.isnan(s1)
+        assert np.array_equal(bs[tp[q]:tp[q + 1]][ok], s1[ok])
