@@ -361,7 +361,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 #undef LK_SCORE_ARGS
 
 #ifndef LK_TOPK_DMA
-#define LK_TOPK_DMA 1  // k = 64 takes score_filter64_kernel (operands by global_load_lds); 0: never
+#define LK_TOPK_DMA 2  // operands by global_load_lds: 1 = k 64 only (score_filter64_kernel), 2 = also
+                       // k 32 / 128 / 256 (score_filter_slab_kernel); 0: never (register-staged)
 #endif
 // ---- the fused filter for 64 features: operands straight into LDS ------------------------------
 //
@@ -568,7 +569,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 }
 
 #if LK_TOPK_DMA >= 2
-// ---- PREPARED, NOT YET RUN ON A GPU (build with -DLK_TOPK_DMA=2; tools/topk_variants.py) -------
+// ---- the same DMA staging for the other feature counts (LK_TOPK_DMA >= 2, the default) ----------
+// Round 3, first run on a GPU (tools/topk_variants.py, 162 541 x 62 423, n = 100, list checksums
+// over all rows identical to the register-staged kernel): k = 32: 9.11 -> 9.00 ms, k = 128:
+// 25.08 -> 24.44 ms (106 TF), k = 256: 46.23 -> 45.02 ms (115 TF = 0.73 of the MFMA peak).
 // The same DMA staging for the other feature counts (KP = 32, 128, 256): the user panel does not
 // stay resident (64 / 128 KiB at KP = 128 / 256), so a slab buffer holds the 16-feature slab of
 // BOTH operands (128 x 16 user floats + 256 x 16 item floats = 24 KiB; two buffers), six DMA
