@@ -803,7 +803,10 @@ __device__ __forceinline__ void bitonic_desc_lds(T *a, unsigned p2, int tid)
 // this selection as an epilogue of score_filter64_kernel, each workgroup sorting its own 128
 // rows while its co-resident partner multiplies: 20.7 ms against 15.4 -- a row is a ~20 us chain
 // of dependent loads, LDS atomics and barriers, tolerable only with 8 rows in flight per CU; two
-// 256-register workgroups per CU give it one.)
+// 256-register workgroups per CU give it one; (iii) a first tier with ONE WAVE per row (512 keys
+// + 1024 hash slots = 8 KiB: 20 rows in flight per CU, no workgroup barrier) in front of these
+// two: 18.0 ms against 15.4 -- more than a quarter of the rows have over 512 candidates and fall
+// through to the next tier, and a wave alone walks the 45 sort steps four pairs per lane.)
 template <int LCAP, int STRIDE>
 __global__ __launch_bounds__(256) void cand_select_kernel(
     const unsigned long long *__restrict__ cand, const unsigned *__restrict__ cand_cnt,
