@@ -72,6 +72,86 @@ def _relabel_csr(mat: sps.csr_array, row_new_of_old, n_rows_new, col_new_of_old,
     return out
 
 
+class TorchComm:
+    "The engine's collectives on ``torch.distributed`` (backend ``nccl`` = RCCL on the GPU boxes)."
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def broadcast(self, t: torch.Tensor):
+        dist.broadcast(t, src=_global_rank(self.group, 0), group=self.group)
+
+    def all_reduce(self, t: torch.Tensor):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def all_gather_rows(self, full: torch.Tensor, lo: int, hi: int):
+        "in place: every rank's row block [lo, hi) of ``full`` ends up in everybody's ``full``"
+        dist.all_gather_into_tensor(full, full[lo:hi], group=self.group)
+
+
+class LoopbackComm:
+    """
+    ``world`` ranks as THREADS of one process exchanging through shared memory -- the same three
+    collectives with the same semantics (rank-ordered sums, in-place row gather), so that the
+    row-sharded engine can run with two or more ranks on ONE GPU (``tests/test_gpu_sharded.py``:
+    the device relabelling with padding rows, the plan views with non-zero row offsets, the
+    Woodbury buffers of a shard -- everything but the wire).  Not a transport: a test double.
+    """
+
+    class _Shared:
+        def __init__(self, world):
+            import threading
+
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+    def __init__(self, shared: "LoopbackComm._Shared", rank: int):
+        self.sh, self.rank, self.world, self.group = shared, rank, shared.world, None
+
+    @staticmethod
+    def make(world: int):
+        sh = LoopbackComm._Shared(world)
+        return [LoopbackComm(sh, r) for r in range(world)]
+
+    def _sync_device(self, t):
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+
+    def broadcast(self, t):
+        self._sync_device(t)
+        self.sh.slots[self.rank] = t
+        self.sh.barrier.wait()
+        if self.rank != 0:
+            t.copy_(self.sh.slots[0])
+            self._sync_device(t)
+        self.sh.barrier.wait()
+
+    def all_reduce(self, t):
+        self._sync_device(t)
+        self.sh.slots[self.rank] = t.clone()
+        self.sh.barrier.wait()
+        acc = self.sh.slots[0].clone()
+        for r in range(1, self.world):  # rank order, like a ring would not guarantee -- fixed here
+            acc += self.sh.slots[r]
+        self.sh.barrier.wait()
+        t.copy_(acc)
+        self._sync_device(t)
+
+    def all_gather_rows(self, full, lo, hi):
+        self._sync_device(full)
+        self.sh.slots[self.rank] = (full[lo:hi], lo, hi)
+        self.sh.barrier.wait()
+        for r in range(self.world):
+            if r != self.rank:
+                src, a, b = self.sh.slots[r]
+                full[a:b].copy_(src)
+        self._sync_device(full)
+        self.sh.barrier.wait()
+
+
 class HipBackend:
     "The product backend: hand-written HIP kernels through the C ABI."
 
@@ -208,6 +288,7 @@ class ImplicitALSEngine:
         group=None,
         explicit: bool = False,
         defer_init: bool = False,
+        comm=None,
     ):
         self.k = int(k)
         self.backend = backend
@@ -216,15 +297,20 @@ class ImplicitALSEngine:
         self.explicit = bool(explicit)
         self.user_reg, self.item_reg = float(user_reg), float(item_reg)
         self.group = group
-        self.world = dist.get_world_size(group) if (group is not None or _dist_on()) else 1
-        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # the collectives: torch.distributed (RCCL) whenever a process group with more than one
+        # rank exists -- or a communicator handed in (tests: LoopbackComm)
+        force = (os.environ.get("LK_ALS_FORCE_COLLECTIVES", "0") == "1" and dist.is_available()
+                 and dist.is_initialized())
+        if comm is None and (group is not None or _dist_on() or force):
+            comm = TorchComm(group)
+        self.comm = comm
+        self.world = comm.world if comm is not None else 1
+        self.rank = comm.rank if comm is not None else 0
         # collectives run whenever there is more than one rank; LK_ALS_FORCE_COLLECTIVES=1 makes
         # a single rank with an initialised process group issue them too (the in-place
         # all-gather on the slice view, the k*k + 1 all-reduce, the init broadcast): the way to
         # execute the RCCL path on device tensors on a one-GPU box (tests/test_gpu_rccl.py)
-        self.collective = self.world > 1 or (
-            os.environ.get("LK_ALS_FORCE_COLLECTIVES", "0") == "1" and dist.is_available()
-            and dist.is_initialized())
+        self.collective = self.world > 1 or force
         n_users, n_items = ui.shape
         self.n_users, self.n_items = n_users, n_items
         on_device = hasattr(ui, "h_indptr")  # a DeviceCSR: the matrix is already in HBM
@@ -297,8 +383,8 @@ class ImplicitALSEngine:
             # every rank must start from the SAME factors (the first user half mixes the local Q
             # with an all-reduced Gramian): rank 0's initialisation wins, whatever the ranks'
             # generators drew (unseeded runs draw differently on every rank)
-            dist.broadcast(self.P, src=_global_rank(self.group, 0), group=self.group)
-            dist.broadcast(self.Q, src=_global_rank(self.group, 0), group=self.group)
+            self.comm.broadcast(self.P)
+            self.comm.broadcast(self.Q)
         # Gramian of the initial Q (user half of epoch 1 needs it); padding rows are 0
         self._qtq = None if self.explicit else self._gramian(self.Q, self.i_lo, self.i_hi,
                                                              self.user_reg)
@@ -309,12 +395,12 @@ class ImplicitALSEngine:
         if not self.collective:
             return self.backend.gramian(full, reg)
         g = self.backend.gramian(full[lo:hi], reg if self.rank == 0 else 0.0)
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+        self.comm.all_reduce(g)
         return g
 
     def _exchange(self, full: torch.Tensor, lo: int, hi: int):
         if self.collective:
-            dist.all_gather_into_tensor(full, full[lo:hi], group=self.group)
+            self.comm.all_gather_rows(full, lo, hi)
 
     # -- training ------------------------------------------------------------
     def train_epoch(self):
@@ -358,14 +444,14 @@ class ImplicitALSEngine:
         buf = torch.empty(kk + 1, dtype=torch.float32, device=g.device)
         buf[:kk] = g.reshape(-1)
         buf[kk:] = (d * d).reshape(-1)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        self.comm.all_reduce(buf)
         return buf[:kk].reshape(self.k, self.k).contiguous(), buf[kk:].sqrt()
 
     def _delta(self, d: torch.Tensor) -> torch.Tensor:
         if not self.collective:
             return d.clone()
         sq = d * d
-        dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
+        self.comm.all_reduce(sq)
         return sq.sqrt()
 
     def check(self):

@@ -912,11 +912,34 @@ __global__ __launch_bounds__(256) void cand_select_kernel(
 __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict__ sub, int64_t ld,
                                                          int64_t n_sub, int r, int64_t n_rows,
                                                          float *__restrict__ tau,
-                                                         unsigned *__restrict__ cand_cnt)
+                                                         unsigned *__restrict__ cand_cnt,
+                                                         const int64_t *__restrict__ excl_ptr,
+                                                         const int32_t *__restrict__ excl_items,
+                                                         int64_t user_base, int stride, int words)
 {
+    // `words` > 0: the row's excluded SAMPLE columns are struck out here, through a per-wave LDS
+    // bitmap (n_sub bits) filled from the exclusion list -- the sample panel is then never
+    // rewritten by score_mask_kernel (a launch and a read-modify-write pass less per call)
+    extern __shared__ unsigned bm_all[];
     const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
     if (b >= n_rows) return;  // wave-uniform
+    unsigned *bm = bm_all + (size_t)wave * words;
+    const bool masked = words > 0 && excl_ptr != nullptr;
+    if (masked) {
+        for (int w = lane; w < words; w += 64) bm[w] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        const int64_t eb = excl_ptr[user_base + b], ee = excl_ptr[user_base + b + 1];
+        for (int64_t e = eb + lane; e < ee; e += 64) {
+            const int it = excl_items[e];
+            if (it >= 0 && it % stride == 0) {
+                const int j = it / stride;
+                if (j < n_sub) atomicOr(&bm[j >> 5], 1u << (j & 31));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     const float *row = sub + b * ld;
     const f32x4 *row4 = reinterpret_cast<const f32x4 *>(row);  // ld % 64 == 0, 256-byte aligned base
     const int64_t n4 = n_sub / 4;
@@ -927,16 +950,19 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict
             const int64_t i = j0 + 64 * c + lane;
             if (i < n4) {
                 const f32x4 x = row4[i];
-                if (x.x == x.x) v[c] = max(v[c], f2key(x.x));
-                if (x.y == x.y) v[c] = max(v[c], f2key(x.y));
-                if (x.z == x.z) v[c] = max(v[c], f2key(x.z));
-                if (x.w == x.w) v[c] = max(v[c], f2key(x.w));
+                // bits of columns 4 i .. 4 i + 3 (4 i is a multiple of 4: never straddles a word)
+                const unsigned ex = masked ? (bm[(4 * i) >> 5] >> ((4 * i) & 31)) & 15u : 0u;
+                if (x.x == x.x && !(ex & 1u)) v[c] = max(v[c], f2key(x.x));
+                if (x.y == x.y && !(ex & 2u)) v[c] = max(v[c], f2key(x.y));
+                if (x.z == x.z && !(ex & 4u)) v[c] = max(v[c], f2key(x.z));
+                if (x.w == x.w && !(ex & 8u)) v[c] = max(v[c], f2key(x.w));
             }
         }
     }
     for (int64_t i = n4 * 4 + lane; i < n_sub; i += 64) {
         const float x = row[i];
-        if (x == x) v[0] = max(v[0], f2key(x));
+        const bool ex = masked && ((bm[i >> 5] >> (i & 31)) & 1u);
+        if (x == x && !ex) v[0] = max(v[0], f2key(x));
     }
     // largest t with #{v >= t} >= r
     unsigned cur = 0u;
@@ -1262,6 +1288,12 @@ static int64_t fused_rows(int64_t n_sub_padded)
 }
 constexpr int FUSED_MAX_N = 128;       // expected candidates <= 8 n <= FUSED_CAP / 2
 
+static bool tau_mask()
+{
+    const char *e = getenv("LK_TOPK_TAU_MASK");  // A/B knob (read per call)
+    return !(e && e[0] == '0');
+}
+
 static int64_t fused_min_items()
 {
     const char *e = getenv("LK_TOPK_FUSED_MIN_ITEMS");  // test hook / tuning knob (read per call)
@@ -1510,12 +1542,18 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
                                ld_users, rows, qs, KP, n_sub, KP, sub, ld_sub,
                                (const float *)nullptr, (unsigned long long *)nullptr,
                                (unsigned *)nullptr, 0);
-            if (d_excl_ptr)
+            // exclusions are struck out of the sample inside sample_tau_kernel (per-wave LDS bitmap)
+            // when 4 bitmaps fit 64 KiB of LDS; LK_TOPK_TAU_MASK=0 or a huge sample: the separate
+            // score_mask_kernel pass over the panel
+            const int words = (int)((n_sub + 31) / 32);
+            const bool tau_mask = d_excl_ptr && lk::tau_mask() && (size_t)words * 16 <= 65536;
+            if (d_excl_ptr && !tau_mask)
                 hipLaunchKernelGGL(lk::score_mask_kernel, dim3((unsigned)rows), dim3(64), 0, st,
                                    d_excl_ptr, d_excl_items, ub, rows, n_items, sub, ld_sub,
                                    stride);
-            hipLaunchKernelGGL(lk::sample_tau_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                               st, sub, ld_sub, n_sub, r_tau, rows, tau, cnt);
+            hipLaunchKernelGGL(lk::sample_tau_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256),
+                               tau_mask ? (size_t)words * 16 : 0, st, sub, ld_sub, n_sub, r_tau, rows,
+                               tau, cnt, d_excl_ptr, d_excl_items, ub, stride, tau_mask ? words : 0);
             // stage 2: the full contraction, candidates only
             // one workgroup per 128 users, walking all item tiles (no global atomics)
             const dim3 ugrid((unsigned)((rows + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB)));

@@ -317,3 +317,54 @@ def test_balanced_ranges_edge_cases():
     assert r[0][0] == 0 and r[-1][1] == 5 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
     assert balanced_ranges(np.zeros(0), 2) == [(0, 0), (0, 0)]
     assert shard_rows_even(5, 2) == [(0, 3), (3, 5)] and shard_rows_even(2, 4)[-1] == (2, 2)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_loopback_comm_equals_gloo_semantics(oracle, world):
+    """``LoopbackComm`` (ranks as threads of one process; used on the GPU box to run the sharded
+    DEVICE path with several ranks on one GPU, tests/test_gpu_sharded.py) gives the engine the same
+    results as the single-process reference order -- the same check the gloo test above makes."""
+    import threading
+
+    from lkpy_amd._als_engine import ImplicitALSEngine, LoopbackComm
+
+    rng = np.random.default_rng(6)
+    n_users, n_items, k, epochs = 211, 97, 8, 3
+    dense = rng.random((n_users, n_items)) < 0.08
+    dense[:, 3] = False
+    ui = sps.csr_array(dense.astype(np.float32) * 40.0)
+    ui.eliminate_zeros()
+    Q0 = oracle.als_initial_params(rng, n_items, k)
+    P0 = oracle.als_initial_params(rng, n_users, k)
+    P, Q = P0.copy(), Q0.copy()
+    iu = sps.csr_array(ui.T)
+    iu.sort_indices()
+    for _ in range(epochs):
+        oracle.als_half_epoch(ui, P, Q, oracle.implicit_otor(Q, 0.1))
+        oracle.als_half_epoch(iu, Q, P, oracle.implicit_otor(P, 0.2))
+
+    comms = LoopbackComm.make(world)
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            eng = ImplicitALSEngine(ui, k, 0.1, 0.2, P0, Q0, OracleBackend(k), comm=comms[r])
+            assert eng.world == world and eng.rank == r
+            for _ in range(epochs):
+                eng.train_epoch()
+            out[r] = (eng.user_embeddings(), eng.item_embeddings())
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+            for c in comms:
+                c.sh.barrier.abort()
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for r in range(world):
+        assert np.array_equal(out[r][0], out[0][0]) and np.array_equal(out[r][1], out[0][1])
+    assert np.linalg.norm(out[0][0] - P) / np.linalg.norm(P) < 1e-4
+    assert np.linalg.norm(out[0][1] - Q) / np.linalg.norm(Q) < 1e-4

@@ -171,12 +171,17 @@ def test_topk_cfg2_all_users_with_exclusions(gpu, oracle, ml25m):
     want_i, want_s = oracle.score_topn_batch(Q, P[users], 100, ptr, idx)
     got_i, got_s = g_idx.cpu().numpy()[users], g_sc.cpu().numpy()[users]
     assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))  # sorted score rows
-    assert np.array_equal(np.sort(got_i, axis=1), np.sort(want_i, axis=1))  # index SETS
+    # index lists: identical, except where different items carry the same score bits (the
+    # reference heap's order among equal scores -- inside the list or at the cut -- is its sift
+    # order; the GPU takes the lower item number): every listed item must really
+    # have the listed score
     differ = np.flatnonzero((got_i != want_i).any(axis=1))
-    for r in differ:  # only among bit-equal scores
-        d = got_i[r] != want_i[r]
-        assert np.array_equal(got_s[r][d].view(np.uint32), want_s[r][d].view(np.uint32))
+    at_cut = 0
+    for r in differ:
+        sc = oracle.score_dense(Q, P[users[r]])
+        assert np.array_equal(sc[got_i[r]].view(np.uint32), got_s[r].view(np.uint32))
+        at_cut += int(not np.array_equal(np.sort(got_i[r]), np.sort(want_i[r])))
     for r in range(len(users)):
         assert not np.isin(got_i[r], idx[ptr[r]:ptr[r + 1]]).any()
-    print(f"\ncfg2 top-100 with exclusions: {len(users)} users, index sets + score bits identical; "
-          f"{len(differ)} lists order equal-score items differently")
+    print(f"\ncfg2 top-100 with exclusions: {len(users)} users, score rows bit-identical; "
+          f"{len(differ)} lists differ among equal-score items ({at_cut} of them at the cut)")
