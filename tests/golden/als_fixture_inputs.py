@@ -89,6 +89,20 @@ def row_entries(case: RowCase):
     return items, vals
 
 
+def explicit_values(case: RowCase) -> np.ndarray:
+    "bias-normalised ratings of the explicit model for the row of ``case``: float32 in [-2.5, 2.5)"
+    stream = 90_000 + case.k * 131 + case.n
+    return ((uniform(stream, case.n) - 0.5) * 5.0).astype(np.float32)
+
+
+EXPLICIT_N = (1, 2, 5, 16, 17, 64, 65, 100, 1000, 2048, 2049, 5000)  # (40 000: a 40 MB product)
+
+
+def explicit_cases():
+    return [RowCase(kind, k, n) for kind in ("centered", "skewed") for k in ROW_K
+            for n in EXPLICIT_N]
+
+
 def ml_small_matrices(path: Path | None = None):
     """
     ml-latest-small as the reference's ``ml_ds`` fixture sees it (items = every movies.csv id,

@@ -11,6 +11,8 @@ executes them, and commits only the resulting input / output VECTORS:
 * ``solve_cholesky``                    ``src/lenskit/math/solve.py:17-41``
 * ``_implicit_otor``                    ``src/lenskit/als/_implicit.py:177-184``
 * ``ImplicitMFTrainer.initial_params``  ``src/lenskit/als/_implicit.py:152-155``
+* ``_train_bias_row_cholesky``          ``src/lenskit/als/_explicit.py:121-147`` (explicit model)
+* ``BiasedMFTrainer.initial_params``    ``src/lenskit/als/_explicit.py:104-108``
 
 Run ONCE in the build container (``/root/reference`` does not exist on the GPU box):
 
@@ -22,6 +24,9 @@ Outputs under ``tests/golden/``:
   128 / 256, constant and varied confidence values: the reference's ``x`` (and its ``OtOr``) for
   inputs that ``als_fixture_inputs.py`` regenerates from integer hashes (no RNG-stream
   dependence);
+* ``als_ref_explicit.npz`` -- the explicit (biased-MF) row solve ``_train_bias_row_cholesky`` on
+  the same synthetic rows with bias-normalised ratings in [-2.5, 2.5), reg 0.1 (A = M^T M +
+  reg n I, rhs M^T r), and the first rows of ``BiasedMFTrainer.initial_params`` (unit rows);
 * ``als_ref_mlsmall.npz`` -- ml-latest-small (cfg1: k = 25, weight 40, reg 0.1, seed 42):
   the reference's ``initial_params`` draws (items first), then three epochs in which every row
   is solved BY THE REFERENCE'S OWN ``_train_new_row`` / ``solve_cholesky`` with ``OtOr`` from its
@@ -76,9 +81,16 @@ def reference_functions():
     otor, _, l_o = _extract(imp, "_implicit_otor")
     init, _, l_i = _extract(imp, "initial_params", "ImplicitMFTrainer")
     me = SimpleNamespace(logger=SimpleNamespace(debug=lambda *a, **k: None))
-    lines = {"solve_cholesky": l_s, "_train_new_row": l_r, "_implicit_otor": l_o, "initial_params": l_i}
+    exp = REF / "src/lenskit/als/_explicit.py"
+    erow, ns_erow, l_e = _extract(exp, "_train_bias_row_cholesky")
+    ns_erow["solve_cholesky"] = solve
+    einit, _, l_ei = _extract(exp, "initial_params", "BiasedMFTrainer")
+    lines = {"solve_cholesky": l_s, "_train_new_row": l_r, "_implicit_otor": l_o,
+             "initial_params": l_i, "_train_bias_row_cholesky": l_e, "explicit initial_params": l_ei}
+    fns = SimpleNamespace(explicit_row=erow,
+                          explicit_init=lambda rng, n, k: einit(SimpleNamespace(rng=rng), n, k))
     return (lambda items, vals, emb, OtOr: row(me, items, vals, emb, OtOr)), otor, \
-        (lambda rng, n, k: init(SimpleNamespace(rng=rng), n, k)), lines
+        (lambda rng, n, k: init(SimpleNamespace(rng=rng), n, k)), lines, fns
 
 
 def half_epoch(row_fn, csr: sps.csr_array, this: np.ndarray, other: np.ndarray, otor: np.ndarray):
@@ -98,7 +110,7 @@ def half_epoch(row_fn, csr: sps.csr_array, this: np.ndarray, other: np.ndarray, 
 
 
 def main():
-    row_fn, otor_fn, init_fn, lines = reference_functions()
+    row_fn, otor_fn, init_fn, lines, xfns = reference_functions()
     print("reference functions extracted at lines", lines)
 
     # ---- synthetic single rows ---------------------------------------------------------
@@ -114,6 +126,19 @@ def main():
         out.setdefault(f"otor_{case.kind}_k{case.k}", OtOr)
     np.savez_compressed(OUT / "als_ref_rows.npz", **out)
     print("als_ref_rows.npz:", len(out), "arrays")
+
+    # ---- explicit model: _train_bias_row_cholesky ---------------------------------------
+    out = {}
+    for case in fx.explicit_cases():
+        emb = fx.embeddings(case)
+        items, _ = fx.row_entries(case)
+        x = xfns.explicit_row(items, fx.explicit_values(case), emb, np.float32(case.reg))
+        assert x.dtype == np.float32
+        out[f"x_{case.name}"] = x
+    init = xfns.explicit_init(np.random.default_rng(fx.ML_SEED), 64, 25)
+    out["init_head"] = init
+    np.savez_compressed(OUT / "als_ref_explicit.npz", **out)
+    print("als_ref_explicit.npz:", len(out), "arrays")
 
     # ---- ml-latest-small, cfg1 ---------------------------------------------------------
     ui, iu = fx.ml_small_matrices(OUT / "ml_small.npz")

@@ -121,3 +121,39 @@ def test_ml_small_half_epochs_against_reference(gpu, oracle, half):
     assert (e[cu < 1e-5] <= 1e-4).all()
     print(f"{half}: GPU vs reference rel {_rel(got, want):.2e}; max err/(cond u) "
           f"{float((e[cond > 0] / cu[cond > 0]).max()):.2f}")
+
+
+@pytest.mark.parametrize("kind", ["centered", "skewed"])
+@pytest.mark.parametrize("k", fx.ROW_K)
+def test_explicit_rows_against_reference(gpu, kind, k):
+    """The explicit (biased-MF) half-epoch kernels against the reference's own
+    ``_train_bias_row_cholesky`` outputs (``als_ref_explicit.npz``; src/lenskit/als/_explicit.py:
+    121-147): 12 row lengths + an empty row in one launch; every row within 1e-4."""
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    gold = np.load(GOLD / "als_ref_explicit.npz")
+    cases = [c for c in fx.explicit_cases() if c.kind == kind and c.k == k]
+    emb = fx.embeddings(cases[0])
+    items = [fx.row_entries(c)[0] for c in cases]
+    vals = [fx.explicit_values(c) for c in cases]
+    lens = [len(i) for i in items] + [0]
+    indptr = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=indptr[1:])
+    mat = sps.csr_array((np.concatenate(vals), np.concatenate(items), indptr),
+                        shape=(len(lens), fx.N_CATALOGUE))
+    csr = D.DeviceCSR.from_arrays(mat.indptr.astype(np.int32), mat.indices, mat.data, mat.shape, gpu)
+    plan = D.ALSPlan(csr, k, _native.SOLVER_CHOLESKY)
+    d_this = D.to_device_padded(np.ones((len(lens), k), np.float32), gpu)
+    d_other = D.to_device_padded(emb, gpu)
+    plan.half_epoch_explicit(d_this, d_other, fx.REG)
+    plan.check_status()
+    got = D.to_host_unpadded(d_this, k)
+    assert not got[-1].any()  # explicit.rs:91-94: empty row -> zeros
+    worst = 0.0
+    for r, c in enumerate(cases):
+        e = _rel(got[r], gold[f"x_{c.name}"])
+        worst = max(worst, e)
+        assert e <= 1.0e-4, (c.name, e)
+    print(f"explicit {kind} k={k}: {len(cases)}/{len(cases)} GPU rows within 1e-4 of the reference's "
+          f"own row solve (worst {worst:.1e})")

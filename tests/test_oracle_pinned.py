@@ -165,3 +165,38 @@ def test_gemm_mode_switch():
     finally:
         L.lko_set_gemm_mode(1)
     assert not np.array_equal(out[0], out[1]) and _rel(out[0], out[1]) < 1e-4
+
+
+@pytest.mark.parametrize("kind", ["centered", "skewed"])
+@pytest.mark.parametrize("k", fx.ROW_K)
+def test_explicit_rows_against_reference_train_bias_row(kind, k):
+    """The explicit (biased-MF) row solve pinned the same way: the C restatement of
+    ``train_explicit_row`` (src/accel/als/explicit.rs:80-119) against the reference's own
+    ``_train_bias_row_cholesky`` (src/lenskit/als/_explicit.py:121-147) from identical inputs:
+    A = M^T M + reg n I, rhs M^T r."""
+    gold = np.load(GOLD / "als_ref_explicit.npz")
+    worst, within = 0.0, 0
+    cases = [c for c in fx.explicit_cases() if c.kind == kind and c.k == k]
+    for c in cases:
+        emb = fx.embeddings(c)
+        items, _ = fx.row_entries(c)
+        vals = fx.explicit_values(c)
+        want = gold[f"x_{c.name}"]
+        m = sps.csr_array((vals, items, np.array([0, len(items)])), shape=(1, fx.N_CATALOGUE))
+        this = np.zeros((1, c.k), np.float32)
+        lko.als_explicit_half_epoch(m, this, emb, c.reg)
+        M = emb[items].astype(np.float64)
+        A = M.T @ M + c.reg * c.n * np.eye(c.k)
+        cond = float(np.linalg.cond(A))
+        e = _rel(this[0], want)
+        assert e <= 0.5 * cond * U32 * np.sqrt(c.n) + 1e-6, (c.name, e, cond)
+        worst = max(worst, e / (cond * U32 * np.sqrt(c.n)))
+        within += e <= 1.0e-4
+    print(f"explicit {kind} k={k}: {within}/{len(cases)} rows within 1e-4 of the reference; "
+          f"max err / (cond u sqrt n) = {worst:.3f}")
+
+
+def test_explicit_initial_params_are_the_reference_draws():
+    gold = np.load(GOLD / "als_ref_explicit.npz")
+    got = lko.als_explicit_initial_params(np.random.default_rng(fx.ML_SEED), 64, 25)
+    assert np.array_equal(got, gold["init_head"])
