@@ -841,6 +841,7 @@ def main():
     ap.add_argument("--no-knn", action="store_true", help="skip the item-kNN build leg")
     ap.add_argument("--no-topk", action="store_true", help="skip the dense top-N scoring leg")
     ap.add_argument("--no-fit", action="store_true", help="skip the end-to-end fit leg")
+    ap.add_argument("--no-cg", action="store_true", help="skip the CG-solver comparison leg")
     ap.add_argument("--no-k128", action="store_true", help="skip the k = 128 leg (configs[3])")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg5 leg (configs[4])")
     ap.add_argument("--k128-steps", type=int, default=10, help="timed epochs of the k128 leg")
@@ -1052,6 +1053,39 @@ def main():
             extra = {"sharded_legs_error": f"{type(exc).__name__}: {exc}"}
         out.update(extra)
 
+    def cg_leg():
+        """the conjugate-gradient row solve ``north_star`` names (the reference
+        itself solves exactly: SURVEY section 0).  ``solver = "cg"`` from the trained state: epoch
+        time beside the exact solver's, and how far one CG epoch lands from the exact epoch run
+        from the same factors."""
+        Ph, Qh = eng.user_embeddings(), eng.item_embeddings()
+        out_cg = {}
+        engs = {}
+        for name, solver in (("exact", _native.SOLVER_CHOLESKY), ("cg", _native.SOLVER_CG)):
+            e2 = ImplicitALSEngine(ui, k, reg, reg, Ph, Qh, HipBackend(k, dev, solver))
+            if name == "cg":
+                e2.u_plan.set_cg(1.0e-6, 0)
+                e2.i_plan.set_cg(1.0e-6, 0)
+            e2.train_epoch()
+            e2.check()
+            engs[name] = (e2.user_embeddings(), e2.item_embeddings())
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                e2.train_epoch()
+            torch.cuda.synchronize(dev)
+            out_cg[name + "_ms_per_epoch"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+            e2.check()
+            del e2
+        rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))  # noqa: E731
+        tr, src = pmc_traffic("r*_cg_k%d_counters.csv" % k, "als_cg_kernel")
+        return {"what": "solver='cg' (Jacobi-preconditioned CG on the implicit normal equations, "
+                "tol 1e-6, warm start) vs the exact solver, from the same trained factors",
+                **out_cg,
+                "one_epoch_rel_diff_P": rel(engs["cg"][0], engs["exact"][0]),
+                "one_epoch_rel_diff_Q": rel(engs["cg"][1], engs["exact"][1]),
+                "hbm_bytes_per_launch_from_pmc": tr, "pmc_source": src}
+
     def k128_leg():
         """BASELINE.json configs[3] on ONE GPU: the same data at k = 128 (``als_blk.hip``): a few
         timed epochs, roofline, and the parity / cpu_baseline pair on a row sample."""
@@ -1086,6 +1120,8 @@ def main():
         leg("parity", als_parity_leg)
     if single and not args.no_topk:
         leg("topk", topk_leg)
+    if single and not args.no_cg and k >= 64:
+        leg("cg", cg_leg)
     if single:
         del eng  # free the engine's HBM before the other legs
         torch.cuda.empty_cache()

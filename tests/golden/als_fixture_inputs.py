@@ -103,6 +103,26 @@ def explicit_cases():
             for n in EXPLICIT_N]
 
 
+EASE_ITEMS, EASE_REG = 1200, 1.0
+EASE_ROWS = np.arange(0, EASE_ITEMS, 50)  # the rows of the inverse that are committed
+
+
+def ease_binary_matrix(path: Path | None = None) -> sps.csr_array:
+    "users x (the 1200 most-rated ml-latest-small items), binary, float32"
+    ui, _ = ml_small_matrices(path)
+    counts = np.diff(sps.csc_array(ui).indptr)
+    top = np.sort(np.argsort(-counts, kind="stable")[:EASE_ITEMS])
+    x = sps.csr_array(ui[:, top], dtype=np.float32)
+    x.data[:] = 1.0
+    return x
+
+
+def ease_cooc(path: Path | None = None) -> np.ndarray:
+    "dense item-item co-occurrence counts incl. the diagonal (knn/ease.py:108), float32"
+    x = ease_binary_matrix(path)
+    return np.asarray((x.T @ x).todense(), dtype=np.float32)
+
+
 def ml_small_matrices(path: Path | None = None):
     """
     ml-latest-small as the reference's ``ml_ds`` fixture sees it (items = every movies.csv id,

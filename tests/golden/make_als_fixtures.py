@@ -140,6 +140,22 @@ def main():
     np.savez_compressed(OUT / "als_ref_explicit.npz", **out)
     print("als_ref_explicit.npz:", len(out), "arrays")
 
+    # ---- EASE: the reference's own SPD inverse ``_chol_invert_torch`` (knn/ease.py:190-209) ----
+    import threading
+
+    import torch
+
+    inv_fn, ns_inv, l_inv = _extract(REF / "src/lenskit/knn/ease.py", "_chol_invert_torch")
+    ns_inv.update(torch=torch, _chol_lock=threading.Lock())
+    cooc = fx.ease_cooc(OUT / "ml_small.npz")
+    cooc[np.diag_indices(len(cooc))] += np.float32(fx.EASE_REG)  # ease.py:113-114
+    inv = inv_fn(cooc.copy(), device="cpu")
+    assert inv.dtype == np.float32
+    np.savez_compressed(OUT / "ease_ref_inverse.npz", rows=fx.EASE_ROWS,
+                        inverse_rows=inv[fx.EASE_ROWS], diag=np.diag(inv).copy())
+    print("ease_ref_inverse.npz: _chol_invert_torch at lines", l_inv, "on a",
+          cooc.shape, "co-occurrence matrix")
+
     # ---- ml-latest-small, cfg1 ---------------------------------------------------------
     ui, iu = fx.ml_small_matrices(OUT / "ml_small.npz")
     U, I = ui.shape

@@ -200,3 +200,26 @@ def test_explicit_initial_params_are_the_reference_draws():
     gold = np.load(GOLD / "als_ref_explicit.npz")
     got = lko.als_explicit_initial_params(np.random.default_rng(fx.ML_SEED), 64, 25)
     assert np.array_equal(got, gold["init_head"])
+
+
+def test_ease_inverse_against_reference_chol_invert_torch(capsys):
+    """EASE: the oracle's SPD inverse (LAPACK ``potrf`` + ``potri``, ``lk_oracle.ease_train``)
+    against the REFERENCE'S OWN ``_chol_invert_torch`` (src/lenskit/knn/ease.py:190-209),
+    executed at fixture time on the co-occurrence matrix of the 1200 most-rated ml-latest-small
+    items (+ reg 1.0 on the diagonal): 24 committed rows and the whole diagonal of the inverse."""
+    gold = np.load(GOLD / "ease_ref_inverse.npz")
+    x = fx.ease_binary_matrix()
+    W = lko.ease_train(x, fx.EASE_REG)  # columns divided by minus their diagonal entry, diag 0
+    # undo the two post-processing lines (ease.py:141-143) with the reference's own diagonal
+    d = gold["diag"].astype(np.float64)
+    rows = gold["rows"]
+    want = gold["inverse_rows"].astype(np.float64)
+    got = -W[rows].astype(np.float64) * d.reshape(1, -1)
+    got[np.arange(len(rows)), rows] = d[rows]
+    err = np.abs(got - want).max() / np.abs(want).max()
+    cooc = fx.ease_cooc().astype(np.float64)
+    cooc[np.diag_indices(len(cooc))] += fx.EASE_REG
+    cond = np.linalg.cond(cooc)
+    print(f"EASE inverse vs the reference's torch Cholesky inverse: max rel err {err:.1e} "
+          f"(cond {cond:.1e})")
+    assert err < 4.0 * cond * U32 + 1e-6
