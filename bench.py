@@ -430,8 +430,10 @@ def knn_score_cpu_and_parity(sims, r_ptr, r_idx, r_val, t_ptr, t_idx, got_s, got
     The cfg3 batch-scoring call (10 000 queries x 100 targets, ``max_nbrs`` 100, ``min_nbrs`` 1)
     through the oracle's ``score_explicit`` restatement (src/accel/knn/item_score.rs:23-111,
     accum.rs) for EVERY query, timed, and compared with the GPU's scores / neighbour counts.
-    Counts and the null pattern must be identical; scores within 1e-5 relative (the accumulator
-    sums the same <= 100 terms in heap order on the CPU, in selection order on the GPU).
+    Counts and the null pattern must be identical; scores within 1e-5 relative -- and since the
+    candidate-list kernel follows the reference's accumulator step for step (same evictions among
+    equal similarities, same summation order, unfused multiply-add), bit for bit:
+    ``scores_bit_identical`` of ``scores_compared``.
     """
     import scipy.sparse as sps
 
@@ -455,6 +457,9 @@ def knn_score_cpu_and_parity(sims, r_ptr, r_idx, r_val, t_ptr, t_idx, got_s, got
                    "null_pattern_identical": nan_same,
                    "score_rel_max": float(rel.max()) if len(rel) else 0.0,
                    "scores_over_1e-5": int((rel > 1e-5).sum()),
+                   "scores_compared": int(fin.sum()),
+                   "scores_bit_identical": int(np.sum(
+                       got_s[fin].view(np.uint32) == want_s[fin].astype(np.float32).view(np.uint32))),
                    "ok": bool(nan_same and np.array_equal(got_c, want_c)
                               and (len(rel) == 0 or rel.max() <= 1e-5))},
     }

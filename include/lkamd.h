@@ -128,6 +128,11 @@ int32_t lk_als_plan_solver(const lk_als_plan *plan);
 /* CG controls (ignored by the Cholesky solver): stop when ||r|| <= tol*||y|| or
  * after max_iter iterations (<=0: k iterations).  Defaults 1e-7 / k. */
 int lk_als_plan_set_cg(lk_als_plan *plan, float tol, int32_t max_iter);
+/* CG iterations spent and non-empty rows solved by the LAST CG half-epoch run with workspace
+ * d_ws (sum over rows; blocking).  Diagnostic: the roofline of the CG kernel is
+ * iterations * (4k flops per entry of the row + 2k^2). */
+int lk_als_plan_cg_stats(const lk_als_plan *plan, void *d_ws, void *stream,
+                         int64_t *out_iterations, int64_t *out_rows);
 /* Attach a task-control block (cancel / progress) to every half-epoch run with this plan. */
 int lk_als_plan_set_ctl(lk_als_plan *plan, lk_task_ctl *ctl);
 /* Short rows at large k (implicit model, padded k = 128 / 256).  A row with n <= 64 entries
@@ -324,8 +329,17 @@ int lk_iknn_truncate_fill(const int64_t *d_sim_indptr, const int32_t *d_sim_indi
  *   score_t = sum_{top max_nbrs by sim} s*v / sum s  (explicit)  or  sum s (implicit);
  *   fewer than min_nbrs contributors => NaN.  out_counts = contributors kept
  *   (-1 for a null target).  Blocking (returns LK_E_NAN_SIM for a NaN similarity).
+ *   Among neighbours of EQUAL similarity at the max_nbrs boundary the reference keeps whichever
+ *   its BinaryHeap happens to hold (accum.rs:106-113: unspecified); here the earlier history
+ *   item stays.  Calls in which no query has more than 1024 targets take the candidate-list
+ *   kernel (targets hashed in LDS, all history rows streamed at once); a query in which some
+ *   target collects more than 256 neighbours, and calls with longer target lists (`score every
+ *   item`), take the one-history-row-at-a-time slot kernel.  LK_KNN_SCORE_LISTS=0 forces the
+ *   latter.  lk_knn_score_last_stats: of the last call on this process, {queries scored by the
+ *   list kernel, queries scored by the slot kernel, longest target list} (test hook).
  * ---------------------------------------------------------------------- */
 size_t lk_iknn_score_workspace_bytes(int64_t n_items, int64_t n_queries, int32_t max_nbrs);
+void lk_knn_score_last_stats(int64_t *out3);
 int lk_iknn_score_batch(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
                         const float *d_sim_values, int64_t n_items, int64_t n_queries,
                         const int64_t *d_ref_ptr, const int32_t *d_ref_items,

@@ -279,6 +279,15 @@ class ALSPlan:
     def set_cg(self, tol: float, max_iter: int = 0):
         check(_native.load().lk_als_plan_set_cg(self._h, float(tol), int(max_iter)))
 
+    def cg_stats(self):
+        "(CG iterations, non-empty rows) of the last CG half-epoch on this plan (blocking)"
+        import ctypes
+
+        it, rows = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(_native.load().lk_als_plan_cg_stats(self._h, _ptr(self.ws), _stream(),
+                                                   ctypes.byref(it), ctypes.byref(rows)))
+        return int(it.value), int(rows.value)
+
     def half_epoch(self, this: torch.Tensor, other: torch.Tensor, otor: torch.Tensor):
         """
         One ALS half-epoch on the current stream; ``this`` ([rows x KP]) is updated in
@@ -518,6 +527,15 @@ def iknn_score_batch(sims: DeviceCSR, ref_ptr, ref_items, ref_rates, tgt_ptr, tg
         "lk_iknn_score_batch",
     )  # fmt: skip
     return out_s, out_c
+
+
+def knn_score_last_stats():
+    "(queries on the candidate-list kernel, queries on the slot kernel, longest target list) of the last call"
+    import ctypes
+
+    out = (ctypes.c_int64 * 3)()
+    _native.load().lk_knn_score_last_stats(out)
+    return tuple(int(x) for x in out)
 
 
 def uknn_score_batch(ratings: DeviceCSR, nbr_ptr, nbr_rows, nbr_sims, tgt_ptr, tgt_items,

@@ -53,12 +53,27 @@ def _score_batch_leg(D, ratings, means, sims, dev, n_users=10_000, n_targets=100
     args = (sims, to(r_ptr), to(r_idx), to(r_val), to(t_ptr), to(t_idx), 100, 1)
     D.iknn_score_batch(*args)
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    s, _c = D.iknn_score_batch(*args)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    res = {"queries": int(len(users)), "targets_per_query": n_targets, "seconds": round(dt, 4),
-           "queries_per_s": round(len(users) / dt, 1), "scored": int(torch.isfinite(s).sum())}
+    dt = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        s, _c = D.iknn_score_batch(*args)
+        torch.cuda.synchronize(dev)
+        dt = min(dt, time.perf_counter() - t0)
+    n_list, n_slot, _ = D.knn_score_last_stats()
+    # what the call has to read: the similarity rows of every history item (column numbers; the
+    # values only where a column is a target), the history and target lists, the outputs
+    row_len = np.diff(sims.indptr.cpu().numpy())
+    streamed = int(row_len[r_idx[r_idx >= 0]].sum())
+    alg_bytes = streamed * 4 + len(r_idx) * 8 + len(t_idx) * 12
+    res = {"queries": int(len(users)), "targets_per_query": n_targets, "seconds": round(dt, 5),
+           "queries_per_s": round(len(users) / dt, 1), "scored": int(torch.isfinite(s).sum()),
+           "kernel": {"candidate_list_queries": n_list, "slot_queries": n_slot},
+           "similarity_entries_streamed": streamed,
+           "roofline": {"bound": "hbm", "achieved": round(alg_bytes / dt / 1e9, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(alg_bytes / dt / 8e12, 4),
+                        "algorithmic_bytes": alg_bytes,
+                        "note": "whole call (two launches, two host syncs); the 47 MB model is "
+                                "L2/MALL resident"}}
     if checker is not None:
         try:
             res.update(checker(sims, r_ptr, r_idx, r_val, t_ptr, t_idx, s.cpu().numpy(),

@@ -66,6 +66,7 @@ def _declare(lib):
         "lk_als_plan_workspace_bytes": (c_size_t, [vp]),
         "lk_als_plan_solver": (c_int32, [vp]),
         "lk_als_plan_set_cg": (c_int, [vp, c_float, c_int32]),
+        "lk_als_plan_cg_stats": (c_int, [vp, vp, vp, POINTER(c_int64), POINTER(c_int64)]),
         "lk_als_plan_short_rows": (c_int64, [vp]),
         "lk_als_plan_woodbury_rows": (c_int64, [vp]),
         "lk_als_plan_set_z": (c_int, [vp, vp]),
@@ -107,6 +108,7 @@ def _declare(lib):
         ),
         "lk_iknn_truncate_fill": (c_int, [vp, vp, vp, c_int64, c_int64, vp, vp, vp, vp, vp]),
         "lk_iknn_score_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32]),
+        "lk_knn_score_last_stats": (None, [POINTER(c_int64)]),
         "lk_iknn_score_batch": (
             c_int,
             [vp, vp, vp, c_int64, c_int64, vp, vp, vp, vp, vp, c_int32, c_int32, vp, vp, vp, vp],

@@ -820,8 +820,9 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     // supplied Z = other * OtOr^-1 for this half-epoch (never with a task-control block: the
     // kernel does not poll it)
     const float *z = p->d_z;
+    const bool prefix = p->dense_limit >= 0;  // CG hybrid: the chunked rows only, no Woodbury
     const bool own_z = !EXPL && p->d_zbuf != nullptr && !p->ctl && p->t_short < n_rows &&
-                       n_cols > 0;
+                       n_cols > 0 && !prefix;
     if (own_z) {
         // Z = other * OtOr^-1 for this half-epoch, all on this stream: the inverse to float64
         // accuracy (spd_inverse.hip; status[1] = its flag, tested by the Woodbury kernels and by
@@ -833,11 +834,12 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
         if (rc != LK_OK) return rc;
         z = p->d_zbuf;
     }
-    const bool use_wb = !EXPL && z != nullptr && !p->ctl && p->t_short < n_rows;
+    const bool use_wb = !EXPL && z != nullptr && !p->ctl && p->t_short < n_rows && !prefix;
     // (17 .. 64 entries: only at padded k = 256 -- at k = 128 the 64 x 64 system costs as much as
     // the dense solve of this file, measured on the ML-25M shape)
     const int64_t n_dense =
-        use_wb ? ((NT == 16 && als_wb64_enabled()) ? p->t_mid : p->t_short) : n_rows;
+        prefix ? (p->dense_limit < n_rows ? p->dense_limit : n_rows)
+               : (use_wb ? ((NT == 16 && als_wb64_enabled()) ? p->t_mid : p->t_short) : n_rows);
     if (use_wb) {
         int rc = als_wb_launch(p, indptr, IS64 ? 1 : 0, indices, values, p->t_short, n_rows,
                                this_, other, z, row_delta, status, st);

@@ -17,10 +17,11 @@
 // per iteration and are summed in wave order, so all waves stay bit-identical and the
 // result is deterministic.
 //
-// Roofline: HBM/L2 bound -- algorithmic bytes per iteration nnz*(4k + 8) + rows*4k^2/…;
-// flops T*(nnz*4k + rows*2k^2).  First version: no LDS residency of the
-// gathered rows across iterations and one row per workgroup (round-2 work: batch rows so
-// that OtOr . P becomes an MFMA GEMM, keep short rows' gathers in LDS).
+// Roofline: HBM/L2 bound -- flops T*(nnz*4k + rows*2k^2).  The gathered
+// rows of a CSR row are read ONCE and stay in registers over the iterations (up to 256 / 128 /
+// 64 entries per row at k = 64 / 128 / 256; longer rows re-gather their tail per iteration), so
+// the traffic is the algorithmic nnz*(4k + 8) + rows*8k instead of T times that; the dot
+// products of 8 items are reduced together (`cg_reduce8`: 10 exchanges, 7 of them DPP).
 #include "als_plan.h"
 #include "common.h"
 
@@ -51,14 +52,69 @@ __device__ __forceinline__ Vec<FPL> vload(const float *p)
     return r;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float cg_dpp(float x)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+// the CG scalars (p.Ap, r.z, r.r): four DPP steps sum a row of 16 lanes, the four row sums are
+// read as scalars -- ~60 cycles of dependent latency instead of six LDS-pipe exchanges (~600)
+// on the serial path of every iteration.  Same value in every lane and in every wave.
+__device__ __forceinline__ float cg_wave_sum(float x)
+{
+    x += cg_dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += cg_dpp<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += cg_dpp<0x141>(x);  // row_half_mirror
+    x += cg_dpp<0x140>(x);  // row_mirror
+    return (bcast(x, 0) + bcast(x, 16)) + (bcast(x, 32) + bcast(x, 48));
+}
 template <int FPL>
 __device__ __forceinline__ float vdot(const Vec<FPL> &a, const Vec<FPL> &b)
 {
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < FPL; ++c) s = fmaf(a.v[c], b.v[c], s);
-    return wave_sum(s);
+    return cg_wave_sum(s);
 }
+
+__device__ __forceinline__ int64_t cg_uniform64(int64_t v)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+// ---- 8 dot products reduced over the wave at once ------------------------------------------
+// a[j] = this lane's share of q_j . p for 8 items.  Instead of 8 separate 6-step butterflies
+// (48 exchanges) the values are folded while they are summed: step A pairs lanes L, L^1 and
+// leaves each with 4 of the 8 items, step B (L^2) with 2, step C (L^4) with one; then the 8
+// lanes that hold the same item are summed across the wave (8, 16, 32).  10 exchanges, 7 of them
+// DPP (quad_perm / row_ror: VALU, no LDS pipe).  Returns the complete dot product of item
+// rev3(lane & 7) (bit-reversed: lane bit 0 chose item bit 2, ...).
+__device__ __forceinline__ float cg_reduce8(const float (&a)[8], int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    float b[4], c[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float keep = b0 ? a[m + 4] : a[m], send = b0 ? a[m] : a[m + 4];
+        b[m] = keep + cg_dpp<0xB1>(send);  // quad_perm [1,0,3,2]: lane ^ 1
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const float keep = b1 ? b[m + 2] : b[m], send = b1 ? b[m] : b[m + 2];
+        c[m] = keep + cg_dpp<0x4E>(send);  // quad_perm [2,3,0,1]: lane ^ 2
+    }
+    const float keep = b2 ? c[1] : c[0], send = b2 ? c[0] : c[1];
+    float d = keep + __shfl_xor(send, 4, 64);
+    d += cg_dpp<0x128>(d);  // row_ror:8 = lane ^ 8 inside the row of 16
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    return d;
+}
+// item j of a group of 8 is finished in the lanes with (lane & 7) == CG_REV3(j)
+#define CG_REV3(j) ((((j) & 1) << 2) | ((j) & 2) | (((j) & 4) >> 2))
 
 template <int KP, bool IS64>
 __global__ __launch_bounds__(256) void als_cg_kernel(
@@ -66,16 +122,20 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
     const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_rows,
     const float *__restrict__ other, float *__restrict__ this_, const float *__restrict__ otor,
     int ld_otor, int k, float tol, int max_iter, float *__restrict__ row_delta,
-    int *__restrict__ status, TaskCtlDev ctl)
+    int *__restrict__ status, TaskCtlDev ctl, int64_t t_begin)
 {
     constexpr int FPL = KP / 64;
     constexpr bool OTOR_LDS = KP <= 128;  // 16 / 64 KiB: loaded once per (persistent) workgroup
-    constexpr int GB = 8;                 // items gathered per wave and batch
+    constexpr int GB = 8;                 // items per reduction group
+    constexpr int RI = 64 / FPL;          // items a wave keeps in registers (64 VGPRs)
+    constexpr int NG = RI / GB;
+    constexpr int TB = FPL <= 2 ? 16 : 8;  // tail entries a wave gathers per batch
     __shared__ float part[4][KP];
     extern __shared__ __attribute__((aligned(16))) float otor_s[];  // OTOR_LDS: KP*KP floats
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const int f0 = lane * FPL;  // first feature of this lane
+    const int myj = CG_REV3(lane & 7);  // the item of a group whose total this lane ends up with
     if (OTOR_LDS) {  // zero padded to KP x KP
         for (int e = threadIdx.x; e < KP * KP; e += 256) {
             const int g = e / KP, f = e % KP;
@@ -85,7 +145,9 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
     }
 
     __shared__ int s_cancel;
-    for (int64_t t = blockIdx.x; t < n_rows; t += gridDim.x) {
+    // tasks [t_begin, n_rows) of the longest-first order (the chunked rows before t_begin were
+    // solved by the exact kernels: als_cg_half_epoch)
+    for (int64_t t = t_begin + blockIdx.x; t < n_rows; t += gridDim.x) {
         if (ctl.d_cancel) {  // AccelTask.cancel: rows not started yet are skipped
             if (threadIdx.x == 0) s_cancel = ctl_cancelled(ctl, (blockIdx.x & 31) == 0) ? 1 : 0;
             __syncthreads();
@@ -93,8 +155,10 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
             __syncthreads();
             if (c) return;
         }
-        const int row = order[t];
-        const int64_t beg = indptr[row], end = indptr[row + 1];
+        // wave-uniform on purpose: the entry numbers and item numbers below become scalar loads
+        // and the gathers `scalar base + lane offset` (no 64-bit address registers per item)
+        const int row = __builtin_amdgcn_readfirstlane(order[t]);
+        const int64_t beg = cg_uniform64(indptr[row]), end = cg_uniform64(indptr[row + 1]);
         float *xrow = this_ + (int64_t)row * KP;
         if (end == beg) {  // implicit.rs:98-101
             if (wave == 0)
@@ -104,41 +168,95 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
             if (ctl.d_done && threadIdx.x == 0) ctl_advance(ctl, 1);
             continue;
         }
-        // A p accumulated over this wave's share of the items and of the OtOr rows,
-        // then combined across the four waves (fixed order)
+        // The row's gathered factor rows stay in REGISTERS for the whole solve: the first
+        // 4 * RI entries are dealt to the waves in equal contiguous shares (a multiple of 8),
+        // wave w keeps its share as qres[i] (lane = feature(s)); only the entries past 4 * RI
+        // of a long row are gathered again in every iteration (`stream`).
+        const int64_t n = end - beg;
+        const int share = n >= 4 * RI ? RI : (int)((n + 4 * GB - 1) / (4 * GB)) * GB;
+        const int64_t rbeg = beg + (int64_t)wave * share;
+        int nres = (int)(end - rbeg < share ? end - rbeg : share);
+        nres = __builtin_amdgcn_readfirstlane(nres < 0 ? 0 : nres);
+        const int64_t sbeg = beg + 4 * (int64_t)share;  // streamed tail (empty unless n > 4 RI)
+        Vec<FPL> qres[RI];
+        float vg[NG];  // lane: the value of item g * 8 + myj of the share (0 past its end)
+        // one coalesced load of the share's item numbers (lane i: item i), handed out by readlane
+        const int myitem = indices[lane < nres ? rbeg + lane : beg];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            vg[g] = 0.f;
+            if (g * GB < nres) {
+                vg[g] = (g * GB + myj < nres) ? values[rbeg + g * GB + myj] : 0.f;
+#pragma unroll
+                for (int j = 0; j < GB; ++j) {
+                    const int i = g * GB + j;
+                    const int64_t it = __builtin_amdgcn_readlane(myitem, i);
+                    qres[i] = vload<FPL>(other + it * KP + f0);
+                    if (i >= nres)  // (item `beg` was read: finite, then dropped)
+#pragma unroll
+                        for (int c = 0; c < FPL; ++c) qres[i].v[c] = 0.f;
+                }
+            }
+        }
+        // A p: this wave's items and its quarter of the OtOr rows, then the four partial
+        // vectors are combined in LDS (fixed order: all waves keep bit-identical vectors)
         auto apply = [&](const Vec<FPL> &p, Vec<FPL> &out) {
             Vec<FPL> u;
 #pragma unroll
             for (int c = 0; c < FPL; ++c) u.v[c] = 0.f;
-            // items: wave w takes batches w, w+4, ... of GB consecutive entries; the GB
-            // gathers of a batch are in flight together and their GB dot-product
-            // reductions are interleaved (independent shuffle chains)
-            for (int64_t e0 = beg + (int64_t)wave * GB; e0 < end; e0 += 4 * GB) {
-                Vec<FPL> q[GB];
-                float dotp[GB], val[GB];
 #pragma unroll
-                for (int j = 0; j < GB; ++j) {
-                    const bool in = e0 + j < end;
-                    const int64_t it = in ? indices[e0 + j] : indices[beg];
-                    val[j] = in ? values[e0 + j] : 0.f;
+            for (int g = 0; g < NG; ++g) {
+                if (g * GB < nres) {
+                    float a[GB];
+#pragma unroll
+                    for (int j = 0; j < GB; ++j) {
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int c = 0; c < FPL; ++c) sacc = fmaf(qres[g * GB + j].v[c], p.v[c], sacc);
+                        a[j] = sacc;
+                    }
+                    const float coefv = vg[g] * cg_reduce8(a, lane);
+#pragma unroll
+                    for (int j = 0; j < GB; ++j) {
+                        const float coef = bcast(coefv, CG_REV3(j));
+#pragma unroll
+                        for (int c = 0; c < FPL; ++c)
+                            u.v[c] = fmaf(coef, qres[g * GB + j].v[c], u.v[c]);
+                    }
+                }
+            }
+            // the tail of a long row: wave w takes batches w, w + 4, ... of TB = 16 entries (two
+            // reduction groups; the 16 gathers of a batch are in flight together)
+            for (int64_t e0 = sbeg + (int64_t)wave * TB; e0 < end; e0 += 4 * TB) {
+                Vec<FPL> q[TB];
+                const int tailitem = indices[(lane < TB && e0 + lane < end) ? e0 + lane : beg];
+                float vmine[TB / GB];
+#pragma unroll
+                for (int h = 0; h < TB / GB; ++h)
+                    vmine[h] = (e0 + h * GB + myj < end) ? values[e0 + h * GB + myj] : 0.f;
+#pragma unroll
+                for (int j = 0; j < TB; ++j) {
+                    const int64_t it = __builtin_amdgcn_readlane(tailitem, j);
                     q[j] = vload<FPL>(other + it * KP + f0);
                 }
 #pragma unroll
-                for (int j = 0; j < GB; ++j) {
-                    float sacc = 0.f;
+                for (int h = 0; h < TB / GB; ++h) {
+                    float a[GB];
 #pragma unroll
-                    for (int c = 0; c < FPL; ++c) sacc = fmaf(q[j].v[c], p.v[c], sacc);
-                    dotp[j] = sacc;
-                }
+                    for (int j = 0; j < GB; ++j) {
+                        float sacc = 0.f;
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1)
+                        for (int c = 0; c < FPL; ++c) sacc = fmaf(q[h * GB + j].v[c], p.v[c], sacc);
+                        a[j] = sacc;
+                    }
+                    const float coefv = vmine[h] * cg_reduce8(a, lane);  // 0 past the end of the row
 #pragma unroll
-                    for (int j = 0; j < GB; ++j) dotp[j] += __shfl_xor(dotp[j], off, 64);
+                    for (int j = 0; j < GB; ++j) {
+                        const float coef = bcast(coefv, CG_REV3(j));
 #pragma unroll
-                for (int j = 0; j < GB; ++j) {
-                    const float coef = val[j] * dotp[j];
-#pragma unroll
-                    for (int c = 0; c < FPL; ++c) u.v[c] = fmaf(coef, q[j].v[c], u.v[c]);
+                        for (int c = 0; c < FPL; ++c)
+                            u.v[c] = fmaf(coef, q[h * GB + j].v[c], u.v[c]);
+                    }
                 }
             }
             for (int g = wave * (KP / 4); g < (wave + 1) * (KP / 4); ++g) {
@@ -178,14 +296,33 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
             Vec<FPL> yw, dw;
 #pragma unroll
             for (int c = 0; c < FPL; ++c) yw.v[c] = dw.v[c] = 0.f;
-            for (int64_t e0 = beg + (int64_t)wave * GB; e0 < end; e0 += 4 * GB) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g * GB < nres) {
+#pragma unroll
+                    for (int j = 0; j < GB; ++j) {
+                        // padding entries: a zero row, so the (v + 1) = 1 adds nothing
+                        const float val = bcast(vg[g], CG_REV3(j));
+#pragma unroll
+                        for (int c = 0; c < FPL; ++c) {
+                            const float qc = qres[g * GB + j].v[c];
+                            yw.v[c] = fmaf(val + 1.0f, qc, yw.v[c]);
+                            dw.v[c] = fmaf(val * qc, qc, dw.v[c]);
+                        }
+                    }
+                }
+            }
+            for (int64_t e0 = sbeg + (int64_t)wave * GB; e0 < end; e0 += 4 * GB) {
                 Vec<FPL> q[GB];
                 float val[GB];
+                const bool mine = lane < GB && e0 + lane < end;
+                const int tailitem = indices[mine ? e0 + lane : beg];
+                const float tailval = mine ? values[e0 + lane] : -1.0f;
 #pragma unroll
                 for (int j = 0; j < GB; ++j) {
                     const bool in = e0 + j < end;
-                    const int64_t it = in ? indices[e0 + j] : indices[beg];
-                    val[j] = in ? values[e0 + j] : -1.0f;  // (v + 1) = 0 and v q q = -q q ...
+                    const int64_t it = __builtin_amdgcn_readlane(tailitem, j);
+                    val[j] = bcast(tailval, j);  // past the end: (v + 1) = 0 and v q q = -q q ...
                     q[j] = vload<FPL>(other + it * KP + f0);
                     if (!in)
 #pragma unroll
@@ -270,6 +407,10 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
             if (lane == 0) row_delta[row] = dd;
         }
         if (__any(bad) && threadIdx.x == 0) atomicCAS(status, 0, row + 1);
+        if (threadIdx.x == 0) {  // lk_als_plan_cg_stats: iterations and rows of this half-epoch
+            atomicAdd(&status[2], it);
+            atomicAdd(&status[3], 1);
+        }
         if (ctl.d_done && threadIdx.x == 0) ctl_advance(ctl, 1);
         __syncthreads();
     }
@@ -279,21 +420,22 @@ template <int KP, bool IS64>
 static int launch_cg(const lk_als_plan *p, const void *indptr, const int32_t *indices,
                      const float *values, int64_t n_rows, int k, float *this_,
                      const float *other, const float *otor, int ld_otor, char *ws,
-                     float *out_frob, hipStream_t st)
+                     float *out_frob, hipStream_t st, int64_t t_begin)
 {
     using IT = typename IndPtr<IS64>::type;
     int *status = reinterpret_cast<int *>(ws + p->off_status);
     float *row_delta = reinterpret_cast<float *>(ws + p->off_delta);
     float *partial = reinterpret_cast<float *>(ws + p->off_partial);
-    LK_HIP_CHECK(hipMemsetAsync(status, 0, 64, st));
+    if (t_begin == 0) LK_HIP_CHECK(hipMemsetAsync(status, 0, 64, st));  // (else: the exact stage did)
     if (p->ctl) {
         LK_HIP_CHECK(hipMemsetAsync(row_delta, 0, (size_t)n_rows * sizeof(float), st));
         int rc = ctl_begin(p->ctl, n_rows, n_rows, st);
         if (rc != LK_OK) return rc;
     }
     const int max_iter = p->cg_max_iter > 0 ? p->cg_max_iter : k;
-    if (n_rows > 0) {
-        int64_t blocks = n_rows < 256 * 8 ? n_rows : 256 * 8;
+    const int64_t n_cg = n_rows - t_begin;
+    if (n_cg > 0) {
+        int64_t blocks = n_cg < 256 * 8 ? n_cg : 256 * 8;
         const size_t lds = KP <= 128 ? (size_t)KP * KP * sizeof(float) : 0;  // OtOr resident
         auto kern = als_cg_kernel<KP, IS64>;
         if (lds > 0)
@@ -303,9 +445,18 @@ static int launch_cg(const lk_als_plan *p, const void *indptr, const int32_t *in
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st,
                            static_cast<const IT *>(indptr), indices, values, p->d_order, n_rows,
                            other, this_, otor, ld_otor, k, p->cg_tol, max_iter, row_delta,
-                           status, p->ctl ? p->ctl->dev() : TaskCtlDev{});
+                           status, p->ctl ? p->ctl->dev() : TaskCtlDev{}, t_begin);
     }
     return launch_delta_reduce(row_delta, n_rows, partial, out_frob, st);
+}
+
+// LK_ALS_CG_HYBRID (test hook / A-B knob): 0 = CG for every row; 1 = the chunked rows (more than
+// LK_ALS_LONG_ROW entries) go to the exact kernels; default 2 = every row longer than the CG
+// kernel keeps in registers does.
+static int cg_hybrid_mode()
+{
+    const char *e = getenv("LK_ALS_CG_HYBRID");
+    return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
 }
 
 int als_cg_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
@@ -313,13 +464,35 @@ int als_cg_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const 
                       const float *other, int ld_other, const float *otor, int ld_otor, char *ws,
                       float *out_frob, hipStream_t st)
 {
-    (void)ld_this;
-    (void)ld_other;
+    // Matrix-free CG pays for itself where a row's gathered factor rows stay in registers over
+    // the iterations: 256 / 128 / 64 entries at padded k = 64 / 128 / 256 (t_cg: 85 % of the
+    // ML-25M user rows, 96 % of its item rows, 40 % of the entries at k = 64).  Longer rows would
+    // gather their tail again in EVERY iteration (measured at k = 64: 62 ms per epoch with CG on
+    // every row -- one workgroup iterating over the 81 491-entry item is 2.5 ms per iteration of
+    // serial gather latency; 29.6 ms with only the chunked rows solved exactly),
+    // while the exact kernels form such a row's normal matrix once, on the matrix cores.  So the
+    // first t_cg tasks of the longest-first order go to the exact kernels, the rest to CG.
+    // (Not with a task-control block: its progress accounting is per launch.)
+    int64_t t_begin = 0;
+    const int mode = p->ctl ? 0 : cg_hybrid_mode();
+    const int64_t t_exact = mode == 2 ? p->t_cg : (mode == 1 ? p->n_long : 0);
+    if (t_exact > 0) {
+        p->dense_limit = t_exact;
+        const int rc =
+            p->KP > 64 ? als_blk_half_epoch(p, indptr, is64, indices, values, n_rows, 0, k, this_,
+                                            other, otor, ld_otor, ws, out_frob, st, false, 0.f)
+                       : als_chol_half_epoch(p, indptr, is64, indices, values, n_rows, k, this_,
+                                             ld_this, other, ld_other, otor, ld_otor, ws, out_frob,
+                                             st);
+        p->dense_limit = -1;
+        if (rc != LK_OK) return rc;
+        t_begin = t_exact;
+    }
 #define LK_CG_CASE(KPV)                                                                     \
     return is64 ? launch_cg<KPV, true>(p, indptr, indices, values, n_rows, k, this_, other, \
-                                       otor, ld_otor, ws, out_frob, st)                     \
+                                       otor, ld_otor, ws, out_frob, st, t_begin)            \
                 : launch_cg<KPV, false>(p, indptr, indices, values, n_rows, k, this_, other, \
-                                        otor, ld_otor, ws, out_frob, st)
+                                        otor, ld_otor, ws, out_frob, st, t_begin)
     switch (p->KP) {
         case 64: LK_CG_CASE(64);
         case 128: LK_CG_CASE(128);
@@ -331,3 +504,16 @@ int als_cg_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const 
 }
 
 }  // namespace lk
+
+extern "C" int lk_als_plan_cg_stats(const lk_als_plan *plan, void *d_ws, void *stream,
+                                    int64_t *out_iterations, int64_t *out_rows)
+{
+    LK_REQUIRE(plan && d_ws, "lk_als_plan_cg_stats: null pointer");
+    int st[4] = {0, 0, 0, 0};
+    LK_HIP_CHECK(hipMemcpyAsync(st, static_cast<char *>(d_ws) + plan->off_status, sizeof(st),
+                                hipMemcpyDeviceToHost, lk::as_stream(stream)));
+    LK_HIP_CHECK(hipStreamSynchronize(lk::as_stream(stream)));
+    if (out_iterations) *out_iterations = st[2];
+    if (out_rows) *out_rows = st[3];
+    return LK_OK;
+}

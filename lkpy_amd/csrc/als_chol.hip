@@ -1418,19 +1418,21 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
         if (rc != LK_OK) return rc;
     }
     if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
-    if (n_rows > 0) {
+    // (CG hybrid: only the chunked rows, the first dense_limit tasks of the order)
+    const int64_t n_solve = p->dense_limit >= 0 && p->dense_limit < n_rows ? p->dense_limit : n_rows;
+    if (n_solve > 0) {
         using IT = typename IndPtr<IS64>::type;
         if (p->ctl)
             hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, true>),
-                               dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st,
+                               dim3((unsigned)((n_solve + 3) / 4)), dim3(256), 0, st,
                                static_cast<const IT *>(indptr), indices, values, p->d_order,
-                               n_rows, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
+                               n_solve, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
                                slabs, row_delta, status, k, reg, p->ctl->dev());
         else
             hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, false>),
-                               dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st,
+                               dim3((unsigned)((n_solve + 3) / 4)), dim3(256), 0, st,
                                static_cast<const IT *>(indptr), indices, values, p->d_order,
-                               n_rows, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
+                               n_solve, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
                                slabs, row_delta, status, k, reg, TaskCtlDev{});
     }
     if (tm) {
@@ -1449,6 +1451,26 @@ int als_cg_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const 
                       const float *values, int64_t n_rows, int k, float *this_, int ld_this,
                       const float *other, int ld_other, const float *otor, int ld_otor, char *ws,
                       float *out_frob, hipStream_t st);
+
+int als_chol_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
+                        const float *values, int64_t n_rows, int k, float *this_, int ld_this,
+                        const float *other, int ld_other, const float *otor, int ld_otor, char *ws,
+                        float *out_frob, hipStream_t st)
+{
+#define LK_CHOL_CASE(NT)                                                                         \
+    return is64 ? launch_chol<NT, true>(p, indptr, indices, values, n_rows, k, this_, ld_this,  \
+                                        other, ld_other, otor, ld_otor, ws, out_frob, st)       \
+                : launch_chol<NT, false>(p, indptr, indices, values, n_rows, k, this_, ld_this, \
+                                         other, ld_other, otor, ld_otor, ws, out_frob, st)
+    switch (p->NT) {
+        case 1: LK_CHOL_CASE(1);
+        case 2: LK_CHOL_CASE(2);
+        case 4: LK_CHOL_CASE(4);
+    }
+#undef LK_CHOL_CASE
+    set_error("lk_als_implicit_half_epoch: no Cholesky kernel for padded k=%d", p->KP);
+    return LK_E_INVALID;
+}
 
 }  // namespace lk
 
@@ -1548,12 +1570,23 @@ extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int i
                 hi = mid;
         }
         p->t_mid = lo;
+        lo = 0;
+        hi = n_rows;
+        const int64_t cg_len = 16384 / KP;
+        while (lo < hi) {  // first task whose row the CG kernel holds in registers
+            const int64_t mid = (lo + hi) >> 1;
+            if (len(order[(size_t)mid]) > cg_len)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        p->t_cg = lo;
     }
     std::vector<int32_t> row_slab((size_t)n_rows, -1);
     std::vector<int32_t> chunk_row;
     std::vector<int64_t> chunk_beg;
     std::vector<int32_t> chunk_len;
-    if (solver == LK_SOLVER_CHOLESKY) {
+    {  // (CG plans too: their chunked rows are solved by the exact kernels, als_cg.hip)
         for (int64_t r = 0; r < n_rows; ++r) {
             int64_t n = len(r);
             if (n > LK_ALS_LONG_ROW) {
@@ -1740,22 +1773,9 @@ extern "C" int lk_als_implicit_half_epoch(const lk_als_plan *plan, const void *d
         return lk::als_blk_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows,
                                       n_cols, k, d_this, d_other, d_otor, ld_otor, ws, d_out_frob,
                                       st, false, 0.f);
-#define LK_CHOL_CASE(NT)                                                                        \
-    return plan->is64 ? lk::launch_chol<NT, true>(plan, d_indptr, d_indices, d_values, n_rows, \
-                                                  k, d_this, ld_this, d_other, ld_other,       \
-                                                  d_otor, ld_otor, ws, d_out_frob, st)         \
-                      : lk::launch_chol<NT, false>(plan, d_indptr, d_indices, d_values,        \
-                                                   n_rows, k, d_this, ld_this, d_other,        \
-                                                   ld_other, d_otor, ld_otor, ws, d_out_frob,  \
-                                                   st)
-    switch (plan->NT) {
-        case 1: LK_CHOL_CASE(1);
-        case 2: LK_CHOL_CASE(2);
-        case 4: LK_CHOL_CASE(4);
-    }
-#undef LK_CHOL_CASE
-    lk::set_error("lk_als_implicit_half_epoch: no Cholesky kernel for padded k=%d", plan->KP);
-    return LK_E_INVALID;
+    return lk::als_chol_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows, k,
+                                   d_this, ld_this, d_other, ld_other, d_otor, ld_otor, ws,
+                                   d_out_frob, st);
 }
 
 extern "C" int lk_als_explicit_half_epoch(const lk_als_plan *plan, const void *d_indptr,

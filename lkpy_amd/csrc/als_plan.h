@@ -32,6 +32,9 @@ struct lk_als_plan {
     // when the caller supplied Z = other * OtOr^-1 for this half-epoch (lk_als_plan_set_z)
     int64_t t_short = 0;
     int64_t t_mid = 0;  // rows with 17 .. 64 entries are [t_mid, t_short): als_wb64_kernel
+    // rows [t_cg, n_rows) have at most 16384 / KP entries (256 / 128 / 64 at padded k = 64 /
+    // 128 / 256): what the CG kernel keeps in registers over its iterations (als_cg.hip)
+    int64_t t_cg = 0;
     mutable const float *d_z = nullptr;
     // ... or a caller-owned [n_cols x KP] buffer the LIBRARY fills with Z at every implicit
     // half-epoch (lk_als_plan_set_z_workspace): OtOr^-1 by spd_inverse.hip, Z by the scoring GEMM
@@ -49,6 +52,9 @@ struct lk_als_plan {
     // workspace layout (byte offsets)
     size_t off_status = 0, off_otor = 0, off_delta = 0, off_partial = 0, off_slabs = 0,
            ws_bytes = 0;
+    // >= 0 (set by the CG half-epoch around its call of the exact launchers): solve only the
+    // rows [0, dense_limit) of the order -- the chunked rows -- and leave the rest to the caller
+    mutable int64_t dense_limit = -1;
     struct lk_task_ctl *ctl = nullptr;  // optional cancel / progress block (lk_als_plan_set_ctl)
     float cg_tol = 1e-7f;
     int32_t cg_max_iter = 0;
@@ -61,6 +67,11 @@ struct lk_als_plan {
 };
 
 namespace lk {
+// exact half-epoch for padded k <= 64: one wave per row (als_chol.hip; implicit model)
+int als_chol_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
+                        const float *values, int64_t n_rows, int k, float *this_, int ld_this,
+                        const float *other, int ld_other, const float *otor, int ld_otor, char *ws,
+                        float *out_frob, hipStream_t st);
 // exact half-epoch for padded k = 128 / 256: one workgroup per row (als_blk.hip)
 size_t als_blk_slab_floats(int NT);
 int als_blk_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,

@@ -19,7 +19,24 @@
 // per-target state is updated with plain loads/stores; a barrier separates rows).  The
 // per-target slots live in a per-workgroup slab of the workspace (L2-resident):
 // cnt[t] (-1 = not a target), minval[t], and max_nbrs (s, v) slots.
+//
+// That kernel (`iknn_score_kernel`) costs a query one barrier per history item and an
+// n_items-wide reset, whatever the number of targets: 13 ms for the cfg3 batch (10 000 queries
+// x 100 targets).  Queries with at most KF_NT_MAX targets -- the `score a candidate list` case --
+// take `iknn_score_fast_kernel` instead: the targets go into an LDS hash table, ALL history rows
+// are streamed concurrently (a wave per row, coalesced; an LDS probe per entry), every hit is
+// appended to its target's list (an LDS counter per target, the (weight, history position, value)
+// triples in an L2-resident slab), and afterwards one wave per target ranks its list: kept are the
+// max_nbrs largest by (weight descending, history position ascending) -- exactly the set the
+// one-at-a-time displacement rule keeps, with the ties among equal weights that the reference
+// leaves to its heap order resolved towards the earlier history item -- and summed in rank
+// order, so the result does not depend on the order the hits arrived in.  A target with more than
+// KF_CAP hits sends its whole query to the slot kernel above (second launch over a query list).
 #include "common.h"
+
+// The reference's sums are plain f32 multiplies and adds (Rust never contracts a * b + c): no
+// FMA contraction anywhere in this file, so that `weight * value` is rounded before it is added.
+#pragma clang fp contract(off)
 
 namespace lk {
 
@@ -145,15 +162,501 @@ __global__ __launch_bounds__(KS_THREADS) void iknn_score_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Candidate-list path (see the file header).
+// ---------------------------------------------------------------------------
+constexpr int KF_THREADS = 256;
+constexpr int KF_WAVES = KF_THREADS / 64;
+constexpr int KF_HT = 2048;       // hash slots (load factor <= 0.5)
+constexpr int KF_NT_MAX = 1024;   // targets per query
+constexpr int KF_CAP = 256;       // history rows per round = the most hits one target collects in it
+constexpr int KF_NBR_MAX = 255;   // max_nbrs the per-wave accumulator buffer holds
+constexpr int KF_MAX_WGS = 1024;
+constexpr int KF_U = 8;           // history rows a wave has in flight
+
+// per workgroup: the round's hits (history position, weight, value) per target, and -- for
+// queries with more than KF_CAP history rows -- the accumulators between rounds
+__host__ __device__ inline size_t kf_slab_bytes(int64_t nt_max, int max_nbrs)
+{
+    return ((size_t)nt_max * (KF_CAP * 12 + (size_t)(max_nbrs + 1) * 8) + 255) / 256 * 256;
+}
+
+__device__ __forceinline__ int kf_hash(int t) { return (int)(((unsigned)t * 2654435761u) >> 21); }
+
+__device__ __forceinline__ int64_t kf_readlane64(int64_t v, int l)
+{
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), l);
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(1024) void seg_max_kernel(const int64_t *__restrict__ ptr, int64_t n,
+                                                       int *__restrict__ out)
+{
+    long long m = 0;
+    for (int64_t q = threadIdx.x; q < n; q += 1024) {
+        const long long d = ptr[q + 1] - ptr[q];
+        m = d > m ? d : m;
+    }
+    if (m > 0x7fffffffLL) m = 0x7fffffffLL;
+    atomicMax(out, (int)m);
+}
+
+// ---- the reference's accumulator, restated for ONE lane on LDS arrays -----------------------
+// `Full(BinaryHeap<AccEntry>)` with the REVERSED ordering of accum.rs:170-184: a min-heap on
+// the weight.  std's BinaryHeap::push = sift_up(0, old_len); pop = swap the last element into
+// the root, sift_down_to_bottom(0), sift_up.  Followed step for step so that WHICH of several
+// equal weights is evicted, and the array order the sums run over, are the reference's.
+struct KfHeap {
+    float *w, *v;
+    int len;
+    __device__ __forceinline__ void sift_up(int pos, float ew, float ev)
+    {
+        while (pos > 0) {
+            const int parent = (pos - 1) >> 1;
+            if (ew >= w[parent]) break;  // hole.element() <= hole.get(parent) in reversed order
+            w[pos] = w[parent];
+            v[pos] = v[parent];
+            pos = parent;
+        }
+        w[pos] = ew;
+        v[pos] = ev;
+    }
+    __device__ __forceinline__ void push(float ew, float ev) { sift_up(len++, ew, ev); }
+    __device__ __forceinline__ void pop()
+    {
+        const float ew = w[len - 1], ev = v[len - 1];
+        --len;
+        if (len == 0) return;
+        const int end = len;
+        int pos = 0, child = 1;
+        const int limit = end >= 2 ? end - 2 : 0;
+        while (child <= limit && end >= 2) {
+            if (w[child] >= w[child + 1]) child += 1;  // hole.get(child) <= hole.get(child + 1)
+            w[pos] = w[child];
+            v[pos] = v[child];
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        if (child == end - 1) {
+            w[pos] = w[child];
+            v[pos] = v[child];
+            pos = child;
+        }
+        sift_up(pos, ew, ev);
+    }
+};
+
+template <bool SWAP>
+__global__ __launch_bounds__(KF_THREADS) void iknn_score_fast_kernel(
+    const int64_t *__restrict__ s_ptr, const int32_t *__restrict__ s_idx,
+    const float *__restrict__ s_val, int64_t n_rows, int64_t n_items, int64_t n_queries,
+    const int64_t *__restrict__ ref_ptr, const int32_t *__restrict__ ref_items,
+    const float *__restrict__ ref_rates, const int64_t *__restrict__ tgt_ptr,
+    const int32_t *__restrict__ tgt_items, int max_nbrs, int min_nbrs, char *__restrict__ ws,
+    int nt_max, float *__restrict__ out_scores, int32_t *__restrict__ out_counts,
+    int *__restrict__ status)
+{
+    __shared__ int hkey[KF_HT];              // item number, -1 = empty
+    __shared__ unsigned short hpos[KF_HT];   // the target position that owns the item's list
+    __shared__ unsigned short tc[KF_NT_MAX + 2];  // hits of the current round per target (32-bit atomics
+                                                  // on pairs: see hit())
+    __shared__ short canon[KF_NT_MAX];       // owner position of target position j, -1 = null target
+    __shared__ int acc_len[KF_NT_MAX];       // accumulator: entries | (heap state << 16)
+    __shared__ float res_s[KF_NT_MAX];
+    __shared__ unsigned char rbuf[KF_WAVES][KF_CAP];  // history position of a round hit (< KF_CAP)
+    __shared__ float sw[KF_WAVES][KF_CAP], sv[KF_WAVES][KF_CAP];  // the round's hits in history order
+    __shared__ float hw[KF_WAVES][KF_CAP], hv[KF_WAVES][KF_CAP];  // the accumulator being updated
+    __shared__ float tw_[KF_WAVES][KF_CAP], tv_[KF_WAVES][KF_CAP];  // vector -> heap staging
+    char *slab = ws + (size_t)blockIdx.x * kf_slab_bytes(nt_max, max_nbrs);
+    unsigned char *slab_r = reinterpret_cast<unsigned char *>(slab);                  // [nt_max][CAP]
+    float *slab_w = reinterpret_cast<float *>(slab + (size_t)nt_max * KF_CAP);        // 256-aligned
+    float *slab_v = slab_w + (size_t)nt_max * KF_CAP;
+    float *acc_w = slab_v + (size_t)nt_max * KF_CAP;  // [nt_max][max_nbrs + 1]
+    float *acc_v = acc_w + (size_t)nt_max * (max_nbrs + 1);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool explicit_ = SWAP ? (s_val != nullptr) : (ref_rates != nullptr);
+    const float nanf_ = __builtin_nanf("");
+    int *tc32 = reinterpret_cast<int *>(tc);
+
+    for (int64_t q = blockIdx.x; q < n_queries; q += gridDim.x) {
+        const int64_t rb = ref_ptr[q], re = ref_ptr[q + 1];
+        const int64_t tb = tgt_ptr[q];
+        const int nt = (int)(tgt_ptr[q + 1] - tb);  // <= nt_max <= KF_NT_MAX (checked by the host)
+        for (int i = tid; i < KF_HT; i += KF_THREADS) hkey[i] = -1;
+        for (int j = tid; j < (KF_NT_MAX + 2) / 2; j += KF_THREADS) tc32[j] = 0;
+        for (int j = tid; j < nt; j += KF_THREADS) acc_len[j] = 0;
+        __syncthreads();
+        // the targets (ScoreAccumulator::new_array, accum.rs:30-37); a repeated item shares one list
+        for (int j = tid; j < nt; j += KF_THREADS) {
+            const int t = tgt_items[tb + j];
+            if (t < 0 || t >= n_items) continue;
+            int slot = kf_hash(t);
+            for (;;) {
+                const int old = atomicCAS(&hkey[slot], -1, t);
+                if (old == -1) {
+                    hpos[slot] = (unsigned short)j;
+                    break;
+                }
+                if (old == t) break;
+                slot = (slot + 1) & (KF_HT - 1);
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < nt; j += KF_THREADS) {
+            const int t = tgt_items[tb + j];
+            int c = -1;
+            if (t >= 0 && t < n_items) {
+                int slot = kf_hash(t);
+                while (hkey[slot] != t) slot = (slot + 1) & (KF_HT - 1);
+                c = hpos[slot];
+            }
+            canon[j] = (short)c;
+        }
+        __syncthreads();
+
+        // one hit: the entry (weight s, value rv) of history row number `rr` of this round lands in
+        // the list of the target that holds item t
+        auto hit = [&](int t, int64_t e, float rscalar, int rr) {
+            if (t < 0) return;
+            int slot = kf_hash(t);
+            int kk;
+            while ((kk = hkey[slot]) != -1 && kk != t) slot = (slot + 1) & (KF_HT - 1);
+            if (kk != t) return;
+            const float s = SWAP ? rscalar : s_val[e];
+            const float rv = SWAP ? (explicit_ ? s_val[e] : 0.f) : rscalar;
+            if (s != s) {
+                atomicCAS(status, 0, 1);
+                return;
+            }
+            const int j = hpos[slot];
+            // 16-bit counter inside a 32-bit LDS atomic (counts stay below 2^16: no carry)
+            const int old = atomicAdd(&tc32[j >> 1], (j & 1) ? 0x10000 : 1);
+            const int pos = (j & 1) ? (int)((unsigned)old >> 16) : (old & 0xffff);
+            if (pos >= KF_CAP) {  // a matrix row that names a column twice
+                atomicCAS(&status[1], 0, 1);
+                return;
+            }
+            const size_t at = (size_t)j * KF_CAP + pos;
+            slab_r[at] = (unsigned char)rr;
+            slab_w[at] = s;
+            slab_v[at] = rv;
+        };
+
+        for (int64_t r0 = rb;; r0 += KF_CAP) {
+            const int64_t r1 = re - r0 > KF_CAP ? r0 + KF_CAP : re;
+            const bool last = r1 >= re;
+            // ---- stream the history rows [r0, r1): a wave takes KF_U rows at a time -----------
+            for (int64_t rbase = r0 + (int64_t)wave * KF_U; rbase < r1; rbase += KF_WAVES * KF_U) {
+                int64_t myb = 0, mye = 0;
+                float myrate = 0.f;
+                if (lane < KF_U && rbase + lane < r1) {
+                    const int ri = ref_items[rbase + lane];
+                    if (ri >= 0 && ri < n_rows) {  // (null reference rows stay empty)
+                        myb = s_ptr[ri];
+                        mye = s_ptr[ri + 1];
+                    }
+                    if (SWAP || explicit_) myrate = ref_rates[rbase + lane];
+                }
+                int64_t sb[KF_U];
+                int ln[KF_U], t0[KF_U], t1[KF_U];
+                float rate[KF_U];
+#pragma unroll
+                for (int u = 0; u < KF_U; ++u) {
+                    sb[u] = kf_readlane64(myb, u);
+                    ln[u] = (int)(kf_readlane64(mye, u) - sb[u]);
+                    rate[u] = bcast(myrate, u);
+                    t0[u] = lane < ln[u] ? s_idx[sb[u] + lane] : -1;
+                    t1[u] = lane + 64 < ln[u] ? s_idx[sb[u] + 64 + lane] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < KF_U; ++u) {
+                    const int rr = (int)(rbase - r0) + u;
+                    hit(t0[u], sb[u] + lane, rate[u], rr);
+                    hit(t1[u], sb[u] + 64 + lane, rate[u], rr);
+                    for (int e = 128 + lane; e < ln[u]; e += 64)
+                        hit(s_idx[sb[u] + e], sb[u] + e, rate[u], rr);
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            // ---- feed the round's hits to the accumulators, in history order: wave per target ----
+            // (owner positions only: a null target or a repeat is copied from its owner at the
+            // end; the hits of the NEXT target are fetched while this one is worked on)
+            auto next_owner = [&](int j) {
+                while (j < nt && (canon[j] != j || (tc[j] == 0 && !last))) j += KF_WAVES;
+                return j;
+            };
+            auto load_hits = [&](int j, int c, int (&rr)[KF_CAP / 64], float (&w)[KF_CAP / 64],
+                                 float (&v)[KF_CAP / 64]) {
+#pragma unroll
+                for (int e = 0; e < KF_CAP / 64; ++e) {
+                    const int i = lane + 64 * e;
+                    rr[e] = 0;
+                    w[e] = v[e] = 0.f;
+                    if (i < c) {
+                        const size_t at = (size_t)j * KF_CAP + i;
+                        rr[e] = slab_r[at];
+                        w[e] = slab_w[at];
+                        v[e] = slab_v[at];
+                    }
+                }
+            };
+            int j = next_owner(wave);
+            int c = j < nt ? tc[j] : 0;
+            int rr_[KF_CAP / 64];
+            float w_[KF_CAP / 64], v_[KF_CAP / 64];
+            load_hits(j < nt ? j : 0, j < nt ? c : 0, rr_, w_, v_);
+            while (j < nt) {
+                const int jn = next_owner(j + KF_WAVES);
+                const int cn = jn < nt ? tc[jn] : 0;
+                int nrr[KF_CAP / 64];
+                float nw[KF_CAP / 64], nv[KF_CAP / 64];
+                load_hits(jn < nt ? jn : 0, jn < nt ? cn : 0, nrr, nw, nv);
+
+                int len = acc_len[j] & 0xffff;
+                bool full = (acc_len[j] >> 16) != 0;
+                // the accumulator as the previous round left it
+                if (r0 > rb && len > 0) {
+                    for (int i = lane; i < len; i += 64) {
+                        hw[wave][i] = acc_w[(size_t)j * (max_nbrs + 1) + i];
+                        hv[wave][i] = acc_v[(size_t)j * (max_nbrs + 1) + i];
+                    }
+                }
+                // sort the hits by history position (distinct): rank = smaller positions
+                int rank[KF_CAP / 64];
+#pragma unroll
+                for (int e = 0; e < KF_CAP / 64; ++e) {
+                    rank[e] = 0;
+                    if (lane + 64 * e < c) rbuf[wave][lane + 64 * e] = (unsigned char)rr_[e];
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int jj = 0; jj < c; ++jj) {
+                    const int x = rbuf[wave][jj];
+#pragma unroll
+                    for (int e = 0; e < KF_CAP / 64; ++e) rank[e] += (x < rr_[e]) ? 1 : 0;
+                }
+#pragma unroll
+                for (int e = 0; e < KF_CAP / 64; ++e) {
+                    if (lane + 64 * e < c) {
+                        sw[wave][rank[e]] = w_[e];
+                        sv[wave][rank[e]] = v_[e];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const float *fw = hw[wave], *fv = hv[wave];  // where the final array is
+                if (last && len == 0 && !full && c <= max_nbrs) {
+                    // the common case -- one round, everything fits: the sorted hits ARE the vector
+                    fw = sw[wave];
+                    fv = sv[wave];
+                    len = c;
+                } else {
+                    // Partial(vec): push while there is room (accum.rs:103-104) -- all lanes at once
+                    int i0 = 0;
+                    if (!full) {
+                        const int room = max_nbrs - len;
+                        i0 = c < room ? c : room;
+                        for (int i = lane; i < i0; i += 64) {
+                            hw[wave][len + i] = sw[wave][i];
+                            hv[wave][len + i] = sv[wave][i];
+                        }
+                        len += i0;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (i0 < c) {  // the rest meets a full accumulator: one lane, entry by entry
+                        if (!full) {
+                            // Partial -> Full (heap_mut, accum.rs:76-83): the vector is popped from
+                            // the back and every element pushed onto an empty heap
+                            for (int i = lane; i < len; i += 64) {
+                                tw_[wave][i] = hw[wave][i];
+                                tv_[wave][i] = hv[wave][i];
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        if (lane == 0) {
+                            KfHeap h{hw[wave], hv[wave], len};
+                            if (!full) {
+                                h.len = 0;
+                                for (int i = len - 1; i >= 0; --i) h.push(tw_[wave][i], tv_[wave][i]);
+                            }
+                            for (int i = i0; i < c; ++i) {
+                                const float ew = sw[wave][i];
+                                if (ew > h.w[0]) {  // accum.rs:108: strictly greater than the minimum
+                                    h.push(ew, sv[wave][i]);
+                                    while (h.len > max_nbrs) h.pop();
+                                }
+                            }
+                        }
+                        full = true;  // (len stays max_nbrs)
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                if (!last) {
+                    for (int i = lane; i < len; i += 64) {
+                        acc_w[(size_t)j * (max_nbrs + 1) + i] = hw[wave][i];
+                        acc_v[(size_t)j * (max_nbrs + 1) + i] = hv[wave][i];
+                    }
+                    if (lane == 0) {
+                        acc_len[j] = len | (full ? 0x10000 : 0);
+                        tc[j] = 0;
+                    }
+                } else {
+                    // total_weight / weighted_sum (accum.rs:121-140): sequential f32 sums over the
+                    // array, the product rounded before it is added (no contraction: see the
+                    // pragma).  The array goes into registers (lane = position), the running sums
+                    // take one element after the other by readlane.
+                    float xw[KF_CAP / 64], xp[KF_CAP / 64];
+#pragma unroll
+                    for (int e = 0; e < KF_CAP / 64; ++e) {
+                        const int i = lane + 64 * e;
+                        xw[e] = i < len ? fw[i] : 0.f;
+                        xp[e] = i < len ? xw[e] * fv[i] : 0.f;
+                    }
+                    float tw = 0.f, wsum = 0.f;
+                    if (len >= min_nbrs) {
+#pragma unroll
+                        for (int e = 0; e < KF_CAP / 64; ++e) {
+                            const int m = len - 64 * e < 64 ? len - 64 * e : 64;
+                            for (int l = 0; l < m; ++l) {
+                                tw = tw + bcast(xw[e], l);
+                                wsum = wsum + bcast(xp[e], l);
+                            }
+                        }
+                    }
+                    if (lane == 0) {
+                        acc_len[j] = len;
+                        res_s[j] = (len >= min_nbrs && len > 0) ? (explicit_ ? wsum / tw : tw) : nanf_;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                j = jn;
+                c = cn;
+#pragma unroll
+                for (int e = 0; e < KF_CAP / 64; ++e) {
+                    rr_[e] = nrr[e];
+                    w_[e] = nw[e];
+                    v_[e] = nv[e];
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (last) break;
+        }
+        for (int j = tid; j < nt; j += KF_THREADS) {
+            const int jo = canon[j];
+            out_scores[tb + j] = jo >= 0 ? res_s[jo] : nanf_;
+            out_counts[tb + j] = jo >= 0 ? (acc_len[jo] & 0xffff) : -1;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace lk
+
+namespace lk {
+
+static int64_t g_score_stats[3] = {0, 0, 0};  // last call: queries on the list kernel, on the slot kernel, max targets
+
+static inline int64_t ks_slot_wgs(int64_t n_queries)
+{
+    int64_t wgs = n_queries < KS_MAX_WGS ? n_queries : KS_MAX_WGS;
+    return wgs < 1 ? 1 : wgs;
+}
+
+// the slab region serves either kernel: slot slabs for up to KS_MAX_WGS workgroups, and room for
+// the list kernel to run at least min(queries, 256) workgroups at the longest admissible target
+// list (more workgroups when the lists are shorter)
+static inline size_t ks_region_bytes(int64_t n_items, int64_t n_queries, int max_nbrs)
+{
+    const size_t a = (size_t)ks_slot_wgs(n_queries) * ks_slab_bytes(n_items, max_nbrs);
+    const size_t b = max_nbrs <= KF_NBR_MAX
+                         ? (size_t)ks_slot_wgs(n_queries) * kf_slab_bytes(KF_NT_MAX, max_nbrs)
+                         : 0;
+    return a > b ? a : b;
+}
+
+static bool score_fast_enabled()
+{
+    const char *e = getenv("LK_KNN_SCORE_LISTS");  // A/B knob and test hook (read per call)
+    return !(e && e[0] == '0');
+}
+
+// both scorers: header (status words) | per-workgroup slabs
+template <bool SWAP>
+static int score_batch(const char *what, const int64_t *d_ptr, const int32_t *d_idx,
+                       const float *d_val, int64_t n_rows, int64_t n_items, int64_t n_queries,
+                       const int64_t *d_ref_ptr, const int32_t *d_ref_items,
+                       const float *d_ref_rates, const int64_t *d_tgt_ptr,
+                       const int32_t *d_tgt_items, int32_t max_nbrs, int32_t min_nbrs, void *d_ws,
+                       float *d_out_scores, int32_t *d_out_counts, hipStream_t st)
+{
+    char *ws = static_cast<char *>(d_ws);
+    int *status = reinterpret_cast<int *>(ws);  // [0] NaN seen, [1] repeated column, [2] max targets
+    char *slabs = ws + 256;
+    const size_t slot_slab = ks_slab_bytes(n_items, max_nbrs);
+    const int64_t slot_wgs = ks_slot_wgs(n_queries);
+    LK_HIP_CHECK(hipMemsetAsync(status, 0, 256, st));
+    int h[3] = {0, 0, 0};
+    g_score_stats[0] = g_score_stats[1] = g_score_stats[2] = 0;
+    bool lists = score_fast_enabled() && max_nbrs <= KF_NBR_MAX;
+    int64_t fast_wgs = 0;
+    if (lists) {
+        hipLaunchKernelGGL(seg_max_kernel, dim3(1), dim3(1024), 0, st, d_tgt_ptr, n_queries,
+                           status + 2);
+        LK_HIP_CHECK(hipMemcpyAsync(h, status, sizeof(h), hipMemcpyDeviceToHost, st));
+        LK_HIP_CHECK(hipStreamSynchronize(st));
+        g_score_stats[2] = h[2];
+        fast_wgs = n_queries < KF_MAX_WGS ? n_queries : KF_MAX_WGS;
+        if (h[2] > 0) {
+            const int64_t fit = (int64_t)(ks_region_bytes(n_items, n_queries, max_nbrs) /
+                                          kf_slab_bytes(h[2], max_nbrs));
+            if (fit < fast_wgs) fast_wgs = fit;
+        }
+        lists = h[2] <= KF_NT_MAX && fast_wgs >= 1;
+    }
+    if (lists) {
+        g_score_stats[0] = n_queries;
+        hipLaunchKernelGGL(iknn_score_fast_kernel<SWAP>, dim3((unsigned)fast_wgs),
+                           dim3(KF_THREADS), 0, st, d_ptr, d_idx, d_val, n_rows, n_items,
+                           n_queries, d_ref_ptr, d_ref_items, d_ref_rates, d_tgt_ptr, d_tgt_items,
+                           max_nbrs, min_nbrs, slabs, h[2] > 0 ? h[2] : 1, d_out_scores,
+                           d_out_counts, status);
+    } else {
+        g_score_stats[1] = n_queries;
+        hipLaunchKernelGGL(iknn_score_kernel<SWAP>, dim3((unsigned)slot_wgs), dim3(KS_THREADS), 0,
+                           st, d_ptr, d_idx, d_val, n_rows, n_items, n_queries, d_ref_ptr,
+                           d_ref_items, d_ref_rates, d_tgt_ptr, d_tgt_items, max_nbrs, min_nbrs,
+                           slabs, slot_slab, d_out_scores, d_out_counts, status);
+    }
+    LK_HIP_CHECK(hipGetLastError());
+    LK_HIP_CHECK(hipMemcpyAsync(h, status, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    LK_HIP_CHECK(hipStreamSynchronize(st));
+    if (h[0] != 0) {
+        set_error("similarity is null");
+        return LK_E_NAN_SIM;
+    }
+    if (h[1] != 0) {
+        set_error("%s: a matrix row names the same column more than once", what);
+        return LK_E_INVALID;
+    }
+    return LK_OK;
+}
+
 }  // namespace lk
 
 extern "C" size_t lk_iknn_score_workspace_bytes(int64_t n_items, int64_t n_queries,
                                                 int32_t max_nbrs)
 {
     if (n_items < 0 || max_nbrs < 1) return 0;
-    int64_t wgs = n_queries < lk::KS_MAX_WGS ? n_queries : lk::KS_MAX_WGS;
-    if (wgs < 1) wgs = 1;
-    return 256 + (size_t)wgs * lk::ks_slab_bytes(n_items, max_nbrs);
+    return 256 + lk::ks_region_bytes(n_items, n_queries, max_nbrs);
+}
+
+extern "C" void lk_knn_score_last_stats(int64_t *out3)
+{
+    if (out3)
+        for (int i = 0; i < 3; ++i) out3[i] = lk::g_score_stats[i];
 }
 
 extern "C" int lk_iknn_score_batch(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
@@ -169,26 +672,11 @@ extern "C" int lk_iknn_score_batch(const int64_t *d_sim_indptr, const int32_t *d
     if (n_queries == 0) return LK_OK;
     LK_REQUIRE(d_sim_indptr && d_ref_ptr && d_tgt_ptr && d_ws && d_out_scores && d_out_counts,
                "lk_iknn_score_batch: null pointer");
-    hipStream_t st = lk::as_stream(stream);
-    char *ws = static_cast<char *>(d_ws);
-    int *status = reinterpret_cast<int *>(ws);
-    LK_HIP_CHECK(hipMemsetAsync(status, 0, 256, st));
-    int64_t wgs = n_queries < lk::KS_MAX_WGS ? n_queries : lk::KS_MAX_WGS;
-    hipLaunchKernelGGL(lk::iknn_score_kernel<false>, dim3((unsigned)wgs), dim3(lk::KS_THREADS), 0,
-                       st, d_sim_indptr, d_sim_indices, d_sim_values, n_items, n_items, n_queries,
-                       d_ref_ptr,
-                       d_ref_items, d_ref_rates, d_tgt_ptr, d_tgt_items, max_nbrs, min_nbrs,
-                       ws + 256, lk::ks_slab_bytes(n_items, max_nbrs), d_out_scores, d_out_counts,
-                       status);
-    LK_HIP_CHECK(hipGetLastError());
-    int h = 0;
-    LK_HIP_CHECK(hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, st));
-    LK_HIP_CHECK(hipStreamSynchronize(st));
-    if (h != 0) {
-        lk::set_error("similarity is null");
-        return LK_E_NAN_SIM;
-    }
-    return LK_OK;
+    return lk::score_batch<false>("lk_iknn_score_batch", d_sim_indptr, d_sim_indices,
+                                  d_sim_values, n_items, n_items, n_queries, d_ref_ptr,
+                                  d_ref_items, d_ref_rates, d_tgt_ptr, d_tgt_items, max_nbrs,
+                                  min_nbrs, d_ws, d_out_scores, d_out_counts,
+                                  lk::as_stream(stream));
 }
 
 extern "C" int lk_uknn_score_batch(const int64_t *d_rat_indptr, const int32_t *d_rat_indices,
@@ -204,25 +692,10 @@ extern "C" int lk_uknn_score_batch(const int64_t *d_rat_indptr, const int32_t *d
     if (n_queries == 0) return LK_OK;
     LK_REQUIRE(d_rat_indptr && d_nbr_ptr && d_tgt_ptr && d_ws && d_out_scores && d_out_counts,
                "lk_uknn_score_batch: null pointer");
-    hipStream_t st = lk::as_stream(stream);
-    char *ws = static_cast<char *>(d_ws);
-    int *status = reinterpret_cast<int *>(ws);
-    LK_HIP_CHECK(hipMemsetAsync(status, 0, 256, st));
-    int64_t wgs = n_queries < lk::KS_MAX_WGS ? n_queries : lk::KS_MAX_WGS;
-    hipLaunchKernelGGL(lk::iknn_score_kernel<true>, dim3((unsigned)wgs), dim3(lk::KS_THREADS), 0,
-                       st, d_rat_indptr, d_rat_indices, d_rat_values, n_users, n_items, n_queries,
-                       d_nbr_ptr, d_nbr_rows, d_nbr_sims, d_tgt_ptr, d_tgt_items, max_nbrs,
-                       min_nbrs, ws + 256, lk::ks_slab_bytes(n_items, max_nbrs), d_out_scores,
-                       d_out_counts, status);
-    LK_HIP_CHECK(hipGetLastError());
-    int h = 0;
-    LK_HIP_CHECK(hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, st));
-    LK_HIP_CHECK(hipStreamSynchronize(st));
-    if (h != 0) {
-        lk::set_error("similarity is null");
-        return LK_E_NAN_SIM;
-    }
-    return LK_OK;
+    return lk::score_batch<true>("lk_uknn_score_batch", d_rat_indptr, d_rat_indices, d_rat_values,
+                                 n_users, n_items, n_queries, d_nbr_ptr, d_nbr_rows, d_nbr_sims,
+                                 d_tgt_ptr, d_tgt_items, max_nbrs, min_nbrs, d_ws, d_out_scores,
+                                 d_out_counts, lk::as_stream(stream));
 }
 
 // ---------------------------------------------------------------------------

@@ -183,13 +183,19 @@ def test_not_spd_reports_error(gpu, rng):
         plan.check_status()
 
 
-@pytest.mark.parametrize("k", [64, 100, 128, 256])
-def test_half_epoch_cg(gpu, oracle, rng, k):
-    """The CG solver (k > 64; forced at k = 64): tolerance-terminated, so it converges to the
-    exact (Cholesky / sposv) answer of the reference."""
+@pytest.mark.parametrize("k,mode", [(64, 2), (64, 1), (64, 0), (100, 2), (128, 2), (128, 0),
+                                    (256, 2), (256, 1), (256, 0)])
+def test_half_epoch_cg(gpu, oracle, rng, monkeypatch, k, mode):
+    """The CG solver: tolerance-terminated, so it converges to the exact (Cholesky / sposv)
+    answer of the reference.  Rows of 1 ... 2 500 entries.  LK_ALS_CG_HYBRID = 2 (default): rows
+    longer than the kernel keeps in registers (256 / 128 / 64 entries at padded k = 64 / 128 /
+    256) are solved by the exact kernels inside the CG half-epoch; 1: only the chunked row
+    (2 500 entries) is, the 700-entry row streams its tail in every iteration; 0: CG iterates
+    over every row."""
     from lkpy_amd import _device as D
     from lkpy_amd import _native
 
+    monkeypatch.setenv("LK_ALS_CG_HYBRID", str(mode))
     n_rows, n_cols = 1500, 3000
     mat = _random_csr(rng, n_rows, n_cols, 25, long_rows=(2500, 700))
     other = (rng.standard_normal((n_cols, k)) * 0.1).astype(np.float32)
@@ -206,6 +212,12 @@ def test_half_epoch_cg(gpu, oracle, rng, k):
     d_other = D.to_device_padded(other, gpu)
     frob = plan.half_epoch(d_this, d_other, D.Gramian(k, gpu)(d_other, 0.1))
     plan.check_status()
+    its, cg_rows = plan.cg_stats()
+    lens = np.diff(mat.indptr)
+    limit = {0: 1 << 40, 1: 2048, 2: 16384 // D.padded_dim(k)}[mode]
+    assert cg_rows == int(np.sum((lens > 0) & (lens <= limit)))
+    print(f"\nk {k} mode {mode}: {cg_rows} of {int(np.sum(lens > 0))} rows by CG, "
+          f"{its / cg_rows:.1f} iterations per row")
     got = D.to_host_unpadded(d_this, k)
     empty = np.diff(mat.indptr) == 0
     assert np.all(got[empty] == 0.0)

@@ -29,12 +29,18 @@ def model(oracle, ml_small, gpu):
     return sims, dsims, means
 
 
+@pytest.mark.parametrize("lists", [True, False])
 @pytest.mark.parametrize("explicit", [True, False])
 @pytest.mark.parametrize("max_nbrs,min_nbrs", [(20, 1), (5, 3), (100, 1)])
-def test_score_batch_matches_oracle(gpu, oracle, ml_small, model, rng, explicit, max_nbrs,
-                                    min_nbrs):
+def test_score_batch_matches_oracle(gpu, oracle, ml_small, model, rng, monkeypatch, explicit,
+                                    max_nbrs, min_nbrs, lists):
+    """Both kernels: the candidate-list kernel (LDS target hash, the reference's accumulator
+    followed step for step: no tie caveat) and, with LK_KNN_SCORE_LISTS=0, the slot kernel (which
+    of several EQUAL similarities is evicted at the max_nbrs boundary may differ from the
+    reference's heap order there)."""
     from lkpy_amd import _device as D
 
+    monkeypatch.setenv("LK_KNN_SCORE_LISTS", "1" if lists else "0")
     sims, dsims, means = model
     csr = sps.csr_array(ml_small["rmat"])
     users = rng.choice(csr.shape[0], 40, replace=False)
@@ -56,8 +62,11 @@ def test_score_batch_matches_oracle(gpu, oracle, ml_small, model, rng, explicit,
     gs, gc = D.iknn_score_batch(dsims, rp, ri, rr if explicit else None, tp, ti, max_nbrs,
                                 min_nbrs)
     gs, gc = gs.cpu().numpy(), gc.cpu().numpy()
+    n_list, n_slot, nt_max = D.knn_score_last_stats()
+    assert (n_list, n_slot) == ((len(users), 0) if lists else (0, len(users)))
+    assert nt_max == 300 or not lists
     dense = None
-    n_tie = 0
+    n_tie = n_bits = n_ok = 0
     for q in range(len(users)):
         ws_, wc = oracle.iknn_score(sims, hists[q], rates[q] if explicit else None, tgts[q],
                                     max_nbrs, min_nbrs)
@@ -66,13 +75,15 @@ def test_score_batch_matches_oracle(gpu, oracle, ml_small, model, rng, explicit,
         assert np.array_equal(np.isnan(s), np.isnan(ws_))
         ok = ~np.isnan(ws_)
         err = np.abs(s - ws_) / np.maximum(np.abs(ws_), 1e-3)
-        if not explicit:
-            assert np.all(err[ok] <= 1e-5)
+        n_ok += int(ok.sum())
+        n_bits += int(np.sum(s[ok].view(np.uint32) == ws_[ok].view(np.uint32)))
+        if lists or not explicit:
+            assert np.all(err[ok] <= 1e-5), (q, float(err[ok].max()))
             continue
-        # Which of several EQUAL-similarity neighbours is evicted at the max_nbrs boundary is
-        # unspecified in the reference (BinaryHeap order, accum.rs:106-113).  Every mismatch
-        # must be exactly such a tie, and the GPU score must be a valid choice among the tied
-        # entries (between the smallest- and largest-rating choices).
+        # Slot kernel: which of several EQUAL-similarity neighbours is evicted at the max_nbrs
+        # boundary follows slot order, not the reference's BinaryHeap order (accum.rs:106-113).
+        # Every mismatch must be exactly such a tie, and the GPU score must be a valid choice
+        # among the tied entries (between the smallest- and largest-rating choices).
         for j in np.flatnonzero(ok & (err > 1e-4)):
             if dense is None:
                 dense = sims.toarray()
@@ -93,7 +104,66 @@ def test_score_batch_matches_oracle(gpu, oracle, ml_small, model, rng, explicit,
             hi = (base + kth * tied_v[-n_free:].sum()) / tw
             assert lo - 1e-4 <= s[j] <= hi + 1e-4, (q, j, lo, s[j], hi)
             n_tie += 1
-    print("tie-induced differences:", n_tie)
+    print(f"\n{'list' if lists else 'slot'} kernel: tie-induced differences {n_tie}; "
+          f"scores bit-identical to the oracle's {n_bits} of {n_ok}")
+    if lists:
+        assert n_bits == n_ok  # same accumulator steps, same summation order, same roundings
+
+
+def test_list_kernel_repeats_long_lists_and_rounds(gpu, oracle, ml_small, model, rng):
+    """The candidate-list kernel's corners: a target item named more than once, exactly 1024
+    targets (the limit; 1025 go to the slot kernel), the heaviest histories (several rounds of
+    256 history rows, the accumulators carried between them) on the most popular targets (lists
+    far past max_nbrs: long runs of heap pushes and pops), max_nbrs = 255 (the limit) and 256."""
+    from lkpy_amd import _device as D
+
+    sims, dsims, means = model
+    csr = sps.csr_array(ml_small["rmat"])
+    pop = np.argsort(-np.diff(sps.csc_array(csr).indptr), kind="stable")
+    heavy = np.argsort(-np.diff(csr.indptr), kind="stable")[:3]
+    light = np.argsort(np.diff(csr.indptr), kind="stable")[:5]
+
+    def hist(u):
+        h = csr.indices[csr.indptr[u] : csr.indptr[u + 1]].astype(np.int32)
+        return h, csr.data[csr.indptr[u] : csr.indptr[u + 1]].astype(np.float32) - means[h]
+
+    def run(users, tgts, max_nbrs, min_nbrs, exact=True):
+        hs, rs = zip(*[hist(u) for u in users])
+        rp, ri, _ = _dev_lists(list(hs), np.int32, gpu)
+        _, rr, _ = _dev_lists(list(rs), np.float32, gpu)
+        tp, ti, tptr = _dev_lists(tgts, np.int32, gpu)
+        gs, gc = D.iknn_score_batch(dsims, rp, ri, rr, tp, ti, max_nbrs, min_nbrs)
+        gs, gc = gs.cpu().numpy(), gc.cpu().numpy()
+        stats = D.knn_score_last_stats()
+        for q in range(len(users)):
+            ws_, wc = oracle.iknn_score(sims, hs[q], rs[q], tgts[q], max_nbrs, min_nbrs)
+            s, c = gs[tptr[q] : tptr[q + 1]], gc[tptr[q] : tptr[q + 1]]
+            assert np.array_equal(c, wc)
+            assert np.array_equal(np.isnan(s), np.isnan(ws_))
+            ok = ~np.isnan(ws_)
+            if exact:
+                assert np.array_equal(s[ok].view(np.uint32), ws_[ok].view(np.uint32))
+            else:
+                # (slot kernel: equal similarities at the max_nbrs boundary, see above)
+                err = np.abs(s - ws_) / np.maximum(np.abs(ws_), 1e-3)
+                assert np.mean(err[ok] <= 1e-5) > 0.85 and np.all(err[ok] < 0.05)
+        return stats
+
+    # repeats + nulls
+    t = rng.choice(csr.shape[1], 200, replace=False).astype(np.int32)
+    t = np.concatenate([t, t[:50], [-1], t[10:20]]).astype(np.int32)
+    assert run(light, [t] * len(light), 20, 2)[:2] == (len(light), 0)
+    # 1024 targets: still the list kernel; 1025: slot kernel
+    t1024 = pop[:1024].astype(np.int32)
+    st = run(light[:2], [t1024, t1024[:7]], 20, 1)
+    assert st == (2, 0, 1024)
+    assert run(light[:2], [pop[:1025].astype(np.int32), t1024[:7]], 20, 1, exact=False)[:2] == (0, 2)
+    # the heaviest histories (2 698, 1 864, 1 291 items: 11 / 8 / 6 rounds) x popular targets
+    tp_ = pop[:100].astype(np.int32)
+    for mn in (20, 100, 255):
+        assert run(list(heavy) + list(light[:2]), [tp_] * 5, mn, 1)[:2] == (5, 0)
+    assert run(list(heavy[:1]), [tp_], 256, 1, exact=False)[:2] == (0, 1)  # past the list kernel's limit
+    assert len(hist(heavy[0])[0]) > 4 * 256
 
 
 def test_known_preds_golden(gpu, oracle, ml_small, model):

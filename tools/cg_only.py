@@ -35,5 +35,10 @@ for _ in range(4):
     torch.cuda.synchronize()
     times.append(time.perf_counter() - t0)
 eng.check()
+iu_, ru_ = eng.u_plan.cg_stats()
+ii_, ri_ = eng.i_plan.cg_stats()
 print(json.dumps({"k": k, "tol": tol, "ms_per_epoch": [round(t * 1e3, 2) for t in times],
-                  "deltas": [float(du), float(di)]}))
+                  "deltas": [float(du), float(di)],
+                  "cg_iterations_per_row": {"user": round(iu_ / max(ru_, 1), 2),
+                                            "item": round(ii_ / max(ri_, 1), 2)},
+                  "rows": [ru_, ri_]}))

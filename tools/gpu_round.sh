@@ -1,9 +1,9 @@
 mkdir -p gpurun_out
-timeout 1800 python -m pytest tests -m gpu -q -s > gpurun_out/gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gputest.log
-tail -n 3 gpurun_out/gputest.log
-PROF_CMD="python tools/cg_only.py 64 1e-6" bash tools/prof_als.sh r03_cg > gpurun_out/prof_cg.log 2>&1
-python tools/summarize_prof.py gpurun_out/prof_r03_cg gpurun_out/r03_cg_k64 > /dev/null 2>&1
-rm -rf gpurun_out/prof_r03_cg
-cp gpurun_out/r03_cg_k64_*.csv profiles/ 2>/dev/null
-timeout 900 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?" >> gpurun_out/bench.err
-tail -n 1 gpurun_out/bench.err
+timeout 900 python -m pytest tests/test_gpu_iknn_score.py tests/test_gpu_uknn.py tests/test_gpu_seam.py tests/test_gpu_pipeline.py -m gpu -q -s > gpurun_out/gputest_knn.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gputest_knn.log
+tail -n 3 gpurun_out/gputest_knn.log
+timeout 600 python -m pytest tests/test_gpu_als.py -m gpu -q -s -k "cg" > gpurun_out/gputest_cg.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gputest_cg.log
+tail -n 3 gpurun_out/gputest_cg.log
+rm -f gpurun_out/cg_only.log
+for k in 64 128 256; do timeout 300 python tools/cg_only.py $k 1e-6 >> gpurun_out/cg_only.log 2>&1; done
+cat gpurun_out/cg_only.log
+timeout 600 python bench.py --steps 5 --no-topk --no-fit --no-k128 --no-cfg5 --no-cg > gpurun_out/bench_knn.log 2> gpurun_out/bench_knn.err; echo "bench rc=$?"
