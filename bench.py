@@ -1081,15 +1081,38 @@ def main():
             torch.cuda.synchronize(dev)
             out_cg[name + "_ms_per_epoch"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
             e2.check()
+            if name == "cg":
+                (iu_, ru_), (ii_, ri_) = e2.u_plan.cg_stats(), e2.i_plan.cg_stats()
+                out_cg["cg_rows"] = {"user": ru_, "item": ri_,
+                                     "of": [int(np.sum(np.diff(ui.indptr) > 0)),
+                                            int(np.sum(np.bincount(ui.indices,
+                                                                   minlength=ui.shape[1]) > 0))]}
+                out_cg["cg_iterations_per_row"] = {"user": round(iu_ / max(ru_, 1), 2),
+                                                   "item": round(ii_ / max(ri_, 1), 2)}
             del e2
         rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))  # noqa: E731
-        tr, src = pmc_traffic("r*_cg_k%d_counters.csv" % k, "als_cg_kernel")
-        return {"what": "solver='cg' (Jacobi-preconditioned CG on the implicit normal equations, "
-                "tol 1e-6, warm start) vs the exact solver, from the same trained factors",
+
+        def rows(a, b):
+            nb = np.linalg.norm(b, axis=1)
+            d = np.linalg.norm(a - b, axis=1) / np.maximum(nb, 1e-30)
+            d[nb == 0] = 0.0
+            return {"row_rel_max": float(d.max()), "rows_over_1e-4": int((d > 1e-4).sum())}
+
+        # (two instances: a workgroup per row, a wave per row; one launch each per half-epoch)
+        kp = 64 if k <= 64 else (128 if k <= 128 else 256)
+        tr4, src = pmc_traffic("r*_cg_k%d_counters.csv" % k, "als_cg_kernel<%d, false, 4>" % kp)
+        tr1, _ = pmc_traffic("r*_cg_k%d_counters.csv" % k, "als_cg_kernel<%d, false, 1>" % kp)
+        tr = None if tr4 is None or tr1 is None else tr4 + tr1
+        return {"what": "solver='cg' vs the exact solver, one epoch from the same trained "
+                "factors: Jacobi-preconditioned matrix-free CG (tol 1e-6, warm start) on the rows "
+                "whose gathered factor rows stay in registers over the iterations (<= 16384 / k' "
+                "entries), the exact kernels on the longer rows (csrc/als_cg.hip)",
                 **out_cg,
                 "one_epoch_rel_diff_P": rel(engs["cg"][0], engs["exact"][0]),
                 "one_epoch_rel_diff_Q": rel(engs["cg"][1], engs["exact"][1]),
-                "hbm_bytes_per_launch_from_pmc": tr, "pmc_source": src}
+                "user_rows": rows(engs["cg"][0], engs["exact"][0]),
+                "item_rows": rows(engs["cg"][1], engs["exact"][1]),
+                "hbm_bytes_per_half_epoch_cg_kernels_from_pmc": tr, "pmc_source": src}
 
     def k128_leg():
         """BASELINE.json configs[3] on ONE GPU: the same data at k = 128 (``als_blk.hip``): a few

@@ -1,27 +1,29 @@
 // als_cg.hip -- implicit-ALS half-epoch, Jacobi-preconditioned conjugate gradient, gfx950.
 //
-// Same contract as the Cholesky kernel (src/accel/als/implicit.rs:35-125): per CSR row
+// Same contract as the Cholesky kernels (src/accel/als/implicit.rs:35-125): per CSR row
 //     A = OtOr + sum_j v_j q_j q_j^T,   y = sum_j (v_j + 1) q_j,   A x = y,
 // but A is never formed: A p = OtOr p + sum_j v_j q_j (q_j . p)  (the north star's "per-user
-// CG step").  This is the solver for k > 64 (normal matrices of 64 KiB / 256 KiB do not fit
-// the per-wave register/LDS budget of the exact path); it is tolerance-terminated
-// (||r|| <= tol ||y||, at most max_iter iterations), warm-started from the previous
-// factor row, so its result converges to the exact solve the reference computes.
+// CG step").  Tolerance-terminated (||r|| <= tol ||y||, at most max_iter iterations), warm-started
+// from the previous factor row, so the result converges to the exact solve the reference computes.
+// An OPTION (solver = "cg"): the exact kernels are the default at every k.
 //
-// One workgroup (4 waves) per row.  Every wave keeps an identical copy of the CG vectors
-// (x, r, z, p, diagonal), lane l holding the FPL = KP/64 contiguous features l*FPL..; the
-// items of the row are dealt to the waves (item j -> wave j mod 4): one coalesced 4*KP-byte
-// gather per item and iteration, a wave-shuffle reduction for q_j . p, an axpy into the
-// wave's partial A p.  The dense term is split the same way (wave w takes rows
-// w*KP/4 .. of OtOr, read coalesced from L2).  The four partial vectors meet in LDS once
-// per iteration and are summed in wave order, so all waves stay bit-identical and the
-// result is deterministic.
+// Lane l of a wave holds the FPL = KP/64 contiguous features l*FPL.. of every CG vector (x, r, z,
+// p, 1/diagonal) and of every gathered factor row.  A row's gathered factor rows stay in
+// REGISTERS over the iterations (RI = 64/FPL rows = 64 VGPRs per wave), so its entries are read
+// once per half-epoch.  Two instances:
+//   NW = 4  one workgroup per row: the entries and the rows of OtOr are split over the four waves,
+//           the four partial A p meet in LDS once per iteration and are summed in wave order (all
+//           waves keep bit-identical vectors; deterministic);  rows of up to 4 RI entries, longer
+//           ones gather their tail again in every iteration;
+//   NW = 1  one WAVE per row, four rows per workgroup: no barrier, no LDS exchange; rows of up to
+//           RI entries.
+// Rows longer than 4 RI entries (16384 / KP) are handed to the exact kernels by
+// als_cg_half_epoch (see there).  The dot products q_j . p of 8 entries are reduced together
+// (`cg_reduce8`), the CG scalars by DPP row sums + readlane (`cg_wave_sum`); OtOr is LDS resident
+// for KP <= 128.
 //
-// Roofline: HBM/L2 bound -- flops T*(nnz*4k + rows*2k^2).  The gathered
-// rows of a CSR row are read ONCE and stay in registers over the iterations (up to 256 / 128 /
-// 64 entries per row at k = 64 / 128 / 256; longer rows re-gather their tail per iteration), so
-// the traffic is the algorithmic nnz*(4k + 8) + rows*8k instead of T times that; the dot
-// products of 8 items are reduced together (`cg_reduce8`: 10 exchanges, 7 of them DPP).
+// Roofline: HBM/L2 bound -- flops T*(nnz*4k + rows*2k^2), bytes nnz*(4k + 8) + rows*8k
+// (SURVEY.md section 8d).
 #include "als_plan.h"
 #include "common.h"
 
@@ -116,14 +118,18 @@ __device__ __forceinline__ float cg_reduce8(const float (&a)[8], int lane)
 // item j of a group of 8 is finished in the lanes with (lane & 7) == CG_REV3(j)
 #define CG_REV3(j) ((((j) & 1) << 2) | ((j) & 2) | (((j) & 4) >> 2))
 
-template <int KP, bool IS64>
-__global__ __launch_bounds__(256) void als_cg_kernel(
+// NW = waves that share one row: 4 (a workgroup per row; rows of up to 4 * RI resident entries,
+// partial vectors combined in LDS with two barriers per iteration) or 1 (a WAVE per row, four rows
+// per workgroup, for rows of at most RI entries: no barrier, no LDS exchange).
+template <int KP, bool IS64, int NW>
+__global__ __launch_bounds__(256, (NW == 1 && KP <= 128) ? 3 : 2) void als_cg_kernel(
     const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_rows,
     const float *__restrict__ other, float *__restrict__ this_, const float *__restrict__ otor,
     int ld_otor, int k, float tol, int max_iter, float *__restrict__ row_delta,
-    int *__restrict__ status, TaskCtlDev ctl, int64_t t_begin)
+    int *__restrict__ status, TaskCtlDev ctl, int64_t t_begin, int64_t t_end)
 {
+    static_assert(NW == 4 || NW == 1, "NW");
     constexpr int FPL = KP / 64;
     constexpr bool OTOR_LDS = KP <= 128;  // 16 / 64 KiB: loaded once per (persistent) workgroup
     constexpr int GB = 8;                 // items per reduction group
@@ -132,9 +138,14 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
     constexpr int TB = FPL <= 2 ? 16 : 8;  // tail entries a wave gathers per batch
     __shared__ float part[4][KP];
     extern __shared__ __attribute__((aligned(16))) float otor_s[];  // OTOR_LDS: KP*KP floats
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = NW == 4 ? wave_in_wg : 0;  // this wave's place in its row's team
+    const bool lead = NW == 1 || wave_in_wg == 0;
     const int lane = lane_id();
     const int f0 = lane * FPL;  // first feature of this lane
+    auto team_sync = [&]() {
+        if constexpr (NW == 4) __syncthreads();
+    };
     const int myj = CG_REV3(lane & 7);  // the item of a group whose total this lane ends up with
     if (OTOR_LDS) {  // zero padded to KP x KP
         for (int e = threadIdx.x; e < KP * KP; e += 256) {
@@ -147,8 +158,10 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
     __shared__ int s_cancel;
     // tasks [t_begin, n_rows) of the longest-first order (the chunked rows before t_begin were
     // solved by the exact kernels: als_cg_half_epoch)
-    for (int64_t t = t_begin + blockIdx.x; t < n_rows; t += gridDim.x) {
-        if (ctl.d_cancel) {  // AccelTask.cancel: rows not started yet are skipped
+    (void)n_rows;
+    for (int64_t t = t_begin + (NW == 4 ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave_in_wg);
+         t < t_end; t += (NW == 4 ? (int64_t)gridDim.x : (int64_t)gridDim.x * 4)) {
+        if (NW == 4 && ctl.d_cancel) {  // AccelTask.cancel: rows not started yet are skipped
             if (threadIdx.x == 0) s_cancel = ctl_cancelled(ctl, (blockIdx.x & 31) == 0) ? 1 : 0;
             __syncthreads();
             const int c = s_cancel;
@@ -161,11 +174,11 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
         const int64_t beg = cg_uniform64(indptr[row]), end = cg_uniform64(indptr[row + 1]);
         float *xrow = this_ + (int64_t)row * KP;
         if (end == beg) {  // implicit.rs:98-101
-            if (wave == 0)
+            if (lead)
 #pragma unroll
                 for (int c = 0; c < FPL; ++c) xrow[f0 + c] = 0.f;
-            if (threadIdx.x == 0) row_delta[row] = 0.f;
-            if (ctl.d_done && threadIdx.x == 0) ctl_advance(ctl, 1);
+            if (lead && lane == 0) row_delta[row] = 0.f;
+            if (ctl.d_done && lead && lane == 0) ctl_advance(ctl, 1);
             continue;
         }
         // The row's gathered factor rows stay in REGISTERS for the whole solve: the first
@@ -173,11 +186,11 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
         // wave w keeps its share as qres[i] (lane = feature(s)); only the entries past 4 * RI
         // of a long row are gathered again in every iteration (`stream`).
         const int64_t n = end - beg;
-        const int share = n >= 4 * RI ? RI : (int)((n + 4 * GB - 1) / (4 * GB)) * GB;
+        const int share = n >= NW * RI ? RI : (int)((n + NW * GB - 1) / (NW * GB)) * GB;
         const int64_t rbeg = beg + (int64_t)wave * share;
         int nres = (int)(end - rbeg < share ? end - rbeg : share);
         nres = __builtin_amdgcn_readfirstlane(nres < 0 ? 0 : nres);
-        const int64_t sbeg = beg + 4 * (int64_t)share;  // streamed tail (empty unless n > 4 RI)
+        const int64_t sbeg = beg + NW * (int64_t)share;  // streamed tail (empty unless n > NW RI)
         Vec<FPL> qres[RI];
         float vg[NG];  // lane: the value of item g * 8 + myj of the share (0 past its end)
         // one coalesced load of the share's item numbers (lane i: item i), handed out by readlane
@@ -196,6 +209,11 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
 #pragma unroll
                         for (int c = 0; c < FPL; ++c) qres[i].v[c] = 0.f;
                 }
+            } else {  // (apply works on pairs of groups: an unused partner is zero rows)
+#pragma unroll
+                for (int j = 0; j < GB; ++j)
+#pragma unroll
+                    for (int c = 0; c < FPL; ++c) qres[g * GB + j].v[c] = 0.f;
             }
         }
         // A p: this wave's items and its quarter of the OtOr rows, then the four partial
@@ -204,30 +222,39 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
             Vec<FPL> u;
 #pragma unroll
             for (int c = 0; c < FPL; ++c) u.v[c] = 0.f;
+            // (two groups per branch: their reductions -- dependent DPP / LDS-pipe chains --
+            // interleave)
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g * GB < nres) {
-                    float a[GB];
+            for (int g2 = 0; g2 < NG; g2 += 2) {
+                if (g2 * GB < nres) {
+                    float a[2][GB];
 #pragma unroll
-                    for (int j = 0; j < GB; ++j) {
-                        float sacc = 0.f;
+                    for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int c = 0; c < FPL; ++c) sacc = fmaf(qres[g * GB + j].v[c], p.v[c], sacc);
-                        a[j] = sacc;
-                    }
-                    const float coefv = vg[g] * cg_reduce8(a, lane);
+                        for (int j = 0; j < GB; ++j) {
+                            float sacc = 0.f;
 #pragma unroll
-                    for (int j = 0; j < GB; ++j) {
-                        const float coef = bcast(coefv, CG_REV3(j));
+                            for (int c = 0; c < FPL; ++c)
+                                sacc = fmaf(qres[(g2 + h) * GB + j].v[c], p.v[c], sacc);
+                            a[h][j] = sacc;
+                        }
+                    float coefv[2];
 #pragma unroll
-                        for (int c = 0; c < FPL; ++c)
-                            u.v[c] = fmaf(coef, qres[g * GB + j].v[c], u.v[c]);
-                    }
+                    for (int h = 0; h < 2; ++h) coefv[h] = vg[g2 + h] * cg_reduce8(a[h], lane);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < GB; ++j) {
+                            const float coef = bcast(coefv[h], CG_REV3(j));
+#pragma unroll
+                            for (int c = 0; c < FPL; ++c)
+                                u.v[c] = fmaf(coef, qres[(g2 + h) * GB + j].v[c], u.v[c]);
+                        }
                 }
             }
             // the tail of a long row: wave w takes batches w, w + 4, ... of TB = 16 entries (two
             // reduction groups; the 16 gathers of a batch are in flight together)
-            for (int64_t e0 = sbeg + (int64_t)wave * TB; e0 < end; e0 += 4 * TB) {
+            for (int64_t e0 = sbeg + (int64_t)wave * TB; e0 < end; e0 += NW * TB) {
                 Vec<FPL> q[TB];
                 const int tailitem = indices[(lane < TB && e0 + lane < end) ? e0 + lane : beg];
                 float vmine[TB / GB];
@@ -259,8 +286,11 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
                     }
                 }
             }
-            for (int g = wave * (KP / 4); g < (wave + 1) * (KP / 4); ++g) {
-                if (g >= k) break;
+            // (LDS copy: zero padded, so no early exit and the loop unrolls into batched reads)
+#pragma unroll 8
+            for (int gi = 0; gi < KP / NW; ++gi) {
+                const int g = wave * (KP / NW) + gi;
+                if (!OTOR_LDS && g >= k) continue;
                 // p[g] lives in lane g / FPL, component g % FPL
                 float pg = 0.f;
 #pragma unroll
@@ -280,14 +310,18 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
                     }
                 }
             }
-            __syncthreads();  // previous readers of `part` are done
+            if constexpr (NW == 1) {
+                out = u;
+            } else {
+                __syncthreads();  // previous readers of `part` are done
 #pragma unroll
-            for (int c = 0; c < FPL; ++c) part[wave][f0 + c] = u.v[c];
-            __syncthreads();
+                for (int c = 0; c < FPL; ++c) part[wave][f0 + c] = u.v[c];
+                __syncthreads();
 #pragma unroll
-            for (int c = 0; c < FPL; ++c)
-                out.v[c] = ((part[0][f0 + c] + part[1][f0 + c]) + part[2][f0 + c]) +
-                           part[3][f0 + c];
+                for (int c = 0; c < FPL; ++c)
+                    out.v[c] = ((part[0][f0 + c] + part[1][f0 + c]) + part[2][f0 + c]) +
+                               part[3][f0 + c];
+            }
         };
 
         // y = sum (v+1) q  and the Jacobi diagonal  d = diag(OtOr) + sum v q^2
@@ -312,7 +346,7 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
                     }
                 }
             }
-            for (int64_t e0 = sbeg + (int64_t)wave * GB; e0 < end; e0 += 4 * GB) {
+            for (int64_t e0 = sbeg + (int64_t)wave * GB; e0 < end; e0 += NW * GB) {
                 Vec<FPL> q[GB];
                 float val[GB];
                 const bool mine = lane < GB && e0 + lane < end;
@@ -336,25 +370,38 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
                         dw.v[c] = fmaf(val[j] * q[j].v[c], q[j].v[c], dw.v[c]);
                     }
             }
-            __syncthreads();
+            if constexpr (NW == 1) {
 #pragma unroll
-            for (int c = 0; c < FPL; ++c) part[wave][f0 + c] = yw.v[c];
-            __syncthreads();
+                for (int c = 0; c < FPL; ++c) {
+                    const int f = f0 + c;
+                    const float od = (f < k) ? otor[(int64_t)f * ld_otor + f] : 1.0f;
+                    y.v[c] = yw.v[c];
+                    d.v[c] = od + dw.v[c];
+                }
+            } else {
+                __syncthreads();
 #pragma unroll
-            for (int c = 0; c < FPL; ++c)
-                y.v[c] = ((part[0][f0 + c] + part[1][f0 + c]) + part[2][f0 + c]) +
-                         part[3][f0 + c];
-            __syncthreads();
+                for (int c = 0; c < FPL; ++c) part[wave][f0 + c] = yw.v[c];
+                __syncthreads();
 #pragma unroll
-            for (int c = 0; c < FPL; ++c) part[wave][f0 + c] = dw.v[c];
-            __syncthreads();
+                for (int c = 0; c < FPL; ++c)
+                    y.v[c] = ((part[0][f0 + c] + part[1][f0 + c]) + part[2][f0 + c]) +
+                             part[3][f0 + c];
+                __syncthreads();
 #pragma unroll
-            for (int c = 0; c < FPL; ++c) {
-                const int f = f0 + c;
-                const float od = (f < k) ? otor[(int64_t)f * ld_otor + f] : 1.0f;
-                d.v[c] = od + (((part[0][f] + part[1][f]) + part[2][f]) + part[3][f]);
+                for (int c = 0; c < FPL; ++c) part[wave][f0 + c] = dw.v[c];
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < FPL; ++c) {
+                    const int f = f0 + c;
+                    const float od = (f < k) ? otor[(int64_t)f * ld_otor + f] : 1.0f;
+                    d.v[c] = od + (((part[0][f] + part[1][f]) + part[2][f]) + part[3][f]);
+                }
             }
         }
+        Vec<FPL> dinv;  // Jacobi preconditioner, inverted once
+#pragma unroll
+        for (int c = 0; c < FPL; ++c) dinv.v[c] = 1.0f / d.v[c];
         Vec<FPL> x, xold, r, z, p, ap;
 #pragma unroll
         for (int c = 0; c < FPL; ++c) xold.v[c] = x.v[c] = xrow[f0 + c];  // warm start
@@ -363,7 +410,7 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
 #pragma unroll
         for (int c = 0; c < FPL; ++c) {
             r.v[c] = y.v[c] - ap.v[c];
-            z.v[c] = r.v[c] / d.v[c];
+            z.v[c] = r.v[c] * dinv.v[c];
             p.v[c] = z.v[c];
         }
         float rz = vdot<FPL>(r, z);
@@ -383,7 +430,7 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
             for (int c = 0; c < FPL; ++c) {
                 x.v[c] = fmaf(alpha, p.v[c], x.v[c]);
                 r.v[c] = fmaf(-alpha, ap.v[c], r.v[c]);
-                z.v[c] = r.v[c] / d.v[c];
+                z.v[c] = r.v[c] * dinv.v[c];
             }
             const float rz_new = vdot<FPL>(r, z);
             rr = vdot<FPL>(r, r);
@@ -400,20 +447,26 @@ __global__ __launch_bounds__(256) void als_cg_kernel(
             dd = fmaf(df, df, dd);
             bad = bad || !(fabsf(x.v[c]) <= 3.0e38f);
         }
-        dd = wave_sum(dd);
-        if (wave == 0) {
+        dd = cg_wave_sum(dd);
+        if (lead) {
 #pragma unroll
             for (int c = 0; c < FPL; ++c) xrow[f0 + c] = (f0 + c < k) ? x.v[c] : 0.f;
             if (lane == 0) row_delta[row] = dd;
         }
-        if (__any(bad) && threadIdx.x == 0) atomicCAS(status, 0, row + 1);
-        if (threadIdx.x == 0) {  // lk_als_plan_cg_stats: iterations and rows of this half-epoch
+        if (__any(bad) && lead && lane == 0) atomicCAS(status, 0, row + 1);
+        if (lead && lane == 0) {  // lk_als_plan_cg_stats: iterations and rows of this half-epoch
             atomicAdd(&status[2], it);
             atomicAdd(&status[3], 1);
         }
-        if (ctl.d_done && threadIdx.x == 0) ctl_advance(ctl, 1);
-        __syncthreads();
+        if (ctl.d_done && lead && lane == 0) ctl_advance(ctl, 1);
+        team_sync();
     }
+}
+
+static bool cg_wave_rows_enabled()
+{
+    const char *e = getenv("LK_ALS_CG_WAVE_ROWS");  // 0: every CG row by a workgroup (A-B knob)
+    return !(e && e[0] == '0');
 }
 
 template <int KP, bool IS64>
@@ -433,19 +486,34 @@ static int launch_cg(const lk_als_plan *p, const void *indptr, const int32_t *in
         if (rc != LK_OK) return rc;
     }
     const int max_iter = p->cg_max_iter > 0 ? p->cg_max_iter : k;
-    const int64_t n_cg = n_rows - t_begin;
-    if (n_cg > 0) {
-        int64_t blocks = n_cg < 256 * 8 ? n_cg : 256 * 8;
-        const size_t lds = KP <= 128 ? (size_t)KP * KP * sizeof(float) : 0;  // OtOr resident
-        auto kern = als_cg_kernel<KP, IS64>;
-        if (lds > 0)
-            LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st,
+    // rows that fit ONE wave's registers (<= 4096 / KP entries: tasks [t_cg1, n_rows)) take the
+    // wave-per-row instance; not with a task-control block (the cancel poll is a workgroup matter)
+    int64_t t_w1 = p->ctl || !cg_wave_rows_enabled() ? n_rows : p->t_cg1;
+    if (t_w1 < t_begin) t_w1 = t_begin;
+    const size_t lds = KP <= 128 ? (size_t)KP * KP * sizeof(float) : 0;  // OtOr resident
+    auto k4 = als_cg_kernel<KP, IS64, 4>;
+    auto k1 = als_cg_kernel<KP, IS64, 1>;
+    if (lds > 0) {
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k4),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (t_w1 > t_begin) {
+        const int64_t n4 = t_w1 - t_begin;
+        const int64_t blocks = n4 < 256 * 8 ? n4 : 256 * 8;
+        hipLaunchKernelGGL(k4, dim3((unsigned)blocks), dim3(256), lds, st,
                            static_cast<const IT *>(indptr), indices, values, p->d_order, n_rows,
                            other, this_, otor, ld_otor, k, p->cg_tol, max_iter, row_delta,
-                           status, p->ctl ? p->ctl->dev() : TaskCtlDev{}, t_begin);
+                           status, p->ctl ? p->ctl->dev() : TaskCtlDev{}, t_begin, t_w1);
+    }
+    if (n_rows > t_w1) {
+        const int64_t n1 = (n_rows - t_w1 + 3) / 4;
+        const int64_t blocks = n1 < 256 * 8 ? n1 : 256 * 8;
+        hipLaunchKernelGGL(k1, dim3((unsigned)blocks), dim3(256), lds, st,
+                           static_cast<const IT *>(indptr), indices, values, p->d_order, n_rows,
+                           other, this_, otor, ld_otor, k, p->cg_tol, max_iter, row_delta,
+                           status, TaskCtlDev{}, t_w1, n_rows);
     }
     return launch_delta_reduce(row_delta, n_rows, partial, out_frob, st);
 }

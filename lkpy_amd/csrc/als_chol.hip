@@ -1581,6 +1581,15 @@ extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int i
                 hi = mid;
         }
         p->t_cg = lo;
+        hi = n_rows;
+        while (lo < hi) {  // ... and that ONE wave holds
+            const int64_t mid = (lo + hi) >> 1;
+            if (len(order[(size_t)mid]) > cg_len / 4)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        p->t_cg1 = lo;
     }
     std::vector<int32_t> row_slab((size_t)n_rows, -1);
     std::vector<int32_t> chunk_row;

@@ -35,6 +35,7 @@ struct lk_als_plan {
     // rows [t_cg, n_rows) have at most 16384 / KP entries (256 / 128 / 64 at padded k = 64 /
     // 128 / 256): what the CG kernel keeps in registers over its iterations (als_cg.hip)
     int64_t t_cg = 0;
+    int64_t t_cg1 = 0;  // rows [t_cg1, n_rows): at most 4096 / KP entries -- one wave's registers
     mutable const float *d_z = nullptr;
     // ... or a caller-owned [n_cols x KP] buffer the LIBRARY fills with Z at every implicit
     // half-epoch (lk_als_plan_set_z_workspace): OtOr^-1 by spd_inverse.hip, Z by the scoring GEMM

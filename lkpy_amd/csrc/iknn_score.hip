@@ -172,7 +172,9 @@ constexpr int KF_NT_MAX = 1024;   // targets per query
 constexpr int KF_CAP = 256;       // history rows per round = the most hits one target collects in it
 constexpr int KF_NBR_MAX = 255;   // max_nbrs the per-wave accumulator buffer holds
 constexpr int KF_MAX_WGS = 1024;
-constexpr int KF_U = 8;           // history rows a wave has in flight
+constexpr int KF_U = 16;          // history rows a wave has in flight
+constexpr int KF_HEAVY = 1024;    // queries with more history rows than this are started first ...
+constexpr int KF_SPLIT = 8;       // ... and scored in this many parts (by target)
 
 // per workgroup: the round's hits (history position, weight, value) per target, and -- for
 // queries with more than KF_CAP history rows -- the accumulators between rounds
@@ -182,6 +184,10 @@ __host__ __device__ inline size_t kf_slab_bytes(int64_t nt_max, int max_nbrs)
 }
 
 __device__ __forceinline__ int kf_hash(int t) { return (int)(((unsigned)t * 2654435761u) >> 21); }
+__device__ __forceinline__ int kf_part(int t, int split)  // split: a power of two
+{
+    return (int)((((unsigned)t * 0x85ebca6bu) >> 13) & (unsigned)(split - 1));
+}
 
 __device__ __forceinline__ int64_t kf_readlane64(int64_t v, int l)
 {
@@ -190,16 +196,21 @@ __device__ __forceinline__ int64_t kf_readlane64(int64_t v, int l)
     return (int64_t)(((unsigned long long)hi << 32) | lo);
 }
 
+// pre-pass of the list kernel: the longest target list (status[2]) and the queries with more than
+// KF_HEAVY history rows (heavy[0 .. status[6]))
 __global__ __launch_bounds__(1024) void seg_max_kernel(const int64_t *__restrict__ ptr, int64_t n,
-                                                       int *__restrict__ out)
+                                                       int *__restrict__ status,
+                                                       const int64_t *__restrict__ ref_ptr,
+                                                       int32_t *__restrict__ heavy, int heavy_len)
 {
     long long m = 0;
     for (int64_t q = threadIdx.x; q < n; q += 1024) {
         const long long d = ptr[q + 1] - ptr[q];
         m = d > m ? d : m;
+        if (ref_ptr[q + 1] - ref_ptr[q] > heavy_len) heavy[atomicAdd(&status[6], 1)] = (int32_t)q;
     }
     if (m > 0x7fffffffLL) m = 0x7fffffffLL;
-    atomicMax(out, (int)m);
+    atomicMax(&status[2], (int)m);
 }
 
 // ---- the reference's accumulator, restated for ONE lane on LDS arrays -----------------------
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(KF_THREADS) void iknn_score_fast_kernel(
     const float *__restrict__ ref_rates, const int64_t *__restrict__ tgt_ptr,
     const int32_t *__restrict__ tgt_items, int max_nbrs, int min_nbrs, char *__restrict__ ws,
     int nt_max, float *__restrict__ out_scores, int32_t *__restrict__ out_counts,
-    int *__restrict__ status)
+    int *__restrict__ status, const int32_t *__restrict__ heavy, int heavy_len, int heavy_split)
 {
     __shared__ int hkey[KF_HT];              // item number, -1 = empty
     __shared__ unsigned short hpos[KF_HT];   // the target position that owns the item's list
@@ -280,9 +291,26 @@ __global__ __launch_bounds__(KF_THREADS) void iknn_score_fast_kernel(
     const bool explicit_ = SWAP ? (s_val != nullptr) : (ref_rates != nullptr);
     const float nanf_ = __builtin_nanf("");
     int *tc32 = reinterpret_cast<int *>(tc);
+    __shared__ int s_q;
 
-    for (int64_t q = blockIdx.x; q < n_queries; q += gridDim.x) {
+    // Work is handed out from two counters (status[4], status[5]): first the queries with more
+    // than KF_HEAVY history rows (listed by the pre-pass: heavy[0 .. status[6])), then the rest.  A long history is many rounds, one after the
+    // other (a target's hits must be applied in history order): the heaviest user of a batch
+    // would otherwise be the whole launch (measured: 2.4 ms for 10 000 ML-25M users, of which a
+    // light query takes ~30 us).  So heavy queries (i) start first and (ii) are cut into KF_SPLIT
+    // PARTS BY TARGET: part g owns the targets whose item number hashes to g, streams the whole
+    // history, and feeds only its own accumulators -- targets are independent of each other.
+    for (int phase = 0; phase < 2; ++phase)
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_q = atomicAdd(&status[4 + phase], 1);
+        __syncthreads();
+        const int split = phase == 0 ? heavy_split : 1;
+        const int part = s_q % split;
+        if (s_q / split >= (phase == 0 ? (int64_t)status[6] : n_queries)) break;
+        const int64_t q = phase == 0 ? (int64_t)heavy[s_q / split] : (int64_t)s_q;
         const int64_t rb = ref_ptr[q], re = ref_ptr[q + 1];
+        if (phase == 1 && (re - rb) > heavy_len) continue;
         const int64_t tb = tgt_ptr[q];
         const int nt = (int)(tgt_ptr[q + 1] - tb);  // <= nt_max <= KF_NT_MAX (checked by the host)
         for (int i = tid; i < KF_HT; i += KF_THREADS) hkey[i] = -1;
@@ -293,6 +321,7 @@ __global__ __launch_bounds__(KF_THREADS) void iknn_score_fast_kernel(
         for (int j = tid; j < nt; j += KF_THREADS) {
             const int t = tgt_items[tb + j];
             if (t < 0 || t >= n_items) continue;
+            if (split > 1 && kf_part(t, split) != part) continue;  // another part's target
             int slot = kf_hash(t);
             for (;;) {
                 const int old = atomicCAS(&hkey[slot], -1, t);
@@ -307,11 +336,15 @@ __global__ __launch_bounds__(KF_THREADS) void iknn_score_fast_kernel(
         __syncthreads();
         for (int j = tid; j < nt; j += KF_THREADS) {
             const int t = tgt_items[tb + j];
-            int c = -1;
+            int c = -1;  // null target
             if (t >= 0 && t < n_items) {
-                int slot = kf_hash(t);
-                while (hkey[slot] != t) slot = (slot + 1) & (KF_HT - 1);
-                c = hpos[slot];
+                if (split > 1 && kf_part(t, split) != part) {
+                    c = -2;  // scored (and written) by another part
+                } else {
+                    int slot = kf_hash(t);
+                    while (hkey[slot] != t) slot = (slot + 1) & (KF_HT - 1);
+                    c = hpos[slot];
+                }
             }
             canon[j] = (short)c;
         }
@@ -546,6 +579,7 @@ __global__ __launch_bounds__(KF_THREADS) void iknn_score_fast_kernel(
         }
         for (int j = tid; j < nt; j += KF_THREADS) {
             const int jo = canon[j];
+            if (jo == -2) continue;
             out_scores[tb + j] = jo >= 0 ? res_s[jo] : nanf_;
             out_counts[tb + j] = jo >= 0 ? (acc_len[jo] & 0xffff) : -1;
         }
@@ -559,6 +593,10 @@ namespace lk {
 
 static int64_t g_score_stats[3] = {0, 0, 0};  // last call: queries on the list kernel, on the slot kernel, max targets
 
+static inline size_t ks_list_bytes(int64_t n_queries)
+{
+    return ((size_t)(n_queries > 0 ? n_queries : 1) * sizeof(int32_t) + 255) / 256 * 256;
+}
 static inline int64_t ks_slot_wgs(int64_t n_queries)
 {
     int64_t wgs = n_queries < KS_MAX_WGS ? n_queries : KS_MAX_WGS;
@@ -593,22 +631,33 @@ static int score_batch(const char *what, const int64_t *d_ptr, const int32_t *d_
                        float *d_out_scores, int32_t *d_out_counts, hipStream_t st)
 {
     char *ws = static_cast<char *>(d_ws);
-    int *status = reinterpret_cast<int *>(ws);  // [0] NaN seen, [1] repeated column, [2] max targets
-    char *slabs = ws + 256;
+    // [0] NaN seen, [1] repeated column, [2] max targets, [4] [5] work counters, [6] heavy queries
+    int *status = reinterpret_cast<int *>(ws);
+    int32_t *heavy = reinterpret_cast<int32_t *>(ws + 256);
+    char *slabs = ws + 256 + ks_list_bytes(n_queries);
     const size_t slot_slab = ks_slab_bytes(n_items, max_nbrs);
     const int64_t slot_wgs = ks_slot_wgs(n_queries);
     LK_HIP_CHECK(hipMemsetAsync(status, 0, 256, st));
     int h[3] = {0, 0, 0};
     g_score_stats[0] = g_score_stats[1] = g_score_stats[2] = 0;
     bool lists = score_fast_enabled() && max_nbrs <= KF_NBR_MAX;
+    // tuning knobs (read per call): history length from which a query is split, and into how
+    // many parts (a power of two)
+    int heavy_len = KF_HEAVY, heavy_split = KF_SPLIT;
+    if (const char *e = getenv("LK_KNN_SCORE_HEAVY")) heavy_len = atoi(e) > 0 ? atoi(e) : heavy_len;
+    if (const char *e = getenv("LK_KNN_SCORE_SPLIT")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) heavy_split = v;
+    }
     int64_t fast_wgs = 0;
     if (lists) {
         hipLaunchKernelGGL(seg_max_kernel, dim3(1), dim3(1024), 0, st, d_tgt_ptr, n_queries,
-                           status + 2);
+                           status, d_ref_ptr, heavy, heavy_len);
         LK_HIP_CHECK(hipMemcpyAsync(h, status, sizeof(h), hipMemcpyDeviceToHost, st));
         LK_HIP_CHECK(hipStreamSynchronize(st));
         g_score_stats[2] = h[2];
-        fast_wgs = n_queries < KF_MAX_WGS ? n_queries : KF_MAX_WGS;
+        // (a heavy query is up to KF_SPLIT work items)
+        fast_wgs = n_queries * heavy_split < KF_MAX_WGS ? n_queries * heavy_split : KF_MAX_WGS;
         if (h[2] > 0) {
             const int64_t fit = (int64_t)(ks_region_bytes(n_items, n_queries, max_nbrs) /
                                           kf_slab_bytes(h[2], max_nbrs));
@@ -622,7 +671,7 @@ static int score_batch(const char *what, const int64_t *d_ptr, const int32_t *d_
                            dim3(KF_THREADS), 0, st, d_ptr, d_idx, d_val, n_rows, n_items,
                            n_queries, d_ref_ptr, d_ref_items, d_ref_rates, d_tgt_ptr, d_tgt_items,
                            max_nbrs, min_nbrs, slabs, h[2] > 0 ? h[2] : 1, d_out_scores,
-                           d_out_counts, status);
+                           d_out_counts, status, heavy, heavy_len, heavy_split);
     } else {
         g_score_stats[1] = n_queries;
         hipLaunchKernelGGL(iknn_score_kernel<SWAP>, dim3((unsigned)slot_wgs), dim3(KS_THREADS), 0,
@@ -650,7 +699,7 @@ extern "C" size_t lk_iknn_score_workspace_bytes(int64_t n_items, int64_t n_queri
                                                 int32_t max_nbrs)
 {
     if (n_items < 0 || max_nbrs < 1) return 0;
-    return 256 + lk::ks_region_bytes(n_items, n_queries, max_nbrs);
+    return 256 + lk::ks_list_bytes(n_queries) + lk::ks_region_bytes(n_items, n_queries, max_nbrs);
 }
 
 extern "C" void lk_knn_score_last_stats(int64_t *out3)
