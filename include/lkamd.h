@@ -329,14 +329,16 @@ int lk_iknn_truncate_fill(const int64_t *d_sim_indptr, const int32_t *d_sim_indi
  *   score_t = sum_{top max_nbrs by sim} s*v / sum s  (explicit)  or  sum s (implicit);
  *   fewer than min_nbrs contributors => NaN.  out_counts = contributors kept
  *   (-1 for a null target).  Blocking (returns LK_E_NAN_SIM for a NaN similarity).
- *   Among neighbours of EQUAL similarity at the max_nbrs boundary the reference keeps whichever
- *   its BinaryHeap happens to hold (accum.rs:106-113: unspecified); here the earlier history
- *   item stays.  Calls in which no query has more than 1024 targets take the candidate-list
- *   kernel (targets hashed in LDS, all history rows streamed at once); a query in which some
- *   target collects more than 256 neighbours, and calls with longer target lists (`score every
- *   item`), take the one-history-row-at-a-time slot kernel.  LK_KNN_SCORE_LISTS=0 forces the
- *   latter.  lk_knn_score_last_stats: of the last call on this process, {queries scored by the
- *   list kernel, queries scored by the slot kernel, longest target list} (test hook).
+ *   Calls in which no query has more than 1024 targets, with max_nbrs <= 255, take the
+ *   candidate-list kernel: targets hashed in LDS, all history rows streamed at once, and the
+ *   reference's accumulator followed step for step (a vector, then std's BinaryHeap push / pop),
+ *   so that WHICH of several equal similarities is evicted at the max_nbrs boundary and the order
+ *   of the f32 sums are the reference's: the scores are bit-identical to its.  Other calls
+ *   (`score every item`) take the one-history-row-at-a-time slot kernel, which runs the same
+ *   accumulator on per-item slots of the workspace (bit-identical as well, slower per target).
+ *   LK_KNN_SCORE_LISTS=0 forces the slot kernel.  The matrix rows must not name a column twice
+ *   (LK_E_INVALID from the list kernel).  lk_knn_score_last_stats: of the calling thread's last
+ *   call, {queries scored by the list kernel, by the slot kernel, longest target list} (test hook).
  * ---------------------------------------------------------------------- */
 size_t lk_iknn_score_workspace_bytes(int64_t n_items, int64_t n_queries, int32_t max_nbrs);
 void lk_knn_score_last_stats(int64_t *out3);

@@ -22,16 +22,18 @@
 //
 // That kernel (`iknn_score_kernel`) costs a query one barrier per history item and an
 // n_items-wide reset, whatever the number of targets: 13 ms for the cfg3 batch (10 000 queries
-// x 100 targets).  Queries with at most KF_NT_MAX targets -- the `score a candidate list` case --
-// take `iknn_score_fast_kernel` instead: the targets go into an LDS hash table, ALL history rows
-// are streamed concurrently (a wave per row, coalesced; an LDS probe per entry), every hit is
-// appended to its target's list (an LDS counter per target, the (weight, history position, value)
-// triples in an L2-resident slab), and afterwards one wave per target ranks its list: kept are the
-// max_nbrs largest by (weight descending, history position ascending) -- exactly the set the
-// one-at-a-time displacement rule keeps, with the ties among equal weights that the reference
-// leaves to its heap order resolved towards the earlier history item -- and summed in rank
-// order, so the result does not depend on the order the hits arrived in.  A target with more than
-// KF_CAP hits sends its whole query to the slot kernel above (second launch over a query list).
+// x 100 targets).  Calls in which no query has more than KF_NT_MAX targets -- the `score a
+// candidate list` case -- take `iknn_score_fast_kernel` instead (and max_nbrs <= KF_NBR_MAX):
+// the targets go into an LDS hash table, the history rows are streamed concurrently (a wave takes
+// KF_U rows at a time, coalesced; an LDS probe per entry), every hit is appended to its target's
+// list (LDS counters, the (history position, weight, value) triples in an L2-resident slab).
+// Histories are cut into rounds of KF_CAP rows, so a list never holds more than KF_CAP hits;
+// after a round one wave per target sorts the hits back into history order and feeds them to the
+// accumulator -- which is the reference's, step for step: a vector while there is room, then
+// std's BinaryHeap push / pop replayed on an LDS copy, so the SAME one of several equal weights
+// is evicted, the array ends in the same order, and the sequential sums over it (product and sum
+// rounded separately) give the reference's bits.  Queries with long histories are started first
+// and split into parts by target (see the kernel).  1.3 ms for the cfg3 batch.
 #include "common.h"
 
 // The reference's sums are plain f32 multiplies and adds (Rust never contracts a * b + c): no
@@ -43,177 +45,16 @@ namespace lk {
 constexpr int KS_THREADS = 512;
 constexpr int KS_MAX_WGS = 256;
 
-struct KsSlab {
-    int32_t *cnt;
-    float *minval;
-    float *slot_s;
-    float *slot_v;
-};
-
+// per workgroup: cnt[t] (-1 = not a target), the heap flag of t, and max_nbrs + 1 (weight, value)
+// slots per item (a push precedes the pop)
 __host__ __device__ inline size_t ks_slab_bytes(int64_t n_items, int max_nbrs)
 {
-    size_t per = (size_t)n_items * (sizeof(int32_t) + sizeof(float)) +
-                 (size_t)n_items * max_nbrs * 2 * sizeof(float);
+    size_t per = (size_t)n_items * (sizeof(int32_t) + sizeof(int32_t)) +
+                 (size_t)n_items * ((size_t)max_nbrs + 1) * 2 * sizeof(float);
     return (per + 255) / 256 * 256;
 }
 
-// SWAP = false: item-kNN (matrix = similarities, entry value = weight, the reference row's
-// rating = value).  SWAP = true: user-kNN (`user_score_items_*`,
-// src/accel/knn/user_score.rs:21-98): matrix = the users' ratings, the reference rows are the
-// neighbours, their similarity (ref_rates) = weight, the entry value (rating; none for
-// implicit feedback: s_val null) = value.  `n_rows` = rows of the matrix, `n_items` = columns.
-template <bool SWAP>
-__global__ __launch_bounds__(KS_THREADS) void iknn_score_kernel(
-    const int64_t *__restrict__ s_ptr, const int32_t *__restrict__ s_idx,
-    const float *__restrict__ s_val, int64_t n_rows, int64_t n_items, int64_t n_queries,
-    const int64_t *__restrict__ ref_ptr, const int32_t *__restrict__ ref_items,
-    const float *__restrict__ ref_rates, const int64_t *__restrict__ tgt_ptr,
-    const int32_t *__restrict__ tgt_items, int max_nbrs, int min_nbrs, char *__restrict__ ws,
-    size_t slab_bytes, float *__restrict__ out_scores, int32_t *__restrict__ out_counts,
-    int *__restrict__ status)
-{
-    char *slab = ws + (size_t)blockIdx.x * slab_bytes;
-    int32_t *cnt = reinterpret_cast<int32_t *>(slab);
-    float *minval = reinterpret_cast<float *>(slab + (size_t)n_items * 4);
-    float *slot_s = reinterpret_cast<float *>(slab + (size_t)n_items * 8);
-    float *slot_v = slot_s + (size_t)n_items * max_nbrs;
-    const int tid = threadIdx.x;
-    const bool explicit_ = SWAP ? (s_val != nullptr) : (ref_rates != nullptr);
-
-    for (int64_t q = blockIdx.x; q < n_queries; q += gridDim.x) {
-        const int64_t rb = ref_ptr[q], re = ref_ptr[q + 1];
-        const int64_t tb = tgt_ptr[q], te = tgt_ptr[q + 1];
-        // enable the targets (ScoreAccumulator::new_array, accum.rs:30-37)
-        for (int64_t t = tid; t < n_items; t += KS_THREADS) cnt[t] = -1;
-        __syncthreads();
-        for (int64_t j = tb + tid; j < te; j += KS_THREADS) {
-            const int t = tgt_items[j];
-            if (t >= 0 && t < n_items) cnt[t] = 0;
-        }
-        __syncthreads();
-        // scatter the history rows, one reference item at a time, in history order
-        for (int64_t r = rb; r < re; ++r) {
-            const int ri = ref_items[r];
-            if (ri < 0 || ri >= n_rows) continue;  // wave-uniform: null reference row
-            const float rscalar = (SWAP || explicit_) ? ref_rates[r] : 0.f;
-            const int64_t sb = s_ptr[ri], se = s_ptr[ri + 1];
-            for (int64_t e = sb + tid; e < se; e += KS_THREADS) {
-                const int t = s_idx[e];
-                const int c = cnt[t];
-                if (c < 0) continue;
-                // (weight, value) of this contribution
-                const float s = SWAP ? rscalar : s_val[e];
-                const float rv = SWAP ? (explicit_ ? s_val[e] : 0.f) : rscalar;
-                if (s != s) {
-                    atomicCAS(status, 0, 1);
-                    continue;
-                }
-                float *ss = slot_s + (size_t)t * max_nbrs;
-                float *sv = slot_v + (size_t)t * max_nbrs;
-                if (c < max_nbrs) {  // Partial(vec): push (accum.rs:103-104)
-                    ss[c] = s;
-                    sv[c] = rv;
-                    cnt[t] = c + 1;
-                    if (c + 1 == max_nbrs) {  // becomes Full: cache the minimum
-                        float m = ss[0];
-                        for (int i = 1; i < max_nbrs; ++i) m = fminf(m, ss[i]);
-                        minval[t] = m;
-                    }
-                } else if (s > minval[t]) {  // Full: displace the minimum (accum.rs:106-113)
-                    int mi = 0;
-                    float m = ss[0];
-                    for (int i = 1; i < max_nbrs; ++i)
-                        if (ss[i] < m) {
-                            m = ss[i];
-                            mi = i;
-                        }
-                    ss[mi] = s;
-                    sv[mi] = rv;
-                    m = ss[0];
-                    for (int i = 1; i < max_nbrs; ++i) m = fminf(m, ss[i]);
-                    minval[t] = m;
-                }
-            }
-            __syncthreads();
-        }
-        // collect (collect_items_averaged / _summed / _counts, accum.rs:186-239)
-        for (int64_t j = tb + tid; j < te; j += KS_THREADS) {
-            const int t = tgt_items[j];
-            float score = __builtin_nanf("");
-            int count = -1;
-            if (t >= 0 && t < n_items) {
-                const int c = cnt[t];
-                count = c;
-                if (c >= min_nbrs && c > 0) {
-                    const float *ss = slot_s + (size_t)t * max_nbrs;
-                    const float *sv = slot_v + (size_t)t * max_nbrs;
-                    float tw = 0.f, wsum = 0.f;
-                    for (int i = 0; i < c; ++i) {
-                        tw += ss[i];
-                        wsum += ss[i] * sv[i];
-                    }
-                    score = explicit_ ? wsum / tw : tw;
-                }
-            }
-            out_scores[j] = score;
-            out_counts[j] = count;
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Candidate-list path (see the file header).
-// ---------------------------------------------------------------------------
-constexpr int KF_THREADS = 256;
-constexpr int KF_WAVES = KF_THREADS / 64;
-constexpr int KF_HT = 2048;       // hash slots (load factor <= 0.5)
-constexpr int KF_NT_MAX = 1024;   // targets per query
-constexpr int KF_CAP = 256;       // history rows per round = the most hits one target collects in it
-constexpr int KF_NBR_MAX = 255;   // max_nbrs the per-wave accumulator buffer holds
-constexpr int KF_MAX_WGS = 1024;
-constexpr int KF_U = 16;          // history rows a wave has in flight
-constexpr int KF_HEAVY = 1024;    // queries with more history rows than this are started first ...
-constexpr int KF_SPLIT = 8;       // ... and scored in this many parts (by target)
-
-// per workgroup: the round's hits (history position, weight, value) per target, and -- for
-// queries with more than KF_CAP history rows -- the accumulators between rounds
-__host__ __device__ inline size_t kf_slab_bytes(int64_t nt_max, int max_nbrs)
-{
-    return ((size_t)nt_max * (KF_CAP * 12 + (size_t)(max_nbrs + 1) * 8) + 255) / 256 * 256;
-}
-
-__device__ __forceinline__ int kf_hash(int t) { return (int)(((unsigned)t * 2654435761u) >> 21); }
-__device__ __forceinline__ int kf_part(int t, int split)  // split: a power of two
-{
-    return (int)((((unsigned)t * 0x85ebca6bu) >> 13) & (unsigned)(split - 1));
-}
-
-__device__ __forceinline__ int64_t kf_readlane64(int64_t v, int l)
-{
-    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l);
-    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), l);
-    return (int64_t)(((unsigned long long)hi << 32) | lo);
-}
-
-// pre-pass of the list kernel: the longest target list (status[2]) and the queries with more than
-// KF_HEAVY history rows (heavy[0 .. status[6]))
-__global__ __launch_bounds__(1024) void seg_max_kernel(const int64_t *__restrict__ ptr, int64_t n,
-                                                       int *__restrict__ status,
-                                                       const int64_t *__restrict__ ref_ptr,
-                                                       int32_t *__restrict__ heavy, int heavy_len)
-{
-    long long m = 0;
-    for (int64_t q = threadIdx.x; q < n; q += 1024) {
-        const long long d = ptr[q + 1] - ptr[q];
-        m = d > m ? d : m;
-        if (ref_ptr[q + 1] - ref_ptr[q] > heavy_len) heavy[atomicAdd(&status[6], 1)] = (int32_t)q;
-    }
-    if (m > 0x7fffffffLL) m = 0x7fffffffLL;
-    atomicMax(&status[2], (int)m);
-}
-
-// ---- the reference's accumulator, restated for ONE lane on LDS arrays -----------------------
+// ---- the reference's accumulator, restated for ONE lane (arrays in LDS or in the slab) ---------
 // `Full(BinaryHeap<AccEntry>)` with the REVERSED ordering of accum.rs:170-184: a min-heap on
 // the weight.  std's BinaryHeap::push = sift_up(0, old_len); pop = swap the last element into
 // the root, sift_down_to_bottom(0), sift_up.  Followed step for step so that WHICH of several
@@ -257,6 +98,171 @@ struct KfHeap {
         sift_up(pos, ew, ev);
     }
 };
+
+
+// SWAP = false: item-kNN (matrix = similarities, entry value = weight, the reference row's
+// rating = value).  SWAP = true: user-kNN (`user_score_items_*`,
+// src/accel/knn/user_score.rs:21-98): matrix = the users' ratings, the reference rows are the
+// neighbours, their similarity (ref_rates) = weight, the entry value (rating; none for
+// implicit feedback: s_val null) = value.  `n_rows` = rows of the matrix, `n_items` = columns.
+template <bool SWAP>
+__global__ __launch_bounds__(KS_THREADS) void iknn_score_kernel(
+    const int64_t *__restrict__ s_ptr, const int32_t *__restrict__ s_idx,
+    const float *__restrict__ s_val, int64_t n_rows, int64_t n_items, int64_t n_queries,
+    const int64_t *__restrict__ ref_ptr, const int32_t *__restrict__ ref_items,
+    const float *__restrict__ ref_rates, const int64_t *__restrict__ tgt_ptr,
+    const int32_t *__restrict__ tgt_items, int max_nbrs, int min_nbrs, char *__restrict__ ws,
+    size_t slab_bytes, float *__restrict__ out_scores, int32_t *__restrict__ out_counts,
+    int *__restrict__ status)
+{
+    char *slab = ws + (size_t)blockIdx.x * slab_bytes;
+    int32_t *cnt = reinterpret_cast<int32_t *>(slab);
+    int32_t *is_heap = reinterpret_cast<int32_t *>(slab + (size_t)n_items * 4);
+    const size_t stride = (size_t)max_nbrs + 1;
+    float *slot_s = reinterpret_cast<float *>(slab + (size_t)n_items * 8);
+    float *slot_v = slot_s + (size_t)n_items * stride;
+    const int tid = threadIdx.x;
+    const bool explicit_ = SWAP ? (s_val != nullptr) : (ref_rates != nullptr);
+
+    for (int64_t q = blockIdx.x; q < n_queries; q += gridDim.x) {
+        const int64_t rb = ref_ptr[q], re = ref_ptr[q + 1];
+        const int64_t tb = tgt_ptr[q], te = tgt_ptr[q + 1];
+        // enable the targets (ScoreAccumulator::new_array, accum.rs:30-37)
+        for (int64_t t = tid; t < n_items; t += KS_THREADS) cnt[t] = -1;
+        __syncthreads();
+        for (int64_t j = tb + tid; j < te; j += KS_THREADS) {
+            const int t = tgt_items[j];
+            if (t >= 0 && t < n_items) {
+                cnt[t] = 0;
+                is_heap[t] = 0;
+            }
+        }
+        __syncthreads();
+        // scatter the history rows, one reference item at a time, in history order
+        for (int64_t r = rb; r < re; ++r) {
+            const int ri = ref_items[r];
+            if (ri < 0 || ri >= n_rows) continue;  // wave-uniform: null reference row
+            const float rscalar = (SWAP || explicit_) ? ref_rates[r] : 0.f;
+            const int64_t sb = s_ptr[ri], se = s_ptr[ri + 1];
+            for (int64_t e = sb + tid; e < se; e += KS_THREADS) {
+                const int t = s_idx[e];
+                const int c = cnt[t];
+                if (c < 0) continue;
+                // (weight, value) of this contribution
+                const float s = SWAP ? rscalar : s_val[e];
+                const float rv = SWAP ? (explicit_ ? s_val[e] : 0.f) : rscalar;
+                if (s != s) {
+                    atomicCAS(status, 0, 1);
+                    continue;
+                }
+                float *ss = slot_s + (size_t)t * stride;
+                float *sv = slot_v + (size_t)t * stride;
+                const bool heap = is_heap[t] != 0;
+                if (!heap && c < max_nbrs) {  // Partial(vec): push (accum.rs:103-104)
+                    ss[c] = s;
+                    sv[c] = rv;
+                    cnt[t] = c + 1;
+                } else {  // Full(heap): the reference's BinaryHeap, step for step
+                    KfHeap h{ss, sv, c};
+                    if (!heap) {
+                        // Partial -> Full (heap_mut, accum.rs:76-83): the vector is popped from the
+                        // back and every element pushed onto an empty heap = reverse it in place,
+                        // then sift element k up into the heap formed by the k before it
+                        for (int i = 0, j = c - 1; i < j; ++i, --j) {
+                            const float a = ss[i], b = sv[i];
+                            ss[i] = ss[j];
+                            sv[i] = sv[j];
+                            ss[j] = a;
+                            sv[j] = b;
+                        }
+                        for (int kk = 1; kk < c; ++kk) h.sift_up(kk, ss[kk], sv[kk]);
+                        is_heap[t] = 1;
+                    }
+                    if (s > ss[0]) {  // accum.rs:108: strictly greater than the minimum
+                        h.push(s, rv);
+                        while (h.len > max_nbrs) h.pop();
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // collect (collect_items_averaged / _summed / _counts, accum.rs:186-239)
+        for (int64_t j = tb + tid; j < te; j += KS_THREADS) {
+            const int t = tgt_items[j];
+            float score = __builtin_nanf("");
+            int count = -1;
+            if (t >= 0 && t < n_items) {
+                const int c = cnt[t];
+                count = c;
+                if (c >= min_nbrs && c > 0) {
+                    // (sequential sums in array order, product rounded before it is added)
+                    const float *ss = slot_s + (size_t)t * stride;
+                    const float *sv = slot_v + (size_t)t * stride;
+                    float tw = 0.f, wsum = 0.f;
+                    for (int i = 0; i < c; ++i) {
+                        tw += ss[i];
+                        wsum += ss[i] * sv[i];
+                    }
+                    score = explicit_ ? wsum / tw : tw;
+                }
+            }
+            out_scores[j] = score;
+            out_counts[j] = count;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Candidate-list path (see the file header).
+// ---------------------------------------------------------------------------
+constexpr int KF_THREADS = 256;
+constexpr int KF_WAVES = KF_THREADS / 64;
+constexpr int KF_HT = 2048;       // hash slots (load factor <= 0.5)
+constexpr int KF_NT_MAX = 1024;   // targets per query
+constexpr int KF_CAP = 256;       // history rows per round = the most hits one target collects in it
+constexpr int KF_NBR_MAX = 255;   // max_nbrs the per-wave accumulator buffer holds
+constexpr int KF_MAX_WGS = 1024;
+constexpr int KF_U = 16;          // history rows a wave has in flight
+constexpr int KF_HEAVY = 2048;    // queries with more history rows than this are started first ...
+constexpr int KF_SPLIT = 8;       // ... and scored in this many parts (by target)
+
+// per workgroup: the round's hits (history position, weight, value) per target, and -- for
+// queries with more than KF_CAP history rows -- the accumulators between rounds
+__host__ __device__ inline size_t kf_slab_bytes(int64_t nt_max, int max_nbrs)
+{
+    return ((size_t)nt_max * (KF_CAP * 12 + (size_t)(max_nbrs + 1) * 8) + 255) / 256 * 256;
+}
+
+__device__ __forceinline__ int kf_hash(int t) { return (int)(((unsigned)t * 2654435761u) >> 21); }
+__device__ __forceinline__ int kf_part(int t, int split)  // split: a power of two
+{
+    return (int)((((unsigned)t * 0x85ebca6bu) >> 13) & (unsigned)(split - 1));
+}
+
+__device__ __forceinline__ int64_t kf_readlane64(int64_t v, int l)
+{
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), l);
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+// pre-pass of the list kernel: the longest target list (status[2]) and the queries with more than
+// KF_HEAVY history rows (heavy[0 .. status[6]))
+__global__ __launch_bounds__(1024) void seg_max_kernel(const int64_t *__restrict__ ptr, int64_t n,
+                                                       int *__restrict__ status,
+                                                       const int64_t *__restrict__ ref_ptr,
+                                                       int32_t *__restrict__ heavy, int heavy_len)
+{
+    long long m = 0;
+    for (int64_t q = threadIdx.x; q < n; q += 1024) {
+        const long long d = ptr[q + 1] - ptr[q];
+        m = d > m ? d : m;
+        if (ref_ptr[q + 1] - ref_ptr[q] > heavy_len) heavy[atomicAdd(&status[6], 1)] = (int32_t)q;
+    }
+    if (m > 0x7fffffffLL) m = 0x7fffffffLL;
+    atomicMax(&status[2], (int)m);
+}
 
 template <bool SWAP>
 __global__ __launch_bounds__(KF_THREADS) void iknn_score_fast_kernel(
@@ -591,7 +597,8 @@ __global__ __launch_bounds__(KF_THREADS) void iknn_score_fast_kernel(
 
 namespace lk {
 
-static int64_t g_score_stats[3] = {0, 0, 0};  // last call: queries on the list kernel, on the slot kernel, max targets
+// last call of the calling thread: queries on the list kernel, on the slot kernel, max targets
+static thread_local int64_t g_score_stats[3] = {0, 0, 0};
 
 static inline size_t ks_list_bytes(int64_t n_queries)
 {

@@ -34,10 +34,10 @@ def model(oracle, ml_small, gpu):
 @pytest.mark.parametrize("max_nbrs,min_nbrs", [(20, 1), (5, 3), (100, 1)])
 def test_score_batch_matches_oracle(gpu, oracle, ml_small, model, rng, monkeypatch, explicit,
                                     max_nbrs, min_nbrs, lists):
-    """Both kernels: the candidate-list kernel (LDS target hash, the reference's accumulator
-    followed step for step: no tie caveat) and, with LK_KNN_SCORE_LISTS=0, the slot kernel (which
-    of several EQUAL similarities is evicted at the max_nbrs boundary may differ from the
-    reference's heap order there)."""
+    """Both kernels -- the candidate-list kernel and, with LK_KNN_SCORE_LISTS=0, the slot kernel --
+    follow the reference's accumulator step for step (the vector, then std's BinaryHeap push /
+    pop: the same one of several EQUAL similarities is evicted at the max_nbrs boundary, the sums
+    run over the same array order): the scores are the oracle's, bit for bit."""
     from lkpy_amd import _device as D
 
     monkeypatch.setenv("LK_KNN_SCORE_LISTS", "1" if lists else "0")
@@ -65,8 +65,7 @@ def test_score_batch_matches_oracle(gpu, oracle, ml_small, model, rng, monkeypat
     n_list, n_slot, nt_max = D.knn_score_last_stats()
     assert (n_list, n_slot) == ((len(users), 0) if lists else (0, len(users)))
     assert nt_max == 300 or not lists
-    dense = None
-    n_tie = n_bits = n_ok = 0
+    n_bits = n_ok = 0
     for q in range(len(users)):
         ws_, wc = oracle.iknn_score(sims, hists[q], rates[q] if explicit else None, tgts[q],
                                     max_nbrs, min_nbrs)
@@ -77,40 +76,13 @@ def test_score_batch_matches_oracle(gpu, oracle, ml_small, model, rng, monkeypat
         err = np.abs(s - ws_) / np.maximum(np.abs(ws_), 1e-3)
         n_ok += int(ok.sum())
         n_bits += int(np.sum(s[ok].view(np.uint32) == ws_[ok].view(np.uint32)))
-        if lists or not explicit:
-            assert np.all(err[ok] <= 1e-5), (q, float(err[ok].max()))
-            continue
-        # Slot kernel: which of several EQUAL-similarity neighbours is evicted at the max_nbrs
-        # boundary follows slot order, not the reference's BinaryHeap order (accum.rs:106-113).
-        # Every mismatch must be exactly such a tie, and the GPU score must be a valid choice
-        # among the tied entries (between the smallest- and largest-rating choices).
-        for j in np.flatnonzero(ok & (err > 1e-4)):
-            if dense is None:
-                dense = sims.toarray()
-            h = hists[q][hists[q] >= 0]
-            v = rates[q][hists[q] >= 0]
-            col = dense[h, tgts[q][j]]
-            m = col > 0
-            cs, cv = col[m], v[m]
-            assert len(cs) > max_nbrs
-            kth = np.sort(cs)[-max_nbrs]
-            above = cs > kth
-            n_free = max_nbrs - int(above.sum())
-            tied_v = np.sort(cv[cs == kth])
-            assert len(tied_v) > n_free  # a genuine tie at the boundary
-            tw = cs[above].sum() + kth * n_free
-            base = (cs[above] * cv[above]).sum()
-            lo = (base + kth * tied_v[:n_free].sum()) / tw
-            hi = (base + kth * tied_v[-n_free:].sum()) / tw
-            assert lo - 1e-4 <= s[j] <= hi + 1e-4, (q, j, lo, s[j], hi)
-            n_tie += 1
-    print(f"\n{'list' if lists else 'slot'} kernel: tie-induced differences {n_tie}; "
-          f"scores bit-identical to the oracle's {n_bits} of {n_ok}")
-    if lists:
-        assert n_bits == n_ok  # same accumulator steps, same summation order, same roundings
+        assert np.all(err[ok] <= 1e-5), (q, float(err[ok].max()))
+    print(f"\n{'list' if lists else 'slot'} kernel: scores bit-identical to the oracle's "
+          f"{n_bits} of {n_ok}")
+    assert n_bits == n_ok  # same accumulator steps, same summation order, same roundings
 
 
-def test_list_kernel_repeats_long_lists_and_rounds(gpu, oracle, ml_small, model, rng):
+def test_list_kernel_repeats_long_lists_and_rounds(gpu, oracle, ml_small, model, rng, monkeypatch):
     """The candidate-list kernel's corners: a target item named more than once, exactly 1024
     targets (the limit; 1025 go to the slot kernel), the heaviest histories (several rounds of
     256 history rows, the accumulators carried between them) on the most popular targets (lists
@@ -127,7 +99,7 @@ def test_list_kernel_repeats_long_lists_and_rounds(gpu, oracle, ml_small, model,
         h = csr.indices[csr.indptr[u] : csr.indptr[u + 1]].astype(np.int32)
         return h, csr.data[csr.indptr[u] : csr.indptr[u + 1]].astype(np.float32) - means[h]
 
-    def run(users, tgts, max_nbrs, min_nbrs, exact=True):
+    def run(users, tgts, max_nbrs, min_nbrs):
         hs, rs = zip(*[hist(u) for u in users])
         rp, ri, _ = _dev_lists(list(hs), np.int32, gpu)
         _, rr, _ = _dev_lists(list(rs), np.float32, gpu)
@@ -141,12 +113,7 @@ def test_list_kernel_repeats_long_lists_and_rounds(gpu, oracle, ml_small, model,
             assert np.array_equal(c, wc)
             assert np.array_equal(np.isnan(s), np.isnan(ws_))
             ok = ~np.isnan(ws_)
-            if exact:
-                assert np.array_equal(s[ok].view(np.uint32), ws_[ok].view(np.uint32))
-            else:
-                # (slot kernel: equal similarities at the max_nbrs boundary, see above)
-                err = np.abs(s - ws_) / np.maximum(np.abs(ws_), 1e-3)
-                assert np.mean(err[ok] <= 1e-5) > 0.85 and np.all(err[ok] < 0.05)
+            assert np.array_equal(s[ok].view(np.uint32), ws_[ok].view(np.uint32))
         return stats
 
     # repeats + nulls
@@ -157,12 +124,19 @@ def test_list_kernel_repeats_long_lists_and_rounds(gpu, oracle, ml_small, model,
     t1024 = pop[:1024].astype(np.int32)
     st = run(light[:2], [t1024, t1024[:7]], 20, 1)
     assert st == (2, 0, 1024)
-    assert run(light[:2], [pop[:1025].astype(np.int32), t1024[:7]], 20, 1, exact=False)[:2] == (0, 2)
-    # the heaviest histories (2 698, 1 864, 1 291 items: 11 / 8 / 6 rounds) x popular targets
+    assert run(light[:2], [pop[:1025].astype(np.int32), t1024[:7]], 20, 1)[:2] == (0, 2)
+    # the heaviest histories (2 698, 1 864, 1 291 items: 11 / 8 / 6 rounds) x popular targets;
+    # with LK_KNN_SCORE_HEAVY=1000 all three are split into parts by target as well
     tp_ = pop[:100].astype(np.int32)
     for mn in (20, 100, 255):
         assert run(list(heavy) + list(light[:2]), [tp_] * 5, mn, 1)[:2] == (5, 0)
-    assert run(list(heavy[:1]), [tp_], 256, 1, exact=False)[:2] == (0, 1)  # past the list kernel's limit
+    monkeypatch.setenv("LK_KNN_SCORE_HEAVY", "1000")
+    for split in ("2", "8", "64"):
+        monkeypatch.setenv("LK_KNN_SCORE_SPLIT", split)
+        assert run(list(heavy) + list(light[:2]), [tp_, t, tp_, t, tp_], 100, 1)[:2] == (5, 0)
+    monkeypatch.delenv("LK_KNN_SCORE_HEAVY")
+    monkeypatch.delenv("LK_KNN_SCORE_SPLIT")
+    assert run(list(heavy[:1]), [tp_], 256, 1)[:2] == (0, 1)  # past the list kernel's limit
     assert len(hist(heavy[0])[0]) > 4 * 256
 
 
