@@ -388,17 +388,24 @@ __global__ __launch_bounds__(KF_THREADS) void iknn_score_fast_kernel(
             const int64_t r1 = re - r0 > KF_CAP ? r0 + KF_CAP : re;
             const bool last = r1 >= re;
             // ---- stream the history rows [r0, r1): a wave takes KF_U rows at a time -----------
-            for (int64_t rbase = r0 + (int64_t)wave * KF_U; rbase < r1; rbase += KF_WAVES * KF_U) {
-                int64_t myb = 0, mye = 0;
-                float myrate = 0.f;
+            // (row descriptors -- history item -> its row's extent, two dependent loads -- are
+            // fetched one sweep AHEAD, under the column loads and the probing of the current one)
+            auto load_desc = [&](int64_t rbase, int64_t &b, int64_t &e, float &rate) {
+                b = e = 0;
+                rate = 0.f;
                 if (lane < KF_U && rbase + lane < r1) {
                     const int ri = ref_items[rbase + lane];
                     if (ri >= 0 && ri < n_rows) {  // (null reference rows stay empty)
-                        myb = s_ptr[ri];
-                        mye = s_ptr[ri + 1];
+                        b = s_ptr[ri];
+                        e = s_ptr[ri + 1];
                     }
-                    if (SWAP || explicit_) myrate = ref_rates[rbase + lane];
+                    if (SWAP || explicit_) rate = ref_rates[rbase + lane];
                 }
+            };
+            int64_t myb, mye;
+            float myrate;
+            load_desc(r0 + (int64_t)wave * KF_U, myb, mye, myrate);
+            for (int64_t rbase = r0 + (int64_t)wave * KF_U; rbase < r1; rbase += KF_WAVES * KF_U) {
                 int64_t sb[KF_U];
                 int ln[KF_U], t0[KF_U], t1[KF_U];
                 float rate[KF_U];
@@ -410,6 +417,9 @@ __global__ __launch_bounds__(KF_THREADS) void iknn_score_fast_kernel(
                     t0[u] = lane < ln[u] ? s_idx[sb[u] + lane] : -1;
                     t1[u] = lane + 64 < ln[u] ? s_idx[sb[u] + 64 + lane] : -1;
                 }
+                int64_t nb, ne;
+                float nrate;
+                load_desc(rbase + KF_WAVES * KF_U, nb, ne, nrate);  // (past r1: empty)
 #pragma unroll
                 for (int u = 0; u < KF_U; ++u) {
                     const int rr = (int)(rbase - r0) + u;
@@ -418,6 +428,9 @@ __global__ __launch_bounds__(KF_THREADS) void iknn_score_fast_kernel(
                     for (int e = 128 + lane; e < ln[u]; e += 64)
                         hit(s_idx[sb[u] + e], sb[u] + e, rate[u], rr);
                 }
+                myb = nb;
+                mye = ne;
+                myrate = nrate;
             }
             __threadfence_block();
             __syncthreads();
