@@ -156,6 +156,15 @@ int lk_als_plan_set_z(lk_als_plan *plan, const float *d_z);
  * their rows exactly as `sposv` would (and reports a row whose own matrix is not positive
  * definite the same way).  No library call, no host synchronisation.  NULL detaches the buffer. */
 int lk_als_plan_set_z_workspace(lk_als_plan *plan, float *d_zbuf);
+/* Several plans over ROW SLICES of one half-epoch (the sharded engine cuts a rank's rows into
+ * slices so that the all-gather of one slice runs under the solve of the next) share one Z: the
+ * leading slice's plan owns the buffer (lk_als_plan_set_z_workspace) and is launched first; the
+ * others are given that buffer and the device address of the leader's "OtOr is not positive
+ * definite" flag (lk_als_plan_z_flag(leader, leader's workspace)), which they copy into their
+ * own status word at every launch -- same stream, so it is final by then.  NULL / NULL detaches. */
+int lk_als_plan_set_z_shared(lk_als_plan *plan, const float *d_z, const void *d_flag);
+int lk_als_plan_set_z_leader(lk_als_plan *plan, int on); /* form Z even without short rows of its own */
+const void *lk_als_plan_z_flag(const lk_als_plan *plan, const void *d_ws);
 /* OtOr^-1 alone (diagnostics / tests): d_out [KP x KP] floats zero padded, *d_flag = 0 or != 0
  * when d_a is not positive definite, d_ws lk_spd_inverse_workspace_bytes(k) bytes; padded
  * k = 128 / 256 only. */

@@ -24,6 +24,16 @@ Collectives per epoch (world > 1): all-gather of the freshly solved P slice, k x
 all-reduce of the slice Gramians, the same for Q, and a scalar all-reduce of the
 squared deltas.  No collective at world == 1.
 
+Overlap (world > 1).  The gathered rows of a half-epoch are needed only by the NEXT half, so a
+rank's rows are cut into ``slices`` (LK_ALS_OVERLAP_SLICES; default 4) equal blocks and the
+relabelling interleaves them -- new row = slice * (world * m) + rank * m + j -- so that slice s
+of ALL ranks is one contiguous super-block: the half-epoch runs slice by slice (one plan per
+slice), and the in-place all-gather of super-block s is issued asynchronously right behind the
+solve of slice s, i.e. it travels over xGMI while slice s + 1 is being solved; the k x k slice
+Gramians of the rank's own rows are formed meanwhile too.  Only the last slice's gather is
+exposed.  (cfg5 at 8 GPUs: 10 GB of user factors per half-epoch, as long on the links as the
+solve takes.)  The slices share one Z = other @ OtOr^-1 (ALSPlanGroup).
+
 The arithmetic lives behind a small backend object so the sharding / exchange logic
 can be exercised on CPU (gloo) in tests with the oracle standing in for the kernels;
 the product backend is :class:`HipBackend` and there is no fallback.
@@ -41,19 +51,23 @@ import torch.distributed as dist
 from . import _native
 
 
-def deal_rows(lengths: np.ndarray, world: int):
+def deal_rows(lengths: np.ndarray, world: int, slices: int = 1):
     """
     Relabelling of rows for ``world`` ranks: returns (new_of_old, old_of_new, rpr) with
-    ``rpr`` rows per rank; new index = rank*rpr + j for the j-th row dealt to ``rank``.
+    ``rpr`` rows per rank.  The j-th row dealt to ``rank`` goes to slice j % slices of that rank;
+    with m = rpr / slices rows per (rank, slice) block, new index =
+    slice * (world * m) + rank * m + j // slices -- for slices == 1: rank * rpr + j.
     Slots beyond the real rows (padding) have old_of_new == -1.
     """
     n = len(lengths)
     order = np.argsort(-lengths.astype(np.int64), kind="stable")
     rpr = (n + world - 1) // world
+    m = (rpr + slices - 1) // slices
+    rpr = m * slices
     j, r = np.divmod(np.arange(n), world)
     # serpentine dealing keeps the per-rank nnz closer than plain round-robin
     r = np.where(j % 2 == 0, r, world - 1 - r)
-    new_pos = r * rpr + j
+    new_pos = (j % slices) * (world * m) + r * m + j // slices
     new_of_old = np.empty(n, dtype=np.int64)
     new_of_old[order] = new_pos
     old_of_new = np.full(world * rpr, -1, dtype=np.int64)
@@ -89,6 +103,16 @@ class TorchComm:
     def all_gather_rows(self, full: torch.Tensor, lo: int, hi: int):
         "in place: every rank's row block [lo, hi) of ``full`` ends up in everybody's ``full``"
         dist.all_gather_into_tensor(full, full[lo:hi], group=self.group)
+
+    def all_gather_block_async(self, full: torch.Tensor, slo: int, shi: int, lo: int, hi: int):
+        """
+        The same inside the super-block [slo, shi) (= the blocks [lo, hi) of all ranks, in rank
+        order), ASYNCHRONOUS: the collective is ordered behind what the current stream holds now
+        (the solve of these rows) and runs beside what is launched next; ``.wait()`` on the
+        returned handle orders the current stream behind it.
+        """
+        return dist.all_gather_into_tensor(full[slo:shi], full[lo:hi], group=self.group,
+                                           async_op=True)
 
 
 class LoopbackComm:
@@ -151,6 +175,15 @@ class LoopbackComm:
         self._sync_device(full)
         self.sh.barrier.wait()
 
+    class _Done:
+        def wait(self):
+            return True
+
+    def all_gather_block_async(self, full, slo, shi, lo, hi):
+        "(test double: done by the time it returns)"
+        self.all_gather_rows(full, lo, hi)
+        return LoopbackComm._Done()
+
 
 class HipBackend:
     "The product backend: hand-written HIP kernels through the C ABI."
@@ -176,7 +209,9 @@ class HipBackend:
         SciPy COO round trips on the host (2.2 s of the 2.3 s set-up on ML-25M): rows gathered in
         dealt order, columns mapped, entry order inside a row kept (the row solve sums over a
         row's entries; any order).  Returns the plans of this rank's user rows ``u_rng`` and item
-        rows ``i_rng`` -- views into the full device matrices, offsets not rebased.
+        rows ``i_rng`` -- views into the full device matrices, offsets not rebased.  ``u_rng`` /
+        ``i_rng`` may be LISTS of ranges (the row slices of the overlapped half-epoch): the plans
+        then come as one ``ALSPlanGroup`` per orientation.
         """
         D = self.D
         lib = _native.require_gpu()
@@ -223,9 +258,17 @@ class HipBackend:
             view.full_h_indptr = h_ptr  # offsets of ALL rows (every rank holds the full arrays)
             return D.ALSPlan(view, self.k, self.solver)
 
-        return (local(ui_new, h_uptr, u_rng[0], u_rng[1], ni),
-                local(iu_new, h_iptr, i_rng[0], i_rng[1], nu),
-                (int(h_uptr[u_rng[1]] - h_uptr[u_rng[0]]), int(h_iptr[i_rng[1]] - h_iptr[i_rng[0]])))
+        def plans(full, h_ptr, rngs, n_cols):
+            if isinstance(rngs, tuple):
+                return local(full, h_ptr, rngs[0], rngs[1], n_cols), \
+                    int(h_ptr[rngs[1]] - h_ptr[rngs[0]])
+            ps = [local(full, h_ptr, lo, hi, n_cols) for lo, hi in rngs]
+            nnz_ = sum(int(h_ptr[hi] - h_ptr[lo]) for lo, hi in rngs)
+            return (ps[0] if len(ps) == 1 else D.ALSPlanGroup(ps, n_cols)), nnz_
+
+        up, unnz = plans(ui_new, h_uptr, u_rng, ni)
+        ip, innz = plans(iu_new, h_iptr, i_rng, nu)
+        return up, ip, (unnz, innz)
 
     def upload(self, mat: np.ndarray) -> torch.Tensor:
         return self.D.to_device_padded(mat, self.dev)
@@ -328,27 +371,46 @@ class ImplicitALSEngine:
             ui = sps.csr_array(ui)
             ulen = np.diff(ui.indptr)
             ilen = np.bincount(ui.indices, minlength=n_items)
-        self.u_new, self.u_old, self.u_rpr = deal_rows(ulen, self.world)
-        self.i_new, self.i_old, self.i_rpr = deal_rows(ilen, self.world)
+        # row slices of the overlapped half-epoch (module docstring): only with collectives, and
+        # only when a slice is still a full launch
+        S = int(os.environ.get("LK_ALS_OVERLAP_SLICES", "0") or 0)
+        if not self.collective:
+            S = 1
+        elif S <= 0:
+            S = 4 if min(n_users, n_items) // self.world >= 4 * 1024 else 1
+        self.slices = S
+        self.u_new, self.u_old, self.u_rpr = deal_rows(ulen, self.world, S)
+        self.i_new, self.i_old, self.i_rpr = deal_rows(ilen, self.world, S)
         nu, ni = self.world * self.u_rpr, self.world * self.i_rpr
 
-        r = self.rank
-        self.u_lo, self.u_hi = r * self.u_rpr, (r + 1) * self.u_rpr
-        self.i_lo, self.i_hi = r * self.i_rpr, (r + 1) * self.i_rpr
+        r, W = self.rank, self.world
+        um, im = self.u_rpr // S, self.i_rpr // S
+        # this rank's block of slice s, and the super-block (all ranks' blocks) it lies in
+        self.u_blocks = [(s_ * W * um + r * um, s_ * W * um + (r + 1) * um) for s_ in range(S)]
+        self.i_blocks = [(s_ * W * im + r * im, s_ * W * im + (r + 1) * im) for s_ in range(S)]
+        self.u_supers = [(s_ * W * um, (s_ + 1) * W * um) for s_ in range(S)]
+        self.i_supers = [(s_ * W * im, (s_ + 1) * W * im) for s_ in range(S)]
+        self.u_lo, self.u_hi = self.u_blocks[0]  # (the whole block of the rank when S == 1)
+        self.i_lo, self.i_hi = self.i_blocks[0]
         if hasattr(backend, "make_plans_on_device"):
             # product path: one upload, relabel + transpose in HBM
             self.u_plan, self.i_plan, self.local_nnz = backend.make_plans_on_device(
-                ui, self.u_old, self.i_new, self.i_old, (self.u_lo, self.u_hi),
-                (self.i_lo, self.i_hi), ilen)
+                ui, self.u_old, self.i_new, self.i_old,
+                self.u_blocks[0] if S == 1 else self.u_blocks,
+                self.i_blocks[0] if S == 1 else self.i_blocks, ilen)
+            self.u_plans = [self.u_plan] if S == 1 else self.u_plan.plans
+            self.i_plans = [self.i_plan] if S == 1 else self.i_plan.plans
         else:  # host restatement (CPU / gloo tests of the sharding logic)
             assert not on_device
             ui_new = _relabel_csr(ui, self.u_new, nu, self.i_new, ni)
             iu_new = sps.csr_array(ui_new.T)
             iu_new.sort_indices()
-            self.u_plan = backend.make_plan(ui_new[self.u_lo : self.u_hi])
-            self.i_plan = backend.make_plan(iu_new[self.i_lo : self.i_hi])
-            self.local_nnz = (int(ui_new.indptr[self.u_hi] - ui_new.indptr[self.u_lo]),
-                              int(iu_new.indptr[self.i_hi] - iu_new.indptr[self.i_lo]))  # fmt: skip
+            self.u_plans = [backend.make_plan(ui_new[lo:hi]) for lo, hi in self.u_blocks]
+            self.i_plans = [backend.make_plan(iu_new[lo:hi]) for lo, hi in self.i_blocks]
+            self.u_plan, self.i_plan = self.u_plans[0], self.i_plans[0]
+            self.local_nnz = (
+                sum(int(ui_new.indptr[hi] - ui_new.indptr[lo]) for lo, hi in self.u_blocks),
+                sum(int(iu_new.indptr[hi] - iu_new.indptr[lo]) for lo, hi in self.i_blocks))
 
         self._nu, self._ni = nu, ni
         self._qtq = None
@@ -386,78 +448,111 @@ class ImplicitALSEngine:
             self.comm.broadcast(self.P)
             self.comm.broadcast(self.Q)
         # Gramian of the initial Q (user half of epoch 1 needs it); padding rows are 0
-        self._qtq = None if self.explicit else self._gramian(self.Q, self.i_lo, self.i_hi,
+        self._qtq = None if self.explicit else self._gramian(self.Q, self.i_blocks,
                                                              self.user_reg)
 
     # -- collectives ---------------------------------------------------------
-    def _gramian(self, full: torch.Tensor, lo: int, hi: int, reg: float) -> torch.Tensor:
+    def _own_gramian(self, full: torch.Tensor, blocks, reg: float) -> torch.Tensor:
+        "sum of the k x k Gramians of this rank's row blocks (+ reg I once, on rank 0)"
+        g = None
+        for n_, (lo, hi) in enumerate(blocks):
+            part = self.backend.gramian(full[lo:hi], reg if (self.rank == 0 and n_ == 0) else 0.0)
+            g = part if g is None else g + part
+        return g
+
+    def _gramian(self, full: torch.Tensor, blocks, reg: float) -> torch.Tensor:
         "M^T M + reg I from slice Gramians (k x k all-reduce when sharded)."
         if not self.collective:
             return self.backend.gramian(full, reg)
-        g = self.backend.gramian(full[lo:hi], reg if self.rank == 0 else 0.0)
+        g = self._own_gramian(full, blocks, reg)
         self.comm.all_reduce(g)
         return g
 
-    def _exchange(self, full: torch.Tensor, lo: int, hi: int):
-        if self.collective:
-            self.comm.all_gather_rows(full, lo, hi)
+    def _half(self, plans, blocks, supers, this: torch.Tensor, other: torch.Tensor, arg):
+        """
+        One half-epoch, slice by slice: the solve of slice s on the current stream, the in-place
+        all-gather of its super-block issued asynchronously right behind it (it runs beside the
+        solve of slice s + 1).  Returns (per-slice delta scalars, gather handles to wait on).
+        """
+        b = self.backend
+        ds, handles = [], []
+        for plan, (lo, hi), (slo, shi) in zip(plans, blocks, supers):
+            if self.explicit:
+                ds.append(b.half_epoch_explicit(plan, this[lo:hi], other, arg))
+            else:
+                ds.append(b.half_epoch(plan, this[lo:hi], other, arg))
+            if self.collective:
+                if len(plans) == 1:
+                    self.comm.all_gather_rows(this, lo, hi)
+                else:
+                    handles.append(self.comm.all_gather_block_async(this, slo, shi, lo, hi))
+        return ds, handles
+
+    @staticmethod
+    def _wait(handles):
+        for h in handles:
+            h.wait()
 
     # -- training ------------------------------------------------------------
     def train_epoch(self):
         "One epoch; returns device tensors (|dP|, |dQ|) -- no host sync inside."
-        b = self.backend
         if self.explicit:
-            du = b.half_epoch_explicit(self.u_plan, self.P[self.u_lo : self.u_hi], self.Q,
-                                       self.user_reg)
-            du = self._delta(du)
-            self._exchange(self.P, self.u_lo, self.u_hi)
-            di = b.half_epoch_explicit(self.i_plan, self.Q[self.i_lo : self.i_hi], self.P,
-                                       self.item_reg)
-            di = self._delta(di)
-            self._exchange(self.Q, self.i_lo, self.i_hi)
+            ds, hs = self._half(self.u_plans, self.u_blocks, self.u_supers, self.P, self.Q,
+                                self.user_reg)
+            self._wait(hs)
+            du = self._delta(ds)
+            ds, hs = self._half(self.i_plans, self.i_blocks, self.i_supers, self.Q, self.P,
+                                self.item_reg)
+            self._wait(hs)
+            di = self._delta(ds)
             self.epochs_trained += 1
             return du, di
         # user half: previous Q (src/lenskit/als/_common.py:251)
-        du = b.half_epoch(self.u_plan, self.P[self.u_lo : self.u_hi], self.Q, self._qtq)
-        self._exchange(self.P, self.u_lo, self.u_hi)
-        ptp, du = self._gramian_and_delta(self.P, self.u_lo, self.u_hi, self.item_reg, du)
+        ds, hs = self._half(self.u_plans, self.u_blocks, self.u_supers, self.P, self.Q, self._qtq)
+        ptp, du = self._gramian_and_delta(self.P, self.u_blocks, self.item_reg, ds, hs)
         # item half: NEW P (_common.py:253)
-        di = b.half_epoch(self.i_plan, self.Q[self.i_lo : self.i_hi], self.P, ptp)
-        self._exchange(self.Q, self.i_lo, self.i_hi)
+        ds, hs = self._half(self.i_plans, self.i_blocks, self.i_supers, self.Q, self.P, ptp)
         # Q^T Q + user_reg I: next epoch's user half AND the scorer's _OtOr
         # (_save_user_otor, src/lenskit/als/_implicit.py:171-175)
-        self._qtq, di = self._gramian_and_delta(self.Q, self.i_lo, self.i_hi, self.user_reg, di)
+        self._qtq, di = self._gramian_and_delta(self.Q, self.i_blocks, self.user_reg, ds, hs)
         self.epochs_trained += 1
         return du, di
 
-    def _gramian_and_delta(self, full: torch.Tensor, lo: int, hi: int, reg: float,
-                           d: torch.Tensor):
+    def _gramian_and_delta(self, full: torch.Tensor, blocks, reg: float, ds, handles):
         """
         The slice Gramian (k x k) and the slice's squared delta travel in ONE all-reduce
         (k*k + 1 floats: latency-bound on xGMI, so one message instead of two); returns
-        (M^T M + reg I, sqrt(sum of squared row deltas)).
+        (M^T M + reg I, sqrt(sum of squared row deltas)).  The Gramians of the rank's OWN rows are
+        formed while the row gathers of the half-epoch are still on the links; the gathers are
+        waited for here, before the next half reads the full matrix.
         """
         if not self.collective:
-            return self.backend.gramian(full, reg), d.clone()
-        g = self.backend.gramian(full[lo:hi], reg if self.rank == 0 else 0.0)
+            return self.backend.gramian(full, reg), ds[0].clone()
+        g = self._own_gramian(full, blocks, reg)
         kk = self.k * self.k
         buf = torch.empty(kk + 1, dtype=torch.float32, device=g.device)
         buf[:kk] = g.reshape(-1)
-        buf[kk:] = (d * d).reshape(-1)
+        sq = ds[0] * ds[0]
+        for d in ds[1:]:
+            sq = sq + d * d
+        buf[kk:] = sq.reshape(-1)
+        self._wait(handles)
         self.comm.all_reduce(buf)
         return buf[:kk].reshape(self.k, self.k).contiguous(), buf[kk:].sqrt()
 
-    def _delta(self, d: torch.Tensor) -> torch.Tensor:
+    def _delta(self, ds) -> torch.Tensor:
         if not self.collective:
-            return d.clone()
-        sq = d * d
+            return ds[0].clone()
+        sq = ds[0] * ds[0]
+        for d in ds[1:]:
+            sq = sq + d * d
         self.comm.all_reduce(sq)
         return sq.sqrt()
 
     def check(self):
         "Synchronise; raise RuntimeError('ALS solve error: ...') if a solve failed."
-        self.backend.check(self.u_plan)
-        self.backend.check(self.i_plan)
+        for plan in self.u_plans + self.i_plans:
+            self.backend.check(plan)
 
     # -- results (host, original labelling) ------------------------------------
     def user_embeddings(self) -> np.ndarray:

@@ -263,13 +263,26 @@ class ALSPlan:
             self.woodbury_rows = self.short_rows  # k = 128: only the 16 x 16 variant pays
         self.use_wb = (self.kp > 64 and self.solver == _native.SOLVER_CHOLESKY and wb_min > 0
                        and self.woodbury_rows >= wb_min)
+        self.negative_values = False
         if self.use_wb and csr.values is not None and csr.values.numel() > 0 \
                 and float(csr.values.min()) < 0.0:
             # the Woodbury kernels take sqrt(v) of every confidence increment: with negative
             # values (use_ratings=True and negative ratings) they would flag rows the dense
             # sposv path still solves -- such matrices keep the dense kernels for every row
             self.use_wb = False
+            self.negative_values = True
         self._z = None
+        self._z_leader = None  # another slice's plan whose Z this one uses (share_z_from)
+        self._z_shared_set = False
+
+    def share_z_from(self, leader: "ALSPlan"):
+        """
+        Row slices of one half-epoch share one Z = other @ OtOr^-1: ``leader`` (launched first in
+        every half-epoch) owns the buffer and forms Z, this plan reads it and copies the leader's
+        "OtOr is not positive definite" flag at every launch (lk_als_plan_set_z_shared).
+        """
+        self._z_leader = leader
+        check(_native.load().lk_als_plan_set_z_leader(leader._h, 1), "lk_als_plan_set_z_leader")
 
     def set_ctl(self, ctl: "TaskCtl | None"):
         "Attach (or detach) a cancel / progress block; check_status then reports a cancel."
@@ -296,7 +309,16 @@ class ALSPlan:
         csr = self.csr
         assert this.shape == (csr.shape[0], self.kp) and other.shape == (csr.shape[1], self.kp)
         assert this.is_contiguous() and other.is_contiguous() and otor.is_contiguous()
-        if self.use_wb and self._z is None:
+        if self.use_wb and self._z_leader is not None:
+            if not self._z_shared_set:
+                ld = self._z_leader
+                assert ld._z is not None, "the leading slice's half-epoch must be launched first"
+                lib = _native.load()
+                check(lib.lk_als_plan_set_z_shared(self._h, _ptr(ld._z),
+                                                   lib.lk_als_plan_z_flag(ld._h, _ptr(ld.ws))),
+                      "lk_als_plan_set_z_shared")
+                self._z_shared_set = True
+        elif self.use_wb and self._z is None:
             # the library forms Z = other @ OtOr^-1 itself at every half-epoch (OtOr^-1 to float64
             # accuracy on the device, csrc/spd_inverse.hip; Z on the scoring GEMM): this side only
             # lends it the [n_cols x KP] buffer -- no library factorisation, no host round trip
@@ -356,6 +378,70 @@ class ALSPlan:
                 self._h = ctypes.c_void_p(0)
         except Exception:
             pass
+
+
+class ALSPlanGroup:
+    """
+    The plans of the ROW SLICES of one orientation on one rank (the sharded engine cuts a rank's
+    rows into slices so that the all-gather of one slice runs under the solve of the next),
+    presented as one plan to whoever only asks about it (bench / tests): timing and statistics
+    are summed, settings go to every slice.  The slices share one Z (the first slice leads).
+    """
+
+    def __init__(self, plans: list[ALSPlan], n_cols: int):
+        from types import SimpleNamespace
+
+        assert len(plans) >= 1
+        self.plans = plans
+        p0 = plans[0]
+        self.k, self.kp, self.solver = p0.k, p0.kp, p0.solver
+        lens = np.concatenate([np.diff(p.csr.h_indptr) for p in plans])
+        h = np.zeros(len(lens) + 1, dtype=p0.csr.h_indptr.dtype)
+        np.cumsum(lens, out=h[1:])
+        # the rank's rows in slice order (row lengths / shapes only: the slices are not contiguous)
+        self.csr = SimpleNamespace(h_indptr=h, indices=p0.csr.indices, values=p0.csr.values,
+                                   shape=(len(lens), n_cols),
+                                   full_h_indptr=getattr(p0.csr, "full_h_indptr", None))
+        self.short_rows = sum(p.short_rows for p in plans)
+        self.woodbury_rows = sum(p.woodbury_rows for p in plans)
+        wb_min = int(os.environ.get("LK_ALS_WB_MIN_ROWS", "4096"))
+        # the Woodbury decision belongs to the half-epoch, not to a slice of it
+        use_wb = (self.kp > 64 and self.solver == _native.SOLVER_CHOLESKY and wb_min > 0
+                  and self.woodbury_rows >= wb_min
+                  and not any(p.negative_values for p in plans))
+        for p in plans:
+            p.use_wb = use_wb
+        for p in plans[1:]:
+            p.share_z_from(p0)
+
+    @property
+    def use_wb(self) -> bool:
+        return bool(self.plans[0].use_wb)
+
+    def set_cg(self, tol: float, max_iter: int = 0):
+        for p in self.plans:
+            p.set_cg(tol, max_iter)
+
+    def cg_stats(self):
+        st = [p.cg_stats() for p in self.plans]
+        return sum(s[0] for s in st), sum(s[1] for s in st)
+
+    def set_ctl(self, ctl):
+        for p in self.plans:
+            p.set_ctl(ctl)
+
+    def enable_timing(self, enable: bool = True):
+        for p in self.plans:
+            p.enable_timing(enable)
+
+    def get_timing(self):
+        "-> (chunk ms, solve ms summed over the slices, half-epochs recorded)"
+        ts = [p.get_timing() for p in self.plans]
+        return sum(t[0] for t in ts), sum(t[1] for t in ts), ts[0][2]
+
+    def check_status(self):
+        for p in self.plans:
+            p.check_status()
 
 
 def iknn_build(ui: DeviceCSR, iu: DeviceCSR, min_sim: float, save_nbrs=None,

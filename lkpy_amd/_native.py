@@ -71,6 +71,9 @@ def _declare(lib):
         "lk_als_plan_woodbury_rows": (c_int64, [vp]),
         "lk_als_plan_set_z": (c_int, [vp, vp]),
         "lk_als_plan_set_z_workspace": (c_int, [vp, vp]),
+        "lk_als_plan_set_z_shared": (c_int, [vp, vp, vp]),
+        "lk_als_plan_set_z_leader": (c_int, [vp, c_int]),
+        "lk_als_plan_z_flag": (vp, [vp, vp]),
         "lk_spd_inverse_workspace_bytes": (c_size_t, [c_int32]),
         "lk_spd_inverse": (c_int, [vp, c_int32, c_int32, vp, vp, vp, vp]),
         "lk_als_implicit_half_epoch": (

@@ -821,8 +821,8 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     // kernel does not poll it)
     const float *z = p->d_z;
     const bool prefix = p->dense_limit >= 0;  // CG hybrid: the chunked rows only, no Woodbury
-    const bool own_z = !EXPL && p->d_zbuf != nullptr && !p->ctl && p->t_short < n_rows &&
-                       n_cols > 0 && !prefix;
+    const bool own_z = !EXPL && p->d_zbuf != nullptr && !p->ctl &&
+                       (p->t_short < n_rows || p->z_for_others) && n_cols > 0 && !prefix;
     if (own_z) {
         // Z = other * OtOr^-1 for this half-epoch, all on this stream: the inverse to float64
         // accuracy (spd_inverse.hip; status[1] = its flag, tested by the Woodbury kernels and by
@@ -834,6 +834,10 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
         if (rc != LK_OK) return rc;
         z = p->d_zbuf;
     }
+    if (!EXPL && p->d_zflag_src && !own_z)  // Z (and its validity) come from the leading slice
+        LK_HIP_CHECK(hipMemcpyAsync(status + 1, p->d_zflag_src, sizeof(int),
+                                    hipMemcpyDeviceToDevice, st));
+    const bool shared_z = !EXPL && p->d_zflag_src != nullptr && !own_z;
     const bool use_wb = !EXPL && z != nullptr && !p->ctl && p->t_short < n_rows && !prefix;
     // (17 .. 64 entries: only at padded k = 256 -- at k = 128 the 64 x 64 system costs as much as
     // the dense solve of this file, measured on the ML-25M shape)
@@ -848,7 +852,7 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
         rc = als_wb64_launch(p, indptr, IS64 ? 1 : 0, indices, values, n_dense, p->t_short,
                              this_, other, z, row_delta, status, st);
         if (rc != LK_OK) return rc;
-        if (own_z)  // no-op unless spd_inverse raised its flag
+        if (own_z || shared_z)  // no-op unless spd_inverse raised its flag
             hipLaunchKernelGGL((als_blk_fallback_kernel<NT, IS64>), dim3(1024), dim3(256), 0, st,
                                static_cast<const IT *>(indptr), indices, values, p->d_order,
                                n_dense, n_rows, p->d_row_slab, other, this_, notor_p, slabs,

@@ -1734,13 +1734,42 @@ extern "C" int lk_als_plan_set_z(lk_als_plan *p, const float *d_z)
     return LK_OK;
 }
 
+extern "C" int lk_als_plan_set_z_shared(lk_als_plan *p, const float *d_z, const void *d_flag)
+{
+    LK_REQUIRE(p != nullptr, "lk_als_plan_set_z_shared: null plan");
+    LK_REQUIRE((d_z == nullptr) == (d_flag == nullptr),
+               "lk_als_plan_set_z_shared: Z and its flag word go together");
+    LK_REQUIRE(d_z == nullptr || p->KP > 64,
+               "lk_als_plan_set_z_shared: the Woodbury kernels serve padded k = 128 / 256 only");
+    p->d_z = d_z;
+    p->d_zflag_src = static_cast<const int *>(d_flag);
+    if (d_z) p->d_zbuf = nullptr;
+    return LK_OK;
+}
+
+extern "C" int lk_als_plan_set_z_leader(lk_als_plan *p, int on)
+{
+    LK_REQUIRE(p != nullptr, "lk_als_plan_set_z_leader: null plan");
+    p->z_for_others = on != 0;
+    return LK_OK;
+}
+
+extern "C" const void *lk_als_plan_z_flag(const lk_als_plan *p, const void *d_ws)
+{
+    if (!p || !d_ws) return nullptr;
+    return static_cast<const char *>(d_ws) + p->off_status + sizeof(int);
+}
+
 extern "C" int lk_als_plan_set_z_workspace(lk_als_plan *p, float *d_zbuf)
 {
     LK_REQUIRE(p != nullptr, "lk_als_plan_set_z_workspace: null plan");
     LK_REQUIRE(d_zbuf == nullptr || p->KP > 64,
                "lk_als_plan_set_z_workspace: the Woodbury kernels serve padded k = 128 / 256 only");
     p->d_zbuf = d_zbuf;
-    if (d_zbuf) p->d_z = nullptr;
+    if (d_zbuf) {
+        p->d_z = nullptr;
+        p->d_zflag_src = nullptr;
+    }
     return LK_OK;
 }
 

@@ -40,6 +40,12 @@ struct lk_als_plan {
     // ... or a caller-owned [n_cols x KP] buffer the LIBRARY fills with Z at every implicit
     // half-epoch (lk_als_plan_set_z_workspace): OtOr^-1 by spd_inverse.hip, Z by the scoring GEMM
     float *d_zbuf = nullptr;
+    // ... or Z as ANOTHER plan of the same half-epoch forms it (lk_als_plan_set_z_shared: the row
+    // slices of a sharded half-epoch share one Z): d_z = that plan's buffer, d_zflag_src = the
+    // device word holding its "OtOr is not positive definite" flag, copied into this plan's
+    // status[1] at every launch
+    const int *d_zflag_src = nullptr;
+    bool z_for_others = false;  // leading slice: form Z even if this slice has no short row itself
     size_t off_ginv = 0, off_invws = 0;  // [KP x KP] float inverse, spd_inverse scratch
     // device-side schedule
     int32_t *d_order = nullptr;      // [n_rows] rows, longest first

@@ -57,14 +57,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, ui, k, P0, Q0, epochs, out, explicit=False):
+def _worker(rank, world, port, ui, k, P0, Q0, epochs, out, explicit=False, slices=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["LK_ALS_OVERLAP_SLICES"] = str(slices)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lkpy_amd._als_engine import ImplicitALSEngine
 
         eng = ImplicitALSEngine(ui, k, 0.1, 0.2, P0, Q0, OracleBackend(k), explicit=explicit)
+        assert eng.slices == (slices if slices > 0 else 1) and len(eng.u_plans) == eng.slices
         deltas = []
         for _ in range(epochs):
             du, di = eng.train_epoch()
@@ -88,10 +90,26 @@ def test_deal_rows_balances_and_round_trips():
         per_rank = [lens[old_of_new[r * rpr:(r + 1) * rpr][old_of_new[r * rpr:(r + 1) * rpr] >= 0]].sum()
                     for r in range(world)]
         assert max(per_rank) - min(per_rank) <= lens.max()  # nnz-balanced to one row
+        # the sliced layout of the overlapped half-epoch: slice s of ALL ranks is contiguous, a
+        # (rank, slice) block holds every slices-th row dealt to the rank
+        for S in (2, 3, 4):
+            new2, old2, rpr2 = deal_rows(lens, world, S)
+            m = rpr2 // S
+            assert rpr2 % S == 0 and rpr2 >= rpr and len(old2) == world * rpr2
+            assert np.array_equal(old2[new2], np.arange(len(lens)))
+            assert np.array_equal(np.sort(new2), np.sort(np.flatnonzero(old2 >= 0)))
+            for r in range(world):
+                mine = np.concatenate([old2[s_ * world * m + r * m: s_ * world * m + (r + 1) * m]
+                                       for s_ in range(S)])
+                base = old_of_new[r * rpr:(r + 1) * rpr]
+                assert np.array_equal(np.sort(mine[mine >= 0]), np.sort(base[base >= 0]))
+                blk = [lens[b[b >= 0]].sum() for b in
+                       (old2[s_ * world * m + r * m: s_ * world * m + (r + 1) * m] for s_ in range(S))]
+                assert max(blk) - min(blk) <= 2 * lens.max() + lens.sum() // (world * 50)
 
 
-@pytest.mark.parametrize("world", [2])
-def test_sharded_engine_matches_single_process(oracle, world):
+@pytest.mark.parametrize("world,slices", [(2, 0), (2, 3)])
+def test_sharded_engine_matches_single_process(oracle, world, slices):
     rng = np.random.default_rng(5)
     n_users, n_items, k, epochs = 301, 157, 8, 3
     dense = rng.random((n_users, n_items)) < 0.06
@@ -115,7 +133,10 @@ def test_sharded_engine_matches_single_process(oracle, world):
     mgr = mp.Manager()
     out = mgr.dict()
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, ui, k, P0, Q0, epochs, out), nprocs=world, join=True)
+    # (slices = 3: the half-epochs run slice by slice with asynchronous gloo all-gathers of the
+    # interleaved super-blocks)
+    mp.spawn(_worker, args=(world, port, ui, k, P0, Q0, epochs, out, False, slices), nprocs=world,
+             join=True)
     assert sorted(out.keys()) == list(range(world))
     for r in range(world):
         gP, gQ, gO, gd, lnnz = out[r]
@@ -129,8 +150,8 @@ def test_sharded_engine_matches_single_process(oracle, world):
     assert out[0][4][0] + out[1][4][0] == ui.nnz and abs(out[0][4][0] - out[1][4][0]) < 0.2 * ui.nnz
 
 
-@pytest.mark.parametrize("world", [2])
-def test_sharded_explicit_engine_matches_single_process(oracle, world):
+@pytest.mark.parametrize("world,slices", [(2, 0), (2, 2)])
+def test_sharded_explicit_engine_matches_single_process(oracle, world, slices):
     "The biased-MF (explicit) mode of the engine: same sharding and exchanges, no Gramian."
     rng = np.random.default_rng(6)
     n_users, n_items, k, epochs = 211, 97, 6, 3
@@ -153,8 +174,8 @@ def test_sharded_explicit_engine_matches_single_process(oracle, world):
         ref_d.append((du, di))
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ui, k, P0, Q0, epochs, out, True), nprocs=world,
-             join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ui, k, P0, Q0, epochs, out, True, slices),
+             nprocs=world, join=True)
     for r in range(world):
         gP, gQ, _, gd, _ = out[r]
         assert np.allclose(gP, P, rtol=1e-3, atol=1e-5) and np.allclose(gQ, Q, rtol=1e-3, atol=1e-5)

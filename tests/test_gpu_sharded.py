@@ -38,6 +38,7 @@ def _run_world(world, ui, k, P0, Q0, gpu, epochs):
             eng = ImplicitALSEngine(ui, k, 0.1, 0.1, P0, Q0,
                                     HipBackend(k, gpu, _native.SOLVER_CHOLESKY), comm=comms[r])
             assert eng.world == world and eng.rank == r and eng.collective
+            assert len(eng.u_plans) == eng.slices and len(eng.i_plans) == eng.slices
             for _ in range(epochs):
                 du, di = eng.train_epoch()
             eng.check()
@@ -70,15 +71,20 @@ def _short_row_matrix(rng, n_users, n_items, mean_len):
                          shape=(n_users, n_items))
 
 
-@pytest.mark.parametrize("world,k,wb", [(2, 32, False), (3, 64, False), (2, 128, True),
-                                        (3, 256, True), (3, 128, False)])
-def test_sharded_device_path_on_one_gpu(gpu, oracle, monkeypatch, world, k, wb):
+@pytest.mark.parametrize("world,k,wb,slices", [(2, 32, False, 1), (3, 64, False, 1),
+                                               (2, 128, True, 1), (3, 256, True, 1),
+                                               (3, 128, False, 1), (2, 64, False, 4),
+                                               (3, 128, True, 3), (2, 256, True, 2)])
+def test_sharded_device_path_on_one_gpu(gpu, oracle, monkeypatch, world, k, wb, slices):
     import torch
 
     from lkpy_amd import _native, synth
     from lkpy_amd._als_engine import HipBackend, ImplicitALSEngine
 
     monkeypatch.setenv("LK_ALS_WB_MIN_ROWS", "1" if wb else "0")
+    # slices > 1: the overlapped half-epoch (one plan per row slice, interleaved relabelling,
+    # super-block gathers, the slices of a half sharing one Z)
+    monkeypatch.setenv("LK_ALS_OVERLAP_SLICES", str(slices))
     rng = np.random.default_rng(2)
     if wb:  # short rows (geometric, mean 8): the Woodbury kernels and a shard's Z buffer
         ui = _short_row_matrix(rng, 4001, 1501, 8)
