@@ -25,7 +25,8 @@ all-reduce of the slice Gramians, the same for Q, and a scalar all-reduce of the
 squared deltas.  No collective at world == 1.
 
 Overlap (world > 1).  The gathered rows of a half-epoch are needed only by the NEXT half, so a
-rank's rows are cut into ``slices`` (LK_ALS_OVERLAP_SLICES; default 4) equal blocks and the
+rank's rows are cut into ``slices`` (LK_ALS_OVERLAP_SLICES; automatic: 4 for factor matrices of
+256 MB and more, else 1) equal blocks and the
 relabelling interleaves them -- new row = slice * (world * m) + rank * m + j -- so that slice s
 of ALL ranks is one contiguous super-block: the half-epoch runs slice by slice (one plan per
 slice), and the in-place all-gather of super-block s is issued asynchronously right behind the
@@ -377,7 +378,12 @@ class ImplicitALSEngine:
         if not self.collective:
             S = 1
         elif S <= 0:
-            S = 4 if min(n_users, n_items) // self.world >= 4 * 1024 else 1
+            # automatic: worth its extra launches (one plan per slice) where the gathered factor
+            # matrix is big -- 256 MB and up: cfg5's 10 GB, not cfg2's 41 MB, whose gather is as
+            # short as the launches it would add -- and a slice is still a full launch
+            gathered = max(n_users, n_items) * getattr(backend, "kp", self.k) * 4
+            S = 4 if (gathered >= (256 << 20)
+                      and min(n_users, n_items) // self.world >= 4 * 1024) else 1
         self.slices = S
         self.u_new, self.u_old, self.u_rpr = deal_rows(ulen, self.world, S)
         self.i_new, self.i_old, self.i_rpr = deal_rows(ilen, self.world, S)
