@@ -118,7 +118,7 @@ class TorchComm:
 
 class LoopbackComm:
     """
-    ``world`` ranks as THREADS of one process exchanging through shared memory -- the same three
+    ``world`` ranks as THREADS of one process exchanging through shared memory -- the same
     collectives with the same semantics (rank-ordered sums, in-place row gather), so that the
     row-sharded engine can run with two or more ranks on ONE GPU (``tests/test_gpu_sharded.py``:
     the device relabelling with padding rows, the plan views with non-zero row offsets, the
