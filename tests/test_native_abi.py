@@ -53,3 +53,14 @@ def test_product_package_never_imports_the_oracle():
     for f in pkg.rglob("*.py"):
         text = f.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_integration_doc_names_every_entry_point():
+    "INTEGRATION.md is the maintainer's map of the C ABI: nothing exported may be missing from it"
+    from pathlib import Path
+
+    from lkpy_amd import _native
+
+    text = (Path(__file__).resolve().parent.parent / "INTEGRATION.md").read_text()
+    missing = [s for s in _native.declared_symbols() if s not in text]
+    assert not missing, missing
