@@ -551,7 +551,8 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
             "solver": "cholesky" if eng.u_plan.solver == 0 else "cg",
             "reg": reg, "weight": 40.0,
             "longest_user_row": int(ulen.max()), "busiest_item": int(ilen.max()),
-            "parallelism": "row-sharded x%d" % world if world > 1 else "single GPU",
+            "parallelism": ("row-sharded x%d, %d row slices per half-epoch (gathers under the solve)"
+                            % (world, getattr(eng, "slices", 1))) if world > 1 else "single GPU",
         },
         "final_deltas": [float(du.item()), float(di.item())],
         "generate_seconds": round(gen_seconds, 3),
@@ -936,7 +937,8 @@ def main():
             "nnz": info["nnz"],
             "reg": reg,
             "weight": weight,
-            "parallelism": "row-sharded x%d" % world if world > 1 else "single GPU",
+            "parallelism": ("row-sharded x%d, %d row slices per half-epoch (gathers under the solve)"
+                            % (world, getattr(eng, "slices", 1))) if world > 1 else "single GPU",
         },
         "final_deltas": list(deltas),
         "setup_seconds": round(setup_seconds, 4),
