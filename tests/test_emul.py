@@ -99,3 +99,22 @@ def test_cg_reduce8_model():
         assert abs(d[lane] - tot[ka.cg_rev3(lane & 7)]) < 1e-12
     assert sorted(ka.cg_rev3(j) for j in range(8)) == list(range(8))
     assert all(ka.cg_rev3(ka.cg_rev3(j)) == j for j in range(8))
+
+
+def test_inverted_diagonal_blocks_are_as_accurate_as_substitution():
+    """tools/emul/blk_diaginv.py -- the numerics of the next k = 128 / 256 row solve:
+    a blocked float32 Cholesky with INVERTED 16 x 16 diagonal blocks (panel rows and both
+    triangular solves as small GEMMs) against the substitution form the kernel uses today."""
+    import blk_diaginv as b
+
+    rng = np.random.default_rng(3)
+    rel = lambda a, c: float(np.linalg.norm(a - c) / np.linalg.norm(c))  # noqa: E731
+    for k, cond in ((48, 1e2), (128, 1e3), (128, 1e5)):
+        q, _ = np.linalg.qr(rng.standard_normal((k, k)))
+        a = (q * np.geomspace(1.0, cond, k)) @ q.T
+        y = rng.standard_normal(k)
+        x64 = np.linalg.solve(a, y)
+        es, ei = rel(b.solve_blocked(a, y, False), x64), rel(b.solve_blocked(a, y, True), x64)
+        u = 2.0 ** -24
+        assert es < 2 * cond * u and ei < 2 * cond * u, (k, cond, es, ei)
+        assert ei < 3 * es + 1e-7, (k, cond, es, ei)
