@@ -286,6 +286,14 @@ int lk_iknn_build_fill(const lk_iknn_plan *plan, const void *d_ui_indptr,
  *     not end up with n valid candidates -- overflowing lists, thresholds that proved too
  *     high -- and redoes exactly those rows through the panel path);
  *   - panel: 2048 users at a time are scored into the workspace and selected from there.
+ * Workspace (ask lk_score_topk_workspace_bytes, never assume): the fused path works on batches
+ * of up to 262 144 users (LK_TOPK_FUSED_ROWS; 65 536 before round 3) and holds per batch
+ * 16 KiB of candidate lists per user (<= 4 GiB) plus the stage-1 sample panel,
+ * users x ceil(n_items / 16) floats, which is what bounds the batch: never more than 16 GiB
+ * (for catalogues so large that 8192 sample rows would exceed it the batch shrinks below 8192
+ * rather than the panel growing).  Ceiling: ~20.5 GiB, reached only with >= 262 144 users and
+ * >= 250 000 items; ML-25M (162 541 x 62 423): 5.3 GiB.  The panel path needs 2048 x n_items
+ * floats.
  * ---------------------------------------------------------------------- */
 size_t lk_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t n);
 int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_users, const float *d_items,

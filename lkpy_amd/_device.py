@@ -263,17 +263,28 @@ class ALSPlan:
             self.woodbury_rows = self.short_rows  # k = 128: only the 16 x 16 variant pays
         self.use_wb = (self.kp > 64 and self.solver == _native.SOLVER_CHOLESKY and wb_min > 0
                        and self.woodbury_rows >= wb_min)
-        self.negative_values = False
-        if self.use_wb and csr.values is not None and csr.values.numel() > 0 \
-                and float(csr.values.min()) < 0.0:
+        self._negative_values = None  # not scanned yet (one reduction + one host sync)
+        if self.use_wb and self.negative_values:
             # the Woodbury kernels take sqrt(v) of every confidence increment: with negative
             # values (use_ratings=True and negative ratings) they would flag rows the dense
             # sposv path still solves -- such matrices keep the dense kernels for every row
             self.use_wb = False
-            self.negative_values = True
         self._z = None
         self._z_leader = None  # another slice's plan whose Z this one uses (share_z_from)
         self._z_shared_set = False
+
+    @property
+    def negative_values(self) -> bool:
+        """
+        Does the matrix hold a confidence value below zero?  Scanned on first use and remembered:
+        whoever is about to switch the Woodbury kernels on asks -- this plan for itself, an
+        ``ALSPlanGroup`` for the half-epoch as a whole (its decision can differ from every
+        slice's own: slices each below LK_ALS_WB_MIN_ROWS whose sum is above it).
+        """
+        if self._negative_values is None:
+            v = self.csr.values
+            self._negative_values = bool(v is not None and v.numel() > 0 and float(v.min()) < 0.0)
+        return self._negative_values
 
     def share_z_from(self, leader: "ALSPlan"):
         """
@@ -407,8 +418,19 @@ class ALSPlanGroup:
         wb_min = int(os.environ.get("LK_ALS_WB_MIN_ROWS", "4096"))
         # the Woodbury decision belongs to the half-epoch, not to a slice of it
         use_wb = (self.kp > 64 and self.solver == _native.SOLVER_CHOLESKY and wb_min > 0
-                  and self.woodbury_rows >= wb_min
-                  and not any(p.negative_values for p in plans))
+                  and self.woodbury_rows >= wb_min)
+        if use_wb:
+            # the slices are views into ONE values array (offsets are not rebased): scan each
+            # distinct array once, whether or not a slice had reason to look on its own
+            seen = {}
+            for p in plans:
+                v = p.csr.values
+                key = None if v is None else (v.data_ptr(), v.numel())
+                if key not in seen:
+                    seen[key] = p.negative_values
+                else:
+                    p._negative_values = seen[key]
+            use_wb = not any(seen.values())
         for p in plans:
             p.use_wb = use_wb
         for p in plans[1:]:

@@ -325,13 +325,16 @@ class ImplicitMFTrainer(ModelTrainer):
         rmat = ints.scipy(attribute="rating", layout="csr") if self.scorer.config.use_ratings \
             else ints.scipy(layout="csr")
         vals = np.require(rmat.data, dtype=np.float32) * np.float32(self.scorer.config.weight)
-        out = sps.csr_array((vals, rmat.indices, rmat.indptr), shape=rmat.shape)
         if getattr(data, "has_duplicates", True):
             # repeated (user, item) pairs: ONE entry with the summed confidence, exactly what
             # the reference's COO -> CSR conversion produces (y gets (2v + 1) once, not (v + 1)
-            # twice)
+            # twice).  ``scipy()`` hands out the Dataset's OWN index arrays without a copy and
+            # ``sum_duplicates`` rewrites indices / indptr in place: canonicalise private copies,
+            # never the dataset (tests/test_host_logic.py::test_prepare_matrix_leaves_dataset_alone)
+            out = sps.csr_array((vals, rmat.indices.copy(), rmat.indptr.copy()), shape=rmat.shape)
             out.sum_duplicates()
-        return out
+            return out
+        return sps.csr_array((vals, rmat.indices, rmat.indptr), shape=rmat.shape)
 
     def initial_params(self, nrows: int, ncols: int) -> np.ndarray:
         "_implicit.py:152-155"
@@ -399,9 +402,6 @@ class BiasedMFScorer(UsesTrainer, Component):
 
     def __getstate__(self):
         return _scorer_state(self)
-
-    def __setstate__(self, state):
-        _restore_scorer_state(self, state)
 
     def __setstate__(self, state):
         _restore_scorer_state(self, state)

@@ -1284,7 +1284,12 @@ static int64_t fused_rows(int64_t n_sub_padded)
     const int64_t by_panel = ((int64_t)16 << 30) / (n_sub_padded * 4);
     if (r > by_panel) r = by_panel;
     r = r / 128 * 128;
-    return r < 8192 ? 8192 : r;
+    // floor: a batch is at least 8192 rows -- unless the catalogue is so large (sample > 512 Ki
+    // items) that 8192 sample rows would not fit the 16 GiB panel bound: the bound wins
+    int64_t lo = 8192;
+    if (lo > by_panel / 128 * 128) lo = by_panel / 128 * 128;
+    if (lo < 128) lo = 128;
+    return r < lo ? lo : r;
 }
 constexpr int FUSED_MAX_N = 128;       // expected candidates <= 8 n <= FUSED_CAP / 2
 

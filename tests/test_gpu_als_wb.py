@@ -183,3 +183,58 @@ def test_otor_not_positive_definite_takes_the_dense_fallback_on_the_device(gpu, 
     assert np.all(got[lens == 0] == 0.0) and np.all(dense[lens == 0] == 0.0)
     # every non-empty row's matrix is singular in both runs: whatever sposv-like garbage the
     # solves leave is reported through the status word, not compared
+
+
+def test_row_slices_with_negative_values_keep_the_dense_kernels(gpu, oracle, rng, monkeypatch):
+    """three row slices, each with fewer short rows than LK_ALS_WB_MIN_ROWS
+    (so no slice looks at the values on its own) but more in sum (so the GROUP wants the Woodbury
+    kernels), over a matrix with negative confidence values (use_ratings with negative ratings):
+    the group must find them and keep the dense kernels -- sqrt(v) of a negative value would be
+    NaN -- and the result must be the oracle's dense sposv solution."""
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    k, n_rows, n_cols = 128, 1800, 2500
+    mat = _short_csr(rng, n_rows, n_cols, True)
+    mat.data[rng.random(mat.nnz) < 0.1] *= -0.05  # a few small negative increments (A stays SPD)
+    assert mat.data.min() < 0
+    other = (rng.standard_normal((n_cols, k)) * 0.1).astype(np.float32)
+    this = (rng.standard_normal((n_rows, k)) * 0.1).astype(np.float32)
+    want = this.copy()
+    oracle.als_half_epoch(mat, want, other, oracle.implicit_otor(other, 0.1))
+
+    full = D.DeviceCSR.from_arrays(mat.indptr.astype(np.int32), mat.indices, mat.data, mat.shape,
+                                   gpu)
+    lens = np.diff(mat.indptr)
+    cuts = [(0, 600), (600, 1200), (1200, 1800)]
+    short = [int(((lens[lo:hi] <= 16)).sum()) for lo, hi in cuts]
+    monkeypatch.setenv("LK_ALS_WB_MIN_ROWS", str(max(short) + 1))
+    assert sum(short) >= max(short) + 1
+    plans = []
+    for lo, hi in cuts:
+        view = D.DeviceCSR(full.indptr[lo:hi + 1], full.indices, full.values, (hi - lo, n_cols),
+                           full.h_indptr[lo:hi + 1])
+        plans.append(D.ALSPlan(view, k, _native.SOLVER_CHOLESKY))
+        assert not plans[-1].use_wb and plans[-1]._negative_values is None  # nobody looked yet
+    group = D.ALSPlanGroup(plans, n_cols)
+    assert not group.use_wb and all(p.negative_values and not p.use_wb for p in plans)
+
+    d_other = D.to_device_padded(other, gpu)
+    d_otor = D.Gramian(k, gpu)(d_other, 0.1)
+    d_this = D.to_device_padded(this, gpu)
+    for (lo, hi), p in zip(cuts, plans):
+        p.half_epoch(d_this[lo:hi], d_other, d_otor)
+    group.check_status()
+    got = D.to_host_unpadded(d_this, k)
+    assert np.isfinite(got).all()
+    rn = np.linalg.norm(want, axis=1)
+    assert np.all(np.linalg.norm(got - want, axis=1) <= 5 * RTOL * np.maximum(rn, 1e-3))
+
+    # the same slices over non-negative values: the group does switch the Woodbury kernels on
+    mat.data[:] = np.abs(mat.data)
+    full2 = D.DeviceCSR.from_arrays(mat.indptr.astype(np.int32), mat.indices, mat.data, mat.shape,
+                                    gpu)
+    plans2 = [D.ALSPlan(D.DeviceCSR(full2.indptr[lo:hi + 1], full2.indices, full2.values,
+                                    (hi - lo, n_cols), full2.h_indptr[lo:hi + 1]), k,
+                        _native.SOLVER_CHOLESKY) for lo, hi in cuts]
+    assert D.ALSPlanGroup(plans2, n_cols).use_wb

@@ -321,3 +321,34 @@ def test_dataset_reports_repeated_pairs():
     m = m.copy()
     m.sum_duplicates()
     assert m.nnz == 3 and m[0, 0] == 5.0
+
+
+def test_prepare_matrix_leaves_dataset_alone():
+    """``prepare_matrix`` canonicalised repeated pairs IN the Dataset's own
+    index arrays (``scipy()`` hands them out without a copy; ``sum_duplicates`` rewrites them in
+    place).  The dataset must be untouched and the matrix must hold the summed entry."""
+    from lkpy_amd.als import ImplicitMFScorer, ImplicitMFTrainer
+    from lkpy_amd.data import Dataset
+
+    ds = Dataset.from_arrays([1, 1, 1, 1, 2, 2, 3], [10, 11, 11, 12, 10, 10, 12],
+                             [1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0])
+    assert ds.has_duplicates
+    cols, ptr, rows = ds._cols.copy(), ds._indptr.copy(), ds._rows.copy()
+    attrs = {k: v.copy() for k, v in ds._attrs.items()}
+    tr = ImplicitMFTrainer.__new__(ImplicitMFTrainer)
+    tr.scorer = ImplicitMFScorer(embedding_size=4, weight=2.0, use_ratings=True)
+    m = tr.prepare_matrix(ds)
+    assert m.nnz == 5 and m.has_canonical_format
+    assert m[0, 1] == 2.0 * (2.0 + 3.0) and m[1, 0] == 2.0 * (5.0 + 6.0)
+    assert np.array_equal(ds._cols, cols) and np.array_equal(ds._indptr, ptr)
+    assert np.array_equal(ds._rows, rows)
+    for k, v in attrs.items():
+        assert np.array_equal(ds._attrs[k], v)
+    # a second model trained on the same dataset sees the same matrix
+    m2 = tr.prepare_matrix(ds)
+    assert (m != m2).nnz == 0
+    # without repeated pairs nothing is copied or summed
+    ds2 = Dataset.from_arrays([1, 1, 2], [10, 11, 10], [1.0, 2.0, 3.0])
+    tr.scorer = ImplicitMFScorer(embedding_size=4)
+    m3 = tr.prepare_matrix(ds2)
+    assert m3.nnz == 3 and np.all(m3.data == 40.0)
