@@ -156,6 +156,20 @@ int lk_als_plan_set_z(lk_als_plan *plan, const float *d_z);
  * their rows exactly as `sposv` would (and reports a row whose own matrix is not positive
  * definite the same way).  No library call, no host synchronisation.  NULL detaches the buffer. */
 int lk_als_plan_set_z_workspace(lk_als_plan *plan, float *d_zbuf);
+/* Strict reproduction of the reference's right-hand side.  `train_row_solve` forms
+ * y = mt.dot(&vals) on a TRANSPOSED (strided) view (src/accel/als/implicit.rs:116-117;
+ * explicit model: src/accel/als/explicit.rs:109), which ndarray evaluates as ONE sequential
+ * float32 chain per feature over the row's entries, product and sum rounded separately.  On rows
+ * of 10^5 .. 10^6 entries that chain drifts 1e-4 .. 7e-2 from the exact sum; the solve kernels'
+ * own (slotted / chunked) sum does not, so on such rows the default result is CLOSER TO FLOAT64
+ * THAN THE REFERENCE IS and can be > 1e-4 away from it.  Hand the plan a device buffer of
+ * n_rows x lk_padded_dim(k) floats and every half-epoch (implicit and explicit) first forms y in
+ * exactly the reference's order (csrc/als_rhs.hip: lane = feature, entries in row order) and the
+ * dense solve kernels take their right-hand side from it -- bit-identical y, so those rows land
+ * within 1e-4 of the reference.  Slower (one latency-bound chain per feature); rows served by
+ * the Woodbury kernels (<= 64 entries at padded k > 64) never form y and are unaffected; ignored
+ * while a task-control block is attached.  NULL detaches (default: the accurate sum). */
+int lk_als_plan_set_rhs_workspace(lk_als_plan *plan, float *d_y);
 /* Several plans over ROW SLICES of one half-epoch (the sharded engine cuts a rank's rows into
  * slices so that the all-gather of one slice runs under the solve of the next) share one Z: the
  * leading slice's plan owns the buffer (lk_als_plan_set_z_workspace) and is launched first; the

@@ -272,6 +272,9 @@ class ALSPlan:
         self._z = None
         self._z_leader = None  # another slice's plan whose Z this one uses (share_z_from)
         self._z_shared_set = False
+        self._yref = None
+        if os.environ.get("LK_ALS_RHS_ORDER", "accurate").lower() == "reference":
+            self.set_rhs_order("reference")
 
     @property
     def negative_values(self) -> bool:
@@ -285,6 +288,26 @@ class ALSPlan:
             v = self.csr.values
             self._negative_values = bool(v is not None and v.numel() > 0 and float(v.min()) < 0.0)
         return self._negative_values
+
+    def set_rhs_order(self, order: str):
+        """
+        ``"reference"``: every half-epoch forms the right-hand side in the reference's own
+        summation order (one sequential float32 chain per feature: implicit.rs:116-117; csrc/
+        als_rhs.hip) and the dense kernels solve with it; ``"accurate"`` (default): the solve
+        kernels' own slotted / chunked sum.  INTEGRATION.md, ``LK_ALS_RHS_ORDER``.
+        """
+        if order not in ("reference", "accurate"):
+            raise ValueError(f"unknown right-hand-side order {order!r}")
+        if order == "reference" and self.solver != _native.SOLVER_CHOLESKY:
+            return  # the CG option has no reference arithmetic to reproduce
+        if order == "reference" and self._yref is None:
+            self._yref = torch.zeros((max(self.csr.shape[0], 1), self.kp), dtype=torch.float32,
+                                     device=self.csr.indices.device)
+        elif order == "accurate":
+            self._yref = None
+        check(_native.load().lk_als_plan_set_rhs_workspace(
+            self._h, _ptr(self._yref) if self._yref is not None else None),
+            "lk_als_plan_set_rhs_workspace")
 
     def share_z_from(self, leader: "ALSPlan"):
         """
@@ -443,6 +466,10 @@ class ALSPlanGroup:
     def set_cg(self, tol: float, max_iter: int = 0):
         for p in self.plans:
             p.set_cg(tol, max_iter)
+
+    def set_rhs_order(self, order: str):
+        for p in self.plans:
+            p.set_rhs_order(order)
 
     def cg_stats(self):
         st = [p.cg_stats() for p in self.plans]

@@ -71,6 +71,7 @@ def _declare(lib):
         "lk_als_plan_woodbury_rows": (c_int64, [vp]),
         "lk_als_plan_set_z": (c_int, [vp, vp]),
         "lk_als_plan_set_z_workspace": (c_int, [vp, vp]),
+        "lk_als_plan_set_rhs_workspace": (c_int, [vp, vp]),
         "lk_als_plan_set_z_shared": (c_int, [vp, vp, vp]),
         "lk_als_plan_set_z_leader": (c_int, [vp, c_int]),
         "lk_als_plan_z_flag": (vp, [vp, vp]),

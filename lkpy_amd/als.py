@@ -80,6 +80,16 @@ def _restore_scorer_state(obj, state: dict):
     obj.__dict__.update(state)
 
 
+def _apply_rhs_order(engine, options: TrainingOptions):
+    """``LK_ALS_RHS_ORDER`` through ``TrainingOptions.environment`` (the process environment is
+    read by the plans themselves): ``reference`` = the right-hand side summed exactly as the
+    reference does (environment knobs)."""
+    order = options.environment.get("LK_ALS_RHS_ORDER") if options is not None else None
+    if order:
+        engine.u_plan.set_rhs_order(order.lower())
+        engine.i_plan.set_rhs_order(order.lower())
+
+
 class UIPair(BaseModel):
     user: PositiveFloat
     item: PositiveFloat
@@ -309,6 +319,7 @@ class ImplicitMFTrainer(ModelTrainer):
                                             None, None, backend, defer_init=True)
         finally:
             th.join()
+        _apply_rhs_order(self.engine, options)
         scorer.item_embeddings, scorer.user_embeddings = init["Q"], init["P"]
         self.engine.set_initial(scorer.user_embeddings, scorer.item_embeddings)
         self.epochs_trained = 0
@@ -487,6 +498,7 @@ class BiasedMFTrainer(ModelTrainer):
         self.engine = ImplicitALSEngine(sps.csr_array(ui), k, cfg.user_reg, cfg.item_reg,
                                         scorer.user_embeddings, scorer.item_embeddings, backend,
                                         explicit=True)
+        _apply_rhs_order(self.engine, options)
         self.epochs_trained = 0
 
     def prepare_matrix(self, data: Dataset) -> sps.coo_array:

@@ -559,7 +559,8 @@ __device__ __forceinline__ void als_blk_solve_body(
     const int32_t *__restrict__ row_slab, const float *__restrict__ other,
     float *__restrict__ this_, const float *__restrict__ notor_p,
     const float *__restrict__ slabs, float *__restrict__ row_delta, int *__restrict__ status,
-    int k, float reg, TaskCtlDev ctl, float *lds, const int64_t t)
+    int k, float reg, TaskCtlDev ctl, float *lds, const int64_t t,
+    const float *__restrict__ y_ref = nullptr)
 {
     using C = Cfg<NT>;
     constexpr int KP = C::KP, NL = C::NL;
@@ -656,7 +657,13 @@ __device__ __forceinline__ void als_blk_solve_body(
     }
     if (wc == 0 && slot == 0) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) lds[C::OFF_Y + (2 * i + wr) * 16 + sub] = yacc[i];
+        for (int i = 0; i < NL; ++i) {
+            // (y_ref: the right-hand side in the reference's summation order, als_rhs.hip --
+            // natural feature order, primed (t, sub) <-> feature sub * NT + pos(t))
+            const int tb = 2 * i + wr;
+            lds[C::OFF_Y + tb * 16 + sub] =
+                y_ref ? y_ref[(int64_t)row * KP + sub * NT + C::pos(tb)] : yacc[i];
+        }
     }
     // (the first barrier of chol_step<0> orders these stores before thread 0 reads them)
 
@@ -722,13 +729,13 @@ __device__ __forceinline__ void als_blk_solve_body(
         const float *__restrict__ other, float *__restrict__ this_,                             \
         const float *__restrict__ notor_p, const float *__restrict__ slabs,                     \
         float *__restrict__ row_delta, int *__restrict__ status, int k, float reg,              \
-        TaskCtlDev ctl)                                                                         \
+        TaskCtlDev ctl, const float *__restrict__ y_ref)                                        \
     {                                                                                           \
         __shared__ __attribute__((aligned(16))) float lds[Cfg<NTV>::LDS_FLOATS];                \
         als_blk_solve_body<NTV, IS64, EXPL, CTL>(indptr, indices, values, order, n_rows,        \
                                                  row_slab, other, this_, notor_p, slabs,        \
                                                  row_delta, status, k, reg, ctl, lds,           \
-                                                 (int64_t)blockIdx.x);                          \
+                                                 (int64_t)blockIdx.x, y_ref);                   \
     }
 
 LK_BLK_KERNEL(als_blk_solve_kernel16, 16, LK_ALS_BLK_ATTR16)
@@ -859,12 +866,18 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
                                row_delta, status, k);
     }
     if (n_dense > 0) {
+        if (!p->ctl) {  // reference-order right-hand side of the dense rows, if asked for
+            int rc = launch_rhs_reference(p, indptr, IS64 ? 1 : 0, indices, values, p->d_order,
+                                          n_dense, other, EXPL, st);
+            if (rc != LK_OK) return rc;
+        }
         const dim3 grid((unsigned)n_dense), block(256);
         const IT *ip = static_cast<const IT *>(indptr);
 #define LK_BLK_LAUNCH(KERN, CTLV)                                                                \
     hipLaunchKernelGGL((KERN<IS64, EXPL, CTLV>), grid, block, 0, st, ip, indices, values,        \
                        p->d_order, n_dense, p->d_row_slab, other, this_, notor_p, slabs,         \
-                       row_delta, status, k, reg, (CTLV) ? p->ctl->dev() : TaskCtlDev{})
+                       row_delta, status, k, reg, (CTLV) ? p->ctl->dev() : TaskCtlDev{},        \
+                       (CTLV) ? nullptr : p->d_yref)
         if constexpr (NT == 16) {
             if (p->ctl)
                 LK_BLK_LAUNCH(als_blk_solve_kernel16, true);

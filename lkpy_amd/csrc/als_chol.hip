@@ -923,14 +923,17 @@ __host__ __device__ constexpr int solve_lds_floats()
 // CTL: poll the task-control block (cancel) before the row and count it when done; a
 // template parameter so that the uncontrolled instantiation -- the training engine's -- is
 // instruction for instruction the tuned kernel
-template <int NT, bool IS64, bool EXPL, bool CTL>
+// YREF: take the right-hand side from `y_ref` ([rows x KP], natural feature order; als_rhs.hip:
+// the reference's summation order) instead of the accumulated one; a template parameter so that
+// the default instantiation is instruction for instruction the tuned kernel
+template <int NT, bool IS64, bool EXPL, bool CTL, bool YREF = false>
 __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_rows,
     const int32_t *__restrict__ row_slab, const float *__restrict__ other, int ld_other,
     float *__restrict__ this_, int ld_this, const float *__restrict__ otor_p,
     const float *__restrict__ slabs, float *__restrict__ row_delta, int *__restrict__ status,
-    int k, float reg, TaskCtlDev ctl)
+    int k, float reg, TaskCtlDev ctl, const float *__restrict__ y_ref = nullptr)
 {
     constexpr int KP = NT * 16;
     __shared__ __attribute__((aligned(16))) float lds_all[4][solve_lds_floats<NT>()];
@@ -1016,6 +1019,12 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     for (int tt = 0; tt < NT; ++tt) {
         G.y[tt] += __shfl_xor(G.y[tt], 16, 64);
         G.y[tt] += __shfl_xor(G.y[tt], 32, 64);
+    }
+    if constexpr (YREF) {
+        // primed (tt, sub) <-> feature sub * NT + tt; pad features carry y = 0 (their factor
+        // columns are zero, so the reference-order sum over them is exactly 0 as well)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) G.y[tt] = y_ref[(int64_t)row * KP + sub * NT + tt];
     }
 #if LK_ALS_PANEL
     const float old = my_valid ? xrow[my_f] : 0.f;
@@ -1422,7 +1431,17 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
     const int64_t n_solve = p->dense_limit >= 0 && p->dense_limit < n_rows ? p->dense_limit : n_rows;
     if (n_solve > 0) {
         using IT = typename IndPtr<IS64>::type;
-        if (p->ctl)
+        if (p->d_yref && !p->ctl) {
+            // reference-order right-hand side (als_rhs.hip), then the solve that takes it
+            int rc = launch_rhs_reference(p, indptr, IS64 ? 1 : 0, indices, values, p->d_order,
+                                          n_solve, other, EXPL, st);
+            if (rc != LK_OK) return rc;
+            hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, false, true>),
+                               dim3((unsigned)((n_solve + 3) / 4)), dim3(256), 0, st,
+                               static_cast<const IT *>(indptr), indices, values, p->d_order,
+                               n_solve, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
+                               slabs, row_delta, status, k, reg, TaskCtlDev{}, p->d_yref);
+        } else if (p->ctl)
             hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, true>),
                                dim3((unsigned)((n_solve + 3) / 4)), dim3(256), 0, st,
                                static_cast<const IT *>(indptr), indices, values, p->d_order,

@@ -46,6 +46,10 @@ struct lk_als_plan {
     // status[1] at every launch
     const int *d_zflag_src = nullptr;
     bool z_for_others = false;  // leading slice: form Z even if this slice has no short row itself
+    // optional [n_rows x KP] buffer (lk_als_plan_set_rhs_workspace): every half-epoch first forms
+    // the right-hand side y in the REFERENCE's order (als_rhs.hip: one sequential float32 chain
+    // per feature, implicit.rs:116-117) and the dense solve kernels take it from there
+    float *d_yref = nullptr;
     size_t off_ginv = 0, off_invws = 0;  // [KP x KP] float inverse, spd_inverse scratch
     // device-side schedule
     int32_t *d_order = nullptr;      // [n_rows] rows, longest first
@@ -102,6 +106,11 @@ int als_wb64_launch(const lk_als_plan *p, const void *indptr, int is64, const in
 size_t spd_inverse_workspace_bytes(int KP);
 int spd_inverse(const float *a, int lda, int k, int KP, float *out, int *flag, void *ws,
                 hipStream_t st);
+// y[row] in the reference's summation order for the rows order[0 .. n_tasks) (als_rhs.hip); a
+// no-op without a rhs workspace
+int launch_rhs_reference(const lk_als_plan *p, const void *indptr, int is64,
+                         const int32_t *indices, const float *values, const int32_t *order,
+                         int64_t n_tasks, const float *other, bool expl, hipStream_t st);
 // slab[head] += slab[head + 1] + ... (chunk order) for every group of the plan (als_chol.hip)
 int launch_slab_group_reduce(const lk_als_plan *p, float *slabs, size_t slab_floats, hipStream_t st);
 // deterministic two-stage sum of the per-row squared deltas -> sqrt (als_chol.hip)
