@@ -140,7 +140,9 @@ def pmc_traffic(pattern: str, kernel_substr: str):
     """
     import csv
 
-    files = sorted((ROOT / "profiles").glob(pattern))
+    pats = [pattern] if isinstance(pattern, str) else list(pattern)
+    files = sorted({f for pat in pats for f in (ROOT / "profiles").glob(pat)},
+                   key=lambda f: f.name)
     if not files:
         return None, None
     fetch, write = [], []
@@ -157,6 +159,63 @@ def pmc_traffic(pattern: str, kernel_substr: str):
     return (2.0 * sum(fetch) / len(fetch) + w) * 1024.0, files[-1].name
 
 
+def pmc_traffic_per_epoch(pattern, anchor_kernel: str):
+    """
+    HBM bytes per EPOCH summed over every kernel of a committed PMC summary (a workload whose
+    epoch is several kernels: cfg5's dense + chunk + Woodbury + Z kernels): sum over kernels of
+    (2 * FETCH_SIZE + WRITE_SIZE) * 1024 * launches, divided by the epochs in the capture
+    (= launches of ``anchor_kernel`` / 2: one per half-epoch).
+    """
+    import csv
+
+    pats = [pattern] if isinstance(pattern, str) else list(pattern)
+    files = sorted({f for pat in pats for f in (ROOT / "profiles").glob(pat)},
+                   key=lambda f: f.name)
+    if not files:
+        return None, None
+    tot, anchor = 0.0, 0
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            n = float(row.get("count", 0) or 0)
+            if row["Counter_Name"] == "FETCH_SIZE":
+                tot += 2.0 * float(row["mean"]) * n * 1024.0
+                if anchor_kernel in row["Kernel_Name"]:
+                    anchor += int(n)
+            elif row["Counter_Name"] == "WRITE_SIZE":
+                tot += float(row["mean"]) * n * 1024.0
+    if anchor < 2 or tot <= 0:
+        return None, None
+    return tot / (anchor / 2.0), files[-1].name
+
+
+def reference_order_recheck(backend, plan, this_dev, lo, hi, other_dev, reg, rows_new, want_rows):
+    """
+    REPRODUCE exception rows instead of refereeing them: the same half-epoch once more with the
+    right-hand side summed in the reference's own order (``LK_ALS_RHS_ORDER=reference``,
+    csrc/als_rhs.hip: one sequential float32 chain per feature, implicit.rs:116-117) and the
+    listed rows against the oracle's.  ``this_dev`` is not modified.
+    """
+    import torch
+
+    plan.set_rhs_order("reference")
+    try:
+        tmp = this_dev.clone()
+        otor = backend.gramian(other_dev, reg)
+        backend.half_epoch(plan, tmp[lo:hi], other_dev, otor)
+        plan.check_status()
+        got = backend.download_rows(tmp, np.asarray(rows_new, dtype=np.int64))
+        del tmp
+    finally:
+        plan.set_rhs_order("accurate")
+    torch.cuda.synchronize()
+    num = np.linalg.norm(got.astype(np.float64) - want_rows, axis=1)
+    den = np.linalg.norm(want_rows.astype(np.float64), axis=1)
+    rel = num / np.maximum(den, 1e-300)
+    return {"rows": int(len(rel)), "within_1e-4": int((rel <= 1.0e-4).sum()),
+            "rel_max": float(rel.max()) if len(rel) else 0.0,
+            "rel": [float(x) for x in rel[:10]]}
+
+
 def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
     """
     One more epoch on the GPU from the trained state, and the SAME two half-epochs on the CPU
@@ -171,6 +230,7 @@ def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
     from oracle import parity
 
     P, Q = eng.user_embeddings(), eng.item_embeddings()
+    Q_before = eng.Q.clone()  # the user half's `other`, for the reference-order recheck
     eng.train_epoch()
     eng.check()
     P1, Q1 = eng.user_embeddings(), eng.item_embeddings()
@@ -197,8 +257,23 @@ def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
         exact, cond = lko.als_referee_f64(sub, other, reg)
         acc = parity.als_half_accounting(got_, want, exact, cond)
         acc.pop("by_cond_decade", None)
+        if acc.get("exceptions"):
+            # the rows over 1e-4, once more with the rhs in the reference's summation order
+            ex = np.array([e["row"] for e in acc["exceptions"]])
+            orig = ex if rows is None else rows[ex]
+            if name == "user":
+                acc["exceptions_in_reference_order"] = reference_order_recheck(
+                    eng.backend, eng.u_plan, eng.P, eng.u_lo, eng.u_hi, Q_before, reg,
+                    eng.u_new[orig], want[ex])
+            else:
+                acc["exceptions_in_reference_order"] = reference_order_recheck(
+                    eng.backend, eng.i_plan, eng.Q, eng.i_lo, eng.i_hi, eng.P, reg,
+                    eng.i_new[orig], want[ex])
         out[name] = acc
+    del Q_before
     exceptions = [dict(e, half=name) for name, o in out.items() for e in o.get("exceptions", [])]
+    reco = [o["exceptions_in_reference_order"] for o in out.values()
+            if "exceptions_in_reference_order" in o]
     par = {
         "what": "one epoch from the trained state, GPU vs oracle from identical inputs, "
         + ("every row" if row_frac >= 1.0 else f"a {row_frac:.3f} row sample"),
@@ -213,6 +288,9 @@ def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
         "row_rel_max": max(out["user"]["row_rel_max"], out["item"]["row_rel_max"]),
         "ok": bool(all(o["ok"] for o in out.values())),
         "exceptions": exceptions,
+        "ok_in_reference_order": bool(all(r["within_1e-4"] == r["rows"] for r in reco)),
+        "exceptions_reproduced_in_reference_order": [sum(r["within_1e-4"] for r in reco),
+                                                     sum(r["rows"] for r in reco)],
         "accounted": bool(all(o["accounted"] for o in out.values())),
         "rows_decidable": sum(o.get("rows_decidable", 0) for o in out.values()),
         "gpu_row_err_over_cond_u_max": max(o["row_err_over_cond_u_max_gpu"] for o in out.values()),
@@ -289,7 +367,7 @@ def fit_leg(ratings, k, epochs, weight):
 
 
 def topk_cpu_and_parity(P, Q, ex_ptr, ex_idx, gpu_idx, gpu_sc, n, budget_s=10.0,
-                        max_users=32768):
+                        max_users=32768, block=1024):
     """
     bench.py's checker leg for the dense top-N call.  The reference's path for one user --
     scores = Q @ u (``ALSBase.__call__``), candidates = all items minus the user's own, heap
@@ -319,7 +397,7 @@ def topk_cpu_and_parity(P, Q, ex_ptr, ex_idx, gpu_idx, gpu_sc, n, budget_s=10.0,
     done, blocks = 0, []
     t0 = time.perf_counter()
     while done < len(users):
-        us = users[done:done + 1024]
+        us = users[done:done + block]
         blocks.append(run(us))
         done += len(us)
         if time.perf_counter() - t0 > budget_s:
@@ -506,11 +584,9 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
     for _ in range(warmup):
         eng.train_epoch()
     eng.check()
-    eng.u_plan.enable_timing(True)
-    eng.i_plan.enable_timing(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(steps):  # no instrumentation inside the timed region
         du, di = eng.train_epoch()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -519,8 +595,15 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # kernel times: one more epoch with HIP events on the launch stream
+    eng.u_plan.enable_timing(True)
+    eng.i_plan.enable_timing(True)
+    eng.train_epoch()
+    barrier()
     cu, su, nu = eng.u_plan.get_timing()
     ci, si, ni = eng.i_plan.get_timing()
+    eng.u_plan.enable_timing(False)
+    eng.i_plan.enable_timing(False)
     ulen = np.diff(eng.u_plan.csr.h_indptr)
     ilen = np.diff(eng.i_plan.csr.h_indptr)
     uwb, iwb = bool(eng.u_plan.use_wb), bool(eng.i_plan.use_wb)
@@ -576,13 +659,18 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
             "woodbury_rows": {"user": int(eng.u_plan.woodbury_rows) if uwb else 0,
                               "item": int(eng.i_plan.woodbury_rows) if iwb else 0},
             "algorithmic_bytes_per_epoch": half_bytes(ulen, k) + half_bytes(ilen, k),
-            "traffic": None,
+            "traffic": None, "traffic_source": None,
             "note": "rows with <= 64 entries are rank-n updates of OtOr and are solved through "
             "the Woodbury identity (same solution, O(n^2 k) flops): algorithmic_flops counts "
             "what this path needs for them; reference_flops = a dense k^3/3 solve for every "
             "row, as the reference does (SURVEY 8d)",
         },
     }
+
+    if world == 1 and args.scale == 1.0:
+        # HBM bytes per epoch over ALL kernels of the epoch, from the committed PMC summary
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic_per_epoch(
+            "r*_cfg5_counters.csv", "als_blk_solve_kernel16")
 
     def leg(name, fn):
         try:
@@ -633,6 +721,14 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
             acc = parity.als_half_accounting(got, want, exact, cond)
             acc.pop("by_cond_decade", None)
             acc["longest_row_checked"] = int(lens.max())
+            if acc.get("exceptions"):
+                # reproduce them: the same half with the rhs in the reference's summation order
+                ex = np.array([e["row"] for e in acc["exceptions"]])
+                for e in acc["exceptions"]:
+                    e["entries"] = int(lens[e["row"]])
+                acc["exceptions_in_reference_order"] = reference_order_recheck(
+                    eng.backend, plan, this_full, lo, hi, other_full, otor_reg, lo + rows[ex],
+                    want[ex])
             cpu_s += dt
             cpu_fl += reference_half_flops(lens, k)
             desc.append(f"{name} half: {len(rows)} of {n_rows} rows ({sub.nnz} nnz, longest "
@@ -652,11 +748,17 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
             "sample": "; ".join(desc) + "; extrapolated to an epoch by algorithmic flops "
             "(reference's dense k^3/3 per row)",
             "host_cpus": os.cpu_count()}
+        reco = [o["exceptions_in_reference_order"] for o in res.values()
+                if "exceptions_in_reference_order" in o]
         return {"what": "user AND item half-epoch, GPU vs oracle from identical inputs, sampled "
                 "rows (the item sample always contains the busiest item)",
                 "rows_checked": res["user"]["rows"] + res["item"]["rows"],
                 "rows_over_1e-4": res["user"]["rows_over_1e-4"] + res["item"]["rows_over_1e-4"],
+                "row_rel_max": max(res["user"]["row_rel_max"], res["item"]["row_rel_max"]),
                 "ok": bool(res["user"]["ok"] and res["item"]["ok"]),
+                "ok_in_reference_order": bool(all(r["within_1e-4"] == r["rows"] for r in reco)),
+                "exceptions_reproduced_in_reference_order": [
+                    sum(r["within_1e-4"] for r in reco), sum(r["rows"] for r in reco)],
                 "accounted": bool(res["user"]["accounted"] and res["item"]["accounted"]),
                 "exceptions": [dict(e, half=h) for h in res for e in res[h].get("exceptions", [])],
                 "user": res["user"], "item": res["item"]}
@@ -668,17 +770,29 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
         excl_ptr = torch.from_numpy(hp[: B + 1]).to(dev)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        D.score_topk(eng.P[:B], eng.Q, k, 100, excl_ptr, eng.u_plan.csr.indices)
+        g_idx, g_sc = D.score_topk(eng.P[:B], eng.Q, k, 100, excl_ptr, eng.u_plan.csr.indices)
         torch.cuda.synchronize(dev)
         tb = time.perf_counter() - t0
         fl = 2.0 * B * eng.Q.shape[0] * k
-        return {"metric": "dense scoring + top-100, %d users x %d items (k=%d), seconds"
-                % (B, eng.Q.shape[0], k),
-                "value": round(tb, 3), "unit": "s", "users_per_s": round(B / tb, 1),
-                "roofline": {"bound": "mfma", "achieved": round(fl / tb / 1e12, 2),
-                             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(fl / tb / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-                             "algorithmic_flops": fl}}
+        res = {"metric": "dense scoring + top-100, %d users x %d items (k=%d), seconds"
+               % (B, eng.Q.shape[0], k),
+               "value": round(tb, 3), "unit": "s", "users_per_s": round(B / tb, 1),
+               "roofline": {"bound": "mfma", "achieved": round(fl / tb / 1e12, 2),
+                            "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(fl / tb / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                            "algorithmic_flops": fl}}
+        if not args.no_cpu:
+            # the reference's per-query path on a seeded user sample of THIS slice: timed and
+            # compared (index lists + score bits) -- VERDICT r3: the slice had neither
+            try:
+                n_ex = int(hp[B])
+                res["cpu_baseline"], res["parity"] = topk_cpu_and_parity(
+                    eng.backend.download(eng.P[:B]), eng.backend.download(eng.Q), hp[: B + 1],
+                    eng.u_plan.csr.indices[:n_ex].cpu().numpy(), g_idx.cpu().numpy(),
+                    g_sc.cpu().numpy(), 100, budget_s=8.0, max_users=4096, block=128)
+            except Exception as exc:  # noqa: BLE001 -- reported in place
+                res["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
+        return res
 
     if rank == 0 and world == 1 and not args.no_cpu:
         leg("parity", parity_leg)
@@ -709,7 +823,7 @@ def main_cfg5(args):
         dist.init_process_group("nccl", device_id=dev)
     out = cfg5_run(args, dev, world, rank, args.steps, args.warmup, args.topk_users)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -744,11 +858,9 @@ def als_timed(ui, P0, Q0, k, reg, steps, warmup, dev, world, scale):
     for _ in range(warmup):
         eng.train_epoch()
     eng.check()
-    eng.u_plan.enable_timing(True)
-    eng.i_plan.enable_timing(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(steps):  # the headline: no instrumentation inside the timed region
         du, di = eng.train_epoch()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -758,8 +870,14 @@ def als_timed(ui, P0, Q0, k, reg, steps, warmup, dev, world, scale):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel (local shard of this rank) ----
+    # ---- roofline of the dominant kernel (local shard of this rank): a SEPARATE pass of the
+    # same epochs with HIP events around the kernels on the launch stream ----
     roof = None
+    eng.u_plan.enable_timing(True)
+    eng.i_plan.enable_timing(True)
+    for _ in range(min(steps, 20)):
+        eng.train_epoch()
+    barrier()
     cu, su, nu = eng.u_plan.get_timing()
     ci, si, ni = eng.i_plan.get_timing()
     eng.u_plan.enable_timing(False)
@@ -810,6 +928,197 @@ def als_timed(ui, P0, Q0, k, reg, steps, warmup, dev, world, scale):
             "r*_k%d_counters.csv" % k if k != 64 else "r*_als_*_counters.csv",
             kname.split("<")[0])
     return eng, backend, elapsed, roof, setup_seconds, (float(du.item()), float(di.item()))
+
+
+def _pick(d, *keys):
+    "the named keys of a dict that are present (compact line)"
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _short(text, n=160):
+    text = str(text)
+    return text if len(text) <= n else text[: n - 3] + "..."
+
+
+def _roof(r):
+    return _pick(r, "kernel", "bound", "achieved", "peak", "unit", "frac", "frac_executed",
+                 "traffic", "avg_launch_ms") if isinstance(r, dict) else None
+
+
+def _cpu(c):
+    if not isinstance(c, dict):
+        return None
+    d = _pick(c, "value", "unit", "cores", "kind", "error")
+    if "sample" in c:
+        d["sample"] = _short(c["sample"], 140)
+    return d
+
+
+def _als_par(par):
+    "digest of an ALS parity object: the raw criterion, counts, the exception rows"
+    if not isinstance(par, dict):
+        return None
+    d = _pick(par, "ok", "rows_checked", "rows_over_1e-4", "row_rel_max", "accounted",
+              "ok_in_reference_order", "exceptions_reproduced_in_reference_order", "error")
+    if par.get("exceptions"):
+        d["exceptions"] = [{k: (round(v, 8) if isinstance(v, float) else v) for k, v in
+                            _pick(e, "half", "row", "entries", "cond", "gpu_vs_oracle",
+                                  "gpu_vs_f64", "oracle_vs_f64").items()}
+                           for e in par["exceptions"][:6]]
+    return d
+
+
+def compact_line(out: dict) -> dict:
+    """
+    The LAST line bench.py prints: the contract's headline fields + ``roofline`` +
+    ``cpu_baseline`` + a digest of every leg (value, roofline fraction, CPU baseline, parity
+    verdict with counts and exceptions), small enough (< 6 KB) for a driver that keeps only the
+    tail of stdout.  The full objects are in the line printed just before it.
+    """
+    c = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+              "higher_is_better", "scaling", "vs_baseline", "dtype")
+    c["data"] = _short(out.get("data", ""), 200)
+    c["config"] = _pick(out.get("config", {}), "workload", "solver", "parallelism", "data_source")
+    if "roofline" in out:
+        c["roofline"] = _roof(out["roofline"])
+    if "cpu_baseline" in out:
+        c["cpu_baseline"] = _cpu(out["cpu_baseline"])
+    par = out.get("parity")
+    if isinstance(par, dict):
+        c["parity"] = _als_par(par)
+        if isinstance(par.get("knn"), dict):
+            c["parity"]["knn_build"] = par["knn"]
+    legs = {}
+    knn = out.get("knn")
+    if isinstance(knn, dict):
+        d = _pick(knn, "value", "unit", "build_seconds_to_host", "build_seconds_to_host_first_call",
+                  "build_save_nbrs_100_seconds", "prepare_seconds", "nnz_out", "error")
+        d["metric"] = "item-kNN model build seconds (HBM-resident; to_host = BASELINE's definition)"
+        d["roofline"] = _roof(knn.get("roofline"))
+        d["cpu_baseline"] = _cpu(knn.get("cpu_baseline"))
+        for name in ("batch_score", "recommend"):
+            sub = knn.get(name)
+            if isinstance(sub, dict):
+                e = _pick(sub, "seconds", "queries", "queries_per_s", "targets_per_query", "n",
+                          "error")
+                e["roofline_frac"] = (sub.get("roofline") or {}).get("frac")
+                e["cpu_baseline"] = _cpu(sub.get("cpu_baseline"))
+                e["parity"] = _pick(sub.get("parity") or {}, "ok", "queries_checked",
+                                    "scores_compared", "scores_bit_identical", "counts_identical",
+                                    "lists_identical", "mismatched_users", "error")
+                d[name] = e
+        legs["knn"] = d
+    topk = out.get("topk")
+    if isinstance(topk, dict):
+        d = _pick(topk, "metric", "value", "unit", "users_per_s", "error")
+        d["roofline"] = _roof(topk.get("roofline"))
+        d["cpu_baseline"] = _cpu(topk.get("cpu_baseline"))
+        d["parity"] = topk.get("parity")
+        legs["topk"] = d
+    if isinstance(out.get("fit"), dict):
+        legs["fit"] = _pick(out["fit"], "fit_seconds", "epochs_per_s_from_log",
+                            "setup_and_download_seconds", "error")
+    if isinstance(out.get("cg"), dict):
+        legs["cg"] = _pick(out["cg"], "exact_ms_per_epoch", "cg_ms_per_epoch",
+                           "cg_iterations_per_row", "one_epoch_rel_diff_P", "one_epoch_rel_diff_Q",
+                           "user_rows", "item_rows", "error")
+    for name in ("k128", "cfg5"):
+        leg = out.get(name)
+        if not isinstance(leg, dict):
+            continue
+        d = _pick(leg, "metric", "value", "unit", "ms_per_step", "steps", "setup_seconds", "error")
+        d["roofline"] = _roof(leg.get("roofline"))
+        d["cpu_baseline"] = _cpu(leg.get("cpu_baseline"))
+        d["parity"] = _als_par(leg.get("parity"))
+        if isinstance(leg.get("topk"), dict):
+            t = leg["topk"]
+            d["topk"] = _pick(t, "value", "unit", "users_per_s", "error")
+            d["topk"]["roofline_frac"] = (t.get("roofline") or {}).get("frac")
+            d["topk"]["cpu_baseline"] = _cpu(t.get("cpu_baseline"))
+            d["topk"]["parity"] = _pick(t.get("parity") or {}, "ok", "users_checked",
+                                        "score_rows_bit_identical", "lists_identical",
+                                        "mismatched_users")
+        legs[name] = d
+    for name in ("sharded_topk", "sharded_knn", "sharded_legs_error"):
+        if name in out:
+            legs[name] = out[name]
+    if legs:
+        c["legs"] = legs
+    c["full_line"] = "the JSON line printed before this one carries every leg in full"
+    return c
+
+
+def _sig(x, digits=5):
+    "floats to 5 significant digits, recursively (the compact line only)"
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if np.isfinite(x) else x
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def emit(out: dict):
+    "rank 0: the full line first, then the compact line LAST (what a tail-keeping driver parses)"
+    print(json.dumps(out), flush=True)
+    c = _sig(compact_line(out))
+    sep = (",", ":")
+    line = json.dumps(c, separators=sep)
+    # never let the digest outgrow the driver's tail (8000 characters): drop detail in this
+    # order, keep every value / fraction / verdict
+    def drop_samples(leg):
+        for key, val in list(leg.items()):
+            if isinstance(val, dict):
+                if key == "cpu_baseline":
+                    val.pop("sample", None)
+                drop_samples(val)
+
+    steps = [lambda: drop_samples(c.get("legs", {})),
+             lambda: c.get("legs", {}).pop("cg", None),
+             lambda: c.get("legs", {}).pop("fit", None),
+             lambda: c.pop("data", None)]
+    for step in steps:
+        if len(line) <= 6000:
+            break
+        step()
+        line = json.dumps(c, separators=sep)
+    print(line, flush=True)
+
+
+def load_ratings(scale: float):
+    """
+    SURVEY 8d / BASELINE.md "Inputs": the real MovieLens-25M when it is on the box -- the
+    reference's fixture path ``data/ml-25m.zip`` (src/lenskit/testing/_movielens.py:34) or an
+    unpacked ``data/ml-25m/``, relative to the repository or the working directory, or whatever
+    ``LK_ML25M`` names -- read by ``lkpy_amd.data.load_movielens`` (the reference's
+    ``load_movielens``: every movies.csv id is an item); else the seeded ML-25M-shaped synthetic.
+    Returns (ratings CSR users x items, f32), a description for ``data``, the source tag.
+    """
+    from lkpy_amd import synth
+
+    cands = [os.environ.get("LK_ML25M")] if os.environ.get("LK_ML25M") else []
+    for base in (ROOT, Path.cwd()):
+        cands += [base / "data" / "ml-25m.zip", base / "data" / "ml-25m"]
+    for c in cands:
+        c = Path(c)
+        if scale == 1.0 and c.exists():
+            from lkpy_amd.data import load_movielens
+
+            ds = load_movielens(c)
+            ratings = ds.interactions().matrix().scipy(attribute="rating", layout="csr")
+            info = synth.describe(ratings)
+            return ratings, ("MovieLens-25M (%s via lkpy_amd.data.load_movielens: %d users x %d "
+                             "items, %d ratings, %d unrated items)"
+                             % (c, info["n_users"], info["n_items"], info["nnz"],
+                                info["empty_items"])), str(c)
+    ratings = synth.ml25m_like(scale=scale)
+    info = synth.describe(ratings)
+    return ratings, ("synthetic (seeded ML-25M-shaped: lkpy_amd.synth.ml25m_like, seed 20260925; "
+                     "the public dataset's counts exactly: nnz %d, user rows %d..%d, busiest item "
+                     "%d, %d unrated items; no data/ml-25m.zip on this box)"
+                     % (info["nnz"], info["user_len_min"], info["user_len_max"],
+                        info["item_len_max"], info["empty_items"])), "synthetic"
 
 
 def maybe_self_launch(args):
@@ -888,7 +1197,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     k, reg, weight = args.k, 0.1, 40.0
-    ratings = synth.ml25m_like(scale=args.scale)
+    ratings, data_desc, data_source = load_ratings(args.scale)
     info = synth.describe(ratings)
     import scipy.sparse as sps
 
@@ -924,13 +1233,11 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (seeded ML-25M-shaped: lkpy_amd.synth.ml25m_like, seed 20260925; the "
-        "public dataset's counts exactly: nnz %d, user rows %d..%d, busiest item %d, %d unrated "
-        "items)" % (info["nnz"], info["user_len_min"], info["user_len_max"],
-                    info["item_len_max"], info["empty_items"]),
+        "data": data_desc,
         "config": {
-            "workload": "MovieLens-25M-shaped, als-implicit k=%d, %d timed epochs, %d x MI355X"
-            % (k, args.steps, world),
+            "workload": "MovieLens-25M%s, als-implicit k=%d, %d timed epochs, %d x MI355X"
+            % ("" if data_source != "synthetic" else "-shaped", k, args.steps, world),
+            "data_source": data_source,
             "solver": "cholesky" if eng.u_plan.solver == 0 else "cg",
             "n_users": info["n_users"],
             "n_items": info["n_items"],
@@ -1008,7 +1315,7 @@ def main():
         if isinstance(res.get("roofline"), dict) and args.scale == 1.0:
             # HBM bytes of the build kernel from the committed PMC summary of the same workload
             res["roofline"]["traffic"], res["roofline"]["traffic_source"] = pmc_traffic(
-                "r*_knn_*_counters.csv", "iknn_build_kernel")
+                ("r*_knn_counters.csv", "r*_knn_sym_counters.csv"), "iknn_build_kernel")
         return res
 
     def sharded_legs():
@@ -1167,7 +1474,7 @@ def main():
     if single and not args.no_cfg5 and k == 64:
         leg("cfg5", cfg5_leg)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

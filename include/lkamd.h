@@ -158,7 +158,7 @@ int lk_als_plan_set_z(lk_als_plan *plan, const float *d_z);
 int lk_als_plan_set_z_workspace(lk_als_plan *plan, float *d_zbuf);
 /* Strict reproduction of the reference's right-hand side.  `train_row_solve` forms
  * y = mt.dot(&vals) on a TRANSPOSED (strided) view (src/accel/als/implicit.rs:116-117;
- * explicit model: src/accel/als/explicit.rs:109), which ndarray evaluates as ONE sequential
+ * explicit model: src/accel/als/explicit.rs:110), which ndarray evaluates as ONE sequential
  * float32 chain per feature over the row's entries, product and sum rounded separately.  On rows
  * of 10^5 .. 10^6 entries that chain drifts 1e-4 .. 7e-2 from the exact sum; the solve kernels'
  * own (slotted / chunked) sum does not, so on such rows the default result is CLOSER TO FLOAT64

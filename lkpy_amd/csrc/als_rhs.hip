@@ -18,7 +18,7 @@
 // entries strictly in order, product and sum rounded separately -- and the solve kernels take
 // their right-hand side from it instead of from their own accumulation.  The normal matrix and
 // the factorisation are unchanged.  It reproduces the reference's y bit for bit (same order,
-// same roundings: explicit.rs:109 is the same call with vals = the ratings), so the rows where
+// same roundings: explicit.rs:110 is the same call with vals = the ratings), so the rows where
 // the default mode is ">1e-4 from the oracle because the ORACLE drifts" come out within 1e-4 of
 // it (tests/test_gpu_als_rhs_order.py).  A diagnostic / strict-reproduction mode: one lane chain
 // per feature is latency bound (the 1.54 M-entry row alone takes ~50 ms).  Rows that go through

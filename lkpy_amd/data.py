@@ -364,3 +364,131 @@ def load_movielens_npz(path) -> Dataset:
     z = np.load(path)
     return Dataset.from_arrays(z["user_id"], z["item_id"], z["rating"],
                                all_item_ids=z["all_item_ids"])  # fmt: skip
+
+
+# ---------------------------------------------------------------------------------------
+# MovieLens files (src/lenskit/data/sources/movielens.py:47-540)
+# ---------------------------------------------------------------------------------------
+
+_ML_NAME = r"^(ml-(?:\d+[MmKk]|latest(?:-small)?))"
+
+
+class _MLSource:
+    "A MovieLens distribution: a ``.zip`` (members under its top directory) or an unpacked directory."
+
+    def __init__(self, path):
+        import re
+        from pathlib import Path
+        from zipfile import ZipFile
+
+        self.loc = Path(path)
+        self.zip = None
+        self.prefix = ""
+        if self.loc.is_file() and self.loc.suffix == ".zip":
+            # movielens.py:481-501: the archive's first entry is its top directory, whose name
+            # gives the version
+            self.zip = ZipFile(self.loc, "r")
+            first = self.zip.infolist()[0].filename
+            m = re.match(_ML_NAME, first)
+            if not m:
+                self.zip.close()
+                raise RuntimeError("invalid ML zip file")
+            self.version = m.group(1).lower()
+            self.prefix = first if first.endswith("/") else first.split("/")[0] + "/"
+            self._names = set(self.zip.namelist())
+        elif self.loc.is_dir():
+            m = re.match(_ML_NAME, self.loc.name)
+            self.version = m.group(1).lower() if m else None
+        else:
+            raise RuntimeError("MovieLens data not found" if not self.loc.exists()
+                               else "not a directory or zip file")
+
+    def has(self, name: str) -> bool:
+        return (self.prefix + name) in self._names if self.zip is not None \
+            else (self.loc / name).exists()
+
+    def open(self, name: str):
+        return self.zip.open(self.prefix + name) if self.zip is not None \
+            else open(self.loc / name, "rb")
+
+    def close(self):
+        if self.zip is not None:
+            self.zip.close()
+
+    def kind(self) -> str:
+        "movielens.py:502-529: by version name, else by the files present"
+        v = self.version
+        if v == "ml-100k" or (v is None and self.has("u.data")):
+            return "100k"
+        if v in ("ml-1m", "ml-10m") or (v is None and self.has("ratings.dat")):
+            return "dat"
+        if v is not None or self.has("ratings.csv"):
+            return "modern"
+        raise RuntimeError("invalid ML directory")
+
+
+def load_movielens_df(path) -> pd.DataFrame:
+    """
+    ``lenskit.data.load_movielens_df`` (src/lenskit/data/sources/movielens.py:455-473): the
+    ratings of a MovieLens distribution (zip or directory, format detected) with columns
+    ``user_id``, ``item_id``, ``rating``, ``timestamp`` and the reference's dtypes (int32 ids,
+    float32 ratings: movielens.py:130-147, 283-298, 418-431).
+    """
+    src = _MLSource(path)
+    try:
+        kind = src.kind()
+        if kind == "modern":
+            with src.open("ratings.csv") as f:
+                df = pd.read_csv(f, dtype={"userId": np.int32, "movieId": np.int32,
+                                           "rating": np.float32, "timestamp": np.int64})
+            df = df.rename(columns={"userId": "user_id", "movieId": "item_id"})
+        elif kind == "dat":
+            with src.open("ratings.dat") as f:
+                df = pd.read_csv(f, sep=":", header=None, usecols=[0, 2, 4, 6],
+                                 names=["user_id", "_ui", "item_id", "_ir", "rating", "_rt",
+                                        "timestamp"],
+                                 dtype={"user_id": np.int32, "item_id": np.int32,
+                                        "rating": np.float32, "timestamp": np.int32})
+        else:
+            with src.open("u.data") as f:
+                df = pd.read_csv(f, sep="\t", header=None,
+                                 names=["user_id", "item_id", "rating", "timestamp"],
+                                 dtype={"user_id": np.int32, "item_id": np.int32,
+                                        "rating": np.float32, "timestamp": np.int32})
+        df["timestamp"] = pd.to_datetime(df["timestamp"], unit="s")
+        return df
+    finally:
+        src.close()
+
+
+def load_movielens(path) -> Dataset:
+    """
+    ``lenskit.data.load_movielens`` (movielens.py:435-452) for the part of the dataset the hot
+    path reads: users = the rating users, **items = every id of the movie table** (so unrated
+    movies are items with empty rows: ML-25M has 62 423 items of which 59 047 are rated;
+    ``MLModernLoader.dataset``, movielens.py:327-345, ``add_entities`` before the interactions,
+    ids the ratings mention beyond the table inserted), interactions (user, item)-sorted with
+    ``rating`` (float32) and ``timestamp``.  Titles, genres, tags and the tag genome are not read.
+    """
+    src = _MLSource(path)
+    try:
+        kind = src.kind()
+        if kind == "modern":
+            with src.open("movies.csv") as f:
+                movie_ids = pd.read_csv(f, usecols=["movieId"],
+                                        dtype={"movieId": np.int32})["movieId"].to_numpy()
+        elif kind == "dat":
+            with src.open("movies.dat") as f:
+                movie_ids = np.array([int(line.split(b"::", 1)[0]) for line in f if line.strip()],
+                                     dtype=np.int32)
+        else:
+            with src.open("u.item") as f:
+                movie_ids = np.array([int(line.split(b"|", 1)[0]) for line in f if line.strip()],
+                                     dtype=np.int32)
+    finally:
+        src.close()
+    df = load_movielens_df(path)
+    items = np.union1d(movie_ids, df["item_id"].to_numpy())  # missing="insert"
+    return Dataset.from_arrays(df["user_id"].to_numpy(), df["item_id"].to_numpy(),
+                               df["rating"].to_numpy(), all_item_ids=items,
+                               timestamp=df["timestamp"].to_numpy())

@@ -126,7 +126,7 @@ def test_reference_order_reproduces_the_long_row(gpu, oracle, k):
 
 
 def test_reference_order_explicit_model(gpu, oracle):
-    "explicit.rs:109 is the same ``mt.dot(&vals)`` with vals = the normalised ratings"
+    "explicit.rs:110 is the same ``mt.dot(&vals)`` with vals = the normalised ratings"
     from lkpy_amd import _device as D
     from lkpy_amd import _native
 

@@ -352,3 +352,59 @@ def test_prepare_matrix_leaves_dataset_alone():
     tr.scorer = ImplicitMFScorer(embedding_size=4)
     m3 = tr.prepare_matrix(ds2)
     assert m3.nnz == 3 and np.all(m3.data == 40.0)
+
+
+def test_load_movielens_zip_and_directory(tmp_path):
+    """``load_movielens`` (src/lenskit/data/sources/movielens.py:327-345,435-452): a zip named like
+    the reference's fixture path (``data/ml-25m.zip``, testing/_movielens.py:34) and an unpacked
+    directory; items = every movies.csv id (unrated movies are empty rows) plus ids only the
+    ratings mention; interactions (user, item)-sorted; float32 ratings."""
+    import zipfile
+
+    from lkpy_amd.data import load_movielens, load_movielens_df
+
+    movies = "movieId,title,genres\n1,A (1990),Drama\n2,B,Comedy\n5,\"C, the\",(no genres listed)\n9,D,Drama\n"
+    ratings = ("userId,movieId,rating,timestamp\n7,5,4.5,100\n3,1,3.0,101\n7,1,0.5,102\n"
+               "3,9,5.0,103\n11,12,2.0,104\n")
+    z = tmp_path / "ml-25m.zip"
+    with zipfile.ZipFile(z, "w") as zf:
+        zf.writestr("ml-25m/", "")
+        zf.writestr("ml-25m/movies.csv", movies)
+        zf.writestr("ml-25m/ratings.csv", ratings)
+    d = tmp_path / "ml-latest-small"
+    d.mkdir()
+    (d / "movies.csv").write_text(movies)
+    (d / "ratings.csv").write_text(ratings)
+    for src in (z, d):
+        ds = load_movielens(src)
+        assert list(ds.users._ids) == [3, 7, 11]
+        assert list(ds.items._ids) == [1, 2, 5, 9, 12]  # movie 2 unrated, 12 inserted
+        m = ds.interactions().matrix().scipy(attribute="rating", layout="csr")
+        assert m.dtype == np.float32 and m.shape == (3, 5)
+        assert m.toarray().tolist() == [[3.0, 0, 0, 5.0, 0], [0.5, 0, 4.5, 0, 0], [0, 0, 0, 0, 2.0]]
+        assert not ds.has_duplicates
+        df = load_movielens_df(src)
+        assert list(df.columns) == ["user_id", "item_id", "rating", "timestamp"]
+        assert df["user_id"].dtype == np.int32 and df["rating"].dtype == np.float32
+    # an unnamed directory is detected by its files (movielens.py:510-529)
+    other = tmp_path / "somewhere"
+    d.rename(other)
+    assert load_movielens(other).interaction_count == 5
+    with pytest.raises(RuntimeError):
+        load_movielens(tmp_path / "absent")
+
+
+def test_load_movielens_equals_the_committed_fixture():
+    "the loader on the reference checkout's ml-latest-small == tests/golden/ml_small.npz"
+    from pathlib import Path
+
+    from lkpy_amd.data import load_movielens, load_movielens_npz
+
+    src = Path("/root/reference/data/ml-latest-small")
+    if not src.exists():
+        pytest.skip("reference checkout not present (GPU box)")
+    ds = load_movielens(src)
+    g = load_movielens_npz(Path(__file__).parent / "golden" / "ml_small.npz")
+    assert ds.users == g.users and ds.items == g.items
+    assert np.array_equal(ds._cols, g._cols) and np.array_equal(ds._indptr, g._indptr)
+    assert np.array_equal(ds._attrs["rating"], g._attrs["rating"])
