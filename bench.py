@@ -543,6 +543,71 @@ def knn_score_cpu_and_parity(sims, r_ptr, r_idx, r_val, t_ptr, t_idx, got_s, got
     }
 
 
+def knn_recommend_cpu_and_parity(sims, r_ptr, r_idx, r_val, means, hits, got_i, got_s, n,
+                                 budget_s=10.0):
+    """
+    The cfg3 recommend call (top-100 for 10 000 users, every item a candidate) through the
+    oracle's restatement of the reference pipeline -- one query after the other: score_explicit
+    over all items, means added back, own items struck, argtopn (src/lenskit/knn/item.py:231-295,
+    basic/candidates.py:77-94, basic/topn.py:45-69) -- on as many of the batch's queries as fit
+    the budget, taken evenly across the (heaviest-first) batch: TIMED (cpu_baseline, extrapolated
+    by similarity entries streamed) and COMPARED: sorted score rows bit for bit, every listed item
+    really carrying its score and not one of the user's own.
+    """
+    import scipy.sparse as sps
+
+    from oracle import lk_oracle as lko
+
+    h = sps.csr_array((sims.values.cpu().numpy(), sims.indices.cpu().numpy(),
+                       sims.indptr.cpu().numpy()), shape=sims.shape)
+    threads = lko.num_threads()
+    B = len(r_ptr) - 1
+    pick = np.unique(np.linspace(0, B - 1, min(B, 2048)).astype(np.int64))
+    done, secs, wi, ws, rows_ = [], 0.0, [], [], []
+    for c0 in range(0, len(pick), 128):
+        qs = pick[c0:c0 + 128]
+        ptr = np.zeros(len(qs) + 1, np.int64)
+        np.cumsum(r_ptr[qs + 1] - r_ptr[qs], out=ptr[1:])
+        take = np.concatenate([np.arange(r_ptr[q], r_ptr[q + 1]) for q in qs])
+        t0 = time.perf_counter()
+        a, b, c = lko.iknn_recommend_batch(h, ptr, r_idx[take], r_val[take], means, 100, 1, n,
+                                           threads, chunk=128)
+        secs += time.perf_counter() - t0
+        wi.append(a)
+        ws.append(b)
+        rows_.append(c)
+        done.extend(qs.tolist())
+        if secs > budget_s:
+            break
+    done = np.asarray(done)
+    wi, ws, rows_ = np.concatenate(wi), np.concatenate(ws), np.concatenate(rows_)
+    gi, gs = got_i[done], got_s[done]
+    sc_same = bool(np.array_equal(gs.view(np.uint32), ws.view(np.uint32)))
+    bad = ties = 0
+    for r, q in enumerate(done):
+        g = gi[r][gi[r] >= 0]
+        genuine = np.array_equal(rows_[r][g].view(np.uint32), gs[r][: len(g)].view(np.uint32)) \
+            and len(np.unique(g)) == len(g) and len(g) == int((wi[r] >= 0).sum())
+        if not genuine:
+            bad += 1
+        elif not np.array_equal(gi[r], wi[r]):
+            ties += 1
+    frac = float(hits[done].sum()) / max(float(hits.sum()), 1.0)
+    return {
+        "cpu_baseline": {"value": round(secs / max(frac, 1e-12), 2), "unit": "s", "cores": threads,
+                         "kind": "port",
+                         "sample": f"{len(done)} of {B} queries ({frac * 100:.1f}% of the "
+                         f"similarity entries) in {secs:.2f}s (score every item + means + own "
+                         f"items struck + heap top-{n} per query; scoring spread over {threads} "
+                         "threads), extrapolated by entries"},
+        "parity": {"queries_checked": int(len(done)), "list_length": int(n),
+                   "score_rows_bit_identical": sc_same,
+                   "lists_identical": int(len(done) - bad - ties),
+                   "lists_differing_among_equal_scores": int(ties),
+                   "mismatched_users": int(bad), "ok": bool(sc_same and bad == 0)},
+    }
+
+
 def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
     """
     BASELINE.json configs[4] / SURVEY.md 8d "cfg5 concrete input": U = 10^7, I = 10^6,
@@ -1311,7 +1376,9 @@ def main():
         from lkpy_amd import _knn_bench
 
         res = _knn_bench.run(ratings, dev, checker=None if args.no_cpu else knn_cpu_and_parity,
-                             score_checker=None if args.no_cpu else knn_score_cpu_and_parity)
+                             score_checker=None if args.no_cpu else knn_score_cpu_and_parity,
+                             recommend_checker=None if args.no_cpu else
+                             knn_recommend_cpu_and_parity)
         if isinstance(res.get("roofline"), dict) and args.scale == 1.0:
             # HBM bytes of the build kernel from the committed PMC summary of the same workload
             res["roofline"]["traffic"], res["roofline"]["traffic_source"] = pmc_traffic(

@@ -350,6 +350,39 @@ int lk_iknn_truncate_fill(const int64_t *d_sim_indptr, const int32_t *d_sim_indi
                           float *d_out_values, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Item-kNN "recommend" for a BATCH of queries: score EVERY item and keep the top n.
+ * Replaces, for a batch, what `pipelines/iknn-explicit.toml`'s recommender runs per query
+ * (src/lenskit/batch/_runner.py:283-308): the candidate selector (all training items minus the
+ * query's own, src/lenskit/basic/candidates.py:77-94), `ItemKNNScorer.__call__` over the
+ * candidates (src/lenskit/knn/item.py:231-295 -> `score_explicit` / `score_implicit`,
+ * src/accel/knn/item_score.rs:23-111, accum.rs), the item means added back (item.py:282), and
+ * `TopNRanker` (src/lenskit/basic/topn.py:45-69 -> src/accel/data/sorting.rs:132-172).
+ *   query q: reference items ref_items[ref_ptr[q]..ref_ptr[q+1]) (negative = null, skipped) with
+ *   centred ratings ref_rates (NULL => implicit feedback); d_item_bias NULL or [n_items] floats
+ *   added to every score (one f32 add, as NumPy's `scores + means`); exclude_refs != 0 strikes
+ *   the query's own items from the candidates; items with fewer than min_nbrs contributors have
+ *   no score and are never listed.  out_idx [n_queries x n] = the n best scored items,
+ *   descending, ties by lower item number, -1 padded; out_score likewise (NaN padded; may be
+ *   NULL).  n < 0: every scored candidate, ranked (output [n_queries x n_items]).
+ *   The SCORES are the reference accumulator's bit for bit (csrc/iknn_recommend.hip: one wave
+ *   per (query, window of 4096 items), hits laid out per item in history order through in-order
+ *   LDS cursors -- no barrier per history row as in lk_iknn_score_batch's slot kernel).
+ *   h_query_hits (HOST, [n_queries]): per query, the summed lengths of its reference items'
+ *   similarity rows (the caller has the row lengths: `item_counts`); max_query_hits >= their
+ *   maximum sizes the workspace.  Queries are processed in batches of <= 4096 and <= 2^28 hits.
+ *   Blocking (returns LK_E_NAN_SIM for a NaN similarity).
+ * ---------------------------------------------------------------------- */
+size_t lk_iknn_recommend_workspace_bytes(int64_t n_items, int64_t n_queries,
+                                         int64_t max_query_hits, int32_t max_nbrs, int32_t n);
+int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
+                      const float *d_sim_values, int64_t n_items, int64_t n_queries,
+                      const int64_t *d_ref_ptr, const int32_t *d_ref_items,
+                      const float *d_ref_rates, const float *d_item_bias, int32_t max_nbrs,
+                      int32_t min_nbrs, int32_t n, int exclude_refs, const int64_t *h_query_hits,
+                      int64_t max_query_hits, void *d_ws, int32_t *d_out_idx, float *d_out_score,
+                      void *stream);
+
+/* ------------------------------------------------------------------------
  * Item-kNN scoring for a BATCH of queries.
  * Replaces `_accel.knn.score_explicit` / `score_implicit`
  * (src/lenskit/_accel/knn.pyi:15-29; src/accel/knn/item_score.rs:23-111,

@@ -664,6 +664,46 @@ def iknn_score_batch(sims: DeviceCSR, ref_ptr, ref_items, ref_rates, tgt_ptr, tg
     return out_s, out_c
 
 
+def iknn_recommend(sims: DeviceCSR, ref_ptr, ref_items, ref_rates, item_bias, max_nbrs: int,
+                   min_nbrs: int, n: int, query_hits: np.ndarray, exclude_refs: bool = True):
+    """
+    Item-kNN top-``n`` recommendations for a batch of queries (lk_iknn_recommend): every item is
+    scored with the reference accumulator's arithmetic (bit for bit), ``item_bias`` (the item
+    means of the explicit model, device f32 [n_items], or None) is added, the query's own items
+    are struck out (``exclude_refs``), and the ``n`` best scored items are returned.
+    ``ref_ptr`` / ``ref_items`` / ``ref_rates``: device CSR-style history lists as for
+    :func:`iknn_score_batch`; ``query_hits``: HOST int64 [queries], per query the summed
+    similarity-row lengths of its history items (``item_counts[ref_items]`` summed per query).
+    Returns device (item numbers int32 [B x n], -1 padded; scores f32 [B x n], NaN padded).
+    """
+    lib = _native.require_gpu()
+    n_items = sims.shape[0]
+    nq = int(ref_ptr.shape[0]) - 1
+    dev = sims.indices.device
+    assert sims.indptr.dtype == torch.int64
+    query_hits = np.ascontiguousarray(query_hits, dtype=np.int64)
+    assert query_hits.shape == (nq,)
+    max_hits = int(query_hits.max()) if nq else 0
+    cols = n_items if n < 0 else int(n)
+    out_i = torch.empty((nq, cols), dtype=torch.int32, device=dev)
+    out_s = torch.empty((nq, cols), dtype=torch.float32, device=dev)
+    if nq == 0 or cols == 0:
+        return out_i, out_s
+    ws = torch.empty(lib.lk_iknn_recommend_workspace_bytes(n_items, nq, max_hits, int(max_nbrs),
+                                                           int(n)),
+                     dtype=torch.uint8, device=dev)
+    check(
+        lib.lk_iknn_recommend(
+            _ptr(sims.indptr), _ptr(sims.indices), _ptr(sims.values), n_items, nq, _ptr(ref_ptr),
+            _ptr(ref_items), _ptr(ref_rates), _ptr(item_bias), int(max_nbrs), int(min_nbrs),
+            int(n), 1 if exclude_refs else 0, query_hits.ctypes.data_as(ctypes.c_void_p),
+            max_hits, _ptr(ws), _ptr(out_i), _ptr(out_s), _stream()
+        ),
+        "lk_iknn_recommend",
+    )  # fmt: skip
+    return out_i, out_s
+
+
 def knn_score_last_stats():
     "(queries on the candidate-list kernel, queries on the slot kernel, longest target list) of the last call"
     import ctypes

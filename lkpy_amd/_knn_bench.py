@@ -83,7 +83,66 @@ def _score_batch_leg(D, ratings, means, sims, dev, n_users=10_000, n_targets=100
     return res
 
 
-def run(ratings: sps.csr_array, dev, reps: int = 2, checker=None, score_checker=None) -> dict:
+def _recommend_leg(D, ratings, means, sims, dev, n_users=10_000, n=100, checker=None) -> dict:
+    """SURVEY.md 8d, cfg3, second half: top-100 recommendations for 10 000 sampled users -- every
+    item scored (max_nbrs = 100, min_nbrs = 1), the user's own items struck out, the 100 best
+    kept -- through one ``lk_iknn_recommend`` call (csrc/iknn_recommend.hip)."""
+    csr = sps.csr_array(ratings)
+    rng = np.random.default_rng(43)
+    users = rng.choice(csr.shape[0], min(n_users, csr.shape[0]), replace=False)
+    lens = np.diff(csr.indptr)[users]
+    counts = np.diff(sims.indptr.cpu().numpy()).astype(np.int64)
+    take = np.concatenate([np.arange(csr.indptr[u], csr.indptr[u + 1]) for u in users])
+    r_idx = csr.indices[take].astype(np.int32)
+    hits = np.add.reduceat(counts[r_idx], np.concatenate([[0], np.cumsum(lens)[:-1]]))
+    order = np.argsort(-hits, kind="stable")  # heaviest first, as ItemKNNScorer.recommend_batch does
+    users, lens, hits = users[order], lens[order], hits[order]
+    r_ptr = np.zeros(len(users) + 1, np.int64)
+    np.cumsum(lens, out=r_ptr[1:])
+    take = np.concatenate([np.arange(csr.indptr[u], csr.indptr[u + 1]) for u in users])
+    r_idx = csr.indices[take].astype(np.int32)
+    mean_h = np.asarray(means, dtype=np.float32).ravel()
+    r_val = (csr.data[take] - mean_h[r_idx]).astype(np.float32)
+
+    def to(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    args = (sims, to(r_ptr), to(r_idx), to(r_val), to(mean_h), 100, 1, n, hits)
+    D.iknn_recommend(*args)
+    torch.cuda.synchronize(dev)
+    dt = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        gi, gs = D.iknn_recommend(*args)
+        torch.cuda.synchronize(dev)
+        dt = min(dt, time.perf_counter() - t0)
+    n_items = sims.shape[0]
+    streamed = int(hits.sum())
+    # what the call has to move: every history item's similarity row twice (count + fill: column
+    # and weight), the score panel once out and once in, the lists
+    alg_bytes = streamed * 16 + 2 * len(users) * n_items * 4 + len(users) * n * 8
+    res = {"queries": int(len(users)), "n": n, "seconds": round(dt, 5),
+           "queries_per_s": round(len(users) / dt, 1),
+           "listed": int((gi >= 0).sum().item()),
+           "similarity_entries_streamed": streamed,
+           "longest_history": int(lens.max()), "most_hits_of_a_query": int(hits.max()),
+           "roofline": {"bound": "hbm", "achieved": round(alg_bytes / dt / 1e9, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(alg_bytes / dt / 8e12, 4),
+                        "algorithmic_bytes": alg_bytes,
+                        "note": "whole call: window table, score-all kernel, own-item mask, "
+                                "selection; the 47 MB model is L2/MALL resident, the 2.5 GB score "
+                                "panel is not"}}
+    if checker is not None:
+        try:
+            res.update(checker(sims, r_ptr, r_idx, r_val, mean_h, hits, gi.cpu().numpy(),
+                               gs.cpu().numpy(), n))
+        except Exception as exc:  # noqa: BLE001 -- reported in place
+            res["parity"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return res
+
+
+def run(ratings: sps.csr_array, dev, reps: int = 2, checker=None, score_checker=None,
+        recommend_checker=None) -> dict:
     """
     ``checker(dui, diu, out) -> (cpu_baseline, parity)``: bench.py's oracle leg, called while the
     full similarity matrix is still resident (this package itself never touches ``oracle/``).
@@ -173,6 +232,10 @@ def run(ratings: sps.csr_array, dev, reps: int = 2, checker=None, score_checker=
         torch.cuda.synchronize(dev)
         t100.append(time.perf_counter() - t0)
     score = _score_batch_leg(D, ratings, means, sims, dev, checker=score_checker)
+    try:
+        reco = _recommend_leg(D, ratings, means, sims, dev, checker=recommend_checker)
+    except Exception as exc:  # noqa: BLE001 -- reported in place
+        reco = {"error": f"{type(exc).__name__}: {exc}"}
     res = {
         "metric": "item-kNN model build seconds (ML-25M-shaped, cosine, min_sim=1e-6, unbounded)",
         "value": round(best, 4),
@@ -191,6 +254,7 @@ def run(ratings: sps.csr_array, dev, reps: int = 2, checker=None, score_checker=
         "save_nbrs_100_nnz": int(sims.indices.shape[0]),
         "train_seconds_incl_prepare": round(t_prep + best, 3),
         "batch_score": score,
+        "recommend": reco,
         "macs": macs,
         "gmacs_per_s": round(macs / best / 1e9, 2),
         "roofline": res_roof,

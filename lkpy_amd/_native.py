@@ -112,6 +112,10 @@ def _declare(lib):
         ),
         "lk_iknn_truncate_fill": (c_int, [vp, vp, vp, c_int64, c_int64, vp, vp, vp, vp, vp]),
         "lk_iknn_score_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32]),
+        "lk_iknn_recommend_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int32,
+                                                         c_int32]),
+        "lk_iknn_recommend": (c_int, [vp, vp, vp, c_int64, c_int64, vp, vp, vp, vp, c_int32,
+                                      c_int32, c_int32, c_int, vp, c_int64, vp, vp, vp, vp]),
         "lk_knn_score_last_stats": (None, [POINTER(c_int64)]),
         "lk_iknn_score_batch": (
             c_int,

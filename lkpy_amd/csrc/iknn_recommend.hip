@@ -1,0 +1,533 @@
+// iknn_recommend.hip -- item-kNN "score every item + top-N" for a BATCH of queries, gfx950.
+//
+// What `pipelines/iknn-explicit.toml`'s recommender does per query, one query per pipeline run
+// (src/lenskit/batch/_runner.py:283-308): candidates = all training items minus the query's
+// own (src/lenskit/basic/candidates.py:77-94), `ItemKNNScorer.__call__` over them
+// (src/lenskit/knn/item.py:231-295 -> `score_explicit` / `score_implicit`,
+// src/accel/knn/item_score.rs:23-111, one `ScoreAccumulator` per item, accum.rs), item means
+// added back (item.py:282), then `TopNRanker` (src/lenskit/basic/topn.py:45-69): the n largest
+// non-NaN scores, descending.
+//
+// The scores are the reference accumulator's BIT FOR BIT (iknn_score.hip explains why that
+// needs its evaluation order: the hits of a target in history order, a vector while there is
+// room, std's BinaryHeap replayed beyond `max_nbrs`, sequential sums with product and sum
+// rounded separately).  `iknn_score_kernel` gets that order from one workgroup barrier per
+// history row; here NOTHING waits on a barrier:
+//
+//  * the catalogue is cut into WINDOWS of RW = 4096 targets; a task is (query, window) and
+//    belongs to ONE WAVE.  A wave executes its LDS operations in program order, so when it walks
+//    the history rows in order, per-target cursors in its private 16 KB of LDS come out in
+//    history order by construction -- no atomics between waves, no sort, no barrier;
+//  * the part of a similarity row that falls into a window is found through a per-call table
+//    (`row_windows_kernel`: lower bounds of the window borders in every row -- rows are sorted
+//    by column), so a wave touches only its own entries;
+//  * pass 1 counts the window's hits per target (`ds_add_u32`, fire and forget), an in-wave
+//    scan turns counts into list offsets, pass 2 re-walks the rows and drops every hit
+//    (weight, value) at its target's cursor (`ds_add_rtn_u32`) -- the lists of a window are
+//    contiguous, in target order, each in history order;
+//  * pass 3: lane l owns targets 64 l .. 64 l + 63 and streams their lists (one contiguous run
+//    per lane): <= max_nbrs hits = the vector's sequential sums; more = the BinaryHeap replay of
+//    iknn_score.hip on a per-lane scratch; the score (+ item mean) replaces the cursor in LDS and
+//    the window leaves as one coalesced row segment of the score panel (NaN where nothing was
+//    scored: no panel memset).
+//  Segments of <= 64 entries (row x window) are loaded D = 8 ahead of their use.
+//
+// The panel rows then lose the query's own items (NaN) and go through the dense path's selection
+// (`row_topn_kernel` / full sort of topk.hip): n largest non-NaN, descending, ties by lower item.
+//
+// Bound: the similarity rows of every history item are streamed twice (count + fill: 16 B per hit
+// of algorithmic traffic, L2 / MALL resident for a truncated model) and every hit costs two LDS
+// atomics; the per-window fixed cost (zero, scan, score sweep, copy-out) is what a short history
+// pays.  bench.py reports the call against the HBM roofline on those bytes.
+#include <vector>
+
+#include "common.h"
+
+#pragma clang fp contract(off)  // weight * value is rounded before it is added (accum.rs:128-130)
+
+namespace lk {
+// selection over a score panel (topk.hip)
+size_t panel_topn_workspace_bytes(int64_t rows, int64_t n_items, int32_t n);
+int panel_topn(const float *panel, int64_t ld_s, int64_t rows, int64_t n_items, int32_t n,
+               void *sort_ws, int32_t *out_idx, float *out_score, hipStream_t st);
+
+namespace rec {
+
+constexpr int RW = 4096;        // targets per window = per wave
+constexpr int RWAVES = 4;       // waves per workgroup (each on its own window task)
+constexpr int RTHREADS = RWAVES * 64;
+constexpr int RD = 8;           // segments in flight per wave
+constexpr int RPAD = RW + RW / 64;  // cursor array: index t + (t >> 6) (conflict-free lane-owned runs)
+
+__device__ __forceinline__ int cidx(int t) { return t + (t >> 6); }
+
+__device__ __forceinline__ int64_t readlane64(int64_t v, int l)
+{
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), l);
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+// woff[r * (nwin + 1) + b] = entries of similarity row r with column < b * RW
+__global__ void row_windows_kernel(const int64_t *__restrict__ s_ptr,
+                                   const int32_t *__restrict__ s_idx, int64_t n_rows, int nwin,
+                                   unsigned *__restrict__ woff)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * (nwin + 1)) return;
+    const int64_t r = i / (nwin + 1);
+    const int64_t key = (i % (nwin + 1)) * RW;
+    const int64_t base = s_ptr[r];
+    int64_t lo = base, hi = s_ptr[r + 1];
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)s_idx[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    woff[i] = (unsigned)(lo - base);
+}
+
+// the reference's accumulator beyond max_nbrs entries, for ONE lane on its own scratch (the code
+// of iknn_score.hip's KfHeap; see there for the correspondence with std's BinaryHeap)
+struct LaneHeap {
+    float *w, *v;
+    int len;
+    __device__ __forceinline__ void sift_up(int pos, float ew, float ev)
+    {
+        while (pos > 0) {
+            const int parent = (pos - 1) >> 1;
+            if (ew >= w[parent]) break;
+            w[pos] = w[parent];
+            v[pos] = v[parent];
+            pos = parent;
+        }
+        w[pos] = ew;
+        v[pos] = ev;
+    }
+    __device__ __forceinline__ void push(float ew, float ev) { sift_up(len++, ew, ev); }
+    __device__ __forceinline__ void pop()
+    {
+        const float ew = w[len - 1], ev = v[len - 1];
+        --len;
+        if (len == 0) return;
+        const int end = len;
+        int pos = 0, child = 1;
+        const int limit = end >= 2 ? end - 2 : 0;
+        while (child <= limit && end >= 2) {
+            if (w[child] >= w[child + 1]) child += 1;
+            w[pos] = w[child];
+            v[pos] = v[child];
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        if (child == end - 1) {
+            w[pos] = w[child];
+            v[pos] = v[child];
+            pos = child;
+        }
+        sift_up(pos, ew, ev);
+    }
+};
+
+// One walk over the history rows of a query for one window.  FILL = false: count the hits per
+// target; FILL = true: drop (weight, value) at the target's cursor.  The (row x window) pieces are
+// cut into segments of <= 64 entries; the column (and weight) loads of RD segments are in flight
+// ahead of the LDS updates, which happen strictly in history order.
+template <bool FILL, bool EXPL>
+__device__ __forceinline__ void walk(unsigned *__restrict__ c, const int64_t *__restrict__ s_ptr,
+                                     const int32_t *__restrict__ s_idx,
+                                     const float *__restrict__ s_val,
+                                     const unsigned *__restrict__ woff, int nwin, int win,
+                                     int64_t n_items, const int32_t *__restrict__ ref_items,
+                                     const float *__restrict__ ref_rates, int64_t rb, int64_t re,
+                                     float2 *__restrict__ hits, int *__restrict__ status, int lane)
+{
+    const int w0 = win * RW;
+    for (int64_t r0 = rb; r0 < re; r0 += 64) {
+        // descriptors of up to 64 history rows: lane = row
+        int64_t a = 0;
+        int n = 0;
+        float rate = 0.f;
+        if (r0 + lane < re) {
+            const int ri = ref_items[r0 + lane];
+            if (ri >= 0 && ri < n_items) {  // null reference rows are skipped (item_score.rs:38-49)
+                const unsigned *wo = woff + (int64_t)ri * (nwin + 1) + win;
+                const unsigned o0 = wo[0], o1 = wo[1];
+                a = s_ptr[ri] + o0;
+                n = (int)(o1 - o0);
+            }
+            if (EXPL) rate = ref_rates[r0 + lane];
+        }
+        unsigned long long mask = __ballot(n > 0);
+        if (!mask) continue;
+        // issue cursor over the segments of the rows in `mask`, ascending = history order
+        int j = __builtin_ctzll(mask);
+        int nj = __builtin_amdgcn_readlane(n, j);
+        int64_t aj = readlane64(a, j);
+        float rj = bcast(rate, j);
+        int base = 0;
+        bool more = true;
+        int t_[RD], cnt_[RD];
+        float s_[RD], r_[RD];
+#pragma unroll
+        for (int d = 0; d < RD; ++d) cnt_[d] = 0;
+        auto issue = [&](int d) {
+            const int cn = nj - base < 64 ? nj - base : 64;
+            const int64_t e = aj + base + (lane < cn ? lane : cn - 1);  // unconditional load
+            t_[d] = s_idx[e] - w0;
+            if (FILL) s_[d] = s_val[e];
+            r_[d] = rj;
+            cnt_[d] = cn;
+            base += 64;
+            if (base >= nj) {
+                mask &= mask - 1;
+                if (mask) {
+                    j = __builtin_ctzll(mask);
+                    nj = __builtin_amdgcn_readlane(n, j);
+                    aj = readlane64(a, j);
+                    rj = bcast(rate, j);
+                    base = 0;
+                } else {
+                    more = false;
+                }
+            }
+        };
+        auto consume = [&](int d) {
+            if (lane < cnt_[d]) {
+                if (!FILL) {
+                    atomicAdd(&c[cidx(t_[d])], 1u);  // ds_add_u32, no return
+                } else {
+                    const unsigned pos = atomicAdd(&c[cidx(t_[d])], 1u);
+                    if (s_[d] != s_[d]) atomicCAS(status, 0, 1);  // accum.rs:146-151
+                    hits[pos] = float2{s_[d], r_[d]};
+                }
+            }
+            cnt_[d] = 0;
+        };
+#pragma unroll
+        for (int d = 0; d < RD; ++d)
+            if (more) issue(d);
+        for (;;) {
+            bool any = false;
+#pragma unroll
+            for (int d = 0; d < RD; ++d) {
+                if (cnt_[d] > 0) {  // wave-uniform
+                    consume(d);
+                    any = true;
+                    if (more) issue(d);
+                }
+            }
+            if (!any) break;
+        }
+    }
+}
+
+// Task = (query of the batch, window); one wave per task, taken from an atomic counter.
+template <bool EXPL>
+__global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
+    const int64_t *__restrict__ s_ptr, const int32_t *__restrict__ s_idx,
+    const float *__restrict__ s_val, int64_t n_items, int nwin, const unsigned *__restrict__ woff,
+    int64_t q0, int64_t nq, const int64_t *__restrict__ ref_ptr,
+    const int32_t *__restrict__ ref_items, const float *__restrict__ ref_rates,
+    const float *__restrict__ item_bias, int max_nbrs, int min_nbrs, float2 *__restrict__ hits,
+    const int64_t *__restrict__ q_hit_base, unsigned long long *__restrict__ q_cursor,
+    float *__restrict__ panel, int64_t ld, float *__restrict__ heap_scratch,
+    int *__restrict__ task_counter, int *__restrict__ status)
+{
+    __shared__ unsigned cur[RWAVES][RPAD];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned *c = cur[wave];
+    const int64_t n_tasks = nq * nwin;
+    float *hw = heap_scratch +
+                ((size_t)(blockIdx.x * RWAVES + wave) * 64 + lane) * (size_t)(max_nbrs + 1) * 2;
+    float *hv = hw + (max_nbrs + 1);
+    const float nanf_ = __builtin_nanf("");
+
+    for (;;) {
+        int task = 0;
+        if (lane == 0) task = atomicAdd(task_counter, 1);
+        task = __builtin_amdgcn_readfirstlane(task);
+        if (task >= n_tasks) break;
+        const int64_t ql = task / nwin;  // query-major: the windows of a query run side by side
+        const int win = task % nwin;
+        const int64_t q = q0 + ql;
+        const int w0 = win * RW;
+        const int wn = (int)((n_items - w0) < RW ? (n_items - w0) : RW);
+        const int64_t rb = ref_ptr[q], re = ref_ptr[q + 1];
+        float *prow = panel + ql * ld + w0;
+        if (re == rb) {  // no history: nothing is scored (item.py:238-245)
+            for (int i = lane; i < wn; i += 64) prow[i] = nanf_;
+            continue;
+        }
+        for (int i = lane; i < RPAD; i += 64) c[i] = 0u;
+
+        // ---- pass 1: hits per target ----------------------------------------------------
+        walk<false, EXPL>(c, s_ptr, s_idx, s_val, woff, nwin, win, n_items, ref_items, ref_rates,
+                          rb, re, nullptr, status, lane);
+
+        // ---- counts -> list offsets: lane l owns targets 64 l .. 64 l + 63 --------------------
+        unsigned run = 0;
+        {
+            unsigned v[64];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) v[i] = c[lane * 65 + i];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const unsigned x = v[i];
+                v[i] = run;
+                run += x;
+            }
+            // exclusive scan of the lanes' totals
+            unsigned incl = run;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            const unsigned excl = incl - run;
+#pragma unroll
+            for (int i = 0; i < 64; ++i) c[lane * 65 + i] = v[i] + excl;
+            run = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);  // hits of the window
+        }
+        const unsigned total = run;
+        if (total == 0) {
+            for (int i = lane; i < wn; i += 64) prow[i] = nanf_;
+            continue;
+        }
+        // the window's share of the query's hit region
+        unsigned long long hb = 0;
+        if (lane == 0) hb = q_hit_base[ql] + atomicAdd(&q_cursor[ql], (unsigned long long)total);
+        hb = (unsigned long long)readlane64((int64_t)hb, 0);
+        float2 *lists = hits + hb;
+
+        // ---- pass 2: the hits, each at its target's cursor (history order by construction) ----
+        walk<true, EXPL>(c, s_ptr, s_idx, s_val, woff, nwin, win, n_items, ref_items, ref_rates,
+                         rb, re, lists, status, lane);
+        // the lists were written by OTHER lanes of this wave: complete the stores (write-through
+        // to L2) and drop whatever stale lines this CU's L1 may hold of the region
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
+        // ---- pass 3: scores.  After the fill c[t] = END of t's list = start of t + 1's ----------
+        unsigned beg = lane == 0 ? 0u : c[(lane - 1) * 65 + 63];
+        for (int i = 0; i < 64; ++i) {
+            const int t = lane * 64 + i;
+            const unsigned end = c[lane * 65 + i];
+            const int cnt = (int)(end - beg);
+            float score = nanf_;
+            const int kept = cnt < max_nbrs ? cnt : max_nbrs;
+            if (cnt > 0 && kept >= min_nbrs && t < wn) {
+                float tw = 0.f, ws = 0.f;
+                const float2 *l = lists + beg;
+                if (cnt <= max_nbrs) {  // Partial(vec): sums in insertion order
+                    for (int x = 0; x < cnt; ++x) {
+                        const float2 h = l[x];
+                        tw += h.x;
+                        if (EXPL) ws += h.x * h.y;
+                    }
+                } else {  // Full(heap): accum.rs:76-83,100-117
+                    for (int x = 0; x < max_nbrs; ++x) {  // vec.pop() from the back, push each
+                        const float2 h = l[max_nbrs - 1 - x];
+                        hw[x] = h.x;
+                        hv[x] = h.y;
+                    }
+                    LaneHeap hp{hw, hv, max_nbrs};
+                    for (int kk = 1; kk < max_nbrs; ++kk) hp.sift_up(kk, hw[kk], hv[kk]);
+                    for (int x = max_nbrs; x < cnt; ++x) {
+                        const float2 h = l[x];
+                        if (h.x > hw[0]) {  // strictly greater than the minimum (accum.rs:108)
+                            hp.push(h.x, h.y);
+                            while (hp.len > max_nbrs) hp.pop();
+                        }
+                    }
+                    for (int x = 0; x < max_nbrs; ++x) {
+                        tw += hw[x];
+                        if (EXPL) ws += hw[x] * hv[x];
+                    }
+                }
+                score = EXPL ? ws / tw : tw;
+                if (item_bias) score = score + item_bias[w0 + t];  // item.py:282 (f32 add)
+            }
+            c[lane * 65 + i] = __builtin_bit_cast(unsigned, score);
+            beg = end;
+        }
+        // ---- the window's segment of the panel row, coalesced -----------------------------------
+        for (int i = lane; i < wn; i += 64) prow[i] = __builtin_bit_cast(float, c[cidx(i)]);
+    }
+}
+
+// panel[q][own item] = NaN (candidates = all items minus the query's, candidates.py:77-94)
+__global__ void mask_refs_kernel(const int64_t *__restrict__ ref_ptr,
+                                 const int32_t *__restrict__ ref_items, int64_t q0, int64_t nq,
+                                 int64_t n_items, float *__restrict__ panel, int64_t ld)
+{
+    const int64_t ql = blockIdx.x;
+    if (ql >= nq) return;
+    const int64_t s = ref_ptr[q0 + ql], e = ref_ptr[q0 + ql + 1];
+    for (int64_t r = s + threadIdx.x; r < e; r += blockDim.x) {
+        const int it = ref_items[r];
+        if (it >= 0 && it < n_items) panel[ql * ld + it] = __builtin_nanf("");
+    }
+}
+
+constexpr int64_t REC_PANEL_ROWS = 4096;            // queries per batch at most
+constexpr int64_t REC_HITS_MIN = (int64_t)1 << 28;  // hit capacity of a batch (2 GiB) unless a
+                                                    // single query needs more
+constexpr int REC_MAX_WGS = 512;
+
+static inline int64_t ld_items(int64_t n_items) { return (n_items + 63) / 64 * 64; }
+static inline int nwindows(int64_t n_items) { return (int)((n_items + RW - 1) / RW); }
+
+struct Layout {
+    size_t off_status, off_woff, off_base, off_cursor, off_heap, off_panel, off_hits, off_sort, bytes;
+    int64_t rows, hit_cap;
+};
+
+static Layout layout(int64_t n_items, int64_t n_queries, int64_t max_query_hits, int32_t max_nbrs,
+                     int32_t n)
+{
+    Layout L;
+    L.rows = n_queries < REC_PANEL_ROWS ? (n_queries > 0 ? n_queries : 1) : REC_PANEL_ROWS;
+    // a batch holds up to REC_HITS_MIN hits (never less than the heaviest query's; a small call
+    // does not pay for more than all of its queries could need)
+    int64_t cap = REC_HITS_MIN;
+    if (max_query_hits > 0 && n_queries > 0 && cap / max_query_hits >= n_queries)
+        cap = max_query_hits * n_queries;
+    L.hit_cap = max_query_hits > cap ? max_query_hits : cap;
+    if (L.hit_cap < 64) L.hit_cap = 64;
+    size_t off = 0;
+    L.off_status = off;
+    off += 256;
+    L.off_woff = off;
+    off += align_up((size_t)n_items * (nwindows(n_items) + 1) * sizeof(unsigned), 256);
+    L.off_base = off;
+    off += align_up((size_t)(n_queries > 0 ? n_queries : 1) * sizeof(int64_t), 256);
+    L.off_cursor = off;
+    off += align_up((size_t)(n_queries > 0 ? n_queries : 1) * sizeof(unsigned long long), 256);
+    L.off_heap = off;
+    off += align_up((size_t)REC_MAX_WGS * RWAVES * 64 * (size_t)(max_nbrs + 1) * 2 * sizeof(float),
+                    256);
+    L.off_panel = off;
+    off += align_up((size_t)L.rows * ld_items(n_items) * sizeof(float), 256);
+    L.off_hits = off;
+    off += align_up((size_t)L.hit_cap * sizeof(float2), 256);
+    L.off_sort = off;
+    off += align_up(panel_topn_workspace_bytes(L.rows, n_items, n), 256);
+    L.bytes = off;
+    return L;
+}
+
+}  // namespace rec
+}  // namespace lk
+
+extern "C" size_t lk_iknn_recommend_workspace_bytes(int64_t n_items, int64_t n_queries,
+                                                    int64_t max_query_hits, int32_t max_nbrs,
+                                                    int32_t n)
+{
+    if (n_items < 0 || n_queries < 0 || max_nbrs < 1) return 0;
+    return lk::rec::layout(n_items, n_queries, max_query_hits, max_nbrs, n).bytes;
+}
+
+extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
+                                 const float *d_sim_values, int64_t n_items, int64_t n_queries,
+                                 const int64_t *d_ref_ptr, const int32_t *d_ref_items,
+                                 const float *d_ref_rates, const float *d_item_bias,
+                                 int32_t max_nbrs, int32_t min_nbrs, int32_t n, int exclude_refs,
+                                 const int64_t *h_query_hits, int64_t max_query_hits, void *d_ws,
+                                 int32_t *d_out_idx, float *d_out_score, void *stream)
+{
+    using namespace lk;
+    using namespace lk::rec;
+    LK_REQUIRE(max_nbrs >= 1 && min_nbrs >= 1, "lk_iknn_recommend: max_nbrs/min_nbrs must be >= 1");
+    LK_REQUIRE(n_items >= 0 && n_queries >= 0, "lk_iknn_recommend: negative size");
+    LK_REQUIRE(n_items < ((int64_t)1 << 31) - RW, "lk_iknn_recommend: too many items");
+    if (n_queries == 0 || n == 0) return LK_OK;
+    const int64_t out_cols = n < 0 ? n_items : n;
+    if (out_cols == 0) return LK_OK;
+    LK_REQUIRE(d_sim_indptr && d_ref_ptr && h_query_hits && d_ws && d_out_idx,
+               "lk_iknn_recommend: null pointer");
+    hipStream_t st = as_stream(stream);
+    const Layout L = layout(n_items, n_queries, max_query_hits, max_nbrs, n);
+    char *ws = static_cast<char *>(d_ws);
+    int *status = reinterpret_cast<int *>(ws + L.off_status);  // [0] NaN similarity, [1] task counter
+    unsigned *woff = reinterpret_cast<unsigned *>(ws + L.off_woff);
+    int64_t *q_base = reinterpret_cast<int64_t *>(ws + L.off_base);
+    auto *q_cursor = reinterpret_cast<unsigned long long *>(ws + L.off_cursor);
+    float *heap = reinterpret_cast<float *>(ws + L.off_heap);
+    float *panel = reinterpret_cast<float *>(ws + L.off_panel);
+    float2 *hits = reinterpret_cast<float2 *>(ws + L.off_hits);
+    void *sort_ws = ws + L.off_sort;
+    const int nwin = nwindows(n_items);
+    const int64_t ld = ld_items(n_items);
+
+    // batches: at most L.rows queries and L.hit_cap hits each; a query's hit region starts at the
+    // sum of the hits of the batch's queries before it
+    std::vector<int64_t> base((size_t)n_queries);
+    std::vector<int64_t> cuts{0};
+    {
+        int64_t acc = 0, rows = 0;
+        for (int64_t q = 0; q < n_queries; ++q) {
+            const int64_t h = h_query_hits[q];
+            LK_REQUIRE(h >= 0 && h <= L.hit_cap,
+                       "lk_iknn_recommend: query %lld has %lld hits, more than max_query_hits",
+                       (long long)q, (long long)h);
+            if (rows == L.rows || acc + h > L.hit_cap) {
+                cuts.push_back(q);
+                acc = 0;
+                rows = 0;
+            }
+            base[(size_t)q] = acc;
+            acc += h;
+            ++rows;
+        }
+        cuts.push_back(n_queries);
+    }
+    LK_HIP_CHECK(hipMemsetAsync(status, 0, 256, st));
+    LK_HIP_CHECK(hipMemcpyAsync(q_base, base.data(), (size_t)n_queries * sizeof(int64_t),
+                                hipMemcpyHostToDevice, st));
+    LK_HIP_CHECK(hipStreamSynchronize(st));  // `base` is host memory that dies with this call
+    LK_HIP_CHECK(hipMemsetAsync(q_cursor, 0, (size_t)n_queries * sizeof(unsigned long long), st));
+    if (n_items > 0) {
+        const int64_t cells = n_items * (nwin + 1);
+        hipLaunchKernelGGL(row_windows_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0,
+                           st, d_sim_indptr, d_sim_indices, n_items, nwin, woff);
+    }
+    for (size_t b = 0; b + 1 < cuts.size(); ++b) {
+        const int64_t q0 = cuts[b], nq = cuts[b + 1] - cuts[b];
+        if (nq <= 0) continue;
+        if (n_items > 0) {
+            LK_HIP_CHECK(hipMemsetAsync(status + 1, 0, sizeof(int), st));
+            const int64_t tasks = nq * nwin;
+            int64_t wgs = (tasks + RWAVES - 1) / RWAVES;
+            if (wgs > REC_MAX_WGS) wgs = REC_MAX_WGS;
+#define LK_REC_LAUNCH(EXPLV)                                                                      \
+    hipLaunchKernelGGL((iknn_score_all_kernel<EXPLV>), dim3((unsigned)wgs), dim3(RTHREADS), 0, st, \
+                       d_sim_indptr, d_sim_indices, d_sim_values, n_items, nwin, woff, q0, nq,    \
+                       d_ref_ptr, d_ref_items, d_ref_rates, d_item_bias, max_nbrs, min_nbrs, hits, \
+                       q_base + q0, q_cursor + q0, panel, ld, heap, status + 1, status)
+            if (d_ref_rates)
+                LK_REC_LAUNCH(true);
+            else
+                LK_REC_LAUNCH(false);
+#undef LK_REC_LAUNCH
+            if (exclude_refs)
+                hipLaunchKernelGGL(mask_refs_kernel, dim3((unsigned)nq), dim3(64), 0, st, d_ref_ptr,
+                                   d_ref_items, q0, nq, n_items, panel, ld);
+        }
+        int rc = panel_topn(panel, ld, nq, n_items, n, sort_ws, d_out_idx + q0 * out_cols,
+                            d_out_score ? d_out_score + q0 * out_cols : nullptr, st);
+        if (rc != LK_OK) return rc;
+    }
+    LK_HIP_CHECK(hipGetLastError());
+    int h = 0;
+    LK_HIP_CHECK(hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, st));
+    LK_HIP_CHECK(hipStreamSynchronize(st));
+    if (h != 0) {
+        set_error("similarity is null");  // accum.rs:146-151 -> ValueError
+        return LK_E_NAN_SIM;
+    }
+    return LK_OK;
+}

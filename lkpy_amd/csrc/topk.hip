@@ -1414,6 +1414,28 @@ extern "C" size_t lk_score_topk_workspace_bytes(int64_t n_users, int64_t n_items
     return bytes;
 }
 
+namespace lk {
+// Selection over a score panel that somebody else filled (iknn_recommend.hip): the n largest
+// non-NaN entries of every row, descending, ties by lower index; n < 0 or n > TOPN_MAX: full sort.
+size_t panel_topn_workspace_bytes(int64_t rows, int64_t n_items, int32_t n)
+{
+    return (n < 0 || n > TOPN_MAX) ? topn_sort_workspace_bytes(rows, n_items) : 0;
+}
+int panel_topn(const float *panel, int64_t ld_s, int64_t rows, int64_t n_items, int32_t n,
+               void *sort_ws, int32_t *out_idx, float *out_score, hipStream_t st)
+{
+    if (rows <= 0 || n == 0) return LK_OK;
+    if (n < 0 || n > TOPN_MAX) {
+        const int64_t cols = n < 0 ? n_items : n;
+        return topn_sort(panel, ld_s, rows, n_items, cols, sort_ws, out_idx, out_score, cols, st);
+    }
+    hipLaunchKernelGGL(row_topn_kernel<TOPN_MAX>, dim3((unsigned)rows), dim3(256), 0, st, panel,
+                       ld_s, n_items, n, out_idx, out_score, (int64_t)n);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+}  // namespace lk
+
 extern "C" size_t lk_argtopn_workspace_bytes(int64_t n_rows, int64_t row_len, int32_t n)
 {
     if (n >= 0 && n <= lk::TOPN_MAX) return 0;

@@ -159,6 +159,64 @@ class ItemKNNScorer(Component):
     def __call__(self, query, items: ItemList) -> ItemList:
         return self.score_batch([query], [items])[0]
 
+    def recommend_batch(self, queries, n: int, *, exclude_history: bool = True):
+        """
+        Top-``n`` lists for many queries at once -- what the ``recommender`` pipeline computes one
+        query at a time (src/lenskit/batch/_runner.py:283-308): candidates = every training item
+        minus the query's own (src/lenskit/basic/candidates.py:77-94), this scorer over them
+        (item.py:231-295, means added back: 282), ``TopNRanker`` (basic/topn.py:45-69).  One
+        ``lk_iknn_recommend`` call: scores bit-identical to the reference accumulator's, items
+        with fewer than ``min_nbrs`` neighbours never listed, queries without history get empty
+        lists (item.py:238-245: all-NaN scores).  Returns (item numbers [B x n] with -1 padding,
+        scores [B x n] with NaN padding), like ``ImplicitMFScorer.recommend_batch``.
+        """
+        st = self._device_sims()
+        d = st["device"]
+        queries = [RecQuery.create(q) for q in queries]
+        r_idx, r_val, r_ptr = [], [], [0]
+        for q in queries:
+            ratings = q.query_items
+            if ratings is None or len(ratings) == 0:
+                r_ptr.append(r_ptr[-1])
+                continue
+            ri = ratings.numbers(vocabulary=self.items, missing="negative")
+            if self.config.explicit:
+                rv = ratings.field("rating")
+                if rv is None:
+                    raise RuntimeError("explicit-feedback scorer must have ratings")
+                rv = np.asarray(rv).astype(np.float32, copy=True)
+                m = ri >= 0
+                rv[m] -= self.item_means[ri[m]]  # mean-centre (item.py:268-271)
+                r_val.append(rv)
+            r_idx.append(ri)
+            r_ptr.append(r_ptr[-1] + len(ri))
+        cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)  # noqa: E731
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)  # noqa: E731
+        idx = cat(r_idx, np.int32)
+        ptr = np.asarray(r_ptr, np.int64)
+        # hits per query: the similarity-row lengths of its history items, summed
+        counts = np.asarray(self.item_counts, dtype=np.int64)
+        per = np.where(idx >= 0, counts[np.maximum(idx, 0)], 0)
+        csum = np.concatenate([[0], np.cumsum(per)])
+        hits = csum[ptr[1:]] - csum[ptr[:-1]]
+        # heaviest queries first (the launch is as long as its longest task chain); undone below
+        order = np.argsort(-hits, kind="stable")
+        lens = np.diff(ptr)[order]
+        optr = np.zeros(len(order) + 1, np.int64)
+        np.cumsum(lens, out=optr[1:])
+        take = np.concatenate([np.arange(ptr[q], ptr[q + 1]) for q in order]) if len(idx) else \
+            np.zeros(0, np.int64)
+        bias = st.get("means")
+        if bias is None and self.config.explicit and self.item_means is not None:
+            bias = st["means"] = to(np.asarray(self.item_means, dtype=np.float32))
+        rr = to(cat(r_val, np.float32)[take]) if self.config.explicit else None
+        oi, osc = D.iknn_recommend(st["sims"], to(optr), to(idx[take]), rr,
+                                   bias if self.config.explicit else None, self.config.max_nbrs,
+                                   self.config.min_nbrs, n, hits[order], exclude_history)
+        inv = np.empty_like(order)
+        inv[order] = np.arange(len(order))
+        return oi.cpu().numpy()[inv], osc.cpu().numpy()[inv]
+
 
 # ---------------------------------------------------------------------------------------
 # User-based k-NN (SURVEY.md section 8f, rank 4)

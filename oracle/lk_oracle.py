@@ -608,6 +608,54 @@ def iknn_score_batch(sims: sps.csr_array, ref_ptr, ref_items, ref_rates, tgt_ptr
     return scores, counts
 
 
+def iknn_recommend_batch(sims: sps.csr_array, ref_ptr, ref_items, ref_rates, item_means,
+                         max_nbrs: int, min_nbrs: int, n: int, n_threads: int = 0,
+                         exclude_refs: bool = True, chunk: int = 256):
+    """
+    The ``recommender`` pipeline of ``iknn-explicit.toml`` for a batch, one query after the other
+    as the reference runs it (src/lenskit/batch/_runner.py:283-308): candidates = every item minus
+    the query's own (src/lenskit/basic/candidates.py:77-94); ``ItemKNNScorer.__call__`` over them
+    = ``score_explicit`` / ``score_implicit`` with all candidates as targets
+    (src/lenskit/knn/item.py:231-295, item_score.rs:23-111) and the item means added back in
+    float32 (item.py:282); ``TopNRanker`` = ``argtopn`` (basic/topn.py:45-69, sorting.rs:132-172).
+    Scoring every item and striking the own items afterwards gives the same lists: targets do
+    not influence each other.  Returns (indices int32 [B x n] padded -1, scores f32 [B x n]
+    padded NaN, full score rows f32 [B x n_items] with NaN for unscored / own items).
+    """
+    ref_ptr = np.asarray(ref_ptr, dtype=np.int64)
+    ref_items = np.asarray(ref_items, dtype=np.int32)
+    n_items = sims.shape[0]
+    B = len(ref_ptr) - 1
+    all_items = np.arange(n_items, dtype=np.int32)
+    out_i = np.full((B, n), -1, dtype=np.int32)
+    out_s = np.full((B, n), np.nan, dtype=np.float32)
+    rows = np.empty((B, n_items), dtype=np.float32)
+    for c0 in range(0, B, chunk):
+        c1 = min(B, c0 + chunk)
+        rp = ref_ptr[c0:c1 + 1] - ref_ptr[c0]
+        ri = ref_items[ref_ptr[c0]:ref_ptr[c1]]
+        rr = None if ref_rates is None else \
+            np.asarray(ref_rates, dtype=np.float32)[ref_ptr[c0]:ref_ptr[c1]]
+        tp = np.arange(c1 - c0 + 1, dtype=np.int64) * n_items
+        sc, _cnt = iknn_score_batch(sims, rp, ri, rr, tp, np.tile(all_items, c1 - c0), max_nbrs,
+                                    min_nbrs, n_threads)
+        sc = sc.reshape(c1 - c0, n_items)
+        for q in range(c0, c1):
+            row = sc[q - c0]
+            if ref_ptr[q + 1] == ref_ptr[q]:
+                row[:] = np.nan  # no history: nothing is scored (item.py:238-245)
+            elif item_means is not None:
+                row += np.asarray(item_means, dtype=np.float32)  # item.py:282 (NaN stays NaN)
+            if exclude_refs:
+                own = ref_items[ref_ptr[q]:ref_ptr[q + 1]]
+                row[own[own >= 0]] = np.nan
+            top = argtopn(row, n)
+            out_i[q, :len(top)] = top
+            out_s[q, :len(top)] = row[top]
+            rows[q] = row
+    return out_i, out_s, rows
+
+
 def uknn_score(ratings: sps.csr_array, nbr_rows, nbr_sims, tgt_items, max_nbrs: int,
                min_nbrs: int, explicit: bool = True) -> np.ndarray:
     """

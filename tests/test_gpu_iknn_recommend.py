@@ -1,0 +1,148 @@
+"""
+``lk_iknn_recommend`` (csrc/iknn_recommend.hip): item-kNN "score every item + top-N" for a batch
+of queries against the oracle's restatement of the reference pipeline
+(src/lenskit/knn/item.py:231-295 -> src/accel/knn/item_score.rs:23-111 + accum.rs;
+src/lenskit/basic/candidates.py:77-94; src/lenskit/basic/topn.py:45-69).
+
+Bar: the SCORE of every listed item carries the reference accumulator's bits; the sorted score
+rows of the lists are bit-identical to the oracle's; every listed item is a genuine candidate
+(scored, not one of the query's own); which of several items with IDENTICAL score bits is listed
+first / kept at the cut is the reference heap's sift order (unspecified: SURVEY 8g-8) and is
+counted, not hidden.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+pytestmark = pytest.mark.gpu
+
+
+def _to(a, dev):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _model(oracle, rng, n_users, n_items, mean_len, save_nbrs):
+    lens = np.clip(rng.geometric(1.0 / mean_len, n_users), 1, n_items // 2)
+    lens[:3] = [n_items // 2, 700, 300]
+    rows = np.repeat(np.arange(n_users), lens)
+    cols = np.concatenate([rng.choice(n_items, ln, replace=False) for ln in lens])
+    vals = rng.integers(1, 11, len(rows)).astype(np.float32) * 0.5
+    rmat = sps.coo_array((vals, (rows, cols)), shape=(n_users, n_items))
+    ui, iu, means, _ = oracle.iknn_prepare(rmat, True)
+    sims = oracle.iknn_build(ui, iu, 1.0e-6, save_nbrs)
+    return sps.csr_array(rmat), sims, np.asarray(means, dtype=np.float32).ravel()
+
+
+def _queries(csr, means, users, rng, with_null=True):
+    lens = np.diff(csr.indptr)[users]
+    ptr = np.zeros(len(users) + 1, np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    take = np.concatenate([np.arange(csr.indptr[u], csr.indptr[u + 1]) for u in users])
+    idx = csr.indices[take].astype(np.int32)
+    # history order as a query hands it over: NOT sorted by item (the accumulator's sums depend on it)
+    for q in range(len(users)):
+        seg = slice(ptr[q], ptr[q + 1])
+        p = rng.permutation(ptr[q + 1] - ptr[q])
+        idx[seg] = idx[seg][p]
+        take[seg] = take[seg][p]
+    val = (csr.data[take] - means[idx]).astype(np.float32)
+    if with_null and len(idx) > 10:
+        idx[5] = -1  # an unknown history item: skipped
+    return ptr, idx, val
+
+
+def _check(gi, gs, wi, ws, rows, ptr, idx):
+    assert np.array_equal(gs.view(np.uint32), ws.view(np.uint32))  # sorted score rows, bit for bit
+    ties = 0
+    for q in range(len(gi)):
+        g = gi[q][gi[q] >= 0]
+        assert len(g) == int((wi[q] >= 0).sum())
+        assert np.array_equal(rows[q][g].view(np.uint32), gs[q][: len(g)].view(np.uint32))
+        own = idx[ptr[q]:ptr[q + 1]]
+        assert not np.isin(g, own[own >= 0]).any()
+        assert len(np.unique(g)) == len(g)
+        if not np.array_equal(gi[q], wi[q]):
+            ties += 1
+    return ties
+
+
+@pytest.mark.parametrize("explicit", [True, False])
+@pytest.mark.parametrize("save_nbrs,max_nbrs,n", [(50, 20, 10), (None, 5, 100), (None, 64, 30)])
+def test_recommend_matches_the_reference_pipeline(gpu, oracle, explicit, save_nbrs, max_nbrs, n):
+    from lkpy_amd import _device as D
+
+    rng = np.random.default_rng(7)
+    n_users, n_items = 600, 9001  # three windows of 4096, the last one partial
+    csr, sims, means = _model(oracle, rng, n_users, n_items, 25, save_nbrs)
+    users = np.concatenate([[0, 1, 2], rng.choice(n_users, 120, replace=False)])
+    ptr, idx, val = _queries(csr, means, users, rng)
+    # one query without history
+    ptr = np.concatenate([ptr, [ptr[-1]]])
+    counts = np.diff(sims.indptr).astype(np.int64)
+    per = np.where(idx >= 0, counts[np.maximum(idx, 0)], 0)
+    cs = np.concatenate([[0], np.cumsum(per)])
+    hits = cs[ptr[1:]] - cs[ptr[:-1]]
+    dsims = D.DeviceCSR.from_arrays(sims.indptr.astype(np.int64), sims.indices, sims.data,
+                                    sims.shape, gpu)
+    gi, gs = D.iknn_recommend(dsims, _to(ptr, gpu), _to(idx, gpu),
+                              _to(val, gpu) if explicit else None,
+                              _to(means, gpu) if explicit else None, max_nbrs, 2, n, hits)
+    gi, gs = gi.cpu().numpy(), gs.cpu().numpy()
+    wi, ws, rows = oracle.iknn_recommend_batch(sims, ptr, idx, val if explicit else None,
+                                               means if explicit else None, max_nbrs, 2, n)
+    ties = _check(gi, gs, wi, ws, rows, ptr, idx)
+    assert (gi[-1] == -1).all() and np.isnan(gs[-1]).all()  # no history: an empty list
+    # the heap path (more than max_nbrs hits on a target) was exercised by the long histories
+    print(f"\nexplicit={explicit} save_nbrs={save_nbrs} max_nbrs={max_nbrs}: {len(gi)} queries, "
+          f"{int((gi >= 0).sum())} listed items, lists differing among equal scores: {ties}")
+    assert ties <= len(gi) // 4
+
+
+def test_recommend_through_the_scorer_and_batch_runner(gpu, oracle, ml_small):
+    """``ItemKNNScorer.recommend_batch`` / ``batch.recommend`` on ml-latest-small: the same lists
+    as one ``pipe.run('recommender')`` per user (the scorer's own per-query path), scores bit for
+    bit, and never a per-user pipeline run inside the batch call."""
+    from lkpy_amd import batch
+    from lkpy_amd.data import load_movielens_npz
+    from lkpy_amd.knn import ItemKNNScorer
+    from lkpy_amd.pipeline import topn_pipeline
+    from pathlib import Path
+
+    ds = load_movielens_npz(Path(__file__).parent / "golden" / "ml_small.npz")
+    scorer = ItemKNNScorer(max_nbrs=20, min_nbrs=2, save_nbrs=200)
+    pipe = topn_pipeline(scorer, predicts_ratings=True, n=10)
+    pipe.train(ds)
+    users = list(ds.users._ids[:40]) + [int(ds.users._ids[-1])]
+    calls = []
+    orig = pipe.run
+    pipe.run = lambda *a, **k: (calls.append(a), orig(*a, **k))[1]
+    got = batch.recommend(pipe, users, 10)
+    assert not calls, "batch.recommend must not fall back to one pipeline run per user"
+    pipe.run = orig
+    diff = 0
+    for u in users:
+        want = pipe.run("recommender", query=u, n=10)
+        g = got[u]
+        ws_, gs_ = np.asarray(want.scores(), np.float32), np.asarray(g.scores(), np.float32)
+        assert np.array_equal(ws_.view(np.uint32), gs_.view(np.uint32)), u
+        if not np.array_equal(want.numbers(vocabulary=scorer.items),
+                              g.numbers(vocabulary=scorer.items)):
+            diff += 1
+    assert diff <= 4  # equal-score items only (checked bit for bit above)
+
+
+def test_nan_similarity_is_the_reference_error(gpu):
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    sims = sps.csr_array(np.array([[0, np.nan, 0.5], [0.2, 0, 0.1], [0.5, 0.1, 0]], np.float32))
+    dsims = D.DeviceCSR.from_arrays(sims.indptr.astype(np.int64), sims.indices, sims.data,
+                                    sims.shape, gpu)
+    ptr = np.array([0, 2], np.int64)
+    idx = np.array([0, 1], np.int32)
+    with pytest.raises(ValueError, match="similarity is null"):
+        D.iknn_recommend(dsims, _to(ptr, gpu), _to(idx, gpu), None, None, 5, 1, 2,
+                         np.array([4], np.int64))
+    assert _native is not None

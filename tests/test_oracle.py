@@ -444,3 +444,39 @@ def test_batch_query_entry_points_equal_the_per_query_functions(oracle, rng):
         assert np.array_equal(np.isnan(bs[tp[q]:tp[q + 1]]), np.isnan(s1))
         ok = ~np.isnan(s1)
         assert np.array_equal(bs[tp[q]:tp[q + 1]][ok], s1[ok])
+
+
+def test_iknn_recommend_batch_is_the_per_query_pipeline(oracle):
+    """The recommend restatement = per query: ``iknn_score`` over the candidates (all items minus
+    the query's own), means added back, ``argtopn`` -- the pinned pieces, composed
+    (src/lenskit/knn/item.py:231-295, basic/candidates.py:77-94, basic/topn.py:45-69)."""
+    import scipy.sparse as sps
+
+    rng = np.random.default_rng(5)
+    n_users, n_items = 80, 300
+    lens = rng.integers(3, 40, n_users)
+    rows = np.repeat(np.arange(n_users), lens)
+    cols = np.concatenate([rng.choice(n_items, ln, replace=False) for ln in lens])
+    rmat = sps.coo_array((rng.integers(1, 11, len(rows)).astype(np.float32) * 0.5, (rows, cols)),
+                         shape=(n_users, n_items))
+    ui, iu, means, _ = oracle.iknn_prepare(rmat, True)
+    sims = oracle.iknn_build(ui, iu, 1.0e-6, None)
+    means = np.asarray(means, np.float32).ravel()
+    csr = sps.csr_array(rmat)
+    users = [0, 5, 9]
+    ptr = np.concatenate([[0], np.cumsum(np.diff(csr.indptr)[users])]).astype(np.int64)
+    idx = np.concatenate([csr.indices[csr.indptr[u]:csr.indptr[u + 1]] for u in users]).astype(np.int32)
+    val = np.concatenate([csr.data[csr.indptr[u]:csr.indptr[u + 1]] for u in users]) - means[idx]
+    wi, ws, full = oracle.iknn_recommend_batch(sims, ptr, idx, val.astype(np.float32), means,
+                                               10, 2, 7)
+    assert wi.shape == (3, 7) and full.shape == (3, n_items)
+    for q, u in enumerate(users):
+        own = idx[ptr[q]:ptr[q + 1]]
+        cand = np.setdiff1d(np.arange(n_items, dtype=np.int32), own)
+        sc, _cnt = oracle.iknn_score(sims, own, val[ptr[q]:ptr[q + 1]].astype(np.float32), cand,
+                                     10, 2)
+        sc = sc + means[cand]
+        top = oracle.argtopn(sc, 7)
+        assert np.array_equal(ws[q][: len(top)].view(np.uint32), sc[top].view(np.uint32))
+        assert np.array_equal(wi[q][: len(top)], cand[top])
+        assert not np.isin(wi[q][wi[q] >= 0], own).any()
