@@ -188,26 +188,30 @@ def pmc_traffic_per_epoch(pattern, anchor_kernel: str):
     return tot / (anchor / 2.0), files[-1].name
 
 
-def reference_order_recheck(backend, plan, this_dev, lo, hi, other_dev, reg, rows_new, want_rows):
+def reference_order_recheck(sub, other, otor, want_rows, k, dev):
     """
-    REPRODUCE exception rows instead of refereeing them: the same half-epoch once more with the
-    right-hand side summed in the reference's own order (``LK_ALS_RHS_ORDER=reference``,
-    csrc/als_rhs.hip: one sequential float32 chain per feature, implicit.rs:116-117) and the
-    listed rows against the oracle's.  ``this_dev`` is not modified.
+    REPRODUCE exception rows instead of refereeing them: the listed rows once more through a
+    REFERENCE-ORDER plan (``lk_als_plan_create_ex`` + rhs workspace: y as one sequential float32
+    chain per feature, the normal matrix in matrixmultiply's 256-entry blocks added in order --
+    src/accel/als/implicit.rs:110-117) from the very inputs the oracle had -- ``sub``: the rows'
+    CSR with the entries in the oracle's order, ``other``: the gathered factor matrix (host array
+    or padded device tensor, same labelling as ``sub``'s columns), ``otor``: the oracle's OtOr --
+    and compared with the oracle's rows.
     """
     import torch
 
-    plan.set_rhs_order("reference")
-    try:
-        tmp = this_dev.clone()
-        otor = backend.gramian(other_dev, reg)
-        backend.half_epoch(plan, tmp[lo:hi], other_dev, otor)
-        plan.check_status()
-        got = backend.download_rows(tmp, np.asarray(rows_new, dtype=np.int64))
-        del tmp
-    finally:
-        plan.set_rhs_order("accurate")
-    torch.cuda.synchronize()
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    csr = D.DeviceCSR.from_arrays(sub.indptr.astype(np.int64), sub.indices.astype(np.int32),
+                                  sub.data.astype(np.float32), sub.shape, dev)
+    plan = D.ALSPlan(csr, k, _native.SOLVER_CHOLESKY, reference_order=True)
+    d_other = other if isinstance(other, torch.Tensor) else D.to_device_padded(other, dev)
+    d_otor = torch.from_numpy(np.ascontiguousarray(otor, dtype=np.float32)).to(dev)
+    this = torch.zeros((sub.shape[0], plan.kp), dtype=torch.float32, device=dev)
+    plan.half_epoch(this, d_other, d_otor)
+    plan.check_status()
+    got = D.to_host_unpadded(this, k)
     num = np.linalg.norm(got.astype(np.float64) - want_rows, axis=1)
     den = np.linalg.norm(want_rows.astype(np.float64), axis=1)
     rel = num / np.maximum(den, 1e-300)
@@ -230,7 +234,6 @@ def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
     from oracle import parity
 
     P, Q = eng.user_embeddings(), eng.item_embeddings()
-    Q_before = eng.Q.clone()  # the user half's `other`, for the reference-order recheck
     eng.train_epoch()
     eng.check()
     P1, Q1 = eng.user_embeddings(), eng.item_embeddings()
@@ -258,19 +261,15 @@ def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
         acc = parity.als_half_accounting(got_, want, exact, cond)
         acc.pop("by_cond_decade", None)
         if acc.get("exceptions"):
-            # the rows over 1e-4, once more with the rhs in the reference's summation order
+            # the rows over 1e-4, once more through a reference-order plan: same rows, same entry
+            # order (the oracle's, i.e. the ORIGINAL labelling -- the engine relabels rows, and
+            # the order of a row's entries is part of the reference's arithmetic), same OtOr
             ex = np.array([e["row"] for e in acc["exceptions"]])
-            orig = ex if rows is None else rows[ex]
-            if name == "user":
-                acc["exceptions_in_reference_order"] = reference_order_recheck(
-                    eng.backend, eng.u_plan, eng.P, eng.u_lo, eng.u_hi, Q_before, reg,
-                    eng.u_new[orig], want[ex])
-            else:
-                acc["exceptions_in_reference_order"] = reference_order_recheck(
-                    eng.backend, eng.i_plan, eng.Q, eng.i_lo, eng.i_hi, eng.P, reg,
-                    eng.i_new[orig], want[ex])
+            for e in acc["exceptions"]:
+                e["entries"] = int(sub.indptr[e["row"] + 1] - sub.indptr[e["row"]])
+            acc["exceptions_in_reference_order"] = reference_order_recheck(
+                sps.csr_array(sub[ex]), other, otor, want[ex], k, eng.backend.dev)
         out[name] = acc
-    del Q_before
     exceptions = [dict(e, half=name) for name, o in out.items() for e in o.get("exceptions", [])]
     reco = [o["exceptions_in_reference_order"] for o in out.values()
             if "exceptions_in_reference_order" in o]
@@ -780,7 +779,8 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
             got = eng.backend.download(this_full[lo:hi][torch.from_numpy(rows).to(dev)])
             want = np.zeros_like(got)
             t0 = time.perf_counter()
-            lko.als_half_epoch(sub, want, other_h, lko.implicit_otor(other_h, otor_reg), threads)
+            otor_h = lko.implicit_otor(other_h, otor_reg)
+            lko.als_half_epoch(sub, want, other_h, otor_h, threads)
             dt = time.perf_counter() - t0
             exact, cond = lko.als_referee_f64(sub, other_h, otor_reg)
             acc = parity.als_half_accounting(got, want, exact, cond)
@@ -792,8 +792,7 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
                 for e in acc["exceptions"]:
                     e["entries"] = int(lens[e["row"]])
                 acc["exceptions_in_reference_order"] = reference_order_recheck(
-                    eng.backend, plan, this_full, lo, hi, other_full, otor_reg, lo + rows[ex],
-                    want[ex])
+                    sps.csr_array(sub[ex]), other_full, otor_h, want[ex], k, dev)
             cpu_s += dt
             cpu_fl += reference_half_flops(lens, k)
             desc.append(f"{name} half: {len(rows)} of {n_rows} rows ({sub.nnz} nnz, longest "

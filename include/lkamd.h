@@ -119,6 +119,18 @@ typedef struct lk_als_plan lk_als_plan;
 
 int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int indptr_is_64, int64_t n_rows,
                        int32_t k, int32_t solver);
+/* The same with flags.  LK_ALS_PLAN_REFERENCE_ORDER: strict reproduction of the reference's
+ * ARITHMETIC ORDER on long rows (exact solver only).  `mtl.dot(&o_picked)`
+ * (src/accel/als/implicit.rs:112) is matrixmultiply's sgemm, which sums the row's entries in
+ * blocks of KC = 256 -- one fma chain per block, the block sums added one after the other -- and
+ * `mt.dot(&vals)` (implicit.rs:117) is one sequential chain per feature.  Such a plan cuts every
+ * row of more than 256 entries into 256-entry chunks (one MFMA fmaf chain each), adds the chunk
+ * slabs in chunk order, OtOr last, and takes y from lk_als_plan_set_rhs_workspace (mandatory for
+ * it).  Slower and, on rows of 10^5+ entries, FURTHER from the exact solution than the default
+ * plan -- exactly as far as the reference is: tests/test_gpu_als_rhs_order.py. */
+#define LK_ALS_PLAN_REFERENCE_ORDER 1
+int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, int indptr_is_64,
+                          int64_t n_rows, int32_t k, int32_t solver, int32_t flags);
 void lk_als_plan_destroy(lk_als_plan *plan);
 /* Device workspace the half-epoch needs (bytes); allocate once, reuse. */
 size_t lk_als_plan_workspace_bytes(const lk_als_plan *plan);

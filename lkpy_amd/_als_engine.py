@@ -52,15 +52,22 @@ import torch.distributed as dist
 from . import _native
 
 
-def deal_rows(lengths: np.ndarray, world: int, slices: int = 1):
+def deal_rows(lengths: np.ndarray, world: int, slices: int = 1, keep_order: bool = False):
     """
     Relabelling of rows for ``world`` ranks: returns (new_of_old, old_of_new, rpr) with
     ``rpr`` rows per rank.  The j-th row dealt to ``rank`` goes to slice j % slices of that rank;
     with m = rpr / slices rows per (rank, slice) block, new index =
     slice * (world * m) + rank * m + j // slices -- for slices == 1: rank * rpr + j.
     Slots beyond the real rows (padding) have old_of_new == -1.
+    ``keep_order`` (one rank, one slice): the identity -- the strict reference-order mode, where
+    the ORDER OF A ROW'S ENTRIES (= ascending label of the other side) is part of the arithmetic
+    (the reference's sequential float32 sums run over it).
     """
     n = len(lengths)
+    if keep_order:
+        assert world == 1 and slices == 1
+        ident = np.arange(n, dtype=np.int64)
+        return ident, ident.copy(), n
     order = np.argsort(-lengths.astype(np.int64), kind="stable")
     rpr = (n + world - 1) // world
     m = (rpr + slices - 1) // slices
@@ -189,7 +196,7 @@ class LoopbackComm:
 class HipBackend:
     "The product backend: hand-written HIP kernels through the C ABI."
 
-    def __init__(self, k: int, dev, solver=_native.SOLVER_AUTO):
+    def __init__(self, k: int, dev, solver=_native.SOLVER_AUTO, reference_order=None):
         from . import _device as D
 
         self.D = D
@@ -197,11 +204,16 @@ class HipBackend:
         self.dev = D.device(dev)
         self.kp = D.padded_dim(k)
         self.solver = solver
+        # strict reproduction of the reference's summation order on long rows (INTEGRATION.md,
+        # LK_ALS_RHS_ORDER): None = what the process environment says
+        if reference_order is None:
+            reference_order = os.environ.get("LK_ALS_RHS_ORDER", "").lower() == "reference"
+        self.reference_order = bool(reference_order) and solver != _native.SOLVER_CG
         self._gram = D.Gramian(k, self.dev)
 
     def make_plan(self, local_csr: sps.csr_array):
         csr = self.D.DeviceCSR.from_scipy(local_csr, self.dev)
-        return self.D.ALSPlan(csr, self.k, self.solver)
+        return self.D.ALSPlan(csr, self.k, self.solver, reference_order=self.reference_order)
 
     def make_plans_on_device(self, ui, u_old, i_new, i_old, u_rng, i_rng, ilen=None):
         """
@@ -257,7 +269,7 @@ class HipBackend:
             view = D.DeviceCSR(full.indptr[lo : hi + 1], full.indices, full.values,
                                (hi - lo, n_cols), h_ptr[lo : hi + 1])
             view.full_h_indptr = h_ptr  # offsets of ALL rows (every rank holds the full arrays)
-            return D.ALSPlan(view, self.k, self.solver)
+            return D.ALSPlan(view, self.k, self.solver, reference_order=self.reference_order)
 
         def plans(full, h_ptr, rngs, n_cols):
             if isinstance(rngs, tuple):
@@ -385,8 +397,11 @@ class ImplicitALSEngine:
             S = 4 if (gathered >= (256 << 20)
                       and min(n_users, n_items) // self.world >= 4 * 1024) else 1
         self.slices = S
-        self.u_new, self.u_old, self.u_rpr = deal_rows(ulen, self.world, S)
-        self.i_new, self.i_old, self.i_rpr = deal_rows(ilen, self.world, S)
+        # strict reference order (LK_ALS_RHS_ORDER=reference on one rank): no relabelling -- the
+        # entries of a row then come in the reference's order, over which its float32 sums run
+        keep = bool(getattr(backend, "reference_order", False)) and self.world == 1 and S == 1
+        self.u_new, self.u_old, self.u_rpr = deal_rows(ulen, self.world, S, keep)
+        self.i_new, self.i_old, self.i_rpr = deal_rows(ilen, self.world, S, keep)
         nu, ni = self.world * self.u_rpr, self.world * self.i_rpr
 
         r, W = self.rank, self.world

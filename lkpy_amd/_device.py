@@ -234,17 +234,25 @@ class Gramian:
 class ALSPlan:
     "Row schedule + workspace of one CSR orientation (lk_als_plan)."
 
-    def __init__(self, csr: DeviceCSR, k: int, solver: int = _native.SOLVER_AUTO):
+    def __init__(self, csr: DeviceCSR, k: int, solver: int = _native.SOLVER_AUTO,
+                 reference_order: bool | None = None):
+        """``reference_order``: sum the normal matrix AND the right-hand side of long rows in the
+        reference's own order (lk_als_plan_create_ex, LK_ALS_PLAN_REFERENCE_ORDER + the rhs
+        workspace); None = what ``LK_ALS_RHS_ORDER`` says (``reference`` / default ``accurate``)."""
         lib = _native.require_gpu()
         self.csr = csr
         self.k = int(k)
         self.kp = padded_dim(k)
         self._h = ctypes.c_void_p(0)
         hp = csr.h_indptr
+        if reference_order is None:
+            reference_order = os.environ.get("LK_ALS_RHS_ORDER", "accurate").lower() == "reference"
+        self.reference_order = bool(reference_order) and int(solver) != _native.SOLVER_CG
         check(
-            lib.lk_als_plan_create(
+            lib.lk_als_plan_create_ex(
                 ctypes.byref(self._h), hp.ctypes.data_as(ctypes.c_void_p),
-                1 if hp.dtype == np.int64 else 0, csr.shape[0], self.k, int(solver)
+                1 if hp.dtype == np.int64 else 0, csr.shape[0], self.k, int(solver),
+                1 if self.reference_order else 0
             ),
             "lk_als_plan_create",
         )  # fmt: skip
@@ -273,7 +281,7 @@ class ALSPlan:
         self._z_leader = None  # another slice's plan whose Z this one uses (share_z_from)
         self._z_shared_set = False
         self._yref = None
-        if os.environ.get("LK_ALS_RHS_ORDER", "accurate").lower() == "reference":
+        if self.reference_order:
             self.set_rhs_order("reference")
 
     @property
@@ -298,6 +306,8 @@ class ALSPlan:
         """
         if order not in ("reference", "accurate"):
             raise ValueError(f"unknown right-hand-side order {order!r}")
+        if order == "accurate" and getattr(self, "reference_order", False):
+            raise ValueError("a reference-order plan cannot switch back: build another plan")
         if order == "reference" and self.solver != _native.SOLVER_CHOLESKY:
             return  # the CG option has no reference arithmetic to reproduce
         if order == "reference" and self._yref is None:

@@ -62,6 +62,8 @@ def _declare(lib):
         "lk_gramian_workspace_bytes": (c_size_t, [c_int32]),
         "lk_gramian": (c_int, [vp, c_int64, c_int32, c_int32, c_float, vp, c_int32, vp, vp]),
         "lk_als_plan_create": (c_int, [POINTER(vp), vp, c_int, c_int64, c_int32, c_int32]),
+        "lk_als_plan_create_ex": (c_int, [POINTER(vp), vp, c_int, c_int64, c_int32, c_int32,
+                                          c_int32]),
         "lk_als_plan_destroy": (None, [vp]),
         "lk_als_plan_workspace_bytes": (c_size_t, [vp]),
         "lk_als_plan_solver": (c_int32, [vp]),

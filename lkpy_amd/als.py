@@ -80,14 +80,12 @@ def _restore_scorer_state(obj, state: dict):
     obj.__dict__.update(state)
 
 
-def _apply_rhs_order(engine, options: TrainingOptions):
-    """``LK_ALS_RHS_ORDER`` through ``TrainingOptions.environment`` (the process environment is
-    read by the plans themselves): ``reference`` = the right-hand side summed exactly as the
-    reference does (environment knobs)."""
-    order = options.environment.get("LK_ALS_RHS_ORDER") if options is not None else None
-    if order:
-        engine.u_plan.set_rhs_order(order.lower())
-        engine.i_plan.set_rhs_order(order.lower())
+def _reference_order(options: TrainingOptions) -> bool | None:
+    """``LK_ALS_RHS_ORDER`` through ``TrainingOptions.environment`` (or the process environment):
+    ``reference`` = long rows summed exactly as the reference sums them (INTEGRATION.md,
+    environment knobs); None = not said here, the backend reads the process environment."""
+    order = options.env_var("LK_ALS_RHS_ORDER", None) if options is not None else None
+    return None if not order else order.lower() == "reference"
 
 
 class UIPair(BaseModel):
@@ -314,12 +312,11 @@ class ImplicitMFTrainer(ModelTrainer):
             ui = self.prepare_matrix(data)
             dev = D.device(None if options.configured_device() in ("cuda", "cpu") else
                            options.configured_device())
-            backend = HipBackend(k, dev, scorer._solver(options))
+            backend = HipBackend(k, dev, scorer._solver(options), _reference_order(options))
             self.engine = ImplicitALSEngine(sps.csr_array(ui), k, cfg.user_reg, cfg.item_reg,
                                             None, None, backend, defer_init=True)
         finally:
             th.join()
-        _apply_rhs_order(self.engine, options)
         scorer.item_embeddings, scorer.user_embeddings = init["Q"], init["P"]
         self.engine.set_initial(scorer.user_embeddings, scorer.item_embeddings)
         self.epochs_trained = 0
@@ -494,11 +491,10 @@ class BiasedMFTrainer(ModelTrainer):
         scorer.user_embeddings = self.initial_params(data.user_count, k)
         dev = D.device(None if options.configured_device() in ("cuda", "cpu") else
                        options.configured_device())
-        backend = HipBackend(k, dev, _native.SOLVER_CHOLESKY)
+        backend = HipBackend(k, dev, _native.SOLVER_CHOLESKY, _reference_order(options))
         self.engine = ImplicitALSEngine(sps.csr_array(ui), k, cfg.user_reg, cfg.item_reg,
                                         scorer.user_embeddings, scorer.item_embeddings, backend,
                                         explicit=True)
-        _apply_rhs_order(self.engine, options)
         self.epochs_trained = 0
 
     def prepare_matrix(self, data: Dataset) -> sps.coo_array:

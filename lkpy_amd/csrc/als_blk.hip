@@ -560,7 +560,7 @@ __device__ __forceinline__ void als_blk_solve_body(
     float *__restrict__ this_, const float *__restrict__ notor_p,
     const float *__restrict__ slabs, float *__restrict__ row_delta, int *__restrict__ status,
     int k, float reg, TaskCtlDev ctl, float *lds, const int64_t t,
-    const float *__restrict__ y_ref = nullptr)
+    const float *__restrict__ y_ref = nullptr, int chunk_rt = 0)
 {
     using C = Cfg<NT>;
     constexpr int KP = C::KP, NL = C::NL;
@@ -616,9 +616,12 @@ __device__ __forceinline__ void als_blk_solve_body(
     const int first_slab = row_slab[row];
     if (first_slab >= 0) {
         const int64_t n = end - beg;
-        const int ns = (int)((n + LK_ALS_CHUNK_BLK - 1) / LK_ALS_CHUNK_BLK);
+        // (reference-order plans: 256-entry chunks, all slabs of the row summed one after the
+        // other into its first slab -- see als_plan.h)
+        const int ch = chunk_rt > 0 ? chunk_rt : LK_ALS_CHUNK_BLK;
+        const int ns = (int)((n + ch - 1) / ch);
         // many chunks: the groups were pre-summed into their heads (slab_group_reduce_kernel)
-        const int step = ns > LK_ALS_SLAB_GROUP ? LK_ALS_SLAB_GROUP : 1;
+        const int step = chunk_rt > 0 ? ns : (ns > LK_ALS_SLAB_GROUP ? LK_ALS_SLAB_GROUP : 1);
         for (int s = 0; s < ns; s += step) {
             const float *slab =
                 slabs + (size_t)(first_slab + s) * C::SLAB + (size_t)wave * C::SLAB_WAVE;
@@ -729,13 +732,13 @@ __device__ __forceinline__ void als_blk_solve_body(
         const float *__restrict__ other, float *__restrict__ this_,                             \
         const float *__restrict__ notor_p, const float *__restrict__ slabs,                     \
         float *__restrict__ row_delta, int *__restrict__ status, int k, float reg,              \
-        TaskCtlDev ctl, const float *__restrict__ y_ref)                                        \
+        TaskCtlDev ctl, const float *__restrict__ y_ref, int chunk_rt)                          \
     {                                                                                           \
         __shared__ __attribute__((aligned(16))) float lds[Cfg<NTV>::LDS_FLOATS];                \
         als_blk_solve_body<NTV, IS64, EXPL, CTL>(indptr, indices, values, order, n_rows,        \
                                                  row_slab, other, this_, notor_p, slabs,        \
                                                  row_delta, status, k, reg, ctl, lds,           \
-                                                 (int64_t)blockIdx.x, y_ref);                   \
+                                                 (int64_t)blockIdx.x, y_ref, chunk_rt);         \
     }
 
 LK_BLK_KERNEL(als_blk_solve_kernel16, 16, LK_ALS_BLK_ATTR16)
@@ -805,6 +808,9 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     float *partial = reinterpret_cast<float *>(ws + p->off_partial);
     float *slabs = reinterpret_cast<float *>(ws + p->off_slabs);
 
+    LK_REQUIRE(!p->ref_order || (p->d_yref && !p->ctl),
+               "a reference-order ALS plan needs its rhs workspace (lk_als_plan_set_rhs_workspace) "
+               "and no task-control block");
     LK_HIP_CHECK(hipMemsetAsync(status, 0, 64, st));
     if (p->ctl) {
         LK_HIP_CHECK(hipMemsetAsync(row_delta, 0, (size_t)n_rows * sizeof(float), st));
@@ -877,7 +883,7 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     hipLaunchKernelGGL((KERN<IS64, EXPL, CTLV>), grid, block, 0, st, ip, indices, values,        \
                        p->d_order, n_dense, p->d_row_slab, other, this_, notor_p, slabs,         \
                        row_delta, status, k, reg, (CTLV) ? p->ctl->dev() : TaskCtlDev{},        \
-                       (CTLV) ? nullptr : p->d_yref)
+                       (CTLV) ? nullptr : p->d_yref, p->ref_order ? p->chunk : 0)
         if constexpr (NT == 16) {
             if (p->ctl)
                 LK_BLK_LAUNCH(als_blk_solve_kernel16, true);

@@ -933,7 +933,8 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     const int32_t *__restrict__ row_slab, const float *__restrict__ other, int ld_other,
     float *__restrict__ this_, int ld_this, const float *__restrict__ otor_p,
     const float *__restrict__ slabs, float *__restrict__ row_delta, int *__restrict__ status,
-    int k, float reg, TaskCtlDev ctl, const float *__restrict__ y_ref = nullptr)
+    int k, float reg, TaskCtlDev ctl, const float *__restrict__ y_ref = nullptr,
+    int chunk_rt = 0)
 {
     constexpr int KP = NT * 16;
     __shared__ __attribute__((aligned(16))) float lds_all[4][solve_lds_floats<NT>()];
@@ -983,9 +984,13 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     const int first_slab = row_slab[row];
     if (first_slab >= 0) {
         const int64_t n = end - beg;
-        const int ns = (int)((n + LK_ALS_CHUNK - 1) / LK_ALS_CHUNK);
+        // (reference-order plans, YREF only: 256-entry chunks whose slabs were summed one after
+        // the other into the row's first slab -- that one is added, after OtOr: a = otor + mtm)
+        const bool refo = YREF && chunk_rt > 0;
+        const int ch = refo ? chunk_rt : LK_ALS_CHUNK;
+        const int ns = (int)((n + ch - 1) / ch);
         // many chunks: the groups were pre-summed into their heads (slab_group_reduce_kernel)
-        const int step = ns > LK_ALS_SLAB_GROUP ? LK_ALS_SLAB_GROUP : 1;
+        const int step = refo ? ns : (ns > LK_ALS_SLAB_GROUP ? LK_ALS_SLAB_GROUP : 1);
         for (int s = 0; s < ns; s += step)
             slab_add<NT>(G, slabs + (size_t)(first_slab + s) * slab_floats<NT>());
     } else {
@@ -1407,6 +1412,9 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
     float *partial = reinterpret_cast<float *>(ws + p->off_partial);
     float *slabs = reinterpret_cast<float *>(ws + p->off_slabs);
 
+    LK_REQUIRE(!p->ref_order || (p->d_yref && !p->ctl),
+               "a reference-order ALS plan needs its rhs workspace (lk_als_plan_set_rhs_workspace) "
+               "and no task-control block");
     LK_HIP_CHECK(hipMemsetAsync(status, 0, 64, st));
     if (p->ctl) {
         // a cancelled half-epoch leaves the rows not yet started untouched; their deltas
@@ -1440,7 +1448,8 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
                                dim3((unsigned)((n_solve + 3) / 4)), dim3(256), 0, st,
                                static_cast<const IT *>(indptr), indices, values, p->d_order,
                                n_solve, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
-                               slabs, row_delta, status, k, reg, TaskCtlDev{}, p->d_yref);
+                               slabs, row_delta, status, k, reg, TaskCtlDev{}, p->d_yref,
+                               p->ref_order ? p->chunk : 0);
         } else if (p->ctl)
             hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, true>),
                                dim3((unsigned)((n_solve + 3) / 4)), dim3(256), 0, st,
@@ -1527,10 +1536,20 @@ static int upload(T **dst, const std::vector<T> &src)
     return LK_OK;
 }
 
+extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, int indptr_is_64,
+                                     int64_t n_rows, int32_t k, int32_t solver, int32_t flags);
+
 extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int indptr_is_64,
                                   int64_t n_rows, int32_t k, int32_t solver)
 {
+    return lk_als_plan_create_ex(out, h_indptr, indptr_is_64, n_rows, k, solver, 0);
+}
+
+extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, int indptr_is_64,
+                                     int64_t n_rows, int32_t k, int32_t solver, int32_t flags)
+{
     LK_REQUIRE(out != nullptr && h_indptr != nullptr, "lk_als_plan_create: null pointer");
+    LK_REQUIRE((flags & ~LK_ALS_PLAN_REFERENCE_ORDER) == 0, "lk_als_plan_create_ex: unknown flags");
     LK_REQUIRE(n_rows >= 0 && n_rows < (int64_t)INT32_MAX, "lk_als_plan_create: bad n_rows");
     int KP = lk_padded_dim(k);
     LK_REQUIRE(KP > 0, "lk_als_plan_create: unsupported embedding size k=%d (1..256)", k);
@@ -1549,6 +1568,17 @@ extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int i
     p->solver = solver;
     p->is64 = indptr_is_64 ? 1 : 0;
     p->cg_max_iter = 0;
+    if (flags & LK_ALS_PLAN_REFERENCE_ORDER) {
+        if (solver != LK_SOLVER_CHOLESKY) {
+            delete p;
+            lk::set_error("lk_als_plan_create_ex: reference order belongs to the exact solver");
+            return LK_E_INVALID;
+        }
+        p->ref_order = true;
+        p->chunk = 256;     // matrixmultiply's KC (oracle/lk_oracle.c: LKO_SGEMM_KC)
+        p->long_row = 256;  // every row the reference sums in more than one block
+    }
+    const int64_t CHUNK = p->chunk, LONG_ROW = p->long_row;
 
     auto len = [&](int64_t r) -> int64_t {
         if (indptr_is_64) {
@@ -1617,12 +1647,12 @@ extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int i
     {  // (CG plans too: their chunked rows are solved by the exact kernels, als_cg.hip)
         for (int64_t r = 0; r < n_rows; ++r) {
             int64_t n = len(r);
-            if (n > LK_ALS_LONG_ROW) {
+            if (n > LONG_ROW) {
                 row_slab[(size_t)r] = (int32_t)chunk_row.size();
-                for (int64_t o = 0; o < n; o += LK_ALS_CHUNK) {
+                for (int64_t o = 0; o < n; o += CHUNK) {
                     chunk_row.push_back((int32_t)r);
                     chunk_beg.push_back(start(r) + o);
-                    chunk_len.push_back((int32_t)std::min<int64_t>(LK_ALS_CHUNK, n - o));
+                    chunk_len.push_back((int32_t)std::min<int64_t>(CHUNK, n - o));
                 }
                 p->n_long++;
             }
@@ -1633,7 +1663,12 @@ extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int i
     std::vector<int32_t> grp_head, grp_cnt;
     for (int64_t r = 0; r < n_rows; ++r) {
         if (row_slab[(size_t)r] < 0) continue;
-        const int64_t ns = (len(r) + LK_ALS_CHUNK - 1) / LK_ALS_CHUNK;
+        const int64_t ns = (len(r) + CHUNK - 1) / CHUNK;
+        if (p->ref_order) {  // ONE group per row: head += every other slab, in chunk order
+            grp_head.push_back(row_slab[(size_t)r]);
+            grp_cnt.push_back((int32_t)ns);
+            continue;
+        }
         if (ns <= LK_ALS_SLAB_GROUP) continue;
         for (int64_t s0 = 0; s0 < ns; s0 += LK_ALS_SLAB_GROUP) {
             const int64_t c = std::min<int64_t>(LK_ALS_SLAB_GROUP, ns - s0);

@@ -50,6 +50,14 @@ struct lk_als_plan {
     // the right-hand side y in the REFERENCE's order (als_rhs.hip: one sequential float32 chain
     // per feature, implicit.rs:116-117) and the dense solve kernels take it from there
     float *d_yref = nullptr;
+    // LK_ALS_PLAN_REFERENCE_ORDER (lk_als_plan_create_ex): the normal matrix is summed in the
+    // reference's order as well -- matrixmultiply's KC = 256 blocks (lk_oracle.c, lko_gram_mtl_m):
+    // every row with more than 256 entries is cut into 256-entry chunks, each chunk one MFMA fmaf
+    // chain from zero, the chunk slabs added ONE AFTER THE OTHER in chunk order (one slab group
+    // per row), OtOr added last.  Such a plan needs the rhs workspace (d_yref) to run.
+    bool ref_order = false;
+    int32_t chunk = LK_ALS_CHUNK;        // CSR entries per chunk of a long row
+    int32_t long_row = LK_ALS_LONG_ROW;  // rows longer than this are chunked
     size_t off_ginv = 0, off_invws = 0;  // [KP x KP] float inverse, spd_inverse scratch
     // device-side schedule
     int32_t *d_order = nullptr;      // [n_rows] rows, longest first

@@ -30,7 +30,7 @@
 //    iknn_score.hip on a per-lane scratch; the score (+ item mean) replaces the cursor in LDS and
 //    the window leaves as one coalesced row segment of the score panel (NaN where nothing was
 //    scored: no panel memset).
-//  Segments of <= 64 entries (row x window) are loaded D = 8 ahead of their use.
+//  Segments of <= 64 entries (row x window) are loaded 16 at a time, ahead of their use.
 //
 // The panel rows then lose the query's own items (NaN) and go through the dense path's selection
 // (`row_topn_kernel` / full sort of topk.hip): n largest non-NaN, descending, ties by lower item.
@@ -56,7 +56,7 @@ namespace rec {
 constexpr int RW = 4096;        // targets per window = per wave
 constexpr int RWAVES = 4;       // waves per workgroup (each on its own window task)
 constexpr int RTHREADS = RWAVES * 64;
-constexpr int RD = 8;           // segments in flight per wave
+constexpr int RD = 16;          // segments in flight per wave
 constexpr int RPAD = RW + RW / 64;  // cursor array: index t + (t >> 6) (conflict-free lane-owned runs)
 
 __device__ __forceinline__ int cidx(int t) { return t + (t >> 6); }
@@ -173,24 +173,32 @@ __device__ __forceinline__ void walk(unsigned *__restrict__ c, const int64_t *__
         float s_[RD], r_[RD];
 #pragma unroll
         for (int d = 0; d < RD; ++d) cnt_[d] = 0;
+        // (every load UNCONDITIONAL: a load inside a branch makes hipcc drain the whole memory
+        // queue before it; a slot issued past the end re-reads the last row's first entry and is
+        // marked empty)
         auto issue = [&](int d) {
-            const int cn = nj - base < 64 ? nj - base : 64;
-            const int64_t e = aj + base + (lane < cn ? lane : cn - 1);  // unconditional load
+            const int left = more ? nj - base : 0;
+            const int cn = left < 64 ? left : 64;
+            const int off = more ? base + (lane < cn ? lane : cn - 1) : 0;
+            const int64_t e = aj + off;
             t_[d] = s_idx[e] - w0;
             if (FILL) s_[d] = s_val[e];
             r_[d] = rj;
             cnt_[d] = cn;
-            base += 64;
-            if (base >= nj) {
-                mask &= mask - 1;
-                if (mask) {
-                    j = __builtin_ctzll(mask);
-                    nj = __builtin_amdgcn_readlane(n, j);
-                    aj = readlane64(a, j);
-                    rj = bcast(rate, j);
-                    base = 0;
-                } else {
-                    more = false;
+            if (more) {  // wave-uniform cursor update (no memory operation inside)
+                base += 64;
+                if (base >= nj) {
+                    mask &= mask - 1;
+                    if (mask) {
+                        j = __builtin_ctzll(mask);
+                        nj = __builtin_amdgcn_readlane(n, j);
+                        aj = readlane64(a, j);
+                        rj = bcast(rate, j);
+                        base = 0;
+                    } else {
+                        more = false;
+                        base = 0;
+                    }
                 }
             }
         };
@@ -206,20 +214,16 @@ __device__ __forceinline__ void walk(unsigned *__restrict__ c, const int64_t *__
             }
             cnt_[d] = 0;
         };
+        // batches of RD segments: all loads of a batch are issued back to back, then consumed in
+        // order -- one memory latency per RD segments.  (A rolling ring, re-issuing a slot right
+        // after it is consumed, makes hipcc wait for ALL outstanding loads -- vmcnt(0) -- at every
+        // consume, i.e. one full latency per segment: 26 ms instead of 3 for the cfg3 batch.)
+        while (more) {
 #pragma unroll
-        for (int d = 0; d < RD; ++d)
-            if (more) issue(d);
-        for (;;) {
-            bool any = false;
+            for (int d = 0; d < RD; ++d) issue(d);
 #pragma unroll
-            for (int d = 0; d < RD; ++d) {
-                if (cnt_[d] > 0) {  // wave-uniform
-                    consume(d);
-                    any = true;
-                    if (more) issue(d);
-                }
-            }
-            if (!any) break;
+            for (int d = 0; d < RD; ++d)
+                if (cnt_[d] > 0) consume(d);  // wave-uniform
         }
     }
 }
