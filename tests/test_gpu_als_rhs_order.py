@@ -111,8 +111,9 @@ def test_reference_order_reproduces_the_long_row(gpu, oracle, k):
         full.set_rhs_order("accurate")
 
     lens = np.diff(mat.indptr)
-    dense_min = 64 if k > 64 else 0
-    rows = np.flatnonzero(lens > dense_min)  # the rows the dense kernels solve
+    # (48 rows: far below LK_ALS_WB_MIN_ROWS, so the dense kernels solve every row at every k)
+    dense_min = 0
+    rows = np.flatnonzero(lens > dense_min)
     # (1) y: bit for bit the reference's chain, on the long, a chunked and a plain row
     for r in (0, 2, 4, 7):
         s, e = mat.indptr[r], mat.indptr[r + 1]
@@ -136,11 +137,8 @@ def test_reference_order_reproduces_the_long_row(gpu, oracle, k):
     # (3) the reference-order plan reproduces the reference on EVERY row (raw 1e-4 criterion)
     assert e_ref.max() < RTOL, (k, e_ref.max())
     assert e_rhs[0] < e_acc[0]
-    # (4) short rows (Woodbury path at k > 64) are untouched by the mode; the empty row stays zero
-    short = np.flatnonzero(lens <= dense_min)
-    assert np.array_equal(got_rhs[short], got_acc[short])
-    assert np.array_equal(got_ref[short], got_acc[short])
-    assert not got_ref[6].any()
+    # (4) the empty row stays zero in every mode
+    assert not got_ref[6].any() and not got_rhs[6].any() and not got_acc[6].any()
 
 
 def test_reference_order_explicit_model(gpu, oracle):
