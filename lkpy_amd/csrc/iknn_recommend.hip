@@ -303,17 +303,21 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
         }
         // the window's share of the query's hit region
         unsigned long long hb = 0;
-        if (lane == 0) hb = q_hit_base[ql] + atomicAdd(&q_cursor[ql], (unsigned long long)total);
+        // (128-byte granules: no cache line is shared between the lists of two waves)
+        if (lane == 0)
+            hb = q_hit_base[ql] +
+                 atomicAdd(&q_cursor[ql], (unsigned long long)((total + 15u) & ~15u));
         hb = (unsigned long long)readlane64((int64_t)hb, 0);
         float2 *lists = hits + hb;
 
         // ---- pass 2: the hits, each at its target's cursor (history order by construction) ----
         walk<true, EXPL>(c, s_ptr, s_idx, s_val, woff, nwin, win, n_items, ref_items, ref_rates,
                          rb, re, lists, status, lane);
-        // the lists were written by OTHER lanes of this wave: complete the stores (write-through
-        // to L2) and drop whatever stale lines this CU's L1 may hold of the region
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // the lists were written by OTHER lanes of this wave: complete the stores before they are
+        // read.  WORKGROUP scope -- writer and reader share the CU's L1; an agent-scope release
+        // is a `buffer_wbl2` (write back the XCD's whole L2) per task: 15 ms of a 22 ms call
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
         // ---- pass 3: scores.  After the fill c[t] = END of t's list = start of t + 1's ----------
         unsigned beg = lane == 0 ? 0u : c[(lane - 1) * 65 + 63];
@@ -397,11 +401,12 @@ static Layout layout(int64_t n_items, int64_t n_queries, int64_t max_query_hits,
     L.rows = n_queries < REC_PANEL_ROWS ? (n_queries > 0 ? n_queries : 1) : REC_PANEL_ROWS;
     // a batch holds up to REC_HITS_MIN hits (never less than the heaviest query's; a small call
     // does not pay for more than all of its queries could need)
+    // (a query's region = its hits + 16 per window: every window's share is rounded up to a
+    // 128-byte granule)
+    const int64_t per_q = max_query_hits + 16 * (int64_t)nwindows(n_items);
     int64_t cap = REC_HITS_MIN;
-    if (max_query_hits > 0 && n_queries > 0 && cap / max_query_hits >= n_queries)
-        cap = max_query_hits * n_queries;
-    L.hit_cap = max_query_hits > cap ? max_query_hits : cap;
-    if (L.hit_cap < 64) L.hit_cap = 64;
+    if (n_queries > 0 && cap / per_q >= n_queries) cap = per_q * n_queries;
+    L.hit_cap = per_q > cap ? per_q : cap;
     size_t off = 0;
     L.off_status = off;
     off += 256;
@@ -474,8 +479,10 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
     {
         int64_t acc = 0, rows = 0;
         for (int64_t q = 0; q < n_queries; ++q) {
-            const int64_t h = h_query_hits[q];
-            LK_REQUIRE(h >= 0 && h <= L.hit_cap,
+            LK_REQUIRE(h_query_hits[q] >= 0, "lk_iknn_recommend: negative hit count");
+            // (+ the rounding of every window's share to a 128-byte granule)
+            const int64_t h = h_query_hits[q] + 16 * (int64_t)nwin;
+            LK_REQUIRE(h <= L.hit_cap,
                        "lk_iknn_recommend: query %lld has %lld hits, more than max_query_hits",
                        (long long)q, (long long)h);
             if (rows == L.rows || acc + h > L.hit_cap) {
