@@ -61,6 +61,28 @@ constexpr int RPAD = RW + RW / 64;  // cursor array: index t + (t >> 6) (conflic
 
 __device__ __forceinline__ int cidx(int t) { return t + (t >> 6); }
 
+#ifdef LK_REC_PHASES
+// Diagnostic build only (tools/knnrec_phases.py): shader-clock cycles per phase summed over all
+// wave tasks -- [0] task set-up, [1] zero, [2] count walk, [3] scan + region, [4] fill walk,
+// [5] score sweep, [6] copy-out, [7] tasks
+__device__ unsigned long long *lk_rec_phase_buf;
+#define LK_RP_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define LK_RP_ADD(i, a, b) ph[i] += (b) - (a)
+#else
+#define LK_RP_T(var)
+#define LK_RP_ADD(i, a, b)
+#endif
+
+// a target with more than max_nbrs hits: its accumulator is the reference's BinaryHeap replay --
+// a long chain of dependent reads and writes of the heap array.  On a per-lane scratch in HBM
+// that chain is ~10 k memory latencies for a 780-hit target: 12 of the 13 ms of the heaviest
+// cfg3 batch.  The sweep therefore only QUEUES such targets; iknn_heap_replay_kernel replays
+// them, one lane per target, on heaps in LDS.
+struct OvfEntry {
+    int ql, item, cnt, pad;
+    unsigned long long list;  // offset of the target's hit list in the hits buffer
+};
+
 __device__ __forceinline__ int64_t readlane64(int64_t v, int l)
 {
     const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l);
@@ -238,9 +260,13 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
     const float *__restrict__ item_bias, int max_nbrs, int min_nbrs, float2 *__restrict__ hits,
     const int64_t *__restrict__ q_hit_base, unsigned long long *__restrict__ q_cursor,
     float *__restrict__ panel, int64_t ld, float *__restrict__ heap_scratch,
-    int *__restrict__ task_counter, int *__restrict__ status)
+    int *__restrict__ task_counter, int *__restrict__ status, OvfEntry *__restrict__ ovf,
+    int ovf_cap, int *__restrict__ ovf_count)
 {
     __shared__ unsigned cur[RWAVES][RPAD];
+#ifdef LK_REC_PHASES
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned *c = cur[wave];
@@ -251,6 +277,7 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
     const float nanf_ = __builtin_nanf("");
 
     for (;;) {
+        LK_RP_T(p0);
         int task = 0;
         if (lane == 0) task = atomicAdd(task_counter, 1);
         task = __builtin_amdgcn_readfirstlane(task);
@@ -266,11 +293,14 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
             for (int i = lane; i < wn; i += 64) prow[i] = nanf_;
             continue;
         }
+        LK_RP_T(p1);
         for (int i = lane; i < RPAD; i += 64) c[i] = 0u;
+        LK_RP_T(p2);
 
         // ---- pass 1: hits per target ----------------------------------------------------
         walk<false, EXPL>(c, s_ptr, s_idx, s_val, woff, nwin, win, n_items, ref_items, ref_rates,
                           rb, re, nullptr, status, lane);
+        LK_RP_T(p3);
 
         // ---- counts -> list offsets: lane l owns targets 64 l .. 64 l + 63 --------------------
         unsigned run = 0;
@@ -309,10 +339,12 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
                  atomicAdd(&q_cursor[ql], (unsigned long long)((total + 15u) & ~15u));
         hb = (unsigned long long)readlane64((int64_t)hb, 0);
         float2 *lists = hits + hb;
+        LK_RP_T(p4);
 
         // ---- pass 2: the hits, each at its target's cursor (history order by construction) ----
         walk<true, EXPL>(c, s_ptr, s_idx, s_val, woff, nwin, win, n_items, ref_items, ref_rates,
                          rb, re, lists, status, lane);
+        LK_RP_T(p5);
         // the lists were written by OTHER lanes of this wave: complete the stores before they are
         // read.  WORKGROUP scope -- writer and reader share the CU's L1; an agent-scope release
         // is a `buffer_wbl2` (write back the XCD's whole L2) per task: 15 ms of a 22 ms call
@@ -330,13 +362,38 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
             if (cnt > 0 && kept >= min_nbrs && t < wn) {
                 float tw = 0.f, ws = 0.f;
                 const float2 *l = lists + beg;
-                if (cnt <= max_nbrs) {  // Partial(vec): sums in insertion order
-                    for (int x = 0; x < cnt; ++x) {
+                bool queued = false;
+                if (cnt > max_nbrs && ovf != nullptr) {
+                    // Full(heap): left to iknn_heap_replay_kernel (LDS heaps) when the queue has room
+                    const int slot = atomicAdd(ovf_count, 1);
+                    if (slot < ovf_cap) {
+                        ovf[slot] = OvfEntry{(int)ql, w0 + t, cnt, 0, hb + beg};
+                        queued = true;
+                    }
+                }
+                if (queued) {
+                    // (the panel cell is written by the replay kernel; NaN until then)
+                } else if (cnt <= max_nbrs) {  // Partial(vec): sums in insertion order
+                    int x = 0;
+                    for (; x + 4 <= cnt; x += 4) {  // four independent loads, summed in order
+                        const float2 h0 = l[x], h1 = l[x + 1], h2 = l[x + 2], h3 = l[x + 3];
+                        tw += h0.x;
+                        tw += h1.x;
+                        tw += h2.x;
+                        tw += h3.x;
+                        if (EXPL) {
+                            ws += h0.x * h0.y;
+                            ws += h1.x * h1.y;
+                            ws += h2.x * h2.y;
+                            ws += h3.x * h3.y;
+                        }
+                    }
+                    for (; x < cnt; ++x) {
                         const float2 h = l[x];
                         tw += h.x;
                         if (EXPL) ws += h.x * h.y;
                     }
-                } else {  // Full(heap): accum.rs:76-83,100-117
+                } else {  // Full(heap) on the per-lane HBM scratch (queue full / no queue)
                     for (int x = 0; x < max_nbrs; ++x) {  // vec.pop() from the back, push each
                         const float2 h = l[max_nbrs - 1 - x];
                         hw[x] = h.x;
@@ -356,15 +413,112 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
                         if (EXPL) ws += hw[x] * hv[x];
                     }
                 }
-                score = EXPL ? ws / tw : tw;
-                if (item_bias) score = score + item_bias[w0 + t];  // item.py:282 (f32 add)
+                if (!queued) {
+                    score = EXPL ? ws / tw : tw;
+                    if (item_bias) score = score + item_bias[w0 + t];  // item.py:282 (f32 add)
+                }
             }
             c[lane * 65 + i] = __builtin_bit_cast(unsigned, score);
             beg = end;
         }
+        LK_RP_T(p6);
         // ---- the window's segment of the panel row, coalesced -----------------------------------
         for (int i = lane; i < wn; i += 64) prow[i] = __builtin_bit_cast(float, c[cidx(i)]);
+        LK_RP_T(p7);
+        LK_RP_ADD(0, p0, p1);
+        LK_RP_ADD(1, p1, p2);
+        LK_RP_ADD(2, p2, p3);
+        LK_RP_ADD(3, p3, p4);
+        LK_RP_ADD(4, p4, p5);
+        LK_RP_ADD(5, p5, p6);
+        LK_RP_ADD(6, p6, p7);
+#ifdef LK_REC_PHASES
+        ph[7] += 1;
+#endif
     }
+#ifdef LK_REC_PHASES
+    if (lane == 0 && lk_rec_phase_buf)
+        for (int i = 0; i < 8; ++i) atomicAdd(&lk_rec_phase_buf[i], ph[i]);
+#endif
+}
+
+// One LANE per queued target: the reference's accumulator replayed on a heap in LDS (slot-major:
+// hw[slot * 64 + lane]), the hit list streamed from the hits buffer.  Writes the panel cell.
+template <bool EXPL>
+__global__ __launch_bounds__(64) void iknn_heap_replay_kernel(
+    const OvfEntry *__restrict__ ovf, const int *__restrict__ ovf_count, int ovf_cap,
+    const float2 *__restrict__ hits, const float *__restrict__ item_bias, int max_nbrs,
+    float *__restrict__ panel, int64_t ld)
+{
+    extern __shared__ float heap_lds[];  // [2][(max_nbrs + 1)][64]
+    int n = *ovf_count;
+    if (n > ovf_cap) n = ovf_cap;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const int lane = threadIdx.x;
+    const OvfEntry e = ovf[i];
+    const float2 *l = hits + e.list;
+    float *hw = heap_lds + lane, *hv = heap_lds + (size_t)(max_nbrs + 1) * 64 + lane;
+    auto W = [&](int s) -> float & { return hw[s * 64]; };
+    auto V = [&](int s) -> float & { return hv[s * 64]; };
+    auto sift_up = [&](int pos, float ew, float ev) {
+        while (pos > 0) {
+            const int parent = (pos - 1) >> 1;
+            if (ew >= W(parent)) break;
+            W(pos) = W(parent);
+            V(pos) = V(parent);
+            pos = parent;
+        }
+        W(pos) = ew;
+        V(pos) = ev;
+    };
+    // Partial -> Full (accum.rs:76-83): vec.pop() from the back, push each
+    for (int x = 0; x < max_nbrs; ++x) {
+        const float2 h = l[max_nbrs - 1 - x];
+        W(x) = h.x;
+        V(x) = h.y;
+    }
+    for (int kk = 1; kk < max_nbrs; ++kk) sift_up(kk, W(kk), V(kk));
+    float wmin = W(0);
+    for (int x0 = max_nbrs; x0 < e.cnt; x0 += 4) {
+        float2 h[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) h[u] = l[x0 + u < e.cnt ? x0 + u : e.cnt - 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (x0 + u < e.cnt && h[u].x > wmin) {  // strictly greater than the minimum
+                // push (sift_up(0, len)), then pop: swap the last element into the root,
+                // sift_down_to_bottom(0), sift_up -- std's BinaryHeap, as in iknn_score.hip
+                sift_up(max_nbrs, h[u].x, h[u].y);
+                const float ew = W(max_nbrs), ev = V(max_nbrs);
+                const int end = max_nbrs;
+                int pos = 0, child = 1;
+                const int limit = end >= 2 ? end - 2 : 0;
+                while (child <= limit && end >= 2) {
+                    if (W(child) >= W(child + 1)) child += 1;
+                    W(pos) = W(child);
+                    V(pos) = V(child);
+                    pos = child;
+                    child = 2 * pos + 1;
+                }
+                if (child == end - 1) {
+                    W(pos) = W(child);
+                    V(pos) = V(child);
+                    pos = child;
+                }
+                sift_up(pos, ew, ev);
+                wmin = W(0);
+            }
+        }
+    }
+    float tw = 0.f, ws = 0.f;
+    for (int x = 0; x < max_nbrs; ++x) {
+        tw += W(x);
+        if (EXPL) ws += W(x) * V(x);
+    }
+    float score = EXPL ? ws / tw : tw;
+    if (item_bias) score = score + item_bias[e.item];
+    panel[(int64_t)e.ql * ld + e.item] = score;
 }
 
 // panel[q][own item] = NaN (candidates = all items minus the query's, candidates.py:77-94)
@@ -390,9 +544,11 @@ static inline int64_t ld_items(int64_t n_items) { return (n_items + 63) / 64 * 6
 static inline int nwindows(int64_t n_items) { return (int)((n_items + RW - 1) / RW); }
 
 struct Layout {
-    size_t off_status, off_woff, off_base, off_cursor, off_heap, off_panel, off_hits, off_sort, bytes;
+    size_t off_status, off_woff, off_base, off_cursor, off_heap, off_ovf, off_panel, off_hits,
+        off_sort, bytes;
     int64_t rows, hit_cap;
 };
+constexpr int REC_OVF_CAP = 1 << 20;  // queued heap targets per batch (more: HBM-scratch path)
 
 static Layout layout(int64_t n_items, int64_t n_queries, int64_t max_query_hits, int32_t max_nbrs,
                      int32_t n)
@@ -419,6 +575,8 @@ static Layout layout(int64_t n_items, int64_t n_queries, int64_t max_query_hits,
     L.off_heap = off;
     off += align_up((size_t)REC_MAX_WGS * RWAVES * 64 * (size_t)(max_nbrs + 1) * 2 * sizeof(float),
                     256);
+    L.off_ovf = off;
+    off += align_up((size_t)REC_OVF_CAP * sizeof(OvfEntry), 256);
     L.off_panel = off;
     off += align_up((size_t)L.rows * ld_items(n_items) * sizeof(float), 256);
     L.off_hits = off;
@@ -431,6 +589,14 @@ static Layout layout(int64_t n_items, int64_t n_queries, int64_t max_query_hits,
 
 }  // namespace rec
 }  // namespace lk
+
+#ifdef LK_REC_PHASES
+extern "C" int lk_rec_phase_set(unsigned long long *d_buf)
+{
+    LK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(lk::rec::lk_rec_phase_buf), &d_buf, sizeof(d_buf)));
+    return LK_OK;
+}
+#endif
 
 extern "C" size_t lk_iknn_recommend_workspace_bytes(int64_t n_items, int64_t n_queries,
                                                     int64_t max_query_hits, int32_t max_nbrs,
@@ -468,6 +634,10 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
     float *heap = reinterpret_cast<float *>(ws + L.off_heap);
     float *panel = reinterpret_cast<float *>(ws + L.off_panel);
     float2 *hits = reinterpret_cast<float2 *>(ws + L.off_hits);
+    OvfEntry *ovf = reinterpret_cast<OvfEntry *>(ws + L.off_ovf);
+    // heaps of one replay workgroup in LDS; beyond 64 KiB (max_nbrs > 127) up to the CU's 160
+    const size_t heap_lds = (size_t)(max_nbrs + 1) * 64 * 2 * sizeof(float);
+    const bool lds_replay = heap_lds <= 150 * 1024;
     void *sort_ws = ws + L.off_sort;
     const int nwin = nwindows(n_items);
     const int64_t ld = ld_items(n_items);
@@ -510,7 +680,7 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
         const int64_t q0 = cuts[b], nq = cuts[b + 1] - cuts[b];
         if (nq <= 0) continue;
         if (n_items > 0) {
-            LK_HIP_CHECK(hipMemsetAsync(status + 1, 0, sizeof(int), st));
+            LK_HIP_CHECK(hipMemsetAsync(status + 1, 0, 2 * sizeof(int), st));  // tasks, queue
             const int64_t tasks = nq * nwin;
             int64_t wgs = (tasks + RWAVES - 1) / RWAVES;
             if (wgs > REC_MAX_WGS) wgs = REC_MAX_WGS;
@@ -518,7 +688,20 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
     hipLaunchKernelGGL((iknn_score_all_kernel<EXPLV>), dim3((unsigned)wgs), dim3(RTHREADS), 0, st, \
                        d_sim_indptr, d_sim_indices, d_sim_values, n_items, nwin, woff, q0, nq,    \
                        d_ref_ptr, d_ref_items, d_ref_rates, d_item_bias, max_nbrs, min_nbrs, hits, \
-                       q_base + q0, q_cursor + q0, panel, ld, heap, status + 1, status)
+                       q_base + q0, q_cursor + q0, panel, ld, heap, status + 1, status,            \
+                       lds_replay ? ovf : nullptr, REC_OVF_CAP, status + 2);                       \
+    if (lds_replay)                                                                               \
+    hipLaunchKernelGGL((iknn_heap_replay_kernel<EXPLV>), dim3(REC_OVF_CAP / 64), dim3(64),         \
+                       heap_lds, st, ovf, status + 2, REC_OVF_CAP, hits, d_item_bias, max_nbrs,    \
+                       panel, ld)
+            if (lds_replay && heap_lds > 64 * 1024) {
+                LK_HIP_CHECK(hipFuncSetAttribute(
+                    reinterpret_cast<const void *>(&iknn_heap_replay_kernel<true>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds));
+                LK_HIP_CHECK(hipFuncSetAttribute(
+                    reinterpret_cast<const void *>(&iknn_heap_replay_kernel<false>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds));
+            }
             if (d_ref_rates)
                 LK_REC_LAUNCH(true);
             else
