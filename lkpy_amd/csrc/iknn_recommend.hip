@@ -352,74 +352,99 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
         // ---- pass 3: scores.  After the fill c[t] = END of t's list = start of t + 1's ----------
+        // Eight targets at a time: the first two hits of each are requested together (unconditional
+        // loads; most lists are that short), so a group costs one memory latency, not one per
+        // non-empty target (the sweep was 47 % of the kernel when every target waited by itself).
         unsigned beg = lane == 0 ? 0u : c[(lane - 1) * 65 + 63];
-        for (int i = 0; i < 64; ++i) {
-            const int t = lane * 64 + i;
-            const unsigned end = c[lane * 65 + i];
-            const int cnt = (int)(end - beg);
-            float score = nanf_;
-            const int kept = cnt < max_nbrs ? cnt : max_nbrs;
-            if (cnt > 0 && kept >= min_nbrs && t < wn) {
-                float tw = 0.f, ws = 0.f;
-                const float2 *l = lists + beg;
-                bool queued = false;
-                if (cnt > max_nbrs && ovf != nullptr) {
-                    // Full(heap): left to iknn_heap_replay_kernel (LDS heaps) when the queue has room
-                    const int slot = atomicAdd(ovf_count, 1);
-                    if (slot < ovf_cap) {
-                        ovf[slot] = OvfEntry{(int)ql, w0 + t, cnt, 0, hb + beg};
-                        queued = true;
-                    }
-                }
-                if (queued) {
-                    // (the panel cell is written by the replay kernel; NaN until then)
-                } else if (cnt <= max_nbrs) {  // Partial(vec): sums in insertion order
-                    int x = 0;
-                    for (; x + 4 <= cnt; x += 4) {  // four independent loads, summed in order
-                        const float2 h0 = l[x], h1 = l[x + 1], h2 = l[x + 2], h3 = l[x + 3];
-                        tw += h0.x;
-                        tw += h1.x;
-                        tw += h2.x;
-                        tw += h3.x;
-                        if (EXPL) {
-                            ws += h0.x * h0.y;
-                            ws += h1.x * h1.y;
-                            ws += h2.x * h2.y;
-                            ws += h3.x * h3.y;
-                        }
-                    }
-                    for (; x < cnt; ++x) {
-                        const float2 h = l[x];
-                        tw += h.x;
-                        if (EXPL) ws += h.x * h.y;
-                    }
-                } else {  // Full(heap) on the per-lane HBM scratch (queue full / no queue)
-                    for (int x = 0; x < max_nbrs; ++x) {  // vec.pop() from the back, push each
-                        const float2 h = l[max_nbrs - 1 - x];
-                        hw[x] = h.x;
-                        hv[x] = h.y;
-                    }
-                    LaneHeap hp{hw, hv, max_nbrs};
-                    for (int kk = 1; kk < max_nbrs; ++kk) hp.sift_up(kk, hw[kk], hv[kk]);
-                    for (int x = max_nbrs; x < cnt; ++x) {
-                        const float2 h = l[x];
-                        if (h.x > hw[0]) {  // strictly greater than the minimum (accum.rs:108)
-                            hp.push(h.x, h.y);
-                            while (hp.len > max_nbrs) hp.pop();
-                        }
-                    }
-                    for (int x = 0; x < max_nbrs; ++x) {
-                        tw += hw[x];
-                        if (EXPL) ws += hw[x] * hv[x];
-                    }
-                }
-                if (!queued) {
-                    score = EXPL ? ws / tw : tw;
-                    if (item_bias) score = score + item_bias[w0 + t];  // item.py:282 (f32 add)
-                }
+        for (int g = 0; g < 8; ++g) {
+            unsigned en[8];
+            float2 f0[8], f1[8];
+            unsigned b = beg;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                en[u] = c[lane * 65 + g * 8 + u];
+                const unsigned cn = en[u] - b;
+                const unsigned a0 = cn > 0 ? b : 0u, a1 = cn > 1 ? b + 1 : a0;
+                f0[u] = lists[a0];
+                f1[u] = lists[a1];
+                b = en[u];
             }
-            c[lane * 65 + i] = __builtin_bit_cast(unsigned, score);
-            beg = end;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = g * 8 + u;
+                const int t = lane * 64 + i;
+                const unsigned end = en[u];
+                const int cnt = (int)(end - beg);
+                float score = nanf_;
+                const int kept = cnt < max_nbrs ? cnt : max_nbrs;
+                if (cnt > 0 && kept >= min_nbrs && t < wn) {
+                    float tw = 0.f, ws = 0.f;
+                    const float2 *l = lists + beg;
+                    bool queued = false;
+                    if (cnt > max_nbrs && ovf != nullptr) {
+                        // Full(heap): left to iknn_heap_replay_kernel when the queue has room
+                        const int slot = atomicAdd(ovf_count, 1);
+                        if (slot < ovf_cap) {
+                            ovf[slot] = OvfEntry{(int)ql, w0 + t, cnt, 0, hb + beg};
+                            queued = true;
+                        }
+                    }
+                    if (queued) {
+                        // (the panel cell is written by the replay kernel; NaN until then)
+                    } else if (cnt <= max_nbrs) {  // Partial(vec): sums in insertion order
+                        tw += f0[u].x;
+                        if (EXPL) ws += f0[u].x * f0[u].y;
+                        if (cnt > 1) {
+                            tw += f1[u].x;
+                            if (EXPL) ws += f1[u].x * f1[u].y;
+                        }
+                        int x = 2;
+                        for (; x + 4 <= cnt; x += 4) {  // four independent loads, summed in order
+                            const float2 h0 = l[x], h1 = l[x + 1], h2 = l[x + 2], h3 = l[x + 3];
+                            tw += h0.x;
+                            tw += h1.x;
+                            tw += h2.x;
+                            tw += h3.x;
+                            if (EXPL) {
+                                ws += h0.x * h0.y;
+                                ws += h1.x * h1.y;
+                                ws += h2.x * h2.y;
+                                ws += h3.x * h3.y;
+                            }
+                        }
+                        for (; x < cnt; ++x) {
+                            const float2 h = l[x];
+                            tw += h.x;
+                            if (EXPL) ws += h.x * h.y;
+                        }
+                    } else {  // Full(heap) on the per-lane HBM scratch (queue full / no queue)
+                        for (int x = 0; x < max_nbrs; ++x) {  // vec.pop() from the back, push each
+                            const float2 h = l[max_nbrs - 1 - x];
+                            hw[x] = h.x;
+                            hv[x] = h.y;
+                        }
+                        LaneHeap hp{hw, hv, max_nbrs};
+                        for (int kk = 1; kk < max_nbrs; ++kk) hp.sift_up(kk, hw[kk], hv[kk]);
+                        for (int x = max_nbrs; x < cnt; ++x) {
+                            const float2 h = l[x];
+                            if (h.x > hw[0]) {  // strictly greater than the minimum (accum.rs:108)
+                                hp.push(h.x, h.y);
+                                while (hp.len > max_nbrs) hp.pop();
+                            }
+                        }
+                        for (int x = 0; x < max_nbrs; ++x) {
+                            tw += hw[x];
+                            if (EXPL) ws += hw[x] * hv[x];
+                        }
+                    }
+                    if (!queued) {
+                        score = EXPL ? ws / tw : tw;
+                        if (item_bias) score = score + item_bias[w0 + t];  // item.py:282 (f32 add)
+                    }
+                }
+                c[lane * 65 + i] = __builtin_bit_cast(unsigned, score);
+                beg = end;
+            }
         }
         LK_RP_T(p6);
         // ---- the window's segment of the panel row, coalesced -----------------------------------
@@ -685,6 +710,7 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
             int64_t wgs = (tasks + RWAVES - 1) / RWAVES;
             if (wgs > REC_MAX_WGS) wgs = REC_MAX_WGS;
 #define LK_REC_LAUNCH(EXPLV)                                                                      \
+    do {                                                                                          \
     hipLaunchKernelGGL((iknn_score_all_kernel<EXPLV>), dim3((unsigned)wgs), dim3(RTHREADS), 0, st, \
                        d_sim_indptr, d_sim_indices, d_sim_values, n_items, nwin, woff, q0, nq,    \
                        d_ref_ptr, d_ref_items, d_ref_rates, d_item_bias, max_nbrs, min_nbrs, hits, \
@@ -693,7 +719,8 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
     if (lds_replay)                                                                               \
     hipLaunchKernelGGL((iknn_heap_replay_kernel<EXPLV>), dim3(REC_OVF_CAP / 64), dim3(64),         \
                        heap_lds, st, ovf, status + 2, REC_OVF_CAP, hits, d_item_bias, max_nbrs,    \
-                       panel, ld)
+                       panel, ld);                                                                 \
+    } while (0)
             if (lds_replay && heap_lds > 64 * 1024) {
                 LK_HIP_CHECK(hipFuncSetAttribute(
                     reinterpret_cast<const void *>(&iknn_heap_replay_kernel<true>),
