@@ -304,9 +304,16 @@ __global__ __launch_bounds__(256) void als_blk_chunk_kernel(
 }
 
 // ---- one step of the blocked factorisation ---------------------------------------------------
+// `rot` (wave-uniform, 0..3): which wave of the workgroup plays "panel wave 0" for this row.  The
+// panel rows of a step are dealt to the waves in order (vtid = panel row), so at k = 128 only two
+// waves ever have rows (R <= 128) and at the late steps only one: a wave WITHOUT panel rows used
+// to run the whole 16-step v_readlane chain anyway (424 instructions per step, for nothing --
+// 62 % of the chain instructions at k = 128, 37 % at k = 256); it now skips it, and the roles
+// rotate with the row number so that the chain-carrying waves of the resident workgroups sit on
+// different SIMDs.
 template <int NT, int b>
 __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__restrict__ lds,
-                                          int tid, int lane, int wave, int wr, int wc,
+                                          int tid, int lane, int wave, int wr, int wc, int rot,
                                           float &minpiv LK_BP_ARG)
 {
     LK_BP_T(bp0);
@@ -317,6 +324,12 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
     float *P = lds + ((b & 1) ? C::OFF_P1 : C::OFF_P0);
     const int sub = lane & 15, slot = lane >> 4;
     const bool phantom = wr > wc;
+    const int vwave = (wave + rot) & 3;  // role in the panel phase
+    const int vtid = vwave * 64 + lane;
+#ifndef LK_BLK_SKIP
+#define LK_BLK_SKIP 1  // 0: every wave runs the chain (rounds 1-3; A/B timing, tools/blk_variants.py)
+#endif
+    const bool has_rows = !LK_BLK_SKIP || vwave * 64 < R;  // wave-uniform
 
     // (1) the owners of block row b publish A'(b-block rows, columns >= b) = -acc, transposed
     // by symmetry into panel rows: tile (b, tj), lane (j = sub, slot) holds
@@ -342,8 +355,10 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
     // broadcasts and no wave waits for another.  Thread 0 carries the right-hand side instead
     // of a matrix row (rows 0..15 of the panel ARE the diagonal block: their `a` is redundant).
     float a[16], d[16];
+    float myrinv = 0.f;
+    if (has_rows) {
     {
-        const int prow = tid < R ? tid : R - 1;
+        const int prow = vtid < R ? vtid : R - 1;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 t = *reinterpret_cast<const f32x4 *>(&P[g * C::P_SUB + prow * 4]);
@@ -357,12 +372,11 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
             d[4 * g + 2] = u.z;
             d[4 * g + 3] = u.w;
         }
-        if (tid == 0) {
+        if (vtid == 0) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[c] = lds[C::OFF_Y + 16 * b + c];
         }
     }
-    float myrinv = 0.f;
     sfor<0, 16>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const float piv = bcast(d[j], j);
@@ -383,13 +397,13 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
     LK_BP_ADD(2, bp1, bp2);
     // (3) L panel rows back in place (MFMA-operand layout), diagonal block + 1/L_jj to their
     // permanent home, z_b = L_bb^-1 (y_b - ...) from thread 0
-    if (tid >= 16 && tid < R) {
+    if (vtid >= 16 && vtid < R) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4 *>(&P[g * C::P_SUB + tid * 4]) =
+            *reinterpret_cast<f32x4 *>(&P[g * C::P_SUB + vtid * 4]) =
                 f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
     }
-    if (wave == 0 && lane < 16) {
+    if (vwave == 0 && lane < 16) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<f32x4 *>(&lds[C::OFF_LD + b * 256 + lane * 16 + 4 * g]) =
@@ -404,14 +418,15 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
             }
         }
     }
+    }  // has_rows
     __syncthreads();
     LK_BP_T(bp3);
     LK_BP_ADD(3, bp2, bp3);
 
     if constexpr (b + 1 < NT) {
         // (4) forward substitution of the rows below: y_r -= L[r][b-block] . z_b
-        if (tid >= 16 && tid < R) {
-            float s = lds[C::OFF_Y + 16 * b + tid];
+        if (has_rows && vtid >= 16 && vtid < R) {
+            float s = lds[C::OFF_Y + 16 * b + vtid];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 z =
@@ -421,7 +436,7 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
                 s = fmaf(-a[4 * g + 2], z.z, s);
                 s = fmaf(-a[4 * g + 3], z.w, s);
             }
-            lds[C::OFF_Y + 16 * b + tid] = s;
+            lds[C::OFF_Y + 16 * b + vtid] = s;
         }
         // keep the operand loads of (5) below this point: hoisted above, they would be live
         // together with a[] and push the kernel past its 256-register budget (scratch spills
@@ -480,7 +495,7 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
 // ---- one block of the back substitution  L^T x = z ---------------------------------------
 template <int NT, int b>
 __device__ __forceinline__ void back_step(const f32x4 (&acc)[Cfg<NT>::T], float *__restrict__ lds,
-                                          int lane, int wave, int wr, int wc)
+                                          int lane, int wave, int wr, int wc, int rot)
 {
     using C = Cfg<NT>;
     constexpr int NL = C::NL;
@@ -510,7 +525,7 @@ __device__ __forceinline__ void back_step(const f32x4 (&acc)[Cfg<NT>::T], float 
     }
     __syncthreads();
     // diagonal block: lane = column c; x_j for j = 15 .. 0, each broadcast to the lanes c < j
-    if (wave == 0) {
+    if (((wave + rot) & 3) == 0) {
         const int c = lane & 15;
         float dc = lds[C::OFF_Z + 16 * b + c] - lds[C::OFF_SP + c] - lds[C::OFF_SP + 16 + c];
         const float ri = lds[C::OFF_RINV + 16 * b + c];
@@ -531,17 +546,18 @@ __device__ __forceinline__ void back_step(const f32x4 (&acc)[Cfg<NT>::T], float 
 
 template <int NT, int... Bs>
 __device__ __forceinline__ void chol_all(f32x4 (&acc)[Cfg<NT>::T], float *lds, int tid, int lane,
-                                         int wave, int wr, int wc, float &minpiv LK_BP_ARG,
+                                         int wave, int wr, int wc, int rot, float &minpiv LK_BP_ARG,
                                          std::integer_sequence<int, Bs...>)
 {
-    (chol_step<NT, Bs>(acc, lds, tid, lane, wave, wr, wc, minpiv LK_BP_PASS), ...);
+    (chol_step<NT, Bs>(acc, lds, tid, lane, wave, wr, wc, rot, minpiv LK_BP_PASS), ...);
 }
 
 template <int NT, int... Bs>
 __device__ __forceinline__ void back_all(const f32x4 (&acc)[Cfg<NT>::T], float *lds, int lane,
-                                         int wave, int wr, int wc, std::integer_sequence<int, Bs...>)
+                                         int wave, int wr, int wc, int rot,
+                                         std::integer_sequence<int, Bs...>)
 {
-    (back_step<NT, NT - 1 - Bs>(acc, lds, lane, wave, wr, wc), ...);
+    (back_step<NT, NT - 1 - Bs>(acc, lds, lane, wave, wr, wc, rot), ...);
 }
 
 #ifndef LK_ALS_BLK_ATTR16
@@ -677,12 +693,16 @@ __device__ __forceinline__ void als_blk_solve_body(
 #if LK_BLK_SOLVE_PRIO
     __builtin_amdgcn_s_setprio(LK_BLK_SOLVE_PRIO);  // see als_chol.hip, LK_ALS_SOLVE_PRIO
 #endif
-    chol_all<NT>(acc, lds, tid, lane, wave, wr, wc, minpiv LK_BP_PASS,
+#ifndef LK_BLK_ROTATE
+#define LK_BLK_ROTATE 1
+#endif
+    const int rot = LK_BLK_ROTATE ? (int)(t & 3) : 0;
+    chol_all<NT>(acc, lds, tid, lane, wave, wr, wc, rot, minpiv LK_BP_PASS,
                  std::make_integer_sequence<int, NT>{});
     LK_BP_T(bp_chol);
 
     // -- phase 3: back substitution ----------------------------------------------------------
-    back_all<NT>(acc, lds, lane, wave, wr, wc, std::make_integer_sequence<int, NT>{});
+    back_all<NT>(acc, lds, lane, wave, wr, wc, rot, std::make_integer_sequence<int, NT>{});
 #if LK_BLK_SOLVE_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif

@@ -359,7 +359,15 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
         for (int g = 0; g < 8; ++g) {
             unsigned en[8];
             float2 f0[8], f1[8];
+            float bias[8];
             unsigned b = beg;
+            // (the item means of the group's targets as well: a load inside the per-target branch
+            // is one more serialised latency per scored target)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = w0 + lane * 64 + g * 8 + u;
+                bias[u] = item_bias ? item_bias[it < n_items ? it : 0] : 0.f;
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 en[u] = c[lane * 65 + g * 8 + u];
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
                     }
                     if (!queued) {
                         score = EXPL ? ws / tw : tw;
-                        if (item_bias) score = score + item_bias[w0 + t];  // item.py:282 (f32 add)
+                        if (item_bias) score = score + bias[u];  // item.py:282 (f32 add)
                     }
                 }
                 c[lane * 65 + i] = __builtin_bit_cast(unsigned, score);
