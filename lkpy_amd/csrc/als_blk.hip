@@ -356,6 +356,9 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
     // of a matrix row (rows 0..15 of the panel ARE the diagonal block: their `a` is redundant).
     float a[16], d[16];
     float myrinv = 0.f;
+#ifdef LK_BLK_PHASES
+    unsigned long long bp2 = bp1;
+#endif
     if (has_rows) {
     {
         const int prow = vtid < R ? vtid : R - 1;
@@ -393,7 +396,9 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
         });
     });
 
-    LK_BP_T(bp2);
+#ifdef LK_BLK_PHASES
+    bp2 = __builtin_amdgcn_s_memtime();
+#endif
     LK_BP_ADD(2, bp1, bp2);
     // (3) L panel rows back in place (MFMA-operand layout), diagonal block + 1/L_jj to their
     // permanent home, z_b = L_bb^-1 (y_b - ...) from thread 0
