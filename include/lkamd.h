@@ -54,8 +54,10 @@ const char *lk_version(void);
 /* Number of visible HIP devices (0 when there is no GPU / no driver). */
 int lk_device_count(void);
 
-/* Padded embedding width used on the device for `k` features:
- * the next of {16, 32, 64, 128, 256}; 0 if k is unsupported (k < 1 or k > 256). */
+/* Padded embedding width used on the device for `k` features: the next of
+ * {16, 32, 64, 128, 256}; for 256 < k <= 1024 the next multiple of 64 (those sizes are solved on
+ * tiles kept in HBM, csrc/als_big.hip: the reference's `POSV::solve`,
+ * src/accel/als/solve.rs:65-107, takes any k); 0 if k is unsupported (k < 1 or k > 1024). */
 int32_t lk_padded_dim(int32_t k);
 
 /* Copy an [n x k] row-major matrix (leading dimension ld_src) into an

@@ -45,7 +45,7 @@ def _stream() -> ctypes.c_void_p:
 def padded_dim(k: int) -> int:
     kp = _native.load().lk_padded_dim(int(k))
     if kp == 0:
-        raise ValueError(f"unsupported embedding size {k} (supported: 1..256)")
+        raise ValueError(f"unsupported embedding size {k} (supported: 1..1024)")
     return kp
 
 
@@ -269,8 +269,8 @@ class ALSPlan:
         wb_min = int(os.environ.get("LK_ALS_WB_MIN_ROWS", "4096"))
         if self.kp < 256:
             self.woodbury_rows = self.short_rows  # k = 128: only the 16 x 16 variant pays
-        self.use_wb = (self.kp > 64 and self.solver == _native.SOLVER_CHOLESKY and wb_min > 0
-                       and self.woodbury_rows >= wb_min)
+        self.use_wb = (64 < self.kp <= 256 and self.solver == _native.SOLVER_CHOLESKY
+                       and wb_min > 0 and self.woodbury_rows >= wb_min)
         self._negative_values = None  # not scanned yet (one reduction + one host sync)
         if self.use_wb and self.negative_values:
             # the Woodbury kernels take sqrt(v) of every confidence increment: with negative
@@ -450,7 +450,7 @@ class ALSPlanGroup:
         self.woodbury_rows = sum(p.woodbury_rows for p in plans)
         wb_min = int(os.environ.get("LK_ALS_WB_MIN_ROWS", "4096"))
         # the Woodbury decision belongs to the half-epoch, not to a slice of it
-        use_wb = (self.kp > 64 and self.solver == _native.SOLVER_CHOLESKY and wb_min > 0
+        use_wb = (64 < self.kp <= 256 and self.solver == _native.SOLVER_CHOLESKY and wb_min > 0
                   and self.woodbury_rows >= wb_min)
         if use_wb:
             # the slices are views into ONE values array (offsets are not rebased): scan each

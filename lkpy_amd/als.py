@@ -106,10 +106,12 @@ class ALSConfig(BaseModel):
     def model_post_init(self, _ctx):
         if self.embedding_size_exp is not None:
             object.__setattr__(self, "embedding_size", 2 ** int(self.embedding_size_exp))
-        if self.embedding_size > 256:
-            # fail at configuration time, not in the middle of training (lk_padded_dim)
+        if self.embedding_size > 1024:
+            # fail at configuration time, not in the middle of training (lk_padded_dim).  Up to
+            # 256 the normal matrix stays in registers; 257 .. 1024 take the HBM-tile solver
+            # (csrc/als_big.hip: exact, slower)
             raise ValueError(
-                f"embedding_size {self.embedding_size} exceeds the device kernels' limit of 256")
+                f"embedding_size {self.embedding_size} exceeds the device kernels' limit of 1024")
         if isinstance(self.regularization, dict):
             object.__setattr__(self, "regularization", UIPair(**self.regularization))
 
@@ -131,7 +133,7 @@ class ImplicitMFConfig(ALSConfig):
     use_ratings: bool = False
     solver: Literal["auto", "cholesky", "cg"] = "auto"
     """Backend knob (also ``LK_ALS_SOLVER``): ``auto`` = ``cholesky`` = the exact solve the
-    reference performs (LAPACK sposv), at every supported embedding size (k <= 256); ``cg`` =
+    reference performs (LAPACK sposv), at every supported embedding size (k <= 1024); ``cg`` =
     tolerance-terminated conjugate gradient (64 <= padded k <= 256), on request only."""
 
 

@@ -1523,6 +1523,8 @@ extern "C" int32_t lk_padded_dim(int32_t k)
     if (k <= 64) return 64;
     if (k <= 128) return 128;
     if (k <= 256) return 256;
+    // above 256: multiples of 64 up to 1024, served by the HBM-tile solver of als_big.hip
+    if (k <= 1024) return (k + 63) / 64 * 64;
     return 0;
 }
 
@@ -1552,13 +1554,15 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
     LK_REQUIRE((flags & ~LK_ALS_PLAN_REFERENCE_ORDER) == 0, "lk_als_plan_create_ex: unknown flags");
     LK_REQUIRE(n_rows >= 0 && n_rows < (int64_t)INT32_MAX, "lk_als_plan_create: bad n_rows");
     int KP = lk_padded_dim(k);
-    LK_REQUIRE(KP > 0, "lk_als_plan_create: unsupported embedding size k=%d (1..256)", k);
+    LK_REQUIRE(KP > 0, "lk_als_plan_create: unsupported embedding size k=%d (1..1024)", k);
     // the reference solves every row exactly (sposv): so does AUTO, at every k
     if (solver == LK_SOLVER_AUTO) solver = LK_SOLVER_CHOLESKY;
     LK_REQUIRE(solver == LK_SOLVER_CHOLESKY || solver == LK_SOLVER_CG,
                "lk_als_plan_create: unknown solver %d", solver);
-    LK_REQUIRE(!(solver == LK_SOLVER_CG && KP < 64),
-               "lk_als_plan_create: the CG solver needs k > 32 (got %d)", k);
+    LK_REQUIRE(!(solver == LK_SOLVER_CG && (KP < 64 || KP > 256)),
+               "lk_als_plan_create: the CG solver serves 32 < k <= 256 (got %d)", k);
+    LK_REQUIRE(!((flags & LK_ALS_PLAN_REFERENCE_ORDER) && KP > 256),
+               "lk_als_plan_create_ex: reference-order plans stop at k = 256 (got %d)", k);
 
     auto *p = new lk_als_plan();
     p->n_rows = n_rows;
@@ -1578,7 +1582,8 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
         p->chunk = 256;     // matrixmultiply's KC (oracle/lk_oracle.c: LKO_SGEMM_KC)
         p->long_row = 256;  // every row the reference sums in more than one block
     }
-    const int64_t CHUNK = p->chunk, LONG_ROW = p->long_row;
+    // (k > 256: no chunk slabs -- als_big.hip spreads a long row over its Gram grid)
+    const int64_t CHUNK = p->chunk, LONG_ROW = KP > 256 ? INT64_MAX : (int64_t)p->long_row;
 
     auto len = [&](int64_t r) -> int64_t {
         if (indptr_is_64) {
@@ -1700,10 +1705,16 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
     off += lk::align_up((size_t)lk::DELTA_BLOCKS * sizeof(float), 256);
     p->off_slabs = off;
     // one-wave slabs (als_chol.hip, k <= 64) or four-wave slabs (als_blk.hip, k = 128 / 256)
-    size_t slab_f = KP > 64 ? lk::als_blk_slab_floats(p->NT)
-                            : (size_t)(lk::als_tiles(p->NT) * 4 + p->NT) * 64;
-    off += lk::align_up((size_t)std::max<int64_t>(p->n_chunks, 1) * slab_f * sizeof(float), 256);
-    if (KP > 64) {  // OtOr^-1 for the Woodbury rows (lk_als_plan_set_z_workspace)
+    if (KP > 256) {
+        // the tile scratch of a batch of rows (als_big.hip) takes the slabs' place
+        off += lk::align_up(lk::als_big_scratch_bytes(KP, n_rows), 256);
+    } else {
+        size_t slab_f = KP > 64 ? lk::als_blk_slab_floats(p->NT)
+                                : (size_t)(lk::als_tiles(p->NT) * 4 + p->NT) * 64;
+        off += lk::align_up((size_t)std::max<int64_t>(p->n_chunks, 1) * slab_f * sizeof(float),
+                            256);
+    }
+    if (KP > 64 && KP <= 256) {  // OtOr^-1 for the Woodbury rows (lk_als_plan_set_z_workspace)
         p->off_ginv = off;
         off += lk::align_up((size_t)KP * KP * sizeof(float), 256);
         p->off_invws = off;
@@ -1793,7 +1804,7 @@ extern "C" int lk_als_plan_set_z_shared(lk_als_plan *p, const float *d_z, const 
     LK_REQUIRE(p != nullptr, "lk_als_plan_set_z_shared: null plan");
     LK_REQUIRE((d_z == nullptr) == (d_flag == nullptr),
                "lk_als_plan_set_z_shared: Z and its flag word go together");
-    LK_REQUIRE(d_z == nullptr || p->KP > 64,
+    LK_REQUIRE(d_z == nullptr || (p->KP > 64 && p->KP <= 256),
                "lk_als_plan_set_z_shared: the Woodbury kernels serve padded k = 128 / 256 only");
     p->d_z = d_z;
     p->d_zflag_src = static_cast<const int *>(d_flag);
@@ -1817,7 +1828,7 @@ extern "C" const void *lk_als_plan_z_flag(const lk_als_plan *p, const void *d_ws
 extern "C" int lk_als_plan_set_z_workspace(lk_als_plan *p, float *d_zbuf)
 {
     LK_REQUIRE(p != nullptr, "lk_als_plan_set_z_workspace: null plan");
-    LK_REQUIRE(d_zbuf == nullptr || p->KP > 64,
+    LK_REQUIRE(d_zbuf == nullptr || (p->KP > 64 && p->KP <= 256),
                "lk_als_plan_set_z_workspace: the Woodbury kernels serve padded k = 128 / 256 only");
     p->d_zbuf = d_zbuf;
     if (d_zbuf) {
@@ -1861,6 +1872,10 @@ extern "C" int lk_als_implicit_half_epoch(const lk_als_plan *plan, const void *d
         return lk::als_cg_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows, k,
                                      d_this, ld_this, d_other, ld_other, d_otor, ld_otor, ws,
                                      d_out_frob, st);
+    if (plan->KP > 256)
+        return lk::als_big_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows, k,
+                                      d_this, d_other, d_otor, ld_otor, ws, d_out_frob, st, false,
+                                      0.f);
     if (plan->KP > 64)
         return lk::als_blk_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows,
                                       n_cols, k, d_this, d_other, d_otor, ld_otor, ws, d_out_frob,
@@ -1893,6 +1908,9 @@ extern "C" int lk_als_explicit_half_epoch(const lk_als_plan *plan, const void *d
                "explicit model");
     hipStream_t st = lk::as_stream(stream);
     char *ws = static_cast<char *>(d_ws);
+    if (plan->KP > 256)
+        return lk::als_big_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows, k,
+                                      d_this, d_other, nullptr, 0, ws, d_out_frob, st, true, reg);
     if (plan->KP > 64)
         return lk::als_blk_half_epoch(plan, d_indptr, plan->is64, d_indices, d_values, n_rows,
                                       n_cols, k, d_this, d_other, nullptr, 0, ws, d_out_frob, st,

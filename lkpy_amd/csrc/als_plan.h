@@ -97,6 +97,16 @@ int als_blk_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const
                        const float *values, int64_t n_rows, int64_t n_cols, int k, float *this_,
                        const float *other, const float *otor, int ld_otor, char *ws,
                        float *out_frob, hipStream_t st, bool expl, float reg);
+// exact half-epoch for padded k > 256 (multiples of 64 up to 1024): the blocked algorithm of
+// als_blk.hip on tiles kept in an HBM scratch (als_big.hip)
+size_t als_big_scratch_bytes(int KP, int64_t n_rows);
+int als_big_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
+                       const float *values, int64_t n_rows, int k, float *this_,
+                       const float *other, const float *otor, int ld_otor, char *ws,
+                       float *out_frob, hipStream_t st, bool expl, float reg);
+size_t gramian_big_workspace_bytes(int KP);
+int gramian_big(const float *m, int64_t n, int k, int KP, float reg, float *out, int ld_out,
+                float *ws, hipStream_t st);
 // rows [t0, n_rows) of the plan order (<= 16 entries each) through the Woodbury kernel (als_wb.hip)
 int als_wb_launch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
                   const float *values, int64_t t0, int64_t n_rows, float *this_,

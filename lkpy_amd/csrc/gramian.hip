@@ -19,6 +19,7 @@
 //   un-permutes and mirrors, so the result is exactly symmetric.
 //
 // Roofline: HBM-bound, algorithmic bytes = n*k*4 (one read of M).
+#include "als_plan.h"
 #include "common.h"
 
 namespace lk {
@@ -238,6 +239,7 @@ extern "C" size_t lk_gramian_workspace_bytes(int32_t k)
 {
     int KP = lk_padded_dim(k);
     if (KP == 0) return 0;
+    if (KP > 256) return lk::gramian_big_workspace_bytes(KP);  // als_big.hip
     return (size_t)512 * KP * KP * sizeof(float);
 }
 
@@ -259,5 +261,6 @@ extern "C" int lk_gramian(const float *d_m, int64_t n, int32_t k, int32_t ld, fl
         case 128: return lk::launch_gramian<8>(d_m, n, k, ld, reg, d_out, ld_out, ws, st);
         case 256: return lk::launch_gramian<16>(d_m, n, k, ld, reg, d_out, ld_out, ws, st);
     }
+    if (KP > 256) return lk::gramian_big(d_m, n, k, KP, reg, d_out, ld_out, ws, st);  // als_big.hip
     return LK_E_INVALID;
 }

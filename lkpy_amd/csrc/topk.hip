@@ -1314,8 +1314,11 @@ static int64_t fused_min_users()
 static bool use_fused(int64_t n_users, int64_t n_items, int32_t n, int kp = SC_KC)
 {
     // kp: whole SC_KC-feature slabs only (the filter kernel loads them without a feature predicate)
+    // (kp <= 256: the fused layout reserves 256 floats per sample row; larger embeddings --
+    // als_big.hip -- take the panel path)
     return n >= 1 && n <= FUSED_MAX_N && n_items >= fused_min_items() &&
-           n_items >= 64 * (int64_t)n && n_users >= fused_min_users() && kp % SC_KC == 0;
+           n_items >= 64 * (int64_t)n && n_users >= fused_min_users() && kp % SC_KC == 0 &&
+           kp <= 256;
 }
 
 // target size of the stage-1 sample: a sixteenth of the catalogue, at least 16 n, a multiple of 256
