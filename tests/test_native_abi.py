@@ -21,12 +21,16 @@ def test_version_padding_and_errors_without_gpu():
     assert b"gfx950" in lib.lk_version()
     assert [lib.lk_padded_dim(k) for k in (1, 16, 17, 25, 64, 65, 128, 200, 256)] == [
         16, 16, 32, 32, 64, 128, 128, 256, 256]  # fmt: skip
-    assert lib.lk_padded_dim(0) == 0 and lib.lk_padded_dim(257) == 0
+    assert lib.lk_padded_dim(0) == 0 and lib.lk_padded_dim(1025) == 0
+    # above 256: multiples of 64 up to 1024 (csrc/als_big.hip)
+    assert [lib.lk_padded_dim(k) for k in (257, 320, 321, 512, 1000, 1024)] == [
+        320, 320, 384, 512, 1024, 1024]
     # argument validation happens before any device work
     h = ctypes.c_void_p(0)
     rc = lib.lk_als_plan_create(ctypes.byref(h), None, 0, 10, 64, 0)
     assert rc == _native.LK_E_INVALID and b"null" in lib.lk_last_error()
-    assert lib.lk_gramian_workspace_bytes(64) > 0 and lib.lk_gramian_workspace_bytes(300) == 0
+    assert lib.lk_gramian_workspace_bytes(64) > 0 and lib.lk_gramian_workspace_bytes(1300) == 0
+    assert lib.lk_gramian_workspace_bytes(300) > 0
 
 
 def test_no_cpu_fallback():
