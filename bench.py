@@ -955,11 +955,26 @@ def als_timed(ui, P0, Q0, k, reg, steps, warmup, dev, world, scale):
     launches = nu + ni
     kname = ("als_solve_kernel<NT=%d>" if backend.kp <= 64 else "als_blk_solve_kernel%d") % (
         backend.kp // 16)
+    # k <= 64 since round 4: the chunk blocks and the solve blocks of the rows without chunks run
+    # in ONE launch (als_fused_kernel, csrc/als_chol.hip; LK_ALS_FUSED=0: two launches as before),
+    # followed by a small als_solve_kernel launch for the rows that consume the slabs: the plan's
+    # two timers are then (fused launch, that small launch) and the roofline is taken over both,
+    # on the flops of both
+    fused = backend.kp <= 64 and os.environ.get("LK_ALS_FUSED", "1") != "0" and (cu + ci) > 0
+    if fused:
+        kname = "als_fused_kernel<NT=%d> (chunk + solve blocks interleaved) + als_solve_kernel " \
+                "(rows with chunks)" % (backend.kp // 16)
     if launches > 0 and (su + si) > 0:
         flops_per_launch = (fu_solve * nu + fi_solve * ni) / launches
         exec_per_launch = (half_mfma_flops(ulen, backend.kp, uwb) * nu
                            + half_mfma_flops(ilen, backend.kp, iwb) * ni) / launches
         avg_ms = (su + si) / launches
+        if fused:
+            flops_per_launch += (fu_chunk * nu + fi_chunk * ni) / launches
+            # (chunk blocks issue the upper tiles too: (NT + 1) / (2 NT) of the 2 k^2 convention)
+            nt = backend.kp // 16
+            exec_per_launch += (fu_chunk * nu + fi_chunk * ni) / launches * (nt + 1) / (2.0 * nt)
+            avg_ms = (su + si + cu + ci) / launches
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         roof = {
             "kernel": kname,
@@ -978,7 +993,9 @@ def als_timed(ui, P0, Q0, k, reg, steps, warmup, dev, world, scale):
             "executed_flops_per_launch": exec_per_launch,
             "algorithmic_bytes_per_launch": (half_bytes(ulen, k) * nu + half_bytes(ilen, k) * ni)
             / launches,
-            "chunk_kernel_ms_per_launch": round((cu + ci) / launches, 4),
+            "chunk_kernel_ms_per_launch": None if fused else round((cu + ci) / launches, 4),
+            "fused_launch_ms": round((cu + ci) / launches, 4) if fused else None,
+            "long_row_solve_ms": round((su + si) / launches, 4) if fused else None,
             "chunk_kernel_flops_per_launch": (fu_chunk * nu + fi_chunk * ni) / launches,
             "note": "frac = SURVEY 8d algorithmic flops (2k^2 per entry) / time / peak; "
             "frac_executed = matrix-core work actually issued (upper tiles only)"
@@ -991,6 +1008,9 @@ def als_timed(ui, P0, Q0, k, reg, steps, warmup, dev, world, scale):
         roof["traffic"], roof["traffic_source"] = pmc_traffic(
             "r*_k%d_counters.csv" % k if k != 64 else "r*_als_*_counters.csv",
             kname.split("<")[0])
+        if roof["traffic"] is None and fused:  # (captures made before the fused launch)
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(
+                "r*_als_*_counters.csv", "als_solve_kernel")
     return eng, backend, elapsed, roof, setup_seconds, (float(du.item()), float(di.item()))
 
 

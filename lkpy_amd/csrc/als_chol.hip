@@ -546,17 +546,26 @@ int launch_slab_group_reduce(const lk_als_plan *p, float *slabs, size_t slab_flo
 }
 
 // ---- chunk kernel: one wave per chunk of a long row ------------------------
+template <int NT>
+__host__ __device__ constexpr int chunk_lds_floats()
+{
+    return GRAM_STAGE_WORDS + ((LK_ALS_GRAM_DMA && NT == 4) ? GRAM_DMA_WORDS : 0);
+}
+
+// (body + thin __global__ wrapper: the fused kernel below runs chunk blocks and solve blocks in
+// ONE launch)
 template <int NT, bool EXPL>
-__global__ __launch_bounds__(256) void als_chunk_kernel(
+__device__ __forceinline__ void als_chunk_body(
     const int32_t *__restrict__ indices, const float *__restrict__ values,
     const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_len,
-    int64_t n_chunks, const float *__restrict__ other, int ld, float *__restrict__ slabs)
+    int64_t n_chunks, const float *__restrict__ other, int ld, float *__restrict__ slabs,
+    const int64_t blk, float *__restrict__ lds_flat)
 {
     constexpr bool DMA = LK_ALS_GRAM_DMA && NT == 4;
-    __shared__ __attribute__((aligned(16))) float
-        stage_all[4][GRAM_STAGE_WORDS + (DMA ? GRAM_DMA_WORDS : 0)];
+    float(*stage_all)[chunk_lds_floats<NT>()] =
+        reinterpret_cast<float(*)[chunk_lds_floats<NT>()]>(lds_flat);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t c = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t c = blk * 4 + wave;
     if (c >= n_chunks) return;
     Gram<NT> G;
 #pragma unroll
@@ -571,6 +580,17 @@ __global__ __launch_bounds__(256) void als_chunk_kernel(
         gram_accumulate<NT>(G, indices, values, beg, beg + chunk_len[c], other, ld, EXPL,
                             stage_all[wave]);
     slab_store<NT>(G, slabs + (size_t)c * slab_floats<NT>());
+}
+
+template <int NT, bool EXPL>
+__global__ __launch_bounds__(256) void als_chunk_kernel(
+    const int32_t *__restrict__ indices, const float *__restrict__ values,
+    const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_len,
+    int64_t n_chunks, const float *__restrict__ other, int ld, float *__restrict__ slabs)
+{
+    __shared__ __attribute__((aligned(16))) float lds_flat[4 * chunk_lds_floats<NT>()];
+    als_chunk_body<NT, EXPL>(indices, values, chunk_beg, chunk_len, n_chunks, other, ld, slabs,
+                             (int64_t)blockIdx.x, lds_flat);
 }
 
 // ---- solve: lane R owns row R of the (primed) normal matrix -----------------
@@ -927,28 +947,29 @@ __host__ __device__ constexpr int solve_lds_floats()
 // the reference's summation order) instead of the accumulated one; a template parameter so that
 // the default instantiation is instruction for instruction the tuned kernel
 template <int NT, bool IS64, bool EXPL, bool CTL, bool YREF = false>
-__global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
+__device__ __forceinline__ void als_solve_body(
     const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_rows,
     const int32_t *__restrict__ row_slab, const float *__restrict__ other, int ld_other,
     float *__restrict__ this_, int ld_this, const float *__restrict__ otor_p,
     const float *__restrict__ slabs, float *__restrict__ row_delta, int *__restrict__ status,
-    int k, float reg, TaskCtlDev ctl, const float *__restrict__ y_ref = nullptr,
-    int chunk_rt = 0)
+    int k, float reg, TaskCtlDev ctl, const float *__restrict__ y_ref, int chunk_rt,
+    const int64_t blk, float *__restrict__ lds_flat)
 {
     constexpr int KP = NT * 16;
-    __shared__ __attribute__((aligned(16))) float lds_all[4][solve_lds_floats<NT>()];
+    float(*lds_all)[solve_lds_floats<NT>()] =
+        reinterpret_cast<float(*)[solve_lds_floats<NT>()]>(lds_flat);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const int sub = lane & 15, slot = lane >> 4;
-    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t t = blk * 4 + wave;
     if (t >= n_rows) return;
     LK_PHASE_T(ph0);
     if constexpr (CTL) {
         // AccelTask.cancel (src/accel/tasks/mod.rs:88-95): rows not started yet are skipped
         int c = 0;
-        if (lane == 0) c = ctl_cancelled(ctl, (blockIdx.x & 63) == 0 && wave == 0) ? 1 : 0;
+        if (lane == 0) c = ctl_cancelled(ctl, (blk & 63) == 0 && wave == 0) ? 1 : 0;
         if (__builtin_amdgcn_readfirstlane(c)) return;
     }
     const int row = order[t];
@@ -1139,6 +1160,67 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     LK_PHASE_ADD(6, (unsigned long long)beg, (unsigned long long)end);
     LK_PHASE_ADD(7, ph0, ph6);
 #endif
+}
+
+template <int NT, bool IS64, bool EXPL, bool CTL, bool YREF = false>
+__global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
+    const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_rows,
+    const int32_t *__restrict__ row_slab, const float *__restrict__ other, int ld_other,
+    float *__restrict__ this_, int ld_this, const float *__restrict__ otor_p,
+    const float *__restrict__ slabs, float *__restrict__ row_delta, int *__restrict__ status,
+    int k, float reg, TaskCtlDev ctl, const float *__restrict__ y_ref = nullptr,
+    int chunk_rt = 0)
+{
+    __shared__ __attribute__((aligned(16))) float lds_flat[4 * solve_lds_floats<NT>()];
+    als_solve_body<NT, IS64, EXPL, CTL, YREF>(indptr, indices, values, order, n_rows, row_slab,
+                                              other, ld_other, this_, ld_this, otor_p, slabs,
+                                              row_delta, status, k, reg, ctl, y_ref, chunk_rt,
+                                              (int64_t)blockIdx.x, lds_flat);
+}
+
+// ---- chunk blocks and short-row solve blocks in ONE launch (round 4) -----------------------------
+// The chunk kernel is pure matrix-core work (one wave per 1024-entry chunk, no factorisation); the
+// solve kernel alternates matrix-core work with a latency-bound v_readlane chain and keeps the
+// matrix cores 58-62 % busy.  Launched one after the other they never overlap -- and a second
+// stream does not help, the first launch fills every wave slot.  Here the chunk blocks are
+// INTERLEAVED with the solve blocks of the rows that need no chunks (block b is a chunk block
+// when b % stride == 0, until the chunks run out), so at any time the resident waves are a mix of
+// both: the chunk waves' MFMAs fill the issue slots the factorisation chains leave.  No
+// dependency between the two kinds of blocks: the rows that DO consume slabs (a prefix of the
+// longest-first order: rows [0, n_long)) are solved by a small launch afterwards, behind the
+// slab-group reduction -- same arithmetic, same bits as the separate launches.
+template <int NT>
+__host__ __device__ constexpr int fused_lds_floats()
+{
+    return 4 * (solve_lds_floats<NT>() > chunk_lds_floats<NT>() ? solve_lds_floats<NT>()
+                                                                : chunk_lds_floats<NT>());
+}
+
+template <int NT, bool IS64, bool EXPL>
+__global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_fused_kernel(
+    const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_short,
+    const int32_t *__restrict__ row_slab, const float *__restrict__ other, int ld_other,
+    float *__restrict__ this_, int ld_this, const float *__restrict__ otor_p,
+    float *__restrict__ slabs, float *__restrict__ row_delta, int *__restrict__ status, int k,
+    float reg, const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_len,
+    int64_t n_chunks, int n_cb, int stride)
+{
+    __shared__ __attribute__((aligned(16))) float lds_flat[fused_lds_floats<NT>()];
+    const int b = blockIdx.x;
+    const int q = b / stride;
+    const bool slot0 = (b - q * stride) == 0;  // wave-uniform: the whole block takes one role
+    if (slot0 && q < n_cb) {
+        als_chunk_body<NT, EXPL>(indices, values, chunk_beg, chunk_len, n_chunks, other, ld_other,
+                                 slabs, (int64_t)q, lds_flat);
+    } else {
+        const int before = slot0 ? n_cb : (q + 1 < n_cb ? q + 1 : n_cb);  // chunk blocks below b
+        als_solve_body<NT, IS64, EXPL, false, false>(
+            indptr, indices, values, order, n_short, row_slab, other, ld_other, this_, ld_this,
+            otor_p, slabs, row_delta, status, k, reg, TaskCtlDev{}, nullptr, 0,
+            (int64_t)(b - before), lds_flat);
+    }
 }
 
 // ---- Woodbury row solve for rows with 17..64 entries at padded k = 128 / 256 -----------------
@@ -1399,6 +1481,13 @@ int launch_delta_reduce(const float *row_delta, int64_t n_rows, float *partial, 
     return LK_OK;
 }
 
+// LK_ALS_FUSED=0: the chunk kernel and the solve kernel as two launches (rounds 1-3; A/B timing)
+static bool als_fused_enabled()
+{
+    const char *e = getenv("LK_ALS_FUSED");
+    return !(e && e[0] == '0');
+}
+
 template <int NT, bool IS64, bool EXPL = false>
 static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *indices,
                        const float *values, int64_t n_rows, int k, float *this_, int ld_this,
@@ -1427,17 +1516,41 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
                        otor, ld_otor, k, otor_p);
     const bool tm = p->timing && p->timing_n < lk_als_plan::TIMING_RING;
     if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][0], st));
-    if (p->n_chunks > 0) {
+    // (CG hybrid: only the chunked rows, the first dense_limit tasks of the order)
+    const int64_t n_solve = p->dense_limit >= 0 && p->dense_limit < n_rows ? p->dense_limit : n_rows;
+    // one launch for the chunks AND the rows that need none (als_fused_kernel): the plain exact
+    // half-epoch only -- no task control, no reference order, not the CG hybrid's prefix
+    const bool fused = als_fused_enabled() && p->n_chunks > 0 && !p->ctl && !p->d_yref &&
+                       !p->ref_order && p->dense_limit < 0 && p->n_long < n_rows;
+    if (fused) {
+        using IT = typename IndPtr<IS64>::type;
+        const int64_t n_short = n_rows - p->n_long;  // tasks [n_long, n_rows) of the order
+        const int64_t n_cb = (p->n_chunks + 3) / 4, n_sb = (n_short + 3) / 4;
+        int64_t stride = (n_cb + n_sb) / n_cb;
+        if (stride < 1) stride = 1;
+        hipLaunchKernelGGL((als_fused_kernel<NT, IS64, EXPL>), dim3((unsigned)(n_cb + n_sb)),
+                           dim3(256), 0, st, static_cast<const IT *>(indptr), indices, values,
+                           p->d_order + p->n_long, n_short, p->d_row_slab, other, ld_other, this_,
+                           ld_this, otor_p, slabs, row_delta, status, k, reg, p->d_chunk_beg,
+                           p->d_chunk_len, p->n_chunks, (int)n_cb, (int)stride);
+        int rc = launch_slab_group_reduce(p, slabs, slab_floats<NT>(), st);
+        if (rc != LK_OK) return rc;
+        if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
+        if (p->n_long > 0)  // the rows that consume the slabs
+            hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, false>),
+                               dim3((unsigned)((p->n_long + 3) / 4)), dim3(256), 0, st,
+                               static_cast<const IT *>(indptr), indices, values, p->d_order,
+                               p->n_long, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
+                               slabs, row_delta, status, k, reg, TaskCtlDev{});
+    } else if (p->n_chunks > 0) {
         hipLaunchKernelGGL((als_chunk_kernel<NT, EXPL>), dim3((unsigned)((p->n_chunks + 3) / 4)),
                            dim3(256), 0, st, indices, values, p->d_chunk_beg, p->d_chunk_len,
                            p->n_chunks, other, ld_other, slabs);
         int rc = launch_slab_group_reduce(p, slabs, slab_floats<NT>(), st);
         if (rc != LK_OK) return rc;
     }
-    if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
-    // (CG hybrid: only the chunked rows, the first dense_limit tasks of the order)
-    const int64_t n_solve = p->dense_limit >= 0 && p->dense_limit < n_rows ? p->dense_limit : n_rows;
-    if (n_solve > 0) {
+    if (!fused && tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
+    if (!fused && n_solve > 0) {
         using IT = typename IndPtr<IS64>::type;
         if (p->d_yref && !p->ctl) {
             // reference-order right-hand side (als_rhs.hip), then the solve that takes it
