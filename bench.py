@@ -955,12 +955,11 @@ def als_timed(ui, P0, Q0, k, reg, steps, warmup, dev, world, scale):
     launches = nu + ni
     kname = ("als_solve_kernel<NT=%d>" if backend.kp <= 64 else "als_blk_solve_kernel%d") % (
         backend.kp // 16)
-    # k <= 64 since round 4: the chunk blocks and the solve blocks of the rows without chunks run
-    # in ONE launch (als_fused_kernel, csrc/als_chol.hip; LK_ALS_FUSED=0: two launches as before),
-    # followed by a small als_solve_kernel launch for the rows that consume the slabs: the plan's
-    # two timers are then (fused launch, that small launch) and the roofline is taken over both,
-    # on the flops of both
-    fused = backend.kp <= 64 and os.environ.get("LK_ALS_FUSED", "1") != "0" and (cu + ci) > 0
+    # LK_ALS_FUSED=1 (an experiment of round 4, slower, off by default): the chunk blocks and the
+    # solve blocks of the rows without chunks run in ONE launch (als_fused_kernel), followed by a
+    # small als_solve_kernel launch for the rows that consume the slabs: the plan's two timers are
+    # then (fused launch, that small launch) and the roofline is taken over both
+    fused = backend.kp <= 64 and os.environ.get("LK_ALS_FUSED", "0") == "1" and (cu + ci) > 0
     if fused:
         kname = "als_fused_kernel<NT=%d> (chunk + solve blocks interleaved) + als_solve_kernel " \
                 "(rows with chunks)" % (backend.kp // 16)

@@ -1179,7 +1179,8 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
                                               (int64_t)blockIdx.x, lds_flat);
 }
 
-// ---- chunk blocks and short-row solve blocks in ONE launch (round 4) -----------------------------
+// ---- chunk blocks and short-row solve blocks in ONE launch (round 4; an experiment, off by
+// default: see als_fused_enabled) -----------------------------------------------------------------
 // The chunk kernel is pure matrix-core work (one wave per 1024-entry chunk, no factorisation); the
 // solve kernel alternates matrix-core work with a latency-bound v_readlane chain and keeps the
 // matrix cores 58-62 % busy.  Launched one after the other they never overlap -- and a second
@@ -1481,11 +1482,15 @@ int launch_delta_reduce(const float *row_delta, int64_t n_rows, float *partial, 
     return LK_OK;
 }
 
-// LK_ALS_FUSED=0: the chunk kernel and the solve kernel as two launches (rounds 1-3; A/B timing)
+// LK_ALS_FUSED=1: chunk blocks and short-row solve blocks in one launch (als_fused_kernel).
+// OFF by default -- measured (tools/fused_ab.py, ML-25M shape, same bits): k = 64 3.35 vs 3.12
+// ms/epoch, k = 32 1.28 vs 1.19: the chunk waves' MFMAs do not fill "idle" matrix-core time of the
+// factorisation chains, they compete with them for the SIMD's issue slots (user half 1.89 vs
+// 1.70 ms, item half 1.38 vs 1.37).  Kept as a knob so that the experiment can be repeated.
 static bool als_fused_enabled()
 {
     const char *e = getenv("LK_ALS_FUSED");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
 }
 
 template <int NT, bool IS64, bool EXPL = false>
