@@ -49,13 +49,16 @@ LONG_ROW = int(os.environ.get("LK_BENCH_LONG_ROW", 2048))  # LK_ALS_LONG_ROW (cs
 CHUNK = 1024  # LK_ALS_CHUNK
 
 
-WB_MAX_N = 64  # rows this short take the Woodbury kernels at padded k > 64 (csrc/als_wb.hip:
-#               n <= 16, one MFMA tile; als_wb64_kernel in csrc/als_chol.hip: 17 .. 64)
+WB_MAX_N = 128  # rows this short take the Woodbury kernels at padded k = 256 (csrc/als_wb.hip:
+#                n <= 16, one MFMA tile; als_wb64_kernel in csrc/als_chol.hip: 17 .. 64;
+#                als_wb128_kernel in csrc/als_blk.hip: 65 .. 128, unless LK_ALS_WB128=0)
 
 
 def _wb_max(k: int) -> int:
-    "longest row the Woodbury kernels take: 64 entries at padded k = 256, 16 at padded k = 128"
-    return WB_MAX_N if k > 128 else 16
+    "longest row the Woodbury kernels take: 128 entries at padded k = 256, 16 at padded k = 128"
+    if k <= 128:
+        return 16
+    return WB_MAX_N if os.environ.get("LK_ALS_WB128", "1") != "0" else 64
 
 
 def half_flops(lengths: np.ndarray, k: int, wb: bool = False):
@@ -107,9 +110,12 @@ def half_mfma_flops(lengths: np.ndarray, kp: int, wb: bool = False):
         # n <= 16: one S0 tile over all features (kp/4 instructions); 17 .. 64: ceil(n/16)^2
         # tiles + the 79 trailing-update instructions of the 64 x 64 hybrid solve
         n16 = int(((lengths > 0) & (lengths <= 16)).sum())
-        mid = lengths[(lengths > 16) & (lengths <= _wb_max(kp))]
+        mid = lengths[(lengths > 16) & (lengths <= min(64, _wb_max(kp)))]
+        big = lengths[(lengths > 64) & (lengths <= _wb_max(kp))]
+        # 65 .. 128: all 36 upper tiles of the 128 x 128 system over kp / 4 steps + the k = 128
+        # blocked solver's trailing updates (4 * 84 instructions)
         wb_mfma = n16 * (kp // 4) + int((((mid + 15) // 16) ** 2).sum()) * (kp // 4) \
-            + 79 * len(mid)
+            + 79 * len(mid) + len(big) * (36 * (kp // 4) + 4 * 84)
         lengths = lengths[lengths > _wb_max(kp)]
     short = lengths[(lengths > 0) & (lengths <= LONG_ROW)]
     groups = int(((short + 3) // 4).sum())
@@ -706,7 +712,7 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
         "setup_seconds": round(setup_seconds, 3),
         "roofline": {
             "kernel": "als_blk_solve_kernel%d + als_blk_chunk_kernel" % (backend.kp // 16)
-            + (" + als_wb_kernel / als_wb64_kernel (rows <= 64 entries)" if (uwb or iwb) else ""),
+            + (" + als_wb / als_wb64 / als_wb128 kernels (rows <= 128 entries)" if (uwb or iwb) else ""),
             "bound": "mfma",
             "achieved": round(ep_flops / (ep_ms * 1e-3) / 1e12, 3),
             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -724,7 +730,7 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
                               "item": int(eng.i_plan.woodbury_rows) if iwb else 0},
             "algorithmic_bytes_per_epoch": half_bytes(ulen, k) + half_bytes(ilen, k),
             "traffic": None, "traffic_source": None,
-            "note": "rows with <= 64 entries are rank-n updates of OtOr and are solved through "
+            "note": "rows with <= 128 entries are rank-n updates of OtOr and are solved through "
             "the Woodbury identity (same solution, O(n^2 k) flops): algorithmic_flops counts "
             "what this path needs for them; reference_flops = a dense k^3/3 solve for every "
             "row, as the reference does (SURVEY 8d)",

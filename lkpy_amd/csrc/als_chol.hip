@@ -1743,6 +1743,16 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
         }
         p->t_mid = lo;
         lo = 0;
+        hi = p->t_mid;
+        while (lo < hi) {  // first task whose row has <= 128 entries
+            const int64_t mid = (lo + hi) >> 1;
+            if (len(order[(size_t)mid]) > 128)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        p->t_128 = lo;
+        lo = 0;
         hi = n_rows;
         const int64_t cg_len = 16384 / KP;
         while (lo < hi) {  // first task whose row the CG kernel holds in registers
@@ -1837,6 +1847,10 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
         off += lk::align_up((size_t)KP * KP * sizeof(float), 256);
         p->off_invws = off;
         off += lk::align_up(lk::spd_inverse_workspace_bytes(KP), 256);
+        if (KP == 256 && p->t_mid > p->t_128 && !p->ref_order) {  // als_wb128_kernel's scratch
+            p->off_wb128 = off;
+            off += lk::align_up(lk::blk::als_wb128_scratch_bytes(p->t_mid - p->t_128), 256);
+        }
     }
     p->ws_bytes = off;
     *out = p;

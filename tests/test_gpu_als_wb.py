@@ -19,6 +19,7 @@ def _short_csr(rng, n_rows, n_cols, varied_values):
     lens = np.where(u < 0.6, rng.integers(0, 17, n_rows),
                     np.where(u < 0.9, rng.integers(17, 65, n_rows), rng.integers(65, 300, n_rows)))
     lens[:65] = np.arange(65)  # every length 0..64 present
+    lens[65:129] = np.arange(65, 129)  # ... and 65..128 (als_wb128_kernel at padded k = 256)
     indptr = np.zeros(n_rows + 1, np.int64)
     np.cumsum(lens, out=indptr[1:])
     indices = np.empty(indptr[-1], np.int32)
@@ -60,7 +61,8 @@ def test_short_rows_vs_oracle_and_dense(gpu, oracle, rng, monkeypatch, k, varied
 
     plan, got, frob, d_this = run(1)
     assert plan.use_wb and plan.short_rows >= 1500
-    wb_max = 64 if plan.kp == 256 else 16  # the 64 x 64 variant only pays at padded k = 256
+    # the 64 x 64 and 128 x 128 variants only pay at padded k = 256
+    wb_max = 128 if plan.kp == 256 else 16
     plan0, dense, frob0, _ = run(0)
     assert not plan0.use_wb
 
@@ -68,6 +70,12 @@ def test_short_rows_vs_oracle_and_dense(gpu, oracle, rng, monkeypatch, k, varied
     assert np.all(got[lens == 0] == 0.0)  # implicit.rs:98-101
     # rows the Woodbury kernels did not touch are bit-identical to the dense run
     assert np.array_equal(got[lens > wb_max], dense[lens > wb_max])
+    # ... with the 128 x 128 variant switched off, so are the rows with 65 .. 128 entries
+    monkeypatch.setenv("LK_ALS_WB128", "0")
+    _, got64, _, _ = run(1)
+    monkeypatch.delenv("LK_ALS_WB128")
+    assert np.array_equal(got64[lens > 64], dense[lens > 64])
+    assert np.array_equal(got64[lens <= 64], got[lens <= 64])
     # ... and with the 64 x 64 variant switched off, so are the rows with 17 .. 64 entries
     monkeypatch.setenv("LK_ALS_WB64", "0")
     _, got16, _, _ = run(1)
