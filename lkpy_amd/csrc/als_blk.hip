@@ -797,186 +797,162 @@ __global__ __launch_bounds__(256) void als_blk_fallback_kernel(
 // Same identity as als_wb.hip / als_wb64_kernel:  S u' = sv o (S0 w),  S = I + diag(sv) S0 diag(sv),
 // S0 = [q_i . z_j],  x = sum_j (w_j - sv_j u'_j) z_j  -- with S up to 128 x 128: the system the
 // k = 128 instance of THIS file's blocked solver factors (4 workgroups per CU, 8 block steps)
-// instead of a 256 x 256 normal matrix (2 per CU, 16 steps, 512 B of scratch per thread): the
-// dense kernel spent 55 ms per cfg5 half-epoch on the 2 % of rows with more than 64 entries, more
-// than half of which have at most 128.
-// S0 is a sum over the 256 features of outer products of n-vectors -- the Gram phase with the roles
-// of entries and features swapped: the workgroup first writes the gathered rows TRANSPOSED and
-// scaled (Qs[f][j] = sv_j q_j[f], Zs[f][j] = sv_j z_j[f]; thread = feature, 16 entries at a time,
-// float4 stores) into its 256 KiB slice of the workspace, then runs the ordinary operand loop
-// over f with A operands from Qs and B operands from Zs onto accumulators that start at -I.
-// Persistent workgroups (the scratch is per resident workgroup), one row per turn.
-constexpr int WB128_N = 128;                       // system size = Cfg<8>::KP
-constexpr int WB128_SCRATCH = 2 * 256 * WB128_N;   // floats per workgroup: Qs, Zs
-constexpr int WB128_MAX_WGS = 1024;
+// instead of a 256 x 256 normal matrix (2 per CU, 16 steps, 512 B of scratch per thread).
+// S0 on the matrix cores without any transposition: the system index IS the entry slot (tile t,
+// lane & 15 = entry 16 t + sub), the contraction runs over the 256 features, 16 per super-step:
+// a lane loads ONE float4 of "its" gathered row per operand tile -- features 16 G + 4 slot .. + 3 --
+// and MFMA step kk contracts feature 16 G + 4 slot + kk on BOTH operands (the enumeration trick
+// of the trailing update), so four instructions cover the 16 features.  (A first version wrote the
+// gathered rows transposed to a 256 KiB scratch per workgroup and streamed them back: bound by
+// that traffic, no faster than the dense kernel.)
+constexpr int WB128_N = 128;  // system size = Cfg<8>::KP
 
 template <bool IS64>
 __global__ __launch_bounds__(256) LK_ALS_BLK_ATTR8 void als_wb128_kernel(
     const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_tasks,
     const float *__restrict__ other, const float *__restrict__ z, float *__restrict__ this_,
-    float *__restrict__ row_delta, int *__restrict__ status, float *__restrict__ scratch)
+    float *__restrict__ row_delta, int *__restrict__ status)
 {
     using C = Cfg<8>;
-    constexpr int KF = 256, NT = 8, NL = 4;
+    constexpr int KF = 256, NL = 4;
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
     __shared__ int s_col[WB128_N];
     __shared__ float s_w[WB128_N], s_sv[WB128_N], s_g[WB128_N], s_t[KF];
     if (status[1] != 0) return;  // Z unavailable (OtOr not positive definite): dense fallback
+    const int64_t task = blockIdx.x;
+    if (task >= n_tasks) return;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = lane_id();
     const int wr = wave & 1, wc = wave >> 1;
     const int sub = lane & 15, slot = lane >> 4;
     const bool phantom = wr > wc;
-    float *Qs = scratch + (size_t)blockIdx.x * WB128_SCRATCH;
-    float *Zs = Qs + 256 * WB128_N;
-    // natural system index i (entry slot) -> primed index of the solver: i = s * NT + pos(t)
-    auto primed = [](int i) {
-        const int sidx = i >> 3, pos = i & 7;
-        const int t = ((pos & 3) << 1) | (pos >> 2);
-        return t * 16 + sidx;
-    };
-
-    for (int64_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
-        const int row = order[task];
-        const int64_t beg = indptr[row], end = indptr[row + 1];
-        const int n = (int)(end - beg);  // 65 .. 128 (any 1 .. 128 is handled)
-        float *xrow = this_ + (int64_t)row * KF;
-        if (tid < WB128_N) {
-            const int64_t e = beg + (tid < n ? tid : n - 1);
-            const float v = tid < n ? values[e] : 0.f;
-            s_col[tid] = indices[e];
-            s_w[tid] = tid < n ? v + 1.0f : 0.f;  // `vals += 1.0` (implicit.rs:116)
-            s_sv[tid] = __builtin_sqrtf(v);       // v < 0: NaN -> reported as not positive definite
-        }
-        __syncthreads();
-        // ---- transposed, scaled copies of the gathered rows; t = sum_j w_j z_j on the way -------
-        float tf = 0.f;
-        for (int j0 = 0; j0 < WB128_N; j0 += 16) {
-            float qv[16], zv[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int j = j0 + u;
-                const int64_t base = (int64_t)s_col[j] * KF + tid;
-                const float sv = s_sv[j];
-                const float zz = z[base];
-                qv[u] = sv * other[base];
-                zv[u] = sv * zz;
-                tf = fmaf(s_w[j], zz, tf);
-            }
-#pragma unroll
-            for (int u4 = 0; u4 < 4; ++u4) {
-                *reinterpret_cast<f32x4 *>(Qs + tid * WB128_N + j0 + 4 * u4) =
-                    f32x4{qv[4 * u4], qv[4 * u4 + 1], qv[4 * u4 + 2], qv[4 * u4 + 3]};
-                *reinterpret_cast<f32x4 *>(Zs + tid * WB128_N + j0 + 4 * u4) =
-                    f32x4{zv[4 * u4], zv[4 * u4 + 1], zv[4 * u4 + 2], zv[4 * u4 + 3]};
-            }
-        }
-        s_t[tid] = tf;
-        __syncthreads();  // Qs / Zs / s_t complete (same CU: workgroup-scope visibility)
-        // ---- right-hand side  sv_i (q_i . t)  into the solver's y (primed order) -----------------
-        for (int i = wave; i < WB128_N; i += 4) {
-            float r = 0.f;
-            if (i < n) {
-                const f32x4 q4 = *reinterpret_cast<const f32x4 *>(other + (int64_t)s_col[i] * KF +
-                                                                 lane * 4);
-                r = q4.x * s_t[lane * 4] + q4.y * s_t[lane * 4 + 1] + q4.z * s_t[lane * 4 + 2] +
-                    q4.w * s_t[lane * 4 + 3];
-                r = wave_sum(r);
-            }
-            if (lane == 0) lds[C::OFF_Y + primed(i)] = i < n ? s_sv[i] * r : 0.f;
-        }
-        // ---- -S = -I - Qs^T Zs on the accumulators (upper tiles, 2 x 2 block-cyclic) -------------
-        f32x4 acc[C::T];
-        sfor<0, NL>([&](auto Jc) {
-            constexpr int J = decltype(Jc)::value;
-            sfor<0, J + 1>([&](auto Ic) {
-                constexpr int I = decltype(Ic)::value;
-                const bool diag = (I == J) && (wr == wc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[lt(I, J)][r] = (diag && (slot * 4 + r) == sub) ? -1.0f : 0.f;
-            });
-        });
-        {
-            // operands of step g: "entry" = feature f = 4 g + slot; a lane loads the NL elements of
-            // Qs[f] its wave's A operands need and the NL of Zs[f] its B operands need
-            float qa[2][NL], qb[2][NL];
-            auto issue = [&](int buf, int g) {
-                const int f = 4 * g + slot;
-                const float *ba = Qs + f * WB128_N + sub * NT;
-                const float *bb = Zs + f * WB128_N + sub * NT;
-                load_vec<NL>(ba + wr * NL, qa[buf]);
-                load_vec<NL>(bb + wc * NL, qb[buf]);
-            };
-            issue(0, 0);
-            for (int g = 0; g < KF / 4; g += 2) {
-                issue(1, g + 1);
-                sfor<0, NL>([&](auto Jc) {
-                    constexpr int J = decltype(Jc)::value;
-                    sfor<0, J + 1>([&](auto Ic) {
-                        constexpr int I = decltype(Ic)::value;
-                        acc[lt(I, J)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                            -qa[0][I], qb[0][J], acc[lt(I, J)], 0, 0, 0);
-                    });
-                });
-                issue(0, g + 2 < KF / 4 ? g + 2 : g + 1);
-                sfor<0, NL>([&](auto Jc) {
-                    constexpr int J = decltype(Jc)::value;
-                    sfor<0, J + 1>([&](auto Ic) {
-                        constexpr int I = decltype(Ic)::value;
-                        acc[lt(I, J)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                            -qa[1][I], qb[1][J], acc[lt(I, J)], 0, 0, 0);
-                    });
-                });
-            }
-        }
-        if (phantom) {  // wave (1, 0): its diagonal local tiles are lower tiles, never read
-            sfor<0, NL>([&](auto Ic) {
-                constexpr int I = decltype(Ic)::value;
-                acc[lt(I, I)] = f32x4{0.f, 0.f, 0.f, 0.f};
-            });
-        }
-        // ---- the 128 x 128 system through this file's blocked solver -----------------------------
-        float minpiv = 3.0e38f;
-#ifdef LK_BLK_PHASES
-        unsigned ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-        const int rot = (int)(task & 3);
-        chol_all<8>(acc, lds, tid, lane, wave, wr, wc, rot, minpiv LK_BP_PASS,
-                    std::make_integer_sequence<int, 8>{});
-        back_all<8>(acc, lds, lane, wave, wr, wc, rot, std::make_integer_sequence<int, 8>{});
-        // g_j = w_j - sv_j u'_j
-        bool bad = !(minpiv > 0.f);
-        if (tid < WB128_N) {
-            const float g = s_w[tid] - s_sv[tid] * lds[C::OFF_X + primed(tid)];
-            s_g[tid] = tid < n ? g : 0.f;
-            bad = bad || !(fabsf(g) <= 3.0e38f);
-        }
-        __syncthreads();
-        // ---- x = sum_j g_j z_j (thread = feature) ---------------------------------------------------
-        float x = 0.f;
-        for (int j = 0; j < n; ++j) x = fmaf(s_g[j], z[(int64_t)s_col[j] * KF + tid], x);
-        const float old = xrow[tid];
-        xrow[tid] = x;
-        const float d = x - old;
-        const float d2 = wave_sum(d * d);
-        if (lane == 0) lds[C::OFF_RED + wave] = d2;
-        if (__any(bad) && lane == 0) atomicCAS(status, 0, row + 1);
-        __syncthreads();
-        if (tid == 0)
-            row_delta[row] = ((lds[C::OFF_RED] + lds[C::OFF_RED + 1]) + lds[C::OFF_RED + 2]) +
-                             lds[C::OFF_RED + 3];
-        __syncthreads();  // LDS is reused by the next row
+    const int row = order[task];
+    const int64_t beg = indptr[row], end = indptr[row + 1];
+    const int n = (int)(end - beg);  // 65 .. 128 (any 1 .. 128 is handled)
+    float *xrow = this_ + (int64_t)row * KF;
+    if (tid < WB128_N) {
+        const int64_t e = beg + (tid < n ? tid : n - 1);
+        const float v = tid < n ? values[e] : 0.f;
+        s_col[tid] = indices[e];
+        s_w[tid] = tid < n ? v + 1.0f : 0.f;  // `vals += 1.0` (implicit.rs:116)
+        s_sv[tid] = __builtin_sqrtf(v);       // v < 0: NaN -> reported as not positive definite
     }
-}
-
-size_t als_wb128_scratch_bytes(int64_t n_rows_65_128)
-{
-    int64_t wgs = n_rows_65_128 < WB128_MAX_WGS ? n_rows_65_128 : WB128_MAX_WGS;
-    if (wgs < 0) wgs = 0;
-    return (size_t)wgs * WB128_SCRATCH * sizeof(float);
+    __syncthreads();
+    // ---- t = sum_j w_j z_j (thread = feature), then the right-hand side sv_i (q_i . t) -------------
+    {
+        float tf = 0.f;
+        for (int j = 0; j < n; ++j) tf = fmaf(s_w[j], z[(int64_t)s_col[j] * KF + tid], tf);
+        s_t[tid] = tf;
+    }
+    __syncthreads();
+    for (int i = wave; i < WB128_N; i += 4) {
+        float r = 0.f;
+        if (i < n) {
+            const f32x4 q4 =
+                *reinterpret_cast<const f32x4 *>(other + (int64_t)s_col[i] * KF + lane * 4);
+            r = q4.x * s_t[lane * 4] + q4.y * s_t[lane * 4 + 1] + q4.z * s_t[lane * 4 + 2] +
+                q4.w * s_t[lane * 4 + 3];
+            r = wave_sum(r);
+        }
+        if (lane == 0) lds[C::OFF_Y + i] = i < n ? s_sv[i] * r : 0.f;  // system index = entry slot
+    }
+    // ---- -S = -I - (sv q)(sv z)^T on the accumulators (upper tiles, 2 x 2 block-cyclic) ------------
+    f32x4 acc[C::T];
+    sfor<0, NL>([&](auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        sfor<0, J + 1>([&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            const bool diag = (I == J) && (wr == wc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[lt(I, J)][r] = (diag && (slot * 4 + r) == sub) ? -1.0f : 0.f;
+        });
+    });
+    {
+        // this lane's operand rows: A tiles ti = 2 I + wr, B tiles tj = 2 J + wc, entry 16 t + sub
+        const float *arow[NL], *brow[NL];
+        float asv[NL], bsv[NL];
+#pragma unroll
+        for (int I = 0; I < NL; ++I) {
+            const int ea = 16 * (2 * I + wr) + sub, eb = 16 * (2 * I + wc) + sub;
+            arow[I] = other + (int64_t)s_col[ea] * KF + 4 * slot;
+            brow[I] = z + (int64_t)s_col[eb] * KF + 4 * slot;
+            asv[I] = -s_sv[ea];  // (negated: the accumulators hold -S)
+            bsv[I] = s_sv[eb];
+        }
+        f32x4 qa[2][NL], qb[2][NL];
+        auto issue = [&](int buf, int G) {
+#pragma unroll
+            for (int I = 0; I < NL; ++I) {
+                qa[buf][I] = *reinterpret_cast<const f32x4 *>(arow[I] + 16 * G);
+                qb[buf][I] = *reinterpret_cast<const f32x4 *>(brow[I] + 16 * G);
+            }
+        };
+        auto consume = [&](int buf) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float a[NL], b[NL];
+#pragma unroll
+                for (int I = 0; I < NL; ++I) {
+                    a[I] = asv[I] * qa[buf][I][kk];
+                    b[I] = bsv[I] * qb[buf][I][kk];
+                }
+                sfor<0, NL>([&](auto Jc) {
+                    constexpr int J = decltype(Jc)::value;
+                    sfor<0, J + 1>([&](auto Ic) {
+                        constexpr int I = decltype(Ic)::value;
+                        acc[lt(I, J)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I], b[J],
+                                                                             acc[lt(I, J)], 0, 0, 0);
+                    });
+                });
+            }
+        };
+        issue(0, 0);
+        for (int G = 0; G < KF / 16; G += 2) {
+            issue(1, G + 1);
+            consume(0);
+            issue(0, G + 2 < KF / 16 ? G + 2 : G + 1);
+            consume(1);
+        }
+    }
+    if (phantom) {  // wave (1, 0): its diagonal local tiles are lower tiles, never read
+        sfor<0, NL>([&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            acc[lt(I, I)] = f32x4{0.f, 0.f, 0.f, 0.f};
+        });
+    }
+    // ---- the 128 x 128 system through this file's blocked solver -----------------------------------
+    float minpiv = 3.0e38f;
+#ifdef LK_BLK_PHASES
+    unsigned ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const int rot = (int)(task & 3);
+    chol_all<8>(acc, lds, tid, lane, wave, wr, wc, rot, minpiv LK_BP_PASS,
+                std::make_integer_sequence<int, 8>{});
+    back_all<8>(acc, lds, lane, wave, wr, wc, rot, std::make_integer_sequence<int, 8>{});
+    // g_j = w_j - sv_j u'_j
+    bool bad = !(minpiv > 0.f);
+    if (tid < WB128_N) {
+        const float g = s_w[tid] - s_sv[tid] * lds[C::OFF_X + tid];
+        s_g[tid] = tid < n ? g : 0.f;
+        bad = bad || !(fabsf(g) <= 3.0e38f);
+    }
+    __syncthreads();
+    // ---- x = sum_j g_j z_j (thread = feature) ---------------------------------------------------------
+    float x = 0.f;
+    for (int j = 0; j < n; ++j) x = fmaf(s_g[j], z[(int64_t)s_col[j] * KF + tid], x);
+    const float old = xrow[tid];
+    xrow[tid] = x;
+    const float d = x - old;
+    const float d2 = wave_sum(d * d);
+    if (lane == 0) lds[C::OFF_RED + wave] = d2;
+    if (__any(bad) && lane == 0) atomicCAS(status, 0, row + 1);
+    __syncthreads();
+    if (tid == 0)
+        row_delta[row] = ((lds[C::OFF_RED] + lds[C::OFF_RED + 1]) + lds[C::OFF_RED + 2]) +
+                         lds[C::OFF_RED + 3];
 }
 
 // -OtOr [k x k] -> primed [KP x KP] of this file's feature order, -1 on the pad diagonal
@@ -1075,7 +1051,7 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     // (65 .. 128 entries at padded k = 256: the same identity with a 128 x 128 system,
     // als_wb128_kernel; LK_ALS_WB128=0 keeps those rows on the dense kernel)
     const bool wb128 = NT == 16 && als_wb64_enabled() && als_wb128_enabled() && use_wb &&
-                       p->off_wb128 != 0 && p->t_128 < p->t_mid;
+                       p->t_128 < p->t_mid;
     const int64_t n_wb64_first = (NT == 16 && als_wb64_enabled()) ? p->t_mid : p->t_short;
     const int64_t n_dense =
         prefix ? (p->dense_limit < n_rows ? p->dense_limit : n_rows)
@@ -1090,11 +1066,9 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
         if (rc != LK_OK) return rc;
         if (wb128) {
             const int64_t nr = p->t_mid - p->t_128;
-            const int64_t wgs = nr < WB128_MAX_WGS ? nr : WB128_MAX_WGS;
-            hipLaunchKernelGGL((als_wb128_kernel<IS64>), dim3((unsigned)wgs), dim3(256), 0, st,
+            hipLaunchKernelGGL((als_wb128_kernel<IS64>), dim3((unsigned)nr), dim3(256), 0, st,
                                static_cast<const IT *>(indptr), indices, values,
-                               p->d_order + p->t_128, nr, other, z, this_, row_delta, status,
-                               reinterpret_cast<float *>(ws + p->off_wb128));
+                               p->d_order + p->t_128, nr, other, z, this_, row_delta, status);
         }
         if (own_z || shared_z)  // no-op unless spd_inverse raised its flag
             hipLaunchKernelGGL((als_blk_fallback_kernel<NT, IS64>), dim3(1024), dim3(256), 0, st,

@@ -1847,10 +1847,6 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
         off += lk::align_up((size_t)KP * KP * sizeof(float), 256);
         p->off_invws = off;
         off += lk::align_up(lk::spd_inverse_workspace_bytes(KP), 256);
-        if (KP == 256 && p->t_mid > p->t_128 && !p->ref_order) {  // als_wb128_kernel's scratch
-            p->off_wb128 = off;
-            off += lk::align_up(lk::blk::als_wb128_scratch_bytes(p->t_mid - p->t_128), 256);
-        }
     }
     p->ws_bytes = off;
     *out = p;

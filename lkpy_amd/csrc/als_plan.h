@@ -33,7 +33,6 @@ struct lk_als_plan {
     int64_t t_short = 0;
     int64_t t_mid = 0;  // rows with 17 .. 64 entries are [t_mid, t_short): als_wb64_kernel
     int64_t t_128 = 0;  // rows with 65 .. 128 entries are [t_128, t_mid): als_wb128_kernel (KP = 256)
-    size_t off_wb128 = 0;  // its per-workgroup scratch (0: none)
     // rows [t_cg, n_rows) have at most 16384 / KP entries (256 / 128 / 64 at padded k = 64 /
     // 128 / 256): what the CG kernel keeps in registers over its iterations (als_cg.hip)
     int64_t t_cg = 0;
@@ -109,9 +108,6 @@ int als_big_half_epoch(const lk_als_plan *p, const void *indptr, int is64, const
 size_t gramian_big_workspace_bytes(int KP);
 int gramian_big(const float *m, int64_t n, int k, int KP, float reg, float *out, int ld_out,
                 float *ws, hipStream_t st);
-namespace blk {
-size_t als_wb128_scratch_bytes(int64_t n_rows_65_128);
-}
 // rows [t0, n_rows) of the plan order (<= 16 entries each) through the Woodbury kernel (als_wb.hip)
 int als_wb_launch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
                   const float *values, int64_t t0, int64_t n_rows, float *this_,
