@@ -92,13 +92,27 @@ __global__ __launch_bounds__(256) void als_wb_kernel(
     const float sv = __builtin_sqrtf(v);     // v < 0: NaN -> reported as not positive definite
 
     f32x4 mq[NQ], zq[NQ];
+#ifndef LK_WB_MASK_LOADS
+#define LK_WB_MASK_LOADS 1
+#endif
     {
         const f32x4 *mp = reinterpret_cast<const f32x4 *>(other + (int64_t)col * KP + s * QF);
         const f32x4 *zp = reinterpret_cast<const f32x4 *>(z + (int64_t)col * KP + s * QF);
+        // Entry slots >= n carry zero weights: their lanes used to re-read the last entry's rows
+        // (L1 hits, but 64 lanes x 32 float4 = 32 KiB through the texture path per row whatever
+        // n -- a quarter of the kernel at cfg5's 9.4 M user rows of 2.3 entries).  ONE branch
+        // around the whole batch of loads: the idle slots issue no memory request at all.
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) mq[q] = mp[q];
+        for (int q = 0; q < NQ; ++q) {
+            mq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            zq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!LK_WB_MASK_LOADS || c < n) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) zq[q] = zp[q];
+            for (int q = 0; q < NQ; ++q) mq[q] = mp[q];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) zq[q] = zp[q];
+        }
     }
     // S0[i][j] = q_i . z_j : lane (s', c') register r = S0[4 s' + r][c']
     f32x4 S0 = f32x4{0.f, 0.f, 0.f, 0.f};
