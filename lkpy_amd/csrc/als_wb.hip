@@ -93,15 +93,15 @@ __global__ __launch_bounds__(256) void als_wb_kernel(
 
     f32x4 mq[NQ], zq[NQ];
 #ifndef LK_WB_MASK_LOADS
-#define LK_WB_MASK_LOADS 1
+#define LK_WB_MASK_LOADS 0  // measured (cfg5, round 4): 1 = 247.0 ms/epoch, 0 = 238.4
 #endif
     {
         const f32x4 *mp = reinterpret_cast<const f32x4 *>(other + (int64_t)col * KP + s * QF);
         const f32x4 *zp = reinterpret_cast<const f32x4 *>(z + (int64_t)col * KP + s * QF);
-        // Entry slots >= n carry zero weights: their lanes used to re-read the last entry's rows
-        // (L1 hits, but 64 lanes x 32 float4 = 32 KiB through the texture path per row whatever
-        // n -- a quarter of the kernel at cfg5's 9.4 M user rows of 2.3 entries).  ONE branch
-        // around the whole batch of loads: the idle slots issue no memory request at all.
+        // Entry slots >= n carry zero weights and re-read the last entry's rows (L1 hits: 32 KiB
+        // through the texture path per row whatever n).  Putting ONE branch around the batch of
+        // loads so that idle slots issue no request (LK_WB_MASK_LOADS=1) is SLOWER -- cfg5 247.0 vs
+        // 238.4 ms/epoch: the divergent region costs more than the redundant L1 hits.
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             mq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
