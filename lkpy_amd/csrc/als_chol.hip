@@ -1313,45 +1313,66 @@ __global__ __launch_bounds__(256) void als_wb64_kernel(
                             mq[ti][el], zq[tj][el], acc[ti][tj], 0, 0, 0);
                 }
     }
-    // S = I + diag(sv) S0 diag(sv) (upper tiles) and the right-hand side sv o (S0 w)
-    Gram<4> G;
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-        float svr[4], rhs[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            svr[r] = __shfl(sv[ti], 4 * s + r, 64);  // sqrt(v) of row 16 ti + 4 s + r
-            float r0 = 0.f;
-#pragma unroll
-            for (int tj = 0; tj < 4; ++tj) r0 += wb_row16_sum(acc[ti][tj][r] * w[tj]);
-            rhs[r] = svr[r] * r0;
-        }
-#pragma unroll
-        for (int tj = ti; tj < 4; ++tj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                G.t[tidx(ti, tj)][r] = svr[r] * sv[tj] * acc[ti][tj][r] +
-                                       ((ti == tj && (4 * s + r) == c) ? 1.0f : 0.f);
-        // rhs of row 16 ti + c for every lane: it sits in row group c >> 2, register c & 3
-        float sel = rhs[0];
-        sel = (c & 3) == 1 ? rhs[1] : sel;
-        sel = (c & 3) == 2 ? rhs[2] : sel;
-        sel = (c & 3) == 3 ? rhs[3] : sel;
-        G.y[ti] = __shfl(sel, (c >> 2) * 16 + c, 64);
-    }
+    // S = I + diag(sv) S0 diag(sv) (upper tiles) and the right-hand side sv o (S0 w); rows with
+    // at most 32 entries (round 4: most of the 17 .. 64 range) are a 32 x 32 system -- the k = 32
+    // instance of the hybrid solver, a quarter of the factorisation work
     float b;
+    float minpiv;
+    auto build = [&](auto &G, auto ntc) {
+        constexpr int NTS = decltype(ntc)::value;
+#pragma unroll
+        for (int ti = 0; ti < NTS; ++ti) {
+            float svr[4], rhs[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                svr[r] = __shfl(sv[ti], 4 * s + r, 64);  // sqrt(v) of row 16 ti + 4 s + r
+                float r0 = 0.f;
+#pragma unroll
+                for (int tj = 0; tj < NTS; ++tj) r0 += wb_row16_sum(acc[ti][tj][r] * w[tj]);
+                rhs[r] = svr[r] * r0;
+            }
+#pragma unroll
+            for (int tj = ti; tj < NTS; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    G.t[tidx(ti, tj)][r] = svr[r] * sv[tj] * acc[ti][tj][r] +
+                                           ((ti == tj && (4 * s + r) == c) ? 1.0f : 0.f);
+            // rhs of row 16 ti + c for every lane: it sits in row group c >> 2, register c & 3
+            float sel = rhs[0];
+            sel = (c & 3) == 1 ? rhs[1] : sel;
+            sel = (c & 3) == 2 ? rhs[2] : sel;
+            sel = (c & 3) == 3 ? rhs[3] : sel;
+            G.y[ti] = __shfl(sel, (c >> 2) * 16 + c, 64);
+        }
+    };
 #ifdef LK_ALS_PHASES
     unsigned long long tmid_unused = 0;
-    const float minpiv = hybrid_solve<4>(G, b, lds, &tmid_unused);
-#else
-    const float minpiv = hybrid_solve<4>(G, b, lds);
 #endif
+    if (nte <= 2) {  // wave-uniform
+        Gram<2> G;
+        build(G, std::integral_constant<int, 2>{});
+#ifdef LK_ALS_PHASES
+        minpiv = hybrid_solve<2>(G, b, lds, &tmid_unused);
+#else
+        minpiv = hybrid_solve<2>(G, b, lds);
+#endif
+    } else {
+        Gram<4> G;
+        build(G, std::integral_constant<int, 4>{});
+#ifdef LK_ALS_PHASES
+        minpiv = hybrid_solve<4>(G, b, lds, &tmid_unused);
+#else
+        minpiv = hybrid_solve<4>(G, b, lds);
+#endif
+    }
     // b = u' of entry `lane`;  g_e = w_e - sv_e u'_e for this lane's four entries
     float g[4];
     bool bad = !(minpiv > 0.f);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        g[t] = w[t] - sv[t] * __shfl(b, 16 * t + c, 64);
+        // (tiles past the row's entries -- and, for a 32 x 32 system, lanes the solver did not
+        // define -- carry no weight)
+        g[t] = t < nte ? w[t] - sv[t] * __shfl(b, 16 * t + c, 64) : 0.f;
         bad = bad || !(fabsf(g[t]) <= 3.0e38f);
     }
     if (__any(bad) && lane == 0) atomicCAS(status, 0, row + 1);
