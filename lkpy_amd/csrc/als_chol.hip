@@ -1282,8 +1282,15 @@ __global__ __launch_bounds__(256) void als_wb64_kernel(
         const float v = el < n ? values[e] : 0.f;
         w[t] = el < n ? v + 1.0f : 0.f;
         sv[t] = __builtin_sqrtf(v);
-        mrow[t] = other + (int64_t)col * KP + s * QF;
-        zrow[t] = z + (int64_t)col * KP + s * QF;
+        // Feature interleave (round 4): step q covers features 16 q .. 16 q + 15 and lane (s, c)
+        // takes 4 s .. 4 s + 3 of them, so the four lanes of an entry slot read 64 CONTIGUOUS
+        // bytes of the gathered row per step.  (Rounds 2-3 gave lane (s, c) the quarter
+        // [64 s, 64 s + 64): 16 bytes per 128-byte line and step, each line revisited on 8
+        // steps -- with 230 MB of rows in flight they did not survive in L2: FETCH_SIZE 164 GB per
+        // cfg5 item half for 32 GB of rows, the kernel ran at 6.6 TB/s of HBM traffic.)  MFMA
+        // step el then contracts features {16 q + el, + 4, + 8, + 12} on BOTH operands.
+        mrow[t] = other + (int64_t)col * KP + 4 * s;
+        zrow[t] = z + (int64_t)col * KP + 4 * s;
     }
     // pass 1: S0 tiles, acc[ti][tj] lane (s', c') register r = S0[16 ti + 4 s' + r][16 tj + c']
     f32x4 acc[4][4];
@@ -1298,8 +1305,8 @@ __global__ __launch_bounds__(256) void als_wb64_kernel(
             mq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             zq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (t < nte) {
-                mq[t] = *reinterpret_cast<const f32x4 *>(mrow[t] + 4 * q);
-                zq[t] = *reinterpret_cast<const f32x4 *>(zrow[t] + 4 * q);
+                mq[t] = *reinterpret_cast<const f32x4 *>(mrow[t] + 16 * q);
+                zq[t] = *reinterpret_cast<const f32x4 *>(zrow[t] + 16 * q);
             }
         }
 #pragma unroll
@@ -1383,7 +1390,7 @@ __global__ __launch_bounds__(256) void als_wb64_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             if (t < nte) {
-                const f32x4 zq = *reinterpret_cast<const f32x4 *>(zrow[t] + 4 * q);
+                const f32x4 zq = *reinterpret_cast<const f32x4 *>(zrow[t] + 16 * q);
                 a4.x = fmaf(g[t], zq.x, a4.x);
                 a4.y = fmaf(g[t], zq.y, a4.y);
                 a4.z = fmaf(g[t], zq.z, a4.z);
@@ -1395,7 +1402,7 @@ __global__ __launch_bounds__(256) void als_wb64_kernel(
         xs.z = wb_row16_sum(a4.z);
         xs.w = wb_row16_sum(a4.w);
         if (c == 0) {
-            f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + s * QF + 4 * q);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + 4 * s + 16 * q);
             const f32x4 old = *dst;
             *dst = xs;
             const f32x4 d = xs - old;
