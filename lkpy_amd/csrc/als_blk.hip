@@ -974,6 +974,13 @@ __global__ void als_blk_prep_otor_kernel(const float *__restrict__ otor, int ld_
     notor_p[idx] = v;
 }
 
+// LK_ALS_WB4=0: rows with <= 4 entries take the wave-per-row kernel too (A/B timing, tests)
+static bool als_wb4_enabled()
+{
+    const char *e = getenv("LK_ALS_WB4");
+    return !(e && e[0] == '0');
+}
+
 // LK_ALS_WB128=0: rows with 65 .. 128 entries stay on the dense kernel (A/B timing, tests)
 static bool als_wb128_enabled()
 {
@@ -1057,8 +1064,13 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
         prefix ? (p->dense_limit < n_rows ? p->dense_limit : n_rows)
                : (use_wb ? (wb128 ? p->t_128 : n_wb64_first) : n_rows);
     if (use_wb) {
-        int rc = als_wb_launch(p, indptr, IS64 ? 1 : 0, indices, values, p->t_short, n_rows,
-                               this_, other, z, row_delta, status, st);
+        // <= 4 entries (and empty rows): four rows per wave; 5 .. 16: a wave per row
+        const int64_t t4 = als_wb4_enabled() ? p->t_4 : n_rows;
+        int rc = als_wb_launch(p, indptr, IS64 ? 1 : 0, indices, values, p->t_short, t4, this_,
+                               other, z, row_delta, status, st);
+        if (rc != LK_OK) return rc;
+        rc = als_wb4_launch(p, indptr, IS64 ? 1 : 0, indices, values, t4, n_rows, this_, other,
+                            z, row_delta, status, st);
         if (rc != LK_OK) return rc;
         // rows with 17 .. 64 entries: the same identity with a 64 x 64 system
         rc = als_wb64_launch(p, indptr, IS64 ? 1 : 0, indices, values, n_wb64_first, p->t_short,

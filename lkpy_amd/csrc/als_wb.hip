@@ -228,7 +228,200 @@ __global__ __launch_bounds__(256) void als_wb_kernel(
     if (lane == 0) row_delta[row] = d2;
 }
 
+// ---- FOUR rows per wave for rows with at most 4 entries (round 4) ---------------------------------
+// 82 % of cfg5's 10^7 user rows have <= 4 entries.  als_wb_kernel spends a whole wave on each --
+// 16 entry slots of which 2.3 are in use on average; at 9.4 M rows the kernel is bound by its
+// instruction stream and the dependent latencies of a row (1.5 TB/s of traffic), not by memory.
+// Here entry slot c = 4 r4 + e belongs to row r4 = c >> 2 of the wave (entry e = c & 3): the same
+// loads, the same single MFMA tile -- whose four DIAGONAL 4 x 4 blocks are the four rows' S0
+// (everything off those blocks is masked to zero, so S is block diagonal and one 16-step
+// factorisation solves the four independent systems) -- the same DPP quad sums, a quarter of the
+// waves.  Empty rows (n = 0) ride along: zero weights give x = 0; their delta is forced to 0
+// (implicit.rs:98-101).
+template <int KP, bool IS64>
+__global__ __launch_bounds__(256) void als_wb4_kernel(
+    const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_tasks,
+    const float *__restrict__ other, const float *__restrict__ z, float *__restrict__ this_,
+    float *__restrict__ row_delta, int *__restrict__ status)
+{
+    constexpr int QF = KP / 4;  // features per quarter
+    constexpr int NQ = QF / 4;  // float4 per quarter
+    __shared__ __attribute__((aligned(16))) float lds_all[4][WB_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int s = lane >> 4, c = lane & 15;
+    const int r4 = c >> 2, e4 = c & 3;
+    const int64_t t = ((int64_t)blockIdx.x * 4 + wave) * 4 + r4;  // this lane's row task
+    if (((int64_t)blockIdx.x * 4 + wave) * 4 >= n_tasks) return;  // wave-uniform
+    if (status[1] != 0) return;  // Z unavailable (OtOr not positive definite): dense fallback
+    const bool have = t < n_tasks;
+    const int row = have ? order[t] : 0;
+    int64_t beg = 0;
+    int n = 0;
+    if (have) {
+        beg = indptr[row];
+        n = (int)(indptr[row + 1] - beg);  // 0 .. 4
+    }
+    float *xrow = this_ + (int64_t)row * KP;
+    float *lds = lds_all[wave];
+
+    // entry e4 of this lane's row (slots >= n: the row's last entry -- or entry 0 of the matrix
+    // for an empty row -- with zero weights)
+    const bool live = e4 < n;
+    const int64_t e = n > 0 ? beg + (live ? e4 : n - 1) : 0;
+    const int col = n > 0 ? indices[e] : 0;  // (an empty row reads factor row 0 with zero weights)
+    const float v = live ? values[e] : 0.f;
+    const float w = live ? v + 1.0f : 0.f;  // `vals += 1.0` (implicit.rs:116)
+    const float sv = __builtin_sqrtf(v);    // v < 0: NaN -> reported as not positive definite
+
+    f32x4 mq[NQ], zq[NQ];
+    {
+        const f32x4 *mp = reinterpret_cast<const f32x4 *>(other + (int64_t)col * KP + s * QF);
+        const f32x4 *zp = reinterpret_cast<const f32x4 *>(z + (int64_t)col * KP + s * QF);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) mq[q] = mp[q];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) zq[q] = zp[q];
+    }
+    // S0[i][j] = q_i . z_j : lane (s', c') register r = S0[4 s' + r][c']; only the diagonal 4 x 4
+    // blocks (4 s' + r and c' in the same row of the wave, i.e. c' >> 2 == s') mean anything
+    f32x4 S0 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int el = 0; el < 4; ++el)
+            S0 = __builtin_amdgcn_mfma_f32_16x16x4f32(mq[q][el], zq[q][el], S0, 0, 0, 0);
+    const bool inblock = r4 == s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S0[r] = inblock ? S0[r] : 0.f;
+
+    float r0[4], svi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        r0[r] = row_sum<2>(S0[r] * w);  // over the row's 4 entry slots (quad), result in e4 == 0
+        svi[r] = __shfl(sv, 4 * s + r, 64);
+    }
+    f32x4 Sm;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Sm[r] = svi[r] * sv * S0[r] + ((4 * s + r) == c ? 1.0f : 0.f);
+    *reinterpret_cast<f32x4 *>(&lds[c * 16 + 4 * s]) = Sm;
+    // right-hand side of system rows 4 s .. 4 s + 3: held by the lane (s, c = 4 s) -- the quad
+    // leader of the diagonal block
+    if (c == 4 * s)
+        *reinterpret_cast<f32x4 *>(&lds[256 + 4 * s]) =
+            f32x4{svi[0] * r0[0], svi[1] * r0[1], svi[2] * r0[2], svi[3] * r0[3]};
+
+    // lane = row (lanes 0..15): right-looking Cholesky with the forward substitution folded in
+    float a[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 tq = *reinterpret_cast<const f32x4 *>(&lds[(lane & 15) * 16 + 4 * q]);
+        a[4 * q + 0] = tq.x;
+        a[4 * q + 1] = tq.y;
+        a[4 * q + 2] = tq.z;
+        a[4 * q + 3] = tq.w;
+    }
+    float b = lds[256 + (lane & 15)];
+    float dinv = 0.f, mypiv = 1.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float piv = bcast(a[j], j);
+        mypiv = (lane == j) ? piv : mypiv;
+        const float rinv = __builtin_amdgcn_rsqf(piv);
+        dinv = (lane == j) ? rinv : dinv;
+        const float lj = (lane > j && lane < 16) ? a[j] * rinv : 0.f;
+        const float zj = bcast(b, j) * rinv;
+        b = fmaf(-lj, zj, b);
+        // (S is block diagonal: only the columns of the same 4 x 4 block can be non-zero)
+#pragma unroll
+        for (int cc = j + 1; cc < (j | 3) + 1; ++cc) a[cc] = fmaf(-lj, bcast(lj, cc), a[cc]);
+        a[j] = lj;  // row `lane` of L, strictly lower part
+    }
+    b *= dinv;  // z of L z = rhs
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 tq;
+        tq.x = (4 * q + 0 < lane) ? a[4 * q + 0] : 0.f;
+        tq.y = (4 * q + 1 < lane) ? a[4 * q + 1] : 0.f;
+        tq.z = (4 * q + 2 < lane) ? a[4 * q + 2] : 0.f;
+        tq.w = (4 * q + 3 < lane) ? a[4 * q + 3] : 0.f;
+        if (lane < 16) *reinterpret_cast<f32x4 *>(&lds[lane * 16 + 4 * q]) = tq;
+    }
+    float lt[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) lt[j] = lds[j * 16 + (lane & 15)];  // L[j][lane], 0 for j <= lane
+#pragma unroll
+    for (int j = 15; j >= 1; --j) {
+        const float xj = bcast(b * dinv, j);
+        b = fmaf(-lt[j], xj, b);
+    }
+    b *= dinv;  // u' of S u' = sv o r0, lane j < 16
+    float g = w - sv * b;  // lanes 0..15 hold entry slot j = lane
+    g = __shfl(g, c, 64);
+    // not positive definite / NaN: reported with the row of the slot's block
+    {
+        const bool badc = lane < 16 && (!(mypiv > 0.f) || !(fabsf(w - sv * b) <= 3.0e38f));
+        if (badc && have) atomicCAS(status, 0, row + 1);
+    }
+
+    // x = sum over the row's 4 entry slots of g z: quad sums, the quad leader writes its quarter
+    float d2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        f32x4 xs;
+        xs.x = row_sum<2>(g * zq[q].x);
+        xs.y = row_sum<2>(g * zq[q].y);
+        xs.z = row_sum<2>(g * zq[q].z);
+        xs.w = row_sum<2>(g * zq[q].w);
+        if (e4 == 0 && have) {
+            f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + s * QF + 4 * q);
+            const f32x4 old = *dst;
+            *dst = xs;
+            const f32x4 d = xs - old;
+            d2 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+        }
+    }
+    // the row's delta: its four quarter leaders are the lanes (s = 0..3, c = 4 r4)
+    float tot = 0.f;
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) tot += __shfl(d2, 16 * ss + 4 * r4, 64);
+    if (s == 0 && e4 == 0 && have) row_delta[row] = n > 0 ? tot : 0.f;  // implicit.rs:98-101
+}
+
 }  // namespace wb
+
+// rows [t0, n_rows) of the plan order (n <= 4 entries each, empty rows included), four per wave
+int als_wb4_launch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
+                   const float *values, int64_t t0, int64_t n_rows, float *this_,
+                   const float *other, const float *z, float *row_delta, int *status,
+                   hipStream_t st)
+{
+    const int64_t n = n_rows - t0;
+    if (n <= 0) return LK_OK;
+    const dim3 grid((unsigned)((n + 15) / 16)), block(256);
+#define LK_WB4(KPV, IS)                                                                         \
+    hipLaunchKernelGGL((wb::als_wb4_kernel<KPV, IS>), grid, block, 0, st,                       \
+                       static_cast<const typename IndPtr<IS>::type *>(indptr), indices, values, \
+                       p->d_order + t0, n, other, z, this_, row_delta, status)
+    if (p->KP == 256) {
+        if (is64)
+            LK_WB4(256, true);
+        else
+            LK_WB4(256, false);
+    } else if (p->KP == 128) {
+        if (is64)
+            LK_WB4(128, true);
+        else
+            LK_WB4(128, false);
+    } else {
+        set_error("Woodbury row solve: unsupported padded embedding size %d", p->KP);
+        return LK_E_INVALID;
+    }
+#undef LK_WB4
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
 
 // rows [t0, n_rows) of the plan order (n <= 16 entries each) through the Woodbury kernel
 int als_wb_launch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
