@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void als_wb_kernel(
         *reinterpret_cast<f32x4 *>(&lds[256 + 4 * s]) =
             f32x4{svi[0] * r0[0], svi[1] * r0[1], svi[2] * r0[2], svi[3] * r0[3]};
 
+    wave_lds_sync();
     // lane = row (lanes 0..15): right-looking Cholesky with the forward substitution folded in
     float a[16];
 #pragma unroll
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256) void als_wb_kernel(
         tq.w = (4 * q + 3 < lane) ? a[4 * q + 3] : 0.f;
         if (lane < 16) *reinterpret_cast<f32x4 *>(&lds[lane * 16 + 4 * q]) = tq;
     }
+    wave_lds_sync();
     float lt[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) lt[j] = lds[j * 16 + (lane & 15)];  // L[j][lane], 0 for j <= lane
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(256) void als_wb4_kernel(
         *reinterpret_cast<f32x4 *>(&lds[256 + 4 * s]) =
             f32x4{svi[0] * r0[0], svi[1] * r0[1], svi[2] * r0[2], svi[3] * r0[3]};
 
+    wave_lds_sync();
     // lane = row (lanes 0..15): right-looking Cholesky with the forward substitution folded in
     float a[16];
 #pragma unroll
@@ -324,6 +327,12 @@ __global__ __launch_bounds__(256) void als_wb4_kernel(
     }
     float b = lds[256 + (lane & 15)];
     float dinv = 0.f, mypiv = 1.0f;
+#ifdef LK_WB4_DEBUG
+    const float dbg_rhs = b;
+    float dbg_diag = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dbg_diag = (lane == j) ? a[j] : dbg_diag;
+#endif
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const float piv = bcast(a[j], j);
@@ -348,6 +357,7 @@ __global__ __launch_bounds__(256) void als_wb4_kernel(
         tq.w = (4 * q + 3 < lane) ? a[4 * q + 3] : 0.f;
         if (lane < 16) *reinterpret_cast<f32x4 *>(&lds[lane * 16 + 4 * q]) = tq;
     }
+    wave_lds_sync();
     float lt[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) lt[j] = lds[j * 16 + (lane & 15)];  // L[j][lane], 0 for j <= lane
@@ -358,6 +368,21 @@ __global__ __launch_bounds__(256) void als_wb4_kernel(
     }
     b *= dinv;  // u' of S u' = sv o r0, lane j < 16
     float g = w - sv * b;  // lanes 0..15 hold entry slot j = lane
+#ifdef LK_WB4_DEBUG
+    {  // dump of the wave's system into the x row of the wave's first task
+        float *dbg = this_ + (int64_t)__builtin_amdgcn_readfirstlane(row) * KP;
+        if (lane < 16) {
+            dbg[lane] = b;
+            dbg[16 + lane] = dbg_rhs;
+            dbg[32 + lane] = mypiv;
+            dbg[48 + lane] = sv;
+            dbg[64 + lane] = w;
+            dbg[80 + lane] = dinv;
+            dbg[96 + lane] = dbg_diag;
+        }
+        return;
+    }
+#endif
     g = __shfl(g, c, 64);
     // not positive definite / NaN: reported with the row of the slot's block
     {

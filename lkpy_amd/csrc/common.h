@@ -73,6 +73,18 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// Lanes of ONE wave exchanging data through LDS: the hardware keeps a wave's LDS operations in
+// order, but to the compiler a store by one lane and a load of the same address by another are
+// unrelated -- it may move the load above the store (seen in als_wb4_kernel: stale right-hand
+// sides).  Wavefront-scope release / acquire fences around a wave barrier cost no instruction
+// and pin the order.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // broadcast lane `src` (compile-time or wave-uniform) of v
 __device__ __forceinline__ float bcast(float v, int src)
 {
