@@ -55,9 +55,14 @@ WB_MAX_N = 128  # rows this short take the Woodbury kernels at padded k = 256 (c
 
 
 def _wb_max(k: int) -> int:
-    "longest row the Woodbury kernels take: 128 entries at padded k = 256, 16 at padded k = 128"
+    """longest row the Woodbury kernels take: 128 entries at padded k = 256; at padded k = 128
+    64 (LK_ALS_WB64_K128, csrc/als_plan.h: 32 x 32 / 64 x 64 systems of als_wb64_kernel), 16
+    with LK_ALS_WB64=0"""
     if k <= 128:
-        return 16
+        if os.environ.get("LK_ALS_WB64", "1") == "0":
+            return 16
+        lim = int(os.environ.get("LK_ALS_WB64_K128", "64"))
+        return 64 if lim >= 64 else (32 if lim >= 32 else 16)
     return WB_MAX_N if os.environ.get("LK_ALS_WB128", "1") != "0" else 64
 
 

@@ -265,10 +265,11 @@ class ALSPlan:
         # when there are enough of them to pay for Z = other @ OtOr^-1 (LK_ALS_WB_MIN_ROWS; 0
         # disables)
         self.short_rows = int(lib.lk_als_plan_short_rows(self._h))        # <= 16 entries
-        self.woodbury_rows = int(lib.lk_als_plan_woodbury_rows(self._h))  # <= 64 entries
+        # rows the Woodbury kernels take: <= 64 entries at padded k = 256 (<= 128 with the
+        # 128 x 128 variant, counted by the caller); at k = 128 <= 16, or <= 32 / 64 with
+        # LK_ALS_WB64_K128 (the library applies the same rule)
+        self.woodbury_rows = int(lib.lk_als_plan_woodbury_rows(self._h))
         wb_min = int(os.environ.get("LK_ALS_WB_MIN_ROWS", "4096"))
-        if self.kp < 256:
-            self.woodbury_rows = self.short_rows  # k = 128: only the 16 x 16 variant pays
         self.use_wb = (64 < self.kp <= 256 and self.solver == _native.SOLVER_CHOLESKY
                        and wb_min > 0 and self.woodbury_rows >= wb_min)
         self._negative_values = None  # not scanned yet (one reduction + one host sync)

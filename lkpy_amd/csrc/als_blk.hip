@@ -207,14 +207,16 @@ __device__ __forceinline__ void ops_consume(f32x4 (&acc)[Cfg<NT>::T], float (&ya
 #ifndef LK_BLK_RING16
 #define LK_BLK_RING16 2  // k = 256: 17 registers per step, the register file is full
 #endif
-template <int NT, bool EXPL>
+#ifndef LK_BLK_RING16_CHUNK
+#define LK_BLK_RING16_CHUNK LK_BLK_RING16  // the chunk kernel (no factorisation state to keep)
+#endif
+template <int NT, bool EXPL, int D = (NT == 16 ? LK_BLK_RING16 : LK_BLK_RING8)>
 __device__ __forceinline__ void gram_accumulate(f32x4 (&acc)[Cfg<NT>::T], float (&yacc)[NT / 2],
                                                 const int32_t *__restrict__ cols,
                                                 const float *__restrict__ vals, int64_t beg,
                                                 int64_t end, const float *__restrict__ other,
                                                 int lane, int wr, int wc)
 {
-    constexpr int D = NT == 16 ? LK_BLK_RING16 : LK_BLK_RING8;
     const int64_t last = end - 1;  // end > beg
     if constexpr (D == 0) {
         for (int64_t base = beg; base < end; base += 64) {
@@ -292,8 +294,8 @@ __global__ __launch_bounds__(256) void als_blk_chunk_kernel(
 #pragma unroll
     for (int i = 0; i < C::NL; ++i) yacc[i] = 0.f;
     const int64_t beg = chunk_beg[c];
-    gram_accumulate<NT, EXPL>(acc, yacc, indices, values, beg, beg + chunk_len[c], other, lane, wr,
-                              wc);
+    gram_accumulate<NT, EXPL, (NT == 16 ? LK_BLK_RING16_CHUNK : LK_BLK_RING8)>(
+        acc, yacc, indices, values, beg, beg + chunk_len[c], other, lane, wr, wc);
     float *slab = slabs + (size_t)c * C::SLAB + (size_t)wave * C::SLAB_WAVE;
 #pragma unroll
     for (int t = 0; t < C::T; ++t)
@@ -301,6 +303,196 @@ __global__ __launch_bounds__(256) void als_blk_chunk_kernel(
         for (int r = 0; r < 4; ++r) slab[(t * 4 + r) * 64 + lane] = acc[t][r];
 #pragma unroll
     for (int i = 0; i < C::NL; ++i) slab[(C::T * 4 + i) * 64 + lane] = yacc[i];
+}
+
+// ---- the chunk kernel at k = 256 with the gathered rows staged through LDS --------------------
+//
+// At cfg5 the chunked rows of the item half gather 6 x 10^7 user rows of 1 KiB out of a 10 GB
+// table: no reuse (TCC hit rate 23 %), 57 GB from HBM in 36 ms = 1.6 TB/s.  als_blk_chunk_kernel
+// keeps the operands of two MFMA steps per wave in flight -- 16 KiB per CU, 4 MB over the chip,
+// a quarter of what 8 TB/s x 2 us of latency asks for -- and every row is requested four times
+// (once per wave, L1-served).  Here a row is requested ONCE, by `global_load_lds_dwordx4` (a
+// wave's instruction moves the whole 1 KiB row, no VGPR involved), into a ring of 4 stages of 16
+// rows (64 KiB of LDS, two workgroups per CU): three stages = 48 KiB per workgroup are in flight
+// while one is consumed, six times the bytes in flight of the register ring.  One barrier per
+// stage publishes everyone's rows and frees the slot consumed before.
+// The LDS side of such a load is linear in the lane, so the bank swizzle sits on the GLOBAL side:
+// position p = 4 s + i of a row holds its 16-byte chunk 4 s + (i ^ (s >> 2)); the operand fetch of
+// the 16 lanes of an entry (chunk 4 s + m, s = 0..15, m fixed per wave role and half) then covers
+// 16 different 4-bank groups.  Same MFMA sequence per entry group as ops_consume above: the
+// slabs are bit-identical to als_blk_chunk_kernel's.
+#ifndef LK_BLK_CHUNK_DMA_STAGES
+#define LK_BLK_CHUNK_DMA_STAGES 4
+#endif
+// lane l: 16 (4) bytes from `src` to LDS byte address lds + 16 l (4 l)
+__device__ __forceinline__ void blk_dma16(const void *src, unsigned lds_byte_addr)
+{
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_byte_addr)
+        : "memory");
+}
+__device__ __forceinline__ void blk_dma4(const void *src, unsigned lds_byte_addr)
+{
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_byte_addr)
+        : "memory");
+}
+// LDS (dynamic): the row ring, then per wave 4 batch slots of [64 columns | 64 values]
+constexpr int CHUNK_DMA_RING_FLOATS = LK_BLK_CHUNK_DMA_STAGES * 16 * 256;
+constexpr int CHUNK_DMA_META_FLOATS = 4 /* waves */ * 4 /* slots */ * 128;
+constexpr size_t CHUNK_DMA_LDS_BYTES = (size_t)(CHUNK_DMA_RING_FLOATS + CHUNK_DMA_META_FLOATS) * 4;
+
+// Every memory operation of the main loop is a DMA issued by inline asm, invisible to hipcc's
+// s_waitcnt insertion -- on purpose: a compiler-counted load among them would be waited for with
+// a count that ignores the younger DMAs, i.e. by draining the ring.  So the column indices and
+// values of a 64-entry batch also arrive by DMA (`global_load_lds_dword`, wave-private slots: no
+// cross-wave ordering to think about), two batches ahead, and all vmcnt waits are explicit:
+// per wave and batch the queue holds, in issue order,
+//     [barrier of stage 4b]   meta(b + 2) x 2, rows(4b + 3) x 4
+//     [barrier of stage 4b+1] rows(4b + 4) x 4   ... +2: rows(4b + 5), +3: rows(4b + 6)
+// so "the rows of stage k have landed" is vmcnt <= 8 (the two younger stages), + 2 where the
+// meta pair was issued in between (stages 4b + 1 and 4b + 2).
+template <bool EXPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void als_blk_chunk_dma_kernel(
+    const int32_t *__restrict__ indices, const float *__restrict__ values,
+    const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_len,
+    const float *__restrict__ other, float *__restrict__ slabs)
+{
+    constexpr int NT = 16;
+    using C = Cfg<NT>;
+    static_assert(LK_BLK_CHUNK_DMA_STAGES == 4, "the slot of a stage is its index within the 64-entry batch");
+    extern __shared__ __attribute__((aligned(1024))) float chunk_dma_lds[];
+    float *ring = chunk_dma_lds;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int wr = wave & 1, wc = wave >> 1;
+    float *meta = chunk_dma_lds + CHUNK_DMA_RING_FLOATS + wave * 512;  // this wave's 4 slots
+    const int64_t c = blockIdx.x;
+    f32x4 acc[C::T];
+    float yacc[C::NL];
+#pragma unroll
+    for (int t = 0; t < C::T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) yacc[i] = 0.f;
+    const int64_t beg = chunk_beg[c];
+    const int len = chunk_len[c];  // >= 1
+    const int64_t end = beg + len, last = end - 1;
+    const int n_stage = (len + 15) >> 4;
+    const unsigned ring_lds = (unsigned)(uintptr_t) reinterpret_cast<void *>(ring);
+    const unsigned meta_lds = (unsigned)(uintptr_t) reinterpret_cast<void *>(meta);
+
+    // this lane's 16 bytes of a row on the global side (see the swizzle above) ...
+    const int ds_ = lane >> 2, di_ = lane & 3;
+    const uint64_t lane_src =
+        (uint64_t)(uintptr_t)other + (uint64_t)(16 * (4 * ds_ + (di_ ^ (ds_ >> 2))));
+    // ... and the operand positions of lane (entry e = lane >> 4, element s = lane & 15)
+    const int s = lane & 15, e4 = lane >> 4;
+    const float *rd = ring + e4 * 256 + 16 * s;
+    const int xa0 = 4 * ((2 * wr) ^ (s >> 2)), xa1 = 4 * ((2 * wr + 1) ^ (s >> 2));
+    const int xb0 = 4 * ((2 * wc) ^ (s >> 2)), xb1 = 4 * ((2 * wc + 1) ^ (s >> 2));
+
+    // columns / values of batch b (entries beg + 64 b ..; past the end: the last entry) -> slot b & 3
+    auto issue_meta = [&](int b) {
+        const int64_t e0 = beg + 64 * (int64_t)b + lane;
+        const int64_t e = e0 < end ? e0 : last;
+        const unsigned dst = meta_lds + (unsigned)(b & 3) * 512u;
+        blk_dma4(indices + e, dst);
+        blk_dma4(values + e, dst + 256u);
+    };
+    // wave w brings row 4 g + w of the stage (g = 0..3); `j` = the stage's index in batch b
+    auto issue_stage = [&](int b, int j) {
+        const int *cols = reinterpret_cast<const int *>(meta + (b & 3) * 128);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const unsigned col = (unsigned)__builtin_amdgcn_readfirstlane(cols[16 * j + 4 * g + wave]);
+            blk_dma16(reinterpret_cast<const void *>(lane_src + (uint64_t)col * 1024ull),
+                      ring_lds + (unsigned)(j * 16 + 4 * g + wave) * 1024u);
+        }
+    };
+    auto fetch = [&](Ops<NT> &o, int b, int j, int g) {
+        const float *p = rd + (j * 16 + 4 * g) * 256;
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(p + xa0);
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(p + xa1);
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(p + xb0);
+        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(p + xb1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o.qa[i] = a0[i];
+            o.qa[4 + i] = a1[i];
+            o.qb[i] = b0[i];
+            o.qb[4 + i] = b1[i];
+        }
+        o.v = meta[(b & 3) * 128 + 64 + 16 * j + 4 * g + e4];
+    };
+
+    issue_meta(0);
+    issue_meta(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (j < n_stage) issue_stage(0, j);
+
+    for (int k0 = 0, b = 0; k0 < n_stage; k0 += 4, ++b) {
+        sfor<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int k = k0 + j;
+            if (k < n_stage) {  // workgroup-uniform
+                const int ahead = n_stage - 1 - k;
+                if (ahead >= 2) {
+                    if (j == 1 || j == 2)
+                        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                } else if (ahead == 1) {
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                // everyone's rows of stage k; everyone done with stage k - 1 (whose slot the
+                // next request overwrites)
+                asm volatile("s_barrier" ::: "memory");
+                if (j == 0) issue_meta(b + 2);  // (slot (b + 2) & 3: batch b - 2's, long consumed)
+                if (k + 3 < n_stage) {
+                    if (j == 0)
+                        issue_stage(b, 3);
+                    else
+                        issue_stage(b + 1, j - 1);
+                }
+                const int nb = len - 16 * k;  // live entries of the stage (may exceed 16)
+                Ops<NT> cur, nxt;
+                fetch(cur, b, j, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g + 1 < 4) fetch(nxt, b, j, g + 1);
+                    ops_consume<NT, EXPL>(acc, yacc, cur, (4 * g + e4) < nb);
+                    cur = nxt;
+                }
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a trailing meta request still targets our LDS)
+    float *slab = slabs + (size_t)c * C::SLAB + (size_t)wave * C::SLAB_WAVE;
+#pragma unroll
+    for (int t = 0; t < C::T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(t * 4 + r) * 64 + lane] = acc[t][r];
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) slab[(C::T * 4 + i) * 64 + lane] = yacc[i];
+}
+
+// LK_BLK_CHUNK_DMA=0: the register-ring chunk kernel at k = 256 too (A/B timing)
+static bool chunk_dma_enabled()
+{
+    const char *e = getenv("LK_BLK_CHUNK_DMA");
+    return !(e && e[0] == '0');
 }
 
 // ---- one step of the blocked factorisation ---------------------------------------------------
@@ -1022,9 +1214,28 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
                        0, st, otor, ld_otor, k, notor_p);
     const bool tm = p->timing && p->timing_n < lk_als_plan::TIMING_RING;
     if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][0], st));
-    if (p->n_chunks > 0)
-        hipLaunchKernelGGL((als_blk_chunk_kernel<NT, EXPL>), dim3((unsigned)p->n_chunks), dim3(256),
-                           0, st, indices, values, p->d_chunk_beg, p->d_chunk_len, other, slabs);
+    if (p->n_chunks > 0) {
+        bool dma = false;
+        if constexpr (NT == 16) dma = chunk_dma_enabled();
+        if (dma) {
+            if constexpr (NT == 16) {  // gathered rows staged through LDS (72 KiB, dynamic)
+                static bool attr_set = false;
+                if (!attr_set) {
+                    LK_HIP_CHECK(hipFuncSetAttribute(
+                        reinterpret_cast<const void *>(&als_blk_chunk_dma_kernel<EXPL>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHUNK_DMA_LDS_BYTES));
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL((als_blk_chunk_dma_kernel<EXPL>), dim3((unsigned)p->n_chunks),
+                                   dim3(256), CHUNK_DMA_LDS_BYTES, st, indices, values,
+                                   p->d_chunk_beg, p->d_chunk_len, other, slabs);
+            }
+        } else {
+            hipLaunchKernelGGL((als_blk_chunk_kernel<NT, EXPL>), dim3((unsigned)p->n_chunks),
+                               dim3(256), 0, st, indices, values, p->d_chunk_beg, p->d_chunk_len,
+                               other, slabs);
+        }
+    }
     {
         int rc = launch_slab_group_reduce(p, slabs, (size_t)C::SLAB, st);
         if (rc != LK_OK) return rc;
@@ -1033,10 +1244,21 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     // short rows (<= 16 entries) of the implicit model: Woodbury kernel, when the caller
     // supplied Z = other * OtOr^-1 for this half-epoch (never with a task-control block: the
     // kernel does not poll it)
+    // first task of the Woodbury kernels: rows <= 16 entries always; 17 .. 64 at padded k = 256
+    // (17 .. 32 / 64 at k = 128 with LK_ALS_WB64_K128 = 32 / 64; LK_ALS_WB64=0: none)
+    int64_t n_wb64_first = p->t_short;
+    if (als_wb64_enabled()) {
+        if (NT == 16) {
+            n_wb64_first = p->t_mid;
+        } else {
+            const int lim = wb64_k128_limit();
+            n_wb64_first = lim >= 64 ? p->t_mid : (lim >= 32 ? p->t_32 : p->t_short);
+        }
+    }
     const float *z = p->d_z;
     const bool prefix = p->dense_limit >= 0;  // CG hybrid: the chunked rows only, no Woodbury
     const bool own_z = !EXPL && p->d_zbuf != nullptr && !p->ctl &&
-                       (p->t_short < n_rows || p->z_for_others) && n_cols > 0 && !prefix;
+                       (n_wb64_first < n_rows || p->z_for_others) && n_cols > 0 && !prefix;
     if (own_z) {
         // Z = other * OtOr^-1 for this half-epoch, all on this stream: the inverse to float64
         // accuracy (spd_inverse.hip; status[1] = its flag, tested by the Woodbury kernels and by
@@ -1052,14 +1274,13 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
         LK_HIP_CHECK(hipMemcpyAsync(status + 1, p->d_zflag_src, sizeof(int),
                                     hipMemcpyDeviceToDevice, st));
     const bool shared_z = !EXPL && p->d_zflag_src != nullptr && !own_z;
-    const bool use_wb = !EXPL && z != nullptr && !p->ctl && p->t_short < n_rows && !prefix;
+    const bool use_wb = !EXPL && z != nullptr && !p->ctl && n_wb64_first < n_rows && !prefix;
     // (17 .. 64 entries: only at padded k = 256 -- at k = 128 the 64 x 64 system costs as much as
     // the dense solve of this file, measured on the ML-25M shape)
     // (65 .. 128 entries at padded k = 256: the same identity with a 128 x 128 system,
     // als_wb128_kernel; LK_ALS_WB128=0 keeps those rows on the dense kernel)
     const bool wb128 = NT == 16 && als_wb64_enabled() && als_wb128_enabled() && use_wb &&
                        p->t_128 < p->t_mid;
-    const int64_t n_wb64_first = (NT == 16 && als_wb64_enabled()) ? p->t_mid : p->t_short;
     const int64_t n_dense =
         prefix ? (p->dense_limit < n_rows ? p->dense_limit : n_rows)
                : (use_wb ? (wb128 ? p->t_128 : n_wb64_first) : n_rows);

@@ -1779,6 +1779,15 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
                 hi = mid;
         }
         p->t_mid = lo;
+        hi = p->t_short;
+        while (lo < hi) {  // first task whose row has <= 32 entries
+            const int64_t mid = (lo + hi) >> 1;
+            if (len(order[(size_t)mid]) > 32)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        p->t_32 = lo;
         lo = 0;
         hi = p->t_mid;
         while (lo < hi) {  // first task whose row has <= 128 entries
@@ -1954,7 +1963,10 @@ extern "C" int64_t lk_als_plan_short_rows(const lk_als_plan *p)
 
 extern "C" int64_t lk_als_plan_woodbury_rows(const lk_als_plan *p)
 {
-    return p ? p->n_rows - p->t_mid : 0;
+    if (!p) return 0;
+    if (p->KP == 256) return p->n_rows - p->t_mid;
+    const int lim = wb64_k128_limit();  // padded k = 128
+    return p->n_rows - (lim >= 64 ? p->t_mid : (lim >= 32 ? p->t_32 : p->t_short));
 }
 
 extern "C" int lk_als_plan_set_z(lk_als_plan *p, const float *d_z)

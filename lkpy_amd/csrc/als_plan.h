@@ -3,7 +3,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #define LK_DELTA_BLOCKS 256
+
+// LK_ALS_WB64_K128: longest row (32 or 64 entries; 0 = none) that the 32 x 32 / 64 x 64 Woodbury
+// systems of als_wb64_kernel take at padded k = 128 (at k = 256: always up to 64)
+#ifndef LK_ALS_WB64_K128_DEFAULT
+#define LK_ALS_WB64_K128_DEFAULT 64
+#endif
+static inline int wb64_k128_limit()
+{
+    const char *e = getenv("LK_ALS_WB64_K128");
+    return e ? atoi(e) : LK_ALS_WB64_K128_DEFAULT;
+}
 
 #ifndef LK_ALS_CHUNK
 #define LK_ALS_CHUNK 1024  // CSR entries per chunk of a long row
@@ -33,6 +46,7 @@ struct lk_als_plan {
     int64_t t_short = 0;
     int64_t t_mid = 0;  // rows with 17 .. 64 entries are [t_mid, t_short): als_wb64_kernel
     int64_t t_4 = 0;    // rows with <= 4 entries are [t_4, n_rows): als_wb4_kernel, four per wave
+    int64_t t_32 = 0;   // rows with 17 .. 32 entries are [t_32, t_short): the 32 x 32 system of als_wb64_kernel (KP = 128)
     int64_t t_128 = 0;  // rows with 65 .. 128 entries are [t_128, t_mid): als_wb128_kernel (KP = 256)
     // rows [t_cg, n_rows) have at most 16384 / KP entries (256 / 128 / 64 at padded k = 64 /
     // 128 / 256): what the CG kernel keeps in registers over its iterations (als_cg.hip)

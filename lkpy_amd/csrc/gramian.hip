@@ -89,7 +89,10 @@ __device__ __forceinline__ void gram_wave(const float *__restrict__ m, int64_t r
         tot[l] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    constexpr int PF = (NT >= 8) ? 2 : 4;  // groups in flight
+#ifndef LK_GRAM_PF_WIDE
+#define LK_GRAM_PF_WIDE 2
+#endif
+    constexpr int PF = (NT >= 8) ? LK_GRAM_PF_WIDE : 4;  // groups in flight
     QVec<NT> qn[PF];
     const int64_t ngroups = (row_end - row_beg + 3) >> 2;
 #pragma unroll

@@ -62,7 +62,7 @@ def test_short_rows_vs_oracle_and_dense(gpu, oracle, rng, monkeypatch, k, varied
     plan, got, frob, d_this = run(1)
     assert plan.use_wb and plan.short_rows >= 1500
     # the 64 x 64 and 128 x 128 variants only pay at padded k = 256
-    wb_max = 128 if plan.kp == 256 else 16
+    wb_max = 128 if plan.kp == 256 else 64  # (k = 128: LK_ALS_WB64_K128 = 64 by default)
     plan0, dense, frob0, _ = run(0)
     assert not plan0.use_wb
 
@@ -215,7 +215,8 @@ def test_row_slices_with_negative_values_keep_the_dense_kernels(gpu, oracle, rng
                                    gpu)
     lens = np.diff(mat.indptr)
     cuts = [(0, 600), (600, 1200), (1200, 1800)]
-    short = [int(((lens[lo:hi] <= 16)).sum()) for lo, hi in cuts]
+    # (padded k = 128: the Woodbury kernels take rows of up to 64 entries, LK_ALS_WB64_K128)
+    short = [int(((lens[lo:hi] <= 64)).sum()) for lo, hi in cuts]
     monkeypatch.setenv("LK_ALS_WB_MIN_ROWS", str(max(short) + 1))
     assert sum(short) >= max(short) + 1
     plans = []
