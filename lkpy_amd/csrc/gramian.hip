@@ -19,6 +19,8 @@
 //   un-permutes and mirrors, so the result is exactly symmetric.
 //
 // Roofline: HBM-bound, algorithmic bytes = n*k*4 (one read of M).
+#include <stdlib.h>
+
 #include "als_plan.h"
 #include "common.h"
 
@@ -165,6 +167,189 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float *__res
     }
 }
 
+// ---- k = 256: the row stream staged through LDS ------------------------------------------------
+//
+// gramian_partial_kernel<16> holds 136 + 136 accumulator registers per wave (one wave per SIMD) and
+// can keep only two 4-row groups of operands in flight next to them: 34 MFMAs x 32 cycles per group
+// cover 2.2 k cycles, less than a loaded HBM round trip -- the matrix cores waited (10.7 ms per
+// cfg5 epoch for 4.4 ms of MFMA work).  Here the rows arrive by `global_load_lds_dwordx4` (a wave's
+// instruction moves one 1 KiB row, no register involved) into a ring of GRAM_DMA_STAGES stages of
+// 16 rows: five stages = 80 KiB per CU are in flight while one is multiplied, one barrier per stage
+// (4 groups = 136 MFMAs per wave) publishes everyone's rows.  The bank swizzle sits on the global
+// side (position 4 s + i of a row holds its 16-byte chunk 4 s + (i ^ (s >> 2))), as in
+// als_blk_chunk_dma_kernel.  Same tiles, same row order, same chain breaks: the slabs are
+// bit-identical to gramian_partial_kernel<16>'s.
+#ifndef LK_GRAM_DMA_STAGES
+#define LK_GRAM_DMA_STAGES 4
+#endif
+constexpr int GRAM_DMA_STAGES = LK_GRAM_DMA_STAGES;
+constexpr size_t GRAM_DMA_LDS_BYTES = (size_t)GRAM_DMA_STAGES * 16 * 1024;
+
+template <int N>
+__device__ __forceinline__ void gram_wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int W>
+__device__ __forceinline__ void gram_wave_dma(const float *__restrict__ m, int64_t row_beg,
+                                              int64_t row_end, float *__restrict__ slab,
+                                              float *ring)
+{
+    constexpr int NT = 16, KP = 256, S = GRAM_DMA_STAGES;
+    constexpr int NTILES = gram_tiles(NT);
+    constexpr int NLOC = (NTILES - W + GRAM_WAVES - 1) / GRAM_WAVES;
+    static_assert(S >= 3 && (S - 2) * 4 <= 60, "ring depth");
+    const int lane = lane_id();
+    const int sub = lane & 15, slot = lane >> 4;
+    // (the second level of gram_wave's two-level sum -- `tot` -- lives in the block's slab in
+    // global memory here, not in 136 more registers: read-modify-written every GRAM_SEG groups,
+    // same float32 additions in the same order, and the kernel fits two workgroups per CU)
+    f32x4 acc[NLOC];
+#pragma unroll
+    for (int l = 0; l < NLOC; ++l) acc[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool flushed = false;
+    const int64_t nrows = row_end - row_beg;
+    const int n_stage = (int)((nrows + 15) >> 4);
+    const unsigned ring_lds = (unsigned)(uintptr_t) reinterpret_cast<void *>(ring);
+    // global side of this lane's 16 bytes of a row; LDS side of the operand chunks of lane
+    // (entry slot, element sub): chunk c of the lane's 16 features = row chunk 4 sub + c
+    const int ds_ = lane >> 2, di_ = lane & 3;
+    const int src_off = 4 * (4 * ds_ + (di_ ^ (ds_ >> 2)));  // floats
+    const float *rd = ring + slot * KP + 16 * sub;
+    int xo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xo[c] = 4 * (c ^ (sub >> 2));
+    const int64_t last_row = row_end - 1;
+
+    // wave W brings rows 4 g + W of the stage (g = 0..3)
+    auto issue = [&](int k) {
+        const int sl = k % S;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int64_t r = row_beg + 16 * (int64_t)k + 4 * g + W;
+            r = r < row_end ? r : last_row;  // (masked at use)
+            const float *src = m + r * KP + src_off;
+            const unsigned dst = ring_lds + (unsigned)(sl * 16 + 4 * g + W) * 1024u;
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(dst)
+                : "memory");
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < S - 1; ++k)
+        if (k < n_stage) issue(k);
+
+    for (int k = 0; k < n_stage; ++k) {
+        // this wave's rows of stage k have landed when at most the rows of the stages issued
+        // after it (up to S - 2 of them, 4 loads each) are still in flight
+        const int ahead = n_stage - 1 - k < S - 2 ? n_stage - 1 - k : S - 2;
+        switch (ahead) {
+            case 0: gram_wait_vm<0>(); break;
+            case 1: gram_wait_vm<4>(); break;
+            case 2: gram_wait_vm<8>(); break;
+            case 3: gram_wait_vm<12>(); break;
+            default: gram_wait_vm<(S - 2) * 4>(); break;
+        }
+        asm volatile("s_barrier" ::: "memory");  // everyone's rows; everyone done with stage k - 1
+        if (k + S - 1 < n_stage) issue(k + S - 1);
+        const float *sp = rd + (k % S) * (16 * KP);
+        const bool full = 16 * (int64_t)(k + 1) <= nrows;  // workgroup-uniform
+        // operands of group g + 1 are read while the 34 MFMAs of group g run
+        auto fetch = [&](float (&q)[NT], int g) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(sp + g * (4 * KP) + xo[c]);
+                q[4 * c + 0] = t.x;
+                q[4 * c + 1] = t.y;
+                q[4 * c + 2] = t.z;
+                q[4 * c + 3] = t.w;
+            }
+            if (!full) {
+                const bool live = 16 * (int64_t)k + 4 * g + slot < nrows;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) q[t] = live ? q[t] : 0.f;
+            }
+        };
+        float qc[NT], qn[NT];
+        fetch(qc, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) fetch(qn, g + 1);
+#pragma unroll
+            for (int l = 0; l < NLOC; ++l) {
+                const int e = l * GRAM_WAVES + W;
+                const int ti = tile_ti(e), tj = tile_tj(e);
+                acc[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc[ti], qc[tj], acc[l], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) qc[t] = qn[t];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((((k + 1) * 4) & (GRAM_SEG - 1)) == 0) {  // every GRAM_SEG groups, as gram_wave
+            // (the tile addresses are derived from a base the compiler cannot see through: hoisted
+            // out of the row loop, 136 of them would be live across it)
+            float *sb = slab + (slot * 4) * KP + sub;
+            asm volatile("" : "+v"(sb));
+#pragma unroll
+            for (int l = 0; l < NLOC; ++l) {
+                const int e = l * GRAM_WAVES + W;
+                const int ti = tile_ti(e), tj = tile_tj(e);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float *p = sb + (ti * 16 + r) * KP + tj * 16;
+                    *p = (flushed ? *p : 0.f) + acc[l][r];  // tot += acc
+                }
+                acc[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            flushed = true;
+        }
+    }
+    float *sb = slab + (slot * 4) * KP + sub;
+    asm volatile("" : "+v"(sb));
+#pragma unroll
+    for (int l = 0; l < NLOC; ++l) {
+        const int e = l * GRAM_WAVES + W;
+        const int ti = tile_ti(e), tj = tile_tj(e);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float *p = sb + (ti * 16 + r) * KP + tj * 16;
+            *p = acc[l][r] + (flushed ? *p : 0.f);  // acc += tot
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gramian_partial_dma_kernel(const float *__restrict__ m,
+                                                                  int64_t n, int64_t rows_per_block,
+                                                                  float *__restrict__ ws)
+{
+    constexpr int KP = 256;
+    extern __shared__ __attribute__((aligned(1024))) float gram_dma_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int64_t row_beg = (int64_t)blockIdx.x * rows_per_block;
+    int64_t row_end = row_beg + rows_per_block;
+    if (row_end > n) row_end = n;
+    if (row_beg > n) row_beg = n;
+    float *slab = ws + (size_t)blockIdx.x * KP * KP;
+    switch (wave) {
+        case 0: gram_wave_dma<0>(m, row_beg, row_end, slab, gram_dma_lds); break;
+        case 1: gram_wave_dma<1>(m, row_beg, row_end, slab, gram_dma_lds); break;
+        case 2: gram_wave_dma<2>(m, row_beg, row_end, slab, gram_dma_lds); break;
+        default: gram_wave_dma<3>(m, row_beg, row_end, slab, gram_dma_lds); break;
+    }
+}
+
+// LK_GRAM_DMA=0: the register-staged kernel at k = 256 too (A/B timing, tests)
+static bool gram_dma_enabled()
+{
+    const char *e = getenv("LK_GRAM_DMA");
+    return !(e && e[0] == '0');
+}
+
 // Sum the slabs (fixed order => bit-reproducible), add reg*I, un-permute, mirror.
 // One workgroup per 64 consecutive primed elements (one coalesced 256-byte segment of
 // every slab); wave w sums slabs w, w+4, ...; the four partial sums are combined in
@@ -229,7 +414,21 @@ static int launch_gramian(const float *m, int64_t n, int k, int ld, float reg, f
     // same places whatever n is
     int64_t rpb = ((n + nb - 1) / nb + 15) / 16 * 16;
     if (rpb < 16) rpb = 16;
-    hipLaunchKernelGGL(gramian_partial_kernel<NT>, dim3(nb), dim3(256), 0, st, m, n, ld, rpb, ws);
+    bool dma = false;
+    if constexpr (NT == 16) dma = gram_dma_enabled() && n >= 16;
+    if (dma) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gramian_partial_dma_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)GRAM_DMA_LDS_BYTES));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gramian_partial_dma_kernel, dim3(nb), dim3(256), GRAM_DMA_LDS_BYTES, st, m,
+                           n, rpb, ws);
+    } else {
+        hipLaunchKernelGGL(gramian_partial_kernel<NT>, dim3(nb), dim3(256), 0, st, m, n, ld, rpb, ws);
+    }
     hipLaunchKernelGGL(gramian_finish_kernel<NT>, dim3(KP * KP / 64), dim3(256), 0, st, ws, nb, k,
                        reg, out, ld_out);
     LK_HIP_CHECK(hipGetLastError());

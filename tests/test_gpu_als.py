@@ -48,6 +48,31 @@ def test_gramian(gpu, oracle, rng, k, n):
     assert np.array_equal(out, out2)
 
 
+@pytest.mark.parametrize("k", [200, 256])
+@pytest.mark.parametrize("n", [15, 16, 17, 4097, 70001, 1_500_000])
+def test_gramian_lds_staged_rows_bit_identical(gpu, monkeypatch, k, n):
+    """k = 256: gramian_partial_dma_kernel (rows staged through LDS, second-level sums in the
+    block's slab) against gramian_partial_kernel<16> (`LK_GRAM_DMA=0`): same tiles, same row
+    order, same chain breaks -- bit for bit; n = 1.5 M makes every block cross several
+    256-group chain breaks."""
+    import torch
+
+    from lkpy_amd import _device as D
+
+    gen = torch.Generator(device=gpu).manual_seed(n)
+    m = torch.zeros((n, 256), device=gpu)
+    m[:, :k] = torch.randn((n, k), device=gpu, generator=gen)
+    g = D.Gramian(k, gpu)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LK_GRAM_DMA", mode)
+        out[mode] = g(m, 0.1).clone()
+    assert torch.equal(out["1"], out["0"])
+    ref = (m[:, :k].double().T @ m[:, :k].double()) + 0.1 * torch.eye(k, device=gpu, dtype=torch.float64)
+    rel = float((out["1"].double() - ref).norm() / ref.norm())
+    assert rel < 1e-5
+
+
 @pytest.mark.parametrize("k", [10, 25, 64])
 @pytest.mark.parametrize("is64", [False, True])
 def test_half_epoch_random(gpu, oracle, rng, k, is64):
