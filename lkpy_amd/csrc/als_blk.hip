@@ -154,25 +154,54 @@ __device__ __forceinline__ void ops_issue(Ops<NT> &o, int g, int col_reg, float 
     load_vec<NL>(base + wc * NL, o.qb);
 }
 
+// ---- donated tiles ---------------------------------------------------------------------------
+// The 2 x 2 block-cyclic deal gives wave (wr, wc) = (1, 0) NL local diagonal tiles that are LOWER
+// tiles of the matrix ("phantom": computed like the others, never read): 4 of its 10 Gram MFMAs
+// per entry group at k = 128, 8 of 36 at k = 256, while the other three waves have no slack --
+// every SIMD issues T MFMAs per group for 36 (136) useful tiles out of 40 (144).  With
+// LK_BLK_DONATE the three other waves each leave NL / 4 of their tiles -- local (d, NL - 1),
+// d < NL / 4 -- to the phantom wave, which accumulates them in its phantom slots (it holds every
+// feature block as one of its two operands: odd blocks as qa, even blocks as qb): T - NL / 4
+// MFMAs per group for every wave (9 instead of 10, 34 instead of 36).  The solve kernel hands the
+// tiles over through LDS after the Gram phase; the chunk kernels store them straight into the
+// owner's part of the slab.  Same products, same accumulation chains: bit-identical results.
+#ifndef LK_BLK_DONATE
+#define LK_BLK_DONATE 1
+#endif
+template <int NT>
+struct Don {
+    static constexpr int NL = NT / 2;
+    static constexpr int PER = LK_BLK_DONATE ? NL / 4 : 0;  // tiles each of the 3 donors leaves
+    static constexpr int ND = 3 * PER;                      // phantom slots in use: lt(p, p), p < ND
+    // donor of phantom slot p: 0 = wave (0,0), 1 = wave (0,1), 2 = wave (1,1)
+    __host__ __device__ static constexpr int donor(int p) { return p / (PER ? PER : 1); }
+    __host__ __device__ static constexpr int dwave(int p) { return donor(p) == 0 ? 0 : (donor(p) == 1 ? 2 : 3); }
+    __host__ __device__ static constexpr int dr(int p) { return donor(p) == 2 ? 1 : 0; }
+    __host__ __device__ static constexpr int dc(int p) { return donor(p) == 0 ? 0 : 1; }
+    __host__ __device__ static constexpr int di(int p) { return p % (PER ? PER : 1); }  // local row
+    __host__ __device__ static constexpr bool donated(int I, int J) { return J == NL - 1 && I < PER; }
+};
+
 // acc -= v q q^T (implicit; explicit: acc -= q q^T), y += (v + 1) q (explicit: v q).
-// ONE straight-line MFMA sequence for every wave and every group (entries past the end of the
-// row are zeroed by a select; the diagonal local tiles of wave (1,0), which would be LOWER
-// tiles, are computed like the others and simply never read): any branch around an MFMA makes
-// the compiler keep two copies of the accumulators and shuffle them at the loop head.
-template <int NT, bool EXPL>
+// ONE straight-line MFMA sequence per wave ROLE (PH: the phantom wave (1, 0), see above) and
+// every group (entries past the end of the row are zeroed by a select): any branch around an
+// MFMA inside the loop makes the compiler keep two copies of the accumulators and shuffle them
+// at the loop head -- the role is a template parameter of the whole loop instead.
+template <int NT, bool EXPL, bool PH = false>
 __device__ __forceinline__ void ops_consume(f32x4 (&acc)[Cfg<NT>::T], float (&yacc)[NT / 2],
                                             const Ops<NT> &o, bool live)
 {
     constexpr int NL = NT / 2;
+    using DN = Don<NT>;
     // `mtl = mt * vals` (implicit.rs:110-111), negated (exact); `vals += 1.0` (implicit.rs:116)
     const float va = EXPL ? -1.0f : -o.v;
     const float v1 = EXPL ? o.v : o.v + 1.0f;
-    float na[NL], qb[NL];
+    float qa[NL], na[NL], qb[NL];
 #pragma unroll
     for (int I = 0; I < NL; ++I) {
-        const float q = live ? o.qa[I] : 0.f;
-        na[I] = q * va;
-        yacc[I] = fmaf(q, v1, yacc[I]);
+        qa[I] = live ? o.qa[I] : 0.f;
+        na[I] = qa[I] * va;
+        yacc[I] = fmaf(qa[I], v1, yacc[I]);
     }
 #pragma unroll
     for (int J = 0; J < NL; ++J) qb[J] = live ? o.qb[J] : 0.f;
@@ -180,7 +209,19 @@ __device__ __forceinline__ void ops_consume(f32x4 (&acc)[Cfg<NT>::T], float (&ya
         constexpr int J = decltype(Jc)::value;
         sfor<0, J + 1>([&](auto Ic) {
             constexpr int I = decltype(Ic)::value;
-            acc[lt(I, J)] = __builtin_amdgcn_mfma_f32_16x16x4f32(na[I], qb[J], acc[lt(I, J)], 0, 0, 0);
+            if constexpr (PH && I == J) {
+                // phantom slot p = I: the donated tile (2 di + dr, 2 (NL - 1) + dc) of its donor
+                if constexpr (I < DN::ND) {
+                    constexpr int p = I, i = DN::di(p);
+                    const float a = DN::dr(p) ? na[i] : qb[i] * va;
+                    const float b = DN::dc(p) ? qa[NL - 1] : qb[NL - 1];
+                    acc[lt(I, J)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[lt(I, J)], 0, 0, 0);
+                }
+            } else if constexpr (!PH && DN::donated(I, J)) {
+                // left to the phantom wave
+            } else {
+                acc[lt(I, J)] = __builtin_amdgcn_mfma_f32_16x16x4f32(na[I], qb[J], acc[lt(I, J)], 0, 0, 0);
+            }
         });
     });
 }
@@ -210,7 +251,7 @@ __device__ __forceinline__ void ops_consume(f32x4 (&acc)[Cfg<NT>::T], float (&ya
 #ifndef LK_BLK_RING16_CHUNK
 #define LK_BLK_RING16_CHUNK LK_BLK_RING16  // the chunk kernel (no factorisation state to keep)
 #endif
-template <int NT, bool EXPL, int D = (NT == 16 ? LK_BLK_RING16 : LK_BLK_RING8)>
+template <int NT, bool EXPL, int D = (NT == 16 ? LK_BLK_RING16 : LK_BLK_RING8), bool PH = false>
 __device__ __forceinline__ void gram_accumulate(f32x4 (&acc)[Cfg<NT>::T], float (&yacc)[NT / 2],
                                                 const int32_t *__restrict__ cols,
                                                 const float *__restrict__ vals, int64_t beg,
@@ -230,7 +271,7 @@ __device__ __forceinline__ void gram_accumulate(f32x4 (&acc)[Cfg<NT>::T], float 
             for (int g = 0; g < ng; ++g) {
                 const int gn = (g + 1 < ng) ? g + 1 : g;
                 ops_issue<NT>(nxt, gn, col_reg, val_reg, other, lane, wr, wc);
-                ops_consume<NT, EXPL>(acc, yacc, cur, (g * 4 + (lane >> 4)) < nb);
+                ops_consume<NT, EXPL, PH>(acc, yacc, cur, (g * 4 + (lane >> 4)) < nb);
                 cur = nxt;
             }
         }
@@ -259,7 +300,7 @@ __device__ __forceinline__ void gram_accumulate(f32x4 (&acc)[Cfg<NT>::T], float 
             for (int g0 = 0; g0 < ng; g0 += D) {
                 sfor<0, D>([&](auto dc) {
                     constexpr int d = decltype(dc)::value;
-                    ops_consume<NT, EXPL>(acc, yacc, ring[d], ((g0 + d) * 4 + (lane >> 4)) < nb);
+                    ops_consume<NT, EXPL, PH>(acc, yacc, ring[d], ((g0 + d) * 4 + (lane >> 4)) < nb);
                     // step g0 + d + D: of this batch, or already of the next one
                     const int sn = g0 + d + D;
                     const bool nx = sn >= 16;  // wave-uniform
@@ -273,6 +314,46 @@ __device__ __forceinline__ void gram_accumulate(f32x4 (&acc)[Cfg<NT>::T], float 
             valB = valC;
         }
     }
+}
+
+// acc / yacc of one chunk -> its slab ([wave][T * 4 + NL][64]); the phantom wave's donated tiles go
+// to their owner's part (the owners skip those tiles), its own phantom positions are zeroed
+template <int NT>
+__device__ __forceinline__ void store_chunk_slab(const f32x4 (&acc)[Cfg<NT>::T],
+                                                 const float (&yacc)[NT / 2], float *slab_chunk,
+                                                 int wave, int lane)
+{
+    using C = Cfg<NT>;
+    using DN = Don<NT>;
+    constexpr int NL = C::NL;
+    const bool ph = wave == 1;
+    float *slab = slab_chunk + (size_t)wave * C::SLAB_WAVE;
+    sfor<0, NL>([&](auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        sfor<0, J + 1>([&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            constexpr int t = lt(I, J);
+            if constexpr (I == J && I < DN::ND) {
+                constexpr int p = I;
+                float *own = slab_chunk + (size_t)DN::dwave(p) * C::SLAB_WAVE;
+                constexpr int td = lt(DN::di(p), NL - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (ph) own[(td * 4 + r) * 64 + lane] = acc[t][r];
+                    slab[(t * 4 + r) * 64 + lane] = ph ? 0.f : acc[t][r];
+                }
+            } else if constexpr (DN::donated(I, J)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ph) slab[(t * 4 + r) * 64 + lane] = acc[t][r];  // (its own real tile)
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(t * 4 + r) * 64 + lane] = acc[t][r];
+            }
+        });
+    });
+#pragma unroll
+    for (int i = 0; i < NL; ++i) slab[(C::T * 4 + i) * 64 + lane] = yacc[i];
 }
 
 // ---- chunk kernel: one workgroup per chunk of a long row -----------------------------------
@@ -294,15 +375,14 @@ __global__ __launch_bounds__(256) void als_blk_chunk_kernel(
 #pragma unroll
     for (int i = 0; i < C::NL; ++i) yacc[i] = 0.f;
     const int64_t beg = chunk_beg[c];
-    gram_accumulate<NT, EXPL, (NT == 16 ? LK_BLK_RING16_CHUNK : LK_BLK_RING8)>(
-        acc, yacc, indices, values, beg, beg + chunk_len[c], other, lane, wr, wc);
-    float *slab = slabs + (size_t)c * C::SLAB + (size_t)wave * C::SLAB_WAVE;
-#pragma unroll
-    for (int t = 0; t < C::T; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) slab[(t * 4 + r) * 64 + lane] = acc[t][r];
-#pragma unroll
-    for (int i = 0; i < C::NL; ++i) slab[(C::T * 4 + i) * 64 + lane] = yacc[i];
+    constexpr int DR = NT == 16 ? LK_BLK_RING16_CHUNK : LK_BLK_RING8;
+    if (wave == 1)  // the phantom wave's role (donated tiles), see Don
+        gram_accumulate<NT, EXPL, DR, true>(acc, yacc, indices, values, beg, beg + chunk_len[c],
+                                            other, lane, wr, wc);
+    else
+        gram_accumulate<NT, EXPL, DR, false>(acc, yacc, indices, values, beg, beg + chunk_len[c],
+                                             other, lane, wr, wc);
+    store_chunk_slab<NT>(acc, yacc, slabs + (size_t)c * C::SLAB, wave, lane);
 }
 
 // ---- the chunk kernel at k = 256 with the gathered rows staged through LDS --------------------
@@ -440,6 +520,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     for (int j = 0; j < 3; ++j)
         if (j < n_stage) issue_stage(0, j);
 
+    auto stages = [&](auto phc) {
+    constexpr bool PH = decltype(phc)::value;
     for (int k0 = 0, b = 0; k0 < n_stage; k0 += 4, ++b) {
         sfor<0, 4>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -472,20 +554,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if (g + 1 < 4) fetch(nxt, b, j, g + 1);
-                    ops_consume<NT, EXPL>(acc, yacc, cur, (4 * g + e4) < nb);
+                    ops_consume<NT, EXPL, PH>(acc, yacc, cur, (4 * g + e4) < nb);
                     cur = nxt;
                 }
             }
         });
     }
+    };
+    if (wave == 1)  // the phantom wave's role (donated tiles), see Don
+        stages(std::integral_constant<bool, true>{});
+    else
+        stages(std::integral_constant<bool, false>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a trailing meta request still targets our LDS)
-    float *slab = slabs + (size_t)c * C::SLAB + (size_t)wave * C::SLAB_WAVE;
-#pragma unroll
-    for (int t = 0; t < C::T; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) slab[(t * 4 + r) * 64 + lane] = acc[t][r];
-#pragma unroll
-    for (int i = 0; i < C::NL; ++i) slab[(C::T * 4 + i) * 64 + lane] = yacc[i];
+    store_chunk_slab<NT>(acc, yacc, slabs + (size_t)c * C::SLAB, wave, lane);
 }
 
 // LK_BLK_CHUNK_DMA=0: the register-ring chunk kernel at k = 256 too (A/B timing)
@@ -815,12 +896,22 @@ __device__ __forceinline__ void als_blk_solve_body(
         constexpr int J = decltype(Jc)::value;
         sfor<0, J + 1>([&](auto Ic) {
             constexpr int I = decltype(Ic)::value;
-            const int ti = 2 * I + wr, tj = 2 * J + wc;
+            int ti = 2 * I + wr, tj = 2 * J + wc;
+            bool zero = I == J && phantom;
+            if constexpr (I == J && I < Don<NT>::ND) {
+                // phantom slot I of wave (1, 0): the tile its donor left to it starts from the
+                // donor's values, so that the accumulation chain is the donor's own
+                using DN = Don<NT>;
+                if (phantom) {
+                    ti = 2 * DN::di(I) + DN::dr(I);
+                    tj = 2 * (NL - 1) + DN::dc(I);
+                    zero = false;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 acc[lt(I, J)][r] =
-                    (I == J && phantom) ? 0.f
-                                        : notor_p[(ti * 16 + slot * 4 + r) * KP + tj * 16 + sub];
+                    zero ? 0.f : notor_p[(ti * 16 + slot * 4 + r) * KP + tj * 16 + sub];
         });
     });
 #pragma unroll
@@ -850,7 +941,34 @@ __device__ __forceinline__ void als_blk_solve_body(
             for (int i = 0; i < NL; ++i) yacc[i] += slab[(C::T * 4 + i) * 64 + lane];
         }
     } else {
-        gram_accumulate<NT, EXPL>(acc, yacc, indices, values, beg, end, other, lane, wr, wc);
+        constexpr int DR = NT == 16 ? LK_BLK_RING16 : LK_BLK_RING8;
+        if (phantom)  // (wave-uniform) the phantom wave's role: donated tiles, see Don
+            gram_accumulate<NT, EXPL, DR, true>(acc, yacc, indices, values, beg, end, other, lane,
+                                                wr, wc);
+        else
+            gram_accumulate<NT, EXPL, DR, false>(acc, yacc, indices, values, beg, end, other, lane,
+                                                 wr, wc);
+        if constexpr (Don<NT>::ND > 0) {
+            // hand the donated tiles to their owners through the second panel buffer (idle until
+            // block step 1 publishes into it)
+            using DN = Don<NT>;
+            float *hand = lds + C::OFF_P1;
+            if (phantom) {
+                sfor<0, DN::ND>([&](auto pc) {
+                    constexpr int pp = decltype(pc)::value;
+                    *reinterpret_cast<f32x4 *>(&hand[pp * 256 + lane * 4]) = acc[lt(pp, pp)];
+                });
+            }
+            __syncthreads();
+            if (!phantom) {
+                const int first = (wave == 0 ? 0 : (wave == 2 ? 1 : 2)) * DN::PER;  // wave-uniform
+                sfor<0, DN::PER>([&](auto dc_) {
+                    constexpr int d = decltype(dc_)::value;
+                    acc[lt(d, NL - 1)] =
+                        *reinterpret_cast<const f32x4 *>(&hand[(first + d) * 256 + lane * 4]);
+                });
+            }
+        }
     }
     if (EXPL) {
         // explicit.rs:104-107: A[i][i] += reg * n on the real features (acc = -A)
