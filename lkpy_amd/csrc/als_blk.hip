@@ -74,6 +74,22 @@ __device__ unsigned *lk_blk_phase_buf;
 #define LK_BP_PASS
 #endif
 
+template <int CTRL>
+__device__ __forceinline__ float blk_dpp_add(float x)
+{
+    const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false);
+    return x + __builtin_bit_cast(float, y);
+}
+// sum over the 16 lanes of a row group, in every lane
+__device__ __forceinline__ float blk_row16_sum(float x)
+{
+    x = blk_dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
+    x = blk_dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]
+    x = blk_dpp_add<0x141>(x);  // row_half_mirror
+    x = blk_dpp_add<0x140>(x);  // row_mirror
+    return x;
+}
+
 template <int B, int E, class F>
 __device__ __forceinline__ void sfor(F &&f)
 {
@@ -793,10 +809,11 @@ __device__ __forceinline__ void back_step(const f32x4 (&acc)[Cfg<NT>::T], float 
                 }
             }
         });
+        // 16-lane butterfly on DPP row operations (VALU, no LDS-crossbar round trip per step):
+        // xor 1, xor 2, then half-mirror / mirror -- the quads (halves) hold equal sums by then,
+        // so these pair the same values as xor 4 / xor 8: bit-identical to the __shfl_xor form
 #pragma unroll
-        for (int m = 1; m < 16; m <<= 1)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] += __shfl_xor(t[r], m, 64);
+        for (int r = 0; r < 4; ++r) t[r] = blk_row16_sum(t[r]);
         if (sub == 0)
             *reinterpret_cast<f32x4 *>(&lds[C::OFF_SP + wc * 16 + slot * 4]) =
                 f32x4{t[0], t[1], t[2], t[3]};
@@ -1017,7 +1034,12 @@ __device__ __forceinline__ void als_blk_solve_body(
     LK_BP_T(bp_chol);
 
     // -- phase 3: back substitution ----------------------------------------------------------
+#ifdef LK_BLK_NO_BACK  // TIMING EXPERIMENT ONLY (wrong results): what the back substitution costs
+    if (tid < KP) lds[C::OFF_X + tid] = lds[C::OFF_Z + tid];
+    __syncthreads();
+#else
     back_all<NT>(acc, lds, lane, wave, wr, wc, rot, std::make_integer_sequence<int, NT>{});
+#endif
 #if LK_BLK_SOLVE_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
