@@ -1320,6 +1320,13 @@ static bool als_wb128_enabled()
     return !(e && e[0] == '0');
 }
 
+// LK_ALS_SIDE_STREAM=0: OtOr^-1 on the launch stream (A/B timing)
+static bool side_stream_enabled()
+{
+    const char *e = getenv("LK_ALS_SIDE_STREAM");
+    return !(e && e[0] == '0');
+}
+
 // LK_ALS_WB64=0: rows with 17 .. 64 entries stay on the dense kernel (A/B timing, tests)
 static bool als_wb64_enabled()
 {
@@ -1352,6 +1359,42 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     }
     hipLaunchKernelGGL(als_blk_prep_otor_kernel<NT>, dim3((C::KP * C::KP + 255) / 256), dim3(256),
                        0, st, otor, ld_otor, k, notor_p);
+    // first task of the Woodbury kernels: rows <= 16 entries always; 17 .. 64 at padded k = 256
+    // (17 .. 32 / 64 at k = 128 with LK_ALS_WB64_K128 = 32 / 64; LK_ALS_WB64=0: none)
+    int64_t n_wb64_first = p->t_short;
+    if (als_wb64_enabled()) {
+        if (NT == 16) {
+            n_wb64_first = p->t_mid;
+        } else {
+            const int lim = wb64_k128_limit();
+            n_wb64_first = lim >= 64 ? p->t_mid : (lim >= 32 ? p->t_32 : p->t_short);
+        }
+    }
+    const bool prefix = p->dense_limit >= 0;  // CG hybrid: the chunked rows only, no Woodbury
+    const bool own_z = !EXPL && p->d_zbuf != nullptr && !p->ctl &&
+                       (n_wb64_first < n_rows || p->z_for_others) && n_cols > 0 && !prefix;
+    // OtOr^-1 to float64 accuracy (spd_inverse.hip; status[1] = its flag, tested by the Woodbury
+    // kernels and by the fallback launch below): one workgroup for most of its time, so it goes
+    // to the plan's side stream, under the chunk kernel, and the Z GEMM waits for it
+    bool inv_on_side = false;
+    if (own_z) {
+        float *ginv = reinterpret_cast<float *>(ws + p->off_ginv);
+        hipStream_t sv = st;
+        if (side_stream_enabled() && p->n_chunks > 0) {
+            if (!p->side) {
+                LK_HIP_CHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+                LK_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+                LK_HIP_CHECK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+            }
+            LK_HIP_CHECK(hipEventRecord(p->ev_fork, st));  // (after the status memset above)
+            LK_HIP_CHECK(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+            sv = p->side;
+            inv_on_side = true;
+        }
+        int rc = spd_inverse(otor, ld_otor, k, C::KP, ginv, status + 1, ws + p->off_invws, sv);
+        if (rc != LK_OK) return rc;
+        if (inv_on_side) LK_HIP_CHECK(hipEventRecord(p->ev_join, p->side));
+    }
     const bool tm = p->timing && p->timing_n < lk_als_plan::TIMING_RING;
     if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][0], st));
     if (p->n_chunks > 0) {
@@ -1384,29 +1427,12 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     // short rows (<= 16 entries) of the implicit model: Woodbury kernel, when the caller
     // supplied Z = other * OtOr^-1 for this half-epoch (never with a task-control block: the
     // kernel does not poll it)
-    // first task of the Woodbury kernels: rows <= 16 entries always; 17 .. 64 at padded k = 256
-    // (17 .. 32 / 64 at k = 128 with LK_ALS_WB64_K128 = 32 / 64; LK_ALS_WB64=0: none)
-    int64_t n_wb64_first = p->t_short;
-    if (als_wb64_enabled()) {
-        if (NT == 16) {
-            n_wb64_first = p->t_mid;
-        } else {
-            const int lim = wb64_k128_limit();
-            n_wb64_first = lim >= 64 ? p->t_mid : (lim >= 32 ? p->t_32 : p->t_short);
-        }
-    }
     const float *z = p->d_z;
-    const bool prefix = p->dense_limit >= 0;  // CG hybrid: the chunked rows only, no Woodbury
-    const bool own_z = !EXPL && p->d_zbuf != nullptr && !p->ctl &&
-                       (n_wb64_first < n_rows || p->z_for_others) && n_cols > 0 && !prefix;
     if (own_z) {
-        // Z = other * OtOr^-1 for this half-epoch, all on this stream: the inverse to float64
-        // accuracy (spd_inverse.hip; status[1] = its flag, tested by the Woodbury kernels and by
-        // the fallback launch below), then one scoring GEMM (k-ordered f32 MFMA, topk.hip)
+        // Z = other * OtOr^-1 for this half-epoch: one scoring GEMM (k-ordered f32 MFMA, topk.hip)
         float *ginv = reinterpret_cast<float *>(ws + p->off_ginv);
-        int rc = spd_inverse(otor, ld_otor, k, C::KP, ginv, status + 1, ws + p->off_invws, st);
-        if (rc != LK_OK) return rc;
-        rc = lk_score_dense(other, C::KP, n_cols, ginv, C::KP, C::KP, k, p->d_zbuf, C::KP, st);
+        if (inv_on_side) LK_HIP_CHECK(hipStreamWaitEvent(st, p->ev_join, 0));
+        int rc = lk_score_dense(other, C::KP, n_cols, ginv, C::KP, C::KP, k, p->d_zbuf, C::KP, st);
         if (rc != LK_OK) return rc;
         z = p->d_zbuf;
     }

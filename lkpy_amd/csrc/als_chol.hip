@@ -1936,6 +1936,12 @@ extern "C" void lk_als_plan_destroy(lk_als_plan *p)
     if (p->ev[0][0])
         for (int i = 0; i < lk_als_plan::TIMING_RING; ++i)
             for (int j = 0; j < 3; ++j) (void)hipEventDestroy(p->ev[i][j]);
+    if (p->side) {
+        (void)hipStreamSynchronize(p->side);
+        (void)hipStreamDestroy(p->side);
+        (void)hipEventDestroy(p->ev_fork);
+        (void)hipEventDestroy(p->ev_join);
+    }
     if (p->d_order) (void)hipFree(p->d_order);
     if (p->d_row_slab) (void)hipFree(p->d_row_slab);
     if (p->d_chunk_row) (void)hipFree(p->d_chunk_row);

@@ -99,6 +99,11 @@ struct lk_als_plan {
     bool timing = false;
     mutable int timing_n = 0;
     mutable hipEvent_t ev[TIMING_RING][3] = {};
+    // side stream of the half-epoch: OtOr^-1 (spd_inverse.hip: a ONE-workgroup sweep, 0.25 ms at
+    // k = 128, 1.7 ms at k = 256) runs there under the chunk kernel instead of in front of the
+    // Z GEMM on the launch stream (created on first use; LK_ALS_SIDE_STREAM=0: launch stream)
+    mutable hipStream_t side = nullptr;
+    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace lk {
