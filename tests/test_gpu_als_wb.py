@@ -247,3 +247,81 @@ def test_row_slices_with_negative_values_keep_the_dense_kernels(gpu, oracle, rng
                                     (hi - lo, n_cols), full2.h_indptr[lo:hi + 1]), k,
                         _native.SOLVER_CHOLESKY) for lo, hi in cuts]
     assert D.ALSPlanGroup(plans2, n_cols).use_wb
+
+
+@pytest.mark.parametrize("k", [128, 256])
+def test_side_stream_inverse_changes_nothing(gpu, rng, monkeypatch, k):
+    """OtOr^-1 on the plan's side stream (under the chunk kernel, csrc/als_blk.hip) against the
+    same work on the launch stream (`LK_ALS_SIDE_STREAM=0`): bit-identical half-epochs, also when
+    repeated (the fork / join events are reused)."""
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    n_cols = 20000
+    lens = np.concatenate([rng.integers(0, 17, 3000), rng.integers(17, 200, 500), [2500, 5000]])
+    indptr = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=indptr[1:])
+    indices = np.concatenate(
+        [np.sort(rng.choice(n_cols, n, replace=False)) for n in lens]).astype(np.int32)
+    mat = sps.csr_array((np.full(indptr[-1], 40.0, np.float32), indices, indptr),
+                        shape=(len(lens), n_cols))
+    other = (rng.standard_normal((n_cols, k)) * 0.1).astype(np.float32)
+    csr = D.DeviceCSR.from_arrays(mat.indptr.astype(np.int32), mat.indices, mat.data, mat.shape, gpu)
+    d_other = D.to_device_padded(other, gpu)
+    d_otor = D.Gramian(k, gpu)(d_other, 0.1)
+    monkeypatch.setenv("LK_ALS_WB_MIN_ROWS", "1")
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LK_ALS_SIDE_STREAM", mode)
+        plan = D.ALSPlan(csr, k, _native.SOLVER_CHOLESKY)
+        assert plan.use_wb
+        d_this = D.to_device_padded(np.zeros((mat.shape[0], k), np.float32), gpu)
+        for _ in range(3):
+            plan.half_epoch(d_this, d_other, d_otor)
+        plan.check_status()
+        got[mode] = D.to_host_unpadded(d_this, k)
+    assert np.isfinite(got["1"]).all()
+    assert np.array_equal(got["1"], got["0"])
+
+
+@pytest.mark.parametrize("limit", ["0", "32", "64"])
+def test_k128_woodbury_range_knob(gpu, oracle, rng, monkeypatch, limit):
+    """Padded k = 128: `LK_ALS_WB64_K128` = 0 / 32 / 64 sends rows of up to 16 / 32 / 64 entries
+    through the Woodbury kernels; every setting within 1e-4 of the oracle's dense sposv, and the
+    rows outside the range bit-identical to the all-dense run."""
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    k, n_cols = 128, 6000
+    lens = np.concatenate([rng.integers(0, 100, 2500), rng.integers(100, 400, 100)])
+    indptr = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=indptr[1:])
+    indices = np.concatenate(
+        [np.sort(rng.choice(n_cols, n, replace=False)) for n in lens]).astype(np.int32)
+    mat = sps.csr_array((np.full(indptr[-1], 40.0, np.float32), indices, indptr),
+                        shape=(len(lens), n_cols))
+    other = (rng.standard_normal((n_cols, k)) * 0.1).astype(np.float32)
+    this = np.zeros((len(lens), k), np.float32)
+    want = this.copy()
+    oracle.als_half_epoch(mat, want, other, oracle.implicit_otor(other, 0.1))
+    csr = D.DeviceCSR.from_arrays(mat.indptr.astype(np.int32), mat.indices, mat.data, mat.shape, gpu)
+    d_other = D.to_device_padded(other, gpu)
+    d_otor = D.Gramian(k, gpu)(d_other, 0.1)
+
+    def run(min_rows):
+        monkeypatch.setenv("LK_ALS_WB_MIN_ROWS", str(min_rows))
+        plan = D.ALSPlan(csr, k, _native.SOLVER_CHOLESKY)
+        d_this = D.to_device_padded(this, gpu)
+        plan.half_epoch(d_this, d_other, d_otor)
+        plan.check_status()
+        return plan, D.to_host_unpadded(d_this, k)
+
+    monkeypatch.setenv("LK_ALS_WB64_K128", limit)
+    plan, got = run(1)
+    _, dense = run(0)
+    top = max(16, int(limit))
+    assert plan.use_wb and plan.woodbury_rows == int((lens <= top).sum())
+    assert np.array_equal(got[lens > top], dense[lens > top])
+    assert not np.array_equal(got[(lens > 0) & (lens <= top)], dense[(lens > 0) & (lens <= top)])
+    err = np.linalg.norm(got - want, axis=1)
+    assert np.all(err <= 5 * RTOL * np.maximum(np.linalg.norm(want, axis=1), 1e-3))
