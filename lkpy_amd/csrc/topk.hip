@@ -814,12 +814,13 @@ __global__ __launch_bounds__(256) void cand_select_kernel(
     int64_t user_base, int n, int32_t *__restrict__ out_idx, float *__restrict__ out_score,
     int64_t out_ld, int *__restrict__ redo /* [0] = count, [1 ..] = user rows */, int redo_cap,
     int *__restrict__ big /* [0] = count, [1 ..] = batch rows with more than LCAP candidates */,
-    int big_cap, const int *__restrict__ row_list /* second tier: the rows to take, or null */)
+    int big_cap, const int *__restrict__ row_list /* second tier: the rows to take, or null */,
+    int64_t row0 = 0 /* first tier over a row range: batch row of workgroup 0 */)
 {
     __shared__ unsigned long long key[LCAP];
     __shared__ int hslot[2 * LCAP];  // open addressing: candidate position + 1, 0 = empty
     const int tid = threadIdx.x;
-    int64_t b = blockIdx.x;
+    int64_t b = blockIdx.x + row0;
     if (row_list) {  // second tier: one workgroup per listed row
         if ((int)blockIdx.x >= min(row_list[0], big_cap)) return;
         b = row_list[1 + blockIdx.x];
@@ -1333,6 +1334,22 @@ static int64_t fused_sub_items(int64_t n_items, int32_t n)
 }
 // the sample is every stride-th item (item ids often follow popularity or age: a prefix of the
 // catalogue would not be representative)
+// LK_TOPK_OVERLAP=0: no side stream (see stage 2 of the fused path)
+static bool topk_overlap()
+{
+    const char *e = getenv("LK_TOPK_OVERLAP");
+    return !(e && e[0] == '0');
+}
+struct TopkSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static TopkSide &topk_side()
+{
+    static thread_local TopkSide s;  // (one per host thread: the sharded tests run ranks as threads)
+    return s;
+}
+
 static int fused_stride(int64_t n_items, int32_t n)
 {
     const int64_t st = n_items / fused_sub_items(n_items, n);
@@ -1585,34 +1602,72 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
                                tau_mask ? (size_t)words * 16 : 0, st, sub, ld_sub, n_sub, r_tau, rows,
                                tau, cnt, d_excl_ptr, d_excl_items, ub, stride, tau_mask ? words : 0);
             // stage 2: the full contraction, candidates only
-            // one workgroup per 128 users, walking all item tiles (no global atomics)
-            const dim3 ugrid((unsigned)((rows + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB)));
-            if (LK_TOPK_DMA && KP == 64)
-                hipLaunchKernelGGL(lk::score_filter64_kernel, ugrid, dim3(256), 0, st, ub_users, rows,
-                                   d_items, n_items, tau, cand, cnt, lk::FUSED_CAP);
-#if LK_TOPK_DMA >= 2
-            else if (KP == 32)
-                hipLaunchKernelGGL(lk::score_filter_slab_kernel<32>, ugrid, dim3(256), 0, st, ub_users,
-                                   rows, d_items, n_items, tau, cand, cnt, lk::FUSED_CAP);
-            else if (KP == 128)
-                hipLaunchKernelGGL(lk::score_filter_slab_kernel<128>, ugrid, dim3(256), 0, st, ub_users,
-                                   rows, d_items, n_items, tau, cand, cnt, lk::FUSED_CAP);
-            else if (KP == 256)
-                hipLaunchKernelGGL(lk::score_filter_slab_kernel<256>, ugrid, dim3(256), 0, st, ub_users,
-                                   rows, d_items, n_items, tau, cand, cnt, lk::FUSED_CAP);
-#endif
-            else
-                hipLaunchKernelGGL(lk::score_filter_kernel, ugrid, dim3(256), 0, st, ub_users,
-                                   ld_users, rows, d_items, ld_items, n_items, KP, (float *)nullptr,
-                                   (int64_t)0, tau, cand, cnt, lk::FUSED_CAP);
-            // stage 3: exclusions, exact order
+            // one workgroup per 128 users, walking all item tiles (no global atomics).
+            // The workgroups all take the same time and two fit a CU: a grid that is not a multiple
+            // of 2 x 256 ends in a partial round with ONE workgroup per CU (cfg2: 1270 workgroups
+            // = 2 full rounds + 246), half of every CU's registers and LDS idle for ~2.5 ms.  The
+            // rows of the full rounds (range A) are therefore filtered by a launch of their own and
+            // their selection -- latency-bound, 16 KiB of LDS per row -- runs on a side stream in
+            // the shadow of the last round (range B); LK_TOPK_OVERLAP=0: one launch each, in order
             int *big = redo + 1 + lk::FUSED_REDO_CAP;  // [0] = count, [1 ..] = rows
             LK_HIP_CHECK(hipMemsetAsync(big, 0, sizeof(int), st));
-            hipLaunchKernelGGL((lk::cand_select_kernel<lk::FUSED_LCAP, lk::FUSED_CAP>),
-                               dim3((unsigned)rows), dim3(256), 0, st, cand, cnt, d_excl_ptr,
-                               d_excl_items, ub, n, d_out_idx + ub * n,
-                               d_out_score ? d_out_score + ub * n : nullptr, (int64_t)n, redo,
-                               lk::FUSED_REDO_CAP, big, lk::FUSED_BIG_CAP, (const int *)nullptr);
+            const int64_t wgs = (rows + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB);
+            const int64_t round = 2 * 256;
+            int64_t rows_a = rows;  // rows of range A (all of them: no split)
+            if (lk::topk_overlap() && wgs > round && wgs % round != 0)
+                rows_a = (wgs / round) * round * (2 * lk::SC_UB);
+            auto filter = [&](int64_t r0, int64_t nr, hipStream_t s) {
+                const dim3 ugrid((unsigned)((nr + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB)));
+                const float *uu = ub_users + r0 * ld_users;
+                float *tau_r = tau + r0;
+                unsigned *cnt_r = cnt + r0;
+                unsigned long long *cand_r = cand + r0 * lk::FUSED_CAP;
+                if (LK_TOPK_DMA && KP == 64)
+                    hipLaunchKernelGGL(lk::score_filter64_kernel, ugrid, dim3(256), 0, s, uu, nr,
+                                       d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP);
+#if LK_TOPK_DMA >= 2
+                else if (KP == 32)
+                    hipLaunchKernelGGL(lk::score_filter_slab_kernel<32>, ugrid, dim3(256), 0, s, uu,
+                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP);
+                else if (KP == 128)
+                    hipLaunchKernelGGL(lk::score_filter_slab_kernel<128>, ugrid, dim3(256), 0, s, uu,
+                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP);
+                else if (KP == 256)
+                    hipLaunchKernelGGL(lk::score_filter_slab_kernel<256>, ugrid, dim3(256), 0, s, uu,
+                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP);
+#endif
+                else
+                    hipLaunchKernelGGL(lk::score_filter_kernel, ugrid, dim3(256), 0, s, uu, ld_users,
+                                       nr, d_items, ld_items, n_items, KP, (float *)nullptr,
+                                       (int64_t)0, tau_r, cand_r, cnt_r, lk::FUSED_CAP);
+            };
+            // stage 3, first tier: exclusions, exact order
+            auto select = [&](int64_t r0, int64_t nr, hipStream_t s) {
+                hipLaunchKernelGGL((lk::cand_select_kernel<lk::FUSED_LCAP, lk::FUSED_CAP>),
+                                   dim3((unsigned)nr), dim3(256), 0, s, cand, cnt, d_excl_ptr,
+                                   d_excl_items, ub, n, d_out_idx + ub * n,
+                                   d_out_score ? d_out_score + ub * n : nullptr, (int64_t)n, redo,
+                                   lk::FUSED_REDO_CAP, big, lk::FUSED_BIG_CAP, (const int *)nullptr,
+                                   r0);
+            };
+            filter(0, rows_a, st);
+            if (rows_a < rows) {
+                lk::TopkSide &sd = lk::topk_side();
+                if (!sd.stream) {
+                    LK_HIP_CHECK(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
+                    LK_HIP_CHECK(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+                    LK_HIP_CHECK(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
+                }
+                LK_HIP_CHECK(hipEventRecord(sd.fork, st));  // range A filtered
+                LK_HIP_CHECK(hipStreamWaitEvent(sd.stream, sd.fork, 0));
+                filter(rows_a, rows - rows_a, st);
+                select(0, rows_a, sd.stream);
+                LK_HIP_CHECK(hipEventRecord(sd.join, sd.stream));
+                select(rows_a, rows - rows_a, st);
+                LK_HIP_CHECK(hipStreamWaitEvent(st, sd.join, 0));
+            } else {
+                select(0, rows, st);
+            }
             hipLaunchKernelGGL((lk::cand_select_kernel<lk::FUSED_CAP, lk::FUSED_CAP>),
                                dim3((unsigned)(rows < lk::FUSED_BIG_CAP ? rows : lk::FUSED_BIG_CAP)),
                                dim3(256), 0, st, cand, cnt, d_excl_ptr, d_excl_items, ub, n,
