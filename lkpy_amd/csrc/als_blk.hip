@@ -1307,6 +1307,11 @@ __global__ void als_blk_prep_otor_kernel(const float *__restrict__ otor, int ld_
 }
 
 // LK_ALS_WB4=0: rows with <= 4 entries take the wave-per-row kernel too (A/B timing, tests)
+static bool als_wb8_enabled()
+{
+    const char *e = getenv("LK_ALS_WB8");
+    return !(e && e[0] == '0');
+}
 static bool als_wb4_enabled()
 {
     const char *e = getenv("LK_ALS_WB4");
@@ -1452,12 +1457,17 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
                : (use_wb ? (wb128 ? p->t_128 : n_wb64_first) : n_rows);
     if (use_wb) {
         // <= 4 entries (and empty rows): four rows per wave; 5 .. 16: a wave per row
+        // (5 .. 8 entries: two rows per wave, LK_ALS_WB8=0: a wave per row)
         const int64_t t4 = als_wb4_enabled() ? p->t_4 : n_rows;
-        int rc = als_wb_launch(p, indptr, IS64 ? 1 : 0, indices, values, p->t_short, t4, this_,
+        const int64_t t8 = als_wb8_enabled() ? p->t_8 : t4;
+        int rc = als_wb_launch(p, indptr, IS64 ? 1 : 0, indices, values, p->t_short, t8, this_,
                                other, z, row_delta, status, st);
         if (rc != LK_OK) return rc;
+        rc = als_wb4_launch(p, indptr, IS64 ? 1 : 0, indices, values, t8, t4, this_, other, z,
+                            row_delta, status, st, 8);
+        if (rc != LK_OK) return rc;
         rc = als_wb4_launch(p, indptr, IS64 ? 1 : 0, indices, values, t4, n_rows, this_, other,
-                            z, row_delta, status, st);
+                            z, row_delta, status, st, 4);
         if (rc != LK_OK) return rc;
         // rows with 17 .. 64 entries: the same identity with a 64 x 64 system
         rc = als_wb64_launch(p, indptr, IS64 ? 1 : 0, indices, values, n_wb64_first, p->t_short,

@@ -1761,6 +1761,15 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
         }
         p->t_short = lo;
         hi = n_rows;
+        while (lo < hi) {  // first task whose row has <= 8 entries
+            const int64_t mid = (lo + hi) >> 1;
+            if (len(order[(size_t)mid]) > 8)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        p->t_8 = lo;
+        hi = n_rows;
         while (lo < hi) {  // first task whose row has <= 4 entries
             const int64_t mid = (lo + hi) >> 1;
             if (len(order[(size_t)mid]) > 4)

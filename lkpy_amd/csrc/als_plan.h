@@ -46,6 +46,7 @@ struct lk_als_plan {
     int64_t t_short = 0;
     int64_t t_mid = 0;  // rows with 17 .. 64 entries are [t_mid, t_short): als_wb64_kernel
     int64_t t_4 = 0;    // rows with <= 4 entries are [t_4, n_rows): als_wb4_kernel, four per wave
+    int64_t t_8 = 0;    // rows with 5 .. 8 entries are [t_8, t_4): als_wb4_kernel<.., 8>, two per wave
     int64_t t_32 = 0;   // rows with 17 .. 32 entries are [t_32, t_short): the 32 x 32 system of als_wb64_kernel (KP = 128)
     int64_t t_128 = 0;  // rows with 65 .. 128 entries are [t_128, t_mid): als_wb128_kernel (KP = 256)
     // rows [t_cg, n_rows) have at most 16384 / KP entries (256 / 128 / 64 at padded k = 64 /
@@ -137,7 +138,7 @@ int als_wb_launch(const lk_als_plan *p, const void *indptr, int is64, const int3
 int als_wb4_launch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
                    const float *values, int64_t t0, int64_t n_rows, float *this_,
                    const float *other, const float *z, float *row_delta, int *status,
-                   hipStream_t st);
+                   hipStream_t st, int slots = 4);
 // (both Woodbury kernels return at once when status[1] != 0: Z is not available -- OtOr was not
 // positive definite -- and the dense fallback launch of als_blk.hip solves their rows)
 // rows [t0, t1) of the plan order (17 .. 64 entries each), als_wb64_kernel (als_chol.hip)

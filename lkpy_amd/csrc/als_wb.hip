@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void als_wb_kernel(
 // factorisation solves the four independent systems) -- the same DPP quad sums, a quarter of the
 // waves.  Empty rows (n = 0) ride along: zero weights give x = 0; their delta is forced to 0
 // (implicit.rs:98-101).
-template <int KP, bool IS64>
+// B = entry slots per row (4 or 8), 16 / B rows per wave
+template <int KP, bool IS64, int B = 4>
 __global__ __launch_bounds__(256) void als_wb4_kernel(
     const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_tasks,
@@ -253,9 +254,12 @@ __global__ __launch_bounds__(256) void als_wb4_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const int s = lane >> 4, c = lane & 15;
-    const int r4 = c >> 2, e4 = c & 3;
-    const int64_t t = ((int64_t)blockIdx.x * 4 + wave) * 4 + r4;  // this lane's row task
-    if (((int64_t)blockIdx.x * 4 + wave) * 4 >= n_tasks) return;  // wave-uniform
+    static_assert(B == 4 || B == 8, "4 or 8 entry slots per row");
+    constexpr int RPW = 16 / B;          // rows per wave
+    constexpr int DEPTH = B == 4 ? 2 : 3;  // butterfly steps over a row's entry slots
+    const int r4 = c / B, e4 = c % B;    // row of the wave, entry of the row
+    const int64_t t = ((int64_t)blockIdx.x * 4 + wave) * RPW + r4;  // this lane's row task
+    if (((int64_t)blockIdx.x * 4 + wave) * RPW >= n_tasks) return;  // wave-uniform
     if (status[1] != 0) return;  // Z unavailable (OtOr not positive definite): dense fallback
     const bool have = t < n_tasks;
     const int row = have ? order[t] : 0;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void als_wb4_kernel(
     int n = 0;
     if (have) {
         beg = indptr[row];
-        n = (int)(indptr[row + 1] - beg);  // 0 .. 4
+        n = (int)(indptr[row + 1] - beg);  // 0 .. B
     }
     float *xrow = this_ + (int64_t)row * KP;
     float *lds = lds_all[wave];
@@ -294,23 +298,23 @@ __global__ __launch_bounds__(256) void als_wb4_kernel(
 #pragma unroll
         for (int el = 0; el < 4; ++el)
             S0 = __builtin_amdgcn_mfma_f32_16x16x4f32(mq[q][el], zq[q][el], S0, 0, 0, 0);
-    const bool inblock = r4 == s;
+    const bool inblock = r4 == (4 * s) / B;  // (rows 4 s .. 4 s + 3 lie in one block)
 #pragma unroll
     for (int r = 0; r < 4; ++r) S0[r] = inblock ? S0[r] : 0.f;
 
     float r0[4], svi[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        r0[r] = row_sum<2>(S0[r] * w);  // over the row's 4 entry slots (quad), result in e4 == 0
+        r0[r] = row_sum<DEPTH>(S0[r] * w);  // over the row's B entry slots, in each of their lanes
         svi[r] = __shfl(sv, 4 * s + r, 64);
     }
     f32x4 Sm;
 #pragma unroll
     for (int r = 0; r < 4; ++r) Sm[r] = svi[r] * sv * S0[r] + ((4 * s + r) == c ? 1.0f : 0.f);
     *reinterpret_cast<f32x4 *>(&lds[c * 16 + 4 * s]) = Sm;
-    // right-hand side of system rows 4 s .. 4 s + 3: held by the lane (s, c = 4 s) -- the quad
-    // leader of the diagonal block
-    if (c == 4 * s)
+    // right-hand side of system rows 4 s .. 4 s + 3: held by the lanes of their block's entry
+    // slots in row group s; its leader writes
+    if (c == B * ((4 * s) / B))
         *reinterpret_cast<f32x4 *>(&lds[256 + 4 * s]) =
             f32x4{svi[0] * r0[0], svi[1] * r0[1], svi[2] * r0[2], svi[3] * r0[3]};
 
@@ -342,9 +346,9 @@ __global__ __launch_bounds__(256) void als_wb4_kernel(
         const float lj = (lane > j && lane < 16) ? a[j] * rinv : 0.f;
         const float zj = bcast(b, j) * rinv;
         b = fmaf(-lj, zj, b);
-        // (S is block diagonal: only the columns of the same 4 x 4 block can be non-zero)
+        // (S is block diagonal: only the columns of the same B x B block can be non-zero)
 #pragma unroll
-        for (int cc = j + 1; cc < (j | 3) + 1; ++cc) a[cc] = fmaf(-lj, bcast(lj, cc), a[cc]);
+        for (int cc = j + 1; cc < (j | (B - 1)) + 1; ++cc) a[cc] = fmaf(-lj, bcast(lj, cc), a[cc]);
         a[j] = lj;  // row `lane` of L, strictly lower part
     }
     b *= dinv;  // z of L z = rhs
@@ -395,10 +399,10 @@ __global__ __launch_bounds__(256) void als_wb4_kernel(
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         f32x4 xs;
-        xs.x = row_sum<2>(g * zq[q].x);
-        xs.y = row_sum<2>(g * zq[q].y);
-        xs.z = row_sum<2>(g * zq[q].z);
-        xs.w = row_sum<2>(g * zq[q].w);
+        xs.x = row_sum<DEPTH>(g * zq[q].x);
+        xs.y = row_sum<DEPTH>(g * zq[q].y);
+        xs.z = row_sum<DEPTH>(g * zq[q].z);
+        xs.w = row_sum<DEPTH>(g * zq[q].w);
         if (e4 == 0 && have) {
             f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + s * QF + 4 * q);
             const f32x4 old = *dst;
@@ -407,42 +411,56 @@ __global__ __launch_bounds__(256) void als_wb4_kernel(
             d2 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
         }
     }
-    // the row's delta: its four quarter leaders are the lanes (s = 0..3, c = 4 r4)
+    // the row's delta: its four quarter leaders are the lanes (s = 0..3, c = B r4)
     float tot = 0.f;
 #pragma unroll
-    for (int ss = 0; ss < 4; ++ss) tot += __shfl(d2, 16 * ss + 4 * r4, 64);
+    for (int ss = 0; ss < 4; ++ss) tot += __shfl(d2, 16 * ss + B * r4, 64);
     if (s == 0 && e4 == 0 && have) row_delta[row] = n > 0 ? tot : 0.f;  // implicit.rs:98-101
 }
 
 }  // namespace wb
 
-// rows [t0, n_rows) of the plan order (n <= 4 entries each, empty rows included), four per wave
+// rows [t0, n_rows) of the plan order (n <= `slots` entries each, empty rows included), 16 / slots
+// per wave (slots = 4 or 8)
 int als_wb4_launch(const lk_als_plan *p, const void *indptr, int is64, const int32_t *indices,
                    const float *values, int64_t t0, int64_t n_rows, float *this_,
                    const float *other, const float *z, float *row_delta, int *status,
-                   hipStream_t st)
+                   hipStream_t st, int slots)
 {
     const int64_t n = n_rows - t0;
     if (n <= 0) return LK_OK;
-    const dim3 grid((unsigned)((n + 15) / 16)), block(256);
-#define LK_WB4(KPV, IS)                                                                         \
-    hipLaunchKernelGGL((wb::als_wb4_kernel<KPV, IS>), grid, block, 0, st,                       \
+    const int64_t per_wg = 4 * (16 / slots);
+    const dim3 grid((unsigned)((n + per_wg - 1) / per_wg)), block(256);
+#define LK_WB4(KPV, IS, BV)                                                                     \
+    hipLaunchKernelGGL((wb::als_wb4_kernel<KPV, IS, BV>), grid, block, 0, st,                   \
                        static_cast<const typename IndPtr<IS>::type *>(indptr), indices, values, \
                        p->d_order + t0, n, other, z, this_, row_delta, status)
+#define LK_WB4_IS(KPV, BV)     \
+    do {                       \
+        if (is64)              \
+            LK_WB4(KPV, true, BV);  \
+        else                   \
+            LK_WB4(KPV, false, BV); \
+    } while (0)
+    if (slots != 4 && slots != 8) {
+        set_error("Woodbury row solve: %d entry slots per row", slots);
+        return LK_E_INVALID;
+    }
     if (p->KP == 256) {
-        if (is64)
-            LK_WB4(256, true);
+        if (slots == 4)
+            LK_WB4_IS(256, 4);
         else
-            LK_WB4(256, false);
+            LK_WB4_IS(256, 8);
     } else if (p->KP == 128) {
-        if (is64)
-            LK_WB4(128, true);
+        if (slots == 4)
+            LK_WB4_IS(128, 4);
         else
-            LK_WB4(128, false);
+            LK_WB4_IS(128, 8);
     } else {
         set_error("Woodbury row solve: unsupported padded embedding size %d", p->KP);
         return LK_E_INVALID;
     }
+#undef LK_WB4_IS
 #undef LK_WB4
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;

@@ -6,7 +6,7 @@ from lkpy_amd import _device as D, _native
 rng = np.random.default_rng(0)
 n_rows, n_cols = 4000, 4000
 k = int(os.environ.get("K", "256"))
-lens = rng.integers(0, 9, n_rows)
+lens = rng.integers(0, 13, n_rows)
 indptr = np.zeros(n_rows + 1, np.int64); np.cumsum(lens, out=indptr[1:])
 indices = np.concatenate([np.sort(rng.choice(n_cols, l, replace=False)) for l in lens]).astype(np.int32)
 mat = sps.csr_array((np.full(indptr[-1], 40.0, np.float32), indices, indptr), shape=(n_rows, n_cols))
@@ -18,7 +18,7 @@ d_otor = D.Gramian(k, dev)(d_other, 0.1)
 res = {}
 os.environ["LK_ALS_WB_MIN_ROWS"] = "1"
 for mode in ("1", "0"):
-    os.environ["LK_ALS_WB4"] = mode
+    os.environ["LK_ALS_WB4"] = mode; os.environ["LK_ALS_WB8"] = mode
     plan = D.ALSPlan(csr, k, _native.SOLVER_CHOLESKY)
     d_this = torch.zeros((n_rows, d_other.shape[1]), device=dev)
     plan.half_epoch(d_this, d_other, d_otor); plan.check_status()
@@ -27,7 +27,7 @@ for mode in ("1", "0"):
 order = np.argsort(-lens, kind="stable")
 pos = np.empty(n_rows, np.int64); pos[order] = np.arange(n_rows)
 t4 = int((lens > 4).sum())
-for n in range(0, 9):
+for n in range(0, 13):
     m = lens == n
     a, b = res["1"][m], res["0"][m]
     err = np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-6)
