@@ -123,7 +123,11 @@ struct Cfg {
     static constexpr int OFF_ZB = OFF_X + KP;       // z of the current block, double buffered
     static constexpr int OFF_SP = OFF_ZB + 32;      // back substitution: partial sums of 2 waves
     static constexpr int OFF_RED = OFF_SP + 32;     // delta reduction
-    static constexpr int LDS_FLOATS = OFF_RED + 8;
+    // LK_BLK_TWIN: the leader wave's multipliers, column by column, for the other panel waves
+    static constexpr int OFF_COL = OFF_RED + 8;     // [16 columns][16]: L_bb[c][j] at j * 16 + c
+    static constexpr int OFF_CRINV = OFF_COL + 256; // 1 / L_jj of the current block
+    static constexpr int OFF_FLAG = OFF_CRINV + 16; // int: 16 b + (columns of block b published)
+    static constexpr int LDS_FLOATS = OFF_FLAG + 16;
     // slab of one chunk: [wave][T*4 + NL][64]
     static constexpr int SLAB_WAVE = (T * 4 + NL) * 64;
     static constexpr int SLAB = 4 * SLAB_WAVE;
@@ -615,6 +619,9 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
     const bool phantom = wr > wc;
     const int vwave = (wave + rot) & 3;  // role in the panel phase
     const int vtid = vwave * 64 + lane;
+#ifndef LK_BLK_TWIN
+#define LK_BLK_TWIN 0  // 1: the diagonal block is factored by the leader wave only (see phase 2)
+#endif
 #ifndef LK_BLK_SKIP
 #define LK_BLK_SKIP 1  // 0: every wave runs the chain (rounds 1-3; A/B timing, tools/blk_variants.py)
 #endif
@@ -624,6 +631,9 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
     // by symmetry into panel rows: tile (b, tj), lane (j = sub, slot) holds
     // D[i = 4 slot + r][j] = A'[16 tj + j][16 b + 4 slot + r] -> panel row 16 (tj - b) + j,
     // columns 4 slot .. 4 slot + 3 = k-group `slot`
+    if constexpr (LK_BLK_TWIN && b == 0) {  // the twins' column counter starts at 0 for every row
+        if (tid == 0) *reinterpret_cast<volatile int *>(&lds[C::OFF_FLAG]) = 0;
+    }
     if (wr == (b & 1)) {
         sfor<Ib, NL>([&](auto Jc) {
             constexpr int J = decltype(Jc)::value;
@@ -648,6 +658,14 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
 #ifdef LK_BLK_PHASES
     unsigned long long bp2 = bp1;
 #endif
+    // LK_BLK_TWIN: the waves with panel rows other than the leader (vwave 0) do not factor the
+    // diagonal block again (136 v_readlane + 136 FMAs each, a third of the chain): the leader
+    // publishes column j of L_bb and 1 / L_jj in LDS as it gets them and raises a counter; a
+    // twin follows one column behind, its multipliers LDS broadcasts.  (A wave's LDS operations
+    // are performed in order, so data before counter needs only a compiler barrier.)  Same
+    // multipliers, same FMAs in the same order: bit-identical.
+    constexpr bool TWINS = LK_BLK_TWIN && R > 64;  // some wave besides the leader has panel rows
+    const bool twin = TWINS && vwave != 0;         // wave-uniform
     if (has_rows) {
     {
         const int prow = vtid < R ? vtid : R - 1;
@@ -658,32 +676,83 @@ __device__ __forceinline__ void chol_step(f32x4 (&acc)[Cfg<NT>::T], float *__res
             a[4 * g + 1] = t.y;
             a[4 * g + 2] = t.z;
             a[4 * g + 3] = t.w;
-            const f32x4 u = *reinterpret_cast<const f32x4 *>(&P[g * C::P_SUB + sub * 4]);
-            d[4 * g + 0] = u.x;
-            d[4 * g + 1] = u.y;
-            d[4 * g + 2] = u.z;
-            d[4 * g + 3] = u.w;
+            if (!twin) {
+                const f32x4 u = *reinterpret_cast<const f32x4 *>(&P[g * C::P_SUB + sub * 4]);
+                d[4 * g + 0] = u.x;
+                d[4 * g + 1] = u.y;
+                d[4 * g + 2] = u.z;
+                d[4 * g + 3] = u.w;
+            }
         }
         if (vtid == 0) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[c] = lds[C::OFF_Y + 16 * b + c];
         }
     }
-    sfor<0, 16>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const float piv = bcast(d[j], j);
-        minpiv = fminf(minpiv, piv);
-        const float rinv = __builtin_amdgcn_rsqf(piv);
-        myrinv = (sub == j) ? rinv : myrinv;
-        d[j] *= rinv;  // lanes >= j: L[lane][j] (lane j: sqrt(pivot))
-        a[j] *= rinv;  // own row: x_j = (a_j - sum_{c<j} x_c L[j][c]) / L[j][j]
-        sfor<j + 1, 16>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            const float m = bcast(d[j], c);  // L[c][j]
-            d[c] = fmaf(-d[j], m, d[c]);
-            a[c] = fmaf(-a[j], m, a[c]);
+    if (!twin) {
+        sfor<0, 16>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const float piv = bcast(d[j], j);
+            minpiv = fminf(minpiv, piv);
+            const float rinv = __builtin_amdgcn_rsqf(piv);
+            myrinv = (sub == j) ? rinv : myrinv;
+            d[j] *= rinv;  // lanes >= j: L[lane][j] (lane j: sqrt(pivot))
+            if constexpr (TWINS) {
+                // every row group holds the same d: four lanes store the same value
+                lds[C::OFF_COL + j * 16 + sub] = d[j];
+                lds[C::OFF_CRINV + j] = rinv;
+                asm volatile("" ::: "memory");
+                *reinterpret_cast<volatile int *>(&lds[C::OFF_FLAG]) = 16 * b + j + 1;
+            }
+            a[j] *= rinv;  // own row: x_j = (a_j - sum_{c<j} x_c L[j][c]) / L[j][j]
+            sfor<j + 1, 16>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const float m = bcast(d[j], c);  // L[c][j]
+                d[c] = fmaf(-d[j], m, d[c]);
+                a[c] = fmaf(-a[j], m, a[c]);
+            });
         });
-    });
+    } else {
+        const unsigned flag_addr = (unsigned)(uintptr_t) reinterpret_cast<void *>(&lds[C::OFF_FLAG]);
+        sfor<0, 16>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            // wait for column j.  ONE asm statement, not a C loop: a loop in the middle of this
+            // straight-line code makes the register allocator spill the accumulators around it
+            // (scratch 20 -> 816 B at k = 128).  Bounded: a wait that gives up reports the row.
+            int seen, sval, spins;
+            asm volatile(
+                "s_mov_b32 %2, 0\n"
+                "1:\n\t"
+                "ds_read_b32 %0, %3\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_readfirstlane_b32 %1, %0\n\t"
+                "s_cmp_ge_i32 %1, %4\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "s_add_u32 %2, %2, 1\n\t"
+                "s_cmp_lt_u32 %2, 0x10000\n\t"
+                "s_cbranch_scc1 1b\n"
+                "2:"
+                : "=&v"(seen), "=&s"(sval), "=&s"(spins)
+                : "v"(flag_addr), "s"(16 * b + j + 1)
+                : "memory", "scc");
+            if (spins >= 0x10000) minpiv = -1.0f;  // (never: reported as a failed solve)
+            const float rinv = lds[C::OFF_CRINV + j];
+            float m[16];
+#pragma unroll
+            for (int q = (j + 1) / 4; q < 4; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(&lds[C::OFF_COL + j * 16 + 4 * q]);
+                m[4 * q + 0] = t.x;
+                m[4 * q + 1] = t.y;
+                m[4 * q + 2] = t.z;
+                m[4 * q + 3] = t.w;
+            }
+            a[j] *= rinv;
+            sfor<j + 1, 16>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                a[c] = fmaf(-a[j], m[c], a[c]);
+            });
+        });
+    }
 
 #ifdef LK_BLK_PHASES
     bp2 = __builtin_amdgcn_s_memtime();
