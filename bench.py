@@ -1258,6 +1258,10 @@ def main():
                     help="N > 1: also time the sharded item-kNN build and dense top-N (on by "
                     "default since round 4; a failure there is reported in place and never "
                     "costs the headline; --no-sharded-legs skips them)")
+    ap.add_argument("--sharded-legs-timeout", type=int, default=240,
+                    help="N > 1: seconds after which a watchdog prints the headline line without "
+                    "the sharded legs and ends the run (a rank failing alone would otherwise "
+                    "leave the others in a collective)")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg5"],
                     help="cfg2: ML-25M-shaped (the default, BASELINE.json configs[1..3]); "
                     "cfg5: synthetic 10M x 1M x 100M generated in HBM, k = 256 (configs[4])")
@@ -1457,10 +1461,29 @@ def main():
         return res
 
     if world > 1 and args.sharded_legs:
+        # The headline is measured; these two legs have never run on more than one GPU.  A rank
+        # that fails alone would leave the others in a collective for ever and the run without
+        # its line: every rank arms the same watchdog, rank 0's prints the headline line as it
+        # stands, then all leave.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["sharded_legs_error"] = ("timeout: no answer from the sharded legs in "
+                                             "%d s, headline line emitted by the watchdog"
+                                             % args.sharded_legs_timeout)
+                emit(out)
+                sys.stdout.flush()
+            os._exit(0)
+
+        dog = threading.Timer(args.sharded_legs_timeout, bail)
+        dog.daemon = True
+        dog.start()
         try:
             extra = sharded_legs()
         except Exception as exc:  # noqa: BLE001 -- reported, not swallowed
             extra = {"sharded_legs_error": f"{type(exc).__name__}: {exc}"}
+        dog.cancel()
         out.update(extra)
 
     def cg_leg():
