@@ -794,6 +794,9 @@ __device__ __forceinline__ void swap16(float &a, float &b)
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
+#ifndef LK_ALS_NOBRANCH
+#define LK_ALS_NOBRANCH 1
+#endif
 template <int NT, int M>
 __device__ __forceinline__ void hybrid_step(Gram<NT> &G, float &b, float &minpiv,
                                             float *__restrict__ lds, const int lane)
@@ -821,11 +824,24 @@ __device__ __forceinline__ void hybrid_step(Gram<NT> &G, float &b, float &minpiv
         const float piv = bcast(pr[s0], j);
         minpiv = fminf(minpiv, piv);
         const float rinv = __builtin_amdgcn_rsqf(piv);
+#if LK_ALS_NOBRANCH
+        // (no exec-mask round trips in the column loop: rinv is wave-uniform, every lane stores
+        // the same value to the same word; lanes outside the stored segment of column j aim at
+        // their own word of the extraction scratch, which is dead until the next panel)
+        rinvarr[j] = rinv;
+        const float lj = (lane > j) ? pr[s0] * rinv : 0.f;  // strictly-lower column j
+        if (j + 1 < KP) {
+            const bool in = lane >= P::c0(j) && lane < KP;
+            float *dst = in ? &lds[P::off(j) + lane - P::c0(j)] : &scr[lane];
+            *dst = lj;
+        }
+#else
         if (lane == 0) rinvarr[j] = rinv;
         const float lj = (lane > j) ? pr[s0] * rinv : 0.f;  // strictly-lower column j
         if (j + 1 < KP) {
             if (lane >= P::c0(j) && lane < KP) lds[P::off(j) + lane - P::c0(j)] = lj;
         }
+#endif
         // forward substitution: z_j = y_j / L_jj, y -= L[:, j] z_j
         const float zj = bcast(b, j) * rinv;
         b = fmaf(-lj, zj, b);
