@@ -154,12 +154,16 @@ int lk_als_plan_set_ctl(lk_als_plan *plan, lk_task_ctl *ctl);
  * Z = other * OtOr^-1 ([n_cols x lk_padded_dim(k)], pad columns zero) supplied by the caller,
  * lk_als_implicit_half_epoch solves those rows through the Woodbury identity (an n x n
  * system, O(n^2 k) instead of the k^3/3 of `sposv`, src/accel/als/solve.rs:65-107) -- the
- * same solution in exact arithmetic, no iteration (n <= 16: one 16 x 16 system per wave;
- * 17 .. 64: a 64 x 64 system on the k = 64 solver).  lk_als_plan_short_rows: how many rows of
+ * same solution in exact arithmetic, no iteration (n <= 4 / 8: four / two rows per wave in one
+ * 16 x 16 tile; n <= 16: one 16 x 16 system per wave; 17 .. 64: a 32 x 32 or 64 x 64 system on the
+ * k <= 64 solver; 65 .. 128 at padded k = 256: a 128 x 128 system on the k = 128 blocked solver).  lk_als_plan_short_rows: how many rows of
  * the plan have <= 16 entries.  lk_als_plan_set_z: Z for the NEXT half-epoch calls (NULL: every row
  * takes the dense solve); the buffer must stay alive until those calls have finished. */
 int64_t lk_als_plan_short_rows(const lk_als_plan *plan);
-int64_t lk_als_plan_woodbury_rows(const lk_als_plan *plan); /* rows with <= 64 entries */
+/* rows the 16 x 16 ... 64 x 64 Woodbury systems take: <= 64 entries at padded k = 256 (rows of
+ * 65 .. 128 entries additionally take a 128 x 128 system there unless LK_ALS_WB128=0); at padded
+ * k = 128 <= 64 / 32 / 16 entries with LK_ALS_WB64_K128 = 64 (default) / 32 / 0 */
+int64_t lk_als_plan_woodbury_rows(const lk_als_plan *plan);
 int lk_als_plan_set_z(lk_als_plan *plan, const float *d_z);
 /* The same path with NOTHING computed on the caller's side: hand the plan a device buffer of
  * n_cols x lk_padded_dim(k) floats and every lk_als_implicit_half_epoch run with it forms Z
