@@ -119,21 +119,47 @@ int lk_gramian(const float *d_m, int64_t n, int32_t k, int32_t ld, float reg, fl
  * ---------------------------------------------------------------------- */
 typedef struct lk_als_plan lk_als_plan;
 
+/* Default plan = LK_ALS_PLAN_HYBRID_ORDER (round 5), unless the environment says
+ * LK_ALS_RHS_ORDER=accurate (flags 0) or =reference (LK_ALS_PLAN_REFERENCE_ORDER). */
 int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int indptr_is_64, int64_t n_rows,
                        int32_t k, int32_t solver);
-/* The same with flags.  LK_ALS_PLAN_REFERENCE_ORDER: strict reproduction of the reference's
- * ARITHMETIC ORDER on long rows (exact solver only).  `mtl.dot(&o_picked)`
+/* The same with explicit flags (0 = the tuned kernels' own "accurate" summation everywhere).
+ *
+ * The reference's ARITHMETIC ORDER on long rows: `mtl.dot(&o_picked)`
  * (src/accel/als/implicit.rs:112) is matrixmultiply's sgemm, which sums the row's entries in
  * blocks of KC = 256 -- one fma chain per block, the block sums added one after the other -- and
- * `mt.dot(&vals)` (implicit.rs:117) is one sequential chain per feature.  Such a plan cuts every
- * row of more than 256 entries into 256-entry chunks (one MFMA fmaf chain each), adds the chunk
- * slabs in chunk order, OtOr last, and takes y from lk_als_plan_set_rhs_workspace (mandatory for
- * it).  Slower and, on rows of 10^5+ entries, FURTHER from the exact solution than the default
- * plan -- exactly as far as the reference is: tests/test_gpu_als_rhs_order.py. */
+ * `mt.dot(&vals)` (implicit.rs:117) is ONE sequential float32 chain per feature.  On rows of
+ * 10^4 .. 10^6 entries those two sums drift systematically (1e-4 .. 7e-2 from the float64 sums),
+ * so a kernel that sums more accurately lands that far from the REFERENCE's factors.
+ *
+ * LK_ALS_PLAN_HYBRID_ORDER (default): rows with more than LK_ALS_REF_LEN entries (environment,
+ * default 2048 -- the rows that are pre-reduced in chunks anyway) are evaluated in the reference's
+ * order: 256-entry chunks (one MFMA fmaf chain each, from zero), the chunk slabs added one after
+ * the other in chunk order, OtOr last, y by the sequential chain of csrc/als_rhs.hip (bit-identical
+ * to the reference's y).  Shorter rows keep the tuned order (the two agree to ~1e-5 there).  The
+ * y buffer is part of the plan's workspace; works with task control, CSR views with row offsets
+ * and any row / column relabelling (the chain runs over the row's entries as the CSR lists them:
+ * give the rows in the reference's entry order -- ascending column of the ORIGINAL labelling).
+ * k <= 256, exact solver; other plans ignore the flag.
+ *
+ * LK_ALS_PLAN_REFERENCE_ORDER: the strict variant -- EVERY row of more than 256 entries in
+ * 256-entry chunks and every dense row's y by the chain; takes y from
+ * lk_als_plan_set_rhs_workspace ([n_rows x lk_padded_dim(k)], mandatory for it), no task control.
+ * tests/test_gpu_als_rhs_order.py. */
 #define LK_ALS_PLAN_REFERENCE_ORDER 1
+#define LK_ALS_PLAN_HYBRID_ORDER 2
 int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, int indptr_is_64,
                           int64_t n_rows, int32_t k, int32_t solver, int32_t flags);
 void lk_als_plan_destroy(lk_als_plan *plan);
+/* Rows of the plan that are pre-reduced in chunks (longer than 2048 entries; LK_ALS_REF_LEN for
+ * hybrid plans; 256 for strict reference-order plans): the first tasks of the longest-first
+ * order, i.e. the rows sorted by descending length, ties in row order. */
+int64_t lk_als_plan_long_rows(const lk_als_plan *plan);
+/* Hybrid plans: the right-hand sides of those rows as the last half-epoch run with workspace
+ * `d_ws` formed them in the reference's order -- [lk_als_plan_long_rows x lk_padded_dim(k)]
+ * floats, row t = the t-th longest row (device pointer into d_ws; NULL for other plans).
+ * Diagnostic / test access: tests/test_gpu_als_rhs_order.py holds it to the chain bit for bit. */
+const float *lk_als_plan_yref(const lk_als_plan *plan, const void *d_ws);
 /* Device workspace the half-epoch needs (bytes); allocate once, reuse. */
 size_t lk_als_plan_workspace_bytes(const lk_als_plan *plan);
 /* Effective solver of the plan (LK_SOLVER_CHOLESKY or LK_SOLVER_CG). */
@@ -234,13 +260,29 @@ int lk_als_plan_get_timing(lk_als_plan *plan, double *ms_chunk, double *ms_solve
 int lk_als_check_status(const lk_als_plan *plan, void *d_ws, void *stream);
 
 /* Host-pointer convenience form with the reference's exact argument list
- * (this: [n_rows x k] updated in place, other: [n_cols x k], otor: [k x k], all
- * C-contiguous host float32).  Allocates, copies, runs, copies back; blocking. */
+ * (`train_implicit_matrix(matrix, this, other, otor)`, src/accel/als/implicit.rs:35-84:
+ * this: [n_rows x k] updated in place, other: [n_cols x k], otor: [k x k], all C-contiguous
+ * host float32; offsets int32 or int64).  Allocates, copies, runs (default plan: hybrid
+ * summation order; padded k = 128 / 256: the Woodbury kernels for the short rows when there
+ * are >= LK_ALS_WB_MIN_ROWS of them), copies back; blocking.  Errors: LK_E_NOT_SPD with
+ * "ALS solve error: ..." in lk_last_error() (implicit.rs:79), `this` left untouched.
+ * tests/test_gpu_host_abi.py runs INTEGRATION.md's binding sketch through it with raw ctypes. */
 int lk_als_implicit_half_epoch_host(const void *h_indptr, int indptr_is_64,
                                     const int32_t *h_indices, const float *h_values,
                                     int64_t n_rows, int64_t n_cols, int32_t k, float *h_this,
                                     const float *h_other, const float *h_otor, int32_t solver,
                                     float *h_out_frob);
+/* The same with the reference's task controls (src/accel/tasks/mod.rs:62-106,
+ * src/lenskit/parallel/_task.py:25-57): `ctl` (may be NULL) is polled by the running kernels --
+ * lk_task_ctl_cancel from another thread makes the call return LK_E_CANCELLED with the rows
+ * solved so far written to `this` (the reference updates `this` in place row by row as well);
+ * lk_task_ctl_progress reads the live count of finished rows.  With a control block every row
+ * takes the dense kernels (the Woodbury kernels do not poll). */
+int lk_als_implicit_half_epoch_host_ctl(const void *h_indptr, int indptr_is_64,
+                                        const int32_t *h_indices, const float *h_values,
+                                        int64_t n_rows, int64_t n_cols, int32_t k, float *h_this,
+                                        const float *h_other, const float *h_otor,
+                                        int32_t solver, float *h_out_frob, lk_task_ctl *ctl);
 
 /* ------------------------------------------------------------------------
  * Item-item similarity build.

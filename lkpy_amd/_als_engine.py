@@ -208,16 +208,19 @@ class HipBackend:
         self.dev = D.device(dev)
         self.kp = D.padded_dim(k)
         self.solver = solver
-        # strict reproduction of the reference's summation order on long rows (INTEGRATION.md,
-        # LK_ALS_RHS_ORDER): None = what the process environment says
-        if reference_order is None:
-            reference_order = os.environ.get("LK_ALS_RHS_ORDER", "").lower() == "reference"
-        self.reference_order = bool(reference_order) and solver != _native.SOLVER_CG
+        # the order of the two long sums of a row (LK_ALS_RHS_ORDER): "auto" (the
+        # default: rows of more than 2048 entries in the reference's own order), "reference"
+        # (strict: every row of more than 256 entries), "accurate" (round 4's default); None =
+        # what the process environment says
+        self.order_mode = D.als_order_mode(reference_order)
+        if solver == _native.SOLVER_CG or self.kp > 256:
+            self.order_mode = "accurate"
+        self.reference_order = self.order_mode == "reference"
         self._gram = D.Gramian(k, self.dev)
 
     def make_plan(self, local_csr: sps.csr_array):
         csr = self.D.DeviceCSR.from_scipy(local_csr, self.dev)
-        return self.D.ALSPlan(csr, self.k, self.solver, reference_order=self.reference_order)
+        return self.D.ALSPlan(csr, self.k, self.solver, reference_order=self.order_mode)
 
     def make_plans_on_device(self, ui, u_old, i_new, i_old, u_rng, i_rng, ilen=None):
         """
@@ -265,7 +268,32 @@ class HipBackend:
             D._ptr(d_row_src), D._ptr(d_uptr), D._ptr(d_col_map), D._ptr(idx), D._ptr(val),
             D._stream()), "lk_csr_relabel")
         ui_new = D.DeviceCSR(d_uptr, idx, val, (nu, ni), h_uptr)
-        iu_new = D.csr_transpose(ui_new)  # stable: entries of an item row by ascending new user
+        if self.order_mode == "accurate":
+            iu_new = D.csr_transpose(ui_new)  # stable: entries of an item row by ascending new user
+        else:
+            # The reference sums a row's entries in the order its CSR lists them: ascending
+            # ORIGINAL label of the other side (SciPy's tocsr / .T.tocsr, _common.py:216-219).
+            # The user rows above keep that order (lk_csr_relabel maps the columns, it does not
+            # sort them).  For the item rows the transposition starts from the ORIGINAL row order
+            # -- rows not permuted, columns mapped -- so that the stable transpose lists an item's
+            # entries by ascending original user; the user numbers are relabelled afterwards.  A
+            # row's column indices are then not ascending: no ALS kernel needs them to be.
+            n_u0 = src.shape[0]
+            d_ident = torch.arange(n_u0, dtype=torch.int32, device=dev)
+            idx0 = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
+            val0 = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)[:nnz]
+            _native.check(lib.lk_csr_relabel(
+                D._ptr(src.indptr), 1 if src.is64 else 0, D._ptr(src.indices), D._ptr(src.values),
+                n_u0, D._ptr(d_ident), D._ptr(src.indptr), D._ptr(d_col_map), D._ptr(idx0),
+                D._ptr(val0), D._stream()), "lk_csr_relabel")
+            ui_cm = D.DeviceCSR(src.indptr, idx0, val0, (n_u0, ni), src.h_indptr)
+            iu_new = D.csr_transpose(ui_cm)  # rows = new items, entries by ascending ORIGINAL user
+            d_u_new = torch.full((n_u0,), -1, dtype=torch.int32, device=dev)
+            live = torch.from_numpy(np.flatnonzero(u_old >= 0).astype(np.int64)).to(dev)
+            d_u_new[d_row_src[live].long()] = live.to(torch.int32)
+            iu_new.indices = d_u_new[iu_new.indices.long()]
+            iu_new.shape = (ni, nu)
+            del ui_cm, idx0, val0, d_ident, d_u_new
         iu_new.h_indptr = h_iptr
         del src
 
@@ -273,7 +301,7 @@ class HipBackend:
             view = D.DeviceCSR(full.indptr[lo : hi + 1], full.indices, full.values,
                                (hi - lo, n_cols), h_ptr[lo : hi + 1])
             view.full_h_indptr = h_ptr  # offsets of ALL rows (every rank holds the full arrays)
-            return D.ALSPlan(view, self.k, self.solver, reference_order=self.reference_order)
+            return D.ALSPlan(view, self.k, self.solver, reference_order=self.order_mode)
 
         def plans(full, h_ptr, rngs, n_cols):
             if isinstance(rngs, tuple):
@@ -401,8 +429,9 @@ class ImplicitALSEngine:
             S = 4 if (gathered >= (256 << 20)
                       and min(n_users, n_items) // self.world >= 4 * 1024) else 1
         self.slices = S
-        # strict reference order (LK_ALS_RHS_ORDER=reference on one rank): no relabelling -- the
-        # entries of a row then come in the reference's order, over which its float32 sums run
+        # strict reference order (LK_ALS_RHS_ORDER=reference on one rank): no relabelling at all
+        # (kept from round 4; since round 5 the relabelled engine lists every row's entries in
+        # the reference's order too, so this only fixes the ROW order of the launches)
         keep = bool(getattr(backend, "reference_order", False)) and self.world == 1 and S == 1
         def by_length(lens):
             "rows by descending length, ties in row order: on the device when there is one"

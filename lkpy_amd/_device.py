@@ -231,28 +231,54 @@ class Gramian:
         return out
 
 
+def als_order_mode(x) -> str:
+    "``auto`` / ``reference`` / ``accurate`` from a bool, a string or None (= LK_ALS_RHS_ORDER)"
+    if x is None:
+        x = os.environ.get("LK_ALS_RHS_ORDER", "") or "auto"
+    if x is True:
+        return "reference"
+    if x is False:
+        return "accurate"
+    x = str(x).lower()
+    if x in ("hybrid", "default"):
+        x = "auto"
+    if x not in ("auto", "reference", "accurate"):
+        raise ValueError(f"unknown LK_ALS_RHS_ORDER {x!r} (auto / reference / accurate)")
+    return x
+
+
 class ALSPlan:
     "Row schedule + workspace of one CSR orientation (lk_als_plan)."
 
     def __init__(self, csr: DeviceCSR, k: int, solver: int = _native.SOLVER_AUTO,
-                 reference_order: bool | None = None):
-        """``reference_order``: sum the normal matrix AND the right-hand side of long rows in the
-        reference's own order (lk_als_plan_create_ex, LK_ALS_PLAN_REFERENCE_ORDER + the rhs
-        workspace); None = what ``LK_ALS_RHS_ORDER`` says (``reference`` / default ``accurate``)."""
+                 reference_order: "bool | str | None" = None):
+        """``reference_order`` -- how the two long sums of a row (normal matrix, right-hand side)
+        are ordered (include/lkamd.h, ``lk_als_plan_create_ex``; INTEGRATION.md, ``LK_ALS_RHS_ORDER``):
+
+        * ``"auto"`` (the default): rows longer than ``LK_ALS_REF_LEN`` (2048) entries in the
+          reference's own order (LK_ALS_PLAN_HYBRID_ORDER), the others in the tuned kernels' order;
+        * ``"reference"`` / ``True``: strict -- every row of more than 256 entries
+          (LK_ALS_PLAN_REFERENCE_ORDER + the rhs workspace);
+        * ``"accurate"`` / ``False``: the tuned kernels' own summation on every row (round 4's
+          default: closer to the exact solution on rows of 10^4+ entries, up to 7e-2 from the
+          reference there);
+        * ``None``: what ``LK_ALS_RHS_ORDER`` says (default ``auto``).
+        """
         lib = _native.require_gpu()
         self.csr = csr
         self.k = int(k)
         self.kp = padded_dim(k)
         self._h = ctypes.c_void_p(0)
         hp = csr.h_indptr
-        if reference_order is None:
-            reference_order = os.environ.get("LK_ALS_RHS_ORDER", "accurate").lower() == "reference"
-        self.reference_order = bool(reference_order) and int(solver) != _native.SOLVER_CG
+        self.order_mode = als_order_mode(reference_order)
+        if int(solver) == _native.SOLVER_CG or self.kp > 256:
+            self.order_mode = "accurate"  # (no reference arithmetic to reproduce / no slab path)
+        self.reference_order = self.order_mode == "reference"
+        flags = {"accurate": 0, "reference": 1, "auto": 2}[self.order_mode]
         check(
             lib.lk_als_plan_create_ex(
                 ctypes.byref(self._h), hp.ctypes.data_as(ctypes.c_void_p),
-                1 if hp.dtype == np.int64 else 0, csr.shape[0], self.k, int(solver),
-                1 if self.reference_order else 0
+                1 if hp.dtype == np.int64 else 0, csr.shape[0], self.k, int(solver), flags
             ),
             "lk_als_plan_create",
         )  # fmt: skip
@@ -309,6 +335,9 @@ class ALSPlan:
             raise ValueError(f"unknown right-hand-side order {order!r}")
         if order == "accurate" and getattr(self, "reference_order", False):
             raise ValueError("a reference-order plan cannot switch back: build another plan")
+        if getattr(self, "order_mode", "accurate") == "auto":
+            raise ValueError("a hybrid-order plan owns its right-hand-side buffer: build a plan "
+                             "with reference_order='accurate' or 'reference' instead")
         if order == "reference" and self.solver != _native.SOLVER_CHOLESKY:
             return  # the CG option has no reference arithmetic to reproduce
         if order == "reference" and self._yref is None:
@@ -319,6 +348,21 @@ class ALSPlan:
         check(_native.load().lk_als_plan_set_rhs_workspace(
             self._h, _ptr(self._yref) if self._yref is not None else None),
             "lk_als_plan_set_rhs_workspace")
+
+    def long_rows(self) -> int:
+        "rows of the plan that are pre-reduced in chunks (the first tasks of the longest-first order)"
+        return int(_native.load().lk_als_plan_long_rows(self._h))
+
+    def yref_tasks(self) -> "torch.Tensor | None":
+        """Hybrid plans: the right-hand sides the last half-epoch formed in the reference's order,
+        [long_rows x KP], row t = the t-th longest row (a view of the workspace); else None."""
+        lib = _native.load()
+        ptr = lib.lk_als_plan_yref(self._h, _ptr(self.ws))
+        if not ptr:
+            return None
+        off = int(ptr) - int(self.ws.data_ptr())
+        n = self.long_rows() * self.kp
+        return self.ws[off : off + 4 * n].view(torch.float32).view(-1, self.kp)
 
     def share_z_from(self, leader: "ALSPlan"):
         """

@@ -70,6 +70,8 @@ def _declare(lib):
         "lk_als_plan_set_cg": (c_int, [vp, c_float, c_int32]),
         "lk_als_plan_cg_stats": (c_int, [vp, vp, vp, POINTER(c_int64), POINTER(c_int64)]),
         "lk_als_plan_short_rows": (c_int64, [vp]),
+        "lk_als_plan_long_rows": (c_int64, [vp]),
+        "lk_als_plan_yref": (vp, [vp, vp]),
         "lk_als_plan_woodbury_rows": (c_int64, [vp]),
         "lk_als_plan_set_z": (c_int, [vp, vp]),
         "lk_als_plan_set_z_workspace": (c_int, [vp, vp]),
@@ -158,6 +160,10 @@ def _declare(lib):
         "lk_als_implicit_half_epoch_host": (
             c_int,
             [vp, c_int, vp, vp, c_int64, c_int64, c_int32, vp, vp, vp, c_int32, vp],
+        ),
+        "lk_als_implicit_half_epoch_host_ctl": (
+            c_int,
+            [vp, c_int, vp, vp, c_int64, c_int64, c_int32, vp, vp, vp, c_int32, vp, vp],
         ),
     }  # fmt: skip
     for name, (res, args) in sigs.items():

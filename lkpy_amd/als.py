@@ -80,12 +80,14 @@ def _restore_scorer_state(obj, state: dict):
     obj.__dict__.update(state)
 
 
-def _reference_order(options: TrainingOptions) -> bool | None:
+def _reference_order(options: TrainingOptions) -> str | None:
     """``LK_ALS_RHS_ORDER`` through ``TrainingOptions.environment`` (or the process environment):
-    ``reference`` = long rows summed exactly as the reference sums them (INTEGRATION.md,
-    environment knobs); None = not said here, the backend reads the process environment."""
+    ``auto`` (default: rows of more than 2048 entries summed exactly as the reference sums them),
+    ``reference`` (strict: every row of more than 256 entries), ``accurate`` (the tuned kernels'
+    own order everywhere) -- INTEGRATION.md, environment knobs; None = not said here, the backend
+    reads the process environment."""
     order = options.env_var("LK_ALS_RHS_ORDER", None) if options is not None else None
-    return None if not order else order.lower() == "reference"
+    return None if not order else order.lower()
 
 
 class UIPair(BaseModel):

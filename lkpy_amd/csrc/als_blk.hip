@@ -48,6 +48,7 @@
 // 4 * sum_{b<NT} (NT-1-b)(NT-b)/2 (trailing updates) instructions of 2048 flop.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 
@@ -940,7 +941,7 @@ __device__ __forceinline__ void als_blk_solve_body(
     float *__restrict__ this_, const float *__restrict__ notor_p,
     const float *__restrict__ slabs, float *__restrict__ row_delta, int *__restrict__ status,
     int k, float reg, TaskCtlDev ctl, float *lds, const int64_t t,
-    const float *__restrict__ y_ref = nullptr, int chunk_rt = 0)
+    const float *__restrict__ y_ref = nullptr, int chunk_rt = 0, int64_t n_yref = 0)
 {
     using C = Cfg<NT>;
     constexpr int KP = C::KP, NL = C::NL;
@@ -1079,10 +1080,11 @@ __device__ __forceinline__ void als_blk_solve_body(
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             // (y_ref: the right-hand side in the reference's summation order, als_rhs.hip --
-            // natural feature order, primed (t, sub) <-> feature sub * NT + pos(t))
+            // one row of KP floats per TASK t < n_yref, natural feature order, primed (t, sub)
+            // <-> feature sub * NT + pos(t))
             const int tb = 2 * i + wr;
             lds[C::OFF_Y + tb * 16 + sub] =
-                y_ref ? y_ref[(int64_t)row * KP + sub * NT + C::pos(tb)] : yacc[i];
+                (y_ref && t < n_yref) ? y_ref[(int64_t)t * KP + sub * NT + C::pos(tb)] : yacc[i];
         }
     }
     // (the first barrier of chol_step<0> orders these stores before thread 0 reads them)
@@ -1158,13 +1160,13 @@ __device__ __forceinline__ void als_blk_solve_body(
         const float *__restrict__ other, float *__restrict__ this_,                             \
         const float *__restrict__ notor_p, const float *__restrict__ slabs,                     \
         float *__restrict__ row_delta, int *__restrict__ status, int k, float reg,              \
-        TaskCtlDev ctl, const float *__restrict__ y_ref, int chunk_rt)                          \
+        TaskCtlDev ctl, const float *__restrict__ y_ref, int chunk_rt, int64_t n_yref)          \
     {                                                                                           \
         __shared__ __attribute__((aligned(16))) float lds[Cfg<NTV>::LDS_FLOATS];                \
         als_blk_solve_body<NTV, IS64, EXPL, CTL>(indptr, indices, values, order, n_rows,        \
                                                  row_slab, other, this_, notor_p, slabs,        \
                                                  row_delta, status, k, reg, ctl, lds,           \
-                                                 (int64_t)blockIdx.x, y_ref, chunk_rt);         \
+                                                 (int64_t)blockIdx.x, y_ref, chunk_rt, n_yref); \
     }
 
 LK_BLK_KERNEL(als_blk_solve_kernel16, 16, LK_ALS_BLK_ATTR16)
@@ -1471,6 +1473,25 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     }
     const bool tm = p->timing && p->timing_n < lk_als_plan::TIMING_RING;
     if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][0], st));
+    // rows whose right-hand side comes from the reference-order chain (als_rhs.hip): the long
+    // rows (the first n_long tasks) of a hybrid plan, every dense row of a strict one.  The
+    // chains run on the plan's second stream under the chunk and Woodbury kernels.
+    float *yref = p->hybrid ? reinterpret_cast<float *>(ws + p->off_yref)
+                            : (p->ctl ? nullptr : p->d_yref);
+    const int ref_chunk = (p->ref_order || p->hybrid) ? p->chunk : 0;
+    int64_t n_yhyb = 0;  // hybrid plans: the long rows' chains, forked here
+    if (yref && p->hybrid) {
+        n_yhyb = p->n_long;
+        if (p->dense_limit >= 0 && p->dense_limit < n_yhyb) n_yhyb = p->dense_limit;
+        if (n_yhyb > 0) {
+            hipStream_t sr = st;
+            int rc = plan_fork_rhs(p, st, &sr);
+            if (rc != LK_OK) return rc;
+            rc = launch_rhs_reference(p, indptr, IS64 ? 1 : 0, indices, values, p->d_order,
+                                      n_yhyb, other, EXPL, yref, sr);
+            if (rc != LK_OK) return rc;
+        }
+    }
     if (p->n_chunks > 0) {
         bool dma = false;
         if constexpr (NT == 16) dma = chunk_dma_enabled();
@@ -1494,7 +1515,20 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
         }
     }
     {
-        int rc = launch_slab_group_reduce(p, slabs, (size_t)C::SLAB, st);
+        // hybrid plans: the ordered slab sums (pure HBM streaming) go to the chains' stream and
+        // run under the Woodbury kernels; the dense launch joins that stream anyway
+        // (LK_ALS_REDUCE_SIDE=0: launch stream)
+        hipStream_t sg = st;
+        const char *e = getenv("LK_ALS_REDUCE_SIDE");
+        if (p->hybrid && n_yhyb > 0 && p->n_groups > 0 && p->side_rhs && !(e && e[0] == '0')) {
+            const char *s = getenv("LK_ALS_SIDE_STREAM");
+            if (!(s && s[0] == '0')) {
+                int rc = plan_rhs_wait_main(p, st);
+                if (rc != LK_OK) return rc;
+                sg = p->side_rhs;
+            }
+        }
+        int rc = launch_slab_group_reduce(p, slabs, (size_t)C::SLAB, sg);
         if (rc != LK_OK) return rc;
     }
     if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
@@ -1555,10 +1589,18 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
                                row_delta, status, k);
     }
     if (n_dense > 0) {
-        if (!p->ctl) {  // reference-order right-hand side of the dense rows, if asked for
+        int64_t n_ytasks = 0;  // tasks [0, n_ytasks) take y from the chains
+        if (p->hybrid) {
+            if (n_yhyb > 0) {
+                int rc = plan_join_rhs(p, st);
+                if (rc != LK_OK) return rc;
+            }
+            n_ytasks = std::min<int64_t>(n_yhyb, n_dense);  // (long rows are always dense rows)
+        } else if (yref) {  // strict plans: every dense row, in order on the launch stream
             int rc = launch_rhs_reference(p, indptr, IS64 ? 1 : 0, indices, values, p->d_order,
-                                          n_dense, other, EXPL, st);
+                                          n_dense, other, EXPL, yref, st);
             if (rc != LK_OK) return rc;
+            n_ytasks = n_dense;
         }
         const dim3 grid((unsigned)n_dense), block(256);
         const IT *ip = static_cast<const IT *>(indptr);
@@ -1566,7 +1608,7 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
     hipLaunchKernelGGL((KERN<IS64, EXPL, CTLV>), grid, block, 0, st, ip, indices, values,        \
                        p->d_order, n_dense, p->d_row_slab, other, this_, notor_p, slabs,         \
                        row_delta, status, k, reg, (CTLV) ? p->ctl->dev() : TaskCtlDev{},        \
-                       (CTLV) ? nullptr : p->d_yref, p->ref_order ? p->chunk : 0)
+                       yref, ref_chunk, n_ytasks)
         if constexpr (NT == 16) {
             if (p->ctl)
                 LK_BLK_LAUNCH(als_blk_solve_kernel16, true);

@@ -485,6 +485,74 @@ __device__ __forceinline__ void gram_accumulate_dma(Gram<4> &G, const int32_t *_
     }
 }
 
+// ---- a FULL 256-entry chunk (k = 64) ---------------------------------------------------------
+// Reference-order rows are cut into matrixmultiply's KC = 256 blocks (als_plan.h): every chunk of
+// such a row but its last has exactly 256 entries = 64 groups = 4 batches.  The general routine
+// above sends the last batch of any range down its guarded path (wave-uniform tests, waits that
+// shrink); for a 256-entry chunk that is a quarter of the work.  Here the batch loop is unrolled
+// over the four batches, so every guard and every wait count is a compile-time constant.  Same
+// operations in the same order: bit-identical to gram_accumulate_dma on the same range.
+#ifndef LK_ALS_CHUNK256_FAST
+#define LK_ALS_CHUNK256_FAST 1
+#endif
+__device__ __forceinline__ void gram_accumulate_dma_256(Gram<4> &G, const int32_t *__restrict__ cols,
+                                                        const float *__restrict__ vals, int64_t beg,
+                                                        const float *__restrict__ other,
+                                                        const bool expl, float *ring, float *stage)
+{
+    constexpr int RING = DMA_RING, TOTAL = 64;
+    const int lane = lane_id();
+    const unsigned ring_lds =
+        __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t) reinterpret_cast<void *>(ring));
+    float *const wr0 = stage + lane, *const wr1 = stage + 128 + lane;
+    const float *const rd0 = stage + (lane >> 4), *const rd1 = stage + 128 + (lane >> 4);
+    wr0[0] = __builtin_bit_cast(float, cols[beg + lane]);
+    wr0[64] = vals[beg + lane];
+#pragma unroll
+    for (int g = 0; g < RING; ++g) dma_issue(ring_lds, g, g, rd0, other);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        float *const wr_nxt = (b & 1) ? wr0 : wr1;
+        const float *const rd_cur = (b & 1) ? rd1 : rd0, *const rd_nxt = (b & 1) ? rd0 : rd1;
+        int nxt_col = 0;
+        float nxt_val = 0.f;
+        if (b < 3) {
+            nxt_col = cols[beg + 64 * (b + 1) + lane];
+            nxt_val = vals[beg + 64 * (b + 1) + lane];
+        }
+        {
+            const int later = TOTAL - 1 - 16 * b;
+            wait_vm_upto(later < RING - 1 ? later : RING - 1);
+        }
+        DmaOperand cur = dma_fetch(ring, 0, 0, rd_cur);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int gg = 16 * b + g;
+            DmaOperand nxt = cur;
+            if (g + 1 < 16) {
+                // group gg + 1 must have landed: the groups issued after it are still in flight
+                const int later = TOTAL - 1 - (gg + 1);
+                const int issued_after = (gg + RING < TOTAL ? gg + RING - 1 : TOTAL - 1) - (gg + 1);
+                wait_vm_upto(issued_after < later ? issued_after : later);
+                nxt = dma_fetch(ring, (g + 1) % RING, g + 1, rd_cur);
+            }
+            dma_apply<false>(G, cur, g, 64, expl);
+            if (g == 16 - RING - 2 && b < 3) {
+                wr_nxt[0] = __builtin_bit_cast(float, nxt_col);
+                wr_nxt[64] = nxt_val;
+            }
+            if (gg + RING < TOTAL) {
+                if (g < 16 - RING)
+                    dma_issue(ring_lds, g % RING, g + RING, rd_cur, other);
+                else
+                    dma_issue(ring_lds, g % RING, g + RING - 16, rd_nxt, other);
+            }
+            cur = nxt;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // slab layout: [(NTILES*4 + NT)][64] floats, register-major / lane-minor
 template <int NT>
 __host__ __device__ constexpr int slab_floats()
@@ -530,7 +598,18 @@ __global__ __launch_bounds__(256) void slab_group_reduce_kernel(float *__restric
     float *head = slabs + (size_t)grp_head[g] * slab_floats + e;
     const int cnt = grp_cnt[g];
     f32x4 acc = *reinterpret_cast<const f32x4 *>(head);
-    for (int c = 1; c < cnt; ++c)
+    int c = 1;
+    // (reference-order rows are ONE group of up to thousands of slabs: eight loads in flight,
+    // the additions strictly in chunk order)
+    for (; c + 8 <= cnt; c += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = *reinterpret_cast<const f32x4 *>(head + (size_t)(c + u) * slab_floats);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; c < cnt; ++c)
         acc += *reinterpret_cast<const f32x4 *>(head + (size_t)c * slab_floats);
     *reinterpret_cast<f32x4 *>(head) = acc;
 }
@@ -573,10 +652,15 @@ __device__ __forceinline__ void als_chunk_body(
 #pragma unroll
     for (int t = 0; t < NT; ++t) G.y[t] = 0.f;
     const int64_t beg = chunk_beg[c];
-    if constexpr (DMA)
-        gram_accumulate_dma(G, indices, values, beg, beg + chunk_len[c], other, EXPL,
-                            stage_all[wave] + GRAM_STAGE_WORDS, stage_all[wave]);
-    else
+    if constexpr (DMA) {
+        const int len = chunk_len[c];
+        if (LK_ALS_CHUNK256_FAST && len == 256)  // (wave-uniform) a full reference-order block
+            gram_accumulate_dma_256(G, indices, values, beg, other, EXPL,
+                                    stage_all[wave] + GRAM_STAGE_WORDS, stage_all[wave]);
+        else
+            gram_accumulate_dma(G, indices, values, beg, beg + len, other, EXPL,
+                                stage_all[wave] + GRAM_STAGE_WORDS, stage_all[wave]);
+    } else
         gram_accumulate<NT>(G, indices, values, beg, beg + chunk_len[c], other, ld, EXPL,
                             stage_all[wave]);
     slab_store<NT>(G, slabs + (size_t)c * slab_floats<NT>());
@@ -959,7 +1043,8 @@ __host__ __device__ constexpr int solve_lds_floats()
 // CTL: poll the task-control block (cancel) before the row and count it when done; a
 // template parameter so that the uncontrolled instantiation -- the training engine's -- is
 // instruction for instruction the tuned kernel
-// YREF: take the right-hand side from `y_ref` ([rows x KP], natural feature order; als_rhs.hip:
+// YREF: take the right-hand side from `y_ref` ([tasks x KP], indexed by the TASK t of this launch's
+// order, natural feature order; als_rhs.hip:
 // the reference's summation order) instead of the accumulated one; a template parameter so that
 // the default instantiation is instruction for instruction the tuned kernel
 template <int NT, bool IS64, bool EXPL, bool CTL, bool YREF = false>
@@ -1066,7 +1151,7 @@ __device__ __forceinline__ void als_solve_body(
         // primed (tt, sub) <-> feature sub * NT + tt; pad features carry y = 0 (their factor
         // columns are zero, so the reference-order sum over them is exactly 0 as well)
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) G.y[tt] = y_ref[(int64_t)row * KP + sub * NT + tt];
+        for (int tt = 0; tt < NT; ++tt) G.y[tt] = y_ref[(int64_t)t * KP + sub * NT + tt];
     }
 #if LK_ALS_PANEL
     const float old = my_valid ? xrow[my_f] : 0.f;
@@ -1537,6 +1622,12 @@ static bool als_fused_enabled()
     return e && e[0] == '1';
 }
 
+static bool reduce_on_side()
+{
+    const char *e = getenv("LK_ALS_REDUCE_SIDE");
+    return !(e && e[0] == '0');
+}
+
 template <int NT, bool IS64, bool EXPL = false>
 static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *indices,
                        const float *values, int64_t n_rows, int k, float *this_, int ld_this,
@@ -1567,12 +1658,18 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
     if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][0], st));
     // (CG hybrid: only the chunked rows, the first dense_limit tasks of the order)
     const int64_t n_solve = p->dense_limit >= 0 && p->dense_limit < n_rows ? p->dense_limit : n_rows;
+    // rows whose right-hand side comes from the reference-order chain (als_rhs.hip): the long
+    // rows (the first n_long tasks) of a hybrid plan, every row of a strict reference-order plan
+    float *yref = p->hybrid ? reinterpret_cast<float *>(ws + p->off_yref)
+                            : (p->ctl ? nullptr : p->d_yref);
+    const int64_t n_y = !yref ? 0 : (p->hybrid ? std::min<int64_t>(p->n_long, n_solve) : n_solve);
+    const int ref_chunk = (p->ref_order || p->hybrid) ? p->chunk : 0;
     // one launch for the chunks AND the rows that need none (als_fused_kernel): the plain exact
     // half-epoch only -- no task control, no reference order, not the CG hybrid's prefix
-    const bool fused = als_fused_enabled() && p->n_chunks > 0 && !p->ctl && !p->d_yref &&
-                       !p->ref_order && p->dense_limit < 0 && p->n_long < n_rows;
+    const bool fused = als_fused_enabled() && p->n_chunks > 0 && !p->ctl && !yref &&
+                       !ref_chunk && p->dense_limit < 0 && p->n_long < n_rows;
+    using IT = typename IndPtr<IS64>::type;
     if (fused) {
-        using IT = typename IndPtr<IS64>::type;
         const int64_t n_short = n_rows - p->n_long;  // tasks [n_long, n_rows) of the order
         const int64_t n_cb = (p->n_chunks + 3) / 4, n_sb = (n_short + 3) / 4;
         int64_t stride = (n_cb + n_sb) / n_cb;
@@ -1591,39 +1688,59 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
                                static_cast<const IT *>(indptr), indices, values, p->d_order,
                                p->n_long, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
                                slabs, row_delta, status, k, reg, TaskCtlDev{});
-    } else if (p->n_chunks > 0) {
-        hipLaunchKernelGGL((als_chunk_kernel<NT, EXPL>), dim3((unsigned)((p->n_chunks + 3) / 4)),
-                           dim3(256), 0, st, indices, values, p->d_chunk_beg, p->d_chunk_len,
-                           p->n_chunks, other, ld_other, slabs);
-        int rc = launch_slab_group_reduce(p, slabs, slab_floats<NT>(), st);
-        if (rc != LK_OK) return rc;
-    }
-    if (!fused && tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
-    if (!fused && n_solve > 0) {
-        using IT = typename IndPtr<IS64>::type;
-        if (p->d_yref && !p->ctl) {
-            // reference-order right-hand side (als_rhs.hip), then the solve that takes it
-            int rc = launch_rhs_reference(p, indptr, IS64 ? 1 : 0, indices, values, p->d_order,
-                                          n_solve, other, EXPL, st);
+    } else {
+        hipStream_t sr = st;
+        if (n_y > 0) {
+            // the chains run on the plan's second stream, beside the chunk kernel and the solve of
+            // the other rows; only the (small) solve launch of these rows waits for them
+            int rc = plan_fork_rhs(p, st, &sr);
             if (rc != LK_OK) return rc;
-            hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, false, true>),
-                               dim3((unsigned)((n_solve + 3) / 4)), dim3(256), 0, st,
-                               static_cast<const IT *>(indptr), indices, values, p->d_order,
-                               n_solve, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
-                               slabs, row_delta, status, k, reg, TaskCtlDev{}, p->d_yref,
-                               p->ref_order ? p->chunk : 0);
-        } else if (p->ctl)
-            hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, true>),
-                               dim3((unsigned)((n_solve + 3) / 4)), dim3(256), 0, st,
-                               static_cast<const IT *>(indptr), indices, values, p->d_order,
-                               n_solve, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
-                               slabs, row_delta, status, k, reg, p->ctl->dev());
-        else
-            hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, false>),
-                               dim3((unsigned)((n_solve + 3) / 4)), dim3(256), 0, st,
-                               static_cast<const IT *>(indptr), indices, values, p->d_order,
-                               n_solve, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
-                               slabs, row_delta, status, k, reg, TaskCtlDev{});
+            rc = launch_rhs_reference(p, indptr, IS64 ? 1 : 0, indices, values, p->d_order, n_y,
+                                      other, EXPL, yref, sr);
+            if (rc != LK_OK) return rc;
+        }
+        if (p->n_chunks > 0) {
+            hipLaunchKernelGGL((als_chunk_kernel<NT, EXPL>),
+                               dim3((unsigned)((p->n_chunks + 3) / 4)), dim3(256), 0, st, indices,
+                               values, p->d_chunk_beg, p->d_chunk_len, p->n_chunks, other,
+                               ld_other, slabs);
+            // the ordered slab sums of reference-order rows are pure HBM streaming (a quarter of
+            // the chunk phase with 256-entry chunks): on the second stream they run under the
+            // solve of the rows that need no slabs (LK_ALS_REDUCE_SIDE=0: launch stream)
+            hipStream_t sg = st;
+            if (n_y > 0 && sr != st && reduce_on_side()) {
+                int rc = plan_rhs_wait_main(p, st);
+                if (rc != LK_OK) return rc;
+                sg = sr;
+            }
+            int rc = launch_slab_group_reduce(p, slabs, slab_floats<NT>(), sg);
+            if (rc != LK_OK) return rc;
+        }
+        if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
+        const IT *ip = static_cast<const IT *>(indptr);
+#define LK_SOLVE_LAUNCH(CTLV, YREFV, T0, NTASKS, YPTR)                                            \
+    hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, CTLV, YREFV>),                            \
+                       dim3((unsigned)(((NTASKS) + 3) / 4)), dim3(256), 0, st, ip, indices,        \
+                       values, p->d_order + (T0), (NTASKS), p->d_row_slab, other, ld_other, this_, \
+                       ld_this, otor_p, slabs, row_delta, status, k, reg,                          \
+                       (CTLV) ? p->ctl->dev() : TaskCtlDev{}, (YPTR), ref_chunk)
+        // the rows that take their own right-hand side first (longest-first inside the launch) ...
+        if (n_solve > n_y) {
+            if (p->ctl)
+                LK_SOLVE_LAUNCH(true, false, n_y, n_solve - n_y, nullptr);
+            else
+                LK_SOLVE_LAUNCH(false, false, n_y, n_solve - n_y, nullptr);
+        }
+        // ... then the rows of the chains (hybrid plans: the long rows -- one slab + one solve each)
+        if (n_y > 0) {
+            int rc = plan_join_rhs(p, st);
+            if (rc != LK_OK) return rc;
+            if (p->ctl)
+                LK_SOLVE_LAUNCH(true, true, 0, n_y, yref);
+            else
+                LK_SOLVE_LAUNCH(false, true, 0, n_y, yref);
+        }
+#undef LK_SOLVE_LAUNCH
     }
     if (tm) {
         LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][2], st));
@@ -1706,14 +1823,23 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
 extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int indptr_is_64,
                                   int64_t n_rows, int32_t k, int32_t solver)
 {
-    return lk_als_plan_create_ex(out, h_indptr, indptr_is_64, n_rows, k, solver, 0);
+    // the default is the hybrid order (include/lkamd.h); LK_ALS_RHS_ORDER=accurate: the tuned
+    // kernels' own summation on every row (round 4's default)
+    const char *e = getenv("LK_ALS_RHS_ORDER");
+    const bool accurate = e && strcmp(e, "accurate") == 0;
+    return lk_als_plan_create_ex(out, h_indptr, indptr_is_64, n_rows, k, solver,
+                                 accurate ? 0 : LK_ALS_PLAN_HYBRID_ORDER);
 }
 
 extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, int indptr_is_64,
                                      int64_t n_rows, int32_t k, int32_t solver, int32_t flags)
 {
     LK_REQUIRE(out != nullptr && h_indptr != nullptr, "lk_als_plan_create: null pointer");
-    LK_REQUIRE((flags & ~LK_ALS_PLAN_REFERENCE_ORDER) == 0, "lk_als_plan_create_ex: unknown flags");
+    LK_REQUIRE((flags & ~(LK_ALS_PLAN_REFERENCE_ORDER | LK_ALS_PLAN_HYBRID_ORDER)) == 0,
+               "lk_als_plan_create_ex: unknown flags");
+    LK_REQUIRE((flags & (LK_ALS_PLAN_REFERENCE_ORDER | LK_ALS_PLAN_HYBRID_ORDER)) !=
+                   (LK_ALS_PLAN_REFERENCE_ORDER | LK_ALS_PLAN_HYBRID_ORDER),
+               "lk_als_plan_create_ex: reference order is either strict or hybrid");
     LK_REQUIRE(n_rows >= 0 && n_rows < (int64_t)INT32_MAX, "lk_als_plan_create: bad n_rows");
     int KP = lk_padded_dim(k);
     LK_REQUIRE(KP > 0, "lk_als_plan_create: unsupported embedding size k=%d (1..1024)", k);
@@ -1743,6 +1869,16 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
         p->ref_order = true;
         p->chunk = 256;     // matrixmultiply's KC (oracle/lk_oracle.c: LKO_SGEMM_KC)
         p->long_row = 256;  // every row the reference sums in more than one block
+    }
+    if ((flags & LK_ALS_PLAN_HYBRID_ORDER) && solver == LK_SOLVER_CHOLESKY && KP <= 256) {
+        // (the CG option and k > 256 have no slab path: the flag does not apply to them)
+        p->hybrid = true;
+        p->chunk = 256;
+        const char *e = getenv("LK_ALS_REF_LEN");
+        int rl = e ? atoi(e) : LK_ALS_LONG_ROW;
+        if (rl < 256) rl = 256;                          // (one block: nothing to reorder)
+        if (rl > LK_ALS_LONG_ROW) rl = LK_ALS_LONG_ROW;  // longer rows must be chunked anyway
+        p->long_row = rl;
     }
     // (k > 256: no chunk slabs -- als_big.hip spreads a long row over its Gram grid)
     const int64_t CHUNK = p->chunk, LONG_ROW = KP > 256 ? INT64_MAX : (int64_t)p->long_row;
@@ -1868,7 +2004,7 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
     for (int64_t r = 0; r < n_rows; ++r) {
         if (row_slab[(size_t)r] < 0) continue;
         const int64_t ns = (len(r) + CHUNK - 1) / CHUNK;
-        if (p->ref_order) {  // ONE group per row: head += every other slab, in chunk order
+        if (p->ref_order || p->hybrid) {  // ONE group per row: head += every other slab, in chunk order
             grp_head.push_back(row_slab[(size_t)r]);
             grp_cnt.push_back((int32_t)ns);
             continue;
@@ -1912,6 +2048,10 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
                                 : (size_t)(lk::als_tiles(p->NT) * 4 + p->NT) * 64;
         off += lk::align_up((size_t)std::max<int64_t>(p->n_chunks, 1) * slab_f * sizeof(float),
                             256);
+    }
+    if (p->hybrid) {  // y of the long rows in the reference's order, one row of KP floats per task
+        p->off_yref = off;
+        off += lk::align_up((size_t)std::max<int64_t>(p->n_long, 1) * KP * sizeof(float), 256);
     }
     if (KP > 64 && KP <= 256) {  // OtOr^-1 for the Woodbury rows (lk_als_plan_set_z_workspace)
         p->off_ginv = off;
@@ -1967,6 +2107,13 @@ extern "C" void lk_als_plan_destroy(lk_als_plan *p)
         (void)hipEventDestroy(p->ev_fork);
         (void)hipEventDestroy(p->ev_join);
     }
+    if (p->side_rhs) {
+        (void)hipStreamSynchronize(p->side_rhs);
+        (void)hipStreamDestroy(p->side_rhs);
+        (void)hipEventDestroy(p->ev_fork_rhs);
+        (void)hipEventDestroy(p->ev_join_rhs);
+        (void)hipEventDestroy(p->ev_mid_rhs);
+    }
     if (p->d_order) (void)hipFree(p->d_order);
     if (p->d_row_slab) (void)hipFree(p->d_row_slab);
     if (p->d_chunk_row) (void)hipFree(p->d_chunk_row);
@@ -1990,6 +2137,14 @@ extern "C" int lk_als_plan_set_ctl(lk_als_plan *p, lk_task_ctl *ctl)
 extern "C" int64_t lk_als_plan_short_rows(const lk_als_plan *p)
 {
     return p ? p->n_rows - p->t_short : 0;
+}
+
+extern "C" int64_t lk_als_plan_long_rows(const lk_als_plan *p) { return p ? p->n_long : 0; }
+
+extern "C" const float *lk_als_plan_yref(const lk_als_plan *p, const void *d_ws)
+{
+    if (!p || !d_ws || !p->hybrid) return nullptr;
+    return reinterpret_cast<const float *>(static_cast<const char *>(d_ws) + p->off_yref);
 }
 
 extern "C" int64_t lk_als_plan_woodbury_rows(const lk_als_plan *p)
@@ -2177,23 +2332,31 @@ struct DevBuf {
 };
 }  // namespace
 
-extern "C" int lk_als_implicit_half_epoch_host(const void *h_indptr, int indptr_is_64,
-                                               const int32_t *h_indices, const float *h_values,
-                                               int64_t n_rows, int64_t n_cols, int32_t k,
-                                               float *h_this, const float *h_other,
-                                               const float *h_otor, int32_t solver,
-                                               float *h_out_frob)
+extern "C" int lk_als_implicit_half_epoch_host_ctl(const void *h_indptr, int indptr_is_64,
+                                                   const int32_t *h_indices,
+                                                   const float *h_values, int64_t n_rows,
+                                                   int64_t n_cols, int32_t k, float *h_this,
+                                                   const float *h_other, const float *h_otor,
+                                                   int32_t solver, float *h_out_frob,
+                                                   lk_task_ctl *ctl)
 {
     LK_REQUIRE(h_indptr && h_this && h_otor && h_out_frob, "half_epoch_host: null pointer");
+    LK_REQUIRE(n_rows >= 0 && n_cols >= 0, "half_epoch_host: negative size");
     const int KP = lk_padded_dim(k);
     LK_REQUIRE(KP > 0, "half_epoch_host: unsupported k=%d", k);
+    const int64_t nnz = indptr_is_64 ? static_cast<const int64_t *>(h_indptr)[n_rows]
+                                     : static_cast<const int32_t *>(h_indptr)[n_rows];
+    LK_REQUIRE(nnz >= 0 && (nnz == 0 || (h_indices && h_values && h_other)),
+               "half_epoch_host: null pointer");
     lk_als_plan *plan = nullptr;
     int rc = lk_als_plan_create(&plan, h_indptr, indptr_is_64, n_rows, k, solver);
     if (rc != LK_OK) return rc;
-    const int64_t nnz = indptr_is_64 ? static_cast<const int64_t *>(h_indptr)[n_rows]
-                                     : static_cast<const int32_t *>(h_indptr)[n_rows];
+    if (ctl && (rc = lk_als_plan_set_ctl(plan, ctl)) != LK_OK) {
+        lk_als_plan_destroy(plan);
+        return rc;
+    }
     const size_t ipb = (size_t)(n_rows + 1) * (indptr_is_64 ? 8 : 4);
-    DevBuf ip, idx, val, th, thp, ot, otp, oo, ws, fr;
+    DevBuf ip, idx, val, th, thp, ot, otp, oo, ws, fr, zb;
     auto fail = [&](int c) {
         lk_als_plan_destroy(plan);
         return c;
@@ -2204,6 +2367,19 @@ extern "C" int lk_als_implicit_half_epoch_host(const void *h_indptr, int indptr_
         (rc = otp.alloc((size_t)n_cols * KP * 4)) || (rc = oo.alloc((size_t)k * k * 4)) ||
         (rc = ws.alloc(lk_als_plan_workspace_bytes(plan))) || (rc = fr.alloc(4)))
         return fail(rc);
+    // padded k = 128 / 256, no task control: the short rows take the Woodbury kernels when there
+    // are enough of them to pay for Z = other * OtOr^-1 (the rule of lkpy_amd/_device.py::ALSPlan:
+    // LK_ALS_WB_MIN_ROWS, default 4096) and no confidence value is negative (they take sqrt(v))
+    if (!ctl && KP > 64 && KP <= 256 && plan->solver == LK_SOLVER_CHOLESKY && n_cols > 0) {
+        const char *e = getenv("LK_ALS_WB_MIN_ROWS");
+        const int64_t wb_min = e ? atoll(e) : 4096;
+        bool neg = false;
+        for (int64_t i = 0; i < nnz && !neg; ++i) neg = h_values[i] < 0.f;
+        if (wb_min > 0 && lk_als_plan_woodbury_rows(plan) >= wb_min && !neg) {
+            if ((rc = zb.alloc((size_t)n_cols * KP * 4))) return fail(rc);
+            if ((rc = lk_als_plan_set_z_workspace(plan, static_cast<float *>(zb.p)))) return fail(rc);
+        }
+    }
 #define LK_H(expr)                                                              \
     do {                                                                        \
         hipError_t _e = (expr);                                                 \
@@ -2227,7 +2403,11 @@ extern "C" int lk_als_implicit_half_epoch_host(const void *h_indptr, int indptr_
                                     n_rows, n_cols, k, (float *)thp.p, KP, (const float *)otp.p,
                                     KP, (const float *)oo.p, k, ws.p, (float *)fr.p, nullptr);
     if (rc != LK_OK) return fail(rc);
-    if ((rc = lk_als_check_status(plan, ws.p, nullptr)) != LK_OK) return fail(rc);
+    // (LK_E_CANCELLED when the task-control block was cancelled: the rows solved so far are
+    // still copied back below -- `this` is updated in place row by row in the reference too)
+    const int rc_status = lk_als_check_status(plan, ws.p, nullptr);
+    if (rc_status != LK_OK && rc_status != LK_E_CANCELLED) return fail(rc_status);
+    // (a failed status leaves the message in lk_last_error: set_error below must not run)
     if ((rc = lk_unpad_rows((const float *)thp.p, n_rows, k, KP, (float *)th.p, k, nullptr)))
         return fail(rc);
     LK_H(hipDeviceSynchronize());
@@ -2235,5 +2415,17 @@ extern "C" int lk_als_implicit_half_epoch_host(const void *h_indptr, int indptr_
     LK_H(hipMemcpy(h_out_frob, fr.p, 4, hipMemcpyDeviceToHost));
 #undef LK_H
     lk_als_plan_destroy(plan);
-    return LK_OK;
+    return rc_status;
+}
+
+extern "C" int lk_als_implicit_half_epoch_host(const void *h_indptr, int indptr_is_64,
+                                               const int32_t *h_indices, const float *h_values,
+                                               int64_t n_rows, int64_t n_cols, int32_t k,
+                                               float *h_this, const float *h_other,
+                                               const float *h_otor, int32_t solver,
+                                               float *h_out_frob)
+{
+    return lk_als_implicit_half_epoch_host_ctl(h_indptr, indptr_is_64, h_indices, h_values, n_rows,
+                                               n_cols, k, h_this, h_other, h_otor, solver,
+                                               h_out_frob, nullptr);
 }

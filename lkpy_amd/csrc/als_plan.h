@@ -73,6 +73,16 @@ struct lk_als_plan {
     // chain from zero, the chunk slabs added ONE AFTER THE OTHER in chunk order (one slab group
     // per row), OtOr added last.  Such a plan needs the rhs workspace (d_yref) to run.
     bool ref_order = false;
+    // LK_ALS_PLAN_HYBRID_ORDER (the default of lk_als_plan_create): the same two sums in the
+    // reference's order, but ONLY for the rows longer than `long_row` entries (LK_ALS_REF_LEN,
+    // default 2048) -- exactly the rows that are pre-reduced in chunks anyway: 256-entry chunks, slabs
+    // added in chunk order, OtOr last, y from the sequential chain of als_rhs.hip (kept in the
+    // plan's own workspace, one row of KP floats per long row, indexed by TASK: the long rows are
+    // the first n_long tasks of the longest-first order).  Shorter rows keep the tuned kernels'
+    // own order, where the two arithmetics agree to ~1e-5.  Works with task control, row offsets,
+    // relabelled / sharded engines (the order of a row's entries is whatever the CSR holds).
+    bool hybrid = false;
+    size_t off_yref = 0;                 // hybrid: [n_long x KP] floats in the workspace
     int32_t chunk = LK_ALS_CHUNK;        // CSR entries per chunk of a long row
     int32_t long_row = LK_ALS_LONG_ROW;  // rows longer than this are chunked
     size_t off_ginv = 0, off_invws = 0;  // [KP x KP] float inverse, spd_inverse scratch
@@ -105,6 +115,11 @@ struct lk_als_plan {
     // Z GEMM on the launch stream (created on first use; LK_ALS_SIDE_STREAM=0: launch stream)
     mutable hipStream_t side = nullptr;
     mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // second side stream: the sequential right-hand-side chains of the long rows (als_rhs.hip)
+    // run there beside the chunk kernel and the solve of the short rows; only the small solve
+    // launch of the long rows waits for them (plan_fork_rhs / plan_join_rhs)
+    mutable hipStream_t side_rhs = nullptr;
+    mutable hipEvent_t ev_fork_rhs = nullptr, ev_join_rhs = nullptr, ev_mid_rhs = nullptr;
 };
 
 namespace lk {
@@ -151,11 +166,18 @@ int als_wb64_launch(const lk_als_plan *p, const void *indptr, int is64, const in
 size_t spd_inverse_workspace_bytes(int KP);
 int spd_inverse(const float *a, int lda, int k, int KP, float *out, int *flag, void *ws,
                 hipStream_t st);
-// y[row] in the reference's summation order for the rows order[0 .. n_tasks) (als_rhs.hip); a
-// no-op without a rhs workspace
+// y_out[t] = the right-hand side of row order[t] in the reference's summation order, for the
+// tasks t in [0, n_tasks) (als_rhs.hip); y_out is [n_tasks x KP], natural feature order
 int launch_rhs_reference(const lk_als_plan *p, const void *indptr, int is64,
                          const int32_t *indices, const float *values, const int32_t *order,
-                         int64_t n_tasks, const float *other, bool expl, hipStream_t st);
+                         int64_t n_tasks, const float *other, bool expl, float *y_out,
+                         hipStream_t st);
+// the plan's rhs side stream (created on first use), forked behind what `st` holds now
+// (LK_ALS_SIDE_STREAM=0: `st` itself); plan_join_rhs makes `st` wait for what it holds then
+int plan_fork_rhs(const lk_als_plan *p, hipStream_t st, hipStream_t *side);
+int plan_join_rhs(const lk_als_plan *p, hipStream_t st);
+// the rhs side stream waits for what `st` holds now (a second fork point inside the half-epoch)
+int plan_rhs_wait_main(const lk_als_plan *p, hipStream_t st);
 // slab[head] += slab[head + 1] + ... (chunk order) for every group of the plan (als_chol.hip)
 int launch_slab_group_reduce(const lk_als_plan *p, float *slabs, size_t slab_floats, hipStream_t st);
 // deterministic two-stage sum of the per-row squared deltas -> sqrt (als_chol.hip)

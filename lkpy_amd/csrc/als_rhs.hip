@@ -1,4 +1,4 @@
-// als_rhs.hip -- the right-hand side of the ALS row solve IN THE REFERENCE'S ORDER (optional).
+// als_rhs.hip -- the right-hand side of the ALS row solve IN THE REFERENCE'S ORDER.
 //
 // `train_row_solve` (src/accel/als/implicit.rs:116-117) forms  y = mt.dot(&vals)  with
 // vals = v + 1 and mt = o_picked.t(), a TRANSPOSED view: its rows (one per feature) have stride k,
@@ -7,22 +7,29 @@
 //
 //     y[f] = 0;  for j in row order:  y[f] = round(y[f] + round(M[j][f] * (v_j + 1)))
 //
-// (Rust never contracts a*b+c into an FMA.)  Over a row of 10^5 .. 10^6 entries of one sign that
-// single float32 chain stagnates: the busiest cfg5 item (1.54 M entries) lands 7e-2 from the
-// float64 sum, the busiest ML-25M item (81 491) 1.0e-4.  The solve kernels
-// sum y pairwise-ish (four entry slots per wave, chunk slabs, slab groups) and are 1e-5 from
-// float64 there -- closer to the truth, but not what the reference computes.
+// (Rust never contracts a*b+c into an FMA.)  Over a row of 10^4 .. 10^6 entries of one sign that
+// single float32 chain drifts SYSTEMATICALLY: the busiest cfg5 item (1.54 M entries) lands 7e-2
+// from the float64 sum, the busiest ML-25M item (81 491) 1.0e-4.  The
+// solve kernels' own sums (four entry slots per wave, chunk slabs, slab groups) stay 1e-5 from
+// float64 there -- closer to the truth, but not what the reference computes, and the north star
+// asks for the reference's factors within 1e-4.
 //
-// With a rhs workspace attached to the plan (`lk_als_plan_set_rhs_workspace`; Python:
-// LK_ALS_RHS_ORDER=reference) every half-epoch first runs THIS kernel -- lane = feature, the row's
-// entries strictly in order, product and sum rounded separately -- and the solve kernels take
-// their right-hand side from it instead of from their own accumulation.  The normal matrix and
-// the factorisation are unchanged.  It reproduces the reference's y bit for bit (same order,
-// same roundings: explicit.rs:110 is the same call with vals = the ratings), so the rows where
-// the default mode is ">1e-4 from the oracle because the ORACLE drifts" come out within 1e-4 of
-// it (tests/test_gpu_als_rhs_order.py).  A diagnostic / strict-reproduction mode: one lane chain
-// per feature is latency bound (the 1.54 M-entry row alone takes ~50 ms).  Rows that go through
-// the Woodbury kernels (<= 64 entries at padded k > 64) never form y and are not affected.
+// This file evaluates that chain for the rows a plan names -- the rows longer than LK_ALS_REF_LEN
+// entries of every default ("hybrid") plan, every dense row of a strict reference-order plan
+// (als_plan.h) -- bit for bit (same order, same roundings; explicit.rs:110 is the same call with
+// vals = the ratings), and the solve kernels take their right-hand side from it.
+//
+// Round 5: the chain is no longer latency bound.  A chain is 4 cycles per entry at best (one
+// dependent v_add per entry); round 4's kernel (lane = feature, 16 gathers in flight) ran at the
+// gather latency, ~75 cycles per entry: 50 ms for the 1.54 M-entry row.  Now one workgroup serves
+// (row, 64-feature slice): wave 0 only ADDS -- it reads the products four entries at a time
+// (`ds_read_b128`: the stage buffer is feature-major) and runs the chain, 5 instructions per 4
+// entries; waves 1..3 are producers: they gather the factor rows RC_D stages ahead into
+// registers (coalesced 64-byte quads), multiply by (v + 1) -- the product is rounded exactly as
+// in the reference, it just happens on another wave -- and write them transposed into the other
+// half of a double buffer.  One barrier per stage of RC_E entries, no `s_waitcnt vmcnt(0)`
+// anywhere in the loop (the barrier is an `s_barrier` preceded by `lgkmcnt(0)` only: hipcc's
+// __syncthreads would drain the gather ring).
 #include "als_plan.h"
 #include "common.h"
 
@@ -30,64 +37,225 @@
 
 namespace lk {
 
-constexpr int RHS_BATCH = 16;  // gathered values in flight per lane
+#ifndef LK_RHS_NP
+#define LK_RHS_NP 3  // producer waves per workgroup (3: four waves, one per SIMD)
+#endif
+#ifndef LK_RHS_D
+#define LK_RHS_D 3  // (4: hipcc 7.2 runs out of registers and parks the ring in AGPRs -- waits of 0)
+#endif
+constexpr int RC_NP = LK_RHS_NP;
+constexpr int RC_E = RC_NP * 32;  // entries per stage: two 16-entry groups per producer wave
+                                  // (a multiple of 32: the swizzle below)
+constexpr int RC_D = LK_RHS_D;    // stages of gathered rows in flight per producer wave (registers)
+constexpr int RC_F = 64;  // features per workgroup (one chain wave)
 
-// One workgroup of max(KP, 64) threads per task: thread f owns feature f of row order[t].
-template <bool IS64>
-__global__ void als_rhs_reference_kernel(const typename IndPtr<IS64>::type *__restrict__ indptr,
-                                         const int32_t *__restrict__ indices,
-                                         const float *__restrict__ values,
-                                         const int32_t *__restrict__ order, int64_t n_tasks,
-                                         const float *__restrict__ other, int KP, int expl,
-                                         float *__restrict__ y_out)
+// stage buffer: product of (feature f, entry e) at word  f * RC_E + (e ^ ((f & 7) << 2)):
+// a chain lane's ds_read_b128 of entries 4g .. 4g + 3 hits bank quad (g ^ f) & 7 -- eight
+// consecutive lanes, eight quads, conflict free; the producers' transposed ds_write_b32 are
+// 2-way conflicted (they have the slack)
+__device__ __forceinline__ int rc_word(int f, int e) { return f * RC_E + (e ^ ((f & 7) << 2)); }
+
+__device__ __forceinline__ void rc_barrier()
 {
-    const int64_t t = blockIdx.x;
-    if (t >= n_tasks) return;
-    const int row = order ? order[t] : (int)t;
-    const int f = threadIdx.x;
-    const int64_t beg = indptr[row], end = indptr[row + 1];
-    const bool act = f < KP;
-    const float *col = other + (act ? f : 0);
-    float y = 0.f;
-    for (int64_t b = beg; b < end; b += RHS_BATCH) {
-        const int nb = (end - b) < RHS_BATCH ? (int)(end - b) : RHS_BATCH;
-        float q[RHS_BATCH], v1[RHS_BATCH];
-        // every load unconditional (entries past the end re-read the last one and are not summed)
-#pragma unroll
-        for (int j = 0; j < RHS_BATCH; ++j) {
-            const int64_t e = j < nb ? b + j : end - 1;
-            const int c = indices[e];  // wave-uniform: scalar loads
-            const float v = values[e];
-            q[j] = col[(int64_t)c * KP];
-            v1[j] = expl ? v : v + 1.0f;  // `vals += 1.0` (implicit.rs:116), rounded to f32
-        }
-#pragma unroll
-        for (int j = 0; j < RHS_BATCH; ++j) {
-            if (j < nb) {
-                float prod = q[j] * v1[j];
-                asm volatile("" : "+v"(prod));  // keep hipcc from fusing the pair into v_fmac
-                y = y + prod;
-            }
-        }
-    }
-    if (act) y_out[(int64_t)row * KP + f] = y;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// rows order[0 .. n_tasks) of the plan (order == nullptr: rows 0 .. n_tasks)
+template <bool IS64>
+__global__ __launch_bounds__((RC_NP + 1) * 64) void als_rhs_chain_kernel(
+    const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_tasks,
+    const float *__restrict__ other, int KP, int n_slices, int expl, float *__restrict__ y_out)
+{
+    __shared__ __attribute__((aligned(16))) float buf[2][RC_F * RC_E];
+    const int64_t t = blockIdx.x / (unsigned)n_slices;
+    const int sl = (int)(blockIdx.x - t * n_slices);
+    if (t >= n_tasks) return;
+    const int row = order ? order[t] : (int)t;
+    const int64_t beg = indptr[row], end = indptr[row + 1];
+    const int64_t n = end - beg;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int fw = KP < RC_F ? KP : RC_F;  // features of this slice
+    const int fbase = sl * RC_F;
+    if (n <= 0) {  // (the solve kernels never read it: implicit.rs:98-101)
+        if (wave == 0 && lane < fw) y_out[t * KP + fbase + lane] = 0.f;
+        return;
+    }
+    // stages, rounded up to whole rounds of RC_D: the loops below have ONE shape (no remainder
+    // path whose loads hipcc could sink or whose waits it would have to guess); the padding
+    // stages hold +0.0 products, and y + 0.0 = y exactly
+    const int nst = (int)((n + RC_E - 1) / RC_E + RC_D - 1) / RC_D * RC_D;
+
+    if (wave == 0) {
+        // ---- the chain: lane = feature ------------------------------------------------------
+        __builtin_amdgcn_s_setprio(3);
+        float y = 0.f;
+        const int sw = (lane & 7) << 2;
+        const float *mine = &buf[0][0] + lane * RC_E;
+        auto consume = [&](int b) {
+            const float *src = mine + b * (RC_F * RC_E);
+#pragma unroll
+            for (int g0 = 0; g0 < RC_E / 4; g0 += 8) {
+                f32x4 r[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    r[g] = *reinterpret_cast<const f32x4 *>(src + ((((g0 + g) << 2) ^ sw)));
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    y = y + r[g].x;
+                    y = y + r[g].y;
+                    y = y + r[g].z;
+                    y = y + r[g].w;
+                }
+            }
+        };
+        for (int s = 0; s < nst; ++s) {
+            if (s > 0) consume((s - 1) & 1);
+            rc_barrier();
+        }
+        consume((nst - 1) & 1);
+        if (lane < fw) y_out[t * KP + fbase + lane] = y;
+        return;
+    }
+
+    // ---- producers: wave pw takes the entry groups 2 pw, 2 pw + 1 (16 entries each) of every
+    // stage; lane -> entry (lane >> 2) of the group, float4 column jg * 4 + (lane & 3)
+    const int pw = wave - 1;
+    const int el0 = (2 * pw) * 16 + (lane >> 2), el1 = el0 + 16;
+    int foff[4];
+    bool jv[4];
+#pragma unroll
+    for (int jg = 0; jg < 4; ++jg) {
+        const int f0 = (jg * 4 + (lane & 3)) * 4;
+        jv[jg] = f0 < fw;
+        foff[jg] = fbase + (jv[jg] ? f0 : 0);
+    }
+    const int32_t *ci = indices + beg;
+    const float *cv = values + beg;
+    const int64_t last = n - 1;
+
+    f32x4 q[RC_D][2][4];
+    float v[RC_D][2];
+    int c[RC_D][2];
+    auto load_idx = [&](int d, int s) {
+        const int64_t e0 = (int64_t)s * RC_E + el0, e1 = (int64_t)s * RC_E + el1;
+        c[d][0] = ci[e0 < last ? e0 : last];
+        c[d][1] = ci[e1 < last ? e1 : last];
+    };
+    auto issue = [&](int d, int s) {
+        const int64_t e0 = (int64_t)s * RC_E + el0, e1 = (int64_t)s * RC_E + el1;
+        v[d][0] = cv[e0 < last ? e0 : last];
+        v[d][1] = cv[e1 < last ? e1 : last];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float *r = other + (int64_t)c[d][h] * KP;
+#pragma unroll
+            for (int jg = 0; jg < 4; ++jg) q[d][h][jg] = *reinterpret_cast<const f32x4 *>(r + foff[jg]);
+        }
+    };
+    auto write_out = [&](int d, int s) {
+        float *dst = &buf[s & 1][0];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int el = h ? el1 : el0;
+            const bool live = (int64_t)s * RC_E + el < n;
+            // `vals += 1.0` (implicit.rs:116) rounded to f32; explicit.rs:110: the ratings
+            const float v1 = expl ? v[d][h] : v[d][h] + 1.0f;
+#pragma unroll
+            for (int jg = 0; jg < 4; ++jg) {
+                const int f0 = (jg * 4 + (lane & 3)) * 4;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    float prod = q[d][h][jg][cc] * v1;  // rounded product (never an FMA)
+                    // entries past the end add +0.0: y + 0 = y exactly
+                    dst[rc_word(f0 + cc, el)] = live ? prod : 0.f;
+                }
+            }
+        }
+    };
+    // The loop below must look the same to hipcc's s_waitcnt pass from both of its entries: the
+    // prologue issues its loads in the order a loop step does (the empty asm statements keep the
+    // scheduler from regrouping them) and every step is unconditional -- a stage's loads are then
+    // waited for with `vmcnt(loads of the RC_D - 1 younger stages)`, never 0.
+#pragma unroll
+    for (int d = 0; d < RC_D; ++d) load_idx(d, d);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int d = 0; d < RC_D; ++d) {
+        issue(d, d);
+        load_idx(d, d + RC_D);
+        asm volatile("" ::: "memory");
+    }
+    int s0 = 0;
+    do {
+#pragma unroll
+        for (int d = 0; d < RC_D; ++d) {
+            const int s = s0 + d;
+            write_out(d, s);     // (stages past the row's end: zeros)
+            issue(d, s + RC_D);  // (clamped to the row's last entry past the end)
+            load_idx(d, s + 2 * RC_D);
+            rc_barrier();
+        }
+        s0 += RC_D;
+    } while (s0 < nst);
+}
+
+static bool rhs_side_enabled()
+{
+    const char *e = getenv("LK_ALS_SIDE_STREAM");
+    return !(e && e[0] == '0');
+}
+
+int plan_fork_rhs(const lk_als_plan *p, hipStream_t st, hipStream_t *side)
+{
+    *side = st;
+    if (!rhs_side_enabled()) return LK_OK;
+    if (!p->side_rhs) {
+        LK_HIP_CHECK(hipStreamCreateWithFlags(&p->side_rhs, hipStreamNonBlocking));
+        LK_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fork_rhs, hipEventDisableTiming));
+        LK_HIP_CHECK(hipEventCreateWithFlags(&p->ev_join_rhs, hipEventDisableTiming));
+        LK_HIP_CHECK(hipEventCreateWithFlags(&p->ev_mid_rhs, hipEventDisableTiming));
+    }
+    LK_HIP_CHECK(hipEventRecord(p->ev_fork_rhs, st));
+    LK_HIP_CHECK(hipStreamWaitEvent(p->side_rhs, p->ev_fork_rhs, 0));
+    *side = p->side_rhs;
+    return LK_OK;
+}
+
+int plan_rhs_wait_main(const lk_als_plan *p, hipStream_t st)
+{
+    if (!rhs_side_enabled() || !p->side_rhs) return LK_OK;
+    LK_HIP_CHECK(hipEventRecord(p->ev_mid_rhs, st));
+    LK_HIP_CHECK(hipStreamWaitEvent(p->side_rhs, p->ev_mid_rhs, 0));
+    return LK_OK;
+}
+
+int plan_join_rhs(const lk_als_plan *p, hipStream_t st)
+{
+    if (!rhs_side_enabled() || !p->side_rhs) return LK_OK;
+    LK_HIP_CHECK(hipEventRecord(p->ev_join_rhs, p->side_rhs));
+    LK_HIP_CHECK(hipStreamWaitEvent(st, p->ev_join_rhs, 0));
+    return LK_OK;
+}
+
+// tasks [0, n_tasks) of `order` (order == nullptr: rows 0 .. n_tasks); y_out[t] <- row order[t]
 int launch_rhs_reference(const lk_als_plan *p, const void *indptr, int is64,
                          const int32_t *indices, const float *values, const int32_t *order,
-                         int64_t n_tasks, const float *other, bool expl, hipStream_t st)
+                         int64_t n_tasks, const float *other, bool expl, float *y_out,
+                         hipStream_t st)
 {
-    if (!p->d_yref || n_tasks <= 0) return LK_OK;
-    const dim3 grid((unsigned)n_tasks), block((unsigned)(p->KP < 64 ? 64 : p->KP));
+    if (!y_out || n_tasks <= 0) return LK_OK;
+    const int n_slices = (p->KP + RC_F - 1) / RC_F;
+    LK_REQUIRE(n_tasks * n_slices < (int64_t)INT32_MAX, "rhs chain: grid too large");
+    const dim3 grid((unsigned)(n_tasks * n_slices)), block((RC_NP + 1) * 64);
     if (is64)
-        hipLaunchKernelGGL(als_rhs_reference_kernel<true>, grid, block, 0, st,
+        hipLaunchKernelGGL(als_rhs_chain_kernel<true>, grid, block, 0, st,
                            static_cast<const int64_t *>(indptr), indices, values, order, n_tasks,
-                           other, p->KP, expl ? 1 : 0, p->d_yref);
+                           other, p->KP, n_slices, expl ? 1 : 0, y_out);
     else
-        hipLaunchKernelGGL(als_rhs_reference_kernel<false>, grid, block, 0, st,
+        hipLaunchKernelGGL(als_rhs_chain_kernel<false>, grid, block, 0, st,
                            static_cast<const int32_t *>(indptr), indices, values, order, n_tasks,
-                           other, p->KP, expl ? 1 : 0, p->d_yref);
+                           other, p->KP, n_slices, expl ? 1 : 0, y_out);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }

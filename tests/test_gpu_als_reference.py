@@ -118,9 +118,16 @@ def test_ml_small_half_epochs_against_reference(gpu, oracle, half):
     # (the CPU oracle meets this with the constant 4; cond is a lower-bound estimate and the
     # a-priori constant of a float32 Cholesky solve is O(k): 16 for the GPU's different order)
     assert (e <= 16.0 * cu + 2.0e-6).all(), float((e / np.maximum(cu, 1e-30)).max())
-    assert (e[cu < 1e-5] <= 1e-4).all()
+    # the raw north-star tolerance wherever it is decidable between two float32 solves of the same
+    # system (cond u < 2.5e-5: VERDICT r4 item 3); the other rows are counted, not hidden
+    decid = (cu < 2.5e-5) & (den > 0)
+    assert (e[decid] <= 1e-4).all(), float(e[decid].max())
+    rest = (~decid) & (den > 0)
     print(f"{half}: GPU vs reference rel {_rel(got, want):.2e}; max err/(cond u) "
-          f"{float((e[cond > 0] / cu[cond > 0]).max()):.2f}")
+          f"{float((e[cond > 0] / cu[cond > 0]).max()):.2f}; rows with cond u < 2.5e-5: "
+          f"{int(decid.sum())}, all within 1e-4 (max {float(e[decid].max()) if decid.any() else 0:.1e}); "
+          f"other rows {int(rest.sum())}, of those over 1e-4: {int((e[rest] > 1e-4).sum())} "
+          f"(max {float(e[rest].max()) if rest.any() else 0:.1e})")
 
 
 @pytest.mark.parametrize("kind", ["centered", "skewed"])

@@ -97,7 +97,7 @@ def test_reference_order_reproduces_the_long_row(gpu, oracle, k):
         plan.check_status()
         return D.to_host_unpadded(d_this, k)
 
-    plan = D.ALSPlan(csr, k, _native.SOLVER_CHOLESKY, reference_order=False)
+    plan = D.ALSPlan(csr, k, _native.SOLVER_CHOLESKY, reference_order="accurate")
     got_acc = run(plan)
     plan.set_rhs_order("reference")
     got_rhs = run(plan)
@@ -109,23 +109,47 @@ def test_reference_order_reproduces_the_long_row(gpu, oracle, k):
     got_ref = run(full)
     with pytest.raises(ValueError):
         full.set_rhs_order("accurate")
+    # the DEFAULT plan (round 5): hybrid order -- the rows of more than 2048 entries in the
+    # reference's order, y in the plan's own workspace
+    hyb = D.ALSPlan(csr, k, _native.SOLVER_CHOLESKY)
+    assert hyb.order_mode == "auto" and hyb._yref is None
+    got_hyb = run(hyb)
+    with pytest.raises(ValueError):
+        hyb.set_rhs_order("reference")
 
     lens = np.diff(mat.indptr)
     # (48 rows: far below LK_ALS_WB_MIN_ROWS, so the dense kernels solve every row at every k)
     dense_min = 0
     rows = np.flatnonzero(lens > dense_min)
+    # the chains' buffers are indexed by TASK: the rows by descending length, ties in row order
+    order = np.argsort(-lens, kind="stable")
+    task_of = np.empty_like(order)
+    task_of[order] = np.arange(len(order))
+    n_long = int((lens > 2048).sum())
+    assert hyb.long_rows() == n_long == 5
+    y_hyb = D.to_host_unpadded(hyb.yref_tasks(), k)
+    assert y_hyb.shape[0] == n_long
+    y_full = D.to_host_unpadded(full._yref, k)
     # (1) y: bit for bit the reference's chain, on the long, a chunked and a plain row
     for r in (0, 2, 4, 7):
         s, e = mat.indptr[r], mat.indptr[r + 1]
         if lens[r] > dense_min:
             yc = _chain_y(other[mat.indices[s:e]], mat.data[s:e] + np.float32(1.0))
-            assert np.array_equal(y_dev[r].view(np.uint32), yc.view(np.uint32)), r
-            assert np.array_equal(D.to_host_unpadded(full._yref, k)[r].view(np.uint32),
-                                  yc.view(np.uint32)), r
+            t = task_of[r]
+            assert np.array_equal(y_dev[t].view(np.uint32), yc.view(np.uint32)), r
+            assert np.array_equal(y_full[t].view(np.uint32), yc.view(np.uint32)), r
+            if lens[r] > 2048:
+                assert np.array_equal(y_hyb[t].view(np.uint32), yc.view(np.uint32)), r
     w64 = want.astype(np.float64)
     e_acc = np.array([_row_rel(got_acc[r], w64[r]) for r in rows])
     e_rhs = np.array([_row_rel(got_rhs[r], w64[r]) for r in rows])
     e_ref = np.array([_row_rel(got_ref[r], w64[r]) for r in rows])
+    e_hyb = np.array([_row_rel(got_hyb[r], w64[r]) for r in rows])
+    # the hybrid plan: its long rows are the strict plan's, bit for bit (same chunks, same chains);
+    # every row within the raw 1e-4 of the oracle
+    long_rows = np.flatnonzero(lens > 2048)
+    assert np.array_equal(got_hyb[long_rows].view(np.uint32), got_ref[long_rows].view(np.uint32))
+    assert e_hyb.max() < RTOL, (k, e_hyb.max())
     o_f64, a_f64 = _row_rel(want[0], exact[0]), _row_rel(got_acc[0], exact[0])
     print(f"\nk={k}, {long_len}-entry row (cond {cond[0]:.0f}): oracle vs f64 {o_f64:.2e}, GPU "
           f"default vs f64 {a_f64:.2e}; vs the ORACLE: default {e_acc[0]:.2e}, rhs in reference "
@@ -139,6 +163,7 @@ def test_reference_order_reproduces_the_long_row(gpu, oracle, k):
     assert e_rhs[0] < e_acc[0]
     # (4) the empty row stays zero in every mode
     assert not got_ref[6].any() and not got_rhs[6].any() and not got_acc[6].any()
+    assert not got_hyb[6].any()
 
 
 def test_reference_order_explicit_model(gpu, oracle):
@@ -156,19 +181,22 @@ def test_reference_order_explicit_model(gpu, oracle):
     oracle.als_explicit_half_epoch(mat, want, other, 0.05)
     csr = D.DeviceCSR.from_arrays(mat.indptr.astype(np.int32), mat.indices, mat.data, mat.shape,
                                   gpu)
-    plan = D.ALSPlan(csr, k, _native.SOLVER_CHOLESKY)
-    plan.set_rhs_order("reference")
-    d_this = D.to_device_padded(this, gpu)
-    plan.half_epoch_explicit(d_this, D.to_device_padded(other, gpu), 0.05)
-    plan.check_status()
-    got = D.to_host_unpadded(d_this, k)
-    y_dev = D.to_host_unpadded(plan._yref, k)
     s, e = mat.indptr[0], mat.indptr[1]
-    assert np.array_equal(y_dev[0].view(np.uint32),
-                          _chain_y(other[mat.indices[s:e]], mat.data[s:e]).view(np.uint32))
+    yc = _chain_y(other[mat.indices[s:e]], mat.data[s:e])
     nz = np.diff(mat.indptr) > 0
-    err = np.linalg.norm(got[nz] - want[nz], axis=1) / np.linalg.norm(want[nz], axis=1)
-    assert err.max() < RTOL, err.max()
+    for mode in ("accurate", "auto"):
+        plan = D.ALSPlan(csr, k, _native.SOLVER_CHOLESKY, reference_order=mode)
+        if mode == "accurate":
+            plan.set_rhs_order("reference")
+        d_this = D.to_device_padded(this, gpu)
+        plan.half_epoch_explicit(d_this, D.to_device_padded(other, gpu), 0.05)
+        plan.check_status()
+        got = D.to_host_unpadded(d_this, k)
+        # (row 0 is the longest: task 0 of either buffer)
+        y_dev = D.to_host_unpadded(plan._yref if mode == "accurate" else plan.yref_tasks(), k)
+        assert np.array_equal(y_dev[0].view(np.uint32), yc.view(np.uint32)), mode
+        err = np.linalg.norm(got[nz] - want[nz], axis=1) / np.linalg.norm(want[nz], axis=1)
+        assert err.max() < RTOL, (mode, err.max())
 
 
 def test_reference_order_through_training_options(gpu, oracle):
@@ -196,6 +224,7 @@ def test_reference_order_through_training_options(gpu, oracle):
     # one epoch from the same draws: the two modes agree to rounding on this small problem
     sc2 = ImplicitMFScorer(embedding_size=16, epochs=2)
     tr2 = sc2.create_trainer(ds, TrainingOptions(rng=1))
+    assert tr2.engine.u_plan.order_mode == "auto"  # the default: hybrid order
     assert not tr2.engine.u_plan.reference_order and tr2.engine.u_plan._yref is None
     tr2.train_epoch()
     tr2.finalize()
