@@ -670,6 +670,10 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    try:
+        coll = collective_times(eng, min(steps, 3), dev, world)
+    except Exception as exc:  # noqa: BLE001
+        coll = {"error": f"{type(exc).__name__}: {exc}"}
     # kernel times: one more epoch with HIP events on the launch stream
     eng.u_plan.enable_timing(True)
     eng.i_plan.enable_timing(True)
@@ -746,6 +750,13 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
         # HBM bytes per epoch over ALL kernels of the epoch, from the committed PMC summary
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic_per_epoch(
             "r*_cfg5_counters.csv", "als_blk_solve_kernel16")
+    if coll:
+        out["collectives"] = coll
+    if world == 1:
+        out["summation_order"] = summation_order_info(
+            eng, lambda mode: ImplicitALSEngine(csr, k, reg, reg, None, None,
+                                                HipBackend(k, dev, _native.SOLVER_AUTO, mode)),
+            steps, elapsed / steps * 1e3, dev)
 
     def leg(name, fn):
         try:
@@ -812,8 +823,18 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
 
         n_u = max(256, eng.u_plan.csr.shape[0] // 400)
         n_i = max(256, eng.i_plan.csr.shape[0] // 400)
-        half("user", eng.u_plan, eng.P, eng.u_lo, eng.u_hi, eng.Q, reg, n_u)
-        half("item", eng.i_plan, eng.Q, eng.i_lo, eng.i_hi, eng.P, reg, n_i, must=(0,))
+        # EVERY row of more than 4096 entries is checked (the rows where the
+        # reference's float32 sums drift: ~2 600 items at full scale, 60 % of the entries), not
+        # just the busiest one; plus the seeded 0.25 % sample of the others
+        def long_rows(plan):
+            hp = plan.csr.h_indptr.astype(np.int64)
+            return np.flatnonzero(np.diff(hp) > 4096)
+
+        lu, li = long_rows(eng.u_plan), long_rows(eng.i_plan)
+        half("user", eng.u_plan, eng.P, eng.u_lo, eng.u_hi, eng.Q, reg, n_u, must=lu)
+        half("item", eng.i_plan, eng.Q, eng.i_lo, eng.i_hi, eng.P, reg, n_i, must=li)
+        res["user"]["rows_over_4096_entries_checked"] = int(len(lu))
+        res["item"]["rows_over_4096_entries_checked"] = int(len(li))
         # keep the engine consistent for the legs that follow (the scorer's Q^T Q)
         eng._qtq = eng.backend.gramian(eng.Q, reg)
         est = cpu_s * (reference_half_flops(ulen, k) + reference_half_flops(ilen, k)) \
@@ -825,8 +846,9 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
             "host_cpus": os.cpu_count()}
         reco = [o["exceptions_in_reference_order"] for o in res.values()
                 if "exceptions_in_reference_order" in o]
-        return {"what": "user AND item half-epoch, GPU vs oracle from identical inputs, sampled "
-                "rows (the item sample always contains the busiest item)",
+        return {"what": "user AND item half-epoch, GPU vs oracle from identical inputs: EVERY row of "
+                "more than 4096 entries + a seeded 0.25 % sample of the others",
+                "rows_over_4096_entries_checked": int(len(lu) + len(li)),
                 "rows_checked": res["user"]["rows"] + res["item"]["rows"],
                 "rows_over_1e-4": res["user"]["rows_over_1e-4"] + res["item"]["rows_over_1e-4"],
                 "row_rel_max": max(res["user"]["row_rel_max"], res["item"]["row_rel_max"]),
@@ -904,6 +926,73 @@ def main_cfg5(args):
         dist.destroy_process_group()
 
 
+def summation_order_info(eng, make_engine, steps, ms_default, dev):
+    """
+    VERDICT r4 item 1: the epoch time of the new DEFAULT summation order (hybrid: rows of more than
+    LK_ALS_REF_LEN entries in the reference's own order) beside round 4's default
+    (``LK_ALS_RHS_ORDER=accurate``) on the same inputs.  ``make_engine(mode)`` builds an engine of
+    the same problem in that mode; it is timed over ``steps`` epochs after 2 warm-up epochs.
+    """
+    import torch
+
+    info = {
+        "default": getattr(eng.u_plan, "order_mode", None),
+        "rows_in_reference_order": {"user": int(eng.u_plan.long_rows()),
+                                    "item": int(eng.i_plan.long_rows())},
+        "ref_len": int(os.environ.get("LK_ALS_REF_LEN", "2048")),
+        "ms_per_step": round(ms_default, 4),
+    }
+    try:
+        e2 = make_engine("accurate")
+        for _ in range(2):
+            e2.train_epoch()
+        e2.check()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e2.train_epoch()
+        torch.cuda.synchronize(dev)
+        info["ms_per_step_accurate_order"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+        info["cost_of_reference_order"] = round(ms_default / info["ms_per_step_accurate_order"], 4)
+        del e2
+        torch.cuda.empty_cache()
+    except Exception as exc:  # noqa: BLE001 -- reported in place
+        info["error"] = f"{type(exc).__name__}: {exc}"
+    return info
+
+
+def collective_times(eng, steps, dev, world):
+    """
+    world > 1: ``steps`` more epochs with the engine's collectives bracketed by events
+    (``TorchComm.enable_timing``): milliseconds per epoch a rank's stream spent in (or waiting
+    for) each kind of collective, for EVERY rank -- gathered to rank 0.  Not part of the timed
+    region; the numbers to hold against DESIGN.md section 6's predicted table.
+    """
+    import torch
+    import torch.distributed as dist
+
+    comm = getattr(eng, "comm", None)
+    if world <= 1 or comm is None or not hasattr(comm, "enable_timing"):
+        return None
+    comm.enable_timing(True)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.train_epoch()
+    torch.cuda.synchronize(dev)
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    mine = {k_: round(v / steps, 4) for k_, v in comm.timing_ms().items()}
+    mine["epoch_ms_with_events"] = round(wall, 4)
+    comm.enable_timing(False)
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    return {"per_rank_ms_per_epoch": allr,
+            "note": "stream time inside blocking collectives / exposed wait of the asynchronous "
+                    "row gathers, per epoch, rank by rank (events on the launch stream; a "
+                    "separate pass after the timed region)"}
+
+
 def als_timed(ui, P0, Q0, k, reg, steps, warmup, dev, world, scale):
     """
     Set up the engine (one upload, relabel + transpose in HBM), run ``warmup`` untimed and
@@ -944,6 +1033,10 @@ def als_timed(ui, P0, Q0, k, reg, steps, warmup, dev, world, scale):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    try:
+        eng.collectives = collective_times(eng, min(steps, 10), dev, world)
+    except Exception as exc:  # noqa: BLE001 -- reported in place, never costs the headline
+        eng.collectives = {"error": f"{type(exc).__name__}: {exc}"}
 
     # ---- roofline of the dominant kernel (local shard of this rank): a SEPARATE pass of the
     # same epochs with HIP events around the kernels on the launch stream ----
@@ -1021,6 +1114,11 @@ def als_timed(ui, P0, Q0, k, reg, steps, warmup, dev, world, scale):
         if roof["traffic"] is None and fused:  # (captures made before the fused launch)
             roof["traffic"], roof["traffic_source"] = pmc_traffic(
                 "r*_als_*_counters.csv", "als_solve_kernel")
+    if world == 1:
+        eng.summation_order = summation_order_info(
+            eng, lambda mode: ImplicitALSEngine(ui, k, reg, reg, P0, Q0,
+                                                HipBackend(k, dev, _native.SOLVER_AUTO, mode)),
+            min(steps, 20), elapsed / steps * 1e3, dev)
     return eng, backend, elapsed, roof, setup_seconds, (float(du.item()), float(di.item()))
 
 
@@ -1053,7 +1151,8 @@ def _als_par(par):
     if not isinstance(par, dict):
         return None
     d = _pick(par, "ok", "rows_checked", "rows_over_1e-4", "row_rel_max", "accounted",
-              "ok_in_reference_order", "exceptions_reproduced_in_reference_order", "error")
+              "rows_over_4096_entries_checked", "ok_in_reference_order",
+              "exceptions_reproduced_in_reference_order", "error")
     if par.get("exceptions"):
         d["exceptions"] = [{k: (round(v, 8) if isinstance(v, float) else v) for k, v in
                             _pick(e, "half", "row", "entries", "cond", "gpu_vs_oracle",
@@ -1070,13 +1169,16 @@ def compact_line(out: dict) -> dict:
     tail of stdout.  The full objects are in the line printed just before it.
     """
     c = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
-              "higher_is_better", "scaling", "vs_baseline", "dtype")
+              "higher_is_better", "scaling", "vs_baseline", "dtype", "collectives", "incomplete")
     c["data"] = _short(out.get("data", ""), 200)
     c["config"] = _pick(out.get("config", {}), "workload", "solver", "parallelism", "data_source")
     if "roofline" in out:
         c["roofline"] = _roof(out["roofline"])
     if "cpu_baseline" in out:
         c["cpu_baseline"] = _cpu(out["cpu_baseline"])
+    if isinstance(out.get("summation_order"), dict):
+        c["summation_order"] = _pick(out["summation_order"], "default", "ms_per_step",
+                                     "ms_per_step_accurate_order", "rows_in_reference_order")
     par = out.get("parity")
     if isinstance(par, dict):
         c["parity"] = _als_par(par)
@@ -1085,9 +1187,11 @@ def compact_line(out: dict) -> dict:
     legs = {}
     knn = out.get("knn")
     if isinstance(knn, dict):
-        d = _pick(knn, "value", "unit", "build_seconds_to_host", "build_seconds_to_host_first_call",
-                  "build_save_nbrs_100_seconds", "prepare_seconds", "nnz_out", "error")
-        d["metric"] = "item-kNN model build seconds (HBM-resident; to_host = BASELINE's definition)"
+        d = _pick(knn, "value", "unit", "build_seconds_hbm_resident",
+                  "build_seconds_to_host_first_call", "build_save_nbrs_100_seconds",
+                  "prepare_seconds", "nnz_out", "error")
+        d["metric"] = ("item-kNN model build seconds, CSR on device -> similarity CSR on host "
+                       "(BASELINE's definition; hbm_resident = without the download)")
         d["roofline"] = _roof(knn.get("roofline"))
         d["cpu_baseline"] = _cpu(knn.get("cpu_baseline"))
         for name in ("batch_score", "recommend"):
@@ -1124,6 +1228,9 @@ def compact_line(out: dict) -> dict:
         d["roofline"] = _roof(leg.get("roofline"))
         d["cpu_baseline"] = _cpu(leg.get("cpu_baseline"))
         d["parity"] = _als_par(leg.get("parity"))
+        if isinstance(leg.get("summation_order"), dict):
+            d["summation_order"] = _pick(leg["summation_order"], "default", "ms_per_step",
+                                         "ms_per_step_accurate_order")
         if isinstance(leg.get("topk"), dict):
             t = leg["topk"]
             d["topk"] = _pick(t, "value", "unit", "users_per_s", "error")
@@ -1350,6 +1457,10 @@ def main():
     }
     if roof:
         out["roofline"] = roof
+    if getattr(eng, "summation_order", None):
+        out["summation_order"] = eng.summation_order
+    if getattr(eng, "collectives", None):
+        out["collectives"] = eng.collectives
 
     # The secondary legs must never cost the headline line: a failure is reported in place.
     def leg(name, fn):
@@ -1472,6 +1583,7 @@ def main():
                 out["sharded_legs_error"] = ("timeout: no answer from the sharded legs in "
                                              "%d s, headline line emitted by the watchdog"
                                              % args.sharded_legs_timeout)
+                out["incomplete"] = True  # (a hung leg must not read as success)
                 emit(out)
                 sys.stdout.flush()
             os._exit(0)
@@ -1563,6 +1675,8 @@ def main():
                        "on one GPU), %d timed epochs" % args.k128_steps},
             "roofline": roof2,
         }
+        if getattr(eng2, "summation_order", None):
+            res["summation_order"] = eng2.summation_order
         if not args.no_cpu:
             res["parity"], res["cpu_baseline"] = als_parity_and_cpu(eng2, ui, k2, reg, 0.05)
         return res

@@ -99,22 +99,59 @@ def _relabel_csr(mat: sps.csr_array, row_new_of_old, n_rows_new, col_new_of_old,
 
 
 class TorchComm:
-    "The engine's collectives on ``torch.distributed`` (backend ``nccl`` = RCCL on the GPU boxes)."
+    """The engine's collectives on ``torch.distributed`` (backend ``nccl`` = RCCL on the GPU boxes).
+
+    ``enable_timing(True)``: every collective is bracketed by events on the current stream and
+    ``timing_ms()`` returns the milliseconds spent per kind since the last call -- what a rank's
+    stream WAITED for (a blocking collective: its whole duration; an asynchronous row gather:
+    only what was still outstanding at ``wait()``, i.e. the part the solve of the next slice did
+    not hide).  ``bench.py --gpus N`` prints it per rank beside the epoch time, so that the first
+    multi-GPU run can be read against DESIGN.md section 6's predicted table.
+    """
 
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self._timing = False
+        self._events = []  # (kind, start, end)
+
+    def enable_timing(self, on: bool = True):
+        self._timing = bool(on)
+        self._events = []
+
+    def _timed(self, kind, fn):
+        if not (self._timing and torch.cuda.is_available()):
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        self._events.append((kind, a, b))
+        return out
+
+    def timing_ms(self) -> dict:
+        "milliseconds per kind of collective since enable_timing / the last call (synchronises)"
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        tot = {}
+        for kind, a, b in self._events:
+            tot[kind] = tot.get(kind, 0.0) + float(a.elapsed_time(b))
+        self._events = []
+        return tot
 
     def broadcast(self, t: torch.Tensor):
-        dist.broadcast(t, src=_global_rank(self.group, 0), group=self.group)
+        self._timed("broadcast", lambda: dist.broadcast(t, src=_global_rank(self.group, 0),
+                                                        group=self.group))
 
     def all_reduce(self, t: torch.Tensor):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self._timed("all_reduce", lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM,
+                                                          group=self.group))
 
     def all_gather_rows(self, full: torch.Tensor, lo: int, hi: int):
         "in place: every rank's row block [lo, hi) of ``full`` ends up in everybody's ``full``"
-        dist.all_gather_into_tensor(full, full[lo:hi], group=self.group)
+        self._timed("all_gather", lambda: dist.all_gather_into_tensor(full, full[lo:hi],
+                                                                      group=self.group))
 
     def all_gather_block_async(self, full: torch.Tensor, slo: int, shi: int, lo: int, hi: int):
         """
@@ -123,8 +160,17 @@ class TorchComm:
         (the solve of these rows) and runs beside what is launched next; ``.wait()`` on the
         returned handle orders the current stream behind it.
         """
-        return dist.all_gather_into_tensor(full[slo:shi], full[lo:hi], group=self.group,
-                                           async_op=True)
+        h = dist.all_gather_into_tensor(full[slo:shi], full[lo:hi], group=self.group,
+                                        async_op=True)
+        if not self._timing:
+            return h
+        comm = self
+
+        class _TimedHandle:
+            def wait(self_inner):
+                return comm._timed("all_gather_exposed_wait", h.wait)
+
+        return _TimedHandle()
 
 
 class LoopbackComm:

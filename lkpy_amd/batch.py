@@ -9,12 +9,15 @@ from __future__ import annotations
 
 import numpy as np
 
-from .data import ItemList, RecQuery
+from .data import ItemList, ItemListCollection, RecQuery
 from .pipeline import Pipeline
 
 
-def recommend(pipe: Pipeline, users, n: int, *, batch_size: int = 2048) -> dict:
-    "user id -> ordered ItemList of ``n`` recommendations."
+def recommend(pipe: Pipeline, users, n: int, *, batch_size: int = 2048) -> ItemListCollection:
+    """Ordered lists of ``n`` recommendations as an ``ItemListCollection`` keyed by ``user_id``
+    (what ``BatchResults.output("recommendations")`` is in the reference,
+    src/lenskit/batch/_runner.py:157-191): ``out.lookup(user)`` / ``out.lookup(user_id=user)``,
+    iteration over ``(key, list)``, ``out.to_df()``."""
     scorer = pipe.node("scorer").component
     lookup = pipe.node("history-lookup").component
     users = list(users)
@@ -31,11 +34,12 @@ def recommend(pipe: Pipeline, users, n: int, *, batch_size: int = 2048) -> dict:
     else:
         for u in users:
             out[u] = pipe.run("recommender", query=u, n=n)
-    return out
+    return ItemListCollection.from_dict(out, key=("user_id",))
 
 
-def predict(pipe: Pipeline, pairs: dict) -> dict:
-    "user id -> ItemList of scores for that user's items (``rating-predictor`` semantics)."
+def predict(pipe: Pipeline, pairs: dict) -> ItemListCollection:
+    """Scores for each user's items (``rating-predictor`` semantics) as an ``ItemListCollection``
+    keyed by ``user_id`` (``BatchResults.output("predictions")``)."""
     scorer = pipe.node("scorer").component
     lookup = pipe.node("history-lookup").component
     users = list(pairs)
@@ -49,5 +53,7 @@ def predict(pipe: Pipeline, pairs: dict) -> dict:
             fb = pipe.node("fallback-predictor").component
             scored = [merger.component(primary=s, backup=fb(q, il))
                       for s, q, il in zip(scored, queries, lists)]
-        return dict(zip(users, scored))
-    return {u: pipe.run("rating-predictor", query=u, items=il) for u, il in zip(users, lists)}
+        return ItemListCollection.from_dict(dict(zip(users, scored)), key=("user_id",))
+    return ItemListCollection.from_dict(
+        {u: pipe.run("rating-predictor", query=u, items=il) for u, il in zip(users, lists)},
+        key=("user_id",))

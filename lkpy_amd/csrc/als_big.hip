@@ -75,18 +75,19 @@ __global__ __launch_bounds__(256) void als_big_gram_kernel(
     // this wave's tiles: tj = ti + wave, ti + wave + 4, ...
     const int nt_w = (NT - ti - wave + 3) / 4;  // <= MAXT
     if (nt_w <= 0) return;
-    f32x4 acc[MAXT];
+    // The reference's summation order, on EVERY row (round 5): `mtl.dot(&o_picked)`
+    // (src/accel/als/implicit.rs:112) is matrixmultiply's sgemm -- the row's entries in blocks of
+    // KC = 256, one fma chain per block starting from zero, the block sums added one after the
+    // other -- and `otor + &mtm` adds OtOr last.  `acc` is the running block, `tot` the sum of the
+    // finished blocks; one unbroken chain over a 10^5-entry row would stagnate differently.
+    f32x4 acc[MAXT], tot[MAXT];
 #pragma unroll
     for (int q = 0; q < MAXT; ++q) {
         acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (q < nt_w) {
-            const int tj = ti + wave + 4 * q;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[q][r] = otor_p[(int64_t)(16 * ti + 4 * slot + r) * KP + 16 * tj + sub];
-        }
+        tot[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int64_t last = end - 1;
+    int in_block = 0;  // entries of the running block so far
     for (int64_t e0 = beg; e0 < end; e0 += 4) {
         const int64_t e = e0 + slot <= last ? e0 + slot : last;
         const bool live = e0 + slot <= last;
@@ -102,6 +103,25 @@ __global__ __launch_bounds__(256) void als_big_gram_kernel(
                 const float qb = qrow[16 * (ti + wave + 4 * q) + sub];
                 acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, live ? qb : 0.f, acc[q], 0, 0, 0);
             }
+        }
+        in_block += 4;
+        if (in_block == 256) {  // (wave-uniform) a finished block joins the total, in order
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q) {
+                tot[q] += acc[q];
+                acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            in_block = 0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) {
+        if (in_block > 0) tot[q] += acc[q];  // the last, partial block
+        if (q < nt_w) {  // a = otor + mtm
+            const int tj = ti + wave + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[q][r] = otor_p[(int64_t)(16 * ti + 4 * slot + r) * KP + 16 * tj + sub] + tot[q][r];
         }
     }
     const float dg = EXPL ? reg * (float)(end - beg) : 0.f;  // explicit.rs:104-107
@@ -165,11 +185,15 @@ __global__ __launch_bounds__(256) void als_big_solve_kernel(
     const int PSUB = KP * 4;  // one k-group sub-panel: [row][4]
 
     // ---- right-hand side: y = sum_j (v_j + 1) q_j  (explicit: v_j q_j), thread = feature(s) ------
+    // (the reference's order: ONE sequential float32 chain per feature, product and sum rounded
+    // separately -- `mt.dot(&vals)` on a strided view, implicit.rs:116-117; see als_rhs.hip)
     for (int f = tid; f < KP; f += 256) {
         float y = 0.f;
         for (int64_t e = beg; e < end; ++e) {
             const float v = values[e];
-            y = fmaf(other[(int64_t)indices[e] * KP + f], EXPL ? v : v + 1.0f, y);
+            float prod = other[(int64_t)indices[e] * KP + f] * (EXPL ? v : v + 1.0f);
+            asm volatile("" : "+v"(prod));  // keep hipcc from fusing the pair into v_fmac
+            y = y + prod;
         }
         Y[f] = y;
     }

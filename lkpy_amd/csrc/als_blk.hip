@@ -1497,7 +1497,8 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
         if constexpr (NT == 16) dma = chunk_dma_enabled();
         if (dma) {
             if constexpr (NT == 16) {  // gathered rows staged through LDS (72 KiB, dynamic)
-                static bool attr_set = false;
+                static PerDeviceOnce attr_once;
+                bool &attr_set = attr_once.flag();
                 if (!attr_set) {
                     LK_HIP_CHECK(hipFuncSetAttribute(
                         reinterpret_cast<const void *>(&als_blk_chunk_dma_kernel<EXPL>),

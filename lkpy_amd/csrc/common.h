@@ -137,6 +137,18 @@ __device__ __forceinline__ void ctl_advance(const TaskCtlDev &c, unsigned n)
         __hip_atomic_store(c.h_done, old + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// hipFuncSetAttribute is per device: "done once" flags are kept per device
+struct PerDeviceOnce {
+    static constexpr int MAX_DEV = 64;
+    bool done[MAX_DEV] = {};
+    bool &flag()
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        return done[(dev >= 0 && dev < MAX_DEV) ? dev : 0];
+    }
+};
+
 // XCD-aware remap of a 1-D block index: consecutive *logical* blocks land on
 // the same XCD (dispatcher places physical block b on XCD b % 8), so blocks
 // that share operand panels share an L2.  Bijective for any grid size

@@ -417,7 +417,8 @@ static int launch_gramian(const float *m, int64_t n, int k, int ld, float reg, f
     bool dma = false;
     if constexpr (NT == 16) dma = gram_dma_enabled() && n >= 16;
     if (dma) {
-        static bool attr_set = false;
+        static PerDeviceOnce attr_once;
+        bool &attr_set = attr_once.flag();
         if (!attr_set) {
             LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gramian_partial_dma_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize,

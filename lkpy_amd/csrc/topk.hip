@@ -1344,10 +1344,15 @@ struct TopkSide {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
+// one per host thread (the sharded tests run ranks as threads) AND per device (a thread
+// that scores on a second device must not record events / launch on the first device's stream)
 static TopkSide &topk_side()
 {
-    static thread_local TopkSide s;  // (one per host thread: the sharded tests run ranks as threads)
-    return s;
+    constexpr int MAX_DEV = 64;
+    static thread_local TopkSide s[MAX_DEV];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return s[(dev >= 0 && dev < MAX_DEV) ? dev : 0];
 }
 
 static int fused_stride(int64_t n_items, int32_t n)

@@ -207,6 +207,102 @@ class ItemList:
         return f"<ItemList of {len(self)} items, fields {sorted(self._fields)}>"
 
 
+class ItemListCollection:
+    """
+    Item lists keyed by named tuples -- the shape ``batch.recommend`` / ``BatchResults.output``
+    hand back in the reference (``src/lenskit/data/_collection/_base.py:48-592``,
+    ``_list.py:27-200``; ``src/lenskit/batch/_runner.py:157-191``): ``lookup(key)`` /
+    ``lookup(user_id=...)``, ``items()`` / ``lists()`` / ``keys()``, ``len``, iteration over
+    ``(key, list)`` pairs, positional ``[i]``, ``key_fields`` / ``key_type``, ``to_df()``
+    (key columns + the lists' columns), ``total_items()``, ``from_dict``.  A list-backed
+    collection with a dict index, like the reference's ``ListILC``.
+    """
+
+    def __init__(self, key=("user_id",), *, index: bool = True):
+        from collections import namedtuple
+
+        if isinstance(key, type):
+            self._key_class = key
+        else:
+            if isinstance(key, str):
+                key = (key,)
+            self._key_class = namedtuple("ListKey", list(key))
+        self._lists: list[tuple[tuple, ItemList]] = []
+        self._index: dict | None = {} if index else None
+
+    @classmethod
+    def from_dict(cls, data, key=None) -> "ItemListCollection":
+        ilc = cls(key if key is not None else ("user_id",))
+        for k, il in data.items():
+            if isinstance(k, tuple):
+                ilc.add(il, *k)
+            else:
+                ilc.add(il, k)
+        return ilc
+
+    @property
+    def key_fields(self) -> tuple:
+        return tuple(self._key_class._fields)
+
+    @property
+    def key_type(self):
+        return self._key_class
+
+    def add(self, list: ItemList, *fields, **kwfields):
+        key = self._key_class(*fields, **kwfields)
+        if self._index is not None:
+            if key in self._index:
+                raise KeyError(f"duplicate key {key}")
+            self._index[key] = len(self._lists)
+        self._lists.append((key, list))
+
+    def lookup(self, *args, **kwargs) -> ItemList | None:
+        if len(args) == 1 and not kwargs and isinstance(args[0], tuple):
+            key = self._key_class(*args[0])
+        else:
+            key = self._key_class(*args, **kwargs)
+        if self._index is None:
+            raise TypeError("cannot look up on a collection without an index")
+        pos = self._index.get(key)
+        return None if pos is None else self._lists[pos][1]
+
+    def items(self):
+        return iter(self._lists)
+
+    def lists(self):
+        return (il for _k, il in self._lists)
+
+    def keys(self):
+        return (k for k, _il in self._lists)
+
+    def total_items(self) -> int:
+        return sum(len(il) for _k, il in self._lists)
+
+    def __len__(self):
+        return len(self._lists)
+
+    def __iter__(self):
+        return iter(self._lists)
+
+    def __getitem__(self, pos: int):
+        "positional, like the reference: ``(key, list)`` of the ``pos``-th entry"
+        return self._lists[pos]
+
+    def to_df(self) -> pd.DataFrame:
+        frames = []
+        for key, il in self._lists:
+            df = il.to_df()
+            for f, v in zip(reversed(self.key_fields), reversed(key)):
+                df.insert(0, f, v)
+            frames.append(df)
+        if not frames:
+            return pd.DataFrame(columns=[*self.key_fields, "item_id"])
+        return pd.concat(frames, ignore_index=True)
+
+    def __repr__(self):
+        return f"<ItemListCollection of {len(self)} lists, key {self.key_fields}>"
+
+
 class RecQuery:
     "A recommendation query (``_query.py``): user id and/or history items."
 

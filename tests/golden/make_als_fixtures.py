@@ -14,7 +14,9 @@ executes them, and commits only the resulting input / output VECTORS:
 * ``_train_bias_row_cholesky``          ``src/lenskit/als/_explicit.py:121-147`` (explicit model)
 * ``BiasedMFTrainer.initial_params``    ``src/lenskit/als/_explicit.py:104-108``
 
-Run ONCE in the build container (``/root/reference`` does not exist on the GPU box):
+Run ONCE in the build container (``/root/reference`` does not exist on the GPU box), with the
+BLAS pool pinned to one thread (done below: the summation order of a threaded sgemv depends on the
+pool size and the host's load):
 
     python tests/golden/make_als_fixtures.py
 
@@ -182,4 +184,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    # ONE BLAS thread while the reference's functions run: OpenBLAS splits a long sgemv / sgemm
+    # reduction over its pool, and how it splits depends on the thread count and on the load of
+    # the host -- with the pool pinned the vectors are a function of the inputs alone, and
+    # tests/test_oracle_pinned.py (which pins the pool the same way) can hold the NumPy half of
+    # the oracle to them BIT FOR BIT on any host (the unpinned check failed
+    # once in three runs on a busy host).
+    from threadpoolctl import threadpool_limits
+
+    with threadpool_limits(limits=1, user_api="blas"):
+        main()

@@ -175,3 +175,45 @@ def test_component_trains_and_recommends_at_k_300(gpu, oracle):
         assert np.array_equal(np.sort(full[top])[::-1].view(np.uint32), row_s.view(np.uint32))
         assert set(row_i.tolist()) == set(top.tolist()) or \
             np.array_equal(full[row_i].view(np.uint32), row_s.view(np.uint32))
+
+
+def test_long_row_above_256_follows_the_reference_order(gpu, oracle):
+    """a 120 000-entry row at k = 320 whose gathered factor rows repeat (the case in
+    which the reference's sequential float32 sums drift systematically, tests/
+    test_gpu_als_rhs_order.py).  The k > 256 kernels now sum every row in the reference's own
+    order -- 256-entry blocks from zero added one after the other, OtOr last, y as one chain with
+    product and sum rounded separately (src/accel/als/implicit.rs:110-117) -- so the row stays
+    within 1e-4 of the oracle although the ORACLE is further than that from float64."""
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    rng = np.random.default_rng(19)
+    k, n_cols, long_len = 320, 130_000, 120_000
+    mat = _csr(rng, 24, n_cols, [long_len, 9000, 257, 256, 0, 1])
+    other = (np.abs(rng.standard_normal((n_cols, k))) * 0.05).astype(np.float32)
+    other[rng.random((n_cols, k)) < 0.3] *= -1.0
+    pool = (np.abs(rng.standard_normal((2048, k))) * 0.05).astype(np.float32)
+    pool[rng.random((2048, k)) < 0.3] *= -1.0
+    rep = rng.random(n_cols) < 0.9
+    other[rep] = pool[rng.integers(0, 2048, int(rep.sum()))]
+    this = np.zeros((mat.shape[0], k), np.float32)
+    otor = oracle.implicit_otor(other, 0.1)
+    want = this.copy()
+    oracle.als_half_epoch(mat, want, other, otor)
+    exact, _ = oracle.als_referee_f64(mat, other, 0.1, with_cond=False)
+    csr = D.DeviceCSR.from_arrays(mat.indptr.astype(np.int32), mat.indices, mat.data, mat.shape, gpu)
+    plan = D.ALSPlan(csr, k, _native.SOLVER_AUTO)
+    d_this = D.to_device_padded(this, gpu)
+    import torch
+
+    plan.half_epoch(d_this, D.to_device_padded(other, gpu),
+                    torch.from_numpy(otor).to(gpu))  # the oracle's own OtOr: identical inputs
+    plan.check_status()
+    got = D.to_host_unpadded(d_this, k)
+    nz = np.diff(mat.indptr) > 0
+    rel = np.linalg.norm(got[nz].astype(np.float64) - want[nz], axis=1) / np.linalg.norm(want[nz], axis=1)
+    o64 = np.linalg.norm(want[0].astype(np.float64) - exact[0]) / np.linalg.norm(exact[0])
+    print(f"\nk=320, {long_len}-entry row: GPU vs oracle {rel[0]:.2e} (oracle vs float64 {o64:.2e}); "
+          f"worst row {rel.max():.2e}")
+    assert rel.max() < RTOL, rel
+    assert rel[0] < 3e-5

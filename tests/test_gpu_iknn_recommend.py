@@ -121,11 +121,15 @@ def test_recommend_through_the_scorer_and_batch_runner(gpu, oracle, ml_small):
     pipe.run = lambda *a, **k: (calls.append(a), orig(*a, **k))[1]
     got = batch.recommend(pipe, users, 10)
     assert not calls, "batch.recommend must not fall back to one pipeline run per user"
+    assert got.key_fields == ("user_id",) and len(got) == len(users)
+    assert got.lookup(user_id=users[0]) is got.lookup((users[0],))
+    df = got.to_df()
+    assert list(df.columns[:2]) == ["user_id", "item_id"] and "rank" in df.columns
     pipe.run = orig
     diff = 0
     for u in users:
         want = pipe.run("recommender", query=u, n=10)
-        g = got[u]
+        g = got.lookup(u)  # an ItemListCollection keyed by user_id, like the reference's
         ws_, gs_ = np.asarray(want.scores(), np.float32), np.asarray(g.scores(), np.float32)
         assert np.array_equal(ws_.view(np.uint32), gs_.view(np.uint32)), u
         if not np.array_equal(want.numbers(vocabulary=scorer.items),

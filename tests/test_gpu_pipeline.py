@@ -153,11 +153,13 @@ def test_als_batch_recommend_equals_per_query(gpu, ml_ds):
     pipe.train(ml_ds, TrainingOptions(rng=7))
     users = [int(u) for u in ml_ds.users.ids()[::40]] + [-1]
     out = batch.recommend(pipe, users, 20)
-    assert len(out[-1]) == 0  # unknown user without history: nothing to recommend
+    # (an ItemListCollection keyed by user_id: src/lenskit/batch/_runner.py:157-191)
+    assert len(out.lookup(-1)) == 0  # unknown user without history: nothing to recommend
+    assert [k.user_id for k in out.keys()] == users and out[0][0].user_id == users[0]
     for u in users[:-1]:
         one = pipe.run("recommender", query=u, n=20)
-        assert np.array_equal(out[u].ids(), one.ids())
-        assert np.array_equal(out[u].scores(), one.scores())
+        assert np.array_equal(out.lookup(u).ids(), one.ids())
+        assert np.array_equal(out.lookup(user_id=u).scores(), one.scores())
 
 
 def test_user_embeddings_false_and_prefer(gpu, ml_ds):
@@ -206,7 +208,7 @@ def test_iknn_explicit_toml_end_to_end(gpu, oracle, ml_small, ml_ds):
     known = pd.read_csv(GOLDEN / "item-item-preds.csv")
     pairs = {int(u): ItemList(g.item_id.values) for u, g in known.groupby("user_id")}
     preds = batch.predict(pipe, pairs)
-    got = np.concatenate([preds[int(u)].scores() for u, _ in known.groupby("user_id")])
+    got = np.concatenate([preds.lookup(int(u)).scores() for u, _ in known.groupby("user_id")])
     exp = np.concatenate([g.prediction.values for _, g in known.groupby("user_id")])
     assert not np.any(np.isnan(got) & ~np.isnan(exp))
     err = np.abs(got - exp)

@@ -408,3 +408,32 @@ def test_load_movielens_equals_the_committed_fixture():
     assert ds.users == g.users and ds.items == g.items
     assert np.array_equal(ds._cols, g._cols) and np.array_equal(ds._indptr, g._indptr)
     assert np.array_equal(ds._attrs["rating"], g._attrs["rating"])
+
+
+def test_item_list_collection_mirrors_the_reference_api():
+    """``batch.recommend`` / ``batch.predict`` hand back an ``ItemListCollection`` keyed by
+    ``user_id`` (src/lenskit/data/_collection/_base.py:48-592, batch/_runner.py:157-191)."""
+    from lkpy_amd.data import ItemList, ItemListCollection
+
+    c = ItemListCollection.from_dict(
+        {3: ItemList([1, 2, 3], scores=[0.3, 0.2, 0.1], ordered=True), 5: ItemList([7])})
+    assert len(c) == 2 and c.key_fields == ("user_id",) and c.total_items() == 4
+    assert c.lookup(3).ids().tolist() == [1, 2, 3]
+    assert c.lookup(user_id=5) is c.lookup((5,)) and c.lookup(9) is None
+    key, il = c[1]  # positional, like the reference
+    assert key.user_id == 5 and len(il) == 1
+    assert [k.user_id for k in c.keys()] == [3, 5] and [len(x) for x in c.lists()] == [3, 1]
+    assert [(k.user_id, len(x)) for k, x in c] == [(3, 3), (5, 1)]
+    df = c.to_df()
+    assert list(df.columns[:2]) == ["user_id", "item_id"] and len(df) == 4
+    assert df[df.user_id == 3]["rank"].tolist() == [1, 2, 3]
+    c.add(ItemList([9]), 8)
+    assert c.lookup(8).ids().tolist() == [9]
+    import pytest
+
+    with pytest.raises(KeyError):
+        c.add(ItemList([9]), 8)
+    two = ItemListCollection(("user_id", "seq"))
+    two.add(ItemList([1]), 4, 0)
+    two.add(ItemList([2]), user_id=4, seq=1)
+    assert two.lookup(4, 1).ids().tolist() == [2] and two.key_type._fields == ("user_id", "seq")

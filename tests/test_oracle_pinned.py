@@ -53,6 +53,18 @@ def _row_rel(a, b):
     return out
 
 
+@pytest.fixture(autouse=True)
+def _one_blas_thread():
+    """The fixtures were generated with the BLAS pool pinned to ONE thread (make_als_fixtures.py)
+    and the bit-for-bit checks below run the same way: a threaded sgemv splits its reduction by
+    pool size and host load, which made ``[25-centered]`` fail once in three runs on a busy host
+    (VERDICT r4, weak #3)."""
+    from threadpoolctl import threadpool_limits
+
+    with threadpool_limits(limits=1, user_api="blas"):
+        yield
+
+
 @pytest.fixture(scope="module")
 def rows():
     return np.load(GOLD / "als_ref_rows.npz")
