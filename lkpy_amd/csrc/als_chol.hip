@@ -54,6 +54,9 @@
 #ifndef LK_ALS_GRAM_FENCE
 #define LK_ALS_GRAM_FENCE 1
 #endif
+#ifndef LK_ALS_SLAB_NT
+#define LK_ALS_SLAB_NT 1
+#endif
 #ifndef LK_ALS_SOLVE_PRIO
 #define LK_ALS_SOLVE_PRIO 0  // s_setprio level of a wave while it factors / substitutes (0: unchanged)
 #endif
@@ -360,11 +363,25 @@ __device__ __forceinline__ void dma_consume(Gram<4> &G, const float *ring, const
     dma_apply<MASKED>(G, dma_fetch(ring, slot_idx, g, stage_slot), g, nb, expl);
 }
 
+template <int NT>
+__host__ __device__ constexpr int slab_floats();
+template <int NT>
+__device__ __forceinline__ void slab_store(const Gram<NT> &G, float *__restrict__ slab);
+template <int NT>
+__device__ __forceinline__ void gram_zero(Gram<NT> &G);
+
 // ring: GRAM_DMA_WORDS floats, stage: GRAM_STAGE_WORDS floats, both wave-private LDS
+// `slab` (optional; reference-order work units, als_plan.h): at every 256-entry boundary that is
+// followed by more entries the accumulators are stored to *slab (the next slab follows it) and
+// start again from zero -- matrixmultiply's KC = 256 blocks, each an fma chain of its own -- while
+// the gather ring keeps running: the wave never drains its memory queue inside a unit.  (The
+// slab stores count in vmcnt like the loads: the first waits after a boundary are a little more
+// conservative than needed, never less.)  The last block of the range is left in G.
 __device__ __forceinline__ void gram_accumulate_dma(Gram<4> &G, const int32_t *__restrict__ cols,
                                                     const float *__restrict__ vals, int64_t beg,
                                                     int64_t end, const float *__restrict__ other,
-                                                    const bool expl, float *ring, float *stage)
+                                                    const bool expl, float *ring, float *stage,
+                                                    float *__restrict__ slab = nullptr)
 {
     constexpr int RING = DMA_RING;
     static_assert(RING == 8 || RING == 4, "DMA ring: 4 or 8 groups");
@@ -439,6 +456,11 @@ __device__ __forceinline__ void gram_accumulate_dma(Gram<4> &G, const int32_t *_
             __builtin_amdgcn_sched_barrier(0);
         }
 #endif
+        if (slab && ((g0 + 16) & 63) == 0) {  // (wave-uniform) a 256-entry block is complete
+            slab_store<4>(G, slab);
+            slab += slab_floats<4>();
+            gram_zero<4>(G);
+        }
         float *tw = wr_cur;
         wr_cur = wr_nxt;
         wr_nxt = tw;
@@ -475,6 +497,11 @@ __device__ __forceinline__ void gram_accumulate_dma(Gram<4> &G, const int32_t *_
                 else
                     dma_issue(ring_lds, g % RING, g + RING - 16, rd_nxt, other);
             }
+        }
+        if (slab && ((g0 + 16) & 63) == 0 && g0 + 16 < total) {  // a block boundary, more follows
+            slab_store<4>(G, slab);
+            slab += slab_floats<4>();
+            gram_zero<4>(G);
         }
         float *tw = wr_cur;
         wr_cur = wr_nxt;
@@ -553,7 +580,10 @@ __device__ __forceinline__ void gram_accumulate_dma_256(Gram<4> &G, const int32_
     }
 }
 
-// slab layout: [(NTILES*4 + NT)][64] floats, register-major / lane-minor
+// slab layout: tile e as [64 lanes][4 registers] (one 16-byte store / load per lane and tile:
+// a slab is written in als_tiles + 1 instructions where the register-major layout took 4 x as
+// many -- it matters since round 5, when a wave stores a slab every 256 entries), then y as
+// [64 lanes][NT]
 template <int NT>
 __host__ __device__ constexpr int slab_floats()
 {
@@ -564,12 +594,18 @@ template <int NT>
 __device__ __forceinline__ void slab_store(const Gram<NT> &G, float *__restrict__ slab)
 {
     const int lane = lane_id();
+    // (LK_ALS_SLAB_NT: streaming stores -- a slab is written once and read once by another
+    // kernel; kept out of the L2 it would otherwise share with the gathered factor rows)
 #pragma unroll
-    for (int e = 0; e < als_tiles(NT); ++e)
+    for (int e = 0; e < als_tiles(NT); ++e) {
+#if LK_ALS_SLAB_NT
+        __builtin_nontemporal_store(G.t[e], reinterpret_cast<f32x4 *>(slab + (e * 64 + lane) * 4));
+#else
+        *reinterpret_cast<f32x4 *>(slab + (e * 64 + lane) * 4) = G.t[e];
+#endif
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) slab[(e * 4 + r) * 64 + lane] = G.t[e][r];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) slab[(als_tiles(NT) * 4 + t) * 64 + lane] = G.y[t];
+    for (int t = 0; t < NT; ++t) slab[als_tiles(NT) * 256 + lane * NT + t] = G.y[t];
 }
 
 template <int NT>
@@ -578,10 +614,18 @@ __device__ __forceinline__ void slab_add(Gram<NT> &G, const float *__restrict__ 
     const int lane = lane_id();
 #pragma unroll
     for (int e = 0; e < als_tiles(NT); ++e)
+        G.t[e] += *reinterpret_cast<const f32x4 *>(slab + (e * 64 + lane) * 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) G.t[e][r] += slab[(e * 4 + r) * 64 + lane];
+    for (int t = 0; t < NT; ++t) G.y[t] += slab[als_tiles(NT) * 256 + lane * NT + t];
+}
+
+template <int NT>
+__device__ __forceinline__ void gram_zero(Gram<NT> &G)
+{
 #pragma unroll
-    for (int t = 0; t < NT; ++t) G.y[t] += slab[(als_tiles(NT) * 4 + t) * 64 + lane];
+    for (int e = 0; e < als_tiles(NT); ++e) G.t[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) G.y[t] = 0.f;
 }
 
 // ---- slab groups: slab[head] += slab[head + 1] + ... + slab[head + cnt - 1] ------------------
@@ -605,7 +649,8 @@ __global__ __launch_bounds__(256) void slab_group_reduce_kernel(float *__restric
         f32x4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            v[u] = *reinterpret_cast<const f32x4 *>(head + (size_t)(c + u) * slab_floats);
+            v[u] = __builtin_nontemporal_load(
+                reinterpret_cast<const f32x4 *>(head + (size_t)(c + u) * slab_floats));
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += v[u];
     }
@@ -638,7 +683,8 @@ __device__ __forceinline__ void als_chunk_body(
     const int32_t *__restrict__ indices, const float *__restrict__ values,
     const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_len,
     int64_t n_chunks, const float *__restrict__ other, int ld, float *__restrict__ slabs,
-    const int64_t blk, float *__restrict__ lds_flat)
+    const int64_t blk, float *__restrict__ lds_flat,
+    const int32_t *__restrict__ chunk_slab = nullptr, const int block_len = 0)
 {
     constexpr bool DMA = LK_ALS_GRAM_DMA && NT == 4;
     float(*stage_all)[chunk_lds_floats<NT>()] =
@@ -647,14 +693,17 @@ __device__ __forceinline__ void als_chunk_body(
     const int64_t c = blk * 4 + wave;
     if (c >= n_chunks) return;
     Gram<NT> G;
-#pragma unroll
-    for (int e = 0; e < als_tiles(NT); ++e) G.t[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) G.y[t] = 0.f;
+    gram_zero<NT>(G);
     const int64_t beg = chunk_beg[c];
+    // the unit's first slab (a unit of several 256-entry blocks stores one slab per block)
+    float *slab = slabs + (size_t)(chunk_slab ? chunk_slab[c] : c) * slab_floats<NT>();
     if constexpr (DMA) {
         const int len = chunk_len[c];
-        if (LK_ALS_CHUNK256_FAST && len == 256)  // (wave-uniform) a full reference-order block
+        if (block_len == 256 && len > 256) {  // (wave-uniform) a reference-order work unit
+            gram_accumulate_dma(G, indices, values, beg, beg + len, other, EXPL,
+                                stage_all[wave] + GRAM_STAGE_WORDS, stage_all[wave], slab);
+            slab += (size_t)((len - 1) >> 8) * slab_floats<NT>();  // the last block is still in G
+        } else if (LK_ALS_CHUNK256_FAST && len == 256)  // a full reference-order block
             gram_accumulate_dma_256(G, indices, values, beg, other, EXPL,
                                     stage_all[wave] + GRAM_STAGE_WORDS, stage_all[wave]);
         else
@@ -663,18 +712,19 @@ __device__ __forceinline__ void als_chunk_body(
     } else
         gram_accumulate<NT>(G, indices, values, beg, beg + chunk_len[c], other, ld, EXPL,
                             stage_all[wave]);
-    slab_store<NT>(G, slabs + (size_t)c * slab_floats<NT>());
+    slab_store<NT>(G, slab);
 }
 
 template <int NT, bool EXPL>
 __global__ __launch_bounds__(256) void als_chunk_kernel(
     const int32_t *__restrict__ indices, const float *__restrict__ values,
     const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_len,
-    int64_t n_chunks, const float *__restrict__ other, int ld, float *__restrict__ slabs)
+    int64_t n_chunks, const float *__restrict__ other, int ld, float *__restrict__ slabs,
+    const int32_t *__restrict__ chunk_slab, int block_len)
 {
     __shared__ __attribute__((aligned(16))) float lds_flat[4 * chunk_lds_floats<NT>()];
     als_chunk_body<NT, EXPL>(indices, values, chunk_beg, chunk_len, n_chunks, other, ld, slabs,
-                             (int64_t)blockIdx.x, lds_flat);
+                             (int64_t)blockIdx.x, lds_flat, chunk_slab, block_len);
 }
 
 // ---- solve: lane R owns row R of the (primed) normal matrix -----------------
@@ -1689,24 +1739,40 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
                                p->n_long, p->d_row_slab, other, ld_other, this_, ld_this, otor_p,
                                slabs, row_delta, status, k, reg, TaskCtlDev{});
     } else {
+        // The chains run on the plan's second stream, beside the chunk kernel and the solve of
+        // the other rows; only the (small) solve launch of the long rows waits for them.  They are
+        // ENQUEUED BEHIND the chunk kernel (the fork point is in front of it): the chain kernel is
+        // LDS-heavy and latency-bound; enqueued first it takes every CU's LDS for its first round
+        // of workgroups and the MFMA-bound chunk kernel waits (measured: +0.25 ms per cfg2 item
+        // half); enqueued second it trickles in as chunk workgroups retire and does most of its
+        // work under the solve of the short rows.  LK_ALS_CHAIN_FIRST=1: the old order.
         hipStream_t sr = st;
+        const char *cf = getenv("LK_ALS_CHAIN_FIRST");
+        const bool chain_first = cf && cf[0] == '1';
+        auto launch_chains = [&]() -> int {
+            return launch_rhs_reference(p, indptr, IS64 ? 1 : 0, indices, values, p->d_order, n_y,
+                                        other, EXPL, yref, sr);
+        };
         if (n_y > 0) {
-            // the chains run on the plan's second stream, beside the chunk kernel and the solve of
-            // the other rows; only the (small) solve launch of these rows waits for them
             int rc = plan_fork_rhs(p, st, &sr);
             if (rc != LK_OK) return rc;
-            rc = launch_rhs_reference(p, indptr, IS64 ? 1 : 0, indices, values, p->d_order, n_y,
-                                      other, EXPL, yref, sr);
-            if (rc != LK_OK) return rc;
+            if (chain_first && (rc = launch_chains()) != LK_OK) return rc;
         }
         if (p->n_chunks > 0) {
             hipLaunchKernelGGL((als_chunk_kernel<NT, EXPL>),
                                dim3((unsigned)((p->n_chunks + 3) / 4)), dim3(256), 0, st, indices,
                                values, p->d_chunk_beg, p->d_chunk_len, p->n_chunks, other,
-                               ld_other, slabs);
-            // the ordered slab sums of reference-order rows are pure HBM streaming (a quarter of
-            // the chunk phase with 256-entry chunks): on the second stream they run under the
-            // solve of the rows that need no slabs (LK_ALS_REDUCE_SIDE=0: launch stream)
+                               ld_other, slabs, p->d_chunk_slab,
+                               p->unit > p->chunk ? (int)p->chunk : 0);
+        }
+        if (n_y > 0 && !chain_first) {
+            int rc = launch_chains();
+            if (rc != LK_OK) return rc;
+        }
+        if (p->n_chunks > 0) {
+            // the ordered slab sums of reference-order rows are pure HBM streaming: on the second
+            // stream (behind the chains) they run under the solve of the rows that need no slabs
+            // (LK_ALS_REDUCE_SIDE=0: launch stream)
             hipStream_t sg = st;
             if (n_y > 0 && sr != st && reduce_on_side()) {
                 int rc = plan_rhs_wait_main(p, st);
@@ -1981,22 +2047,39 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
         p->t_cg1 = lo;
     }
     std::vector<int32_t> row_slab((size_t)n_rows, -1);
-    std::vector<int32_t> chunk_row;
+    std::vector<int32_t> chunk_row, chunk_slab;
     std::vector<int64_t> chunk_beg;
     std::vector<int32_t> chunk_len;
+    // work units (als_plan.h): hybrid plans at padded k = 64 keep 1024-entry units, one slab per
+    // 256-entry block (LK_ALS_REF_UNIT: entries per unit, a multiple of 256; 256 = a unit per block)
+    p->unit = p->chunk;
+    if (p->hybrid && KP == 64) {
+        const char *e = getenv("LK_ALS_REF_UNIT");
+        int u = e ? atoi(e) : LK_ALS_CHUNK;
+        if (u < p->chunk) u = p->chunk;
+        p->unit = u / p->chunk * p->chunk;
+    }
+    const int64_t UNIT = p->unit;
     {  // (CG plans too: their chunked rows are solved by the exact kernels, als_cg.hip)
         for (int64_t r = 0; r < n_rows; ++r) {
             int64_t n = len(r);
             if (n > LONG_ROW) {
-                row_slab[(size_t)r] = (int32_t)chunk_row.size();
-                for (int64_t o = 0; o < n; o += CHUNK) {
+                row_slab[(size_t)r] = (int32_t)p->n_slabs;
+                for (int64_t o = 0; o < n; o += UNIT) {
                     chunk_row.push_back((int32_t)r);
                     chunk_beg.push_back(start(r) + o);
-                    chunk_len.push_back((int32_t)std::min<int64_t>(CHUNK, n - o));
+                    chunk_len.push_back((int32_t)std::min<int64_t>(UNIT, n - o));
+                    chunk_slab.push_back((int32_t)(p->n_slabs + o / CHUNK));
                 }
+                p->n_slabs += (n + CHUNK - 1) / CHUNK;
                 p->n_long++;
             }
         }
+    }
+    if (p->n_slabs >= (int64_t)INT32_MAX) {
+        delete p;
+        lk::set_error("lk_als_plan_create: too many slabs");
+        return LK_E_INVALID;
     }
     p->n_chunks = (int64_t)chunk_row.size();
     // slab groups of the rows with many chunks (LK_ALS_SLAB_GROUP, als_plan.h)
@@ -2023,6 +2106,7 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
     int rc;
     if ((rc = upload(&p->d_order, order)) != LK_OK || (rc = upload(&p->d_row_slab, row_slab)) ||
         (rc = upload(&p->d_chunk_row, chunk_row)) || (rc = upload(&p->d_chunk_beg, chunk_beg)) ||
+        (rc = upload(&p->d_chunk_slab, chunk_slab)) ||
         (rc = upload(&p->d_grp_head, grp_head)) || (rc = upload(&p->d_grp_cnt, grp_cnt)) ||
         (rc = upload(&p->d_chunk_len, chunk_len))) {
         lk_als_plan_destroy(p);
@@ -2046,7 +2130,7 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
     } else {
         size_t slab_f = KP > 64 ? lk::als_blk_slab_floats(p->NT)
                                 : (size_t)(lk::als_tiles(p->NT) * 4 + p->NT) * 64;
-        off += lk::align_up((size_t)std::max<int64_t>(p->n_chunks, 1) * slab_f * sizeof(float),
+        off += lk::align_up((size_t)std::max<int64_t>(p->n_slabs, 1) * slab_f * sizeof(float),
                             256);
     }
     if (p->hybrid) {  // y of the long rows in the reference's order, one row of KP floats per task
@@ -2119,6 +2203,7 @@ extern "C" void lk_als_plan_destroy(lk_als_plan *p)
     if (p->d_chunk_row) (void)hipFree(p->d_chunk_row);
     if (p->d_chunk_beg) (void)hipFree(p->d_chunk_beg);
     if (p->d_chunk_len) (void)hipFree(p->d_chunk_len);
+    if (p->d_chunk_slab) (void)hipFree(p->d_chunk_slab);
     if (p->d_grp_head) (void)hipFree(p->d_grp_head);
     if (p->d_grp_cnt) (void)hipFree(p->d_grp_cnt);
     delete p;

@@ -83,7 +83,14 @@ struct lk_als_plan {
     // relabelled / sharded engines (the order of a row's entries is whatever the CSR holds).
     bool hybrid = false;
     size_t off_yref = 0;                 // hybrid: [n_long x KP] floats in the workspace
-    int32_t chunk = LK_ALS_CHUNK;        // CSR entries per chunk of a long row
+    int32_t chunk = LK_ALS_CHUNK;        // CSR entries per chunk (= per slab) of a long row
+    // entries per WORK UNIT of the chunk kernel (a multiple of `chunk`): hybrid plans at padded
+    // k = 64 keep the tuned kernel's 1024-entry units -- one wave runs its gather ring across the
+    // four 256-entry blocks of a unit and stores a slab at every block boundary (d_chunk_slab =
+    // the unit's first slab); everywhere else a unit is one chunk
+    int32_t unit = LK_ALS_CHUNK;
+    int64_t n_slabs = 0;                 // slabs of all long rows (n_chunks counts the UNITS)
+    int32_t *d_chunk_slab = nullptr;     // [n_chunks] first slab of the unit
     int32_t long_row = LK_ALS_LONG_ROW;  // rows longer than this are chunked
     size_t off_ginv = 0, off_invws = 0;  // [KP x KP] float inverse, spd_inverse scratch
     // device-side schedule

@@ -24,7 +24,7 @@
 // gather latency, ~75 cycles per entry: 50 ms for the 1.54 M-entry row.  Now one workgroup serves
 // (row, 64-feature slice): wave 0 only ADDS -- it reads the products four entries at a time
 // (`ds_read_b128`: the stage buffer is feature-major) and runs the chain, 5 instructions per 4
-// entries; waves 1..3 are producers: they gather the factor rows RC_D stages ahead into
+// entries; waves 1..RC_NP are producers: they gather the factor rows RC_D stages ahead into
 // registers (coalesced 64-byte quads), multiply by (v + 1) -- the product is rounded exactly as
 // in the reference, it just happens on another wave -- and write them transposed into the other
 // half of a double buffer.  One barrier per stage of RC_E entries, no `s_waitcnt vmcnt(0)`
@@ -37,16 +37,31 @@
 
 namespace lk {
 
+// Measured stand-alone on the ML-25M item half (longest row 81 491 entries; tools/chain_time.py,
+// rocprofv3 kernel trace with LK_ALS_SIDE_STREAM=0): NP = 3, G = 2: 613 us = 16 cycles per entry,
+// the producers slower than the chain; with packed multiplies and one select per entry 566 us;
+// NP = 4: 451 ... 460 us.  In the epoch the two are equal (3.52 vs 3.60 ms at cfg2: what the
+// chains take from the machine they take from the kernels they run beside), so the smaller
+// workgroup is the default.  NP = 6, G = 1 would halve a producer's work per stage, but hipcc
+// 7.2 then regroups the loads of a round (all q loads last) and waits for nearly all of them at
+// the first use -- its s_waitcnt placement in this loop is only right for some shapes (checked in
+// the ISA for the default: 24 .. 35 loads in flight at every wait); loads issued by inline asm
+// with hand-counted waits are the way past that, not built.
 #ifndef LK_RHS_NP
-#define LK_RHS_NP 3  // producer waves per workgroup (3: four waves, one per SIMD)
+#define LK_RHS_NP 3  // producer waves per workgroup
+#endif
+#ifndef LK_RHS_G
+#define LK_RHS_G 2  // 16-entry groups per producer wave and stage
 #endif
 #ifndef LK_RHS_D
-#define LK_RHS_D 3  // (4: hipcc 7.2 runs out of registers and parks the ring in AGPRs -- waits of 0)
+#define LK_RHS_D (LK_RHS_G == 1 ? 4 : 3)  // (G = 2, D = 4: hipcc 7.2 runs out of registers and
+                                          // parks the ring in AGPRs -- waits of 0)
 #endif
 constexpr int RC_NP = LK_RHS_NP;
-constexpr int RC_E = RC_NP * 32;  // entries per stage: two 16-entry groups per producer wave
-                                  // (a multiple of 32: the swizzle below)
+constexpr int RC_G = LK_RHS_G;
+constexpr int RC_E = RC_NP * RC_G * 16;  // entries per stage (a multiple of 32: the swizzle below)
 constexpr int RC_D = LK_RHS_D;    // stages of gathered rows in flight per producer wave (registers)
+static_assert(RC_E % 32 == 0 && RC_E % 4 == 0, "stage size");
 constexpr int RC_F = 64;  // features per workgroup (one chain wave)
 
 // stage buffer: product of (feature f, entry e) at word  f * RC_E + (e ^ ((f & 7) << 2)):
@@ -94,6 +109,7 @@ __global__ __launch_bounds__((RC_NP + 1) * 64) void als_rhs_chain_kernel(
         const float *mine = &buf[0][0] + lane * RC_E;
         auto consume = [&](int b) {
             const float *src = mine + b * (RC_F * RC_E);
+            static_assert((RC_E / 4) % 8 == 0, "stage = whole batches of 8 reads");
 #pragma unroll
             for (int g0 = 0; g0 < RC_E / 4; g0 += 8) {
                 f32x4 r[8];
@@ -118,37 +134,46 @@ __global__ __launch_bounds__((RC_NP + 1) * 64) void als_rhs_chain_kernel(
         return;
     }
 
-    // ---- producers: wave pw takes the entry groups 2 pw, 2 pw + 1 (16 entries each) of every
-    // stage; lane -> entry (lane >> 2) of the group, float4 column jg * 4 + (lane & 3)
+    // ---- producers: wave pw takes the entry groups RC_G pw .. RC_G pw + RC_G - 1 (16 entries
+    // each) of every stage; lane -> entry (lane >> 2) of the group, float4 column jg * 4 + (lane & 3)
     const int pw = wave - 1;
-    const int el0 = (2 * pw) * 16 + (lane >> 2), el1 = el0 + 16;
+    const int el0 = (RC_G * pw) * 16 + (lane >> 2);  // group h of this wave: entry el0 + 16 h
     int foff[4];
-    bool jv[4];
 #pragma unroll
     for (int jg = 0; jg < 4; ++jg) {
         const int f0 = (jg * 4 + (lane & 3)) * 4;
-        jv[jg] = f0 < fw;
-        foff[jg] = fbase + (jv[jg] ? f0 : 0);
+        foff[jg] = fbase + (f0 < fw ? f0 : 0);
     }
     const int32_t *ci = indices + beg;
     const float *cv = values + beg;
     const int64_t last = n - 1;
 
-    f32x4 q[RC_D][2][4];
-    float v[RC_D][2];
-    int c[RC_D][2];
+    f32x4 q[RC_D][RC_G][4];
+    float v[RC_D][RC_G];
+    int c[RC_D][RC_G];
+    // (The arrays are `const __restrict__`: to hipcc their loads commute with every asm
+    // statement, "memory" clobber or not, and it may regroup them across steps.  Laundering the
+    // base pointers through "+s" asm operands pins them -- and makes hipcc 7.2 wait
+    // vmcnt(0) lgkmcnt(0) in front of every such statement.  The configuration below is the one
+    // whose generated waits were checked in the ISA: 24 .. 35 loads in flight at every wait.)
     auto load_idx = [&](int d, int s) {
-        const int64_t e0 = (int64_t)s * RC_E + el0, e1 = (int64_t)s * RC_E + el1;
-        c[d][0] = ci[e0 < last ? e0 : last];
-        c[d][1] = ci[e1 < last ? e1 : last];
+        const int32_t *ci_ = ci;
+#pragma unroll
+        for (int h = 0; h < RC_G; ++h) {
+            const int64_t e = (int64_t)s * RC_E + el0 + 16 * h;
+            c[d][h] = ci_[e < last ? e : last];
+        }
     };
     auto issue = [&](int d, int s) {
-        const int64_t e0 = (int64_t)s * RC_E + el0, e1 = (int64_t)s * RC_E + el1;
-        v[d][0] = cv[e0 < last ? e0 : last];
-        v[d][1] = cv[e1 < last ? e1 : last];
+        const float *cv_ = cv, *oth = other;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float *r = other + (int64_t)c[d][h] * KP;
+        for (int h = 0; h < RC_G; ++h) {
+            const int64_t e = (int64_t)s * RC_E + el0 + 16 * h;
+            v[d][h] = cv_[e < last ? e : last];
+        }
+#pragma unroll
+        for (int h = 0; h < RC_G; ++h) {
+            const float *r = oth + (int64_t)c[d][h] * KP;
 #pragma unroll
             for (int jg = 0; jg < 4; ++jg) q[d][h][jg] = *reinterpret_cast<const f32x4 *>(r + foff[jg]);
         }
@@ -156,20 +181,30 @@ __global__ __launch_bounds__((RC_NP + 1) * 64) void als_rhs_chain_kernel(
     auto write_out = [&](int d, int s) {
         float *dst = &buf[s & 1][0];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int el = h ? el1 : el0;
+        for (int h = 0; h < RC_G; ++h) {
+            const int el = el0 + 16 * h;
             const bool live = (int64_t)s * RC_E + el < n;
-            // `vals += 1.0` (implicit.rs:116) rounded to f32; explicit.rs:110: the ratings
-            const float v1 = expl ? v[d][h] : v[d][h] + 1.0f;
+            // `vals += 1.0` (implicit.rs:116) rounded to f32; explicit.rs:110: the ratings.
+            // Entries past the end multiply by +0.0: the chain then adds a zero, y + 0 = y exactly
+            // (one select per entry instead of one per product)
+            float v1 = expl ? v[d][h] : v[d][h] + 1.0f;
+            v1 = live ? v1 : 0.f;
+            // (pins this step's multiplications behind the previous step's barrier: volatile asm
+            // statements keep their order, and without it hipcc hoists the products of EVERY ring
+            // slot to the top of a round and waits vmcnt(0) there -- checked in the ISA)
+            asm volatile("" : "+v"(v1));
+            const f32x2 v2 = f32x2{v1, v1};
 #pragma unroll
             for (int jg = 0; jg < 4; ++jg) {
                 const int f0 = (jg * 4 + (lane & 3)) * 4;
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    float prod = q[d][h][jg][cc] * v1;  // rounded product (never an FMA)
-                    // entries past the end add +0.0: y + 0 = y exactly
-                    dst[rc_word(f0 + cc, el)] = live ? prod : 0.f;
-                }
+                // rounded products, two per instruction (v_pk_mul_f32; never an FMA: nothing is
+                // added here)
+                const f32x2 lo = f32x2{q[d][h][jg].x, q[d][h][jg].y} * v2;
+                const f32x2 hi = f32x2{q[d][h][jg].z, q[d][h][jg].w} * v2;
+                dst[rc_word(f0 + 0, el)] = lo.x;
+                dst[rc_word(f0 + 1, el)] = lo.y;
+                dst[rc_word(f0 + 2, el)] = hi.x;
+                dst[rc_word(f0 + 3, el)] = hi.y;
             }
         }
     };
