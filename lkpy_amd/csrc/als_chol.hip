@@ -100,7 +100,46 @@ template <int NT>
 struct Gram {
     f32x4 t[als_tiles(NT)];
     float y[NT];
+    float yc = 0.f;  // SEQY: the reference's sequential y chain, lane (sub, slot) = feature sub * NT + slot
 };
+
+// (inline asm: chained __builtin_amdgcn_permlane*_swap calls are miscompiled by hipcc 7.2 --
+// both results of the later swaps land in one register; the s_nop covers the two wait states
+// a VALU write of an operand needs before the swap reads it)
+__device__ __forceinline__ void swap32(float &a, float &b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16(float &a, float &b)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+// SEQY -- the right-hand side in the REFERENCE's order inside the Gram loop (round 5).  The
+// reference forms y as ONE sequential float32 chain per feature, product and sum rounded
+// separately (src/accel/als/implicit.rs:116-117; als_rhs.hip); the tuned loop kept four partial
+// sums per feature (one per entry slot, fused multiply-adds) and combined them at the end.  On
+// the CPU that difference alone explains most of the distance between the two arithmetics on
+// rows of a few hundred entries (tools: DESIGN.md section 2): y in the reference's order halves
+// it.  A lane holds NT features of ONE entry (its slot); after the 4 x 4 (register x slot)
+// transposition -- the two v_permlane32_swap + two v_permlane16_swap of the hybrid solver --
+// lane (sub, t) holds the products of the group's FOUR entries for feature sub * NT + t and adds
+// them in entry order: bit for bit the reference's chain.  +12 instructions per 4-entry group.
+template <int NT>
+__device__ __forceinline__ void y_chain_step(float &yc, const float (&q)[NT], const float v1)
+{
+    float p[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) p[t] = t < NT ? __fmul_rn(q[t < NT ? t : 0], v1) : 0.f;
+    swap32(p[0], p[2]);
+    swap32(p[1], p[3]);
+    swap16(p[0], p[1]);
+    swap16(p[2], p[3]);
+    yc = __fadd_rn(yc, p[0]);
+    yc = __fadd_rn(yc, p[1]);
+    yc = __fadd_rn(yc, p[2]);
+    yc = __fadd_rn(yc, p[3]);
+}
 
 template <int NT>
 __device__ __forceinline__ void load_q(const float *p, float (&q)[NT])
@@ -153,7 +192,7 @@ __device__ __forceinline__ void ring_issue(GatherRing<NT> &R, const int slot_idx
     load_q<NT>(other + (int64_t)col * KP + (lane & 15) * NT, R.q[slot_idx]);
 }
 
-template <int NT, bool MASKED>
+template <int NT, bool MASKED, bool SEQY = false>
 __device__ __forceinline__ void ring_consume(Gram<NT> &G, const GatherRing<NT> &R,
                                              const int slot_idx, const int g, const int nb,
                                              const bool expl)
@@ -179,13 +218,17 @@ __device__ __forceinline__ void ring_consume(Gram<NT> &G, const GatherRing<NT> &
             G.t[tidx(ti, tj)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], q[tj],
                                                                      G.t[tidx(ti, tj)], 0, 0, 0);
     const float v1 = expl ? v : v + 1.0f;  // `vals += 1.0` (implicit.rs:116)
+    if constexpr (SEQY) {
+        y_chain_step<NT>(G.yc, q, v1);
+    } else {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) G.y[t] = fmaf(q[t], v1, G.y[t]);
+        for (int t = 0; t < NT; ++t) G.y[t] = fmaf(q[t], v1, G.y[t]);
+    }
 }
 
 constexpr int GRAM_STAGE_WORDS = 256;  // two batches of 64 (column, value) pairs
 
-template <int NT>
+template <int NT, bool SEQY = false>
 __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__restrict__ cols,
                                                 const float *__restrict__ vals, int64_t beg,
                                                 int64_t end, const float *__restrict__ other,
@@ -225,7 +268,7 @@ __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__re
         }
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            ring_consume<NT, false>(G, R, g % RING, g, 64, expl);
+            ring_consume<NT, false, SEQY>(G, R, g % RING, g, 64, expl);
             if (g == 16 - RING - 2) {
                 // the next batch goes to LDS two groups before its first entries are needed
                 wr_nxt[0] = __builtin_bit_cast(float, nxt_col);
@@ -254,7 +297,7 @@ __device__ __forceinline__ void gram_accumulate(Gram<NT> &G, const int32_t *__re
         const int ngroups = (nb + 3) >> 2;
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            if (g < ngroups) ring_consume<NT, true>(G, R, g % RING, g, nb, expl);
+            if (g < ngroups) ring_consume<NT, true, SEQY>(G, R, g % RING, g, nb, expl);
             if (g < 16 - RING) ring_issue<NT>(R, g % RING, g + RING, rd_cur, other);
         }
     }
@@ -330,7 +373,7 @@ __device__ __forceinline__ DmaOperand dma_fetch(const float *ring, const int slo
     return o;
 }
 
-template <bool MASKED>
+template <bool MASKED, bool SEQY = false>
 __device__ __forceinline__ void dma_apply(Gram<4> &G, const DmaOperand &o, const int g,
                                           const int nb, const bool expl)
 {
@@ -351,16 +394,20 @@ __device__ __forceinline__ void dma_apply(Gram<4> &G, const DmaOperand &o, const
             G.t[tidx(ti, tj)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], q[tj],
                                                                      G.t[tidx(ti, tj)], 0, 0, 0);
     const float v1 = expl ? v : v + 1.0f;
+    if constexpr (SEQY) {
+        y_chain_step<4>(G.yc, q, v1);
+    } else {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) G.y[t] = fmaf(q[t], v1, G.y[t]);
+        for (int t = 0; t < 4; ++t) G.y[t] = fmaf(q[t], v1, G.y[t]);
+    }
 }
 
-template <bool MASKED>
+template <bool MASKED, bool SEQY = false>
 __device__ __forceinline__ void dma_consume(Gram<4> &G, const float *ring, const int slot_idx,
                                             const int g, const int nb, const float *stage_slot,
                                             const bool expl)
 {
-    dma_apply<MASKED>(G, dma_fetch(ring, slot_idx, g, stage_slot), g, nb, expl);
+    dma_apply<MASKED, SEQY>(G, dma_fetch(ring, slot_idx, g, stage_slot), g, nb, expl);
 }
 
 template <int NT>
@@ -377,6 +424,7 @@ __device__ __forceinline__ void gram_zero(Gram<NT> &G);
 // the gather ring keeps running: the wave never drains its memory queue inside a unit.  (The
 // slab stores count in vmcnt like the loads: the first waits after a boundary are a little more
 // conservative than needed, never less.)  The last block of the range is left in G.
+template <bool SEQY = false>
 __device__ __forceinline__ void gram_accumulate_dma(Gram<4> &G, const int32_t *__restrict__ cols,
                                                     const float *__restrict__ vals, int64_t beg,
                                                     int64_t end, const float *__restrict__ other,
@@ -428,7 +476,7 @@ __device__ __forceinline__ void gram_accumulate_dma(Gram<4> &G, const int32_t *_
                 wait_vm<RING - 2>();
                 nxt = dma_fetch(ring, (g + 1) % RING, g + 1, rd_cur);
             }
-            dma_apply<false>(G, cur, g, 64, expl);
+            dma_apply<false, SEQY>(G, cur, g, 64, expl);
             if (g == 16 - RING - 2) {
                 wr_nxt[0] = __builtin_bit_cast(float, nxt_col);
                 wr_nxt[64] = nxt_val;
@@ -444,7 +492,7 @@ __device__ __forceinline__ void gram_accumulate_dma(Gram<4> &G, const int32_t *_
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             wait_vm<RING - 1>();
-            dma_consume<false>(G, ring, g % RING, g, 64, rd_cur, expl);
+            dma_consume<false, SEQY>(G, ring, g % RING, g, 64, rd_cur, expl);
             if (g == 16 - RING - 2) {
                 wr_nxt[0] = __builtin_bit_cast(float, nxt_col);
                 wr_nxt[64] = nxt_val;
@@ -485,7 +533,7 @@ __device__ __forceinline__ void gram_accumulate_dma(Gram<4> &G, const int32_t *_
             if (gg < total) {
                 const int later = total - 1 - gg;  // groups issued after this one
                 wait_vm_upto(later < RING - 1 ? later : RING - 1);
-                dma_consume<true>(G, ring, g % RING, g, nb, rd_cur, expl);
+                dma_consume<true, SEQY>(G, ring, g % RING, g, nb, rd_cur, expl);
             }
             if (g == 16 - RING - 2 && more) {
                 wr_nxt[0] = __builtin_bit_cast(float, nxt_col);
@@ -916,17 +964,6 @@ __host__ __device__ constexpr int hybrid_lds_floats()
     return LPack<NT * 16>::SIZE + NT * 16 + 256;
 }
 
-// (inline asm: chained __builtin_amdgcn_permlane*_swap calls are miscompiled by hipcc 7.2 --
-// both results of the later swaps land in one register; the s_nop covers the two wait states
-// a VALU write of an operand needs before the swap reads it)
-__device__ __forceinline__ void swap32(float &a, float &b)
-{
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void swap16(float &a, float &b)
-{
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
 
 #ifndef LK_ALS_NOBRANCH
 #define LK_ALS_NOBRANCH 1
@@ -1097,7 +1134,10 @@ __host__ __device__ constexpr int solve_lds_floats()
 // order, natural feature order; als_rhs.hip:
 // the reference's summation order) instead of the accumulated one; a template parameter so that
 // the default instantiation is instruction for instruction the tuned kernel
-template <int NT, bool IS64, bool EXPL, bool CTL, bool YREF = false>
+// SEQY: rows that form their own right-hand side do it in the reference's order (y_chain_step); a
+// template parameter so that LK_ALS_RHS_ORDER=accurate keeps round 4's kernel instruction for
+// instruction
+template <int NT, bool IS64, bool EXPL, bool CTL, bool YREF = false, bool SEQY = false>
 __device__ __forceinline__ void als_solve_body(
     const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_rows,
@@ -1170,11 +1210,12 @@ __device__ __forceinline__ void als_solve_body(
         // batches and, for k = 64, holds the ring of prefetched factor rows)
 #if LK_ALS_GRAM_DMA && LK_ALS_PANEL == 2
         if constexpr (NT == 4)
-            gram_accumulate_dma(G, indices, values, beg, end, other, EXPL, lds,
-                                lds + LPack<KP>::SIZE + KP);
+            gram_accumulate_dma<SEQY && !YREF>(G, indices, values, beg, end, other, EXPL, lds,
+                                               lds + LPack<KP>::SIZE + KP);
         else
 #endif
-            gram_accumulate<NT>(G, indices, values, beg, end, other, ld_other, EXPL, lds);
+            gram_accumulate<NT, SEQY && !YREF>(G, indices, values, beg, end, other, ld_other,
+                                               EXPL, lds);
     }
     if (EXPL) {
         // explicit.rs:104-107: mtm[i][i] += reg * n, AFTER the product, real features only
@@ -1191,11 +1232,17 @@ __device__ __forceinline__ void als_solve_body(
     asm volatile("" : "+v"(G.t[0]), "+v"(G.t[als_tiles(NT) - 1]));
 #endif
     LK_PHASE_T(ph2);
-    // y: combine the 4 entry slots -> every lane has the full y for feature (t, sub)
+    if (SEQY && !YREF && first_slab < 0) {
+        // the chain of feature sub * NT + tt lives in lane (sub, slot = tt): hand it to every slot
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-        G.y[tt] += __shfl_xor(G.y[tt], 16, 64);
-        G.y[tt] += __shfl_xor(G.y[tt], 32, 64);
+        for (int tt = 0; tt < NT; ++tt) G.y[tt] = __shfl(G.yc, sub + 16 * tt, 64);
+    } else {
+        // y: combine the 4 entry slots -> every lane has the full y for feature (t, sub)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            G.y[tt] += __shfl_xor(G.y[tt], 16, 64);
+            G.y[tt] += __shfl_xor(G.y[tt], 32, 64);
+        }
     }
     if constexpr (YREF) {
         // primed (tt, sub) <-> feature sub * NT + tt; pad features carry y = 0 (their factor
@@ -1313,7 +1360,7 @@ __device__ __forceinline__ void als_solve_body(
 #endif
 }
 
-template <int NT, bool IS64, bool EXPL, bool CTL, bool YREF = false>
+template <int NT, bool IS64, bool EXPL, bool CTL, bool YREF = false, bool SEQY = false>
 __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     const typename IndPtr<IS64>::type *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ values, const int32_t *__restrict__ order, int64_t n_rows,
@@ -1324,10 +1371,10 @@ __global__ __launch_bounds__(256) LK_ALS_SOLVE_ATTR void als_solve_kernel(
     int chunk_rt = 0)
 {
     __shared__ __attribute__((aligned(16))) float lds_flat[4 * solve_lds_floats<NT>()];
-    als_solve_body<NT, IS64, EXPL, CTL, YREF>(indptr, indices, values, order, n_rows, row_slab,
-                                              other, ld_other, this_, ld_this, otor_p, slabs,
-                                              row_delta, status, k, reg, ctl, y_ref, chunk_rt,
-                                              (int64_t)blockIdx.x, lds_flat);
+    als_solve_body<NT, IS64, EXPL, CTL, YREF, SEQY>(indptr, indices, values, order, n_rows,
+                                                    row_slab, other, ld_other, this_, ld_this,
+                                                    otor_p, slabs, row_delta, status, k, reg, ctl,
+                                                    y_ref, chunk_rt, (int64_t)blockIdx.x, lds_flat);
 }
 
 // ---- chunk blocks and short-row solve blocks in ONE launch (round 4; an experiment, off by
@@ -1672,6 +1719,12 @@ static bool als_fused_enabled()
     return e && e[0] == '1';
 }
 
+static bool seqy_enabled()
+{
+    const char *e = getenv("LK_ALS_SEQY");
+    return !(e && e[0] == '0');
+}
+
 static bool reduce_on_side()
 {
     const char *e = getenv("LK_ALS_REDUCE_SIDE");
@@ -1785,17 +1838,29 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
         if (tm) LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][1], st));
         const IT *ip = static_cast<const IT *>(indptr);
 #define LK_SOLVE_LAUNCH(CTLV, YREFV, T0, NTASKS, YPTR)                                            \
-    hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, CTLV, YREFV>),                            \
+    LK_SOLVE_LAUNCH_S(CTLV, YREFV, false, T0, NTASKS, YPTR)
+#define LK_SOLVE_LAUNCH_S(CTLV, YREFV, SEQV, T0, NTASKS, YPTR)                                    \
+    hipLaunchKernelGGL((als_solve_kernel<NT, IS64, EXPL, CTLV, YREFV, SEQV>),                      \
                        dim3((unsigned)(((NTASKS) + 3) / 4)), dim3(256), 0, st, ip, indices,        \
                        values, p->d_order + (T0), (NTASKS), p->d_row_slab, other, ld_other, this_, \
                        ld_this, otor_p, slabs, row_delta, status, k, reg,                          \
                        (CTLV) ? p->ctl->dev() : TaskCtlDev{}, (YPTR), ref_chunk)
         // the rows that take their own right-hand side first (longest-first inside the launch) ...
+        // (hybrid / reference-order plans: these rows form y in the reference's order inside
+        // their Gram loop -- SEQY; LK_ALS_SEQY=0: the four-slot sums of the accurate mode)
+        const bool seqy = (p->hybrid || p->ref_order) && seqy_enabled();
         if (n_solve > n_y) {
-            if (p->ctl)
-                LK_SOLVE_LAUNCH(true, false, n_y, n_solve - n_y, nullptr);
-            else
-                LK_SOLVE_LAUNCH(false, false, n_y, n_solve - n_y, nullptr);
+            if (p->ctl) {
+                if (seqy)
+                    LK_SOLVE_LAUNCH_S(true, false, true, n_y, n_solve - n_y, nullptr);
+                else
+                    LK_SOLVE_LAUNCH(true, false, n_y, n_solve - n_y, nullptr);
+            } else {
+                if (seqy)
+                    LK_SOLVE_LAUNCH_S(false, false, true, n_y, n_solve - n_y, nullptr);
+                else
+                    LK_SOLVE_LAUNCH(false, false, n_y, n_solve - n_y, nullptr);
+            }
         }
         // ... then the rows of the chains (hybrid plans: the long rows -- one slab + one solve each)
         if (n_y > 0) {
@@ -1807,6 +1872,7 @@ static int launch_chol(const lk_als_plan *p, const void *indptr, const int32_t *
                 LK_SOLVE_LAUNCH(false, true, 0, n_y, yref);
         }
 #undef LK_SOLVE_LAUNCH
+#undef LK_SOLVE_LAUNCH_S
     }
     if (tm) {
         LK_HIP_CHECK(hipEventRecord(p->ev[p->timing_n][2], st));

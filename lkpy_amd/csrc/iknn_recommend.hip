@@ -53,13 +53,18 @@ int panel_topn(const float *panel, int64_t ld_s, int64_t rows, int64_t n_items, 
 
 namespace rec {
 
-constexpr int RW = 4096;        // targets per window = per wave
+#ifndef LK_REC_RW
+#define LK_REC_RW 4096
+#endif
+constexpr int RW = LK_REC_RW;   // targets per window = per wave (a multiple of 512)
+constexpr int TPL = RW / 64;    // targets per lane in the scan / sweep (lane-owned runs)
+static_assert(RW % 512 == 0, "window = 64 lanes x groups of 8 targets");
 constexpr int RWAVES = 4;       // waves per workgroup (each on its own window task)
 constexpr int RTHREADS = RWAVES * 64;
 constexpr int RD = 16;          // segments in flight per wave
-constexpr int RPAD = RW + RW / 64;  // cursor array: index t + (t >> 6) (conflict-free lane-owned runs)
+constexpr int RPAD = RW + 64;  // cursor array: index t + t / TPL (conflict-free lane-owned runs)
 
-__device__ __forceinline__ int cidx(int t) { return t + (t >> 6); }
+__device__ __forceinline__ int cidx(int t) { return t + t / TPL; }
 
 #ifdef LK_REC_PHASES
 // Diagnostic build only (tools/knnrec_phases.py): shader-clock cycles per phase summed over all
@@ -305,11 +310,11 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
         // ---- counts -> list offsets: lane l owns targets 64 l .. 64 l + 63 --------------------
         unsigned run = 0;
         {
-            unsigned v[64];
+            unsigned v[TPL];
 #pragma unroll
-            for (int i = 0; i < 64; ++i) v[i] = c[lane * 65 + i];
+            for (int i = 0; i < TPL; ++i) v[i] = c[lane * (TPL + 1) + i];
 #pragma unroll
-            for (int i = 0; i < 64; ++i) {
+            for (int i = 0; i < TPL; ++i) {
                 const unsigned x = v[i];
                 v[i] = run;
                 run += x;
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
             }
             const unsigned excl = incl - run;
 #pragma unroll
-            for (int i = 0; i < 64; ++i) c[lane * 65 + i] = v[i] + excl;
+            for (int i = 0; i < TPL; ++i) c[lane * (TPL + 1) + i] = v[i] + excl;
             run = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);  // hits of the window
         }
         const unsigned total = run;
@@ -355,8 +360,8 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
         // Eight targets at a time: the first two hits of each are requested together (unconditional
         // loads; most lists are that short), so a group costs one memory latency, not one per
         // non-empty target (the sweep was 47 % of the kernel when every target waited by itself).
-        unsigned beg = lane == 0 ? 0u : c[(lane - 1) * 65 + 63];
-        for (int g = 0; g < 8; ++g) {
+        unsigned beg = lane == 0 ? 0u : c[(lane - 1) * (TPL + 1) + TPL - 1];
+        for (int g = 0; g < TPL / 8; ++g) {
             unsigned en[8];
             float2 f0[8], f1[8];
             float bias[8];
@@ -365,12 +370,12 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
             // is one more serialised latency per scored target)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int it = w0 + lane * 64 + g * 8 + u;
+                const int it = w0 + lane * TPL + g * 8 + u;
                 bias[u] = item_bias ? item_bias[it < n_items ? it : 0] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                en[u] = c[lane * 65 + g * 8 + u];
+                en[u] = c[lane * (TPL + 1) + g * 8 + u];
                 const unsigned cn = en[u] - b;
                 const unsigned a0 = cn > 0 ? b : 0u, a1 = cn > 1 ? b + 1 : a0;
                 f0[u] = lists[a0];
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = g * 8 + u;
-                const int t = lane * 64 + i;
+                const int t = lane * TPL + i;
                 const unsigned end = en[u];
                 const int cnt = (int)(end - beg);
                 float score = nanf_;
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
                         if (item_bias) score = score + bias[u];  // item.py:282 (f32 add)
                     }
                 }
-                c[lane * 65 + i] = __builtin_bit_cast(unsigned, score);
+                c[lane * (TPL + 1) + i] = __builtin_bit_cast(unsigned, score);
                 beg = end;
             }
         }
@@ -571,7 +576,7 @@ __global__ void mask_refs_kernel(const int64_t *__restrict__ ref_ptr,
 constexpr int64_t REC_PANEL_ROWS = 4096;            // queries per batch at most
 constexpr int64_t REC_HITS_MIN = (int64_t)1 << 28;  // hit capacity of a batch (2 GiB) unless a
                                                     // single query needs more
-constexpr int REC_MAX_WGS = 512;
+constexpr int REC_MAX_WGS = 512 * (4096 / RW > 1 ? 4096 / RW : 1);  // persistent grid: what the LDS lets a CU hold
 
 static inline int64_t ld_items(int64_t n_items) { return (n_items + 63) / 64 * 64; }
 static inline int nwindows(int64_t n_items) { return (int)((n_items + RW - 1) / RW); }
