@@ -121,6 +121,7 @@ def _declare(lib):
         "lk_iknn_recommend": (c_int, [vp, vp, vp, c_int64, c_int64, vp, vp, vp, vp, c_int32,
                                       c_int32, c_int32, c_int, vp, c_int64, vp, vp, vp, vp]),
         "lk_knn_score_last_stats": (None, [POINTER(c_int64)]),
+        "lk_iknn_recommend_last_packed": (c_int, []),
         "lk_iknn_score_batch": (
             c_int,
             [vp, vp, vp, c_int64, c_int64, vp, vp, vp, vp, vp, c_int32, c_int32, vp, vp, vp, vp],

@@ -255,8 +255,148 @@ __device__ __forceinline__ void walk(unsigned *__restrict__ c, const int64_t *__
     }
 }
 
+// ---- the same walk with the (row x window) pieces PACKED (round 5) -----------------------------
+// With a truncated model (save_nbrs = 100) a history row leaves ~6 of its 100 entries in a
+// 4096-target window: the walk above spends a whole 64-lane load and a whole 64-lane LDS atomic on
+// each such piece -- 10 % of the lanes busy, and the call is bound by the NUMBER of pieces (one
+// memory latency per RD of them).  Here the pieces of a 64-row chunk are one stream of
+// T = sum n_j entries, taken 64 at a time: lane l of a batch holds stream position p, finds its
+// row j (the last row whose exclusive prefix is <= p: a 6-step binary search over the chunk's 64
+// prefixes in LDS) and its entry a_j + (p - prefix_j).  Counting needs no order.  Filling needs
+// the hits of a TARGET in history order: stream order is history order, batches follow each other
+// in program order, and inside a batch two lanes that hit the same target take their cursor
+// values in LANE order -- the LDS resolves same-address atomics of one instruction in ascending
+// lane order on this hardware; `lds_atomic_order_probe_kernel` checks exactly that on the device
+// before the packed walk is ever used, and without it the walk above serves (LK_REC_PACKED=0
+// forces that).  Scores stay the reference accumulator's, bit for bit (tests/
+// test_gpu_iknn_recommend.py, the bench's recommend parity).
+constexpr int RDP = 8;  // batches (of 64 entries) in flight per wave
+constexpr int LQ_CAP = 192;  // per-wave queue of "longer" targets of a window (sweep, phase B)
+
+template <bool FILL, bool EXPL>
+__device__ __forceinline__ void walk_packed(
+    unsigned *__restrict__ c, unsigned *__restrict__ dsc, const int64_t *__restrict__ s_ptr,
+    const int32_t *__restrict__ s_idx, const float *__restrict__ s_val,
+    const unsigned *__restrict__ woff, int nwin, int win, int64_t n_items,
+    const int32_t *__restrict__ ref_items, const float *__restrict__ ref_rates, int64_t rb,
+    int64_t re, float2 *__restrict__ hits, int *__restrict__ status, int lane)
+{
+    const int w0 = win * RW;
+    // descriptor table of the chunk (wave-private LDS): [0..63] exclusive prefix, [64..127] /
+    // [128..191] low / high word of (piece address - prefix), [192..255] the row's rating
+    unsigned *d_ex = dsc, *d_lo = dsc + 64, *d_hi = dsc + 128;
+    float *d_rt = reinterpret_cast<float *>(dsc + 192);
+    for (int64_t r0 = rb; r0 < re; r0 += 64) {
+        int64_t a = 0;
+        int n = 0;
+        float rate = 0.f;
+        if (r0 + lane < re) {
+            const int ri = ref_items[r0 + lane];
+            if (ri >= 0 && ri < n_items) {  // null reference rows are skipped (item_score.rs:38-49)
+                const unsigned *wo = woff + (int64_t)ri * (nwin + 1) + win;
+                const unsigned o0 = wo[0], o1 = wo[1];
+                a = s_ptr[ri] + o0;
+                n = (int)(o1 - o0);
+            }
+            if (EXPL) rate = ref_rates[r0 + lane];
+        }
+        unsigned incl = (unsigned)n;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total == 0) continue;  // (wave-uniform)
+        const unsigned excl = incl - (unsigned)n;
+        const int64_t rel = a - (int64_t)excl;
+        wave_lds_sync();  // the previous chunk's readers are done
+        d_ex[lane] = excl;
+        d_lo[lane] = (unsigned)rel;
+        d_hi[lane] = (unsigned)((unsigned long long)rel >> 32);
+        d_rt[lane] = rate;
+        wave_lds_sync();
+        for (unsigned p0 = 0; p0 < total; p0 += 64u * RDP) {
+            int t_[RDP];
+            float s_[RDP], r_[RDP];
+            bool live_[RDP];
+            // (every load unconditional: positions past the end re-read the stream's last entry)
+#pragma unroll
+            for (int d = 0; d < RDP; ++d) {
+                const unsigned p = p0 + 64u * d + lane;
+                live_[d] = p < total;
+                const unsigned pc = live_[d] ? p : total - 1;
+                // the last row j with prefix_j <= pc (rows without entries share the prefix of
+                // the next row with entries, which comes after them)
+                int lo = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1)
+                    if (d_ex[lo + step] <= pc) lo += step;
+                const int64_t e = (int64_t)(((unsigned long long)d_hi[lo] << 32) | d_lo[lo]) +
+                                  (int64_t)pc;
+                t_[d] = s_idx[e] - w0;
+                if (FILL) {
+                    s_[d] = s_val[e];
+                    r_[d] = d_rt[lo];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < RDP; ++d) {
+                if (p0 + 64u * d >= total) break;  // (wave-uniform)
+                if (live_[d]) {
+                    if (!FILL) {
+                        atomicAdd(&c[cidx(t_[d])], 1u);  // ds_add_u32, no return
+                    } else {
+                        const unsigned pos = atomicAdd(&c[cidx(t_[d])], 1u);  // lane order
+                        if (s_[d] != s_[d]) atomicCAS(status, 0, 1);  // accum.rs:146-151
+                        hits[pos] = float2{s_[d], r_[d]};
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Does the LDS hand out the old values of same-address `ds_add_rtn_u32`s of ONE instruction in
+// ascending lane order?  (What walk_packed's fill pass relies on.)  Several conflict patterns;
+// *ok = 0 as soon as a lane's old value differs from the number of lower lanes with its address.
+__global__ void lds_atomic_order_probe_kernel(int *__restrict__ ok)
+{
+    __shared__ unsigned cell[64];
+    const int lane = threadIdx.x;
+    for (int pat = 0; pat < 12; ++pat) {
+        cell[lane] = 0u;
+        __syncthreads();
+        int addr;
+        switch (pat) {
+            case 0: addr = 0; break;
+            case 1: addr = lane & 1; break;
+            case 2: addr = lane % 5; break;
+            case 3: addr = (lane * 7) % 13; break;
+            case 4: addr = lane >> 4; break;
+            case 5: addr = (lane >> 1) & 7; break;
+            case 6: addr = (lane * lane) % 11; break;
+            case 7: addr = lane & 31; break;       // the two halves of the wave collide
+            case 8: addr = 63 - (lane & 7); break;
+            case 9: addr = (lane ^ 21) % 3; break;
+            case 10: addr = lane < 40 ? 3 : lane;  break;
+            default: addr = (lane * 37 + 11) % 17; break;
+        }
+        const unsigned old = atomicAdd(&cell[addr], 1u);
+        __syncthreads();
+        // number of lower lanes with the same address
+        unsigned want = 0;
+        for (int l = 0; l < 64; ++l) {
+            const int al = __shfl(addr, l, 64);
+            if (l < lane && al == addr) ++want;
+        }
+        if (old != want) atomicExch(ok, 0);
+        __syncthreads();
+    }
+}
+
 // Task = (query of the batch, window); one wave per task, taken from an atomic counter.
-template <bool EXPL>
+template <bool EXPL, bool PACKED = false>
 __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
     const int64_t *__restrict__ s_ptr, const int32_t *__restrict__ s_idx,
     const float *__restrict__ s_val, int64_t n_items, int nwin, const unsigned *__restrict__ woff,
@@ -269,12 +409,17 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
     int ovf_cap, int *__restrict__ ovf_count)
 {
     __shared__ unsigned cur[RWAVES][RPAD];
+    __shared__ unsigned dsc_all[PACKED ? RWAVES : 1][PACKED ? 256 : 1];
+    // targets with 3 .. max_nbrs hits, left to a second phase of the sweep (see there): [0] the
+    // count, then (beg, cnt << 12 | target) pairs
+    __shared__ unsigned lq_all[RWAVES][2 + 2 * LQ_CAP];
 #ifdef LK_REC_PHASES
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned *c = cur[wave];
+    unsigned *lq = lq_all[wave];
     const int64_t n_tasks = nq * nwin;
     float *hw = heap_scratch +
                 ((size_t)(blockIdx.x * RWAVES + wave) * 64 + lane) * (size_t)(max_nbrs + 1) * 2;
@@ -300,11 +445,16 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
         }
         LK_RP_T(p1);
         for (int i = lane; i < RPAD; i += 64) c[i] = 0u;
+        if (lane == 0) lq[0] = 0u;
         LK_RP_T(p2);
 
         // ---- pass 1: hits per target ----------------------------------------------------
-        walk<false, EXPL>(c, s_ptr, s_idx, s_val, woff, nwin, win, n_items, ref_items, ref_rates,
-                          rb, re, nullptr, status, lane);
+        if constexpr (PACKED)
+            walk_packed<false, EXPL>(c, dsc_all[wave], s_ptr, s_idx, s_val, woff, nwin, win,
+                                     n_items, ref_items, ref_rates, rb, re, nullptr, status, lane);
+        else
+            walk<false, EXPL>(c, s_ptr, s_idx, s_val, woff, nwin, win, n_items, ref_items,
+                              ref_rates, rb, re, nullptr, status, lane);
         LK_RP_T(p3);
 
         // ---- counts -> list offsets: lane l owns targets 64 l .. 64 l + 63 --------------------
@@ -347,8 +497,12 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
         LK_RP_T(p4);
 
         // ---- pass 2: the hits, each at its target's cursor (history order by construction) ----
-        walk<true, EXPL>(c, s_ptr, s_idx, s_val, woff, nwin, win, n_items, ref_items, ref_rates,
-                         rb, re, lists, status, lane);
+        if constexpr (PACKED)
+            walk_packed<true, EXPL>(c, dsc_all[wave], s_ptr, s_idx, s_val, woff, nwin, win,
+                                    n_items, ref_items, ref_rates, rb, re, lists, status, lane);
+        else
+            walk<true, EXPL>(c, s_ptr, s_idx, s_val, woff, nwin, win, n_items, ref_items,
+                             ref_rates, rb, re, lists, status, lane);
         LK_RP_T(p5);
         // the lists were written by OTHER lanes of this wave: complete the stores before they are
         // read.  WORKGROUP scope -- writer and reader share the CU's L1; an agent-scope release
@@ -360,33 +514,46 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
         // Eight targets at a time: the first two hits of each are requested together (unconditional
         // loads; most lists are that short), so a group costs one memory latency, not one per
         // non-empty target (the sweep was 47 % of the kernel when every target waited by itself).
-        unsigned beg = lane == 0 ? 0u : c[(lane - 1) * (TPL + 1) + TPL - 1];
+        // (round 5) Targets are INTERLEAVED over the lanes here -- lane l takes targets l, l + 64,
+        // ... -- not the lane-owned runs of the scan: with runs every lane of a load touched a cache
+        // line of its own (item means 256 bytes apart, lists far apart), 24 such loads per group,
+        // and the CU's address path (one line per cycle, shared by its eight waves) was what the
+        // sweep ran at: 88 k cycles per task.  Interleaved, a load's 64 addresses are neighbours
+        // (consecutive targets' lists follow each other in the hit region).  A target's list
+        // starts where its predecessor's ends: the neighbour lane's `end` (lane 0: the carry).
+        unsigned carry = 0u;
         for (int g = 0; g < TPL / 8; ++g) {
-            unsigned en[8];
+            unsigned en[8], bg[8];
             float2 f0[8], f1[8];
             float bias[8];
-            unsigned b = beg;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) en[u] = c[cidx(64 * (8 * g + u) + lane)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned prev = __shfl_up(en[u], 1, 64);
+                const unsigned first =
+                    u == 0 ? carry : (unsigned)__builtin_amdgcn_readlane((int)en[u > 0 ? u - 1 : 0], 63);
+                bg[u] = lane == 0 ? first : prev;
+            }
+            carry = (unsigned)__builtin_amdgcn_readlane((int)en[7], 63);
             // (the item means of the group's targets as well: a load inside the per-target branch
             // is one more serialised latency per scored target)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int it = w0 + lane * TPL + g * 8 + u;
+                const int it = w0 + 64 * (8 * g + u) + lane;
                 bias[u] = item_bias ? item_bias[it < n_items ? it : 0] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                en[u] = c[lane * (TPL + 1) + g * 8 + u];
-                const unsigned cn = en[u] - b;
-                const unsigned a0 = cn > 0 ? b : 0u, a1 = cn > 1 ? b + 1 : a0;
+                const unsigned cn = en[u] - bg[u];
+                const unsigned a0 = cn > 0 ? bg[u] : 0u, a1 = cn > 1 ? bg[u] + 1 : a0;
                 f0[u] = lists[a0];
                 f1[u] = lists[a1];
-                b = en[u];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = g * 8 + u;
-                const int t = lane * TPL + i;
-                const unsigned end = en[u];
+                const int t = 64 * (8 * g + u) + lane;
+                const unsigned beg = bg[u], end = en[u];
                 const int cnt = (int)(end - beg);
                 float score = nanf_;
                 const int kept = cnt < max_nbrs ? cnt : max_nbrs;
@@ -402,8 +569,23 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
                             queued = true;
                         }
                     }
-                    if (queued) {
-                        // (the panel cell is written by the replay kernel; NaN until then)
+                    bool later = false;
+                    if (!queued && cnt > 2 && cnt <= max_nbrs && cnt < (1 << 20)) {
+                        // 3 .. max_nbrs hits: one more memory latency per four hits if summed
+                        // here, in a loop the whole wave waits in (lanes diverge on the list
+                        // length: the sweep was 56 % of the kernel, nearly all of it these
+                        // waits).  Left to phase B below, where every lane streams a list of its
+                        // own with eight loads in flight.
+                        const unsigned slot = atomicAdd(&lq[0], 1u);
+                        if (slot < (unsigned)LQ_CAP) {
+                            lq[2 + 2 * slot] = beg;
+                            lq[3 + 2 * slot] = ((unsigned)cnt << 12) | (unsigned)t;
+                            later = true;
+                        }
+                    }
+                    if (queued || later) {
+                        // (the panel cell is written by the replay kernel / the cursor cell by
+                        // phase B; NaN until then)
                     } else if (cnt <= max_nbrs) {  // Partial(vec): sums in insertion order
                         tw += f0[u].x;
                         if (EXPL) ws += f0[u].x * f0[u].y;
@@ -450,15 +632,45 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
                             if (EXPL) ws += hw[x] * hv[x];
                         }
                     }
-                    if (!queued) {
+                    if (!queued && !later) {
                         score = EXPL ? ws / tw : tw;
                         if (item_bias) score = score + bias[u];  // item.py:282 (f32 add)
                     }
                 }
-                c[lane * (TPL + 1) + i] = __builtin_bit_cast(unsigned, score);
-                beg = end;
+                c[cidx(t)] = __builtin_bit_cast(unsigned, score);
             }
         }
+        // ---- phase B: the queued targets, a lane per list, eight hits in flight ----------------
+        wave_lds_sync();
+        {
+            const unsigned nq_ = lq[0] < (unsigned)LQ_CAP ? lq[0] : (unsigned)LQ_CAP;
+            for (unsigned qi = lane; qi < ((nq_ + 63u) & ~63u); qi += 64) {
+                const bool on = qi < nq_;
+                const unsigned b0 = on ? lq[2 + 2 * qi] : 0u;
+                const unsigned w = on ? lq[3 + 2 * qi] : 0u;
+                const int t = (int)(w & 4095u), cnt = (int)(w >> 12);
+                const float2 *l = lists + b0;
+                float tw = 0.f, ws = 0.f;
+                for (int x = 0; x < cnt; x += 8) {  // (lanes diverge on cnt: ONE loop for all lists)
+                    float2 h[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) h[u] = l[x + u < cnt ? x + u : cnt - 1];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (x + u < cnt) {  // insertion order (accum.rs: the vector's sums)
+                            tw += h[u].x;
+                            if (EXPL) ws += h[u].x * h[u].y;
+                        }
+                    }
+                }
+                if (on) {
+                    float score = EXPL ? ws / tw : tw;
+                    if (item_bias) score = score + item_bias[w0 + t];  // item.py:282 (f32 add)
+                    c[cidx(t)] = __builtin_bit_cast(unsigned, score);
+                }
+            }
+        }
+        wave_lds_sync();
         LK_RP_T(p6);
         // ---- the window's segment of the panel row, coalesced -----------------------------------
         for (int i = lane; i < wn; i += 64) prow[i] = __builtin_bit_cast(float, c[cidx(i)]);
@@ -636,6 +848,11 @@ extern "C" int lk_rec_phase_set(unsigned long long *d_buf)
 }
 #endif
 
+static int g_rec_last_packed = -1;
+// 1 / 0: the last lk_iknn_recommend call of this process took the packed / the piece-wise walk
+// (-1: none yet) -- test hook, like lk_knn_score_last_stats
+extern "C" int lk_iknn_recommend_last_packed(void) { return g_rec_last_packed; }
+
 extern "C" size_t lk_iknn_recommend_workspace_bytes(int64_t n_items, int64_t n_queries,
                                                     int64_t max_query_hits, int32_t max_nbrs,
                                                     int32_t n)
@@ -705,6 +922,29 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
         cuts.push_back(n_queries);
     }
     LK_HIP_CHECK(hipMemsetAsync(status, 0, 256, st));
+    // the packed walk needs same-address LDS atomics of one instruction served in lane order:
+    // probed once per device (status[3] is free until the first batch); LK_REC_PACKED=0: never
+    bool packed = false;
+    {
+        static PerDeviceOnce probed, lane_order;
+        const char *e = getenv("LK_REC_PACKED");
+        if (!(e && e[0] == '0')) {
+            bool &done = probed.flag();
+            bool &good = lane_order.flag();
+            if (!done) {
+                int one = 1, got = 0;
+                LK_HIP_CHECK(hipMemcpyAsync(status + 3, &one, sizeof(int), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(lds_atomic_order_probe_kernel, dim3(1), dim3(64), 0, st, status + 3);
+                LK_HIP_CHECK(hipMemcpyAsync(&got, status + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+                LK_HIP_CHECK(hipStreamSynchronize(st));
+                good = got == 1;
+                done = true;
+                LK_HIP_CHECK(hipMemsetAsync(status + 3, 0, sizeof(int), st));
+            }
+            packed = good;
+        }
+    }
+    g_rec_last_packed = packed ? 1 : 0;
     LK_HIP_CHECK(hipMemcpyAsync(q_base, base.data(), (size_t)n_queries * sizeof(int64_t),
                                 hipMemcpyHostToDevice, st));
     LK_HIP_CHECK(hipStreamSynchronize(st));  // `base` is host memory that dies with this call
@@ -724,6 +964,13 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
             if (wgs > REC_MAX_WGS) wgs = REC_MAX_WGS;
 #define LK_REC_LAUNCH(EXPLV)                                                                      \
     do {                                                                                          \
+    if (packed)                                                                                   \
+    hipLaunchKernelGGL((iknn_score_all_kernel<EXPLV, true>), dim3((unsigned)wgs), dim3(RTHREADS),  \
+                       0, st, d_sim_indptr, d_sim_indices, d_sim_values, n_items, nwin, woff, q0,  \
+                       nq, d_ref_ptr, d_ref_items, d_ref_rates, d_item_bias, max_nbrs, min_nbrs,   \
+                       hits, q_base + q0, q_cursor + q0, panel, ld, heap, status + 1, status,      \
+                       lds_replay ? ovf : nullptr, REC_OVF_CAP, status + 2);                       \
+    else                                                                                          \
     hipLaunchKernelGGL((iknn_score_all_kernel<EXPLV>), dim3((unsigned)wgs), dim3(RTHREADS), 0, st, \
                        d_sim_indptr, d_sim_indices, d_sim_values, n_items, nwin, woff, q0, nq,    \
                        d_ref_ptr, d_ref_items, d_ref_rates, d_item_bias, max_nbrs, min_nbrs, hits, \

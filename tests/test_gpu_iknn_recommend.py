@@ -68,10 +68,19 @@ def _check(gi, gs, wi, ws, rows, ptr, idx):
     return ties
 
 
+@pytest.mark.parametrize("walk", ["packed", "pieces"])
 @pytest.mark.parametrize("explicit", [True, False])
 @pytest.mark.parametrize("save_nbrs,max_nbrs,n", [(50, 20, 10), (None, 5, 100), (None, 64, 30)])
-def test_recommend_matches_the_reference_pipeline(gpu, oracle, explicit, save_nbrs, max_nbrs, n):
+def test_recommend_matches_the_reference_pipeline(gpu, oracle, monkeypatch, walk, explicit,
+                                                  save_nbrs, max_nbrs, n):
+    """Both walks of the similarity rows (round 5: the (row x window) pieces PACKED 64 entries to
+    the instruction -- relies on same-address LDS atomics of one instruction being served in lane
+    order, probed on the device -- and the piece-by-piece walk it falls back to): the same bits."""
     from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    if walk == "pieces":
+        monkeypatch.setenv("LK_REC_PACKED", "0")
 
     rng = np.random.default_rng(7)
     n_users, n_items = 600, 9001  # three windows of 4096, the last one partial
@@ -90,6 +99,8 @@ def test_recommend_matches_the_reference_pipeline(gpu, oracle, explicit, save_nb
                               _to(val, gpu) if explicit else None,
                               _to(means, gpu) if explicit else None, max_nbrs, 2, n, hits)
     gi, gs = gi.cpu().numpy(), gs.cpu().numpy()
+    # the probe of the LDS atomic order must pass on an MI355X: the packed walk is the product path
+    assert _native.load().lk_iknn_recommend_last_packed() == (1 if walk == "packed" else 0)
     wi, ws, rows = oracle.iknn_recommend_batch(sims, ptr, idx, val if explicit else None,
                                                means if explicit else None, max_nbrs, 2, n)
     ties = _check(gi, gs, wi, ws, rows, ptr, idx)
