@@ -43,6 +43,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+NO_ORDER_AB = False  # --no-order-ab
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix)
 HBM_PEAK_GBS = 8000.0  # same guide: HBM3E peak 8 TB/s
 LONG_ROW = int(os.environ.get("LK_BENCH_LONG_ROW", 2048))  # LK_ALS_LONG_ROW (csrc/als_plan.h)
@@ -752,7 +753,7 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
             "r*_cfg5_counters.csv", "als_blk_solve_kernel16")
     if coll:
         out["collectives"] = coll
-    if world == 1:
+    if world == 1 and not NO_ORDER_AB:
         out["summation_order"] = summation_order_info(
             eng, lambda mode: ImplicitALSEngine(csr, k, reg, reg, None, None,
                                                 HipBackend(k, dev, _native.SOLVER_AUTO, mode)),
@@ -1114,7 +1115,7 @@ def als_timed(ui, P0, Q0, k, reg, steps, warmup, dev, world, scale):
         if roof["traffic"] is None and fused:  # (captures made before the fused launch)
             roof["traffic"], roof["traffic_source"] = pmc_traffic(
                 "r*_als_*_counters.csv", "als_solve_kernel")
-    if world == 1:
+    if world == 1 and not NO_ORDER_AB:
         eng.summation_order = summation_order_info(
             eng, lambda mode: ImplicitALSEngine(ui, k, reg, reg, P0, Q0,
                                                 HipBackend(k, dev, _native.SOLVER_AUTO, mode)),
@@ -1360,6 +1361,9 @@ def main():
     ap.add_argument("--no-cg", action="store_true", help="skip the CG-solver comparison leg")
     ap.add_argument("--no-k128", action="store_true", help="skip the k = 128 leg (configs[3])")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg5 leg (configs[4])")
+    ap.add_argument("--no-order-ab", action="store_true",
+                    help="skip timing LK_ALS_RHS_ORDER=accurate beside the default summation "
+                         "order (profiling runs: keeps the kernel statistics to one mode)")
     ap.add_argument("--k128-steps", type=int, default=10, help="timed epochs of the k128 leg")
     ap.add_argument("--sharded-legs", action=argparse.BooleanOptionalAction, default=True,
                     help="N > 1: also time the sharded item-kNN build and dense top-N (on by "
@@ -1375,6 +1379,8 @@ def main():
     ap.add_argument("--topk-users", type=int, default=0,
                     help="cfg5: users of the dense top-K leg (default: 1/8 of the users)")
     args = ap.parse_args()
+    global NO_ORDER_AB
+    NO_ORDER_AB = bool(args.no_order_ab)
     maybe_self_launch(args)
     if args.steps is None:
         args.steps = 3 if args.config == "cfg5" else 50

@@ -465,7 +465,8 @@ template <bool EXPL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void als_blk_chunk_dma_kernel(
     const int32_t *__restrict__ indices, const float *__restrict__ values,
     const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_len,
-    const float *__restrict__ other, float *__restrict__ slabs)
+    const float *__restrict__ other, float *__restrict__ slabs,
+    const int32_t *__restrict__ chunk_slab, int block_len)
 {
     constexpr int NT = 16;
     using C = Cfg<NT>;
@@ -487,6 +488,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     const int len = chunk_len[c];  // >= 1
     const int64_t end = beg + len, last = end - 1;
     const int n_stage = (len + 15) >> 4;
+    // Reference-order WORK UNITS (als_plan.h, round 5): a unit of several 256-entry blocks keeps
+    // the row ring running across its blocks and stores one slab per block -- the accumulators
+    // are written out and start again from zero at every block boundary that is followed by more
+    // entries (matrixmultiply's KC = 256 blocks, each an fma chain of its own).  The slab stores
+    // count in vmcnt like the DMAs: the explicit waits below are then a little more conservative
+    // than needed (never less).  block_len == 0: one slab for the whole range.
+    float *slab = slabs + (size_t)(chunk_slab ? chunk_slab[c] : c) * C::SLAB;
+    const int flush_stages = block_len > 0 ? block_len >> 4 : 0;  // stages per block (16)
     const unsigned ring_lds = (unsigned)(uintptr_t) reinterpret_cast<void *>(ring);
     const unsigned meta_lds = (unsigned)(uintptr_t) reinterpret_cast<void *>(meta);
 
@@ -578,6 +587,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                     ops_consume<NT, EXPL, PH>(acc, yacc, cur, (4 * g + e4) < nb);
                     cur = nxt;
                 }
+                if (j == 3 && flush_stages > 0 && ((k + 1) % flush_stages) == 0 &&
+                    k + 1 < n_stage) {  // (workgroup-uniform) a block is complete, more follow
+                    store_chunk_slab<NT>(acc, yacc, slab, wave, lane);
+                    slab += C::SLAB;
+#pragma unroll
+                    for (int t = 0; t < C::T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < C::NL; ++i) yacc[i] = 0.f;
+                }
             }
         });
     }
@@ -587,7 +605,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     else
         stages(std::integral_constant<bool, false>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a trailing meta request still targets our LDS)
-    store_chunk_slab<NT>(acc, yacc, slabs + (size_t)c * C::SLAB, wave, lane);
+    store_chunk_slab<NT>(acc, yacc, slab, wave, lane);
 }
 
 // LK_BLK_CHUNK_DMA=0: the register-ring chunk kernel at k = 256 too (A/B timing)
@@ -1507,7 +1525,8 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
                 }
                 hipLaunchKernelGGL((als_blk_chunk_dma_kernel<EXPL>), dim3((unsigned)p->n_chunks),
                                    dim3(256), CHUNK_DMA_LDS_BYTES, st, indices, values,
-                                   p->d_chunk_beg, p->d_chunk_len, other, slabs);
+                                   p->d_chunk_beg, p->d_chunk_len, other, slabs, p->d_chunk_slab,
+                                   p->unit > p->chunk ? (int)p->chunk : 0);
             }
         } else {
             hipLaunchKernelGGL((als_blk_chunk_kernel<NT, EXPL>), dim3((unsigned)p->n_chunks),

@@ -2119,7 +2119,12 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
     // work units (als_plan.h): hybrid plans at padded k = 64 keep 1024-entry units, one slab per
     // 256-entry block (LK_ALS_REF_UNIT: entries per unit, a multiple of 256; 256 = a unit per block)
     p->unit = p->chunk;
-    if (p->hybrid && KP == 64) {
+    // (padded k = 256: the LDS-staged chunk kernel of als_blk.hip takes units as well; with
+    // LK_BLK_CHUNK_DMA=0 -- the register-ring kernel, which has no block boundaries -- a unit is
+    // a chunk)
+    const char *dma_off = getenv("LK_BLK_CHUNK_DMA");
+    const bool units256 = KP == 256 && !(dma_off && dma_off[0] == '0');
+    if (p->hybrid && (KP == 64 || units256)) {
         const char *e = getenv("LK_ALS_REF_UNIT");
         int u = e ? atoi(e) : LK_ALS_CHUNK;
         if (u < p->chunk) u = p->chunk;

@@ -10,7 +10,7 @@ TAG=${1:-r1}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD=${PROF_CMD:-"python bench.py --steps 5 --warmup 1 --no-cpu --no-knn --no-topk --no-fit --no-k128 --no-cfg5 --no-cg"}
+CMD=${PROF_CMD:-"python bench.py --steps 5 --warmup 1 --no-cpu --no-knn --no-topk --no-fit --no-k128 --no-cfg5 --no-cg --no-order-ab"}
 PASSES=${PROF_PASSES:-all}
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o als -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU \

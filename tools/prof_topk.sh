@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_topk_$TAG
 mkdir -p $OUT
 # default: the bench workload itself (trained factors, the users' own items excluded)
-CMD=${PROF_CMD:-"python bench.py --steps 3 --warmup 1 --no-cpu --no-knn --no-fit --no-k128 --no-cfg5 --no-cg"}
+CMD=${PROF_CMD:-"python bench.py --steps 3 --warmup 1 --no-cpu --no-knn --no-fit --no-k128 --no-cfg5 --no-cg --no-order-ab"}
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o topk -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
   --kernel-trace --output-format csv -d $OUT/pmc1 -o topk -- $CMD > $OUT/pmc1.log 2>&1
