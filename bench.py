@@ -157,14 +157,21 @@ def pmc_traffic(pattern: str, kernel_substr: str):
                    key=lambda f: f.name)
     if not files:
         return None, None
-    fetch, write = [], []
+    rows = []
     with open(files[-1]) as f:
         for row in csv.DictReader(f):
-            if kernel_substr in row["Kernel_Name"]:
-                if row["Counter_Name"] == "FETCH_SIZE":
-                    fetch.append(float(row["mean"]))
-                elif row["Counter_Name"] == "WRITE_SIZE":
-                    write.append(float(row["mean"]))
+            if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] in ("FETCH_SIZE",
+                                                                              "WRITE_SIZE"):
+                rows.append((float(row.get("Grid_Size") or 0), row["Counter_Name"],
+                             float(row["mean"])))
+    if not rows:
+        return None, None
+    # the launches of the kernel proper: since round 5 a half-epoch also has a SMALL launch of the
+    # same kernel for the long rows (a few hundred workgroups: their right-hand sides come from
+    # the chain kernel) -- averaging it in would halve the figure
+    gmax = max(r[0] for r in rows)
+    fetch = [m for g, c, m in rows if c == "FETCH_SIZE" and g >= 0.05 * gmax]
+    write = [m for g, c, m in rows if c == "WRITE_SIZE" and g >= 0.05 * gmax]
     if not fetch:
         return None, None
     w = sum(write) / len(write) if write else 0.0
