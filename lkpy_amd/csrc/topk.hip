@@ -55,21 +55,26 @@ __device__ unsigned long long *lk_topk_phase_buf;
 #define LK_TP_ADD(i, a, b)
 #endif
 
-// FILTER = false: write the score tile to `scores`.  FILTER = true (fused selection, stage 2):
-// nothing is written but the entries that reach the row's threshold tau[u] (a lower bound of
-// its n-th largest candidate score, from stage 1): they are appended to the row's candidate
-// list as (key << 32 | ~index) -- the B x I score matrix never exists in memory.
+// MODE 0 (panel): write the score tile to `scores`.  MODE 1 (fused selection, stage 2): nothing
+// is written but the entries that reach the row's threshold tau[u] (a lower bound of its n-th
+// largest candidate score, from stage 1): they are appended to the row's candidate list as
+// (key << 32 | ~index) -- the B x I score matrix never exists in memory.  MODE 2 (stage 1, round
+// 5): the workgroup walks every tile of the SAMPLE items and keeps a running maximum per
+// accumulator cell -- 256 class maxima per row (class = sample column mod 256), written once to
+// scores[u * ld_s + class] at the end: 1 KiB per row instead of the row's whole sample panel.
 // UT: 32-user sub-tiles per wave.  Workgroup tile = (64 UT) users x 256 items, wave tile =
 // (32 UT) users x 128 items.  UT = 2 (the fused path: no C tile to write, so the accumulators
 // may fill the registers) halves the operand bytes per flop -- at k = 64 the 64 x 256 tile is
 // bound by L2 -> LDS traffic, not by the matrix cores.
-template <bool FILTER, int UT>
+template <int MODE, int UT>
 __device__ __forceinline__ void score_panel_body(
     const float *__restrict__ users, int ld_u, int64_t n_users, const float *__restrict__ items,
     int ld_i, int64_t n_items, int kp, float *__restrict__ scores, int64_t ld_s,
     const float *__restrict__ tau, unsigned long long *__restrict__ cand,
     unsigned *__restrict__ cand_cnt, int cand_cap, float *lds_all)
 {
+    constexpr bool FILTER = MODE == 1;  // candidates appended in the epilogue
+    constexpr bool WALK = MODE != 0;    // the workgroup owns its rows and walks the item tiles
     constexpr int UB = SC_UB * UT;
     float *lu = lds_all;
     float *li = lds_all + UB * SC_LD;
@@ -78,7 +83,7 @@ __device__ __forceinline__ void score_panel_body(
     // panel writer: grid (item tiles, user tiles), one tile per workgroup.  Fused filter: grid
     // (user tiles): the workgroup OWNS its rows and walks every item tile, so the per-row
     // candidate counters live in LDS and no global atomic is ever issued.
-    const int64_t u0 = (int64_t)(FILTER ? blockIdx.x : blockIdx.y) * UB;
+    const int64_t u0 = (int64_t)(WALK ? blockIdx.x : blockIdx.y) * UB;
     const int wu = (wave & 1) * 32 * UT;  // wave's user offset inside the tile
     const int wi = (wave >> 1) * 128;     // wave's item offset inside the tile
     const int64_t n_itiles = (n_items + SC_IB - 1) / SC_IB;
@@ -101,9 +106,19 @@ __device__ __forceinline__ void score_panel_body(
     constexpr int IV = SC_IB * (SC_KC / 4) / 256;  // float4 per thread, item panel
     f32x4 ru[UV], ri[IV];
 
-    const int64_t it_begin = FILTER ? 0 : (int64_t)blockIdx.x;
-    const int64_t it_end = FILTER ? n_itiles : it_begin + 1;
+    const int64_t it_begin = WALK ? 0 : (int64_t)blockIdx.x;
+    const int64_t it_end = WALK ? n_itiles : it_begin + 1;
     int64_t itile = it_begin;
+    // MODE 2: running class maxima, NaN = nothing yet (v_max_f32 returns the other operand)
+    f32x16 mx[UT][4];
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx[ut][t][r] = __builtin_nanf("");
+    }
     do {
         const int64_t i0 = itile * SC_IB;
         f32x16 acc[UT][4];
@@ -117,7 +132,7 @@ __device__ __forceinline__ void score_panel_body(
         // Software pipeline: the next 32-feature slab of both panels is fetched into registers
         // (coalesced float4 reads) while the MFMAs of the current slab run out of LDS.
         auto fetch = [&](int64_t t0, int kc) {  // t0: first item of the tile
-            if constexpr (FILTER) {
+            if constexpr (WALK) {
                 // the fused path runs with kp % SC_KC == 0 (use_fused): no feature predicate; rows
                 // past the end are clamped to the last one (their scores are never taken: tau =
                 // +inf for such users, the `in` test for such items) -- unpredicated loads, one
@@ -176,7 +191,7 @@ __device__ __forceinline__ void score_panel_body(
         LK_TP_T(tp0);
         // filter: the first slab of every tile but the first was requested in the previous
         // tile's epilogue
-        if (!FILTER || itile == it_begin) fetch(i0, 0);
+        if (!WALK || itile == it_begin) fetch(i0, 0);
         for (int kc = 0; kc < kp; kc += SC_KC) {
             LK_TP_T(tp1);
             stage();
@@ -210,7 +225,21 @@ __device__ __forceinline__ void score_panel_body(
             LK_TP_ADD(2, tp3, tp4);
         }
         // C/D: col (item) = lane&31, row (user) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-        if constexpr (!FILTER) {
+        if constexpr (MODE == 2) {
+            // the next tile's first slab, in flight behind the maxima
+            if (itile + 1 < it_end) fetch(i0 + SC_IB, 0);
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    // columns past the end (clamped operand rows) never count
+                    const bool in = i0 + wi + t * 32 + (lane & 31) < n_items;
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg)
+                        mx[ut][t][rg] = __builtin_fmaxf(
+                            mx[ut][t][rg], in ? acc[ut][t][rg] : __builtin_nanf(""));
+                }
+        } else if constexpr (MODE == 0) {
 #pragma unroll
             for (int ut = 0; ut < UT; ++ut)
 #pragma unroll
@@ -319,9 +348,23 @@ __device__ __forceinline__ void score_panel_body(
             LK_TP_ADD(5, tp7, tp8);
             LK_TP_ADD(6, 0, 1);
         }
-        if constexpr (!FILTER) break;  // one tile per workgroup: no loop at all for the compiler
+        if constexpr (!WALK) break;  // one tile per workgroup: no loop at all for the compiler
         ++itile;
     } while (itile < it_end);
+    if constexpr (MODE == 2) {
+        // class = column of the 256-wide tile; C/D layout as above
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int cls = wi + t * 32 + (lane & 31);
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int64_t u = u0 + wu + ut * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+                    if (u < n_users) scores[u * ld_s + cls] = mx[ut][t][rg];
+                }
+            }
+    }
     if constexpr (FILTER) {
         __syncthreads();
         for (int r = tid; r < UB; r += 256)
@@ -346,8 +389,18 @@ __device__ __forceinline__ void score_panel_body(
 __global__ __launch_bounds__(256) void score_panel_kernel(LK_SCORE_ARGS)
 {
     __shared__ __attribute__((aligned(16))) float lds_all[(SC_UB + SC_IB) * SC_LD];
-    score_panel_body<false, 1>(users, ld_u, n_users, items, ld_i, n_items, kp, scores, ld_s, tau,
+    score_panel_body<0, 1>(users, ld_u, n_users, items, ld_i, n_items, kp, scores, ld_s, tau,
                                cand, cand_cnt, cand_cap, lds_all);
+}
+
+// stage 1 of the fused selection (round 5): a workgroup owns 64 rows, walks the sample tiles and
+// writes 256 class maxima per row -- `scores` is the [rows x 256] class table, ld_s = 256
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void sample_cmax_kernel(
+    LK_SCORE_ARGS)
+{
+    __shared__ __attribute__((aligned(16))) float lds_all[(SC_UB + SC_IB) * SC_LD];
+    score_panel_body<2, 1>(users, ld_u, n_users, items, ld_i, n_items, kp, scores, ld_s, tau, cand,
+                           cand_cnt, cand_cap, lds_all);
 }
 
 // the fused filter: 128 x 256 tile, 128 accumulator registers, held to 2 workgroups per CU
@@ -355,7 +408,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     LK_SCORE_ARGS)
 {
     __shared__ __attribute__((aligned(16))) float lds_all[(2 * SC_UB + SC_IB) * SC_LD + 4 * SC_UB];
-    score_panel_body<true, 2>(users, ld_u, n_users, items, ld_i, n_items, kp, scores, ld_s, tau,
+    score_panel_body<1, 2>(users, ld_u, n_users, items, ld_i, n_items, kp, scores, ld_s, tau,
                               cand, cand_cnt, cand_cap, lds_all);
 }
 #undef LK_SCORE_ARGS
@@ -902,6 +955,384 @@ __global__ __launch_bounds__(256) void cand_select_kernel(
     if (tid == 0 && ((unsigned)(n - 1) >= p2 || key[n - 1] == 0ull)) flag();
 }
 
+#ifdef LK_WSEL_PHASES
+// Diagnostic build only (tools/wsel_phases.py): s_memtime ticks of cand_select_wave_kernel summed
+// over all rows, 10 words: [0] row scalars, [1] candidate loads, [2] hash clear + insert,
+// [3] exclusion walk, [4] look-up, [5] count + threshold search, [6] compaction, [7] sort,
+// [8] output, [9] rows.  Every stamp waits for the memory operations before it.
+__device__ unsigned long long *lk_wsel_phase_buf;
+#define LK_WP_T(var)                                          \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define LK_WP_ADD(i, a, b) wp[i] += (b) - (a)
+#else
+#define LK_WP_T(var)
+#define LK_WP_ADD(i, a, b)
+#endif
+// Stage 3, first tier, a WAVE per row (round 5; `cand_select_kernel` above stays as the second
+// tier and as LK_TOPK_SELECT=sort).  The row's candidates never sort as a whole: they sit in
+// registers (16 keys per lane: up to 1024), the excluded ones are struck out through a per-wave
+// LDS hash of the candidates' item numbers (a slot holds item + 1; an exclusion that finds its
+// item sets the slot's top bit; every candidate then looks its own slot up again), the threshold
+// key comes from a bitwise search with wave ballots that stops as soon as between n and 128 keys
+// reach it (keys are distinct: (score key << 32 | ~item)), and only those <= 128 keys are
+// compacted through LDS and sorted -- a 128-key bitonic network IN REGISTERS (two keys per lane,
+// partners by DPP / ds_bpermute), no workgroup barrier anywhere.  5.25 KiB of LDS and <= 64
+// registers per row: 30 rows in flight per CU against 8 (16 beside a filter workgroup):
+//  * the first 512 candidates are requested before the row's count is known (the list has room
+//    for 2048: what lies beyond the count is dropped after the load), the first 192 exclusions
+//    before the hash is built, the next 192 while the current ones are looked up;
+//  * table probes go out together (four key registers of a lane, the three exclusions of a
+//    batch) and only the collisions walk on one by one;
+//  * loops over the key registers branch once per group of eight (rows of up to 512 candidates
+//    use one group), not once per register: a branch costs a wave more than eight compares;
+//  * the search runs on the score halves of the keys with 32-bit compares; the index halves are
+//    searched (64-bit compares) only when more than 128 keys share the threshold score.
+constexpr int WSEL_CAP = 1024;  // candidates a wave keeps in registers
+constexpr int WSEL_TAB = 1344;  // hash slots (load <= 0.76, 0.26 at the usual 350 candidates)
+constexpr int WSEL_GRP = 8;     // key registers per group: the first group is always processed
+                                // (and loaded before the count is known), the second if m > 512
+constexpr int WSEL_LS = 4;      // table probes of a lane that go out together
+constexpr int EXCL_UNROLL = 3;  // exclusion entries a lane has in flight (twice that: the next
+                                // batch is requested before the current one is looked up)
+
+// v[lane ^ J] for all 64 lanes: DPP inside a row of 16 (quad_perm for 1 and 2, row_half_mirror
+// then a reversed quad for 4, row_ror:8 for 8), ds_bpermute across rows
+template <int J>
+__device__ __forceinline__ unsigned xor_lane(unsigned v)
+{
+    const int x = (int)v;
+    if constexpr (J == 1)
+        return (unsigned)__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);
+    else if constexpr (J == 2)
+        return (unsigned)__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);
+    else if constexpr (J == 4)
+        return (unsigned)__builtin_amdgcn_update_dpp(
+            0, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false), 0x1B, 0xf, 0xf, false);
+    else if constexpr (J == 8)
+        return (unsigned)__builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);
+    else
+        return (unsigned)__shfl_xor(x, J, 64);
+}
+
+// Bitonic network over 128 keys held two per lane (register H of lane l = element l + 64 H),
+// descending.  Element i is compared with i ^ J; the pair sorts descending iff (i & KK) == 0; the
+// lower element of the pair (bit J clear) keeps the larger key then, the upper the smaller.
+template <int KK, int J>
+__device__ __forceinline__ void bitonic128_steps(unsigned long long (&r)[2], int lane)
+{
+    if constexpr (J == 64) {  // the two registers of a lane (KK = 128: descending)
+        const unsigned long long x = r[0], y = r[1];
+        r[0] = x > y ? x : y;
+        r[1] = x > y ? y : x;
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned xl = (unsigned)r[h], xh = (unsigned)(r[h] >> 32);
+            const unsigned long long y =
+                ((unsigned long long)xor_lane<J>(xh) << 32) | xor_lane<J>(xl);
+            const bool keep_max = ((lane & J) == 0) == (((lane + 64 * h) & KK) == 0);
+            if ((r[h] > y) != keep_max) r[h] = y;
+        }
+    }
+    if constexpr (J > 1) bitonic128_steps<KK, J / 2>(r, lane);
+}
+template <int KK>
+__device__ __forceinline__ void bitonic128_desc(unsigned long long (&r)[2], int lane)
+{
+    bitonic128_steps<KK, KK / 2>(r, lane);
+    if constexpr (KK < 128) bitonic128_desc<KK * 2>(r, lane);
+}
+
+template <int STRIDE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void cand_select_wave_kernel(
+    const unsigned long long *__restrict__ cand, const unsigned *__restrict__ cand_cnt,
+    const int64_t *__restrict__ excl_ptr, const int32_t *__restrict__ excl_items,
+    int64_t user_base, int n, int32_t *__restrict__ out_idx, float *__restrict__ out_score,
+    int64_t out_ld, int *__restrict__ redo /* [0] = count, [1 ..] = user rows */, int redo_cap,
+    int *__restrict__ big /* [0] = count, [1 ..] = batch rows with more than WSEL_CAP candidates */,
+    int big_cap, int64_t row0 /* batch row of workgroup 0 */)
+{
+    constexpr int NJ = WSEL_CAP / 64, NG = NJ / WSEL_GRP;
+    static_assert(STRIDE >= 64 * WSEL_GRP, "eager loads stay inside the row's list");
+    // open addressing: item + 1, top bit = excluded; the 128 selected keys reuse its space
+    __shared__ __attribute__((aligned(16))) unsigned tab[WSEL_TAB];
+    unsigned long long *sbuf = reinterpret_cast<unsigned long long *>(tab);
+    const int lane = threadIdx.x;
+    const int64_t b = (int64_t)blockIdx.x + row0;
+#ifdef LK_WSEL_PHASES
+    unsigned long long wp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
+#endif
+    LK_WP_T(wp0);
+    unsigned long long k[NJ];
+#pragma unroll
+    for (int j = 0; j < WSEL_GRP; ++j) k[j] = cand[b * STRIDE + j * 64 + lane];
+    const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)cand_cnt[b]);
+    int64_t eb = 0, ee = 0;
+    if (excl_ptr) {
+        eb = excl_ptr[user_base + b];
+        ee = excl_ptr[user_base + b + 1];
+    }
+#ifdef LK_WSEL_PHASES
+    asm volatile("" ::"s"(m), "s"(eb), "s"(ee));
+#endif
+    LK_WP_T(wp1);
+    LK_WP_ADD(0, wp0, wp1);
+    auto flag = [&]() {
+        const int pos = atomicAdd(&redo[0], 1);
+        if (pos < redo_cap) redo[1 + pos] = (int)(user_base + b);
+    };
+    if (m > (unsigned)STRIDE) {  // the list overflowed: the exact redo path
+        if (lane == 0) flag();
+        return;
+    }
+    if (m > (unsigned)WSEL_CAP) {  // second tier (cand_select_kernel with room for STRIDE keys)
+        if (lane == 0) {
+            const int pos = big ? atomicAdd(&big[0], 1) : big_cap;
+            if (pos < big_cap)
+                big[1 + pos] = (int)b;
+            else
+                flag();
+        }
+        return;
+    }
+    // key registers in use: group 0 always (empty slots hold 0 and never count), group 1 if the
+    // row has more than 512 candidates -- ONE wave-uniform branch per loop, not one per register
+    const int ng = m > (unsigned)(64 * WSEL_GRP) ? NG : 1;
+    // the first batch of the exclusion list, in flight while the table is built
+    int its[EXCL_UNROLL];
+#pragma unroll
+    for (int u = 0; u < EXCL_UNROLL; ++u) {
+        const int64_t e = eb + u * 64 + lane;
+        its[u] = e < ee ? excl_items[e] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const unsigned i = (unsigned)(j * 64 + lane);
+        if (j < WSEL_GRP) {
+            if (i >= m) k[j] = 0ull;
+        } else {
+            k[j] = 0ull;
+        }
+    }
+    if (ng > 1) {
+#pragma unroll
+        for (int j = WSEL_GRP; j < NJ; ++j) {
+            const unsigned i = (unsigned)(j * 64 + lane);
+            if (i < m) k[j] = cand[b * STRIDE + i];
+        }
+    }
+    LK_WP_T(wp2);
+    LK_WP_ADD(1, wp1, wp2);
+    auto slot_of = [](unsigned it) { return __umulhi(it * 2654435761u, (unsigned)WSEL_TAB); };
+    auto next = [](unsigned h) { return h + 1u == (unsigned)WSEL_TAB ? 0u : h + 1u; };
+    if (ee > eb) {
+        {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            for (int i = lane; i < WSEL_TAB / 4; i += 64) reinterpret_cast<f32x4 *>(tab)[i] = z;
+        }
+        wave_lds_sync();
+        // insert: a group's first slots are tried together, collisions walk on one by one
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g >= ng) break;  // wave-uniform
+#pragma unroll
+            for (int q = 0; q < WSEL_GRP; q += WSEL_LS) {
+                unsigned old[WSEL_LS];
+#pragma unroll
+                for (int jj = 0; jj < WSEL_LS; ++jj) {
+                    const unsigned long long key = k[g * WSEL_GRP + q + jj];
+                    const unsigned it = 0xffffffffu - (unsigned)(key & 0xffffffffu);
+                    old[jj] = key != 0ull ? atomicCAS(&tab[slot_of(it)], 0u, it + 1u) : 0u;
+                }
+#pragma unroll
+                for (int jj = 0; jj < WSEL_LS; ++jj)
+                    if (old[jj] != 0u) {
+                        const unsigned it =
+                            0xffffffffu - (unsigned)(k[g * WSEL_GRP + q + jj] & 0xffffffffu);
+                        unsigned h = next(slot_of(it));
+                        while (atomicCAS(&tab[h], 0u, it + 1u) != 0u) h = next(h);
+                    }
+            }
+        }
+        wave_lds_sync();
+        LK_WP_T(wp3);
+        LK_WP_ADD(2, wp2, wp3);
+        // the exclusion list, 3 x 64 entries at a time, the next batch requested before this one
+        // is looked up (a launch is at least as long as its longest row -- ML-25M: 32 202 entries)
+        for (int64_t e0 = eb; e0 < ee; e0 += 64 * EXCL_UNROLL) {
+            int nxt[EXCL_UNROLL];
+            const bool more = e0 + 64 * EXCL_UNROLL < ee;  // wave-uniform
+#pragma unroll
+            for (int u = 0; u < EXCL_UNROLL; ++u) {
+                const int64_t e = e0 + 64 * EXCL_UNROLL + u * 64 + lane;
+                nxt[u] = (more && e < ee) ? excl_items[e] : -1;
+            }
+            unsigned sl[EXCL_UNROLL];
+#pragma unroll
+            for (int u = 0; u < EXCL_UNROLL; ++u)
+                sl[u] = its[u] >= 0 ? tab[slot_of((unsigned)its[u])] : 0u;
+#pragma unroll
+            for (int u = 0; u < EXCL_UNROLL; ++u) {
+                unsigned s = sl[u];
+                if (s == 0u) continue;  // not a candidate (or no entry)
+                const unsigned it1 = (unsigned)its[u] + 1u;
+                unsigned h = slot_of((unsigned)its[u]);
+                for (;;) {
+                    if ((s & 0x7fffffffu) == it1) {
+                        tab[h] = s | 0x80000000u;  // excluded
+                        break;
+                    }
+                    h = next(h);
+                    s = tab[h];
+                    if (s == 0u) break;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EXCL_UNROLL; ++u) its[u] = nxt[u];
+        }
+        wave_lds_sync();
+        LK_WP_T(wp4);
+        LK_WP_ADD(3, wp3, wp4);
+        // every candidate finds its slot again: struck?
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g >= ng) break;  // wave-uniform
+#pragma unroll
+            for (int q = 0; q < WSEL_GRP; q += WSEL_LS) {
+                unsigned sl[WSEL_LS];
+#pragma unroll
+                for (int jj = 0; jj < WSEL_LS; ++jj) {
+                    const unsigned long long key = k[g * WSEL_GRP + q + jj];
+                    sl[jj] = key != 0ull
+                                 ? tab[slot_of(0xffffffffu - (unsigned)(key & 0xffffffffu))]
+                                 : 0u;
+                }
+#pragma unroll
+                for (int jj = 0; jj < WSEL_LS; ++jj) {
+                    const int j = g * WSEL_GRP + q + jj;
+                    if (k[j] == 0ull) continue;
+                    const unsigned it = 0xffffffffu - (unsigned)(k[j] & 0xffffffffu);
+                    unsigned s = sl[jj], h = slot_of(it);
+                    while ((s & 0x7fffffffu) != it + 1u && s != 0u) {  // (s == 0: cannot happen)
+                        h = next(h);
+                        s = tab[h];
+                    }
+                    if (s >> 31) k[j] = 0ull;
+                }
+            }
+        }
+        LK_WP_T(wp5);
+        LK_WP_ADD(4, wp4, wp5);
+        wave_lds_sync();  // the table is dead: the selected keys take its place
+    }
+    LK_WP_T(wp6);
+    // ballots over the key registers in use
+    auto count = [&](auto pred) {
+        int c = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g >= ng) break;  // wave-uniform
+#pragma unroll
+            for (int jj = 0; jj < WSEL_GRP; ++jj)
+                c += __popcll(__builtin_amdgcn_ballot_w64(pred(k[g * WSEL_GRP + jj])));
+        }
+        return c;
+    };
+    const int valid = count([](unsigned long long x) { return x != 0ull; });
+    // cur: count(key >= cur) >= n throughout; done once it is also <= 128 (or cur is the n-th key)
+    unsigned long long cur = 1ull;  // <= 128 valid keys: all of them
+    if (valid > 128) {
+        // score halves first (a valid key's score half is > 0: f2key(-inf) = 0x007fffff)
+        unsigned ch = 0u;
+        bool done = false;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned trial = ch | (1u << bit);
+            const int cnt =
+                count([trial](unsigned long long x) { return (unsigned)(x >> 32) >= trial; });
+            if (cnt >= n) {  // wave-uniform
+                ch = trial;
+                if (cnt <= 128) {
+                    done = true;
+                    break;
+                }
+            }
+        }
+        cur = (unsigned long long)ch << 32;
+        if (!done) {
+            // more than 128 keys reach the n-th best score: its ties are cut by the index halves
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned long long trial = cur | (1ull << bit);
+                const int cnt = count([trial](unsigned long long x) { return x >= trial; });
+                if (cnt >= n) {
+                    cur = trial;
+                    if (cnt <= 128) break;
+                }
+            }
+        }
+    }
+    LK_WP_T(wp7);
+    LK_WP_ADD(5, wp6, wp7);
+    int base = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g >= ng) break;  // wave-uniform
+#pragma unroll
+        for (int jj = 0; jj < WSEL_GRP; ++jj) {
+            const unsigned long long key = k[g * WSEL_GRP + jj];
+            const bool take = key >= cur;  // cur >= 1: never a struck or empty slot
+            const unsigned long long mk = __builtin_amdgcn_ballot_w64(take);
+            // takers in the lanes below this one
+            const unsigned below = __builtin_amdgcn_mbcnt_hi(
+                (unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            if (take) sbuf[base + (int)below] = key;
+            base += __popcll(mk);
+        }
+    }
+    wave_lds_sync();
+    // two keys per lane (element lane and element 64 + lane; nothing beyond `base`), sorted
+    // descending by a bitonic network in registers: no LDS round trip per step
+    unsigned long long r[2];
+    r[0] = lane < base ? sbuf[lane] : 0ull;
+    r[1] = lane + 64 < base ? sbuf[lane + 64] : 0ull;
+    LK_WP_T(wp8);
+    LK_WP_ADD(6, wp7, wp8);
+    bitonic128_desc<2>(r, lane);
+    LK_WP_T(wp9);
+    LK_WP_ADD(7, wp8, wp9);
+    int32_t *oidx = out_idx + b * out_ld;
+    float *osc = out_score ? out_score + b * out_ld : nullptr;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+        if (i < n) {
+            const unsigned long long c = r[h];
+            if (c != 0ull) {
+                oidx[i] = (int32_t)(0xffffffffu - (unsigned)(c & 0xffffffffu));
+                if (osc) osc[i] = key2f((unsigned)(c >> 32));
+            } else {
+                oidx[i] = -1;
+                if (osc) osc[i] = __builtin_nanf("");
+            }
+        }
+    }
+    // fewer than n valid candidates: listed and redone exactly by the caller
+    if (lane == 0 && valid < n) flag();
+#ifdef LK_WSEL_PHASES
+    LK_WP_T(wp10);
+    LK_WP_ADD(8, wp9, wp10);
+    if (lane == 0 && lk_wsel_phase_buf) {
+        // a record per row ([2][262144][16] words: this kernel's, then cmax_tau_kernel's) -- no
+        // shared counters: 10^6 atomics on one line would be the only thing measured
+        unsigned long long *dst = lk_wsel_phase_buf + (size_t)b * 16;
+        for (int i = 0; i < 9; ++i) dst[i] = wp[i];
+        dst[9] = wp0;
+        dst[10] = wp10;
+        dst[11] = m | ((unsigned long long)(ee - eb) << 32);
+    }
+#endif
+}
+
 // Stage 1 of the fused selection, a wave per row: tau[b] = the r-th largest of 256 class maxima
 // of the row's sample scores (class = float4 index mod 256; NaN -- excluded items -- skipped).
 // At least r sample scores reach it, so it is a lower bound of the r-th largest sample score
@@ -978,6 +1409,179 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict
         tau[b] = cur ? key2f(cur) : -__builtin_inff();
         cand_cnt[b] = 0u;
     }
+}
+
+// Stage 1 with the class maxima from the sample GEMM's epilogue (sample_cmax_kernel; round 5), a
+// wave per row.  cmax[b][c] = the maximum over the sample columns j = c (mod 256) of the row's
+// scores -- taken WITHOUT the row's exclusions, and a user's own items are exactly its high scores.
+// So the classes that hold an excluded sample column ("dirty": about ten per row at a sample of
+// 1/15) cannot be used as they are.  Up to `drop_max` of them are simply DROPPED: the threshold is
+// then a rank of the remaining classes -- a sample of (256 - d) / 256 of the sample, which holds
+// none of the row's exclusions -- and the rank is the one fused_tau_rank gives for that smaller
+// sampling fraction (ranks.r[d]: the same 1e-6 bound on "fewer than n items reach tau").  Rows with
+// more dirty classes (ML-25M: users with more than ~3000 items) are REPAIRED: the class maximum is
+// taken again over the columns that are not excluded, each score recomputed as the GEMM computes
+// it (fmaf over the padded features in order: the same bits), a lane per (class, column), merged
+// by an LDS atomic max on the ordered key.  (Repairing every row was the first version: 0.73 ms
+// per call against 0.52 for the kernel it replaced -- 170 gathered 256-byte rows per user, each
+// lane its own row, is 1024 cache-line requests per 64 scores.)  tau[b] = the r-th largest class
+// key, as in sample_tau_kernel.
+// LDS per wave: bitmap of the excluded sample columns [words] | dirty-class bits [8] | count [8]
+// | dirty-class list [256] | class keys [256].
+constexpr int CMAX_LDS_EXTRA = 16 + 256 + 256;  // words per wave beside the bitmap
+constexpr int CMAX_DROP_MAX = 128;              // dirty classes dropped rather than repaired
+struct TauRanks {
+    unsigned char r[CMAX_DROP_MAX + 1];  // rank for d dropped classes (r[0]: none dropped)
+};
+__global__ __launch_bounds__(256) void cmax_tau_kernel(
+    const float *__restrict__ cmax, const float *__restrict__ users, int ld_u,
+    const float *__restrict__ qs, int kp, int64_t n_sub, TauRanks ranks, int drop_max,
+    int64_t n_rows, float *__restrict__ tau, unsigned *__restrict__ cand_cnt,
+    const int64_t *__restrict__ excl_ptr, const int32_t *__restrict__ excl_items,
+    int64_t user_base, int stride, int words)
+{
+    int r = ranks.r[0];
+    extern __shared__ unsigned bm_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= n_rows) return;  // wave-uniform
+    unsigned *bm = bm_all + (size_t)wave * (words + CMAX_LDS_EXTRA);
+    unsigned *dirty = bm + words;
+    unsigned *nd_p = dirty + 8;
+    unsigned *dlist = dirty + 16;
+    unsigned *ckey = dlist + 256;
+#ifdef LK_WSEL_PHASES
+    // [32 ..]: [0] row loads, [1] clear + exclusion walk, [2] class keys to LDS, [3] repairs,
+    // [4] search + store, [9] rows, [10] the longest row, [11] its dirty classes
+    unsigned long long wp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
+    unsigned long long nd_seen = 0;
+#endif
+    LK_WP_T(wp0);
+    const f32x4 x = reinterpret_cast<const f32x4 *>(cmax + b * 256)[lane];
+    unsigned v[4];  // classes 4 lane .. 4 lane + 3; 0 = no valid score (keys are >= f2key(-inf) > 0)
+    v[0] = x.x == x.x ? f2key(x.x) : 0u;
+    v[1] = x.y == x.y ? f2key(x.y) : 0u;
+    v[2] = x.z == x.z ? f2key(x.z) : 0u;
+    v[3] = x.w == x.w ? f2key(x.w) : 0u;
+    int64_t eb = 0, ee = 0;
+    if (excl_ptr) {
+        eb = excl_ptr[user_base + b];
+        ee = excl_ptr[user_base + b + 1];
+    }
+#ifdef LK_WSEL_PHASES
+    asm volatile("" ::"s"(eb), "s"(ee), "v"(v[0]), "v"(v[3]));
+#endif
+    LK_WP_T(wp1);
+    LK_WP_ADD(0, wp0, wp1);
+    if (ee > eb) {
+        for (int w = lane; w < words + 16; w += 64) bm[w] = 0u;  // bitmap, dirty bits, count
+        wave_lds_sync();
+        // eight loads in flight per lane: a launch is at least as long as its longest list
+        for (int64_t e0 = eb; e0 < ee; e0 += 64 * EXCL_UNROLL) {
+            int its[EXCL_UNROLL];
+#pragma unroll
+            for (int u = 0; u < EXCL_UNROLL; ++u) {
+                const int64_t e = e0 + u * 64 + lane;
+                its[u] = e < ee ? excl_items[e] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < EXCL_UNROLL; ++u) {
+                const int it = its[u];
+                if (it >= 0 && it % stride == 0) {
+                    const int j = it / stride;
+                    if (j < n_sub) {
+                        atomicOr(&bm[j >> 5], 1u << (j & 31));
+                        const unsigned cls = (unsigned)j & 255u, bit = 1u << (cls & 31u);
+                        const unsigned old = atomicOr(&dirty[cls >> 5], bit);
+                        if (!(old & bit)) dlist[atomicAdd(nd_p, 1u)] = cls;  // first to mark it
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
+        const int nd = __builtin_amdgcn_readfirstlane((int)*nd_p);
+        LK_WP_T(wp2);
+        LK_WP_ADD(1, wp1, wp2);
+#ifdef LK_WSEL_PHASES
+        nd_seen = (unsigned long long)nd;
+#endif
+        if (nd > 0 && nd <= drop_max) {
+            // classes 4 lane .. 4 lane + 3: bits (4 lane) & 31 .. + 3 of their word
+            const unsigned bits = (dirty[(4 * lane) >> 5] >> ((4 * lane) & 31)) & 15u;
+            if (bits & 1u) v[0] = 0u;
+            if (bits & 2u) v[1] = 0u;
+            if (bits & 4u) v[2] = 0u;
+            if (bits & 8u) v[3] = 0u;
+            r = ranks.r[nd];
+        } else if (nd > 0) {
+            ckey[4 * lane + 0] = v[0];
+            ckey[4 * lane + 1] = v[1];
+            ckey[4 * lane + 2] = v[2];
+            ckey[4 * lane + 3] = v[3];
+            wave_lds_sync();
+            for (int d = lane; d < nd; d += 64) ckey[dlist[d]] = 0u;
+            wave_lds_sync();
+            LK_WP_T(wp3);
+            LK_WP_ADD(2, wp2, wp3);
+            const int cpc = (int)((n_sub + 255) / 256);  // columns per class, at most
+            const int total = nd * cpc;
+            const float *urow = users + b * ld_u;  // wave-uniform: scalar loads
+            for (int p0 = 0; p0 < total; p0 += 64) {
+                const int p = p0 + lane;
+                const int d = p / cpc, s = p - d * cpc;
+                if (p < total) {
+                    const unsigned cls = dlist[d];
+                    const int64_t j = (int64_t)cls + 256 * (int64_t)s;
+                    if (j < n_sub && !((bm[j >> 5] >> (j & 31)) & 1u)) {
+                        const f32x4 *q4 = reinterpret_cast<const f32x4 *>(qs + j * kp);
+                        float acc = 0.f;
+#pragma unroll 8
+                        for (int kk = 0; kk < kp; kk += 4) {
+                            const f32x4 q = q4[kk >> 2];
+                            acc = __builtin_fmaf(urow[kk + 0], q.x, acc);
+                            acc = __builtin_fmaf(urow[kk + 1], q.y, acc);
+                            acc = __builtin_fmaf(urow[kk + 2], q.z, acc);
+                            acc = __builtin_fmaf(urow[kk + 3], q.w, acc);
+                        }
+                        if (acc == acc) atomicMax(&ckey[cls], f2key(acc));
+                    }
+                }
+            }
+            wave_lds_sync();
+            v[0] = ckey[4 * lane + 0];
+            v[1] = ckey[4 * lane + 1];
+            v[2] = ckey[4 * lane + 2];
+            v[3] = ckey[4 * lane + 3];
+            LK_WP_T(wp4);
+            LK_WP_ADD(3, wp3, wp4);
+        }
+    }
+    LK_WP_T(wp5);
+    // largest t with #{v >= t} >= r
+    unsigned cur = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned trial = cur | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cnt += __popcll(__builtin_amdgcn_ballot_w64(v[c] >= trial));
+        if (cnt >= r) cur = trial;  // wave-uniform
+    }
+    if (lane == 0) {
+        tau[b] = cur ? key2f(cur) : -__builtin_inff();
+        cand_cnt[b] = 0u;
+    }
+#ifdef LK_WSEL_PHASES
+    LK_WP_T(wp6);
+    LK_WP_ADD(4, wp5, wp6);
+    if (lane == 0 && lk_wsel_phase_buf) {
+        unsigned long long *dst = lk_wsel_phase_buf + ((size_t)262144 + (size_t)b) * 16;
+        for (int i = 0; i < 5; ++i) dst[i] = wp[i];
+        dst[9] = wp0;
+        dst[10] = wp6;
+        dst[11] = nd_seen | ((unsigned long long)(ee - eb) << 32);
+    }
+#endif
 }
 
 // scores[b][excluded item] = NaN  (NaN is skipped by the selection, like the reference).
@@ -1300,6 +1904,21 @@ static bool tau_mask()
     return !(e && e[0] == '0');
 }
 
+// LK_TOPK_STAGE1=panel: the round-4 stage 1 (sample panel written, sample_tau_kernel sweeps it);
+// default: class maxima from the sample GEMM's epilogue (sample_cmax_kernel + cmax_tau_kernel)
+static bool stage1_cmax()
+{
+    const char *e = getenv("LK_TOPK_STAGE1");  // A/B knob (read per call)
+    return !(e && e[0] == 'p');
+}
+// LK_TOPK_SELECT=sort: the round-4 first selection tier (a workgroup per row, whole-list sort);
+// default: a wave per row, threshold search + 128-key sort (cand_select_wave_kernel)
+static bool select_wave()
+{
+    const char *e = getenv("LK_TOPK_SELECT");  // A/B knob (read per call)
+    return !(e && e[0] == 's');
+}
+
 static int64_t fused_min_items()
 {
     const char *e = getenv("LK_TOPK_FUSED_MIN_ITEMS");  // test hook / tuning knob (read per call)
@@ -1368,11 +1987,17 @@ static int64_t fused_sample_items(int64_t n_items, int32_t n)
 // rank of the sample score used as the threshold: smallest r with P[Binomial(n-1, f) >= r] <= 1e-6,
 // f = sample fraction (at least r of the row's n-1 best items would have to be in the sample
 // for fewer than n items to reach the threshold).  LK_TOPK_TAU_EXACT=1: r = n (a certain bound).
-static int fused_tau_rank(int64_t n_items, int32_t n)
+static bool tau_exact()
 {
     const char *e = getenv("LK_TOPK_TAU_EXACT");
-    if (e && e[0] == '1') return n;
-    const double f = (double)fused_sample_items(n_items, n) / (double)n_items;
+    return e && e[0] == '1';
+}
+// `keep`: the part of the sample the threshold is taken from (cmax_tau_kernel drops the classes
+// that hold an exclusion)
+static int fused_tau_rank(int64_t n_items, int32_t n, double keep = 1.0)
+{
+    if (tau_exact()) return n;
+    const double f = keep * (double)fused_sample_items(n_items, n) / (double)n_items;
     const int m = n - 1;
     // tail[r] = P[X >= r], X ~ Binomial(m, f), from the pmf
     double pmf = 1.0;
@@ -1418,6 +2043,14 @@ static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n)
 }
 
 }  // namespace lk
+
+#ifdef LK_WSEL_PHASES
+extern "C" int lk_wsel_phase_set(unsigned long long *d_buf)
+{
+    LK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(lk::lk_wsel_phase_buf), &d_buf, sizeof(d_buf)));
+    return LK_OK;
+}
+#endif
 
 #ifdef LK_TOPK_PHASES
 extern "C" int lk_topk_phase_set(unsigned long long *d_buf)
@@ -1590,22 +2223,48 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
             const dim3 ugrid_sub((unsigned)((n_sub + lk::SC_IB - 1) / lk::SC_IB),
                                  (unsigned)((rows + lk::SC_UB - 1) / lk::SC_UB));
             // stage 1: threshold from the sample
-            hipLaunchKernelGGL(lk::score_panel_kernel, ugrid_sub, dim3(256), 0, st, ub_users,
-                               ld_users, rows, qs, KP, n_sub, KP, sub, ld_sub,
-                               (const float *)nullptr, (unsigned long long *)nullptr,
-                               (unsigned *)nullptr, 0);
-            // exclusions are struck out of the sample inside sample_tau_kernel (per-wave LDS bitmap)
-            // when 4 bitmaps fit 64 KiB of LDS; LK_TOPK_TAU_MASK=0 or a huge sample: the separate
-            // score_mask_kernel pass over the panel
             const int words = (int)((n_sub + 31) / 32);
-            const bool tau_mask = d_excl_ptr && lk::tau_mask() && (size_t)words * 16 <= 65536;
-            if (d_excl_ptr && !tau_mask)
-                hipLaunchKernelGGL(lk::score_mask_kernel, dim3((unsigned)rows), dim3(64), 0, st,
-                                   d_excl_ptr, d_excl_items, ub, rows, n_items, sub, ld_sub,
-                                   stride);
-            hipLaunchKernelGGL(lk::sample_tau_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256),
-                               tau_mask ? (size_t)words * 16 : 0, st, sub, ld_sub, n_sub, r_tau, rows,
-                               tau, cnt, d_excl_ptr, d_excl_items, ub, stride, tau_mask ? words : 0);
+            const size_t cmax_lds = (size_t)(words + lk::CMAX_LDS_EXTRA) * 16;  // 4 waves
+            if (lk::stage1_cmax() && cmax_lds <= 65536) {
+                // 256 class maxima per row from the sample GEMM's epilogue ([rows x 256] floats at
+                // the head of the sample panel's space); exclusions repaired in cmax_tau_kernel
+                hipLaunchKernelGGL(lk::sample_cmax_kernel,
+                                   dim3((unsigned)((rows + lk::SC_UB - 1) / lk::SC_UB)), dim3(256), 0,
+                                   st, ub_users, ld_users, rows, qs, KP, n_sub, KP, sub, (int64_t)256,
+                                   (const float *)nullptr, (unsigned long long *)nullptr,
+                                   (unsigned *)nullptr, 0);
+                // LK_TOPK_TAU_EXACT=1 (r = n, a certain bound): every dirty class is repaired -- a
+                // row must keep n classes.  LK_TOPK_DROP_MAX: A/B knob.
+                lk::TauRanks ranks;
+                for (int d = 0; d <= lk::CMAX_DROP_MAX; ++d)
+                    ranks.r[d] = (unsigned char)lk::fused_tau_rank(n_items, n, (256 - d) / 256.0);
+                int drop_max = lk::tau_exact() ? 0 : lk::CMAX_DROP_MAX;
+                if (const char *e = getenv("LK_TOPK_DROP_MAX")) {
+                    const int v = atoi(e);
+                    if (v >= 0 && v < drop_max) drop_max = v;
+                }
+                hipLaunchKernelGGL(lk::cmax_tau_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256),
+                                   cmax_lds, st, sub, ub_users, ld_users, qs, KP, n_sub, ranks,
+                                   drop_max, rows, tau, cnt, d_excl_ptr, d_excl_items, ub, stride,
+                                   words);
+            } else {
+                hipLaunchKernelGGL(lk::score_panel_kernel, ugrid_sub, dim3(256), 0, st, ub_users,
+                                   ld_users, rows, qs, KP, n_sub, KP, sub, ld_sub,
+                                   (const float *)nullptr, (unsigned long long *)nullptr,
+                                   (unsigned *)nullptr, 0);
+                // exclusions are struck out of the sample inside sample_tau_kernel (per-wave LDS
+                // bitmap) when 4 bitmaps fit 64 KiB of LDS; LK_TOPK_TAU_MASK=0 or a huge sample:
+                // the separate score_mask_kernel pass over the panel
+                const bool tau_mask = d_excl_ptr && lk::tau_mask() && (size_t)words * 16 <= 65536;
+                if (d_excl_ptr && !tau_mask)
+                    hipLaunchKernelGGL(lk::score_mask_kernel, dim3((unsigned)rows), dim3(64), 0, st,
+                                       d_excl_ptr, d_excl_items, ub, rows, n_items, sub, ld_sub,
+                                       stride);
+                hipLaunchKernelGGL(lk::sample_tau_kernel, dim3((unsigned)((rows + 3) / 4)),
+                                   dim3(256), tau_mask ? (size_t)words * 16 : 0, st, sub, ld_sub,
+                                   n_sub, r_tau, rows, tau, cnt, d_excl_ptr, d_excl_items, ub, stride,
+                                   tau_mask ? words : 0);
+            }
             // stage 2: the full contraction, candidates only
             // one workgroup per 128 users, walking all item tiles (no global atomics).
             // The workgroups all take the same time and two fit a CU: a grid that is not a multiple
@@ -1647,7 +2306,16 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
                                        (int64_t)0, tau_r, cand_r, cnt_r, lk::FUSED_CAP);
             };
             // stage 3, first tier: exclusions, exact order
+            const bool wave_sel = lk::select_wave();
             auto select = [&](int64_t r0, int64_t nr, hipStream_t s) {
+                if (wave_sel) {
+                    hipLaunchKernelGGL((lk::cand_select_wave_kernel<lk::FUSED_CAP>),
+                                       dim3((unsigned)nr), dim3(64), 0, s, cand, cnt, d_excl_ptr,
+                                       d_excl_items, ub, n, d_out_idx + ub * n,
+                                       d_out_score ? d_out_score + ub * n : nullptr, (int64_t)n,
+                                       redo, lk::FUSED_REDO_CAP, big, lk::FUSED_BIG_CAP, r0);
+                    return;
+                }
                 hipLaunchKernelGGL((lk::cand_select_kernel<lk::FUSED_LCAP, lk::FUSED_CAP>),
                                    dim3((unsigned)nr), dim3(256), 0, s, cand, cnt, d_excl_ptr,
                                    d_excl_items, ub, n, d_out_idx + ub * n,

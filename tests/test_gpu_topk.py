@@ -120,8 +120,18 @@ def _oracle_topn(oracle, Q, u, excl, n):
     return s, want
 
 
+ROUND4 = ("panel", "sort")  # LK_TOPK_STAGE1 / LK_TOPK_SELECT: the kernels round 5 replaced
+ROUND5 = ("cmax", "wave")   # the defaults: class maxima from the sample GEMM, a wave per row
+
+
+def _variant(monkeypatch, variant):
+    monkeypatch.setenv("LK_TOPK_STAGE1", variant[0])
+    monkeypatch.setenv("LK_TOPK_SELECT", variant[1])
+
+
+@pytest.mark.parametrize("variant", [ROUND5, ROUND4, ("cmax", "sort")])
 @pytest.mark.parametrize("k,n", [(64, 100), (25, 10), (128, 128), (10, 10)])
-def test_score_topk_fused_path(gpu, oracle, rng, k, n, monkeypatch):
+def test_score_topk_fused_path(gpu, oracle, rng, k, n, monkeypatch, variant):
     """
     The fused scoring + selection path (catalogues >= 16 384 items: stage-1 threshold from an
     item sample, stage-2 GEMM emitting candidates only, stage-3 exact order) gives the SAME
@@ -132,6 +142,7 @@ def test_score_topk_fused_path(gpu, oracle, rng, k, n, monkeypatch):
     """
     from lkpy_amd import _device as D
 
+    _variant(monkeypatch, variant)
     monkeypatch.setenv("LK_TOPK_FUSED_MIN_USERS", "1")
     B, I = 200, 20000
     U = rng.standard_normal((B, k)).astype(np.float32)
@@ -178,8 +189,9 @@ def test_score_topk_fused_no_overflow_rows(gpu, oracle, rng, monkeypatch):
         assert np.array_equal(idx[b], want) and np.array_equal(sc[b], s[want])
 
 
+@pytest.mark.parametrize("variant", [ROUND5, ROUND4])
 @pytest.mark.parametrize("exact", [False, True])
-def test_score_topk_fused_threshold_misses_are_redone(gpu, oracle, rng, monkeypatch, exact):
+def test_score_topk_fused_threshold_misses_are_redone(gpu, oracle, rng, monkeypatch, exact, variant):
     """
     The fused path's threshold is a RANK of the strided item sample chosen so that "fewer than n
     items reach it" is a 1e-6 event -- under random sampling.  An adversarial catalogue (every
@@ -189,6 +201,7 @@ def test_score_topk_fused_threshold_misses_are_redone(gpu, oracle, rng, monkeypa
     """
     from lkpy_amd import _device as D
 
+    _variant(monkeypatch, variant)
     monkeypatch.setenv("LK_TOPK_FUSED_MIN_USERS", "1")
     if exact:
         monkeypatch.setenv("LK_TOPK_TAU_EXACT", "1")
@@ -215,7 +228,8 @@ def test_score_topk_fused_threshold_misses_are_redone(gpu, oracle, rng, monkeypa
         assert np.array_equal(sc[b].view(np.uint32), s[want].view(np.uint32)), b
 
 
-def test_score_topk_fused_non_finite_scores(gpu, rng, monkeypatch):
+@pytest.mark.parametrize("variant", [ROUND5, ROUND4])
+def test_score_topk_fused_non_finite_scores(gpu, rng, monkeypatch, variant):
     """
     NaN and infinite scores through the fused path: its epilogue flags "not below the threshold"
     (true for NaN), stores the lane's accumulators and tests them again in the flush -- NaN must
@@ -224,6 +238,7 @@ def test_score_topk_fused_non_finite_scores(gpu, rng, monkeypatch):
     """
     from lkpy_amd import _device as D
 
+    _variant(monkeypatch, variant)
     monkeypatch.setenv("LK_TOPK_FUSED_MIN_USERS", "1")
     B, I, k, n = 150, 17000, 64, 50
     U = rng.standard_normal((B, k)).astype(np.float32)
