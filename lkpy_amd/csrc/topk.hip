@@ -989,7 +989,7 @@ __device__ unsigned long long *lk_wsel_phase_buf;
 //  * the search runs on the score halves of the keys with 32-bit compares; the index halves are
 //    searched (64-bit compares) only when more than 128 keys share the threshold score.
 constexpr int WSEL_CAP = 1024;  // candidates a wave keeps in registers
-constexpr int WSEL_TAB = 1344;  // hash slots (load <= 0.76, 0.26 at the usual 350 candidates)
+// hash slots: 21 / 16 of the capacity (load <= 0.76, 0.26 at the usual 350 candidates)
 constexpr int WSEL_GRP = 8;     // key registers per group: the first group is always processed
                                 // (and loaded before the count is known), the second if m > 512
 constexpr int WSEL_LS = 4;      // table probes of a lane that go out together
@@ -1044,22 +1044,22 @@ __device__ __forceinline__ void bitonic128_desc(unsigned long long (&r)[2], int 
     if constexpr (KK < 128) bitonic128_desc<KK * 2>(r, lane);
 }
 
-template <int STRIDE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void cand_select_wave_kernel(
+template <int STRIDE, int CAP>
+__device__ __forceinline__ void wave_select_row(
+    const int64_t b /* batch row, wave-uniform */, unsigned *tab /* LDS, CAP / 16 * 21 words */,
     const unsigned long long *__restrict__ cand, const unsigned *__restrict__ cand_cnt,
     const int64_t *__restrict__ excl_ptr, const int32_t *__restrict__ excl_items,
     int64_t user_base, int n, int32_t *__restrict__ out_idx, float *__restrict__ out_score,
     int64_t out_ld, int *__restrict__ redo /* [0] = count, [1 ..] = user rows */, int redo_cap,
-    int *__restrict__ big /* [0] = count, [1 ..] = batch rows with more than WSEL_CAP candidates */,
-    int big_cap, int64_t row0 /* batch row of workgroup 0 */)
+    int *__restrict__ big /* [0] = count, [1 ..] = batch rows with more than CAP candidates */,
+    int big_cap)
 {
-    constexpr int NJ = WSEL_CAP / 64, NG = NJ / WSEL_GRP;
+    constexpr int NJ = CAP / 64, NG = NJ / WSEL_GRP, WSEL_TAB = CAP / 16 * 21;
     static_assert(STRIDE >= 64 * WSEL_GRP, "eager loads stay inside the row's list");
+    static_assert(WSEL_TAB % 4 == 0 && WSEL_TAB * 4 >= 128 * 8, "table holds the 128 selected keys");
     // open addressing: item + 1, top bit = excluded; the 128 selected keys reuse its space
-    __shared__ __attribute__((aligned(16))) unsigned tab[WSEL_TAB];
     unsigned long long *sbuf = reinterpret_cast<unsigned long long *>(tab);
     const int lane = threadIdx.x;
-    const int64_t b = (int64_t)blockIdx.x + row0;
 #ifdef LK_WSEL_PHASES
     unsigned long long wp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
 #endif
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void ca
         if (lane == 0) flag();
         return;
     }
-    if (m > (unsigned)WSEL_CAP) {  // second tier (cand_select_kernel with room for STRIDE keys)
+    if (m > (unsigned)CAP) {  // second tier (cand_select_kernel with room for STRIDE keys)
         if (lane == 0) {
             const int pos = big ? atomicAdd(&big[0], 1) : big_cap;
             if (pos < big_cap)
@@ -1096,9 +1096,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void ca
         }
         return;
     }
-    // key registers in use: group 0 always (empty slots hold 0 and never count), group 1 if the
-    // row has more than 512 candidates -- ONE wave-uniform branch per loop, not one per register
-    const int ng = m > (unsigned)(64 * WSEL_GRP) ? NG : 1;
+    // key registers in use, in groups of eight: group 0 always (empty slots hold 0 and never
+    // count), the next per 512 candidates -- ONE wave-uniform branch per group and loop, not one
+    // per register
+    const int ng = m > (unsigned)(64 * WSEL_GRP) ? (int)((m + 64 * WSEL_GRP - 1) / (64 * WSEL_GRP)) : 1;
     // the first batch of the exclusion list, in flight while the table is built
     int its[EXCL_UNROLL];
 #pragma unroll
@@ -1333,6 +1334,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void ca
 #endif
 }
 
+// first tier: a row per workgroup of one wave, up to WSEL_CAP candidates in registers
+template <int STRIDE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void cand_select_wave_kernel(
+    const unsigned long long *__restrict__ cand, const unsigned *__restrict__ cand_cnt,
+    const int64_t *__restrict__ excl_ptr, const int32_t *__restrict__ excl_items,
+    int64_t user_base, int n, int32_t *__restrict__ out_idx, float *__restrict__ out_score,
+    int64_t out_ld, int *__restrict__ redo, int redo_cap, int *__restrict__ big, int big_cap,
+    int64_t row0 /* batch row of workgroup 0 */)
+{
+    __shared__ __attribute__((aligned(16))) unsigned tab[WSEL_CAP / 16 * 21];
+    wave_select_row<STRIDE, WSEL_CAP>((int64_t)blockIdx.x + row0, tab, cand, cand_cnt, excl_ptr,
+                                      excl_items, user_base, n, out_idx, out_score, out_ld, redo,
+                                      redo_cap, big, big_cap);
+}
+
 // Stage 1 of the fused selection, a wave per row: tau[b] = the r-th largest of 256 class maxima
 // of the row's sample scores (class = float4 index mod 256; NaN -- excluded items -- skipped).
 // At least r sample scores reach it, so it is a lower bound of the r-th largest sample score
@@ -1419,7 +1435,8 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict
 // then a rank of the remaining classes -- a sample of (256 - d) / 256 of the sample, which holds
 // none of the row's exclusions -- and the rank is the one fused_tau_rank gives for that smaller
 // sampling fraction (ranks.r[d]: the same 1e-6 bound on "fewer than n items reach tau").  Rows with
-// more dirty classes (ML-25M: users with more than ~3000 items) are REPAIRED: the class maximum is
+// more dirty classes (ML-25M: users with more than ~3000 items) keep too few classes that way:
+// `repair_max` of their dirty classes are REPAIRED (the rest dropped): the class maximum is
 // taken again over the columns that are not excluded, each score recomputed as the GEMM computes
 // it (fmaf over the padded features in order: the same bits), a lane per (class, column), merged
 // by an LDS atomic max on the ordered key.  (Repairing every row was the first version: 0.73 ms
@@ -1429,14 +1446,17 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict
 // LDS per wave: bitmap of the excluded sample columns [words] | dirty-class bits [8] | count [8]
 // | dirty-class list [256] | class keys [256].
 constexpr int CMAX_LDS_EXTRA = 16 + 256 + 256;  // words per wave beside the bitmap
-constexpr int CMAX_DROP_MAX = 128;              // dirty classes dropped rather than repaired
+constexpr int CMAX_DROP_MAX = 128;              // up to here every dirty class is dropped
+constexpr int CMAX_REPAIR_MAX = 64;             // beyond: this many are repaired, the rest dropped
+constexpr int CMAX_RANKS = 256 - CMAX_REPAIR_MAX + 1;
+constexpr int TAU_UNROLL = 8;                   // exclusion entries a lane has in flight
 struct TauRanks {
-    unsigned char r[CMAX_DROP_MAX + 1];  // rank for d dropped classes (r[0]: none dropped)
+    unsigned char r[CMAX_RANKS];  // rank for d dropped classes (r[0]: none dropped)
 };
 __global__ __launch_bounds__(256) void cmax_tau_kernel(
     const float *__restrict__ cmax, const float *__restrict__ users, int ld_u,
     const float *__restrict__ qs, int kp, int64_t n_sub, TauRanks ranks, int drop_max,
-    int64_t n_rows, float *__restrict__ tau, unsigned *__restrict__ cand_cnt,
+    int repair_max, int64_t n_rows, float *__restrict__ tau, unsigned *__restrict__ cand_cnt,
     const int64_t *__restrict__ excl_ptr, const int32_t *__restrict__ excl_items,
     int64_t user_base, int stride, int words)
 {
@@ -1477,16 +1497,24 @@ __global__ __launch_bounds__(256) void cmax_tau_kernel(
     if (ee > eb) {
         for (int w = lane; w < words + 16; w += 64) bm[w] = 0u;  // bitmap, dirty bits, count
         wave_lds_sync();
-        // eight loads in flight per lane: a launch is at least as long as its longest list
-        for (int64_t e0 = eb; e0 < ee; e0 += 64 * EXCL_UNROLL) {
-            int its[EXCL_UNROLL];
+        // eight loads in flight per lane, the next eight requested before these are marked: a
+        // launch is at least as long as its longest list
+        int its[TAU_UNROLL];
 #pragma unroll
-            for (int u = 0; u < EXCL_UNROLL; ++u) {
-                const int64_t e = e0 + u * 64 + lane;
-                its[u] = e < ee ? excl_items[e] : -1;
+        for (int u = 0; u < TAU_UNROLL; ++u) {
+            const int64_t e = eb + u * 64 + lane;
+            its[u] = e < ee ? excl_items[e] : -1;
+        }
+        for (int64_t e0 = eb; e0 < ee; e0 += 64 * TAU_UNROLL) {
+            int nxt[TAU_UNROLL];
+            const bool more = e0 + 64 * TAU_UNROLL < ee;  // wave-uniform
+#pragma unroll
+            for (int u = 0; u < TAU_UNROLL; ++u) {
+                const int64_t e = e0 + 64 * TAU_UNROLL + u * 64 + lane;
+                nxt[u] = (more && e < ee) ? excl_items[e] : -1;
             }
 #pragma unroll
-            for (int u = 0; u < EXCL_UNROLL; ++u) {
+            for (int u = 0; u < TAU_UNROLL; ++u) {
                 const int it = its[u];
                 if (it >= 0 && it % stride == 0) {
                     const int j = it / stride;
@@ -1498,6 +1526,8 @@ __global__ __launch_bounds__(256) void cmax_tau_kernel(
                     }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < TAU_UNROLL; ++u) its[u] = nxt[u];
         }
         wave_lds_sync();
         const int nd = __builtin_amdgcn_readfirstlane((int)*nd_p);
@@ -1524,8 +1554,12 @@ __global__ __launch_bounds__(256) void cmax_tau_kernel(
             wave_lds_sync();
             LK_WP_T(wp3);
             LK_WP_ADD(2, wp2, wp3);
+            // at most repair_max classes are repaired (the first of the list: any will do); the
+            // others stay at "no score" -- dropped, like the rows with few dirty classes
+            const int n_rep = nd < repair_max ? nd : repair_max;
+            r = ranks.r[nd - n_rep];
             const int cpc = (int)((n_sub + 255) / 256);  // columns per class, at most
-            const int total = nd * cpc;
+            const int total = n_rep * cpc;
             const float *urow = users + b * ld_u;  // wave-uniform: scalar loads
             for (int p0 = 0; p0 < total; p0 += 64) {
                 const int p = p0 + lane;
@@ -1873,7 +1907,8 @@ static int64_t padded_items(int64_t n_items) { return (n_items + 63) / 64 * 64; 
 // list, or a row that simply has fewer than n valid items) is listed and redone EXACTLY
 // through the panel path -- so the results are those of the panel path, bit for bit, always.
 #ifndef LK_TOPK_SAMPLE_DIV_DEFAULT
-#define LK_TOPK_SAMPLE_DIV_DEFAULT 16  // measured: 8 -> 23.5 ms, 16 -> 22.5, 32 -> 23.6 (ML-25M, k = 64)
+#define LK_TOPK_SAMPLE_DIV_DEFAULT 24  // cfg2, k = 64, round 5: 12 -> 12.72 ms, 16 -> 12.34, 20 -> 12.20, 24 -> 12.15, 32 -> 12.16
+                                       // (round 1, sample panel + whole-list sorts: 8 -> 23.5, 16 -> 22.5, 32 -> 23.6)
 #endif
 constexpr int FUSED_CAP = 2048;        // candidates per row
 // Rows per batch of the fused path.  One launch over ALL rows lets the hardware deal the
@@ -2034,8 +2069,8 @@ static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n)
     off += align_up((size_t)rows * 4, 256);
     L.off_cand = off;
     off += align_up((size_t)rows * FUSED_CAP * 8, 256);
-    L.off_flags = off;  // redo list: count + rows
-    off += align_up((size_t)(1 + FUSED_REDO_CAP + 1 + FUSED_BIG_CAP) * 4, 256);
+    L.off_flags = off;  // redo list: count + rows; the second tier's two lists likewise
+    off += align_up((size_t)(1 + FUSED_REDO_CAP + 2 * (1 + FUSED_BIG_CAP)) * 4, 256);
     L.off_qs = off;     // sample of the item factors, [n_sample x 256 floats at most]
     off += align_up((size_t)nsub * 256 * 4, 256);
     L.bytes = off;
@@ -2220,51 +2255,58 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
             const int64_t ub = bi * FUSED_ROWS;
             const int64_t rows = (n_users - ub) < FUSED_ROWS ? (n_users - ub) : FUSED_ROWS;
             const float *ub_users = d_users + ub * ld_users;
-            const dim3 ugrid_sub((unsigned)((n_sub + lk::SC_IB - 1) / lk::SC_IB),
-                                 (unsigned)((rows + lk::SC_UB - 1) / lk::SC_UB));
-            // stage 1: threshold from the sample
+            // stage 1 for rows [r0, r0 + nr) of the batch: threshold from the sample
             const int words = (int)((n_sub + 31) / 32);
             const size_t cmax_lds = (size_t)(words + lk::CMAX_LDS_EXTRA) * 16;  // 4 waves
-            if (lk::stage1_cmax() && cmax_lds <= 65536) {
-                // 256 class maxima per row from the sample GEMM's epilogue ([rows x 256] floats at
-                // the head of the sample panel's space); exclusions repaired in cmax_tau_kernel
-                hipLaunchKernelGGL(lk::sample_cmax_kernel,
-                                   dim3((unsigned)((rows + lk::SC_UB - 1) / lk::SC_UB)), dim3(256), 0,
-                                   st, ub_users, ld_users, rows, qs, KP, n_sub, KP, sub, (int64_t)256,
-                                   (const float *)nullptr, (unsigned long long *)nullptr,
-                                   (unsigned *)nullptr, 0);
-                // LK_TOPK_TAU_EXACT=1 (r = n, a certain bound): every dirty class is repaired -- a
-                // row must keep n classes.  LK_TOPK_DROP_MAX: A/B knob.
-                lk::TauRanks ranks;
-                for (int d = 0; d <= lk::CMAX_DROP_MAX; ++d)
-                    ranks.r[d] = (unsigned char)lk::fused_tau_rank(n_items, n, (256 - d) / 256.0);
-                int drop_max = lk::tau_exact() ? 0 : lk::CMAX_DROP_MAX;
-                if (const char *e = getenv("LK_TOPK_DROP_MAX")) {
-                    const int v = atoi(e);
-                    if (v >= 0 && v < drop_max) drop_max = v;
+            const bool use_cmax = lk::stage1_cmax() && cmax_lds <= 65536;
+            auto stage1 = [&](int64_t r0, int64_t nr, hipStream_t s) {
+                const float *uu = ub_users + r0 * ld_users;
+                if (use_cmax) {
+                    // 256 class maxima per row from the sample GEMM's epilogue ([rows x 256] floats
+                    // at the head of the sample panel's space); exclusions in cmax_tau_kernel
+                    float *cm = sub + r0 * 256;
+                    hipLaunchKernelGGL(lk::sample_cmax_kernel,
+                                       dim3((unsigned)((nr + lk::SC_UB - 1) / lk::SC_UB)), dim3(256), 0,
+                                       s, uu, ld_users, nr, qs, KP, n_sub, KP, cm, (int64_t)256,
+                                       (const float *)nullptr, (unsigned long long *)nullptr,
+                                       (unsigned *)nullptr, 0);
+                    // LK_TOPK_TAU_EXACT=1 (r = n, a certain bound): every dirty class is repaired --
+                    // a row must keep n classes.  LK_TOPK_DROP_MAX: A/B knob.
+                    lk::TauRanks ranks;
+                    for (int d = 0; d <= lk::CMAX_RANKS - 1; ++d)
+                        ranks.r[d] =
+                            (unsigned char)lk::fused_tau_rank(n_items, n, (256 - d) / 256.0);
+                    int drop_max = lk::tau_exact() ? 0 : lk::CMAX_DROP_MAX;
+                    if (const char *e = getenv("LK_TOPK_DROP_MAX")) {
+                        const int v = atoi(e);
+                        if (v >= 0 && v < drop_max) drop_max = v;
+                    }
+                    const int repair_max = lk::tau_exact() ? 256 : lk::CMAX_REPAIR_MAX;
+                    hipLaunchKernelGGL(lk::cmax_tau_kernel, dim3((unsigned)((nr + 3) / 4)),
+                                       dim3(256), cmax_lds, s, cm, uu, ld_users, qs, KP, n_sub, ranks,
+                                       drop_max, repair_max, nr, tau + r0, cnt + r0, d_excl_ptr,
+                                       d_excl_items, ub + r0, stride, words);
+                    return;
                 }
-                hipLaunchKernelGGL(lk::cmax_tau_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256),
-                                   cmax_lds, st, sub, ub_users, ld_users, qs, KP, n_sub, ranks,
-                                   drop_max, rows, tau, cnt, d_excl_ptr, d_excl_items, ub, stride,
-                                   words);
-            } else {
-                hipLaunchKernelGGL(lk::score_panel_kernel, ugrid_sub, dim3(256), 0, st, ub_users,
-                                   ld_users, rows, qs, KP, n_sub, KP, sub, ld_sub,
-                                   (const float *)nullptr, (unsigned long long *)nullptr,
-                                   (unsigned *)nullptr, 0);
+                float *sp = sub + r0 * ld_sub;
+                const dim3 ugrid_sub((unsigned)((n_sub + lk::SC_IB - 1) / lk::SC_IB),
+                                     (unsigned)((nr + lk::SC_UB - 1) / lk::SC_UB));
+                hipLaunchKernelGGL(lk::score_panel_kernel, ugrid_sub, dim3(256), 0, s, uu, ld_users,
+                                   nr, qs, KP, n_sub, KP, sp, ld_sub, (const float *)nullptr,
+                                   (unsigned long long *)nullptr, (unsigned *)nullptr, 0);
                 // exclusions are struck out of the sample inside sample_tau_kernel (per-wave LDS
                 // bitmap) when 4 bitmaps fit 64 KiB of LDS; LK_TOPK_TAU_MASK=0 or a huge sample:
                 // the separate score_mask_kernel pass over the panel
                 const bool tau_mask = d_excl_ptr && lk::tau_mask() && (size_t)words * 16 <= 65536;
                 if (d_excl_ptr && !tau_mask)
-                    hipLaunchKernelGGL(lk::score_mask_kernel, dim3((unsigned)rows), dim3(64), 0, st,
-                                       d_excl_ptr, d_excl_items, ub, rows, n_items, sub, ld_sub,
+                    hipLaunchKernelGGL(lk::score_mask_kernel, dim3((unsigned)nr), dim3(64), 0, s,
+                                       d_excl_ptr, d_excl_items, ub + r0, nr, n_items, sp, ld_sub,
                                        stride);
-                hipLaunchKernelGGL(lk::sample_tau_kernel, dim3((unsigned)((rows + 3) / 4)),
-                                   dim3(256), tau_mask ? (size_t)words * 16 : 0, st, sub, ld_sub,
-                                   n_sub, r_tau, rows, tau, cnt, d_excl_ptr, d_excl_items, ub, stride,
+                hipLaunchKernelGGL(lk::sample_tau_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256),
+                                   tau_mask ? (size_t)words * 16 : 0, s, sp, ld_sub, n_sub, r_tau, nr,
+                                   tau + r0, cnt + r0, d_excl_ptr, d_excl_items, ub + r0, stride,
                                    tau_mask ? words : 0);
-            }
+            };
             // stage 2: the full contraction, candidates only
             // one workgroup per 128 users, walking all item tiles (no global atomics).
             // The workgroups all take the same time and two fit a CU: a grid that is not a multiple
@@ -2273,8 +2315,11 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
             // rows of the full rounds (range A) are therefore filtered by a launch of their own and
             // their selection -- latency-bound, 16 KiB of LDS per row -- runs on a side stream in
             // the shadow of the last round (range B); LK_TOPK_OVERLAP=0: one launch each, in order
-            int *big = redo + 1 + lk::FUSED_REDO_CAP;  // [0] = count, [1 ..] = rows
+            // rows for the second selection tier, a list per range: [0] = count, [1 ..] = rows
+            int *big = redo + 1 + lk::FUSED_REDO_CAP;
+            int *big_b = big + 1 + lk::FUSED_BIG_CAP;
             LK_HIP_CHECK(hipMemsetAsync(big, 0, sizeof(int), st));
+            LK_HIP_CHECK(hipMemsetAsync(big_b, 0, sizeof(int), st));
             const int64_t wgs = (rows + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB);
             const int64_t round = 2 * 256;
             int64_t rows_a = rows;  // rows of range A (all of them: no split)
@@ -2307,7 +2352,7 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
             };
             // stage 3, first tier: exclusions, exact order
             const bool wave_sel = lk::select_wave();
-            auto select = [&](int64_t r0, int64_t nr, hipStream_t s) {
+            auto select = [&](int64_t r0, int64_t nr, hipStream_t s, int *big) {
                 if (wave_sel) {
                     hipLaunchKernelGGL((lk::cand_select_wave_kernel<lk::FUSED_CAP>),
                                        dim3((unsigned)nr), dim3(64), 0, s, cand, cnt, d_excl_ptr,
@@ -2323,7 +2368,20 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
                                    lk::FUSED_REDO_CAP, big, lk::FUSED_BIG_CAP, (const int *)nullptr,
                                    r0);
             };
-            filter(0, rows_a, st);
+            // second tier: the rows the first listed (more candidates than it holds; mostly the
+            // users with hundreds of items of their own among the candidates: 5 % of ML-25M's).
+            // A workgroup per listed row, whole-list sort: measured against a wave per row with 32
+            // keys per lane (0.34 against 1.34 ms beside the partial round) -- these rows are all
+            // hash walks and a 2048-key sort, work for 256 threads.  Range A's rows are listed by
+            // the side stream's launch and taken there, beside the partial round, too.
+            auto tier2 = [&](int64_t nr, hipStream_t s, const int *list) {
+                const dim3 grid2((unsigned)(nr < lk::FUSED_BIG_CAP ? nr : lk::FUSED_BIG_CAP));
+                hipLaunchKernelGGL((lk::cand_select_kernel<lk::FUSED_CAP, lk::FUSED_CAP>), grid2,
+                                   dim3(256), 0, s, cand, cnt, d_excl_ptr, d_excl_items, ub, n,
+                                   d_out_idx + ub * n, d_out_score ? d_out_score + ub * n : nullptr,
+                                   (int64_t)n, redo, lk::FUSED_REDO_CAP, (int *)nullptr,
+                                   lk::FUSED_BIG_CAP, list);
+            };
             if (rows_a < rows) {
                 lk::TopkSide &sd = lk::topk_side();
                 if (!sd.stream) {
@@ -2331,22 +2389,30 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
                     LK_HIP_CHECK(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
                     LK_HIP_CHECK(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
                 }
+                // (Measured and dropped in round 5: the partial round FIRST with range A's stage 1
+                // beside it on the side stream -- a seventh of the call's matrix-core work where
+                // half of every CU idles -- and range B's selection beside range A's filter:
+                // 16.6 ms against 12.3.  The lone filter workgroups slow from 2.5 to 4.2-5.4 ms
+                // next to a sample_cmax workgroup, the full rounds from 8.7 to 10.4 ms next to the
+                // selection: whatever shares a SIMD with the filter costs it more than it saves.)
+                stage1(0, rows, st);
+                filter(0, rows_a, st);
                 LK_HIP_CHECK(hipEventRecord(sd.fork, st));  // range A filtered
                 LK_HIP_CHECK(hipStreamWaitEvent(sd.stream, sd.fork, 0));
                 filter(rows_a, rows - rows_a, st);
-                select(0, rows_a, sd.stream);
+                // both tiers of range A's selection beside the partial round
+                select(0, rows_a, sd.stream, big);
+                tier2(rows_a, sd.stream, big);
                 LK_HIP_CHECK(hipEventRecord(sd.join, sd.stream));
-                select(rows_a, rows - rows_a, st);
+                select(rows_a, rows - rows_a, st, big_b);
+                tier2(rows - rows_a, st, big_b);
                 LK_HIP_CHECK(hipStreamWaitEvent(st, sd.join, 0));
             } else {
-                select(0, rows, st);
+                stage1(0, rows, st);
+                filter(0, rows, st);
+                select(0, rows, st, big);
+                tier2(rows, st, big);
             }
-            hipLaunchKernelGGL((lk::cand_select_kernel<lk::FUSED_CAP, lk::FUSED_CAP>),
-                               dim3((unsigned)(rows < lk::FUSED_BIG_CAP ? rows : lk::FUSED_BIG_CAP)),
-                               dim3(256), 0, st, cand, cnt, d_excl_ptr, d_excl_items, ub, n,
-                               d_out_idx + ub * n, d_out_score ? d_out_score + ub * n : nullptr,
-                               (int64_t)n, redo, lk::FUSED_REDO_CAP, (int *)nullptr,
-                               lk::FUSED_BIG_CAP, (const int *)big);
         }
         LK_HIP_CHECK(hipGetLastError());
         // rows that did not end up with n valid candidates are redone exactly, one by one

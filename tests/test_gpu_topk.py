@@ -203,13 +203,18 @@ def test_score_topk_fused_threshold_misses_are_redone(gpu, oracle, rng, monkeypa
 
     _variant(monkeypatch, variant)
     monkeypatch.setenv("LK_TOPK_FUSED_MIN_USERS", "1")
+    div = 24  # LK_TOPK_SAMPLE_DIV_DEFAULT
     if exact:
+        # r = n at a sample of 1/16: ~1600 candidates per row -- the second selection tier
+        # (more than 1024, at most 2048 candidates) takes the rows
         monkeypatch.setenv("LK_TOPK_TAU_EXACT", "1")
+        div = 16
+        monkeypatch.setenv("LK_TOPK_SAMPLE_DIV", "16")
     B, I, k, n = 96, 40000, 32, 100
     U = np.abs(rng.standard_normal((B, k))).astype(np.float32)
     Q = (rng.standard_normal((I, k)) * 0.01).astype(np.float32)
-    # the sample is every (I // sub)-th item with sub = max(I / 16, 16 n) rounded up to 256
-    sub = max(I // 16, 16 * n)
+    # the sample is every (I // sub)-th item with sub = max(I / div, 16 n) rounded up to 256
+    sub = max(I // div, 16 * n)
     sub = (sub + 255) // 256 * 256
     stride = I // sub
     hot = np.arange(0, I, stride)[:400]

@@ -65,21 +65,24 @@ for s1, s3 in (("panel", "sort"), ("cmax", "sort"), ("panel", "wave"), ("cmax", 
     print(json.dumps(rec), flush=True)
 os.environ.pop("LK_TOPK_STAGE1")
 os.environ.pop("LK_TOPK_SELECT")
-# knob sweeps on the default path (lists compared with the reference pair's)
-for knob, values in (("LK_TOPK_SAMPLE_DIV", os.environ.get("LK_AB_DIVS", "")),
-                     ("LK_TOPK_DROP_MAX", os.environ.get("LK_AB_DROPS", ""))):
-    for v in [x for x in values.split(",") if x]:
-        os.environ[knob] = v
-        ts = []
-        for _ in range(5):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            idx, sc = D.score_topk(eng.P, eng.Q, k, n, excl_ptr, excl_idx)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
-        print(json.dumps({knob: v, "ms": round(min(ts) * 1e3, 3),
-                          "lists_identical": bool(torch.equal(idx, ref[0]))}), flush=True)
-    os.environ.pop(knob, None)
+# knob sweeps on the default path (lists compared with the reference pair's):
+# LK_AB_SWEEP="LK_TOPK_SCHEDULE=1;LK_TOPK_SAMPLE_DIV=16,LK_TOPK_SCHEDULE=1;..."
+for setting in [x for x in os.environ.get("LK_AB_SWEEP", "").split(";") if x]:
+    pairs = [kv.split("=") for kv in setting.split(",")]
+    for kk, vv in pairs:
+        os.environ[kk] = vv
+    ts = []
+    for _ in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx, sc = D.score_topk(eng.P, eng.Q, k, n, excl_ptr, excl_idx)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    print(json.dumps({"knobs": setting, "ms": round(min(ts) * 1e3, 3),
+                      "median_ms": round(float(np.median(ts)) * 1e3, 3),
+                      "lists_identical": bool(torch.equal(idx, ref[0]))}), flush=True)
+    for kk, _ in pairs:
+        os.environ.pop(kk, None)
 # no exclusions at all (the scorer without a training-item mask)
 ts = []
 for _ in range(4):
