@@ -85,9 +85,10 @@ struct lk_als_plan {
     size_t off_yref = 0;                 // hybrid: [n_long x KP] floats in the workspace
     int32_t chunk = LK_ALS_CHUNK;        // CSR entries per chunk (= per slab) of a long row
     // entries per WORK UNIT of the chunk kernel (a multiple of `chunk`): hybrid plans at padded
-    // k = 64 keep the tuned kernel's 1024-entry units -- one wave runs its gather ring across the
-    // four 256-entry blocks of a unit and stores a slab at every block boundary (d_chunk_slab =
-    // the unit's first slab); everywhere else a unit is one chunk
+    // k = 64 (als_chunk_kernel) and k = 256 (the LDS-staged als_blk_chunk_dma_kernel) keep the
+    // tuned kernels' 1024-entry units -- one wave / workgroup runs its gather ring across the four
+    // 256-entry blocks of a unit and stores a slab at every block boundary (d_chunk_slab = the
+    // unit's first slab); everywhere else a unit is one chunk
     int32_t unit = LK_ALS_CHUNK;
     int64_t n_slabs = 0;                 // slabs of all long rows (n_chunks counts the UNITS)
     int32_t *d_chunk_slab = nullptr;     // [n_chunks] first slab of the unit

@@ -4,7 +4,8 @@ how the index arithmetic of csrc/als_chol.hip (accumulator-tile layout, L image,
 transposition) is checked without a GPU.  Likewise the LDS placement of the DMA-staged top-K
 filter kernel (csrc/topk.hip::score_filter64_kernel), the per-target accumulator of the kNN
 scoring kernels (csrc/iknn_score.hip: rounds, rank sort, BinaryHeap replay, in-place heapify)
-against the C oracle, and the folded 8-way reduction of the CG kernel (csrc/als_cg.hip).
+against the C oracle, the folded 8-way reduction of the CG kernel (csrc/als_cg.hip), and the
+wave-per-row selection of the fused top-N path (csrc/topk.hip::cand_select_wave_kernel).
 """
 import sys
 from pathlib import Path
@@ -118,3 +119,11 @@ def test_inverted_diagonal_blocks_are_as_accurate_as_substitution():
         u = 2.0 ** -24
         assert es < 2 * cond * u and ei < 2 * cond * u, (k, cond, es, ei)
         assert ei < 3 * es + 1e-7, (k, cond, es, ei)
+
+
+def test_wave_select_model_equals_a_sort():
+    """hash of the candidates' items with struck exclusions, two-stage threshold search, ballot
+    compaction, 128-key register network: the top n of what survives, in order"""
+    import wave_select as w
+
+    assert w.main(trials=120) > 32  # the index-half search ran (more than 128 equal scores)

@@ -2,13 +2,36 @@
 """
 NumPy model of ``cand_select_wave_kernel`` (csrc/topk.hip): 64 lanes x 16 key registers, the
 hash of the candidates' item numbers (slot = item + 1, top bit = excluded), the bitwise threshold
-search with its early exit, the ballot compaction and the 128-key bitonic network -- checked
+search (score halves, then index halves) with its early exit, the ballot compaction and the
+128-key bitonic network in registers -- checked
 against a plain sort on random rows (ties in the score, exclusions in any order, duplicates in the
 exclusion list, fewer than n valid candidates).  Written before the kernel first ran.
 """
 import numpy as np
 
 NJ, W = 16, 64
+
+
+def sort128_registers(keys):
+    """bitonic128_desc: two keys per lane (register h of lane l = element l + 64 h); element i
+    meets i ^ j; the pair sorts descending iff (i & kk) == 0; x[lane ^ j] is the DPP / bpermute"""
+    lane = np.arange(W)
+    r = [keys[:W].copy(), keys[W:].copy()]
+    kk = 2
+    while kk <= 128:
+        j = kk >> 1
+        while j > 0:
+            if j == 64:
+                r = [np.maximum(r[0], r[1]), np.minimum(r[0], r[1])]
+            else:
+                for h in (0, 1):
+                    x = r[h]
+                    y = x[lane ^ j]
+                    keep_max = ((lane & j) == 0) == (((lane + 64 * h) & kk) == 0)
+                    r[h] = np.where((x > y) != keep_max, y, x)
+            j >>= 1
+        kk <<= 1
+    return np.concatenate(r)
 
 
 def model(cand, excl, n):
@@ -90,21 +113,7 @@ def model(cand, excl, n):
             sbuf[pos[take]] = k[j][take]
             base += int(take.sum())
     assert n <= base <= 128 or valid < n or valid <= 128, (base, valid)
-    kk = 2
-    while kk <= 128:
-        j = kk >> 1
-        while j > 0:
-            new = sbuf.copy()
-            for q in range(W):
-                i = ((q & ~(j - 1)) << 1) | (q & (j - 1))
-                p = i | j
-                x, y = sbuf[i], sbuf[p]
-                desc = (i & kk) == 0
-                if (x < y) if desc else (x > y):
-                    new[i], new[p] = y, x
-            sbuf = new
-            j >>= 1
-        kk <<= 1
+    sbuf = sort128_registers(sbuf)
     return sbuf[:n], valid, steps
 
 
@@ -114,10 +123,10 @@ def f2key(x):
     return int(~u & 0xffffffff) if u & 0x80000000 else int(u | 0x80000000)
 
 
-def main():
+def main(trials=300):
     rng = np.random.default_rng(5)
     tot_steps = []
-    for trial in range(300):
+    for trial in range(trials):
         m = int(rng.choice([0, 1, 63, 64, 65, 100, 128, 129, 350, 700, 1024]))
         n = int(rng.choice([1, 10, 100, 128]))
         items = rng.choice(60000, m, replace=False)
@@ -137,8 +146,9 @@ def main():
         assert valid == len(keep)
         assert np.array_equal(got, want), (trial, m, n, ne)
         tot_steps.append(steps)
-    print("wave_select model: 300 rows identical to a sort; search steps mean",
+    print(f"wave_select model: {trials} rows identical to a sort; search steps mean",
           float(np.mean([s for s in tot_steps if s])), "max", max(tot_steps))
+    return max(tot_steps)
 
 
 if __name__ == "__main__":
