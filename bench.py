@@ -207,6 +207,38 @@ def pmc_traffic_per_epoch(pattern, anchor_kernel: str):
     return tot / (anchor / 2.0), files[-1].name
 
 
+TOPK_KERNELS = ("score_filter", "sample_cmax", "cmax_tau", "cand_select", "sample_rows", "sample_tau",
+                "score_panel", "score_mask", "row_topn")
+
+
+def pmc_traffic_topk(pattern="r*topk_counters.csv"):
+    """
+    HBM bytes per ``lk_score_topk`` call from the newest committed PMC summary of the top-N leg:
+    the sum over its kernels of (2 * FETCH_SIZE + WRITE_SIZE) * 1024 * launches, divided by the
+    calls in the capture (= launches of ``sample_rows_kernel``, one per fused call).
+    """
+    import csv
+
+    files = sorted((ROOT / "profiles").glob(pattern), key=lambda f: f.name)
+    if not files:
+        return None, None
+    tot, calls = 0.0, 0
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            if not any(kn in row["Kernel_Name"] for kn in TOPK_KERNELS):
+                continue
+            n = float(row.get("count", 0) or 0)
+            if row["Counter_Name"] == "FETCH_SIZE":
+                tot += 2.0 * float(row["mean"]) * n * 1024.0
+                if "sample_rows_kernel" in row["Kernel_Name"]:
+                    calls += int(n)
+            elif row["Counter_Name"] == "WRITE_SIZE":
+                tot += float(row["mean"]) * n * 1024.0
+    if calls < 1 or tot <= 0:
+        return None, None
+    return tot / calls, files[-1].name
+
+
 def reference_order_recheck(sub, other, otor, want_rows, k, dev):
     """
     REPRODUCE exception rows instead of refereeing them: the listed rows once more through a
@@ -1519,6 +1551,11 @@ def main():
                 "note": "end to end: GEMM + exclusion + selection, whole call wall time",
             },
         }
+        tr, src = pmc_traffic_topk()
+        res["roofline"]["traffic"] = tr
+        res["roofline"]["traffic_source"] = (
+            f"profiles/{src}: sum over the call's kernels of (2*FETCH_SIZE + WRITE_SIZE)*1024"
+            if src else None)
         if not args.no_cpu:
             try:
                 res["cpu_baseline"], res["parity"] = topk_cpu_and_parity(

@@ -369,15 +369,20 @@ __global__ __launch_bounds__(256) void gramian_finish_kernel(const float *__rest
     if (ti <= tj) {  // lower tiles are never written by the partial kernel
         // the slabs are summed in float64 (up to 512 of them: a float32 sum would add another
         // ~sqrt(512 / 8) roundings on top of the chains'); one rounding to float32 at the end
+        // eight loads in flight per lane: the kernel is 64 ... 1024 workgroups of dependent
+        // 256-byte reads, i.e. latency (k = 64: 30 us with two in flight -- 1 % of a cfg2 epoch)
         const float *src = ws + idx;
-        double s0 = 0.0, s1 = 0.0;
+        double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         int b = wave;
-        for (; b + 4 < nblocks; b += 8) {
-            s0 += (double)src[(size_t)b * KP * KP];
-            s1 += (double)src[(size_t)(b + 4) * KP * KP];
+        for (; b + 28 < nblocks; b += 32) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = src[(size_t)(b + 4 * u) * KP * KP];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += (double)x[u];
         }
-        if (b < nblocks) s0 += (double)src[(size_t)b * KP * KP];
-        sd = s0 + s1;
+        for (int u = 0; b < nblocks; b += 4, ++u) s[u] += (double)src[(size_t)b * KP * KP];
+        sd = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
     part[wave][lane] = sd;
     __syncthreads();

@@ -1914,16 +1914,24 @@ constexpr int FUSED_CAP = 2048;        // candidates per row
 // Rows per batch of the fused path.  One launch over ALL rows lets the hardware deal the
 // 128-user workgroups to the CUs as they finish: 162 541 users are 1270 workgroups = 2.48 waves
 // of 512 resident workgroups, against 3 launches (512 + 512 + 246, the last one at one
-// workgroup per CU) when batches were 65 536 rows.  Bounded by the stage-1 sample panel
-// (rows x sample items floats: 16 GiB at most) and the candidate lists (rows x 16 KiB).
+// workgroup per CU) when batches were 65 536 rows.  Bounded by the candidate lists (rows x
+// 16 KiB) and, when stage 1 writes the sample panel (`panel`: LK_TOPK_STAGE1=panel or a sample too
+// large for cmax_tau_kernel's bitmaps), by that panel (rows x sample items floats: 16 GiB at
+// most).  A batch of several rounds is a WHOLE number of rounds (512 workgroups = 65 536 rows): at
+// k = 256 a partial round takes as long as a full one (a filter workgroup alone on its CU runs
+// no faster: 252 ms for 259 workgroups, 255 ms for 512), and the panel bound used to cut batches
+// wherever it fell -- a million-item catalogue at a sample of 1/24 got batches of 771 workgroups,
+// two rounds of time for one and a half of work (1.19 s against 0.96 s for 205 824 users).
 // LK_TOPK_FUSED_ROWS overrides (tuning knob / A-B runs).
-static int64_t fused_rows(int64_t n_sub_padded)
+static int64_t fused_rows(int64_t n_sub_padded, bool panel)
 {
     const char *e = getenv("LK_TOPK_FUSED_ROWS");
     int64_t r = e ? (int64_t)atol(e) : (int64_t)262144;
-    const int64_t by_panel = ((int64_t)16 << 30) / (n_sub_padded * 4);
+    const int64_t by_panel = panel ? ((int64_t)16 << 30) / (n_sub_padded * 4) : r;
     if (r > by_panel) r = by_panel;
     r = r / 128 * 128;
+    const int64_t round = 512 * 128;
+    if (r > round) r = r / round * round;
     // floor: a batch is at least 8192 rows -- unless the catalogue is so large (sample > 512 Ki
     // items) that 8192 sample rows would not fit the 16 GiB panel bound: the bound wins
     int64_t lo = 8192;
@@ -2054,15 +2062,24 @@ struct FusedLayout {
     size_t off_sub, off_tau, off_cnt, off_cand, off_flags, off_qs, bytes;
 };
 
+// stage 1 as class maxima (sample_cmax_kernel + cmax_tau_kernel): unless switched off, and as long
+// as four waves' bitmaps of the sample fit 64 KiB of LDS (catalogues up to ~3 M items at 1/24)
+static bool cmax_usable(int64_t n_items, int32_t n)
+{
+    const int64_t words = (fused_sample_items(n_items, n) + 31) / 32;
+    return stage1_cmax() && (size_t)(words + CMAX_LDS_EXTRA) * 16 <= 65536;
+}
+
 static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n)
 {
     const int64_t nsub = padded_items(fused_sample_items(n_items, n));
-    const int64_t FUSED_ROWS = fused_rows(nsub);
+    const bool cmax = cmax_usable(n_items, n);
+    const int64_t FUSED_ROWS = fused_rows(nsub, !cmax);
     const int64_t rows = n_users < FUSED_ROWS ? n_users : FUSED_ROWS;
     FusedLayout L;
     size_t off = 0;
-    L.off_sub = off;
-    off += align_up((size_t)rows * nsub * 4, 256);
+    L.off_sub = off;  // the sample panel, or 256 class maxima per row
+    off += align_up((size_t)rows * (cmax ? 256 : nsub) * 4, 256);
     L.off_tau = off;
     off += align_up((size_t)rows * 4, 256);
     L.off_cnt = off;
@@ -2242,7 +2259,8 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
         const int64_t n_sub = lk::fused_sample_items(n_items, n);
         const int64_t ld_sub = lk::padded_items(n_sub);
         const int r_tau = lk::fused_tau_rank(n_items, n);
-        const int64_t FUSED_ROWS = lk::fused_rows(ld_sub);
+        const bool use_cmax = lk::cmax_usable(n_items, n);
+        const int64_t FUSED_ROWS = lk::fused_rows(ld_sub, !use_cmax);
         const int64_t batches = (n_users + FUSED_ROWS - 1) / FUSED_ROWS;
         LK_HIP_CHECK(hipMemsetAsync(redo, 0, sizeof(int), st));
         // the sample rows of the item factors, contiguous
@@ -2258,7 +2276,6 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
             // stage 1 for rows [r0, r0 + nr) of the batch: threshold from the sample
             const int words = (int)((n_sub + 31) / 32);
             const size_t cmax_lds = (size_t)(words + lk::CMAX_LDS_EXTRA) * 16;  // 4 waves
-            const bool use_cmax = lk::stage1_cmax() && cmax_lds <= 65536;
             auto stage1 = [&](int64_t r0, int64_t nr, hipStream_t s) {
                 const float *uu = ub_users + r0 * ld_users;
                 if (use_cmax) {

@@ -263,3 +263,30 @@ def test_score_topk_fused_non_finite_scores(gpu, rng, monkeypatch, variant):
     assert np.array_equal(sc2.cpu().numpy().view(np.uint32), sc.cpu().numpy().view(np.uint32))
     sc = sc.cpu().numpy()
     assert not np.isnan(sc[idx.cpu().numpy() >= 0]).any()
+
+
+def test_score_topk_fused_in_batches(gpu, rng, monkeypatch):
+    """Several batches of the fused path (LK_TOPK_FUSED_ROWS; a million-item catalogue or more than
+    262 144 users in production): per-batch thresholds, candidate lists, second-tier lists and
+    output offsets -- the panel path's lists, bit for bit, with and without exclusions."""
+    from lkpy_amd import _device as D
+
+    monkeypatch.setenv("LK_TOPK_FUSED_MIN_USERS", "1")
+    monkeypatch.setenv("LK_TOPK_FUSED_ROWS", "8192")
+    B, I, k, n = 20000, 17000, 32, 20
+    U = rng.standard_normal((B, k)).astype(np.float32)
+    Q = (rng.standard_normal((I, k)) * (0.2 + rng.random((I, 1)))).astype(np.float32)
+    lens = rng.integers(0, 40, B)
+    lens[8191] = 9000   # a heavy row at the end of the first batch
+    lens[8192] = 3000   # and at the start of the second
+    ptr = np.zeros(B + 1, np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    ex = rng.integers(0, I, ptr[-1]).astype(np.int32)  # duplicates allowed, any order
+    dU, dQ = D.to_device_padded(U, gpu), D.to_device_padded(Q, gpu)
+    dptr, dex = torch.from_numpy(ptr).to(gpu), torch.from_numpy(ex).to(gpu)
+    got = [D.score_topk(dU, dQ, k, n, dptr, dex), D.score_topk(dU, dQ, k, n)]
+    monkeypatch.setenv("LK_TOPK_FUSED_MIN_ITEMS", "1000000000")  # the panel path
+    want = [D.score_topk(dU, dQ, k, n, dptr, dex), D.score_topk(dU, dQ, k, n)]
+    for (gi, gs), (wi, ws) in zip(got, want):
+        assert torch.equal(gi, wi)
+        assert torch.equal(gs.view(torch.int32), ws.view(torch.int32))
