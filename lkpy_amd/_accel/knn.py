@@ -82,7 +82,8 @@ def _score(sims, ref_items, ref_rates, tgt_items, max_nbrs, min_nbrs):
             rr_np = ref_rates.fill_null(0).to_numpy(zero_copy_only=False)
         else:
             rr_np = np.asarray(ref_rates)
-        rr = torch.from_numpy(np.ascontiguousarray(rr_np, dtype=np.float32)).to(dev)
+        # (an Arrow buffer's NumPy view is read-only: torch wants a writable array -- a copy)
+        rr = torch.from_numpy(np.array(rr_np, dtype=np.float32, order="C")).to(dev)
     one = lambda n: torch.tensor([0, n], dtype=torch.int64, device=dev)  # noqa: E731
     s, c = D.iknn_score_batch(dsims, one(len(ri)), torch.from_numpy(ri).to(dev), rr,
                               one(len(ti)), torch.from_numpy(ti).to(dev), max_nbrs, min_nbrs)
