@@ -1599,10 +1599,17 @@ def main():
 
         res = {}
         if not args.no_topk:
-            hp = eng.u_plan.csr.full_h_indptr.astype(np.int64)
-            excl_ptr = torch.from_numpy(hp).to(dev)
+            hp = eng.u_plan.csr.full_h_indptr
+            if hp is None:  # LK_ALS_SETUP=sharded: no rank holds every user's row
+                from lkpy_amd._als_engine import relabelled_user_lists
+
+                hp, ex = relabelled_user_lists(ratings, eng.u_old, eng.i_new)
+                excl_idx = torch.from_numpy(ex).to(dev)
+            else:
+                excl_idx = eng.u_plan.csr.indices
+            excl_ptr = torch.from_numpy(hp.astype(np.int64)).to(dev)
             run = lambda: _sharded.score_topk_sharded(  # noqa: E731
-                eng.P, eng.Q, k, 100, excl_ptr, eng.u_plan.csr.indices, collect=False)
+                eng.P, eng.Q, k, 100, excl_ptr, excl_idx, collect=False)
             run()
             tb = timed(run)
             fl = 2.0 * eng.P.shape[0] * eng.Q.shape[0] * k

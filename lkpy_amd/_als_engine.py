@@ -98,6 +98,93 @@ def _relabel_csr(mat: sps.csr_array, row_new_of_old, n_rows_new, col_new_of_old,
     return out
 
 
+def shard_local_blocks(indptr: torch.Tensor, indices: torch.Tensor, values: torch.Tensor,
+                       u_old: np.ndarray, u_new: np.ndarray, i_new: np.ndarray,
+                       u_blocks, i_blocks, by_new_user: bool):
+    """
+    Per-rank set-up (``LK_ALS_SETUP=sharded``): the rows THIS rank solves, in both orientations,
+    cut out of the original CSR without ever forming the relabelled matrix or its transpose in
+    full.  Plain torch on whatever device the arrays live on (HBM in the product, host tensors in
+    the gloo tests), so the same code is exercised on CPU:
+
+    * user side: the rank's user rows (``u_blocks``: ranges of NEW row numbers; ``u_old[new]`` =
+      original row or -1 for padding) gathered in dealt order, columns mapped by ``i_new``, the
+      order of a row's entries kept -- what ``lk_csr_relabel`` does for all rows;
+    * item side: ONE pass over the entries keeps those whose new item number falls into
+      ``i_blocks`` (nnz / world of them), their original user comes from a search in the offsets,
+      and a stable sort by (local item row, user) lists every item row's entries by ascending
+      ORIGINAL user (``by_new_user=False``: the reference's order, _common.py:216-219) or by
+      ascending new user (``True``: what the full stable transpose of the relabelled matrix gives
+      in ``accurate`` mode); the user numbers are then relabelled by ``u_new``.
+
+    Returns ``{"u": (h_ptr, ptr, idx, val), "i": (...)}``: offsets over the rank's rows in block
+    order (host NumPy + device), int32 indices, float32 values -- entry for entry the rows
+    ``make_plans_on_device`` would view out of the full matrices.
+    """
+    dev = indices.device
+    n_u0 = len(u_new)
+    ptr64 = indptr.to(torch.int64)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)  # noqa: E731
+    d_i_new = t(i_new, torch.int64)
+
+    # ---- user side: gather the rank's rows
+    rows_new = np.concatenate([np.arange(lo, hi, dtype=np.int64) for lo, hi in u_blocks])
+    src_row = u_old[rows_new]  # original row, -1 = padding
+    d_src = t(np.maximum(src_row, 0), torch.int64)
+    lens = (ptr64[d_src + 1] - ptr64[d_src]) * t(src_row >= 0, torch.int64)
+    u_ptr = torch.zeros(len(rows_new) + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=u_ptr[1:])
+    total = int(u_ptr[-1])
+    # entry e of local row r sits at source position start[r] + (e - u_ptr[r])
+    shift = torch.repeat_interleave(ptr64[d_src] - u_ptr[:-1], lens, output_size=total)
+    pos = torch.arange(total, dtype=torch.int64, device=dev) + shift
+    u_idx = d_i_new[indices[pos].to(torch.int64)].to(torch.int32)
+    u_val = values[pos]
+
+    # ---- item side: the entries of the rank's items, by (item row, user)
+    ni = int(i_new.max()) + 1 if len(i_new) else 0
+    ni = max(ni, max((hi for _, hi in i_blocks), default=0))
+    loc_of_new = torch.full((ni,), -1, dtype=torch.int64, device=dev)
+    rows_i = np.concatenate([np.arange(lo, hi, dtype=np.int64) for lo, hi in i_blocks])
+    loc_of_new[t(rows_i, torch.int64)] = torch.arange(len(rows_i), dtype=torch.int64, device=dev)
+    loc = loc_of_new[d_i_new[indices.to(torch.int64)]]
+    sel = torch.nonzero(loc >= 0).flatten()  # ascending position = ascending original user
+    loc = loc[sel]
+    orig_user = torch.searchsorted(ptr64, sel, right=True) - 1
+    user = t(u_new, torch.int64)[orig_user] if by_new_user else orig_user
+    order = torch.sort(loc * max(n_u0, int(u_new.max()) + 1 if n_u0 else 1) + user,
+                       stable=True).indices
+    counts = torch.bincount(loc, minlength=len(rows_i))
+    i_ptr = torch.zeros(len(rows_i) + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=i_ptr[1:])
+    i_idx = t(u_new, torch.int64)[orig_user[order]].to(torch.int32)
+    i_val = values[sel[order]]
+    return {"u": (u_ptr.cpu().numpy(), u_ptr, u_idx, u_val),
+            "i": (i_ptr.cpu().numpy(), i_ptr, i_idx, i_val)}
+
+
+def relabelled_user_lists(ui: sps.csr_array, u_old: np.ndarray, i_new: np.ndarray):
+    """
+    (offsets int64, items int32) of ALL user rows in the engine's row order with the engine's item
+    numbers -- the exclusion lists of a top-N call on ``eng.P`` / ``eng.Q``.  With the default
+    set-up every rank has them on the device (``eng.u_plan.csr.full_h_indptr`` / ``.indices``);
+    with ``LK_ALS_SETUP=sharded`` no rank does, and whoever scores all users builds them here.
+    """
+    ui = sps.csr_array(ui)
+    src = np.maximum(u_old, 0)
+    lens = np.where(u_old >= 0, np.diff(ui.indptr)[src], 0).astype(np.int64)
+    ptr = np.zeros(len(u_old) + 1, dtype=np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    pos = np.arange(ptr[-1], dtype=np.int64) + np.repeat(ui.indptr[src].astype(np.int64) - ptr[:-1],
+                                                         lens)
+    return ptr, i_new[ui.indices[pos]].astype(np.int32)
+
+
+def sharded_setup() -> bool:
+    "LK_ALS_SETUP=sharded: every rank derives only its own rows (default: the full matrices)"
+    return os.environ.get("LK_ALS_SETUP", "").strip().lower() == "sharded"
+
+
 class TorchComm:
     """The engine's collectives on ``torch.distributed`` (backend ``nccl`` = RCCL on the GPU boxes).
 
@@ -361,6 +448,48 @@ class HipBackend:
         ip, innz = plans(iu_new, h_iptr, i_rng, nu)
         return up, ip, (unnz, innz)
 
+    def make_plans_sharded(self, ui, u_old, u_new, i_new, n_items_new, u_rng, i_rng):
+        """
+        ``LK_ALS_SETUP=sharded`` (world > 1): the plans of this rank's rows from arrays that hold
+        ONLY this rank's rows -- one upload of the original CSR, then :func:`shard_local_blocks`
+        (the user rows gathered, the item rows cut out of one pass over the entries and sorted):
+        nothing of the size of the whole relabelled matrix or its transpose is built, the original
+        is released, and what stays resident is nnz / world entries per orientation.  Same entry
+        order per row as ``make_plans_on_device``; ``u_rng`` / ``i_rng`` as there.
+        """
+        D = self.D
+        dev = self.dev
+        if isinstance(ui, D.DeviceCSR):
+            src = ui
+        else:
+            src = D.DeviceCSR.from_arrays(ui.indptr, ui.indices, ui.data, ui.shape, dev)
+        ub = [u_rng] if isinstance(u_rng, tuple) else list(u_rng)
+        ib = [i_rng] if isinstance(i_rng, tuple) else list(i_rng)
+        out = shard_local_blocks(src.indptr, src.indices, src.values, u_old, u_new, i_new, ub, ib,
+                                 by_new_user=self.order_mode == "accurate")
+        pdt = src.h_indptr.dtype
+        tdt = torch.int64 if pdt == np.int64 else torch.int32
+        del src
+
+        def plans(arrs, blocks, n_cols):
+            h_ptr, d_ptr, idx, val = arrs
+            h_ptr = h_ptr.astype(pdt)
+            d_ptr = d_ptr.to(tdt)
+            full = D.DeviceCSR(d_ptr, idx, val, (len(h_ptr) - 1, n_cols), h_ptr)
+            ps, lo = [], 0
+            for b_lo, b_hi in blocks:  # the rank's blocks lie one behind the other in its arrays
+                hi = lo + (b_hi - b_lo)
+                view = D.DeviceCSR(full.indptr[lo : hi + 1], full.indices, full.values,
+                                   (hi - lo, n_cols), h_ptr[lo : hi + 1])
+                view.full_h_indptr = None  # no rank holds the offsets of all rows
+                ps.append(D.ALSPlan(view, self.k, self.solver, reference_order=self.order_mode))
+                lo = hi
+            return (ps[0] if len(ps) == 1 else D.ALSPlanGroup(ps, n_cols)), int(h_ptr[-1])
+
+        up, unnz = plans(out["u"], ub, n_items_new)
+        ip, innz = plans(out["i"], ib, len(u_old))
+        return up, ip, (unnz, innz)
+
     def upload(self, mat: np.ndarray) -> torch.Tensor:
         return self.D.to_device_padded(mat, self.dev)
 
@@ -499,14 +628,47 @@ class ImplicitALSEngine:
         self.i_supers = [(s_ * W * im, (s_ + 1) * W * im) for s_ in range(S)]
         self.u_lo, self.u_hi = self.u_blocks[0]  # (the whole block of the rank when S == 1)
         self.i_lo, self.i_hi = self.i_blocks[0]
+        # LK_ALS_SETUP=sharded (more than one rank): each rank derives only its own rows
+        self.sharded_setup = self.world > 1 and sharded_setup()
         if hasattr(backend, "make_plans_on_device"):
             # product path: one upload, relabel + transpose in HBM
-            self.u_plan, self.i_plan, self.local_nnz = backend.make_plans_on_device(
-                ui, self.u_old, self.i_new, self.i_old,
-                self.u_blocks[0] if S == 1 else self.u_blocks,
-                self.i_blocks[0] if S == 1 else self.i_blocks, ilen)
+            if self.sharded_setup and hasattr(backend, "make_plans_sharded"):
+                self.u_plan, self.i_plan, self.local_nnz = backend.make_plans_sharded(
+                    ui, self.u_old, self.u_new, self.i_new, ni,
+                    self.u_blocks[0] if S == 1 else self.u_blocks,
+                    self.i_blocks[0] if S == 1 else self.i_blocks)
+            else:
+                self.u_plan, self.i_plan, self.local_nnz = backend.make_plans_on_device(
+                    ui, self.u_old, self.i_new, self.i_old,
+                    self.u_blocks[0] if S == 1 else self.u_blocks,
+                    self.i_blocks[0] if S == 1 else self.i_blocks, ilen)
             self.u_plans = [self.u_plan] if S == 1 else self.u_plan.plans
             self.i_plans = [self.i_plan] if S == 1 else self.i_plan.plans
+        elif self.sharded_setup:  # the same per-rank set-up on host tensors (gloo tests)
+            assert not on_device
+            out = shard_local_blocks(
+                torch.from_numpy(ui.indptr.astype(np.int64)),
+                torch.from_numpy(ui.indices.astype(np.int32)),
+                torch.from_numpy(np.ascontiguousarray(ui.data, dtype=np.float32)),
+                self.u_old, self.u_new, self.i_new, self.u_blocks, self.i_blocks,
+                by_new_user=True)
+
+            def host_plans(arrs, blocks, n_cols):
+                h_ptr, _, idx, val = arrs
+                ps, lo = [], 0
+                for b_lo, b_hi in blocks:
+                    hi = lo + (b_hi - b_lo)
+                    a, b = int(h_ptr[lo]), int(h_ptr[hi])
+                    ps.append(backend.make_plan(sps.csr_array(
+                        (val[a:b].numpy(), idx[a:b].numpy(), h_ptr[lo : hi + 1] - a),
+                        shape=(hi - lo, n_cols))))
+                    lo = hi
+                return ps, int(h_ptr[-1])
+
+            self.u_plans, unnz = host_plans(out["u"], self.u_blocks, ni)
+            self.i_plans, innz = host_plans(out["i"], self.i_blocks, nu)
+            self.u_plan, self.i_plan = self.u_plans[0], self.i_plans[0]
+            self.local_nnz = (unnz, innz)
         else:  # host restatement (CPU / gloo tests of the sharding logic)
             assert not on_device
             ui_new = _relabel_csr(ui, self.u_new, nu, self.i_new, ni)

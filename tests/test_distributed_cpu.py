@@ -57,15 +57,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, ui, k, P0, Q0, epochs, out, explicit=False, slices=0):
+def _worker(rank, world, port, ui, k, P0, Q0, epochs, out, explicit=False, slices=0,
+            setup="full"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["LK_ALS_OVERLAP_SLICES"] = str(slices)
+    os.environ["LK_ALS_SETUP"] = setup
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lkpy_amd._als_engine import ImplicitALSEngine
 
         eng = ImplicitALSEngine(ui, k, 0.1, 0.2, P0, Q0, OracleBackend(k), explicit=explicit)
+        assert eng.sharded_setup == (setup == "sharded")
         assert eng.slices == (slices if slices > 0 else 1) and len(eng.u_plans) == eng.slices
         deltas = []
         for _ in range(epochs):
@@ -108,8 +111,11 @@ def test_deal_rows_balances_and_round_trips():
                 assert max(blk) - min(blk) <= 2 * lens.max() + lens.sum() // (world * 50)
 
 
-@pytest.mark.parametrize("world,slices", [(2, 0), (2, 3)])
-def test_sharded_engine_matches_single_process(oracle, world, slices):
+@pytest.mark.parametrize("world,slices,setup", [(2, 0, "full"), (2, 3, "full"),
+                                                (2, 0, "sharded"), (2, 3, "sharded")])
+def test_sharded_engine_matches_single_process(oracle, world, slices, setup):
+    """(``setup = "sharded"``: LK_ALS_SETUP=sharded -- every rank cuts only its own rows out of the
+    original matrix, ``shard_local_blocks``; same factors, same per-rank entry counts)"""
     rng = np.random.default_rng(5)
     n_users, n_items, k, epochs = 301, 157, 8, 3
     dense = rng.random((n_users, n_items)) < 0.06
@@ -135,8 +141,8 @@ def test_sharded_engine_matches_single_process(oracle, world, slices):
     port = _free_port()
     # (slices = 3: the half-epochs run slice by slice with asynchronous gloo all-gathers of the
     # interleaved super-blocks)
-    mp.spawn(_worker, args=(world, port, ui, k, P0, Q0, epochs, out, False, slices), nprocs=world,
-             join=True)
+    mp.spawn(_worker, args=(world, port, ui, k, P0, Q0, epochs, out, False, slices, setup),
+             nprocs=world, join=True)
     assert sorted(out.keys()) == list(range(world))
     for r in range(world):
         gP, gQ, gO, gd, lnnz = out[r]
@@ -328,6 +334,71 @@ def test_topk_sharded_world2(oracle, rng):
         s = oracle.score_dense(Q, P[u])
         assert np.array_equal(idx[u], oracle.argtopn(s, n))
         assert np.array_equal(sc[u], s[idx[u]])
+
+
+@pytest.mark.parametrize("world,S", [(2, 1), (3, 2), (2, 3)])
+def test_shard_local_blocks_are_the_rows_of_the_full_relabelling(world, S):
+    """The per-rank set-up (``shard_local_blocks``, plain torch: the product runs it on HBM
+    tensors): a rank's user rows = the original rows in dealt order with mapped columns and the
+    entry order kept; its item rows = the columns of the original matrix with the entries by
+    ascending ORIGINAL user (the reference's order) or ascending new user -- entry for entry what
+    the full relabel + stable transpose lists for those rows; padding rows are empty."""
+    from lkpy_amd._als_engine import deal_rows, shard_local_blocks
+
+    rng = np.random.default_rng(3)
+    n_users, n_items = 301, 157
+    dense = rng.random((n_users, n_items)) < 0.06
+    dense[:, 5] = False
+    dense[7, :] = False
+    ui = sps.csr_array(dense * rng.random((n_users, n_items)).astype(np.float32))
+    ui.eliminate_zeros()
+    ui.sort_indices()
+    csc = sps.csc_array(ui)
+    u_new, u_old, u_rpr = deal_rows(np.diff(ui.indptr), world, S)
+    i_new, i_old, i_rpr = deal_rows(np.bincount(ui.indices, minlength=n_items), world, S)
+    um, im = u_rpr // S, i_rpr // S
+    seen_u = seen_i = 0
+    for r in range(world):
+        ub = [(s_ * world * um + r * um, s_ * world * um + (r + 1) * um) for s_ in range(S)]
+        ib = [(s_ * world * im + r * im, s_ * world * im + (r + 1) * im) for s_ in range(S)]
+        for by_new in (True, False):
+            out = shard_local_blocks(torch.from_numpy(ui.indptr.astype(np.int64)),
+                                     torch.from_numpy(ui.indices.astype(np.int32)),
+                                     torch.from_numpy(ui.data), u_old, u_new, i_new, ub, ib, by_new)
+            hp, _, idx, val = out["u"]
+            for loc, rn in enumerate(np.concatenate([np.arange(lo, hi) for lo, hi in ub])):
+                o = u_old[rn]
+                gi, gv = idx[hp[loc]:hp[loc + 1]].numpy(), val[hp[loc]:hp[loc + 1]].numpy()
+                if o < 0:
+                    assert len(gi) == 0
+                    continue
+                seg = slice(ui.indptr[o], ui.indptr[o + 1])
+                assert np.array_equal(gi, i_new[ui.indices[seg]]) and np.array_equal(gv, ui.data[seg])
+            seen_u += int(hp[-1]) if by_new else 0
+            hp, _, idx, val = out["i"]
+            for loc, rn in enumerate(np.concatenate([np.arange(lo, hi) for lo, hi in ib])):
+                o = i_old[rn]
+                gi, gv = idx[hp[loc]:hp[loc + 1]].numpy(), val[hp[loc]:hp[loc + 1]].numpy()
+                if o < 0:
+                    assert len(gi) == 0
+                    continue
+                seg = slice(csc.indptr[o], csc.indptr[o + 1])  # ascending original user
+                wi, wv = u_new[csc.indices[seg]], csc.data[seg]
+                if by_new:
+                    p = np.argsort(wi, kind="stable")
+                    wi, wv = wi[p], wv[p]
+                assert np.array_equal(gi, wi) and np.array_equal(gv, wv)
+            seen_i += int(hp[-1]) if by_new else 0
+    assert seen_u == ui.nnz and seen_i == ui.nnz  # the ranks' rows partition the matrix
+    # the exclusion lists of a top-N call over all users (bench's sharded leg under this set-up)
+    from lkpy_amd._als_engine import relabelled_user_lists
+
+    ptr, ex = relabelled_user_lists(ui, u_old, i_new)
+    assert ptr[-1] == ui.nnz and len(ptr) == len(u_old) + 1
+    for rn in range(0, len(u_old), 7):
+        o = u_old[rn]
+        want = i_new[ui.indices[ui.indptr[o]:ui.indptr[o + 1]]] if o >= 0 else np.zeros(0, np.int64)
+        assert np.array_equal(ex[ptr[rn]:ptr[rn + 1]], want)
 
 
 def test_balanced_ranges_edge_cases():

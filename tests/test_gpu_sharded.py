@@ -39,6 +39,9 @@ def _run_world(world, ui, k, P0, Q0, gpu, epochs):
                                     HipBackend(k, gpu, _native.SOLVER_CHOLESKY), comm=comms[r])
             assert eng.world == world and eng.rank == r and eng.collective
             assert len(eng.u_plans) == eng.slices and len(eng.i_plans) == eng.slices
+            if eng.sharded_setup:  # the rank's arrays hold its own rows and nothing else
+                assert eng.u_plans[0].csr.indices.numel() == eng.local_nnz[0]
+                assert eng.i_plans[0].csr.indices.numel() == eng.local_nnz[1]
             for _ in range(epochs):
                 du, di = eng.train_epoch()
             eng.check()
@@ -71,12 +74,17 @@ def _short_row_matrix(rng, n_users, n_items, mean_len):
                          shape=(n_users, n_items))
 
 
-@pytest.mark.parametrize("world,k,wb,slices", [(2, 32, False, 1), (3, 64, False, 1),
-                                               (2, 128, True, 1), (3, 256, True, 1),
-                                               (3, 128, False, 1), (2, 64, False, 4),
-                                               (3, 128, True, 3), (2, 256, True, 2)])
-def test_sharded_device_path_on_one_gpu(gpu, oracle, monkeypatch, world, k, wb, slices):
+@pytest.mark.parametrize("world,k,wb,slices,setup", [
+    (2, 32, False, 1, "full"), (3, 64, False, 1, "full"), (2, 128, True, 1, "full"),
+    (3, 256, True, 1, "full"), (3, 128, False, 1, "full"), (2, 64, False, 4, "full"),
+    (3, 128, True, 3, "full"), (2, 256, True, 2, "full"),
+    # LK_ALS_SETUP=sharded: every rank derives only its own rows (shard_local_blocks on HBM
+    # tensors: gather, searchsorted, stable sort), plans on arrays that hold nnz / world entries
+    (3, 64, False, 1, "sharded"), (2, 64, False, 4, "sharded"), (3, 128, True, 3, "sharded")])
+def test_sharded_device_path_on_one_gpu(gpu, oracle, monkeypatch, world, k, wb, slices, setup):
     import torch
+
+    monkeypatch.setenv("LK_ALS_SETUP", setup)
 
     from lkpy_amd import _native, synth
     from lkpy_amd._als_engine import HipBackend, ImplicitALSEngine
