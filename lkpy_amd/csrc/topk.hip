@@ -1895,12 +1895,13 @@ static int64_t score_batch()
 static int64_t padded_items(int64_t n_items) { return (n_items + 63) / 64 * 64; }
 
 // ---- fused scoring + selection (never materialises the B x I score matrix) -----------------
-// Stage 1: a strided SAMPLE of the items (every stride-th, about a sixteenth of the catalogue) is
-// scored into a small panel; tau_b = the r-th best of the row's valid sample scores.  r = n
-// would make tau_b a certain lower bound of the row's n-th best overall (16 n candidates per
-// row); instead r is the smallest rank for which "fewer than n items of the whole catalogue
-// reach tau_b" is a 1e-6 event per row under the sampling (binomial tail, fused_tau_rank):
-// r = 21 for n = 100 -- ~330 candidates per row to compact, append, hash and sort.  Stage 2:
+// Stage 1: a strided SAMPLE of the items (every stride-th, about 1 / 24 of the catalogue) is
+// scored -- class maxima kept in the GEMM's epilogue (round 5), or a small panel (the fallback);
+// tau_b = the r-th best of the row's valid sample classes.  r = n would make tau_b a certain
+// lower bound of the row's n-th best overall (24 n candidates per row); instead r is the
+// smallest rank for which "fewer than n items of the whole catalogue reach tau_b" is a 1e-6
+// event per row under the sampling (binomial tail, fused_tau_rank): r = 18 for n = 100 at
+// ML-25M's 1 / 22 -- ~400 candidates per row to append, hash and select from.  Stage 2:
 // the full GEMM, whose epilogue appends the entries >= tau_b to the row's candidate list.
 // Stage 3: exclusions struck out, exact (score desc, index asc) order among the candidates;
 // a row that ends up with fewer than n valid candidates (the rare event above, an overflowing
@@ -1984,7 +1985,7 @@ static bool use_fused(int64_t n_users, int64_t n_items, int32_t n, int kp = SC_K
            kp <= 256;
 }
 
-// target size of the stage-1 sample: a sixteenth of the catalogue, at least 16 n, a multiple of 256
+// target size of the stage-1 sample: catalogue / 24 (LK_TOPK_SAMPLE_DIV), at least 16 n, a multiple of 256
 static int64_t fused_sub_items(int64_t n_items, int32_t n)
 {
     const char *e = getenv("LK_TOPK_SAMPLE_DIV");  // tuning knob: catalogue / sample size
