@@ -48,6 +48,10 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: peak FP3
 HBM_PEAK_GBS = 8000.0  # same guide: HBM3E peak 8 TB/s
 LONG_ROW = int(os.environ.get("LK_BENCH_LONG_ROW", 2048))  # LK_ALS_LONG_ROW (csrc/als_plan.h)
 CHUNK = 1024  # LK_ALS_CHUNK
+# the CG leg's stopping rule ||r|| <= tol ||y||: the error of a row is up to cond(A) * tol, and
+# cond(A) ~ 200 on the trained state -- 1e-6 (rounds 3-5) left the worst item rows AT 1e-4
+# (9.6e-5 in the driver's run, 23 rows over in another); 2.5e-7 keeps them under 5e-5
+CG_TOL = float(os.environ.get("LK_BENCH_CG_TOL", 2.5e-7))
 
 
 WB_MAX_N = 128  # rows this short take the Woodbury kernels at padded k = 256 (csrc/als_wb.hip:
@@ -361,7 +365,7 @@ def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
     return par, cpu
 
 
-def fit_leg(ratings, k, epochs, weight):
+def fit_leg(ratings, k, epochs, weight, keep: dict | None = None):
     """
     ``ImplicitMFScorer(embedding_size=k, epochs=epochs).train(dataset)``: the call
     ``north_star`` names, end to end, and the per-epoch wall times the reference logs
@@ -405,6 +409,8 @@ def fit_leg(ratings, k, epochs, weight):
         training._log.removeHandler(tap)
         training._log.setLevel(old_level)
     assert scorer.item_embeddings.shape == (n_items, k)
+    if keep is not None:
+        keep["scorer"], keep["ds"] = scorer, ds  # the recommend leg serves from this model
     ep = tap.times
     return {
         "what": f"ImplicitMFScorer(embedding_size={k}, epochs={epochs}).train(dataset), host "
@@ -414,6 +420,176 @@ def fit_leg(ratings, k, epochs, weight):
         "epochs_per_s_from_log": round(len(ep[1:]) / sum(ep[1:]), 2) if len(ep) > 1 else None,
         "setup_and_download_seconds": round(fit - sum(ep), 4) if ep else None,
     }
+
+
+
+def recommend_leg(scorer, ds, n_users=10000, n=100, no_cpu=False):
+    """
+    ``pipelines/als-implicit.toml``'s recommend path for a BATCH of users at the cfg2 scale, as
+    the reference runs it per query (src/lenskit/batch/_runner.py:283-308): training history
+    (basic/history.py:77-95) -> the user re-solved from that history (``new_user_embedding``,
+    als/_implicit.py:77-130, ``_OtOr`` from the trained state) -> scores of all items
+    (als/_common.py:159-170) -> candidates minus the history (basic/candidates.py:77-94) ->
+    top-``n`` (accel/data/sorting.rs:132-172).  Here: ``UserTrainingHistoryLookup.batch`` +
+    ``ImplicitMFScorer.recommend_batch`` -- one row-gather launch, one fold-in half-epoch, one
+    fused score + top-N call.  The model is the one the ``fit`` leg trained through the component.
+    """
+    import torch
+
+    from lkpy_amd import _device as D
+    from lkpy_amd import batch as lk_batch
+    from lkpy_amd.basic import UserTrainingHistoryLookup
+    from lkpy_amd.pipeline import Pipeline
+
+    pipe = Pipeline.load_config(ROOT / "tests" / "golden" / "pipelines" / "als-implicit.toml")
+    pipe.node("scorer").component = scorer           # the trained model in the TOML's pipeline
+    lookup = pipe.node("history-lookup").component
+    lookup.train(ds)
+    pipe.node("candidate-selector").component.train(ds)
+    rng = np.random.default_rng(11)
+    users = rng.choice(ds.users.ids(), min(n_users, ds.user_count), replace=False)
+    k = scorer.config.embedding_size
+    dev = D.device()
+    sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
+
+    scorer.recommend_batch(lookup.batch(users[:512]), n)  # uploads: training matrix, Q, OtOr
+    walls, walls_ilc = [], []
+    for _ in range(5):
+        sync()
+        t0 = time.perf_counter()
+        hb = lookup.batch(users)
+        g_idx, g_sc = scorer.recommend_batch(hb, n)
+        walls.append(time.perf_counter() - t0)
+    for _ in range(3):
+        sync()
+        t0 = time.perf_counter()
+        ilc = lk_batch.recommend(pipe, users, n)
+        walls_ilc.append(time.perf_counter() - t0)
+    wall = min(walls)
+    assert len(ilc) == len(users) and len(ilc.lookup(users[0].item())) == n
+
+    # the device work of the same call, piece by piece, on the launch stream (torch's current
+    # stream IS the stream every lk_* call is given): HIP events around each piece, a spin kernel
+    # ahead of it so the host is done enqueuing before the first kernel of the piece starts
+    st = scorer._device_state()
+    hb = lookup.batch(users)
+    lens = hb.lengths
+
+    def timed(fn, reps=5):
+        best = None
+        for _ in range(reps):
+            sync()
+            torch.cuda._sleep(4_000_000)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            res = fn()
+            b.record()
+            sync()
+            ms = a.elapsed_time(b)
+            best = ms if best is None or ms < best else best
+        return best, res
+
+    src = lookup._device_matrix()["csr"]
+    if not scorer.config.use_ratings:  # implicit: the constant weight, no rating read
+        src = D.DeviceCSR(src.indptr, src.indices, None, src.shape, src.h_indptr)
+    t_gather, hist = timed(lambda: D.gather_rows(src, hb.user_nums, scale=scorer.config.weight))
+    plan = D.ALSPlan(hist, k, scorer._solver())
+    u = torch.zeros((len(users), plan.kp), dtype=torch.float32, device=dev)
+    t_fold, _ = timed(lambda: plan.half_epoch(u, st["Q"], st["OtOr"]))
+    plan.check_status()
+    t_topk, (d_idx, d_sc) = timed(lambda: D.score_topk(u, st["Q"], k, n, hist.indptr,
+                                                        hist.indices))
+    gpu_ms = t_gather + t_fold + t_topk
+    t_down0 = time.perf_counter()
+    D.to_host(torch.cat([d_idx.view(torch.float32), d_sc], dim=1))
+    t_down = time.perf_counter() - t_down0
+    fold_flops = sum(half_flops(lens, k))
+    topk_flops = 2.0 * len(users) * len(ds.items) * k
+    res = {
+        "metric": "als-implicit.toml batch recommend: %d users' training histories -> batched "
+                  "fold-in -> scores of all %d items -> top-%d without the history, seconds"
+                  % (len(users), len(ds.items), n),
+        "value": round(wall, 5), "unit": "s", "higher_is_better": False,
+        "users": int(len(users)), "users_per_s": round(len(users) / wall, 1),
+        "history_entries": int(lens.sum()),
+        "call": "scorer.recommend_batch(lookup.batch(users), n): user ids in, host [B x n] item "
+                "numbers + scores out (download included)",
+        "seconds_through_batch_recommend": round(min(walls_ilc), 5),
+        "device_ms": {"gather_histories": round(t_gather, 4), "fold_in": round(t_fold, 4),
+                      "score_topn": round(t_topk, 4), "sum": round(gpu_ms, 4)},
+        "download_seconds": round(t_down, 5),
+        "host_seconds": round(max(wall - gpu_ms / 1e3 - t_down, 0.0), 5),
+        "host_fraction_of_call": round(max(wall - gpu_ms / 1e3 - t_down, 0.0) / wall, 4),
+        "roofline": {
+            "kernel": "the fold-in launch (lk_als_implicit_half_epoch over the histories' CSR)",
+            "bound": "mfma", "achieved": round(fold_flops / (t_fold * 1e-3) / 1e12, 3),
+            "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(fold_flops / (t_fold * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+            "algorithmic_flops": fold_flops, "traffic": None,
+            "score_topn_frac": round(topk_flops / (t_topk * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+            "note": "nnz (2k^2 + 2k) + rows (k^3/3 + 2k^2) over the batch's histories / HIP-event "
+                    "time of the launch; 10^4 rows fill the chip for a fraction of a millisecond, "
+                    "so launch ramp and tail are a visible part of it",
+        },
+    }
+    if no_cpu:
+        return res
+    from oracle import lk_oracle as lko
+    from oracle import parity
+
+    # the reference's per-query path on the host, from the same trained model
+    Q = np.ascontiguousarray(scorer.item_embeddings)
+    OtOr = np.ascontiguousarray(scorer._OtOr)
+    hp = ds._indptr
+    w32 = np.float32(scorer.config.weight)
+    u_gpu = D.to_host_unpadded(u, k)
+    nums = hb.user_nums
+    want_u = np.zeros_like(u_gpu)
+    t0 = time.perf_counter()
+    for r, un in enumerate(nums):
+        items = ds._cols[hp[un]:hp[un + 1]]
+        want_u[r] = lko.als_fold_in(items, np.full(len(items), w32, np.float32), Q, OtOr)
+    t_fold_cpu = time.perf_counter() - t0
+    num = np.linalg.norm(u_gpu.astype(np.float64) - want_u, axis=1)
+    den = np.linalg.norm(want_u.astype(np.float64), axis=1)
+    rel = num / np.maximum(den, 1e-300)
+    # lists: the oracle's score + exclusion + heap top-n FROM THE GPU'S query vectors
+    threads = lko.num_threads()
+    m = min(len(users), 4096)
+    ptr = np.zeros(m + 1, np.int64)
+    np.cumsum(lens[:m], out=ptr[1:])
+    ex = np.concatenate([ds._cols[hp[un]:hp[un + 1]] for un in nums[:m]]).astype(np.int32)
+    lko.score_topn_batch(Q, u_gpu[:threads], n, None, None, threads)  # page-in
+    t0 = time.perf_counter()
+    want_i, want_s = lko.score_topn_batch(Q, u_gpu[:m], n, ptr, ex, threads)
+    t_list_cpu = time.perf_counter() - t0
+    lists = parity.topn_accounting(np.asarray(g_idx)[:m], np.asarray(g_sc)[:m], want_i, want_s,
+                                   lambda r: lko.score_dense(Q, u_gpu[r]))
+    # one thread, the reference's loop: fold-in then score + top-n per query
+    m1 = min(m, 512)
+    t0 = time.perf_counter()
+    lko.score_topn_batch(Q, u_gpu[:m1], n, ptr[:m1 + 1], ex[:ptr[m1]], 1)
+    t_list_1 = (time.perf_counter() - t0) / m1
+    per_user_1 = t_fold_cpu / len(users) + t_list_1
+    res["cpu_baseline"] = {
+        "value": round(per_user_1 * len(users), 3), "unit": "s", "cores": 1, "kind": "port",
+        "sample": f"the reference's per-query loop on ONE thread (its batch runner's default "
+                  f"worker): fold-in of all {len(users)} users ({t_fold_cpu:.2f}s, NumPy + SciPy "
+                  f"cho_factor as _implicit.py:101-130) + score / exclusion / heap top-{n} of "
+                  f"{m1} users ({t_list_1 * m1:.2f}s), extrapolated by users",
+        "score_topn_all_threads_seconds": round(t_list_cpu / m * len(users), 3),
+        "threads": threads,
+    }
+    res["parity"] = {
+        "fold_in": {"rows_checked": int(len(rel)), "rows_over_1e-4": int((rel > 1e-4).sum()),
+                    "row_rel_max": float(rel.max()), "row_rel_p50": float(np.median(rel)),
+                    "ok": bool((rel <= 1e-4).all()),
+                    "criterion": "every fold-in vector within 1e-4 (relative, raw) of the "
+                                 "oracle's _train_new_row restatement from the same model"},
+        "lists": lists,
+        "ok": bool((rel <= 1e-4).all() and lists["ok"]),
+    }
+    return res
 
 
 def topk_cpu_and_parity(P, Q, ex_ptr, ex_idx, gpu_idx, gpu_sc, n, budget_s=10.0,
@@ -460,38 +636,10 @@ def topk_cpu_and_parity(P, Q, ex_ptr, ex_idx, gpu_idx, gpu_sc, n, budget_s=10.0,
            "sample": f"{done} of {n_users} users in {dt:.2f}s (score_dense + exclusion + heap "
            f"top-N per user, the reference's per-query path, queries spread over {threads} "
            "threads), extrapolated by users"}
-    got_i, got_s = gpu_idx[users], gpu_sc[users]
-    same = (got_i == want_i).all(axis=1)
-    # north_star: "integer top-K index sets bit-exact".  The sorted score rows must be bit-identical
-    # position by position and every listed item must really carry the listed score.  Where
-    # DIFFERENT items have the same score bits (duplicate factor rows: items with identical
-    # interaction patterns) the reference's heap decides by its internal sift order -- which of
-    # two equal scores it pops first inside the list, and, when the tie straddles the cut, which
-    # one it keeps (heap.rs:39-64 compares scores only; SURVEY.md section 8g item 8: unspecified);
-    # the GPU takes the lower item number.  Such rows are counted in the two `ties_*` fields,
-    # anything else in `mismatched_users`.
-    sc_same = bool(np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32)))
-    ties_in, ties_cut, bad = 0, 0, 0
-    for r in np.flatnonzero(~same):
-        u = users[r]
-        sc = lko.score_dense(Q, P[u])  # the oracle's score of every item for this user
-        g, w = got_i[r], want_i[r]
-        genuine = np.array_equal(sc[g[g >= 0]].view(np.uint32),
-                                 got_s[r][g >= 0].view(np.uint32))
-        rows_equal = np.array_equal(got_s[r].view(np.uint32), want_s[r].view(np.uint32))
-        if not (genuine and rows_equal):
-            bad += 1
-        elif np.array_equal(np.sort(g), np.sort(w)):
-            ties_in += 1   # same set, equal-score items in another order
-        else:
-            ties_cut += 1  # a tie at the cut: another item with the cut's score is listed
-    par = {"users_checked": int(done), "list_length": int(n),
-           "score_rows_bit_identical": sc_same,
-           "lists_identical": int(same.sum()),
-           "ties_ordered_differently_inside_list": int(ties_in),
-           "ties_resolved_differently_at_the_cut": int(ties_cut),
-           "mismatched_users": int(bad),
-           "ok": bool(sc_same and bad == 0)}
+    from oracle import parity
+
+    par = parity.topn_accounting(gpu_idx[users], gpu_sc[users], want_i, want_s,
+                                 lambda r: lko.score_dense(Q, P[users[r]]))
     return cpu, par
 
 
@@ -1256,6 +1404,21 @@ def compact_line(out: dict) -> dict:
     if isinstance(out.get("fit"), dict):
         legs["fit"] = _pick(out["fit"], "fit_seconds", "epochs_per_s_from_log",
                             "setup_and_download_seconds", "error")
+    rec = out.get("recommend")
+    if isinstance(rec, dict):
+        d = _pick(rec, "value", "unit", "users", "users_per_s", "seconds_through_batch_recommend",
+                  "device_ms", "host_fraction_of_call", "error")
+        d["metric"] = "als-implicit.toml batch recommend (history -> fold-in -> score -> top-100)"
+        d["roofline"] = _roof(rec.get("roofline"))
+        d["cpu_baseline"] = _cpu(rec.get("cpu_baseline"))
+        pr = rec.get("parity") or {}
+        d["parity"] = {"ok": pr.get("ok"),
+                       "fold_in": _pick(pr.get("fold_in") or {}, "rows_checked", "rows_over_1e-4",
+                                        "row_rel_max", "ok"),
+                       "lists": _pick(pr.get("lists") or {}, "users_checked",
+                                      "score_rows_bit_identical", "lists_identical",
+                                      "mismatched_users", "ok")}
+        legs["recommend"] = d
     if isinstance(out.get("cg"), dict):
         legs["cg"] = _pick(out["cg"], "exact_ms_per_epoch", "cg_ms_per_epoch",
                            "cg_iterations_per_row", "one_epoch_rel_diff_P", "one_epoch_rel_diff_Q",
@@ -1397,6 +1560,8 @@ def main():
     ap.add_argument("--no-knn", action="store_true", help="skip the item-kNN build leg")
     ap.add_argument("--no-topk", action="store_true", help="skip the dense top-N scoring leg")
     ap.add_argument("--no-fit", action="store_true", help="skip the end-to-end fit leg")
+    ap.add_argument("--no-recommend", action="store_true",
+                    help="skip the als-implicit.toml batch recommend leg (needs the fit leg)")
     ap.add_argument("--no-cg", action="store_true", help="skip the CG-solver comparison leg")
     ap.add_argument("--no-k128", action="store_true", help="skip the k = 128 leg (configs[3])")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg5 leg (configs[4])")
@@ -1666,8 +1831,8 @@ def main():
         for name, solver in (("exact", _native.SOLVER_CHOLESKY), ("cg", _native.SOLVER_CG)):
             e2 = ImplicitALSEngine(ui, k, reg, reg, Ph, Qh, HipBackend(k, dev, solver))
             if name == "cg":
-                e2.u_plan.set_cg(1.0e-6, 0)
-                e2.i_plan.set_cg(1.0e-6, 0)
+                e2.u_plan.set_cg(CG_TOL, 0)
+                e2.i_plan.set_cg(CG_TOL, 0)
             e2.train_epoch()
             e2.check()
             engs[name] = (e2.user_embeddings(), e2.item_embeddings())
@@ -1701,7 +1866,8 @@ def main():
         tr1, _ = pmc_traffic("r*_cg_k%d_counters.csv" % k, "als_cg_kernel<%d, false, 1>" % kp)
         tr = None if tr4 is None or tr1 is None else tr4 + tr1
         return {"what": "solver='cg' vs the exact solver, one epoch from the same trained "
-                "factors: Jacobi-preconditioned matrix-free CG (tol 1e-6, warm start) on the rows "
+                "factors: Jacobi-preconditioned matrix-free CG (tol %.1e, warm start) on the rows " % CG_TOL
+                +
                 "whose gathered factor rows stay in registers over the iterations (<= 16384 / k' "
                 "entries), the exact kernels on the longer rows (csrc/als_cg.hip)",
                 **out_cg,
@@ -1753,7 +1919,13 @@ def main():
         del eng  # free the engine's HBM before the other legs
         torch.cuda.empty_cache()
     if single and not args.no_fit:
-        leg("fit", lambda: fit_leg(ratings, k, 20, weight))  # configs[1]: 20 epochs
+        kept = {}
+        leg("fit", lambda: fit_leg(ratings, k, 20, weight, kept))  # configs[1]: 20 epochs
+        if kept and not args.no_recommend:
+            leg("recommend", lambda: recommend_leg(kept["scorer"], kept["ds"], 10000, 100,
+                                                   args.no_cpu))
+        kept.clear()
+        torch.cuda.empty_cache()
     if single and not args.no_knn:
         leg("knn", knn_leg)
         if isinstance(out.get("parity"), dict) and isinstance(out["knn"], dict):

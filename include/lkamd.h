@@ -572,6 +572,23 @@ int lk_csr_relabel(const void *d_indptr, int indptr_is_64, const int32_t *d_indi
                    const void *d_out_indptr, const int32_t *d_col_map, int32_t *d_out_indices,
                    float *d_out_values, void *stream);
 
+/* Row gather of a CSR matrix on the device: the histories of a BATCH of queries cut out of the
+ * training matrix in one launch.  Replaces, for a whole batch, the per-query
+ * `UserTrainingHistoryLookup.__call__` -> `MatrixRelationshipSet.row_items`
+ * (src/lenskit/basic/history.py:37-95) + the value vector of `ImplicitMFScorer.new_user_embedding`
+ * (src/lenskit/als/_implicit.py:77-99: `ratings * weight`, or `np.full(n, weight)`), which the
+ * reference's batch runner repeats query by query (src/lenskit/batch/_runner.py:283-308).
+ * Output row r takes the entries of input row d_rows[r] (-1: an empty row) in their stored order;
+ * d_out_indptr [n_rows_out + 1] (int64, the caller's prefix sums of the picked rows' lengths)
+ * says where; out value = (d_values[e] - d_col_bias[column]) * scale in float32 (d_values NULL:
+ * 1.0f in its place; d_col_bias NULL: nothing subtracted -- the item-kNN scorer mean-centres
+ * the history ratings this way, src/lenskit/knn/item.py:268-271; d_out_values NULL: structure
+ * only).  Asynchronous on `stream`. */
+int lk_csr_gather_rows(const void *d_indptr, int indptr_is_64, const int32_t *d_indices,
+                       const float *d_values, int64_t n_rows_out, const int32_t *d_rows,
+                       const int64_t *d_out_indptr, const float *d_col_bias, float scale,
+                       int32_t *d_out_indices, float *d_out_values, void *stream);
+
 /* ------------------------------------------------------------------------
  * Item-kNN rating normalisation (`ItemKNNScorer._center_ratings` / `_normalize_rows`,
  * src/lenskit/knn/item.py:202-228) on the ITEM-MAJOR matrix produced by lk_csr_transpose:

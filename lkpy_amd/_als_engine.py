@@ -181,8 +181,26 @@ def relabelled_user_lists(ui: sps.csr_array, u_old: np.ndarray, i_new: np.ndarra
 
 
 def sharded_setup() -> bool:
-    "LK_ALS_SETUP=sharded: every rank derives only its own rows (default: the full matrices)"
-    return os.environ.get("LK_ALS_SETUP", "").strip().lower() == "sharded"
+    """With more than one rank every rank derives only its OWN rows from the one upload of the
+    matrix (the default since round 6; bit-checked under gloo and with ranks as threads on one
+    GPU); ``LK_ALS_SETUP=full`` (or ``replicated``): every rank relabels and transposes the full
+    matrix, as rounds 1-5 did."""
+    v = os.environ.get("LK_ALS_SETUP", "").strip().lower()
+    if v in ("", "sharded"):
+        return True
+    if v in ("full", "replicated"):
+        return False
+    raise ValueError(f"unknown LK_ALS_SETUP {v!r} (sharded / full)")
+
+
+def sharded_z() -> bool:
+    "LK_ALS_Z=sharded: Z = other @ OtOr^-1 formed once across the ranks (default: on every rank)"
+    v = os.environ.get("LK_ALS_Z", "").strip().lower()
+    if v in ("", "replicated"):
+        return False
+    if v == "sharded":
+        return True
+    raise ValueError(f"unknown LK_ALS_Z {v!r} (replicated / sharded)")
 
 
 class TorchComm:
@@ -683,6 +701,21 @@ class ImplicitALSEngine:
 
         self._nu, self._ni = nu, ni
         self._qtq = None
+        # LK_ALS_Z=sharded: the Woodbury operand Z formed once across the ranks.  Whether a half
+        # takes it is decided for ALL ranks together (a rank whose own rows need no Z still owes
+        # the others its share of the rows): one small all-reduce at set-up
+        self._zs = {}
+        if (self.world > 1 and not self.explicit and sharded_z() and hasattr(backend, "kp")
+                and backend.kp in (128, 256) and hasattr(backend, "D")):
+            want = torch.tensor([float(any(getattr(p, "use_wb", False) for p in self.u_plans)),
+                                 float(any(getattr(p, "use_wb", False) for p in self.i_plans))],
+                                dtype=torch.float32, device=backend.dev)
+            self.comm.all_reduce(want)
+            want = want.cpu().numpy() > 0
+            if want[0]:  # user half: other = Q
+                self._zs["u"] = backend.D.ShardedZ(ni, self.k, backend.dev)
+            if want[1]:  # item half: other = P
+                self._zs["i"] = backend.D.ShardedZ(nu, self.k, backend.dev)
         if not defer_init:
             self.set_initial(user_init, item_init)
         self.epochs_trained = 0
@@ -745,6 +778,12 @@ class ImplicitALSEngine:
         """
         b = self.backend
         ds, handles = [], []
+        zs = self._zs.get("u" if plans is self.u_plans else "i") if self._zs else None
+        if zs is not None:
+            z, flag = zs.form(other, arg, self.rank, self.world, self.comm)
+            for plan in plans:
+                if plan.use_wb and getattr(plan, "_z_ext", None) is None:
+                    plan.set_external_z(z, flag)
         for plan, (lo, hi), (slo, shi) in zip(plans, blocks, supers):
             if self.explicit:
                 ds.append(b.half_epoch_explicit(plan, this[lo:hi], other, arg))

@@ -373,6 +373,19 @@ class ALSPlan:
         self._z_leader = leader
         check(_native.load().lk_als_plan_set_z_leader(leader._h, 1), "lk_als_plan_set_z_leader")
 
+    def set_external_z(self, z: torch.Tensor, flag: torch.Tensor):
+        """
+        Z = other @ OtOr^-1 formed OUTSIDE the plan for every half-epoch (:class:`ShardedZ`: each
+        rank forms its share of the rows, one all-gather; ``LK_ALS_Z=sharded``): the plan reads
+        ``z`` and copies ``flag`` ("OtOr is not positive definite") into its status word at every
+        launch (lk_als_plan_set_z_shared) instead of running the n_cols x KP x KP GEMM itself.
+        """
+        assert z.shape[1] == self.kp and z.shape[0] == self.csr.shape[1] and z.is_contiguous()
+        self._z_ext = (z, flag)  # kept alive with the plan
+        check(_native.load().lk_als_plan_set_z_shared(self._h, _ptr(z), _ptr(flag)),
+              "lk_als_plan_set_z_shared")
+        self._z_shared_set = True
+
     def set_ctl(self, ctl: "TaskCtl | None"):
         "Attach (or detach) a cancel / progress block; check_status then reports a cancel."
         self._ctl = ctl  # keep it alive as long as the plan refers to it
@@ -398,7 +411,9 @@ class ALSPlan:
         csr = self.csr
         assert this.shape == (csr.shape[0], self.kp) and other.shape == (csr.shape[1], self.kp)
         assert this.is_contiguous() and other.is_contiguous() and otor.is_contiguous()
-        if self.use_wb and self._z_leader is not None:
+        if self.use_wb and getattr(self, "_z_ext", None) is not None:
+            pass  # Z arrives from outside (set_external_z)
+        elif self.use_wb and self._z_leader is not None:
             if not self._z_shared_set:
                 ld = self._z_leader
                 assert ld._z is not None, "the leading slice's half-epoch must be launched first"
@@ -467,6 +482,45 @@ class ALSPlan:
                 self._h = ctypes.c_void_p(0)
         except Exception:
             pass
+
+
+class ShardedZ:
+    """
+    Z = other @ OtOr^-1 (the Woodbury kernels' operand at padded k = 128 / 256) formed ONCE ACROSS
+    THE RANKS instead of once per rank: every rank inverts the k x k OtOr (spd_inverse.hip,
+    microseconds), multiplies its own 1 / world share of the rows of ``other`` (the scoring GEMM)
+    and the shares are all-gathered in place.  With the default (``LK_ALS_Z=replicated``) every
+    rank runs the whole n_cols x KP x KP GEMM -- work that does not shrink with the number of
+    GPUs (the cap on cfg5's scaling); sharded it costs one more all-gather of
+    the size of the factor gather.  Same bits either way: a row of Z depends on that row of
+    ``other`` and on OtOr^-1 only.
+    """
+
+    def __init__(self, n_rows: int, k: int, dev):
+        lib = _native.require_gpu()
+        self.k, self.kp = int(k), padded_dim(k)
+        assert self.kp in (128, 256)
+        self.z = torch.empty((n_rows, self.kp), dtype=torch.float32, device=dev)
+        self.ginv = torch.empty((self.kp, self.kp), dtype=torch.float32, device=dev)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ws = torch.empty(lib.lk_spd_inverse_workspace_bytes(self.k), dtype=torch.uint8,
+                              device=dev)
+
+    def form(self, other: torch.Tensor, otor: torch.Tensor, rank: int, world: int, comm):
+        lib = _native.load()
+        n = other.shape[0]
+        assert n == self.z.shape[0] and n % world == 0 and other.is_contiguous()
+        self.flag.zero_()
+        check(lib.lk_spd_inverse(_ptr(otor), otor.stride(0), self.k, _ptr(self.ginv),
+                                 _ptr(self.flag), _ptr(self.ws), _stream()), "lk_spd_inverse")
+        share = n // world
+        lo, hi = rank * share, (rank + 1) * share
+        if share:
+            check(lib.lk_score_dense(_ptr(other[lo:hi]), self.kp, share, _ptr(self.ginv), self.kp,
+                                     self.kp, self.k, _ptr(self.z[lo:hi]), self.kp, _stream()),
+                  "lk_score_dense")
+            comm.all_gather_rows(self.z, lo, hi)
+        return self.z, self.flag
 
 
 class ALSPlanGroup:
@@ -865,17 +919,22 @@ def score_dense(users: torch.Tensor, items: torch.Tensor, k: int) -> torch.Tenso
 
 
 def fold_in(hist: DeviceCSR, items: torch.Tensor, otor: torch.Tensor, k: int,
-            solver: int = _native.SOLVER_AUTO) -> torch.Tensor:
+            solver: int = _native.SOLVER_AUTO, pending: list | None = None) -> torch.Tensor:
     """
     Batched new-user embeddings (``ImplicitMFScorer._train_new_row``,
     src/lenskit/als/_implicit.py:101-130): one ALS row solve per history row of ``hist``
     (queries x items CSR, values = weight or weight*rating) against ``items`` and
     ``otor`` = Q^T Q + user_reg I.  Returns [n_queries x KP]; empty histories give zeros.
+    ``pending``: the launch is left unchecked and its plan appended there -- the caller runs
+    ``check_status`` once its own launches are queued behind this one (no host wait in between).
     """
     plan = ALSPlan(hist, k, solver)
     out = torch.zeros((hist.shape[0], plan.kp), dtype=torch.float32, device=items.device)
     plan.half_epoch(out, items, otor)
-    plan.check_status()
+    if pending is None:
+        plan.check_status()
+    else:
+        pending.append(plan)
     return out
 
 
@@ -890,6 +949,48 @@ def fold_in_explicit(hist: DeviceCSR, items: torch.Tensor, reg: float, k: int) -
     plan.half_epoch_explicit(out, items, reg)
     plan.check_status()
     return out
+
+
+def gather_rows(csr: DeviceCSR, rows: np.ndarray, *, scale: float = 1.0,
+                with_values: bool = True, col_bias: torch.Tensor | None = None) -> DeviceCSR:
+    """
+    The rows ``rows`` (HOST int32, -1 = an empty row) of a device CSR as a new device CSR with
+    int64 offsets (lk_csr_gather_rows): the histories of a batch of queries cut out of the
+    training matrix in one launch (src/lenskit/basic/history.py:37-95 per query in the
+    reference).  Values are ``csr.values * scale`` in float32, or the constant ``scale`` when the
+    matrix holds none (src/lenskit/als/_implicit.py:83-92); ``col_bias`` (device f32 per column)
+    is subtracted before the scaling (item.py:268-271); ``with_values=False``: structure only.  The offsets are prefix sums of the host copy of ``csr``'s offsets: a few thousand
+    integers on the host, nothing of the size of the matrix.
+    """
+    lib = _native.require_gpu()
+    hp = csr.h_indptr
+    assert hp is not None, "gather_rows needs the host copy of the offsets"
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    B = int(rows.shape[0])
+    safe = np.where(rows >= 0, rows, 0)
+    lens = np.where(rows >= 0, hp[safe + 1] - hp[safe], 0).astype(np.int64)
+    ptr = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    dev = csr.indices.device
+    nnz = int(ptr[-1])
+    # one upload for the two small host arrays (offsets, row numbers)
+    packed = np.empty(2 * (B + 1) + B + (B & 1), dtype=np.int32)
+    packed[:2 * (B + 1)] = ptr.view(np.int32)
+    packed[2 * (B + 1):2 * (B + 1) + B] = rows
+    d_packed = torch.from_numpy(packed).to(dev, non_blocking=True)
+    d_ptr = d_packed[:2 * (B + 1)].view(torch.int64)
+    d_rows = d_packed[2 * (B + 1):2 * (B + 1) + B]
+    out_idx = torch.empty(nnz, dtype=torch.int32, device=dev)
+    out_val = torch.empty(nnz, dtype=torch.float32, device=dev) if with_values else None
+    if B and nnz:
+        check(
+            lib.lk_csr_gather_rows(_ptr(csr.indptr), 1 if csr.is64 else 0, _ptr(csr.indices),
+                                   _ptr(csr.values), B, _ptr(d_rows), _ptr(d_ptr), _ptr(col_bias),
+                                   float(np.float32(scale)), _ptr(out_idx), _ptr(out_val),
+                                   _stream()),
+            "lk_csr_gather_rows",
+        )
+    return DeviceCSR(d_ptr, out_idx, out_val, (B, csr.shape[1]), ptr)
 
 
 def csr_transpose(csr: DeviceCSR, with_values: bool = True) -> DeviceCSR:

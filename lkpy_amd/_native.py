@@ -158,6 +158,9 @@ def _declare(lib):
         ),
         "lk_synth_zipf_rows": (c_int, [vp, c_int64, c_int64, ctypes.c_uint64, vp, c_int64, vp, vp]),
         "lk_csr_relabel": (c_int, [vp, c_int, vp, vp, c_int64, vp, vp, vp, vp, vp, vp]),
+        "lk_csr_gather_rows": (
+            c_int, [vp, c_int, vp, vp, c_int64, vp, vp, vp, c_float, vp, vp, vp]
+        ),
         "lk_als_implicit_half_epoch_host": (
             c_int,
             [vp, c_int, vp, vp, c_int64, c_int64, c_int32, vp, vp, vp, c_int32, vp],

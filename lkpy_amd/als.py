@@ -151,6 +151,7 @@ class ImplicitMFScorer(UsesTrainer, Component):
     """
 
     config: ImplicitMFConfig
+    accepts_history_batch = True  # recommend_batch takes a lkpy_amd.basic.HistoryBatch
 
     users: Vocabulary | None = None
     items: Vocabulary
@@ -269,12 +270,80 @@ class ImplicitMFScorer(UsesTrainer, Component):
         scores[mask] = all_scores[item_nums[mask]]
         return ItemList(items, scores=scores)
 
-    def recommend_batch(self, queries, n: int, *, exclude_history: bool = True):
+    def _history_batch_embeddings(self, batch, pending: list | None = None):
+        """
+        ``_query_embeddings`` for a :class:`lkpy_amd.basic.HistoryBatch`: the histories' CSR is cut
+        out of the HBM-resident training matrix by one kernel (no per-query Python), the fold-in
+        is ONE half-epoch launch over it (_implicit.py:77-130 per query in the reference), and
+        the precedence of ``ALSBase.__call__`` (_common.py:139-157) is applied with host masks
+        over the batch: history present and user_embeddings != "prefer" -> fold-in; else the
+        stored row of a known user; else invalid.  Returns (device [B x KP], valid, history CSR).
+        """
+        st = self._device_state()
+        cfg = self.config
+        k = cfg.embedding_size
+        B = len(batch)
+        has_hist = batch.lengths > 0
+        stored = np.full(B, -1, dtype=np.int64)
+        if self.user_embeddings is not None and self.users is not None:
+            if batch.users is self.users or batch.users == self.users:
+                stored = batch.user_nums.astype(np.int64)
+            else:
+                stored = self.users.numbers(batch.user_ids, missing="negative").astype(np.int64)
+        fold = has_hist if cfg.user_embeddings != "prefer" else (has_hist & (stored < 0))
+        hist = batch.csr(use_ratings=cfg.use_ratings, scale=cfg.weight)
+        if fold.all():
+            u = D.fold_in(hist, st["Q"], st["OtOr"], k, self._solver(), pending)
+        elif fold.any():
+            sub = batch.subset(fold).csr(use_ratings=cfg.use_ratings, scale=cfg.weight)
+            u = torch.zeros((B, D.padded_dim(k)), dtype=torch.float32, device=st["device"])
+            u[torch.from_numpy(np.flatnonzero(fold)).to(st["device"])] = \
+                D.fold_in(sub, st["Q"], st["OtOr"], k, self._solver(), pending)
+        else:
+            u = torch.zeros((B, D.padded_dim(k)), dtype=torch.float32, device=st["device"])
+        take = ~fold & (stored >= 0)
+        if take.any():
+            rows = np.ascontiguousarray(self.user_embeddings[stored[take]], dtype=np.float32)
+            u[torch.from_numpy(np.flatnonzero(take)).to(st["device"])] = \
+                D.to_device_padded(rows, st["device"])
+        return u, fold | take, hist
+
+    def recommend_batch(self, queries, n: int, *, exclude_history: bool = True,
+                        device_output: bool = False):
         """
         Batched fold-in + dense scoring + top-N for many queries at once (the reference
-        loops queries in Python, src/lenskit/batch/_runner.py:283-308).  Returns
-        (item numbers [B x n] with -1 padding, scores [B x n] with NaN padding).
+        loops queries in Python, src/lenskit/batch/_runner.py:283-308).  ``queries``: a list of
+        queries, or a :class:`lkpy_amd.basic.HistoryBatch` (training histories by user number: the
+        whole call then has no per-query host work).  Returns (item numbers [B x n] with -1
+        padding, scores [B x n] with NaN padding) as host arrays (``device_output``: as device
+        tensors, nothing downloaded).
         """
+        from .basic import HistoryBatch
+
+        if isinstance(queries, HistoryBatch) and not (
+                queries.items is self.items or queries.items == self.items):
+            queries = queries.queries()  # (another item vocabulary: the per-query mapping)
+        if isinstance(queries, HistoryBatch):
+            pending: list = []  # the fold-in's status is read once the scoring is queued behind it
+            u, valid, hist = self._history_batch_embeddings(queries, pending)
+            st = self._device_state()
+            if exclude_history:
+                idx, sc = D.score_topk(u, st["Q"], self.config.embedding_size, n, hist.indptr,
+                                       hist.indices)
+            else:
+                idx, sc = D.score_topk(u, st["Q"], self.config.embedding_size, n)
+            for plan in pending:
+                plan.check_status()  # RuntimeError("ALS solve error: ...") like the fold-in alone
+            if not valid.all():
+                bad = torch.from_numpy(np.flatnonzero(~valid)).to(st["device"])
+                idx[bad] = -1
+                sc[bad] = float("nan")
+            if device_output:
+                return idx, sc
+            both = torch.cat([idx.view(torch.float32), sc], dim=1)  # one crossing, not two
+            host = D.to_host(both)
+            cols = idx.shape[1]
+            return host[:, :cols].view(np.int32), host[:, cols:]
         queries = [RecQuery.create(q) for q in queries]
         u, valid = self._query_embeddings(queries)
         st = self._device_state()

@@ -44,6 +44,110 @@ class UserTrainingHistoryLookup(Component):
         return query
 
 
+    # -- whole batches of queries --------------------------------
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.pop("_dev", None)
+        return st
+
+    def _device_matrix(self):
+        "The training matrix resident in HBM (uploaded once, never pickled): offsets, items, ratings."
+        st = self.__dict__.get("_dev")
+        if st is None:
+            from . import _device as D
+
+            ds = self.interactions._ds
+            dev = D.device()
+            rat = ds._attrs.get("rating")
+            st = {"device": dev,
+                  "csr": D.DeviceCSR.from_arrays(
+                      ds._indptr, ds._cols,
+                      np.zeros(0, np.float32) if rat is None else rat,
+                      (ds.user_count, ds.item_count), dev),
+                  "has_ratings": rat is not None}
+            if rat is None:
+                st["csr"].values = None
+            self._dev = st
+        return st
+
+    def batch(self, user_ids) -> "HistoryBatch":
+        """
+        The training histories of MANY users at once: what ``__call__`` does per query
+        (src/lenskit/basic/history.py:77-95: attach ``interactions.row_items(user_id)`` as the
+        query's history) for a whole batch, without building an ``ItemList`` per user -- the user
+        numbers come from one vectorised vocabulary lookup and the rows are cut out of the
+        HBM-resident training matrix by one kernel when a scorer asks for them
+        (:meth:`HistoryBatch.csr`).  Unknown users get empty histories, like the reference.
+        """
+        ids = np.asarray(list(user_ids) if not isinstance(user_ids, np.ndarray) else user_ids)
+        vocab = self.interactions.row_vocabulary
+        id_type = vocab.ids().dtype
+        if ids.dtype.kind in "US" and issubclass(id_type.type, np.number):
+            ids = ids.astype(id_type)  # (history.py:85-87: string ids for a numeric vocabulary)
+        nums = vocab.numbers(ids, missing="negative") if len(ids) else np.zeros(0, np.int32)
+        return HistoryBatch(self, ids, nums)
+
+
+class HistoryBatch:
+    """
+    The histories of a batch of queries as rows of the training matrix (user numbers), not as
+    one ``ItemList`` per user: ``len``, ``user_ids``, ``user_nums`` (-1 = unknown user),
+    ``lengths`` (host), ``items`` (the vocabulary the item numbers refer to), and :meth:`csr` --
+    the histories' CSR in HBM, cut out by ``lk_csr_gather_rows``.  ``queries()`` gives the plain
+    per-query objects for scorers without a batched path.
+    """
+
+    def __init__(self, lookup: "UserTrainingHistoryLookup", user_ids: np.ndarray,
+                 user_nums: np.ndarray):
+        self.lookup = lookup
+        self.user_ids = user_ids
+        self.user_nums = np.ascontiguousarray(user_nums, dtype=np.int32)
+        ds = lookup.interactions._ds
+        self.items: Vocabulary = ds.items
+        self.users: Vocabulary = ds.users
+        hp = ds._indptr
+        safe = np.maximum(self.user_nums, 0)
+        self.lengths = np.where(self.user_nums >= 0, hp[safe + 1] - hp[safe], 0).astype(np.int64)
+        self._cache: dict = {}
+
+    def __len__(self):
+        return len(self.user_nums)
+
+    @property
+    def has_ratings(self) -> bool:
+        return "rating" in self.lookup.interactions._ds._attrs
+
+    def csr(self, *, use_ratings: bool = False, scale: float = 1.0, with_values: bool = True,
+            col_bias=None):
+        """Device CSR (queries x items, int64 offsets; ``h_indptr`` = the host copy) of the
+        histories; values = ``rating * scale`` (``use_ratings``) or the constant ``scale``, with
+        ``col_bias`` (device f32 per item) subtracted from the rating first."""
+        from . import _device as D
+
+        key = (bool(use_ratings), float(scale), bool(with_values),
+               None if col_bias is None else int(col_bias.data_ptr()))
+        hit = self._cache.get(key)
+        if hit is not None:
+            return hit
+        st = self.lookup._device_matrix()
+        src = st["csr"]
+        if use_ratings and not st["has_ratings"]:
+            raise ValueError("no ratings in user items")  # (_implicit.py:85-86)
+        if not use_ratings and src.values is not None:
+            src = D.DeviceCSR(src.indptr, src.indices, None, src.shape, src.h_indptr)
+        out = D.gather_rows(src, self.user_nums, scale=scale, with_values=with_values,
+                            col_bias=col_bias)
+        self._cache[key] = out
+        return out
+
+    def subset(self, mask: np.ndarray) -> "HistoryBatch":
+        return HistoryBatch(self.lookup, self.user_ids[mask], self.user_nums[mask])
+
+    def queries(self) -> list:
+        return [self.lookup(RecQuery.create(u.item() if isinstance(u, np.generic) else u))
+                for u in self.user_ids]
+
+
 class TrainingItemsCandidateConfig(BaseModel):
     exclude: str | None = "query"
 

@@ -13,7 +13,7 @@ from .data import ItemList, ItemListCollection, RecQuery
 from .pipeline import Pipeline
 
 
-def recommend(pipe: Pipeline, users, n: int, *, batch_size: int = 2048) -> ItemListCollection:
+def recommend(pipe: Pipeline, users, n: int, *, batch_size: int = 16384) -> ItemListCollection:
     """Ordered lists of ``n`` recommendations as an ``ItemListCollection`` keyed by ``user_id``
     (what ``BatchResults.output("recommendations")`` is in the reference,
     src/lenskit/batch/_runner.py:157-191): ``out.lookup(user)`` / ``out.lookup(user_id=user)``,
@@ -22,6 +22,19 @@ def recommend(pipe: Pipeline, users, n: int, *, batch_size: int = 2048) -> ItemL
     lookup = pipe.node("history-lookup").component
     users = list(users)
     out = {}
+    if hasattr(scorer, "recommend_batch") and hasattr(lookup, "batch") and \
+            getattr(scorer, "accepts_history_batch", False):
+        # the whole batch by user number: the histories are rows of the HBM-resident training
+        # matrix, no per-query host work; the lists are built when somebody looks at them
+        idx, sc = [], []
+        for s in range(0, len(users), batch_size):
+            i, v = scorer.recommend_batch(lookup.batch(users[s:s + batch_size]), n)
+            idx.append(i)
+            sc.append(v)
+        if not idx:
+            return ItemListCollection(("user_id",))
+        return ItemListCollection.from_arrays(users, np.concatenate(idx), np.concatenate(sc),
+                                              scorer.items, key=("user_id",))
     if hasattr(scorer, "recommend_batch"):
         for s in range(0, len(users), batch_size):
             chunk = users[s:s + batch_size]

@@ -91,6 +91,33 @@ __global__ __launch_bounds__(256) void relabel_kernel(
     }
 }
 
+// row gather: output row r = input row rows[r] (or empty), indices copied, values copied and
+// scaled (or the constant `scale` where the matrix holds no values); one wave per output row
+template <typename IT>
+__global__ __launch_bounds__(256) void gather_rows_kernel(
+    const IT *__restrict__ in_ptr, const int32_t *__restrict__ in_idx,
+    const float *__restrict__ in_val, int64_t n_rows_out, const int32_t *__restrict__ rows,
+    const int64_t *__restrict__ out_ptr, const float *__restrict__ col_bias, float scale,
+    int32_t *__restrict__ out_idx, float *__restrict__ out_val)
+{
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows_out) return;
+    const int src = rows[r];
+    if (src < 0) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t sb = (int64_t)in_ptr[src];
+    const int64_t db = out_ptr[r], n = out_ptr[r + 1] - db;  // (the caller's lengths decide)
+    for (int64_t e = lane; e < n; e += 64) {
+        const int32_t c = in_idx[sb + e];
+        out_idx[db + e] = c;
+        if (out_val) {
+            float v = in_val ? in_val[sb + e] : 1.0f;
+            if (col_bias) v -= col_bias[c];
+            out_val[db + e] = v * scale;
+        }
+    }
+}
+
 static int key_bits(int64_t n_cols)
 {
     int b = 1;
@@ -196,6 +223,28 @@ extern "C" int lk_csr_relabel(const void *d_indptr, int indptr_is_64, const int3
                            static_cast<const int32_t *>(d_indptr), d_indices, d_values, n_rows_out,
                            d_row_src, static_cast<const int32_t *>(d_out_indptr), d_col_map,
                            d_out_indices, d_out_values);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+extern "C" int lk_csr_gather_rows(const void *d_indptr, int indptr_is_64, const int32_t *d_indices,
+                                  const float *d_values, int64_t n_rows_out, const int32_t *d_rows,
+                                  const int64_t *d_out_indptr, const float *d_col_bias, float scale,
+                                  int32_t *d_out_indices, float *d_out_values, void *stream)
+{
+    LK_REQUIRE(n_rows_out >= 0, "lk_csr_gather_rows: negative size");
+    if (n_rows_out == 0) return LK_OK;
+    LK_REQUIRE(d_indptr && d_rows && d_out_indptr, "lk_csr_gather_rows: null pointer");
+    hipStream_t st = lk::as_stream(stream);
+    const dim3 grid((unsigned)((n_rows_out + 3) / 4)), block(256);
+    if (indptr_is_64)
+        hipLaunchKernelGGL(lk::gather_rows_kernel<int64_t>, grid, block, 0, st,
+                           static_cast<const int64_t *>(d_indptr), d_indices, d_values, n_rows_out,
+                           d_rows, d_out_indptr, d_col_bias, scale, d_out_indices, d_out_values);
+    else
+        hipLaunchKernelGGL(lk::gather_rows_kernel<int32_t>, grid, block, 0, st,
+                           static_cast<const int32_t *>(d_indptr), d_indices, d_values, n_rows_out,
+                           d_rows, d_out_indptr, d_col_bias, scale, d_out_indices, d_out_values);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }

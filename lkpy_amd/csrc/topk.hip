@@ -435,6 +435,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 // The records of the epilogue live in item buffer 1 (idle between a tile's last slab and the
 // next tile's first prefetch into it) -- wave w's 64 records are exactly the 4 KiB its own DMA
 // instructions write, so no barrier separates the flush from the next tile.
+// Item-split launches (small batches: fewer than one round of 2 x 256 workgroups of 128 users each
+// would leave most of the chip idle -- 10 000 users are 79 workgroups): blockIdx.y walks the item
+// tiles [t_lo, t_hi) only, and the candidates of a row, now found by several workgroups, are
+// appended through the row's global counter (zeroed by stage 1) instead of an LDS counter.
+// The list's ORDER then depends on timing; its content does not, and the selection sorts it.
+#define LK_FILTER_SPLIT_RANGE                                                                      \
+    const bool split = tiles_per_wg > 0;                                                           \
+    const int64_t t_lo = split ? (int64_t)blockIdx.y * tiles_per_wg : 0;                           \
+    const int64_t t_hi = split ? (t_lo + tiles_per_wg < n_itiles ? t_lo + tiles_per_wg : n_itiles) \
+                               : n_itiles;                                                         \
+    if (t_lo >= t_hi) return;
+
 constexpr int F64_U_FLOATS = 128 * 64;
 constexpr int F64_I_FLOATS = 256 * 16;  // one slab buffer
 constexpr int F64_LDS_FLOATS = F64_U_FLOATS + 2 * F64_I_FLOATS + 4 * 64 /* record ids */ + 2 * 128;
@@ -453,7 +465,7 @@ __device__ __forceinline__ void lds_dma16(const void *src, unsigned lds_byte_add
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void score_filter64_kernel(
     const float *__restrict__ users, int64_t n_users, const float *__restrict__ items,
     int64_t n_items, const float *__restrict__ tau, unsigned long long *__restrict__ cand,
-    unsigned *__restrict__ cand_cnt, int cand_cap)
+    unsigned *__restrict__ cand_cnt, int cand_cap, int tiles_per_wg)
 {
     constexpr int UT = 2, UB = 128;
     __shared__ __attribute__((aligned(1024))) float lds_all[F64_LDS_FLOATS];
@@ -467,6 +479,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     const int64_t u0 = (int64_t)blockIdx.x * UB;
     const int wu = (wave & 1) * 64, wi = (wave >> 1) * 128;
     const int64_t n_itiles = (n_items + SC_IB - 1) / SC_IB;
+    LK_FILTER_SPLIT_RANGE
     const unsigned lds_u = (unsigned)(uintptr_t)lu, lds_i = (unsigned)(uintptr_t)li;
 
     for (int r = tid; r < UB; r += 256) {
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
             lds_dma16(src, lds_i + (unsigned)(s & 1) * (F64_I_FLOATS * 4u) + (unsigned)n * 1024u);
         }
     };
-    slab_dma(0, 0);
+    slab_dma(t_lo * SC_IB, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -519,7 +532,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     unsigned *rids = rids_all + wave * 64;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    for (int64_t itile = 0; itile < n_itiles; ++itile) {
+    for (int64_t itile = t_lo; itile < t_hi; ++itile) {
         const int64_t i0 = itile * SC_IB;
         f32x16 acc[UT][4];
 #pragma unroll
@@ -532,7 +545,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         for (int s = 0; s < 4; ++s) {
             // request the next slab (of this tile, or the first of the next one)
             if (s < 3) slab_dma(i0, s + 1);
-            else if (itile + 1 < n_itiles) slab_dma(i0 + SC_IB, 0);
+            else if (itile + 1 < t_hi) slab_dma(i0 + SC_IB, 0);
             const float *ib = li + (s & 1) * F64_I_FLOATS;
 #pragma unroll
             for (int kk = 0; kk < 16; kk += 2) {
@@ -570,7 +583,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                 // the flag is "not below": NaN ends here, and so does a +inf score of a row past
                 // the end (tau = +inf, clamped operands)
                 if (x >= s_tau[row] && (int64_t)(u0 + row) < n_users) {
-                    const unsigned pos = atomicAdd(&s_cnt[row], 1u);  // LDS
+                    // (an item-split launch: the row's list is shared by several workgroups)
+                    const unsigned pos = split ? atomicAdd(&cand_cnt[u0 + row], 1u)
+                                               : atomicAdd(&s_cnt[row], 1u);  // LDS
                     if (pos < (unsigned)cand_cap)
                         cand[(u0 + row) * cand_cap + pos] =
                             ((unsigned long long)f2key(x) << 32) | (0xffffffffu - it);
@@ -617,8 +632,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         flush();
     }
     __syncthreads();
-    for (int rr = tid; rr < UB; rr += 256)
-        if (u0 + rr < n_users) cand_cnt[u0 + rr] = s_cnt[rr];
+    if (!split)
+        for (int rr = tid; rr < UB; rr += 256)
+            if (u0 + rr < n_users) cand_cnt[u0 + rr] = s_cnt[rr];
 }
 
 #if LK_TOPK_DMA >= 2
@@ -637,7 +653,7 @@ template <int KP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void score_filter_slab_kernel(
     const float *__restrict__ users, int64_t n_users, const float *__restrict__ items,
     int64_t n_items, const float *__restrict__ tau, unsigned long long *__restrict__ cand,
-    unsigned *__restrict__ cand_cnt, int cand_cap)
+    unsigned *__restrict__ cand_cnt, int cand_cap, int tiles_per_wg)
 {
     constexpr int UT = 2, UB = 128, NS = KP / 16;
     static_assert(NS >= 2 && NS % 2 == 0, "an even number of 16-feature slabs");
@@ -651,6 +667,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     const int64_t u0 = (int64_t)blockIdx.x * UB;
     const int wu = (wave & 1) * 64, wi = (wave >> 1) * 128;
     const int64_t n_itiles = (n_items + SC_IB - 1) / SC_IB;
+    LK_FILTER_SPLIT_RANGE
     const unsigned lds0 = (unsigned)(uintptr_t)lds_all;
 
     for (int r = tid; r < UB; r += 256) {
@@ -681,7 +698,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
             lds_dma16(src, buf + (unsigned)(US * 4) + (unsigned)n * 1024u);
         }
     };
-    slab_dma(0, 0);
+    slab_dma(t_lo * SC_IB, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -696,7 +713,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     unsigned *rids = rids_all + wave * 64;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    for (int64_t itile = 0; itile < n_itiles; ++itile) {
+    for (int64_t itile = t_lo; itile < t_hi; ++itile) {
         const int64_t i0 = itile * SC_IB;
         f32x16 acc[UT][4];
 #pragma unroll
@@ -710,7 +727,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
             for (int par = 0; par < 2; ++par) {
                 const int s = 2 * sp + par;
                 if (s + 1 < NS) slab_dma(i0, s + 1);
-                else if (itile + 1 < n_itiles) slab_dma(i0 + SC_IB, 0);
+                else if (itile + 1 < t_hi) slab_dma(i0 + SC_IB, 0);
                 const float *bb = lds_all + par * BUF;
 #pragma unroll
                 for (int kk = 0; kk < 16; kk += 2) {
@@ -746,7 +763,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                 const float x = rvals[rec * 16 + rg];
                 const unsigned row = rowb + (rg & 3) + 8 * (rg >> 2);
                 if (x >= s_tau[row] && (int64_t)(u0 + row) < n_users) {
-                    const unsigned pos = atomicAdd(&s_cnt[row], 1u);  // LDS
+                    // (an item-split launch: the row's list is shared by several workgroups)
+                    const unsigned pos = split ? atomicAdd(&cand_cnt[u0 + row], 1u)
+                                               : atomicAdd(&s_cnt[row], 1u);  // LDS
                     if (pos < (unsigned)cand_cap)
                         cand[(u0 + row) * cand_cap + pos] =
                             ((unsigned long long)f2key(x) << 32) | (0xffffffffu - it);
@@ -793,8 +812,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         flush();
     }
     __syncthreads();
-    for (int rr = tid; rr < UB; rr += 256)
-        if (u0 + rr < n_users) cand_cnt[u0 + rr] = s_cnt[rr];
+    if (!split)
+        for (int rr = tid; rr < UB; rr += 256)
+            if (u0 + rr < n_users) cand_cnt[u0 + rr] = s_cnt[rr];
 }
 #endif  // LK_TOPK_DMA >= 2
 
@@ -2003,6 +2023,11 @@ static bool topk_overlap()
     const char *e = getenv("LK_TOPK_OVERLAP");
     return !(e && e[0] == '0');
 }
+static bool topk_split()
+{
+    const char *e = getenv("LK_TOPK_SPLIT");  // 0: never split the item tiles of a small batch
+    return !(e && e[0] == '0');
+}
 struct TopkSide {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
@@ -2344,24 +2369,43 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
             if (lk::topk_overlap() && wgs > round && wgs % round != 0)
                 rows_a = (wgs / round) * round * (2 * lk::SC_UB);
             auto filter = [&](int64_t r0, int64_t nr, hipStream_t s) {
-                const dim3 ugrid((unsigned)((nr + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB)));
+                dim3 ugrid((unsigned)((nr + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB)));
                 const float *uu = ub_users + r0 * ld_users;
                 float *tau_r = tau + r0;
                 unsigned *cnt_r = cnt + r0;
                 unsigned long long *cand_r = cand + r0 * lk::FUSED_CAP;
+                // fewer workgroups than one round (2 per CU): split the item tiles among several
+                // workgroups per 128 users (LK_TOPK_SPLIT=0: never)
+                int tiles_per_wg = 0;
+                const int64_t n_itiles = (n_items + lk::SC_IB - 1) / lk::SC_IB;
+                const bool dma_kernel = (LK_TOPK_DMA && KP == 64) ||
+                                        (LK_TOPK_DMA >= 2 && (KP == 32 || KP == 128 || KP == 256));
+                if (dma_kernel && lk::topk_split() && ugrid.x < 2 * 256 && n_itiles >= 8) {
+                    int64_t parts = (2 * 256 + ugrid.x - 1) / ugrid.x;
+                    if (parts > n_itiles / 4) parts = n_itiles / 4;  // >= 4 tiles per workgroup
+                    if (parts > 1) {
+                        tiles_per_wg = (int)((n_itiles + parts - 1) / parts);
+                        ugrid.y = (unsigned)((n_itiles + tiles_per_wg - 1) / tiles_per_wg);
+                        // (the rows' counters are zero: stage 1 leaves them so)
+                    }
+                }
                 if (LK_TOPK_DMA && KP == 64)
                     hipLaunchKernelGGL(lk::score_filter64_kernel, ugrid, dim3(256), 0, s, uu, nr,
-                                       d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP);
+                                       d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP,
+                                       tiles_per_wg);
 #if LK_TOPK_DMA >= 2
                 else if (KP == 32)
                     hipLaunchKernelGGL(lk::score_filter_slab_kernel<32>, ugrid, dim3(256), 0, s, uu,
-                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP);
+                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP,
+                                       tiles_per_wg);
                 else if (KP == 128)
                     hipLaunchKernelGGL(lk::score_filter_slab_kernel<128>, ugrid, dim3(256), 0, s, uu,
-                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP);
+                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP,
+                                       tiles_per_wg);
                 else if (KP == 256)
                     hipLaunchKernelGGL(lk::score_filter_slab_kernel<256>, ugrid, dim3(256), 0, s, uu,
-                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP);
+                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP,
+                                       tiles_per_wg);
 #endif
                 else
                     hipLaunchKernelGGL(lk::score_filter_kernel, ugrid, dim3(256), 0, s, uu, ld_users,

@@ -248,13 +248,35 @@ class ItemListCollection:
     def key_type(self):
         return self._key_class
 
+    @classmethod
+    def from_arrays(cls, keys, item_nums: np.ndarray, scores: np.ndarray, vocabulary: Vocabulary,
+                    key=("user_id",)) -> "ItemListCollection":
+        """
+        A collection over the [B x n] result arrays of a batched recommend call (item numbers with
+        -1 padding, scores): the ``ItemList`` of a key is only built when somebody asks for it
+        (``lookup`` / iteration / ``[i]``), so handing back ten thousand lists costs nothing per
+        list.  ``to_df`` and ``total_items`` work on the arrays directly.
+        """
+        ilc = cls(key)
+        ilc._lists = _LazyLists(ilc._key_class, keys, item_nums, scores, vocabulary)
+        ilc._index_stale = True  # the key -> position dict is built by the first ``lookup``
+        return ilc
+
+    def _ensure_index(self):
+        if getattr(self, "_index_stale", False) and self._index is not None:
+            self._index_stale = False
+            ll = self._lists
+            fresh = {ll.key(pos): pos for pos in range(len(ll.raw_keys))}
+            fresh.update(self._index)  # (lists added since are later: the last of equal keys wins)
+            self._index = fresh
+
     def add(self, list: ItemList, *fields, **kwfields):
         key = self._key_class(*fields, **kwfields)
-        if self._index is not None:
-            if key in self._index:
-                raise KeyError(f"duplicate key {key}")
-            self._index[key] = len(self._lists)
         self._lists.append((key, list))
+        if self._index is not None:
+            # equal keys: every list is kept, ``lookup`` returns the LAST one -- the reference's
+            # ``ListILC._add`` (src/lenskit/data/_collection/_list.py:190-193, 203-227)
+            self._index[key] = len(self._lists) - 1
 
     def lookup(self, *args, **kwargs) -> ItemList | None:
         if len(args) == 1 and not kwargs and isinstance(args[0], tuple):
@@ -263,6 +285,7 @@ class ItemListCollection:
             key = self._key_class(*args, **kwargs)
         if self._index is None:
             raise TypeError("cannot look up on a collection without an index")
+        self._ensure_index()
         pos = self._index.get(key)
         return None if pos is None else self._lists[pos][1]
 
@@ -273,9 +296,13 @@ class ItemListCollection:
         return (il for _k, il in self._lists)
 
     def keys(self):
+        if isinstance(self._lists, _LazyLists):
+            return self._lists.all_keys()
         return (k for k, _il in self._lists)
 
     def total_items(self) -> int:
+        if isinstance(self._lists, _LazyLists):
+            return self._lists.total_items()
         return sum(len(il) for _k, il in self._lists)
 
     def __len__(self):
@@ -289,6 +316,8 @@ class ItemListCollection:
         return self._lists[pos]
 
     def to_df(self) -> pd.DataFrame:
+        if isinstance(self._lists, _LazyLists):
+            return self._lists.to_df(self.key_fields)
         frames = []
         for key, il in self._lists:
             df = il.to_df()
@@ -301,6 +330,90 @@ class ItemListCollection:
 
     def __repr__(self):
         return f"<ItemListCollection of {len(self)} lists, key {self.key_fields}>"
+
+
+class _LazyLists:
+    """
+    The ``(key, ItemList)`` sequence of an array-backed collection (``from_arrays``): behaves like
+    the list ``ItemListCollection`` keeps, builds an entry on access (and remembers it).
+    """
+
+    def __init__(self, key_class, keys, item_nums, scores, vocabulary):
+        self.key_class = key_class
+        self.raw_keys = keys if isinstance(keys, np.ndarray) else list(keys)
+        self.nums, self.scores, self.vocab = item_nums, scores, vocabulary
+        self.extra: list = []  # lists appended later (``add``)
+        self._made: dict = {}
+
+    def key(self, pos: int):
+        k = self.raw_keys[pos]
+        if isinstance(k, self.key_class):
+            return k
+        if isinstance(k, tuple):
+            return self.key_class(*k)
+        return self.key_class(k.item() if isinstance(k, np.generic) else k)
+
+    def all_keys(self):
+        for pos in range(len(self.raw_keys)):
+            yield self.key(pos)
+        for k, _il in self.extra:
+            yield k
+
+    def __len__(self):
+        return len(self.raw_keys) + len(self.extra)
+
+    def _make(self, pos: int):
+        hit = self._made.get(pos)
+        if hit is None:
+            row = self.nums[pos]
+            keep = row >= 0
+            hit = (self.key(pos), ItemList(item_nums=row[keep], vocabulary=self.vocab,
+                                           scores=self.scores[pos][keep], ordered=True))
+            self._made[pos] = hit
+        return hit
+
+    def __getitem__(self, pos):
+        if isinstance(pos, slice):
+            return [self[i] for i in range(*pos.indices(len(self)))]
+        if pos < 0:
+            pos += len(self)
+        if pos >= len(self.raw_keys):
+            return self.extra[pos - len(self.raw_keys)]
+        return self._make(pos)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def append(self, entry):
+        self.extra.append(entry)
+
+    def total_items(self) -> int:
+        return int((self.nums >= 0).sum()) + sum(len(il) for _k, il in self.extra)
+
+    def to_df(self, key_fields) -> pd.DataFrame:
+        keep = self.nums >= 0
+        counts = keep.sum(axis=1)
+        cols = {}
+        for j, f in enumerate(key_fields):
+            col = self.raw_keys if (j == 0 and isinstance(self.raw_keys, np.ndarray)
+                                    and self.raw_keys.ndim == 1) else \
+                np.asarray([self.key(p)[j] for p in range(len(self.raw_keys))])
+            cols[f] = np.repeat(col, counts)
+        cols["item_id"] = self.vocab.ids(self.nums[keep])
+        cols["score"] = self.scores[keep]
+        ends = np.cumsum(counts)
+        cols["rank"] = np.arange(1, int(ends[-1]) + 1 if len(ends) else 1) - \
+            np.repeat(ends - counts, counts)
+        df = pd.DataFrame(cols)
+        if self.extra:
+            frames = [df]
+            for key, il in self.extra:
+                d2 = il.to_df()
+                for f, v in zip(reversed(key_fields), reversed(key)):
+                    d2.insert(0, f, v)
+                frames.append(d2)
+            df = pd.concat(frames, ignore_index=True)
+        return df
 
 
 class RecQuery:

@@ -47,7 +47,10 @@ int lko_num_threads(void)
 {
 #ifdef _OPENMP
     int n = omp_get_max_threads();
-    return n > LKO_MAX_THREADS ? LKO_MAX_THREADS : n;
+    int cap = LKO_MAX_THREADS;
+    const char *e = getenv("LKO_MAX_THREADS"); /* experiments with the cap (tools/oracle_threads.py) */
+    if (e && atoi(e) > 0) cap = atoi(e);
+    return n > cap ? cap : n;
 #else
     return 1;
 #endif

@@ -158,3 +158,44 @@ def knn_rows_equal(gpu_ptr, gpu_idx, gpu_val, want) -> dict:
                        np.asarray(want.data, np.float32).view(np.uint32)))
     return {"rows_checked": int(len(wp) - 1), "entries_checked": int(wp[-1]),
             "bitwise_equal": bool(same_ptr and same_idx and same_val)}
+
+
+def topn_accounting(got_i, got_s, want_i, want_s, dense_scores_of_row) -> dict:
+    """
+    Top-N lists of the GPU (``got_*``) against the oracle's (``want_*``) for the same queries
+    FROM THE SAME QUERY VECTORS, [rows x n] with -1 / NaN padding.  ``north_star``: "integer
+    top-K index sets bit-exact".  The sorted score rows must be bit-identical position by
+    position and every listed item must really carry the listed score.  Where DIFFERENT items
+    have the same score bits (duplicate factor rows: items with identical interaction patterns)
+    the reference's heap decides by its internal sift order -- which of two equal scores it pops
+    first inside the list, and, when the tie straddles the cut, which one it keeps
+    (src/accel/indirect/heap.rs:39-64 compares scores only; SURVEY.md section 8g item 8:
+    unspecified); the GPU takes the lower item number.  Such rows are counted in the two ``ties_*``
+    fields, anything else in ``mismatched_users``.  ``dense_scores_of_row(r)`` -> the oracle's
+    score of every item for row ``r`` (only called for rows whose lists differ).
+    """
+    got_i, want_i = np.asarray(got_i), np.asarray(want_i)
+    got_s = np.ascontiguousarray(got_s, dtype=np.float32)
+    want_s = np.ascontiguousarray(want_s, dtype=np.float32)
+    same = (got_i == want_i).all(axis=1)
+    sc_same = bool(np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32)))
+    ties_in, ties_cut, bad = 0, 0, 0
+    for r in np.flatnonzero(~same):
+        sc = dense_scores_of_row(int(r))
+        g, w = got_i[r], want_i[r]
+        genuine = np.array_equal(sc[g[g >= 0]].view(np.uint32),
+                                 got_s[r][g >= 0].view(np.uint32))
+        rows_equal = np.array_equal(got_s[r].view(np.uint32), want_s[r].view(np.uint32))
+        if not (genuine and rows_equal):
+            bad += 1
+        elif np.array_equal(np.sort(g), np.sort(w)):
+            ties_in += 1   # same set, equal-score items in another order
+        else:
+            ties_cut += 1  # a tie at the cut: another item with the cut's score is listed
+    return {"users_checked": int(got_i.shape[0]), "list_length": int(got_i.shape[1]),
+            "score_rows_bit_identical": sc_same,
+            "lists_identical": int(same.sum()),
+            "ties_ordered_differently_inside_list": int(ties_in),
+            "ties_resolved_differently_at_the_cut": int(ties_cut),
+            "mismatched_users": int(bad),
+            "ok": bool(sc_same and bad == 0)}

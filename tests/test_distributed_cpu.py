@@ -68,7 +68,7 @@ def _worker(rank, world, port, ui, k, P0, Q0, epochs, out, explicit=False, slice
         from lkpy_amd._als_engine import ImplicitALSEngine
 
         eng = ImplicitALSEngine(ui, k, 0.1, 0.2, P0, Q0, OracleBackend(k), explicit=explicit)
-        assert eng.sharded_setup == (setup == "sharded")
+        assert eng.sharded_setup == (setup in ("", "sharded"))
         assert eng.slices == (slices if slices > 0 else 1) and len(eng.u_plans) == eng.slices
         deltas = []
         for _ in range(epochs):
@@ -112,10 +112,11 @@ def test_deal_rows_balances_and_round_trips():
 
 
 @pytest.mark.parametrize("world,slices,setup", [(2, 0, "full"), (2, 3, "full"),
-                                                (2, 0, "sharded"), (2, 3, "sharded")])
+                                                (2, 0, "sharded"), (2, 3, "sharded"), (2, 0, "")])
 def test_sharded_engine_matches_single_process(oracle, world, slices, setup):
-    """(``setup = "sharded"``: LK_ALS_SETUP=sharded -- every rank cuts only its own rows out of the
-    original matrix, ``shard_local_blocks``; same factors, same per-rank entry counts)"""
+    """(``setup = "sharded"``, and ``""`` = the variable unset, the default since round 6: every
+    rank cuts only its own rows out of the original matrix, ``shard_local_blocks``; same factors,
+    same per-rank entry counts.  ``"full"``: rounds 1-5's set-up, LK_ALS_SETUP=full)"""
     rng = np.random.default_rng(5)
     n_users, n_items, k, epochs = 301, 157, 8, 3
     dense = rng.random((n_users, n_items)) < 0.06

@@ -47,7 +47,7 @@ def _run_world(world, ui, k, P0, Q0, gpu, epochs):
             eng.check()
             torch.cuda.synchronize()
             out[r] = (eng.P.clone(), eng.Q.clone(), eng.user_embeddings(), eng.item_embeddings(),
-                      eng.otor(), float(du), float(di), eng.u_plan.use_wb)
+                      eng.otor(), float(du), float(di), eng.u_plan.use_wb, sorted(eng._zs))
         except BaseException as e:  # noqa: BLE001 -- re-raised in the main thread
             errs.append(e)
             for c in comms:
@@ -78,13 +78,20 @@ def _short_row_matrix(rng, n_users, n_items, mean_len):
     (2, 32, False, 1, "full"), (3, 64, False, 1, "full"), (2, 128, True, 1, "full"),
     (3, 256, True, 1, "full"), (3, 128, False, 1, "full"), (2, 64, False, 4, "full"),
     (3, 128, True, 3, "full"), (2, 256, True, 2, "full"),
-    # LK_ALS_SETUP=sharded: every rank derives only its own rows (shard_local_blocks on HBM
-    # tensors: gather, searchsorted, stable sort), plans on arrays that hold nnz / world entries
-    (3, 64, False, 1, "sharded"), (2, 64, False, 4, "sharded"), (3, 128, True, 3, "sharded")])
+    # LK_ALS_SETUP=sharded (the default since round 6): every rank derives only its own rows
+    # (shard_local_blocks on HBM tensors: gather, searchsorted, stable sort), plans on arrays
+    # that hold nnz / world entries
+    (3, 64, False, 1, "sharded"), (2, 64, False, 4, "sharded"), (3, 128, True, 3, "sharded"),
+    # LK_ALS_Z=sharded: Z = other @ OtOr^-1 formed once ACROSS the ranks (ShardedZ: each rank
+    # its share of the rows + one all-gather) instead of once per rank
+    (2, 128, True, 1, "sharded+z"), (3, 256, True, 1, "sharded+z"), (3, 128, True, 3, "sharded+z"),
+    (2, 256, True, 2, "full+z")])
 def test_sharded_device_path_on_one_gpu(gpu, oracle, monkeypatch, world, k, wb, slices, setup):
     import torch
 
+    setup, _, zmode = setup.partition("+")
     monkeypatch.setenv("LK_ALS_SETUP", setup)
+    monkeypatch.setenv("LK_ALS_Z", "sharded" if zmode == "z" else "replicated")
 
     from lkpy_amd import _native, synth
     from lkpy_amd._als_engine import HipBackend, ImplicitALSEngine
@@ -125,6 +132,8 @@ def test_sharded_device_path_on_one_gpu(gpu, oracle, monkeypatch, world, k, wb, 
         assert res[r][5] == res[0][5] and res[r][6] == res[0][6]
     if wb:
         assert any(res[r][7] for r in range(world))  # some shard took the Woodbury kernels
+    if zmode == "z":  # every rank took part in forming Z for the halves that use it
+        assert all(res[r][8] == res[0][8] for r in range(world)) and res[0][8]
 
     rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))  # noqa: E731
     eP, eQ = rel(res[0][2], P1), rel(res[0][3], Q1)

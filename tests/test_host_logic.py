@@ -429,11 +429,59 @@ def test_item_list_collection_mirrors_the_reference_api():
     assert df[df.user_id == 3]["rank"].tolist() == [1, 2, 3]
     c.add(ItemList([9]), 8)
     assert c.lookup(8).ids().tolist() == [9]
-    import pytest
-
-    with pytest.raises(KeyError):
-        c.add(ItemList([9]), 8)
+    # equal keys: both lists are kept, ``lookup`` gives the LAST one -- the reference's ListILC
+    # (src/lenskit/data/_collection/_list.py:190-193, 203-227)
+    c.add(ItemList([10, 11]), 8)
+    assert len(c) == 4 and c.lookup(8).ids().tolist() == [10, 11]
+    assert [k.user_id for k in c.keys()] == [3, 5, 8, 8]
     two = ItemListCollection(("user_id", "seq"))
     two.add(ItemList([1]), 4, 0)
     two.add(ItemList([2]), user_id=4, seq=1)
     assert two.lookup(4, 1).ids().tolist() == [2] and two.key_type._fields == ("user_id", "seq")
+
+
+def test_array_backed_collection_builds_lists_on_demand():
+    """``ItemListCollection.from_arrays``: the [B x n] arrays of a batched recommend call as a
+    collection; keys, lists and the lookup index are only built when asked for."""
+    from lkpy_amd.data import ItemList, ItemListCollection, Vocabulary
+
+    v = Vocabulary(np.arange(100, 120), "item")
+    nums = np.array([[3, 2, -1], [5, 6, 7], [-1, -1, -1]], np.int32)
+    sc = np.array([[.9, .8, np.nan], [.5, .4, .3], [np.nan] * 3], np.float32)
+    c = ItemListCollection.from_arrays(np.array([11, 12, 13]), nums, sc, v)
+    assert len(c) == 3 and c.total_items() == 5 and not c._lists._made
+    assert [k.user_id for k in c.keys()] == [11, 12, 13] and isinstance(c[0][0].user_id, int)
+    assert c.lookup(11).ids().tolist() == [103, 102] and c.lookup(11).ordered
+    assert c.lookup(user_id=12).scores().tolist() == sc[1].tolist()
+    assert len(c.lookup(13)) == 0 and c.lookup(99) is None
+    assert c[1][0].user_id == 12 and c[-1][0].user_id == 13
+    df = c.to_df()
+    assert df["user_id"].tolist() == [11, 11, 12, 12, 12]
+    assert df["item_id"].tolist() == [103, 102, 105, 106, 107] and df["rank"].tolist() == [1, 2, 1, 2, 3]
+    c.add(ItemList(item_nums=[1], vocabulary=v, scores=[1.0]), 12)  # the last of equal keys wins
+    assert len(c) == 4 and c.lookup(12).ids().tolist() == [101]
+    assert [k.user_id for k, _ in c] == [11, 12, 13, 12] and c.total_items() == 6
+
+
+def test_history_batch_host_side():
+    """``UserTrainingHistoryLookup.batch``: user numbers by one vocabulary lookup, unknown users
+    as empty histories (src/lenskit/basic/history.py:77-95), string ids for a numeric vocabulary
+    converted (85-87), ``queries()`` == the per-query lookup."""
+    from lkpy_amd.basic import UserTrainingHistoryLookup
+    from lkpy_amd.data import Dataset
+
+    ds = Dataset.from_arrays([10, 10, 20, 30, 30, 30], [1, 2, 2, 1, 2, 3],
+                             [4.0, 3.0, 5.0, 1.0, 2.0, 3.0])
+    lk = UserTrainingHistoryLookup()
+    lk.train(ds)
+    hb = lk.batch([30, 99, 10, "20"])
+    assert len(hb) == 4 and hb.user_nums.tolist() == [2, -1, 0, 1]
+    assert hb.lengths.tolist() == [3, 0, 2, 1] and hb.has_ratings and hb.items is ds.items
+    qs = hb.queries()
+    assert [q.user_id for q in qs] == [30, 99, 10, 20]
+    assert qs[0].query_items.ids().tolist() == [1, 2, 3] and qs[1].query_items is None
+    sub = hb.subset(np.array([True, False, True, False]))
+    assert sub.user_nums.tolist() == [2, 0] and sub.lengths.tolist() == [3, 2]
+    import pickle
+
+    assert pickle.loads(pickle.dumps(lk)).batch([10]).lengths.tolist() == [2]
