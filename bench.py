@@ -294,7 +294,24 @@ def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
     P1, Q1 = eng.user_embeddings(), eng.item_embeddings()
     iu = sps.csr_array(ui.T)
     iu.sort_indices()
-    threads = lko.num_threads()
+    # how many threads?  The port's row-parallel loop calls SciPy's bundled OpenBLAS sposv from
+    # every thread; on the 256-thread bench host MORE threads were SLOWER (tools/oracle_threads.py,
+    # 5 M entries: 0.18 s at 8 threads, 0.33 s at 32, 0.81 s at 64, a crash at 128).  The baseline
+    # is the port at its BEST: a seeded row sample of the user half at 8 / 16 / 32 threads first,
+    # the fastest count for the measurement proper; all three are reported.
+    cap = lko.num_threads()
+    crng = np.random.default_rng(9)
+    crow = np.sort(crng.choice(ui.shape[0], max(512, ui.shape[0] // 40), replace=False))
+    csub, cthis = sps.csr_array(ui[crow]), P[crow]
+    cotor = lko.implicit_otor(Q, reg)
+    tried = {}
+    for t_ in sorted({min(8, cap), min(16, cap), cap}):
+        w_ = np.ascontiguousarray(cthis.copy())
+        lko.als_half_epoch(csub, w_, Q, cotor, t_)  # (first touch)
+        t0 = time.perf_counter()
+        lko.als_half_epoch(csub, w_, Q, cotor, t_)
+        tried[t_] = time.perf_counter() - t0
+    threads = min(tried, key=tried.get)
     rng = np.random.default_rng(5)
     out, secs, desc = {}, 0.0, []
     for name, mat, this, other, got in (("user", ui, P, Q, P1), ("item", iu, Q, P1, Q1)):
@@ -362,6 +379,14 @@ def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
         "host_cpus": os.cpu_count(),
         "cpu_seconds_per_epoch": round(secs, 3),
     }
+    cpu["threads_tried_seconds_on_sample"] = {str(t_): round(v, 4) for t_, v in tried.items()}
+    cpu["threads_note"] = (
+        "`cores` = the fastest of 8 / 16 / %d threads on a %d-row sample of the user half (the "
+        "port's row-parallel loop calls SciPy's bundled OpenBLAS sposv from every thread; beyond "
+        "~8 callers it slows down and at 128 it crashes -- tools/oracle_threads.py); the "
+        "reference's own default is min(ncpus, 8) threads (src/lenskit/schemas/settings.py:"
+        "182-185), BASELINE.md section 2 names $(nproc) = %d here" % (cap, len(crow),
+                                                                      os.cpu_count() or 0))
     return par, cpu
 
 
@@ -1149,6 +1174,51 @@ def summation_order_info(eng, make_engine, steps, ms_default, dev):
     return info
 
 
+# one-GPU epoch times (ms) of the committed bench lines, and the per-epoch time of work that does
+# NOT shrink with the ranks (cfg5's Z = other @ OtOr^-1 GEMM + inverse, every rank in full unless
+# LK_ALS_Z=sharded) -- the inputs of DESIGN.md section 6's predicted table
+ONE_GPU_MS = {64: 3.59, 128: 15.3, 256: 202.0}
+REPLICATED_MS = {256: 14.0}
+
+
+def predicted_epoch(eng, world):
+    """
+    DESIGN.md section 6's model of an N-GPU epoch, evaluated for THIS run so the measured line can
+    be read against it without a calculator: sharded kernels = one-GPU epoch / N; every rank's
+    replicated work; the row gathers on a full mesh ((N - 1)/N of the bytes over min(N - 1, 7)
+    links of 153 GB/s), of which only the last of S row slices is exposed; 2 small all-reduces of
+    ~30 us.  ``ring_ms``: the same bytes if RCCL rings (one link's rate).  A prediction made before
+    any multi-GPU run existed -- its value is in how the measured terms differ from it.
+    """
+    try:
+        kp = int(getattr(eng.backend, "kp", eng.k))
+        n1 = ONE_GPU_MS.get(kp)
+        if n1 is None or world < 2:
+            return None
+        from lkpy_amd._als_engine import sharded_z
+        S = int(getattr(eng, "slices", 1))
+        gathered = (eng.P.shape[0] + eng.Q.shape[0]) * kp * 4.0
+        zrep = REPLICATED_MS.get(kp, 0.0)
+        if sharded_z():
+            gathered += (eng.P.shape[0] + eng.Q.shape[0]) * kp * 4.0 if zrep else 0.0
+            zrep = zrep / world
+        link = 153e9
+        mesh = (world - 1) / world * gathered / (min(world - 1, 7) * link) * 1e3
+        ring = (world - 1) / world * gathered / link * 1e3
+        sharded = (n1 - REPLICATED_MS.get(kp, 0.0)) / world
+        fixed = 0.06
+        return {"model": "DESIGN.md section 6", "one_gpu_ms": n1, "world": world,
+                "sharded_kernels_ms": round(sharded, 3), "replicated_ms": round(zrep, 3),
+                "gather_bytes_per_epoch": gathered, "row_slices": S,
+                "gather_mesh_ms": round(mesh, 3), "gather_exposed_ms": round(mesh / S, 3),
+                "small_all_reduces_ms": fixed,
+                "epoch_ms": round(sharded + zrep + mesh / S + fixed, 3),
+                "epoch_ms_if_ring": round(sharded + zrep + max(ring / S, ring - sharded) + fixed, 3),
+                "z": "sharded" if sharded_z() else "replicated"}
+    except Exception as exc:  # noqa: BLE001 -- a reading aid, never costs the line
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def collective_times(eng, steps, dev, world):
     """
     world > 1: ``steps`` more epochs with the engine's collectives bracketed by events
@@ -1176,6 +1246,7 @@ def collective_times(eng, steps, dev, world):
     allr = [None] * world
     dist.all_gather_object(allr, mine)
     return {"per_rank_ms_per_epoch": allr,
+            "predicted": predicted_epoch(eng, world),
             "note": "stream time inside blocking collectives / exposed wait of the asynchronous "
                     "row gathers, per epoch, rank by rank (events on the launch stream; a "
                     "separate pass after the timed region)"}
@@ -1329,6 +1400,8 @@ def _cpu(c):
     if not isinstance(c, dict):
         return None
     d = _pick(c, "value", "unit", "cores", "kind", "error")
+    if isinstance(c.get("threads_tried_seconds_on_sample"), dict):
+        d["threads_tried_s"] = c["threads_tried_seconds_on_sample"]
     if "sample" in c:
         d["sample"] = _short(c["sample"], 140)
     return d
@@ -1808,7 +1881,7 @@ def main():
                 out["incomplete"] = True  # (a hung leg must not read as success)
                 emit(out)
                 sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)  # the line is out, marked incomplete -- and the run does not read as a success
 
         dog = threading.Timer(args.sharded_legs_timeout, bail)
         dog.daemon = True

@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <utility>
+#include <strings.h>
 #include <vector>
 
 #include "als_plan.h"
@@ -1957,10 +1958,22 @@ extern "C" int lk_als_plan_create(lk_als_plan **out, const void *h_indptr, int i
 {
     // the default is the hybrid order (include/lkamd.h); LK_ALS_RHS_ORDER=accurate: the tuned
     // kernels' own summation on every row (round 4's default)
+    // (case-insensitive, unknown values refused -- the rules of lkpy_amd._device.als_order_mode.
+    // `reference` = the STRICT mode needs the caller's right-hand-side workspace
+    // (lk_als_plan_set_rhs_workspace): a plan made here gets the flag, the caller attaches the
+    // buffer; until then its rows > 256 entries sum the normal matrix in the reference's blocks
+    // and the right-hand side in the kernels' own order)
     const char *e = getenv("LK_ALS_RHS_ORDER");
-    const bool accurate = e && strcmp(e, "accurate") == 0;
-    return lk_als_plan_create_ex(out, h_indptr, indptr_is_64, n_rows, k, solver,
-                                 accurate ? 0 : LK_ALS_PLAN_HYBRID_ORDER);
+    int32_t flags = LK_ALS_PLAN_HYBRID_ORDER;
+    if (e && e[0]) {
+        if (!strcasecmp(e, "accurate")) flags = 0;
+        else if (!strcasecmp(e, "reference")) flags = LK_ALS_PLAN_REFERENCE_ORDER;
+        else
+            LK_REQUIRE(!strcasecmp(e, "auto") || !strcasecmp(e, "hybrid") || !strcasecmp(e, "default"),
+                       "lk_als_plan_create: unknown LK_ALS_RHS_ORDER '%s' (auto / reference / accurate)",
+                       e);
+    }
+    return lk_als_plan_create_ex(out, h_indptr, indptr_is_64, n_rows, k, solver, flags);
 }
 
 extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, int indptr_is_64,
@@ -2124,7 +2137,9 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
     // a chunk)
     const char *dma_off = getenv("LK_BLK_CHUNK_DMA");
     const bool units256 = KP == 256 && !(dma_off && dma_off[0] == '0');
-    if (p->hybrid && (KP == 64 || units256)) {
+    // (padded k = 64: only the LDS-DMA Gram accumulation flushes a slab per 256-entry block; a
+    // -DLK_ALS_GRAM_DMA=0 build stores one slab per unit, so there a unit must be a chunk)
+    if (p->hybrid && ((KP == 64 && LK_ALS_GRAM_DMA) || units256)) {
         const char *e = getenv("LK_ALS_REF_UNIT");
         int u = e ? atoi(e) : LK_ALS_CHUNK;
         if (u < p->chunk) u = p->chunk;
@@ -2174,14 +2189,46 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
     }
     p->n_groups = (int64_t)grp_head.size();
 
-    int rc;
-    if ((rc = upload(&p->d_order, order)) != LK_OK || (rc = upload(&p->d_row_slab, row_slab)) ||
-        (rc = upload(&p->d_chunk_row, chunk_row)) || (rc = upload(&p->d_chunk_beg, chunk_beg)) ||
-        (rc = upload(&p->d_chunk_slab, chunk_slab)) ||
-        (rc = upload(&p->d_grp_head, grp_head)) || (rc = upload(&p->d_grp_cnt, grp_cnt)) ||
-        (rc = upload(&p->d_chunk_len, chunk_len))) {
-        lk_als_plan_destroy(p);
-        return rc;
+    // the schedule arrays: ONE device allocation and ONE copy (a fold-in plan of a batch of queries
+    // is built per call -- eight allocations and blocking copies were 0.4 ms of a 4 ms call)
+    {
+        auto padded = [](size_t bytes) { return lk::align_up(std::max<size_t>(bytes, 8), 256); };
+        const size_t b_order = padded(order.size() * 4), b_rslab = padded(row_slab.size() * 4),
+                     b_crow = padded(chunk_row.size() * 4), b_cbeg = padded(chunk_beg.size() * 8),
+                     b_cslab = padded(chunk_slab.size() * 4), b_ghead = padded(grp_head.size() * 4),
+                     b_gcnt = padded(grp_cnt.size() * 4), b_clen = padded(chunk_len.size() * 4);
+        const size_t total = b_order + b_rslab + b_crow + b_cbeg + b_cslab + b_ghead + b_gcnt + b_clen;
+        std::vector<char> host(total, 0);
+        size_t o = 0;
+        auto put = [&](const void *src, size_t bytes, size_t slot) {
+            if (bytes) memcpy(host.data() + o, src, bytes);
+            const size_t at = o;
+            o += slot;
+            return at;
+        };
+        const size_t o_order = put(order.data(), order.size() * 4, b_order);
+        const size_t o_rslab = put(row_slab.data(), row_slab.size() * 4, b_rslab);
+        const size_t o_cbeg = put(chunk_beg.data(), chunk_beg.size() * 8, b_cbeg);
+        const size_t o_crow = put(chunk_row.data(), chunk_row.size() * 4, b_crow);
+        const size_t o_cslab = put(chunk_slab.data(), chunk_slab.size() * 4, b_cslab);
+        const size_t o_ghead = put(grp_head.data(), grp_head.size() * 4, b_ghead);
+        const size_t o_gcnt = put(grp_cnt.data(), grp_cnt.size() * 4, b_gcnt);
+        const size_t o_clen = put(chunk_len.data(), chunk_len.size() * 4, b_clen);
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->d_pack), total);
+        if (e == hipSuccess) e = hipMemcpy(p->d_pack, host.data(), total, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            lk::set_error("lk_als_plan_create: %s", hipGetErrorString(e));
+            lk_als_plan_destroy(p);
+            return LK_E_HIP;
+        }
+        p->d_order = reinterpret_cast<int32_t *>(p->d_pack + o_order);
+        p->d_row_slab = reinterpret_cast<int32_t *>(p->d_pack + o_rslab);
+        p->d_chunk_beg = reinterpret_cast<int64_t *>(p->d_pack + o_cbeg);
+        p->d_chunk_row = reinterpret_cast<int32_t *>(p->d_pack + o_crow);
+        p->d_chunk_slab = reinterpret_cast<int32_t *>(p->d_pack + o_cslab);
+        p->d_grp_head = reinterpret_cast<int32_t *>(p->d_pack + o_ghead);
+        p->d_grp_cnt = reinterpret_cast<int32_t *>(p->d_pack + o_gcnt);
+        p->d_chunk_len = reinterpret_cast<int32_t *>(p->d_pack + o_clen);
     }
 
     size_t off = 0;
@@ -2269,14 +2316,7 @@ extern "C" void lk_als_plan_destroy(lk_als_plan *p)
         (void)hipEventDestroy(p->ev_join_rhs);
         (void)hipEventDestroy(p->ev_mid_rhs);
     }
-    if (p->d_order) (void)hipFree(p->d_order);
-    if (p->d_row_slab) (void)hipFree(p->d_row_slab);
-    if (p->d_chunk_row) (void)hipFree(p->d_chunk_row);
-    if (p->d_chunk_beg) (void)hipFree(p->d_chunk_beg);
-    if (p->d_chunk_len) (void)hipFree(p->d_chunk_len);
-    if (p->d_chunk_slab) (void)hipFree(p->d_chunk_slab);
-    if (p->d_grp_head) (void)hipFree(p->d_grp_head);
-    if (p->d_grp_cnt) (void)hipFree(p->d_grp_cnt);
+    if (p->d_pack) (void)hipFree(p->d_pack);  // (d_order ... d_chunk_len point into it)
     delete p;
 }
 

@@ -95,6 +95,7 @@ struct lk_als_plan {
     int32_t long_row = LK_ALS_LONG_ROW;  // rows longer than this are chunked
     size_t off_ginv = 0, off_invws = 0;  // [KP x KP] float inverse, spd_inverse scratch
     // device-side schedule
+    char *d_pack = nullptr;          // the one device allocation the arrays below live in
     int32_t *d_order = nullptr;      // [n_rows] rows, longest first
     int32_t *d_row_slab = nullptr;   // [n_rows] first slab of the row or -1
     int32_t *d_chunk_row = nullptr;  // [n_chunks]

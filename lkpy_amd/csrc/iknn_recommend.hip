@@ -57,6 +57,8 @@ namespace rec {
 #define LK_REC_RW 4096
 #endif
 constexpr int RW = LK_REC_RW;   // targets per window = per wave (a multiple of 512)
+static_assert(RW % 512 == 0 && RW <= 4096,
+              "phase B's queue words pack (count << 12) | target: a window holds at most 4096 targets");
 constexpr int TPL = RW / 64;    // targets per lane in the scan / sweep (lane-owned runs)
 static_assert(RW % 512 == 0, "window = 64 lanes x groups of 8 targets");
 constexpr int RWAVES = 4;       // waves per workgroup (each on its own window task)
