@@ -95,6 +95,15 @@ def to_host(t: torch.Tensor, threads: int = 0, index_bound: int | None = None) -
     index_bound <= 65 536 it crosses the link as uint16 (``lk_download_i32_narrow``).
     """
     nbytes = t.numel() * t.element_size()
+    if t.is_cuda and (256 << 10) <= nbytes < (64 << 20) and t.dtype in _NP_OF:
+        # mid-sized results (the [B x n] lists of a batch recommend call: 8 MB): one DMA into a
+        # pinned block of torch's caching host allocator -- a plain ``.cpu()`` lands in fresh
+        # pageable pages at 10 ... 40 GB/s (0.2 ... 0.8 ms for those 8 MB, measured); the array
+        # keeps the block alive and hands it back to the cache when it is dropped
+        host = torch.empty(tuple(t.shape), dtype=t.dtype, pin_memory=True)
+        host.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return host.numpy()
     if not t.is_cuda or nbytes < (64 << 20) or t.dtype not in _NP_OF:
         return t.cpu().numpy()
     t = t.contiguous()

@@ -20,21 +20,25 @@ def recommend(pipe: Pipeline, users, n: int, *, batch_size: int = 16384) -> Item
     iteration over ``(key, list)``, ``out.to_df()``."""
     scorer = pipe.node("scorer").component
     lookup = pipe.node("history-lookup").component
-    users = list(users)
-    out = {}
     if hasattr(scorer, "recommend_batch") and hasattr(lookup, "batch") and \
             getattr(scorer, "accepts_history_batch", False):
         # the whole batch by user number: the histories are rows of the HBM-resident training
-        # matrix, no per-query host work; the lists are built when somebody looks at them
+        # matrix, no per-query host work (an id ARRAY stays an array); the lists are built when
+        # somebody looks at them
+        ids = users if isinstance(users, np.ndarray) else np.asarray(list(users))
         idx, sc = [], []
-        for s in range(0, len(users), batch_size):
-            i, v = scorer.recommend_batch(lookup.batch(users[s:s + batch_size]), n)
+        for s in range(0, len(ids), batch_size):
+            i, v = scorer.recommend_batch(lookup.batch(ids[s:s + batch_size]), n)
             idx.append(i)
             sc.append(v)
         if not idx:
             return ItemListCollection(("user_id",))
-        return ItemListCollection.from_arrays(users, np.concatenate(idx), np.concatenate(sc),
+        one = len(idx) == 1
+        return ItemListCollection.from_arrays(ids, idx[0] if one else np.concatenate(idx),
+                                              sc[0] if one else np.concatenate(sc),
                                               scorer.items, key=("user_id",))
+    users = list(users)
+    out = {}
     if hasattr(scorer, "recommend_batch"):
         for s in range(0, len(users), batch_size):
             chunk = users[s:s + batch_size]

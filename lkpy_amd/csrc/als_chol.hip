@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <utility>
+#include <mutex>
 #include <strings.h>
 #include <vector>
 
@@ -1940,6 +1941,59 @@ extern "C" int32_t lk_padded_dim(int32_t k)
     return 0;
 }
 
+// ---- pool of schedule buffers (per device; plans of a few thousand rows come and go per call) ----
+namespace {
+struct PackPool {
+    static constexpr int SLOTS = 8;
+    static constexpr size_t MAX_BYTES = (size_t)8 << 20;  // larger buffers are not pooled
+    std::mutex mu;
+    struct Slot {
+        char *ptr = nullptr;
+        size_t cap = 0;
+        int dev = -1;
+    } slot[SLOTS];
+};
+PackPool &pack_pool()
+{
+    static PackPool pool;
+    return pool;
+}
+char *pack_pool_take(size_t bytes, size_t *cap)
+{
+    if (bytes > PackPool::MAX_BYTES) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    PackPool &pl = pack_pool();
+    std::lock_guard<std::mutex> lock(pl.mu);
+    int best = -1;
+    for (int i = 0; i < PackPool::SLOTS; ++i)
+        if (pl.slot[i].ptr && pl.slot[i].dev == dev && pl.slot[i].cap >= bytes &&
+            (best < 0 || pl.slot[i].cap < pl.slot[best].cap))
+            best = i;
+    if (best < 0) return nullptr;
+    char *ptr = pl.slot[best].ptr;
+    *cap = pl.slot[best].cap;
+    pl.slot[best].ptr = nullptr;
+    return ptr;
+}
+bool pack_pool_give(char *ptr, size_t cap)
+{
+    if (cap > PackPool::MAX_BYTES) return false;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    PackPool &pl = pack_pool();
+    std::lock_guard<std::mutex> lock(pl.mu);
+    for (int i = 0; i < PackPool::SLOTS; ++i)
+        if (!pl.slot[i].ptr) {
+            pl.slot[i].ptr = ptr;
+            pl.slot[i].cap = cap;
+            pl.slot[i].dev = dev;
+            return true;
+        }
+    return false;  // pool full: the caller frees
+}
+}  // namespace
+
 template <typename T>
 static int upload(T **dst, const std::vector<T> &src)
 {
@@ -2041,10 +2095,29 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
                             : (int64_t) static_cast<const int32_t *>(h_indptr)[r];
     };
 
+    // rows by descending length, ties in row order: one sort of packed 64-bit keys
+    // (inverted length << 32 | row) -- the same order a stable sort by length gives, at a third
+    // of its time (a fold-in plan is built per call; cfg5's user plan orders 10^7 rows)
     std::vector<int32_t> order((size_t)n_rows);
-    for (int64_t r = 0; r < n_rows; ++r) order[(size_t)r] = (int32_t)r;
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int32_t x, int32_t y) { return len(x) > len(y); });
+    {
+        std::vector<uint64_t> keys((size_t)n_rows);
+        bool fits = true;
+        for (int64_t r = 0; r < n_rows; ++r) {
+            const int64_t n = len(r);
+            if (n < 0 || n > (int64_t)0xffffffffll) fits = false;
+            keys[(size_t)r] = ((uint64_t)(0xffffffffull - (uint64_t)(n & 0xffffffffll)) << 32) |
+                              (uint64_t)(uint32_t)r;
+        }
+        if (fits) {
+            std::sort(keys.begin(), keys.end());
+            for (int64_t r = 0; r < n_rows; ++r)
+                order[(size_t)r] = (int32_t)(uint32_t)(keys[(size_t)r] & 0xffffffffull);
+        } else {  // (a row of 2^32 entries or more: the comparison sort)
+            for (int64_t r = 0; r < n_rows; ++r) order[(size_t)r] = (int32_t)r;
+            std::stable_sort(order.begin(), order.end(),
+                             [&](int32_t x, int32_t y) { return len(x) > len(y); });
+        }
+    }
 
     {
         // first task whose row has <= 16 entries (the order is longest first)
@@ -2214,7 +2287,12 @@ extern "C" int lk_als_plan_create_ex(lk_als_plan **out, const void *h_indptr, in
         const size_t o_ghead = put(grp_head.data(), grp_head.size() * 4, b_ghead);
         const size_t o_gcnt = put(grp_cnt.data(), grp_cnt.size() * 4, b_gcnt);
         const size_t o_clen = put(chunk_len.data(), chunk_len.size() * 4, b_clen);
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->d_pack), total);
+        hipError_t e = hipSuccess;
+        p->d_pack = pack_pool_take(total, &p->pack_cap);
+        if (!p->d_pack) {
+            p->pack_cap = total;
+            e = hipMalloc(reinterpret_cast<void **>(&p->d_pack), total);
+        }
         if (e == hipSuccess) e = hipMemcpy(p->d_pack, host.data(), total, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             lk::set_error("lk_als_plan_create: %s", hipGetErrorString(e));
@@ -2316,7 +2394,13 @@ extern "C" void lk_als_plan_destroy(lk_als_plan *p)
         (void)hipEventDestroy(p->ev_join_rhs);
         (void)hipEventDestroy(p->ev_mid_rhs);
     }
-    if (p->d_pack) (void)hipFree(p->d_pack);  // (d_order ... d_chunk_len point into it)
+    // (d_order ... d_chunk_len point into d_pack.)  Small schedule buffers go back to a per-device
+    // pool instead of hipFree: a fold-in plan lives for one call, and hipMalloc + hipFree were a
+    // quarter of a millisecond of it.  hipFree waits for the device; so does this.
+    if (p->d_pack) {
+        (void)hipDeviceSynchronize();
+        if (!pack_pool_give(p->d_pack, p->pack_cap)) (void)hipFree(p->d_pack);
+    }
     delete p;
 }
 

@@ -96,6 +96,7 @@ struct lk_als_plan {
     size_t off_ginv = 0, off_invws = 0;  // [KP x KP] float inverse, spd_inverse scratch
     // device-side schedule
     char *d_pack = nullptr;          // the one device allocation the arrays below live in
+    size_t pack_cap = 0;             // its size (it may come from, and return to, a pool)
     int32_t *d_order = nullptr;      // [n_rows] rows, longest first
     int32_t *d_row_slab = nullptr;   // [n_rows] first slab of the row or -1
     int32_t *d_chunk_row = nullptr;  // [n_chunks]

@@ -807,6 +807,16 @@ static Layout layout(int64_t n_items, int64_t n_queries, int64_t max_query_hits,
 {
     Layout L;
     L.rows = n_queries < REC_PANEL_ROWS ? (n_queries > 0 ? n_queries : 1) : REC_PANEL_ROWS;
+    // the score panel is rows x n_items floats: beyond BASELINE's 62 k items the batch shrinks so
+    // that the panel stays inside a byte budget (LK_REC_PANEL_GB, default 8: 2 000 queries per
+    // batch at 10^6 items) instead of growing with the catalogue
+    {
+        const char *e = getenv("LK_REC_PANEL_GB");
+        const double gb = e && atof(e) > 0 ? atof(e) : 8.0;
+        int64_t fit = (int64_t)(gb * (double)(1ull << 30) / ((double)ld_items(n_items) * 4.0));
+        if (fit < 64) fit = 64;
+        if (L.rows > fit) L.rows = fit;
+    }
     // a batch holds up to REC_HITS_MIN hits (never less than the heaviest query's; a small call
     // does not pay for more than all of its queries could need)
     // (a query's region = its hits + 16 per window: every window's share is rounded up to a
@@ -882,6 +892,12 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
     LK_REQUIRE(d_sim_indptr && d_ref_ptr && h_query_hits && d_ws && d_out_idx,
                "lk_iknn_recommend: null pointer");
     hipStream_t st = as_stream(stream);
+    // the per-row window offsets are n_items x (n_items / RW + 1) words: 15 MB at 62 k items, 1 GB
+    // at 10^6 -- refused, with the reason, where that table alone would pass 16 GiB (4 x 10^6 items)
+    LK_REQUIRE((double)n_items * (double)(nwindows(n_items) + 1) * 4.0 <= 16.0 * (double)(1ull << 30),
+               "lk_iknn_recommend: the window table of a %lld-item catalogue exceeds 16 GiB; "
+               "score such catalogues through lk_iknn_score_batch with explicit target lists",
+               (long long)n_items);
     const Layout L = layout(n_items, n_queries, max_query_hits, max_nbrs, n);
     char *ws = static_cast<char *>(d_ws);
     int *status = reinterpret_cast<int *>(ws + L.off_status);  // [0] NaN similarity, [1] task counter

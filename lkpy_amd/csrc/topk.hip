@@ -2368,6 +2368,10 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
             int64_t rows_a = rows;  // rows of range A (all of them: no split)
             if (lk::topk_overlap() && wgs > round && wgs % round != 0)
                 rows_a = (wgs / round) * round * (2 * lk::SC_UB);
+            // item-split launches: only when the WHOLE batch is less than one round of workgroups
+            // (measured on the 1270-workgroup cfg2 call: splitting its partial last round of 246
+            // in two made the call slower, 13.1 against 12.3 ms)
+            const bool may_split = wgs <= round;
             auto filter = [&](int64_t r0, int64_t nr, hipStream_t s) {
                 dim3 ugrid((unsigned)((nr + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB)));
                 const float *uu = ub_users + r0 * ld_users;
@@ -2380,7 +2384,8 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
                 const int64_t n_itiles = (n_items + lk::SC_IB - 1) / lk::SC_IB;
                 const bool dma_kernel = (LK_TOPK_DMA && KP == 64) ||
                                         (LK_TOPK_DMA >= 2 && (KP == 32 || KP == 128 || KP == 256));
-                if (dma_kernel && lk::topk_split() && ugrid.x < 2 * 256 && n_itiles >= 8) {
+                if (may_split && dma_kernel && lk::topk_split() && ugrid.x < 2 * 256 &&
+                    n_itiles >= 8) {
                     int64_t parts = (2 * 256 + ugrid.x - 1) / ugrid.x;
                     if (parts > n_itiles / 4) parts = n_itiles / 4;  // >= 4 tiles per workgroup
                     if (parts > 1) {

@@ -68,7 +68,7 @@ def _check(gi, gs, wi, ws, rows, ptr, idx):
     return ties
 
 
-@pytest.mark.parametrize("walk", ["packed", "pieces"])
+@pytest.mark.parametrize("walk", ["packed", "pieces", "packed-small-panel"])
 @pytest.mark.parametrize("explicit", [True, False])
 @pytest.mark.parametrize("save_nbrs,max_nbrs,n", [(50, 20, 10), (None, 5, 100), (None, 64, 30)])
 def test_recommend_matches_the_reference_pipeline(gpu, oracle, monkeypatch, walk, explicit,
@@ -81,6 +81,11 @@ def test_recommend_matches_the_reference_pipeline(gpu, oracle, monkeypatch, walk
 
     if walk == "pieces":
         monkeypatch.setenv("LK_REC_PACKED", "0")
+    if walk.endswith("small-panel"):
+        # the score panel's byte budget (LK_REC_PANEL_GB; round 6): so small here that the 124
+        # queries go through in two batches of 64 rows -- the same lists
+        monkeypatch.setenv("LK_REC_PANEL_GB", "0.000001")
+        walk = "packed"
 
     rng = np.random.default_rng(7)
     n_users, n_items = 600, 9001  # three windows of 4096, the last one partial

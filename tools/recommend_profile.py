@@ -20,6 +20,7 @@ from lkpy_amd.data import Dataset, Vocabulary  # noqa: E402
 from lkpy_amd.training import TrainingOptions  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+SHORT = len(sys.argv) > 2 and sys.argv[2] == "short"  # profiling runs: the whole call only
 r = synth.ml25m_like()
 nu, ni = r.shape
 rows = np.repeat(np.arange(nu, dtype=np.int32), np.diff(r.indptr))
@@ -47,6 +48,9 @@ def t(label, fn, reps=7):
     return res
 
 
+if SHORT:
+    t("whole call", lambda: sc.recommend_batch(lk.batch(users), 100), reps=10)
+    sys.exit(0)
 hb = t("lookup.batch (vocabulary, lengths)", lambda: lk.batch(users))
 src = lk._device_matrix()["csr"]
 src = D.DeviceCSR(src.indptr, src.indices, None, src.shape, src.h_indptr)
