@@ -1476,7 +1476,8 @@ static int launch_blk(const lk_als_plan *p, const void *indptr, const int32_t *i
         hipStream_t sv = st;
         if (side_stream_enabled() && p->n_chunks > 0) {
             if (!p->side) {
-                LK_HIP_CHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+                p->side = lk::side_stream_acquire();
+                LK_REQUIRE(p->side != nullptr, "als: no side stream");
                 LK_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
                 LK_HIP_CHECK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
             }

@@ -246,7 +246,8 @@ int plan_fork_rhs(const lk_als_plan *p, hipStream_t st, hipStream_t *side)
     *side = st;
     if (!rhs_side_enabled()) return LK_OK;
     if (!p->side_rhs) {
-        LK_HIP_CHECK(hipStreamCreateWithFlags(&p->side_rhs, hipStreamNonBlocking));
+        p->side_rhs = lk::side_stream_acquire();
+        LK_REQUIRE(p->side_rhs != nullptr, "als: no side stream");
         LK_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fork_rhs, hipEventDisableTiming));
         LK_HIP_CHECK(hipEventCreateWithFlags(&p->ev_join_rhs, hipEventDisableTiming));
         LK_HIP_CHECK(hipEventCreateWithFlags(&p->ev_mid_rhs, hipEventDisableTiming));

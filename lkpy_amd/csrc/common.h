@@ -35,6 +35,13 @@ void set_error(const char *fmt, ...);
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Non-blocking side streams from a per-device pool (misc.hip): a plan that lives for one call (the
+// fold-in of a batch of queries) would otherwise create and destroy two streams per call -- a
+// quarter of a millisecond.  A released stream may still hold queued work: whoever takes it next
+// simply queues behind it.
+hipStream_t side_stream_acquire();
+void side_stream_release(hipStream_t s);
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

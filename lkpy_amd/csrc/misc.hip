@@ -1,6 +1,10 @@
 // misc.hip -- error plumbing, device query, pad/unpad of factor matrices.
 #include <stdarg.h>
 
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "common.h"
 
 namespace lk {
@@ -13,6 +17,54 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+namespace {
+struct SideStreamPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> idle;  // (device, stream)
+};
+SideStreamPool &side_pool()
+{
+    static SideStreamPool *pool = new SideStreamPool();  // (never destroyed: outlives every plan)
+    return *pool;
+}
+}  // namespace
+
+hipStream_t side_stream_acquire()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    {
+        SideStreamPool &pl = side_pool();
+        std::lock_guard<std::mutex> lock(pl.mu);
+        for (size_t i = 0; i < pl.idle.size(); ++i)
+            if (pl.idle[i].first == dev) {
+                hipStream_t s = pl.idle[i].second;
+                pl.idle.erase(pl.idle.begin() + (long)i);
+                return s;
+            }
+    }
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return s;
+}
+
+void side_stream_release(hipStream_t s)
+{
+    if (!s) return;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipStreamDestroy(s);
+        return;
+    }
+    SideStreamPool &pl = side_pool();
+    std::lock_guard<std::mutex> lock(pl.mu);
+    if (pl.idle.size() >= 64) {
+        (void)hipStreamDestroy(s);
+        return;
+    }
+    pl.idle.emplace_back(dev, s);
 }
 
 // [n x k] (ld_src) -> [n x ld_dst], zero pad columns

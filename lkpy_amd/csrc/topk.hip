@@ -436,16 +436,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 // next tile's first prefetch into it) -- wave w's 64 records are exactly the 4 KiB its own DMA
 // instructions write, so no barrier separates the flush from the next tile.
 // Item-split launches (small batches: fewer than one round of 2 x 256 workgroups of 128 users each
-// would leave most of the chip idle -- 10 000 users are 79 workgroups): blockIdx.y walks the item
-// tiles [t_lo, t_hi) only, and the candidates of a row, now found by several workgroups, are
-// appended through the row's global counter (zeroed by stage 1) instead of an LDS counter.
-// The list's ORDER then depends on timing; its content does not, and the selection sorts it.
-#define LK_FILTER_SPLIT_RANGE                                                                      \
-    const bool split = tiles_per_wg > 0;                                                           \
-    const int64_t t_lo = split ? (int64_t)blockIdx.y * tiles_per_wg : 0;                           \
-    const int64_t t_hi = split ? (t_lo + tiles_per_wg < n_itiles ? t_lo + tiles_per_wg : n_itiles) \
-                               : n_itiles;                                                         \
-    if (t_lo >= t_hi) return;
+// would leave most of the chip idle -- 10 000 users are 79 workgroups): blockIdx.y = part y of
+// S = gridDim.y walks the item tiles y, y + S, y + 2 S, ... (interleaved: item numbers often follow
+// popularity, a contiguous range would put most candidates into part 0) and keeps ITS candidates of
+// a row in a sub-list of its own -- sub_cap entries at ((row * S + y) * sub_cap), count in
+// cand_cnt[row * S + y], positions from the workgroup's LDS counter as in the unsplit launch --
+// which cand_merge_kernel then packs into the row's list.  (A first version appended to the
+// row's list through a global counter: an atomic with return crosses the XCDs' L2s, and one to
+// three such round trips per tile and wave doubled the kernel's time.)
+#define LK_FILTER_SPLIT_RANGE                                                                    \
+    const bool split = tiles_per_wg > 0;                                                         \
+    const int64_t t_step = split ? (int64_t)gridDim.y : 1;                                       \
+    const int64_t t_lo = split ? (int64_t)blockIdx.y : 0;                                        \
+    const int64_t t_hi = n_itiles;                                                               \
+    const int64_t l_stride = split ? t_step * (int64_t)tiles_per_wg : (int64_t)cand_cap;         \
+    const int64_t l_off = split ? (int64_t)blockIdx.y * tiles_per_wg : 0;                        \
+    const unsigned l_cap = split ? (unsigned)tiles_per_wg : (unsigned)cand_cap;                  \
+    if (t_lo >= t_hi) {                                                                          \
+        for (int rr = threadIdx.x; rr < 128; rr += 256)                                          \
+            if ((int64_t)blockIdx.x * 128 + rr < n_users)                                        \
+                cand_cnt[((int64_t)blockIdx.x * 128 + rr) * t_step + t_lo] = 0u;                 \
+        return;                                                                                  \
+    }
 
 constexpr int F64_U_FLOATS = 128 * 64;
 constexpr int F64_I_FLOATS = 256 * 16;  // one slab buffer
@@ -532,7 +544,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     unsigned *rids = rids_all + wave * 64;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    for (int64_t itile = t_lo; itile < t_hi; ++itile) {
+    for (int64_t itile = t_lo; itile < t_hi; itile += t_step) {
         const int64_t i0 = itile * SC_IB;
         f32x16 acc[UT][4];
 #pragma unroll
@@ -545,7 +557,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         for (int s = 0; s < 4; ++s) {
             // request the next slab (of this tile, or the first of the next one)
             if (s < 3) slab_dma(i0, s + 1);
-            else if (itile + 1 < t_hi) slab_dma(i0 + SC_IB, 0);
+            else if (itile + t_step < t_hi) slab_dma(i0 + t_step * SC_IB, 0);
             const float *ib = li + (s & 1) * F64_I_FLOATS;
 #pragma unroll
             for (int kk = 0; kk < 16; kk += 2) {
@@ -583,11 +595,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                 // the flag is "not below": NaN ends here, and so does a +inf score of a row past
                 // the end (tau = +inf, clamped operands)
                 if (x >= s_tau[row] && (int64_t)(u0 + row) < n_users) {
-                    // (an item-split launch: the row's list is shared by several workgroups)
-                    const unsigned pos = split ? atomicAdd(&cand_cnt[u0 + row], 1u)
-                                               : atomicAdd(&s_cnt[row], 1u);  // LDS
-                    if (pos < (unsigned)cand_cap)
-                        cand[(u0 + row) * cand_cap + pos] =
+                    const unsigned pos = atomicAdd(&s_cnt[row], 1u);  // LDS
+                    if (pos < l_cap)  // (item-split launch: this part's sub-list of the row)
+                        cand[(u0 + row) * l_stride + l_off + pos] =
                             ((unsigned long long)f2key(x) << 32) | (0xffffffffu - it);
                 }
             }
@@ -632,9 +642,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         flush();
     }
     __syncthreads();
-    if (!split)
-        for (int rr = tid; rr < UB; rr += 256)
-            if (u0 + rr < n_users) cand_cnt[u0 + rr] = s_cnt[rr];
+    for (int rr = tid; rr < UB; rr += 256)
+        if (u0 + rr < n_users) cand_cnt[(u0 + rr) * t_step + t_lo] = s_cnt[rr];
 }
 
 #if LK_TOPK_DMA >= 2
@@ -713,7 +722,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     unsigned *rids = rids_all + wave * 64;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    for (int64_t itile = t_lo; itile < t_hi; ++itile) {
+    for (int64_t itile = t_lo; itile < t_hi; itile += t_step) {
         const int64_t i0 = itile * SC_IB;
         f32x16 acc[UT][4];
 #pragma unroll
@@ -727,7 +736,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
             for (int par = 0; par < 2; ++par) {
                 const int s = 2 * sp + par;
                 if (s + 1 < NS) slab_dma(i0, s + 1);
-                else if (itile + 1 < t_hi) slab_dma(i0 + SC_IB, 0);
+                else if (itile + t_step < t_hi) slab_dma(i0 + t_step * SC_IB, 0);
                 const float *bb = lds_all + par * BUF;
 #pragma unroll
                 for (int kk = 0; kk < 16; kk += 2) {
@@ -763,11 +772,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                 const float x = rvals[rec * 16 + rg];
                 const unsigned row = rowb + (rg & 3) + 8 * (rg >> 2);
                 if (x >= s_tau[row] && (int64_t)(u0 + row) < n_users) {
-                    // (an item-split launch: the row's list is shared by several workgroups)
-                    const unsigned pos = split ? atomicAdd(&cand_cnt[u0 + row], 1u)
-                                               : atomicAdd(&s_cnt[row], 1u);  // LDS
-                    if (pos < (unsigned)cand_cap)
-                        cand[(u0 + row) * cand_cap + pos] =
+                    const unsigned pos = atomicAdd(&s_cnt[row], 1u);  // LDS
+                    if (pos < l_cap)  // (item-split launch: this part's sub-list of the row)
+                        cand[(u0 + row) * l_stride + l_off + pos] =
                             ((unsigned long long)f2key(x) << 32) | (0xffffffffu - it);
                 }
             }
@@ -812,9 +819,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         flush();
     }
     __syncthreads();
-    if (!split)
-        for (int rr = tid; rr < UB; rr += 256)
-            if (u0 + rr < n_users) cand_cnt[u0 + rr] = s_cnt[rr];
+    for (int rr = tid; rr < UB; rr += 256)
+        if (u0 + rr < n_users) cand_cnt[(u0 + rr) * t_step + t_lo] = s_cnt[rr];
 }
 #endif  // LK_TOPK_DMA >= 2
 
@@ -1064,6 +1070,7 @@ __device__ __forceinline__ void bitonic128_desc(unsigned long long (&r)[2], int 
     if constexpr (KK < 128) bitonic128_desc<KK * 2>(r, lane);
 }
 
+constexpr int WSEL_LONG_EXCL = 1024;  // exclusion entries beyond which a row goes to the second tier
 template <int STRIDE, int CAP>
 __device__ __forceinline__ void wave_select_row(
     const int64_t b /* batch row, wave-uniform */, unsigned *tab /* LDS, CAP / 16 * 21 words */,
@@ -1072,7 +1079,7 @@ __device__ __forceinline__ void wave_select_row(
     int64_t user_base, int n, int32_t *__restrict__ out_idx, float *__restrict__ out_score,
     int64_t out_ld, int *__restrict__ redo /* [0] = count, [1 ..] = user rows */, int redo_cap,
     int *__restrict__ big /* [0] = count, [1 ..] = batch rows with more than CAP candidates */,
-    int big_cap)
+    int big_cap, int long_excl = WSEL_LONG_EXCL)
 {
     constexpr int NJ = CAP / 64, NG = NJ / WSEL_GRP, WSEL_TAB = CAP / 16 * 21;
     static_assert(STRIDE >= 64 * WSEL_GRP, "eager loads stay inside the row's list");
@@ -1106,7 +1113,12 @@ __device__ __forceinline__ void wave_select_row(
         if (lane == 0) flag();
         return;
     }
-    if (m > (unsigned)CAP) {  // second tier (cand_select_kernel with room for STRIDE keys)
+    // second tier (cand_select_kernel: a workgroup per row with room for STRIDE keys): rows with
+    // more candidates than this tier holds -- and rows with a very long exclusion list, which 256
+    // threads walk four times as fast as one wave: a launch is as long as its longest row, and in
+    // a SMALL batch (10 000 sampled users: 0.5 ms of the 2.1 ms call) nothing hides that walk
+    // (long_excl: 1024 entries, 256 in a small batch -- lk::long_excl)
+    if (m > (unsigned)CAP || ee - eb > (int64_t)long_excl) {
         if (lane == 0) {
             const int pos = big ? atomicAdd(&big[0], 1) : big_cap;
             if (pos < big_cap)
@@ -1361,12 +1373,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void ca
     const int64_t *__restrict__ excl_ptr, const int32_t *__restrict__ excl_items,
     int64_t user_base, int n, int32_t *__restrict__ out_idx, float *__restrict__ out_score,
     int64_t out_ld, int *__restrict__ redo, int redo_cap, int *__restrict__ big, int big_cap,
-    int64_t row0 /* batch row of workgroup 0 */)
+    int64_t row0 /* batch row of workgroup 0 */, int long_excl)
 {
     __shared__ __attribute__((aligned(16))) unsigned tab[WSEL_CAP / 16 * 21];
     wave_select_row<STRIDE, WSEL_CAP>((int64_t)blockIdx.x + row0, tab, cand, cand_cnt, excl_ptr,
                                       excl_items, user_base, n, out_idx, out_score, out_ld, redo,
-                                      redo_cap, big, big_cap);
+                                      redo_cap, big, big_cap, long_excl);
 }
 
 // Stage 1 of the fused selection, a wave per row: tau[b] = the r-th largest of 256 class maxima
@@ -1962,6 +1974,39 @@ static int64_t fused_rows(int64_t n_sub_padded, bool panel)
 }
 constexpr int FUSED_MAX_N = 128;       // expected candidates <= 8 n <= FUSED_CAP / 2
 
+// Item-split filter launches (LK_FILTER_SPLIT_RANGE): the S sub-lists of a row -> the row's list.
+// One wave per row: lane s holds part s's count, a wave scan gives the offsets, the parts are
+// copied one after the other (64 keys per step).  A part that overflowed its sub-list makes the
+// row an overflowed row (count STRIDE + 1: the exact redo path takes it).
+__global__ __launch_bounds__(256) void cand_merge_kernel(
+    const unsigned long long *__restrict__ sub, const unsigned *__restrict__ sub_cnt, int parts,
+    int sub_cap, int64_t rows, unsigned long long *__restrict__ cand, unsigned *__restrict__ cnt,
+    int stride)
+{
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned c = lane < parts ? sub_cnt[b * parts + lane] : 0u;
+    const bool over = __any(c > (unsigned)sub_cap);
+    unsigned incl = c;  // inclusive scan over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    const unsigned total = __shfl(incl, 63, 64);
+    if (over || total > (unsigned)stride) {
+        if (lane == 0) cnt[b] = (unsigned)stride + 1u;
+        return;
+    }
+    for (int p = 0; p < parts; ++p) {
+        const unsigned n = __shfl(c, p, 64), base = __shfl(incl, p, 64) - n;
+        const unsigned long long *src = sub + (b * parts + p) * (int64_t)sub_cap;
+        for (unsigned i = lane; i < n; i += 64) cand[b * stride + base + i] = src[i];
+    }
+    if (lane == 0) cnt[b] = total;
+}
+
 static bool tau_mask()
 {
     const char *e = getenv("LK_TOPK_TAU_MASK");  // A/B knob (read per call)
@@ -2022,6 +2067,16 @@ static bool topk_overlap()
 {
     const char *e = getenv("LK_TOPK_OVERLAP");
     return !(e && e[0] == '0');
+}
+// Measured (ML-25M shape, trained factors, n = 100): the cfg2 call over all 162 541 users takes
+// 12.0 ms with the boundary at 4096 or 1024 and 12.5 at 256 (its selection hides beside the filter's
+// partial round either way); a 10 000-user batch -- where the selection launch stands alone and is
+// as long as its slowest row -- 2.55 / 2.13 / 2.01 / 2.10 ms at 4096 / 1024 / 256 / 64.
+static int long_excl(bool small_batch)
+{
+    const char *e = getenv("LK_TOPK_LONG_EXCL");  // tuning knob
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : (small_batch ? 256 : WSEL_LONG_EXCL);
 }
 static bool topk_split()
 {
@@ -2085,8 +2140,25 @@ constexpr int FUSED_LCAP = 1024;      // candidates the first selection tier hol
 constexpr int FUSED_BIG_CAP = 32768;  // rows per batch the second tier takes (more: redo path)
 
 struct FusedLayout {
-    size_t off_sub, off_tau, off_cnt, off_cand, off_flags, off_qs, bytes;
+    size_t off_sub, off_tau, off_cnt, off_cand, off_flags, off_qs, off_parts, off_pcnt, bytes;
+    int parts, part_cap;  // item-split launches of a small batch (parts <= 1: none)
 };
+constexpr int FUSED_PART_CAP = 512;  // candidates per (row, part) sub-list
+
+// how many parts the item tiles of a batch of `rows` users are split into: as many as keep the
+// launch inside ONE round of 2 x 256 workgroups, at least 4 tiles each; 1 = no split
+static int filter_parts(int64_t rows, int64_t n_items, int kp)
+{
+    const int64_t wgs = (rows + 2 * SC_UB - 1) / (2 * SC_UB);
+    const int64_t n_itiles = (n_items + SC_IB - 1) / SC_IB;
+    const bool dma_kernel = (LK_TOPK_DMA && kp == 64) ||
+                            (LK_TOPK_DMA >= 2 && (kp == 32 || kp == 128 || kp == 256));
+    if (!dma_kernel || !topk_split() || wgs >= 2 * 256 || n_itiles < 8) return 1;
+    int64_t parts = (2 * 256) / wgs;
+    if (parts > n_itiles / 4) parts = n_itiles / 4;
+    if (parts > 64) parts = 64;  // (cand_merge_kernel: a lane per part)
+    return parts < 2 ? 1 : (int)parts;
+}
 
 // stage 1 as class maxima (sample_cmax_kernel + cmax_tau_kernel): unless switched off, and as long
 // as four waves' bitmaps of the sample fit 64 KiB of LDS (catalogues up to ~3 M items at 1/24)
@@ -2096,7 +2168,7 @@ static bool cmax_usable(int64_t n_items, int32_t n)
     return stage1_cmax() && (size_t)(words + CMAX_LDS_EXTRA) * 16 <= 65536;
 }
 
-static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n)
+static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n, int kp = SC_KC)
 {
     const int64_t nsub = padded_items(fused_sample_items(n_items, n));
     const bool cmax = cmax_usable(n_items, n);
@@ -2116,6 +2188,18 @@ static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n)
     off += align_up((size_t)(1 + FUSED_REDO_CAP + 2 * (1 + FUSED_BIG_CAP)) * 4, 256);
     L.off_qs = off;     // sample of the item factors, [n_sample x 256 floats at most]
     off += align_up((size_t)nsub * 256 * 4, 256);
+    // sub-lists of an item-split launch (only a batch below one round of workgroups has them:
+    // rows * parts <= 64 Ki, i.e. at most 256 MiB).  Sized for the largest split any feature
+    // count would take, so that the workspace does not depend on k.
+    L.parts = filter_parts(rows, n_items, kp);
+    L.part_cap = FUSED_PART_CAP;
+    L.off_parts = L.off_pcnt = off;
+    const int maxp = filter_parts(rows, n_items, 64);
+    if (maxp > 1) {
+        off += align_up((size_t)rows * maxp * FUSED_PART_CAP * 8, 256);
+        L.off_pcnt = off;
+        off += align_up((size_t)rows * maxp * 4, 256);
+    }
     L.bytes = off;
     return L;
 }
@@ -2273,8 +2357,10 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
     };
 
     if (!full && lk::use_fused(n_users, n_items, n, KP)) {
-        const lk::FusedLayout L = lk::fused_layout(n_users, n_items, n);
+        const lk::FusedLayout L = lk::fused_layout(n_users, n_items, n, KP);
         char *fw = static_cast<char *>(d_ws) + panel_bytes;
+        auto *pcand = reinterpret_cast<unsigned long long *>(fw + L.off_parts);
+        unsigned *pcnt = reinterpret_cast<unsigned *>(fw + L.off_pcnt);
         float *sub = reinterpret_cast<float *>(fw + L.off_sub);
         float *tau = reinterpret_cast<float *>(fw + L.off_tau);
         unsigned *cnt = reinterpret_cast<unsigned *>(fw + L.off_cnt);
@@ -2371,51 +2457,49 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
             // item-split launches: only when the WHOLE batch is less than one round of workgroups
             // (measured on the 1270-workgroup cfg2 call: splitting its partial last round of 246
             // in two made the call slower, 13.1 against 12.3 ms)
-            const bool may_split = wgs <= round;
+            const int parts = batches == 1 ? L.parts : 1;
             auto filter = [&](int64_t r0, int64_t nr, hipStream_t s) {
                 dim3 ugrid((unsigned)((nr + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB)));
                 const float *uu = ub_users + r0 * ld_users;
                 float *tau_r = tau + r0;
                 unsigned *cnt_r = cnt + r0;
                 unsigned long long *cand_r = cand + r0 * lk::FUSED_CAP;
-                // fewer workgroups than one round (2 per CU): split the item tiles among several
-                // workgroups per 128 users (LK_TOPK_SPLIT=0: never)
+                // (split launches: the kernels' `tiles_per_wg` argument carries the sub-list
+                // capacity, their lists and counters are the parts' -- LK_FILTER_SPLIT_RANGE)
                 int tiles_per_wg = 0;
-                const int64_t n_itiles = (n_items + lk::SC_IB - 1) / lk::SC_IB;
-                const bool dma_kernel = (LK_TOPK_DMA && KP == 64) ||
-                                        (LK_TOPK_DMA >= 2 && (KP == 32 || KP == 128 || KP == 256));
-                if (may_split && dma_kernel && lk::topk_split() && ugrid.x < 2 * 256 &&
-                    n_itiles >= 8) {
-                    int64_t parts = (2 * 256 + ugrid.x - 1) / ugrid.x;
-                    if (parts > n_itiles / 4) parts = n_itiles / 4;  // >= 4 tiles per workgroup
-                    if (parts > 1) {
-                        tiles_per_wg = (int)((n_itiles + parts - 1) / parts);
-                        ugrid.y = (unsigned)((n_itiles + tiles_per_wg - 1) / tiles_per_wg);
-                        // (the rows' counters are zero: stage 1 leaves them so)
-                    }
+                int cap_arg = lk::FUSED_CAP;
+                if (parts > 1) {
+                    ugrid.y = (unsigned)parts;
+                    tiles_per_wg = L.part_cap;
+                    cand_r = pcand + r0 * parts * (int64_t)L.part_cap;
+                    cnt_r = pcnt + r0 * parts;
                 }
                 if (LK_TOPK_DMA && KP == 64)
                     hipLaunchKernelGGL(lk::score_filter64_kernel, ugrid, dim3(256), 0, s, uu, nr,
-                                       d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP,
+                                       d_items, n_items, tau_r, cand_r, cnt_r, cap_arg,
                                        tiles_per_wg);
 #if LK_TOPK_DMA >= 2
                 else if (KP == 32)
                     hipLaunchKernelGGL(lk::score_filter_slab_kernel<32>, ugrid, dim3(256), 0, s, uu,
-                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP,
+                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, cap_arg,
                                        tiles_per_wg);
                 else if (KP == 128)
                     hipLaunchKernelGGL(lk::score_filter_slab_kernel<128>, ugrid, dim3(256), 0, s, uu,
-                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP,
+                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, cap_arg,
                                        tiles_per_wg);
                 else if (KP == 256)
                     hipLaunchKernelGGL(lk::score_filter_slab_kernel<256>, ugrid, dim3(256), 0, s, uu,
-                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, lk::FUSED_CAP,
+                                       nr, d_items, n_items, tau_r, cand_r, cnt_r, cap_arg,
                                        tiles_per_wg);
 #endif
                 else
                     hipLaunchKernelGGL(lk::score_filter_kernel, ugrid, dim3(256), 0, s, uu, ld_users,
                                        nr, d_items, ld_items, n_items, KP, (float *)nullptr,
                                        (int64_t)0, tau_r, cand_r, cnt_r, lk::FUSED_CAP);
+                if (parts > 1)
+                    hipLaunchKernelGGL(lk::cand_merge_kernel, dim3((unsigned)((nr + 3) / 4)),
+                                       dim3(256), 0, s, cand_r, cnt_r, parts, L.part_cap, nr,
+                                       cand + r0 * lk::FUSED_CAP, cnt + r0, lk::FUSED_CAP);
             };
             // stage 3, first tier: exclusions, exact order
             const bool wave_sel = lk::select_wave();
@@ -2425,7 +2509,8 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
                                        dim3((unsigned)nr), dim3(64), 0, s, cand, cnt, d_excl_ptr,
                                        d_excl_items, ub, n, d_out_idx + ub * n,
                                        d_out_score ? d_out_score + ub * n : nullptr, (int64_t)n,
-                                       redo, lk::FUSED_REDO_CAP, big, lk::FUSED_BIG_CAP, r0);
+                                       redo, lk::FUSED_REDO_CAP, big, lk::FUSED_BIG_CAP, r0,
+                                       lk::long_excl(parts > 1));
                     return;
                 }
                 hipLaunchKernelGGL((lk::cand_select_kernel<lk::FUSED_LCAP, lk::FUSED_CAP>),

@@ -56,6 +56,28 @@ src = lk._device_matrix()["csr"]
 src = D.DeviceCSR(src.indptr, src.indices, None, src.shape, src.h_indptr)
 hist = t("gather_rows (host prefix + kernel)", lambda: D.gather_rows(src, hb.user_nums, scale=40.0))
 plan = t("ALSPlan(hist)", lambda: D.ALSPlan(hist, 64))
+import ctypes  # noqa: E402
+
+from lkpy_amd import _native  # noqa: E402
+
+lib = _native.load()
+hp = hist.h_indptr
+
+
+def raw_plan():
+    h = ctypes.c_void_p(0)
+    lib.lk_als_plan_create_ex(ctypes.byref(h), hp.ctypes.data_as(ctypes.c_void_p), 1, len(hp) - 1,
+                              64, 2, 2)
+    return h
+
+
+h = t("  lk_als_plan_create_ex alone", raw_plan)
+t("  lk_als_plan_destroy", lambda: lib.lk_als_plan_destroy(raw_plan()))
+wsb = lib.lk_als_plan_workspace_bytes(h)
+print("  workspace bytes", wsb)
+t("  torch.empty(workspace)", lambda: torch.empty(wsb, dtype=torch.uint8, device=st["device"]))
+t("  torch.zeros(1)", lambda: torch.zeros(1, dtype=torch.float32, device=st["device"]))
+t("  torch.zeros(B x 64)", lambda: torch.zeros((B, 64), dtype=torch.float32, device=st["device"]))
 u = torch.zeros((B, plan.kp), dtype=torch.float32, device=st["device"])
 t("plan.half_epoch", lambda: plan.half_epoch(u, st["Q"], st["OtOr"]))
 t("plan.check_status", lambda: plan.check_status())
@@ -67,6 +89,23 @@ for split in ("1", "0"):
 os.environ["LK_TOPK_SPLIT"] = "1"
 t("cat + to_host", lambda: D.to_host(torch.cat([idx.view(torch.float32), scv], dim=1)))
 t("whole call", lambda: sc.recommend_batch(lk.batch(users), 100))
+if len(sys.argv) > 2 and sys.argv[2] == "longexcl":
+    import os
+    for le in ("4096", "1024", "256", "64", "1"):
+        os.environ["LK_TOPK_LONG_EXCL"] = le
+        t(f"whole call, LK_TOPK_LONG_EXCL={le}", lambda: sc.recommend_batch(lk.batch(users), 100))
+    sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "cprofile":
+    import cProfile
+    import pstats
+
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(50):
+        sc.recommend_batch(lk.batch(users), 100)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+    sys.exit(0)
 for b2 in (1000, 2000, 5000, 20000, 50000):
     if b2 <= nu:
         us = np.random.default_rng(1).choice(ds.users.ids(), b2, replace=False)
