@@ -170,6 +170,13 @@ class ItemKNNScorer(Component):
         lists (item.py:238-245: all-NaN scores).  Returns (item numbers [B x n] with -1 padding,
         scores [B x n] with NaN padding), like ``ImplicitMFScorer.recommend_batch``.
         """
+        from .basic import HistoryBatch
+
+        if isinstance(queries, HistoryBatch) and not (
+                queries.items is self.items or queries.items == self.items):
+            queries = queries.queries()  # (another item vocabulary: the per-query mapping)
+        if isinstance(queries, HistoryBatch):
+            return self._recommend_history_batch(queries, n, exclude_history)
         st = self._device_sims()
         d = st["device"]
         queries = [RecQuery.create(q) for q in queries]
@@ -216,6 +223,55 @@ class ItemKNNScorer(Component):
         inv = np.empty_like(order)
         inv[order] = np.arange(len(order))
         return oi.cpu().numpy()[inv], osc.cpu().numpy()[inv]
+
+
+    accepts_history_batch = True  # recommend_batch takes a lkpy_amd.basic.HistoryBatch
+
+    def _recommend_history_batch(self, batch, n: int, exclude_history: bool):
+        """
+        ``recommend_batch`` for training histories by user number (``UserTrainingHistoryLookup.
+        batch``): nothing is done per query on the host.  The histories -- in the training rows'
+        order, which is what the reference's lookup hands the scorer (basic/history.py:77-95) --
+        are cut out of the HBM-resident training matrix with the ratings mean-centred on the way
+        (``lk_csr_gather_rows`` with the item means as column bias: item.py:268-271); a query's
+        hit count (the summed similarity-row lengths of its history items, what the launch is
+        balanced by) is a property of the USER, computed once for every training user on the
+        device; the batch goes heaviest query first and the lists come back in the caller's order.
+        """
+        st = self._device_sims()
+        d = st["device"]
+        if self.config.explicit and not batch.has_ratings:
+            raise RuntimeError("explicit-feedback scorer must have ratings")
+        bias = st.get("means")
+        if bias is None and self.config.explicit and self.item_means is not None:
+            bias = st["means"] = torch.from_numpy(
+                np.asarray(self.item_means, dtype=np.float32)).to(d)
+        key = ("user_hits", id(batch.lookup))
+        user_hits = st.get(key)
+        if user_hits is None:
+            # hits of every training user: counts[item] summed over the user's row, on the device
+            mat = batch.lookup._device_matrix()["csr"]
+            cnt = torch.from_numpy(np.asarray(self.item_counts, dtype=np.int64)).to(d)
+            csum = torch.zeros(mat.indices.numel() + 1, dtype=torch.int64, device=d)
+            torch.cumsum(cnt[mat.indices.long()], 0, out=csum[1:])
+            ptr = mat.indptr.long()
+            user_hits = st[key] = (csum[ptr[1:]] - csum[ptr[:-1]]).cpu().numpy()
+        nums = batch.user_nums
+        hits = np.where(nums >= 0, user_hits[np.maximum(nums, 0)], 0).astype(np.int64)
+        order = np.argsort(-hits, kind="stable")  # heaviest queries first; undone below
+        sub = batch.subset(order)
+        hist = sub.csr(use_ratings=self.config.explicit, scale=1.0,
+                       col_bias=bias if self.config.explicit else None,
+                       with_values=self.config.explicit)
+        oi, osc = D.iknn_recommend(st["sims"], hist.indptr, hist.indices,
+                                   hist.values if self.config.explicit else None,
+                                   bias if self.config.explicit else None, self.config.max_nbrs,
+                                   self.config.min_nbrs, n, hits[order], exclude_history)
+        inv = torch.from_numpy(np.argsort(order, kind="stable")).to(d)
+        both = torch.cat([oi.view(torch.float32), osc], dim=1)[inv]
+        host = D.to_host(both)
+        cols = oi.shape[1]
+        return host[:, :cols].view(np.int32), host[:, cols:]
 
 
 # ---------------------------------------------------------------------------------------

@@ -152,6 +152,28 @@ def test_recommend_through_the_scorer_and_batch_runner(gpu, oracle, ml_small):
                               g.numbers(vocabulary=scorer.items)):
             diff += 1
     assert diff <= 4  # equal-score items only (checked bit for bit above)
+    # round 6: the batch went by USER NUMBER (HistoryBatch: histories gathered from the
+    # HBM-resident training matrix, mean-centred in the gather kernel, hit counts per user from
+    # the device) -- the same arrays as the per-query list path, bit for bit, unknown user included
+    from lkpy_amd.data import RecQuery
+
+    lookup = pipe.node("history-lookup").component
+    ids = users + [-7]
+    gi, gs = scorer.recommend_batch(lookup.batch(ids), 10)
+    li, ls = scorer.recommend_batch([lookup(RecQuery.create(u)) for u in ids], 10)
+    assert np.array_equal(gi, li)
+    assert np.array_equal(np.ascontiguousarray(gs).view(np.uint32),
+                          np.ascontiguousarray(ls).view(np.uint32))
+    assert (gi[-1] == -1).all() and np.isnan(gs[-1]).all()
+    imp = ItemKNNScorer(max_nbrs=20, min_nbrs=2, save_nbrs=200, feedback="implicit")
+    pipe2 = topn_pipeline(imp, n=10)
+    pipe2.train(ds)
+    lk2 = pipe2.node("history-lookup").component
+    gi, gs = imp.recommend_batch(lk2.batch(ids), 10)
+    li, ls = imp.recommend_batch([lk2(RecQuery.create(u)) for u in ids], 10)
+    assert np.array_equal(gi, li)
+    assert np.array_equal(np.ascontiguousarray(gs).view(np.uint32),
+                          np.ascontiguousarray(ls).view(np.uint32))
 
 
 def test_nan_similarity_is_the_reference_error(gpu):

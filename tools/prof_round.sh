@@ -3,7 +3,7 @@
 # condensed by tools/summarize_prof.py into gpurun_out/<tag>_*  ->  copy to profiles/.
 #   tools/prof_round.sh r04
 set -u
-R=${1:-r05}
+R=${1:-r06}
 BASE="--no-cpu --no-knn --no-topk --no-fit --no-k128 --no-cfg5 --no-cg --no-order-ab"
 # cfg2 headline (k = 64): all passes
 PROF_PASSES=all bash tools/prof_als.sh ${R}_als_k64 > /dev/null 2>&1
@@ -31,6 +31,8 @@ python tools/summarize_prof.py gpurun_out/prof_topk_${R} gpurun_out/${R}_topk
 bash tools/prof_knn.sh ${R} > /dev/null 2>&1
 python tools/summarize_prof.py gpurun_out/prof_knn_${R} gpurun_out/${R}_knn
 bash tools/prof_knnrec.sh ${R}_knnrec > /dev/null 2>&1
+# the als-implicit.toml batch recommend call (round 6)
+bash tools/prof_recommend.sh ${R} > /dev/null 2>&1
 ls gpurun_out/${R}_* | head -40
 # the raw captures are large: keep only the summaries in what gpurun merges back
 rm -rf gpurun_out/prof_*
