@@ -49,10 +49,11 @@ HBM_PEAK_GBS = 8000.0  # same guide: HBM3E peak 8 TB/s
 LONG_ROW = int(os.environ.get("LK_BENCH_LONG_ROW", 2048))  # LK_ALS_LONG_ROW (csrc/als_plan.h)
 CHUNK = 1024  # LK_ALS_CHUNK
 # the CG leg's stopping rule ||r|| <= tol ||y||: the error of a row is up to cond(A) * tol, and
-# cond(A) ~ 200 on the trained state -- 1e-6 (rounds 3-5) left the worst item rows AT 1e-4
-# (9.6e-5 in the driver's run, 23 rows over in another); the item half also inherits the user half's
-# difference (its input P is the CG engine's own), so the tolerance is 1e-7
-CG_TOL = float(os.environ.get("LK_BENCH_CG_TOL", 1.0e-7))
+# cond(A) ~ 200 on the trained state -- 1e-6 (rounds 3-5) left the worst rows AT 1e-4 (9.6e-5 in the
+# driver's run, 23 rows over in another).  2.5e-7 and 1e-7 give the SAME worst user row (1.9e-5: the
+# float32 floor of the two solvers' difference) at 10.6 and 11.1 ms per epoch; the item half's
+# 9.5e-5 is not CG error but that 1.9e-5 propagated -- its input P is the CG engine's own user half
+CG_TOL = float(os.environ.get("LK_BENCH_CG_TOL", 2.5e-7))
 
 
 WB_MAX_N = 128  # rows this short take the Woodbury kernels at padded k = 256 (csrc/als_wb.hip:
@@ -558,6 +559,11 @@ def recommend_leg(scorer, ds, n_users=10000, n=100, no_cpu=False):
                     "so launch ramp and tail are a visible part of it",
         },
     }
+    # HBM bytes per fold-in launch from the committed PMC summary of the same call
+    # (tools/prof_recommend.sh; the fold-in plan's offsets are 64-bit: the <4, true, ...> instance)
+    res["roofline"]["traffic"], res["roofline"]["traffic_source"] = pmc_traffic(
+        "r*_recommend_counters.csv", "als_solve_kernel<4, true")
+    res["roofline"]["algorithmic_bytes"] = half_bytes(lens, k)
     if no_cpu:
         return res
     from oracle import lk_oracle as lko
@@ -1946,7 +1952,9 @@ def main():
                 "factors: Jacobi-preconditioned matrix-free CG (tol %.1e, warm start) on the rows " % CG_TOL
                 +
                 "whose gathered factor rows stay in registers over the iterations (<= 16384 / k' "
-                "entries), the exact kernels on the longer rows (csrc/als_cg.hip)",
+                "entries), the exact kernels on the longer rows (csrc/als_cg.hip); `user_rows` compares the two "
+                "solvers from IDENTICAL inputs, `item_rows` from each engine's own user half (the "
+                "difference of the inputs, up to `user_rows.row_rel_max` per row, is in it)",
                 **out_cg,
                 "one_epoch_rel_diff_P": rel(engs["cg"][0], engs["exact"][0]),
                 "one_epoch_rel_diff_Q": rel(engs["cg"][1], engs["exact"][1]),

@@ -2143,7 +2143,16 @@ struct FusedLayout {
     size_t off_sub, off_tau, off_cnt, off_cand, off_flags, off_qs, off_parts, off_pcnt, bytes;
     int parts, part_cap;  // item-split launches of a small batch (parts <= 1: none)
 };
-constexpr int FUSED_PART_CAP = 512;  // candidates per (row, part) sub-list
+// candidates per (row, part) sub-list: twice a row's whole list divided by the parts (the tiles are
+// interleaved, so a part holds ~1/S of a row's candidates; a part that overflows sends the row to
+// the exact redo path), at least 512: S = 2 -> 2048, 4 -> 1024, 6 -> 768, >= 8 -> 512
+static int filter_part_cap(int parts)
+{
+    if (parts < 2) return FUSED_CAP;
+    int c = (2 * FUSED_CAP / parts + 127) / 128 * 128;
+    if (c < 512) c = 512;
+    return c > FUSED_CAP ? FUSED_CAP : c;
+}
 
 // how many parts the item tiles of a batch of `rows` users are split into: as many as keep the
 // launch inside ONE round of 2 x 256 workgroups, at least 4 tiles each; 1 = no split
@@ -2189,14 +2198,14 @@ static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n, int
     L.off_qs = off;     // sample of the item factors, [n_sample x 256 floats at most]
     off += align_up((size_t)nsub * 256 * 4, 256);
     // sub-lists of an item-split launch (only a batch below one round of workgroups has them:
-    // rows * parts <= 64 Ki, i.e. at most 256 MiB).  Sized for the largest split any feature
+    // rows * parts <= 64 Ki and parts * capacity <= 2 lists: at most 1 GiB, at 32 Ki rows).  Sized for the largest split any feature
     // count would take, so that the workspace does not depend on k.
     L.parts = filter_parts(rows, n_items, kp);
-    L.part_cap = FUSED_PART_CAP;
+    L.part_cap = filter_part_cap(L.parts);
     L.off_parts = L.off_pcnt = off;
     const int maxp = filter_parts(rows, n_items, 64);
     if (maxp > 1) {
-        off += align_up((size_t)rows * maxp * FUSED_PART_CAP * 8, 256);
+        off += align_up((size_t)rows * maxp * filter_part_cap(maxp) * 8, 256);
         L.off_pcnt = off;
         off += align_up((size_t)rows * maxp * 4, 256);
     }

@@ -290,3 +290,32 @@ def test_score_topk_fused_in_batches(gpu, rng, monkeypatch):
     for (gi, gs), (wi, ws) in zip(got, want):
         assert torch.equal(gi, wi)
         assert torch.equal(gs.view(torch.int32), ws.view(torch.int32))
+
+
+@pytest.mark.parametrize("B", [30000, 20000, 12000, 8500])
+def test_score_topk_item_split_equals_unsplit(gpu, rng, monkeypatch, B):
+    """Round 6: batches below one round of filter workgroups split the item tiles over 2 ... 7
+    parts (30 000 / 20 000 / 12 000 / 8 500 users -> 2 / 3 / 5 / 7; interleaved tiles, per-part
+    candidate sub-lists, ``cand_merge_kernel``).  Same lists and score bits as the unsplit launch
+    (``LK_TOPK_SPLIT=0``), exclusion lists of every length included -- rows with more than 256
+    exclusion entries take the workgroup selection tier in a split batch."""
+    from lkpy_amd import _device as D
+
+    k, n, I = 64, 100, 20000
+    g = torch.Generator(device=gpu).manual_seed(B)
+    U = torch.randn(B, k, device=gpu, generator=g) * 0.3
+    Q = torch.randn(I, k, device=gpu, generator=g) * 0.3
+    Q[7000:7100] = Q[100:200]  # exact ties between distant items (different tiles, different parts)
+    U[5] = 0.0                 # every score equal: every part's sub-list overflows -> redo path
+    lens = rng.integers(0, 400, B)
+    lens[:4] = [0, 5000, 300, 257]
+    ptr = np.zeros(B + 1, np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    ex = rng.integers(0, I, int(ptr[-1])).astype(np.int32)  # (repeats allowed: any list is a set)
+    dptr, dex = torch.from_numpy(ptr).to(gpu), torch.from_numpy(ex).to(gpu)
+    idx, sc = D.score_topk(U, Q, k, n, dptr, dex)
+    monkeypatch.setenv("LK_TOPK_SPLIT", "0")
+    idx0, sc0 = D.score_topk(U, Q, k, n, dptr, dex)
+    assert torch.equal(idx, idx0)
+    assert torch.equal(sc.view(torch.int32), sc0.view(torch.int32))
+    assert (idx[1] >= 0).all() and not np.isin(idx[1].cpu().numpy(), ex[ptr[1]:ptr[2]]).any()
