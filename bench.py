@@ -605,8 +605,10 @@ def recommend_leg(scorer, ds, n_users=10000, n=100, no_cpu=False):
     per_user_1 = t_fold_cpu / len(users) + t_list_1
     res["cpu_baseline"] = {
         "value": round(per_user_1 * len(users), 3), "unit": "s", "cores": 1, "kind": "port",
-        "sample": f"the reference's per-query loop on ONE thread (its batch runner's default "
-                  f"worker): fold-in of all {len(users)} users ({t_fold_cpu:.2f}s, NumPy + SciPy "
+        "sample": f"the reference's per-query loop on ONE thread -- its batch runner's default on a "
+                  f"GIL interpreter: num_batch_jobs = 1 (schemas/settings.py:190-194) -> "
+                  f"_sequential_results (batch/_runner.py:281-288): fold-in of all {len(users)} "
+                  f"users ({t_fold_cpu:.2f}s, NumPy + SciPy "
                   f"cho_factor as _implicit.py:101-130) + score / exclusion / heap top-{n} of "
                   f"{m1} users ({t_list_1 * m1:.2f}s), extrapolated by users",
         "score_topn_all_threads_seconds": round(t_list_cpu / m * len(users), 3),

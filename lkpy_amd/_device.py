@@ -986,7 +986,7 @@ def gather_rows(csr: DeviceCSR, rows: np.ndarray, *, scale: float = 1.0,
     packed = np.empty(2 * (B + 1) + B + (B & 1), dtype=np.int32)
     packed[:2 * (B + 1)] = ptr.view(np.int32)
     packed[2 * (B + 1):2 * (B + 1) + B] = rows
-    d_packed = torch.from_numpy(packed).to(dev, non_blocking=True)
+    d_packed = torch.from_numpy(packed).to(dev)
     d_ptr = d_packed[:2 * (B + 1)].view(torch.int64)
     d_rows = d_packed[2 * (B + 1):2 * (B + 1) + B]
     out_idx = torch.empty(nnz, dtype=torch.int32, device=dev)
