@@ -200,6 +200,16 @@ def test_half_epoch_ml_small_cfg1(gpu, oracle, ml_small):
           "of those over 1e-4, their max):")
     for r in undecided:
         print("  %d %s %d %d %d %.2e" % r)
+    # The undecidable rows are not a place to hide a regression: their count over 1e-4
+    # and their worst distance from the oracle are PINNED to what this build measures on an MI355X
+    # (round 6; the kernels are deterministic) with 1.5 x / 2 x of slack.  For scale: the oracle
+    # itself is 1.4e-4 ... 6.9e-4 from float64 in these half-epochs (second table column above).
+    pinned = {(0, "user"): (0, 0.0), (0, "item"): (9066, 2.17e-3), (1, "user"): (134, 2.83e-3),
+              (1, "item"): (7354, 9.26e-4), (2, "user"): (111, 2.50e-3), (2, "item"): (3531, 4.41e-4)}
+    for ep, name, _dec, _other, n_over, worst in undecided:
+        cnt, mx = pinned[(ep, name)]
+        assert n_over <= 1.5 * cnt + 5, (ep, name, n_over, cnt)
+        assert worst <= 2.0 * mx + 1e-6, (ep, name, worst, mx)
 
 
 def test_not_spd_reports_error(gpu, rng):

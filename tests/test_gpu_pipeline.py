@@ -41,9 +41,10 @@ def test_als_implicit_toml_trains_like_the_reference(gpu, oracle, ml_small, ml_d
     want = oracle.als_train(ind, 64, 5, np.random.SeedSequence(42).spawn(3)[2])
     # two float32 implementations of an ill-conditioned iteration: ~1e-3 apart (see
     # test_gpu_als.py::test_half_epoch_ml_small_cfg1 for the per-half-epoch analysis)
-    assert _rel(scorer.item_embeddings, want.item_embeddings) < 2e-2
-    assert _rel(scorer.user_embeddings, want.user_embeddings) < 2e-2
-    assert _rel(scorer._OtOr, want.OtOr) < 2e-2
+    traj = (_rel(scorer.item_embeddings, want.item_embeddings),
+            _rel(scorer.user_embeddings, want.user_embeddings), _rel(scorer._OtOr, want.OtOr))
+    print("\n5-epoch trajectories GPU vs oracle (Q, P, OtOr):", ["%.2e" % t for t in traj])
+    assert max(traj) < 4e-3  # (measured 1.25e-3 / 9.8e-4 / 1.0e-3; rounds 1-5 allowed 2e-2)
     empty = np.bincount(ind.col, minlength=9125) == 0
     assert np.all(scorer.item_embeddings[empty] == 0)
 
@@ -79,6 +80,11 @@ def test_als_implicit_toml_trains_like_the_reference(gpu, oracle, ml_small, ml_d
         # ORACLE: two backward-stable solves of one system differ by at most ~2 x 16 cond u)
         cu = cond[nz] * 2.0**-24
         assert (e <= 32.0 * cu + 2e-6).all(), (name, float((e / cu).max()))
+        # the undecidable rows, pinned (a regression must not hide there): measured on an
+        # MI355X in round 6 -- user half 9 rows over 1e-4 (worst 4.1e-4), item half 1064 (2.6e-4)
+        cap_n, cap_e = {"user": (20, 8.0e-4), "item": (1600, 5.2e-4)}[name]
+        assert int((e[~decid] > 1e-4).sum()) <= cap_n and mx(e[~decid]) <= cap_e, \
+            (name, int((e[~decid] > 1e-4).sum()), mx(e[~decid]))
         print(f"\ncfg1 epoch 6 from identical inputs, {name} half: {int(decid.sum())} rows with "
               f"cond u < 2.5e-5, all within 1e-4 (max {mx(e[decid]):.1e}); other rows "
               f"{int((~decid).sum())}, of those over 1e-4: {int((e[~decid] > 1e-4).sum())} (max "
@@ -127,7 +133,7 @@ def test_als_implicit_toml_trains_like_the_reference(gpu, oracle, ml_small, ml_d
     print(f"\nrecommend parity over {len(users)} users: lists bit-identical given the same query "
           f"vector: {len(users)}/{len(users)}; with the CPU fold-in vector: {same_cpu_foldin} "
           f"identical, {near_ties} differ at near-ties only; fold-in rel err max {fold_err:.2e}")
-    assert fold_err < 5e-3
+    assert fold_err < 1e-3  # (measured 3.9e-4: cond 1e3 .. 2e5 on ml-latest-small; round 5 allowed 5e-3)
 
     # NaN semantics (tests/models/test_als_implicit.py:277-298, _common.py:145-170)
     from lkpy_amd.data import ItemList
