@@ -117,6 +117,11 @@ def shard_local_blocks(indptr: torch.Tensor, indices: torch.Tensor, values: torc
       ascending new user (``True``: what the full stable transpose of the relabelled matrix gives
       in ``accurate`` mode); the user numbers are then relabelled by ``u_new``.
 
+    What stays RESIDENT is nnz / world entries per orientation; the item-side pass itself holds
+    three int64 temporaries of the size of the whole matrix for its duration (the widened indices,
+    the mapped item numbers, the block search: ~24 B per entry, 2.4 GB at cfg5 -- ADVICE r5; not
+    chunked: a set-up transient on a 288 GB device).
+
     Returns ``{"u": (h_ptr, ptr, idx, val), "i": (...)}``: offsets over the rank's rows in block
     order (host NumPy + device), int32 indices, float32 values -- entry for entry the rows
     ``make_plans_on_device`` would view out of the full matrices.

@@ -806,7 +806,12 @@ static Layout layout(int64_t n_items, int64_t n_queries, int64_t max_query_hits,
                      int32_t n)
 {
     Layout L;
-    L.rows = n_queries < REC_PANEL_ROWS ? (n_queries > 0 ? n_queries : 1) : REC_PANEL_ROWS;
+    int64_t panel_rows = REC_PANEL_ROWS;
+    if (const char *e = getenv("LK_REC_PANEL_ROWS")) {  // tuning knob: queries per batch at most
+        const long v = atol(e);
+        if (v >= 64) panel_rows = v;
+    }
+    L.rows = n_queries < panel_rows ? (n_queries > 0 ? n_queries : 1) : panel_rows;
     // the score panel is rows x n_items floats: beyond BASELINE's 62 k items the batch shrinks so
     // that the panel stays inside a byte budget (LK_REC_PANEL_GB, default 8: 2 000 queries per
     // batch at 10^6 items) instead of growing with the catalogue
