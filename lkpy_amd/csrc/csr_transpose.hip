@@ -9,15 +9,15 @@
 //
 // A stable LSD radix sort of (column -> entry position) IS that counting sort, so the
 // result is identical to the reference's, entry for entry (integer work: bit-exact).  The
-// sort is rocPRIM's device radix sort (a plain library primitive, like rocBLAS for a plain
-// GEMM); the offsets come from a binary search per output row over the sorted columns, the
-// source rows from a binary search per entry over the input offsets.  HBM bound:
-// ~ (4 + W) * nnz bytes per sort pass over ceil(log2(n_cols) / 8) passes.
+// sort is this repository's own (radix_sort.h: 8-bit digits, stable passes, tiles reordered
+// through LDS; rounds 1-5 called rocPRIM here); the offsets come from a binary search per
+// output row over the sorted columns, the source rows from a binary search per entry over the
+// input offsets.  HBM bound: (12 + 2 W) * nnz bytes per pass over ceil(log2(n_cols) / 8) passes
+// (W = 4 or 8: the width of an entry position).
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include "common.h"
+#include "radix_sort.h"
 
 namespace lk {
 
@@ -130,20 +130,26 @@ static int transpose_impl(const IT *in_ptr, const int32_t *in_idx, int64_t n_row
                           int64_t nnz, IT *out_ptr, int32_t *out_idx, IT *out_perm, char *ws,
                           size_t ws_bytes, hipStream_t st)
 {
+    // workspace: sorted columns | column ping-pong | positions (iota) | sorted positions |
+    // position ping-pong | the sort's histogram
     uint32_t *keys_out = reinterpret_cast<uint32_t *>(ws);
     size_t off = align_up((size_t)nnz * 4, 256);
+    uint32_t *keys_tmp = reinterpret_cast<uint32_t *>(ws + off);
+    off += align_up((size_t)nnz * 4, 256);
     VT *vals_in = reinterpret_cast<VT *>(ws + off);
     off += align_up((size_t)nnz * sizeof(VT), 256);
     VT *vals_out = reinterpret_cast<VT *>(ws + off);
     off += align_up((size_t)nnz * sizeof(VT), 256);
+    VT *vals_tmp = reinterpret_cast<VT *>(ws + off);
+    off += align_up((size_t)nnz * sizeof(VT), 256);
     void *tmp = ws + off;
-    size_t tmp_bytes = ws_bytes > off ? ws_bytes - off : 0;
+    (void)ws_bytes;
     const uint32_t *keys_in = reinterpret_cast<const uint32_t *>(in_idx);
     if (nnz > 0) {
         hipLaunchKernelGGL(tr_iota_kernel<VT>, dim3(1024), dim3(256), 0, st, vals_in, nnz);
-        LK_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in,
-                                               vals_out, (size_t)nnz, 0u,
-                                               (unsigned)key_bits(n_cols), st));
+        int rc = radix_sort_pairs<uint32_t, VT>(keys_in, vals_in, keys_out, vals_out, keys_tmp,
+                                                vals_tmp, nnz, 0, key_bits(n_cols), tmp, st);
+        if (rc != LK_OK) return rc;
         hipLaunchKernelGGL((tr_rows_kernel<IT, VT>), dim3(2048), dim3(256), 0, st, in_ptr, n_rows,
                            vals_out, nnz, out_idx, out_perm);
     }
@@ -153,27 +159,15 @@ static int transpose_impl(const IT *in_ptr, const int32_t *in_idx, int64_t n_row
     return LK_OK;
 }
 
-template <typename VT>
-static size_t sort_temp_bytes(int64_t nnz, int64_t n_cols)
-{
-    size_t bytes = 0;
-    if (nnz <= 0) return 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)nullptr,
-                                    (uint32_t *)nullptr, (const VT *)nullptr, (VT *)nullptr,
-                                    (size_t)nnz, 0u, (unsigned)key_bits(n_cols), (hipStream_t)0);
-    return bytes;
-}
-
 }  // namespace lk
 
 extern "C" size_t lk_csr_transpose_workspace_bytes(int64_t nnz, int64_t n_cols, int indptr_is_64)
 {
     if (nnz < 0 || n_cols < 0) return 0;
     const size_t vt = indptr_is_64 ? 8 : 4;
-    const size_t tmp = indptr_is_64 ? lk::sort_temp_bytes<uint64_t>(nnz, n_cols)
-                                    : lk::sort_temp_bytes<uint32_t>(nnz, n_cols);
-    return lk::align_up((size_t)nnz * 4, 256) + 2 * lk::align_up((size_t)nnz * vt, 256) +
-           lk::align_up(tmp, 256) + 256;
+    (void)n_cols;
+    return 2 * lk::align_up((size_t)nnz * 4, 256) + 3 * lk::align_up((size_t)nnz * vt, 256) +
+           lk::align_up(lk::radix_sort_temp_bytes(nnz), 256) + 256;
 }
 
 extern "C" int lk_csr_transpose(const void *d_indptr, int indptr_is_64, const int32_t *d_indices,

@@ -8,19 +8,21 @@
 // rule as the top-N selection kernel, so the two paths agree on every prefix.
 //
 // Not a hot path of the benchmark (the ranking lists of the pipelines are n <= a few
-// hundred and take the selection kernel of topk.hip): keys = order-preserving unsigned
-// images of the scores (NaN -> 0, below every valid key), values = column numbers, one
-// STABLE segmented radix sort (rocPRIM) per batch of rows, then the valid prefix of every
-// row is emitted.  HBM traffic: a radix sort's 4 passes x 16 B per entry.
-#include <rocprim/device/device_segmented_radix_sort.hpp>
-
+// hundred and take the selection kernel of topk.hip): keys = (row << 32) | the INVERTED
+// order-preserving unsigned image of the score (NaN -> key 0, inverted 0xffffffff: behind every
+// valid key of its row), values = column numbers, one STABLE ascending radix sort of the 64-bit
+// keys per batch of rows (radix_sort.h, this repository's own: rounds 1-5 called rocPRIM's
+// segmented sort) -- rows stay where they are, inside a row the scores descend and equal scores
+// keep the column order --, then the valid prefix of every row is emitted.  HBM traffic:
+// 4 + ceil(log2(rows) / 8) passes x 32 B per entry.
 #include "common.h"
+#include "radix_sort.h"
 
 namespace lk {
 
 __global__ void sort_keys_kernel(const float *__restrict__ scores, int64_t ld_s, int64_t row_len,
-                                 int64_t n_rows, uint32_t *__restrict__ keys,
-                                 int32_t *__restrict__ vals, uint32_t *__restrict__ offsets)
+                                 int64_t n_rows, unsigned long long *__restrict__ keys,
+                                 uint32_t *__restrict__ vals)
 {
     const int64_t total = n_rows * row_len;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -28,16 +30,14 @@ __global__ void sort_keys_kernel(const float *__restrict__ scores, int64_t ld_s,
         const int64_t r = e / row_len;
         const int64_t c = e - r * row_len;
         const float x = scores[r * ld_s + c];
-        keys[e] = (x == x) ? f2key(x) : 0u;  // every valid key is >= f2key(-inf) > 0
-        vals[e] = (int32_t)c;
+        const uint32_t k = (x == x) ? f2key(x) : 0u;  // every valid key is >= f2key(-inf) > 0
+        keys[e] = ((unsigned long long)r << 32) | (unsigned long long)(0xffffffffu - k);
+        vals[e] = (uint32_t)c;
     }
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_rows;
-         r += (int64_t)gridDim.x * blockDim.x)
-        offsets[r] = (uint32_t)(r * row_len);
 }
 
-__global__ void sort_emit_kernel(const uint32_t *__restrict__ keys,
-                                 const int32_t *__restrict__ vals, int64_t row_len,
+__global__ void sort_emit_kernel(const unsigned long long *__restrict__ keys,
+                                 const uint32_t *__restrict__ vals, int64_t row_len,
                                  int64_t n_rows, int64_t n, int32_t *__restrict__ out_idx,
                                  float *__restrict__ out_score, int64_t out_ld)
 {
@@ -48,8 +48,8 @@ __global__ void sort_emit_kernel(const uint32_t *__restrict__ keys,
         uint32_t k = 0u;
         int32_t v = -1;
         if (j < row_len) {
-            k = keys[r * row_len + j];
-            v = vals[r * row_len + j];
+            k = 0xffffffffu - (uint32_t)(keys[r * row_len + j] & 0xffffffffull);
+            v = (int32_t)vals[r * row_len + j];
         }
         const bool ok = k != 0u;
         out_idx[r * out_ld + j] = ok ? v : -1;
@@ -65,14 +65,11 @@ static int64_t sort_batch_rows(int64_t n_rows, int64_t row_len)
     return b < n_rows ? b : n_rows;
 }
 
-static size_t sort_temp_bytes(int64_t batch, int64_t row_len)
+static int row_bits(int64_t rows)
 {
-    size_t bytes = 0;
-    (void)rocprim::segmented_radix_sort_pairs_desc(
-        nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const int32_t *)nullptr,
-        (int32_t *)nullptr, (unsigned)(batch * row_len), (unsigned)batch,
-        (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0, 32, (hipStream_t) nullptr);
-    return bytes;
+    int b = 0;
+    while (((int64_t)1 << b) < rows) ++b;
+    return b;
 }
 
 size_t topn_sort_workspace_bytes(int64_t n_rows, int64_t row_len)
@@ -80,8 +77,9 @@ size_t topn_sort_workspace_bytes(int64_t n_rows, int64_t row_len)
     if (n_rows <= 0 || row_len <= 0) return 256;
     const int64_t b = sort_batch_rows(n_rows, row_len);
     const size_t e = (size_t)b * (size_t)row_len;
-    return 4 * align_up(e * 4, 256) + align_up((size_t)(b + 1) * 4, 256) +
-           align_up(sort_temp_bytes(b, row_len), 256) + 256;
+    // keys in / out / ping-pong (8 B), values in / out / ping-pong (4 B), the sort's histogram
+    return 3 * align_up(e * 8, 256) + 3 * align_up(e * 4, 256) +
+           align_up(radix_sort_temp_bytes((int64_t)e), 256) + 256;
 }
 
 // rows of `scores` (row stride ld_s) -> out_idx[r][0..n) (and out_score): every valid entry
@@ -94,17 +92,18 @@ int topn_sort(const float *scores, int64_t ld_s, int64_t n_rows, int64_t row_len
     const int64_t batch = sort_batch_rows(n_rows, row_len);
     const size_t e = (size_t)batch * (size_t)row_len;
     char *p = static_cast<char *>(ws);
-    uint32_t *k_in = reinterpret_cast<uint32_t *>(p);
+    auto *k_in = reinterpret_cast<unsigned long long *>(p);
+    p += align_up(e * 8, 256);
+    auto *k_out = reinterpret_cast<unsigned long long *>(p);
+    p += align_up(e * 8, 256);
+    auto *k_tmp = reinterpret_cast<unsigned long long *>(p);
+    p += align_up(e * 8, 256);
+    uint32_t *v_in = reinterpret_cast<uint32_t *>(p);
     p += align_up(e * 4, 256);
-    uint32_t *k_out = reinterpret_cast<uint32_t *>(p);
+    uint32_t *v_out = reinterpret_cast<uint32_t *>(p);
     p += align_up(e * 4, 256);
-    int32_t *v_in = reinterpret_cast<int32_t *>(p);
+    uint32_t *v_tmp = reinterpret_cast<uint32_t *>(p);
     p += align_up(e * 4, 256);
-    int32_t *v_out = reinterpret_cast<int32_t *>(p);
-    p += align_up(e * 4, 256);
-    uint32_t *offs = reinterpret_cast<uint32_t *>(p);
-    p += align_up((size_t)(batch + 1) * 4, 256);
-    size_t tmp_bytes = sort_temp_bytes(batch, row_len);
     void *tmp = p;
     for (int64_t r0 = 0; r0 < n_rows; r0 += batch) {
         const int64_t rows = (n_rows - r0) < batch ? (n_rows - r0) : batch;
@@ -112,12 +111,10 @@ int topn_sort(const float *scores, int64_t ld_s, int64_t n_rows, int64_t row_len
         if (row_len > 0) {
             const unsigned g = (unsigned)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
             hipLaunchKernelGGL(sort_keys_kernel, dim3(g ? g : 1), dim3(256), 0, st,
-                               scores + r0 * ld_s, ld_s, row_len, rows, k_in, v_in, offs);
-            size_t tb = tmp_bytes;
-            LK_HIP_CHECK(rocprim::segmented_radix_sort_pairs_desc(
-                tmp, tb, (const uint32_t *)k_in, k_out, (const int32_t *)v_in, v_out,
-                (unsigned)tot, (unsigned)rows, (const uint32_t *)offs,
-                (const uint32_t *)(offs + 1), 0, 32, st));
+                               scores + r0 * ld_s, ld_s, row_len, rows, k_in, v_in);
+            int rc = radix_sort_pairs<unsigned long long, uint32_t>(
+                k_in, v_in, k_out, v_out, k_tmp, v_tmp, tot, 0, 32 + row_bits(rows), tmp, st);
+            if (rc != LK_OK) return rc;
         }
         const int64_t ot = rows * n;
         const unsigned g2 = (unsigned)((ot + 255) / 256 < 8192 ? (ot + 255) / 256 : 8192);

@@ -73,3 +73,27 @@ def test_to_host_staged_download(gpu, dtype, n):
     # a second transfer reuses the ring; a 2-D view keeps its shape
     t2 = t[: (n // 7) * 7].reshape(-1, 7)
     assert np.array_equal(D.to_host(t2), t2.cpu().numpy())
+
+
+@pytest.mark.parametrize("n_rows,n_cols,nnz", [(20000, 300, 3_000_000), (3000, 70001, 2_500_000),
+                                                (10, 5, 37), (1, 100000, 4097), (4096, 4096, 4096)])
+def test_transpose_hand_written_sort_sizes(gpu, oracle, rng, n_rows, n_cols, nnz):
+    """Round 6: the transpose's stable radix sort is this repository's own (csrc/radix_sort.h: 8-bit
+    digits, 4096-key tiles; rounds 1-5 called rocPRIM).  Sizes that end inside a tile, span
+    hundreds of tiles, take one / two / three digit passes; heavy duplicate columns (stability is
+    what keeps an output row's entries in source-row order): offsets, indices and the permutation
+    equal to the oracle's counting-sort transpose, entry for entry."""
+    from lkpy_amd import _device as D
+
+    rows = np.sort(rng.integers(0, n_rows, nnz))
+    cols = rng.integers(0, n_cols, nnz)
+    m = sps.csr_array((np.ones(nnz, np.float32), (rows, cols)), shape=(n_rows, n_cols))
+    m.sum_duplicates()
+    m.sort_indices()
+    m.data = rng.standard_normal(m.nnz).astype(np.float32)
+    csr = D.DeviceCSR.from_arrays(m.indptr, m.indices, m.data, m.shape, gpu)
+    t = D.csr_transpose(csr)
+    ptr, idx, perm = oracle.transpose_csr(m.indptr, m.indices, n_cols)
+    assert np.array_equal(t.indptr.cpu().numpy(), ptr)
+    assert np.array_equal(t.indices.cpu().numpy(), idx)
+    assert np.array_equal(t.perm.cpu().numpy(), perm)
