@@ -298,22 +298,24 @@ def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
     iu.sort_indices()
     # how many threads?  The port's row-parallel loop calls SciPy's bundled OpenBLAS sposv from
     # every thread; on the 256-thread bench host MORE threads were SLOWER (tools/oracle_threads.py,
-    # 5 M entries: 0.18 s at 8 threads, 0.33 s at 32, 0.81 s at 64, a crash at 128).  The baseline
-    # is the port at its BEST: a seeded row sample of the user half at 8 / 16 / 32 threads first,
-    # the fastest count for the measurement proper; all three are reported.
+    # 5 M entries: 0.18 s at 8 threads, 0.33 s at 32, 0.81 s at 64, a crash at 128) -- and a short
+    # sample does not show it reliably (30 ms samples picked 8, 16 and 32 in three runs of this
+    # file while the full user half took 1.0 / 1.1 / 2.0 s).  So the USER HALF ITSELF is timed at
+    # 8 / 16 / 32 threads when every row is checked (row results do not depend on the thread
+    # count), the fastest count is the baseline's, and all three times are reported.
     cap = lko.num_threads()
-    crng = np.random.default_rng(9)
-    crow = np.sort(crng.choice(ui.shape[0], max(512, ui.shape[0] // 40), replace=False))
-    csub, cthis = sps.csr_array(ui[crow]), P[crow]
-    cotor = lko.implicit_otor(Q, reg)
+    cands = sorted({min(8, cap), min(16, cap), cap})
     tried = {}
-    for t_ in sorted({min(8, cap), min(16, cap), cap}):
-        w_ = np.ascontiguousarray(cthis.copy())
-        lko.als_half_epoch(csub, w_, Q, cotor, t_)  # (first touch)
-        t0 = time.perf_counter()
-        lko.als_half_epoch(csub, w_, Q, cotor, t_)
-        tried[t_] = time.perf_counter() - t0
-    threads = min(tried, key=tried.get)
+    if row_frac >= 1.0:
+        otor_u = lko.implicit_otor(Q, reg)
+        for t_ in cands:
+            w_ = np.ascontiguousarray(P.copy())
+            t0 = time.perf_counter()
+            lko.als_half_epoch(ui, w_, Q, otor_u, t_)
+            tried[t_] = time.perf_counter() - t0
+        threads = min(tried, key=tried.get)
+    else:
+        threads = min(8, cap)  # (sampled legs: the reference's own default, min(ncpus, 8))
     rng = np.random.default_rng(5)
     out, secs, desc = {}, 0.0, []
     for name, mat, this, other, got in (("user", ui, P, Q, P1), ("item", iu, Q, P1, Q1)):
@@ -381,14 +383,13 @@ def als_parity_and_cpu(eng, ui, k, reg, row_frac: float):
         "host_cpus": os.cpu_count(),
         "cpu_seconds_per_epoch": round(secs, 3),
     }
-    cpu["threads_tried_seconds_on_sample"] = {str(t_): round(v, 4) for t_, v in tried.items()}
+    cpu["threads_tried_user_half_seconds"] = {str(t_): round(v, 3) for t_, v in tried.items()}
     cpu["threads_note"] = (
-        "`cores` = the fastest of 8 / 16 / %d threads on a %d-row sample of the user half (the "
-        "port's row-parallel loop calls SciPy's bundled OpenBLAS sposv from every thread; beyond "
-        "~8 callers it slows down and at 128 it crashes -- tools/oracle_threads.py); the "
-        "reference's own default is min(ncpus, 8) threads (src/lenskit/schemas/settings.py:"
-        "182-185), BASELINE.md section 2 names $(nproc) = %d here" % (cap, len(crow),
-                                                                      os.cpu_count() or 0))
+        "`cores` = the fastest of 8 / 16 / %d threads for the FULL user half (the port's "
+        "row-parallel loop calls SciPy's bundled OpenBLAS sposv from every thread; beyond ~8-16 "
+        "callers it slows down and at 128 it crashes -- tools/oracle_threads.py); sampled legs "
+        "use min(ncpus, 8), the reference's own default (src/lenskit/schemas/settings.py:182-185); "
+        "BASELINE.md section 2 names $(nproc) = %d here" % (cap, os.cpu_count() or 0))
     return par, cpu
 
 
@@ -1412,8 +1413,8 @@ def _cpu(c):
     if not isinstance(c, dict):
         return None
     d = _pick(c, "value", "unit", "cores", "kind", "error")
-    if isinstance(c.get("threads_tried_seconds_on_sample"), dict):
-        d["threads_tried_s"] = c["threads_tried_seconds_on_sample"]
+    if isinstance(c.get("threads_tried_user_half_seconds"), dict) and c["threads_tried_user_half_seconds"]:
+        d["threads_tried_s"] = c["threads_tried_user_half_seconds"]
     if "sample" in c:
         d["sample"] = _short(c["sample"], 140)
     return d
