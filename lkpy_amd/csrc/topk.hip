@@ -2142,6 +2142,7 @@ constexpr int FUSED_BIG_CAP = 32768;  // rows per batch the second tier takes (m
 struct FusedLayout {
     size_t off_sub, off_tau, off_cnt, off_cand, off_flags, off_qs, off_parts, off_pcnt, bytes;
     int parts, part_cap;  // item-split launches of a small batch (parts <= 1: none)
+    int tail_parts;       // ... of the partial last round of a large batch
 };
 // candidates per (row, part) sub-list: twice a row's whole list divided by the parts (the tiles are
 // interleaved, so a part holds ~1/S of a row's candidates; a part that overflows sends the row to
@@ -2167,6 +2168,25 @@ static int filter_parts(int64_t rows, int64_t n_items, int kp)
     if (parts > n_itiles / 4) parts = n_itiles / 4;
     if (parts > 64) parts = 64;  // (cand_merge_kernel: a lane per part)
     return parts < 2 ? 1 : (int)parts;
+}
+
+// rows of the partial LAST round of a batch of several rounds of filter workgroups (0: the batch
+// is whole rounds, or a single round)
+static int64_t tail_rows(int64_t rows)
+{
+    const int64_t wgs = (rows + 2 * SC_UB - 1) / (2 * SC_UB), round = 2 * 256;
+    if (!topk_overlap() || wgs <= round || wgs % round == 0) return 0;
+    return rows - (wgs / round) * round * (2 * SC_UB);
+}
+// LK_TOPK_SPLIT_TAIL=1 (default 0): the partial last round of a large batch is item-split as a
+// small batch is (its workgroups otherwise sit one per CU).  Measured twice on the cfg2 call (1270
+// workgroups = two rounds + 246): 13.1 against 12.3 ms with global counters, 12.1 against 11.9 ms
+// with per-part sub-lists -- the lone workgroups of the last round run at 0.55 of a paired one's
+// time, which splitting them does not beat.  Kept as a knob, off.
+static bool topk_split_tail()
+{
+    const char *e = getenv("LK_TOPK_SPLIT_TAIL");
+    return e && e[0] == '1';
 }
 
 // stage 1 as class maxima (sample_cmax_kernel + cmax_tau_kernel): unless switched off, and as long
@@ -2203,11 +2223,21 @@ static FusedLayout fused_layout(int64_t n_users, int64_t n_items, int32_t n, int
     L.parts = filter_parts(rows, n_items, kp);
     L.part_cap = filter_part_cap(L.parts);
     L.off_parts = L.off_pcnt = off;
-    const int maxp = filter_parts(rows, n_items, 64);
+    int maxp = filter_parts(rows, n_items, 64);
+    int64_t sub_rows = rows;
+    // ... or the partial last round of a batch of several rounds (its rows only)
+    L.tail_parts = 1;
+    const int64_t tr = tail_rows(rows);
+    if (maxp <= 1 && tr > 0 && topk_split_tail()) {
+        L.tail_parts = filter_parts(tr, n_items, kp);
+        maxp = filter_parts(tr, n_items, 64);
+        sub_rows = tr;
+        L.part_cap = filter_part_cap(L.tail_parts);
+    }
     if (maxp > 1) {
-        off += align_up((size_t)rows * maxp * filter_part_cap(maxp) * 8, 256);
+        off += align_up((size_t)sub_rows * maxp * filter_part_cap(maxp) * 8, 256);
         L.off_pcnt = off;
-        off += align_up((size_t)rows * maxp * 4, 256);
+        off += align_up((size_t)sub_rows * maxp * 4, 256);
     }
     L.bytes = off;
     return L;
@@ -2467,7 +2497,9 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
             // (measured on the 1270-workgroup cfg2 call: splitting its partial last round of 246
             // in two made the call slower, 13.1 against 12.3 ms)
             const int parts = batches == 1 ? L.parts : 1;
-            auto filter = [&](int64_t r0, int64_t nr, hipStream_t s) {
+            // (LK_TOPK_SPLIT_TAIL=1: the partial last round split as well -- measured slower, off)
+            const int tail_parts = batches == 1 ? L.tail_parts : 1;
+            auto filter = [&](int64_t r0, int64_t nr, hipStream_t s, int parts = 1) {
                 dim3 ugrid((unsigned)((nr + 2 * lk::SC_UB - 1) / (2 * lk::SC_UB)));
                 const float *uu = ub_users + r0 * ld_users;
                 float *tau_r = tau + r0;
@@ -2477,11 +2509,11 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
                 // capacity, their lists and counters are the parts' -- LK_FILTER_SPLIT_RANGE)
                 int tiles_per_wg = 0;
                 int cap_arg = lk::FUSED_CAP;
-                if (parts > 1) {
+                if (parts > 1) {  // (the sub-list buffers hold THIS launch's rows from their start)
                     ugrid.y = (unsigned)parts;
                     tiles_per_wg = L.part_cap;
-                    cand_r = pcand + r0 * parts * (int64_t)L.part_cap;
-                    cnt_r = pcnt + r0 * parts;
+                    cand_r = pcand;
+                    cnt_r = pcnt;
                 }
                 if (LK_TOPK_DMA && KP == 64)
                     hipLaunchKernelGGL(lk::score_filter64_kernel, ugrid, dim3(256), 0, s, uu, nr,
@@ -2560,7 +2592,7 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
                 filter(0, rows_a, st);
                 LK_HIP_CHECK(hipEventRecord(sd.fork, st));  // range A filtered
                 LK_HIP_CHECK(hipStreamWaitEvent(sd.stream, sd.fork, 0));
-                filter(rows_a, rows - rows_a, st);
+                filter(rows_a, rows - rows_a, st, tail_parts);
                 // both tiers of range A's selection beside the partial round
                 select(0, rows_a, sd.stream, big);
                 tier2(rows_a, sd.stream, big);
@@ -2570,7 +2602,7 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
                 LK_HIP_CHECK(hipStreamWaitEvent(st, sd.join, 0));
             } else {
                 stage1(0, rows, st);
-                filter(0, rows, st);
+                filter(0, rows, st, parts);
                 select(0, rows, st, big);
                 tier2(rows, st, big);
             }
