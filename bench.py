@@ -678,6 +678,51 @@ def topk_cpu_and_parity(P, Q, ex_ptr, ex_idx, gpu_idx, gpu_sc, n, budget_s=10.0,
     return cpu, par
 
 
+
+def knn_component_recommend(ratings, gpu_lists=None, n_users=10000, n=100):
+    """
+    ``pipelines/iknn-explicit.toml``'s recommend path for a batch of users THROUGH THE COMPONENTS
+    (the ``knn.recommend`` leg above calls ``lk_iknn_recommend`` on arrays the bench prepared):
+    ``Pipeline.load_config`` -> ``train`` (``save_nbrs = 100``, ``max_nbrs = 100``: the model of
+    that leg) -> ``batch.recommend(pipe, users, 100)`` = ``UserTrainingHistoryLookup.batch`` (user
+    numbers) + ``ItemKNNScorer.recommend_batch`` (histories gathered and mean-centred on the
+    device, hit counts per user from the device).  Same users as the array-level leg.
+    """
+    import torch
+
+    from lkpy_amd import batch as lk_batch
+    from lkpy_amd.data import Dataset, Vocabulary
+    from lkpy_amd.pipeline import Pipeline
+
+    n_u, n_i = ratings.shape
+    rows = np.repeat(np.arange(n_u, dtype=np.int32), np.diff(ratings.indptr))
+    ds = Dataset(Vocabulary(np.arange(n_u), "user", reorder=False),
+                 Vocabulary(np.arange(n_i), "item", reorder=False),
+                 rows, ratings.indices, {"rating": ratings.data})
+    pipe = Pipeline.load_config(ROOT / "tests" / "golden" / "pipelines" / "iknn-explicit.toml")
+    scorer = pipe.node("scorer").component
+    scorer.config.save_nbrs, scorer.config.max_nbrs, scorer.config.min_nbrs = 100, 100, 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.train(ds)
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t0
+    users = np.random.default_rng(43).choice(n_u, min(n_users, n_u), replace=False)
+    lk_batch.recommend(pipe, users[:256], n)  # uploads: training matrix, item means, hit counts
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = lk_batch.recommend(pipe, users, n)
+        ts.append(time.perf_counter() - t0)
+    res = {"what": "iknn-explicit.toml (save_nbrs = max_nbrs = 100) trained through the pipeline, "
+                   "batch.recommend(pipe, 10 000 user ids, 100): ids in, array-backed "
+                   "ItemListCollection out",
+           "seconds": round(min(ts), 5), "users": int(len(users)),
+           "users_per_s": round(len(users) / min(ts), 1),
+           "pipeline_train_seconds": round(t_train, 3), "listed": int(out.total_items())}
+    return res
+
 def _gather_rows(out, rows):
     "rows of a DeviceCSR similarity matrix -> host (ptr, idx, val); torch as plumbing only"
     import torch
@@ -1474,6 +1519,8 @@ def compact_line(out: dict) -> dict:
                 e = _pick(sub, "seconds", "queries", "queries_per_s", "targets_per_query", "n",
                           "error")
                 e["roofline_frac"] = (sub.get("roofline") or {}).get("frac")
+                if isinstance(sub.get("through_components"), dict):
+                    e["seconds_through_components"] = sub["through_components"].get("seconds")
                 e["cpu_baseline"] = _cpu(sub.get("cpu_baseline"))
                 e["parity"] = _pick(sub.get("parity") or {}, "ok", "queries_checked",
                                     "scores_compared", "scores_bit_identical", "counts_identical",
@@ -1824,6 +1871,11 @@ def main():
                              score_checker=None if args.no_cpu else knn_score_cpu_and_parity,
                              recommend_checker=None if args.no_cpu else
                              knn_recommend_cpu_and_parity)
+        if isinstance(res.get("recommend"), dict) and "error" not in res["recommend"]:
+            try:
+                res["recommend"]["through_components"] = knn_component_recommend(ratings)
+            except Exception as exc:  # noqa: BLE001 -- reported in place
+                res["recommend"]["through_components"] = {"error": f"{type(exc).__name__}: {exc}"}
         if isinstance(res.get("roofline"), dict) and args.scale == 1.0:
             # HBM bytes of the build kernel from the committed PMC summary of the same workload
             res["roofline"]["traffic"], res["roofline"]["traffic_source"] = pmc_traffic(
