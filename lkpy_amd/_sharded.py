@@ -48,12 +48,19 @@ def balanced_ranges(weights: np.ndarray, world: int) -> list[tuple[int, int]]:
 
 
 def _send(t: torch.Tensor, dst: int, group):
-    dist.send(t.contiguous(), dst=dist.get_global_rank(group, dst) if group is not None else dst,
-              group=group)
+    t = t.contiguous()
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        # RCCL point-to-point is ordered on the current stream; a host-staged backend (gloo: the
+        # two-process tests on one GPU) reads the buffer from the host side -- the kernels that
+        # produced it must have finished
+        torch.cuda.current_stream(t.device).synchronize()
+    dist.send(t, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
 
 
 def _recv(t: torch.Tensor, src: int, group):
     dist.recv(t, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        torch.cuda.current_stream(t.device).synchronize()
 
 
 def stitch_csr_blocks(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor, n_rows_total: int,

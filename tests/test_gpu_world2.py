@@ -138,3 +138,71 @@ def test_two_processes_one_gpu(gpu, oracle, tmp_path, k, wb, env):
     assert eP < 1e-4 and eQ < 1e-4 and rel(r0["otor"], G1) < 1e-4
     assert float(r0["du"]) == pytest.approx(du, rel=1e-3)
     assert float(r0["di"]) == pytest.approx(di, rel=1e-3)
+
+
+def _worker_legs(rank, world, port, ratings, U, Q, k, n, ex_ptr, ex_idx, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    import torch
+    import torch.distributed as dist
+
+    from lkpy_amd import _device as D
+    from lkpy_amd import _sharded
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dui, diu, _means, _ = D.iknn_prepare(ratings, True, dev)
+        ranges, sims = _sharded.iknn_build_sharded(dui, diu, 1.0e-6, None)
+        dU, dQ = D.to_device_padded(U, dev), D.to_device_padded(Q, dev)
+        _r2, top = _sharded.score_topk_sharded(dU, dQ, k, n, torch.from_numpy(ex_ptr).to(dev),
+                                               torch.from_numpy(ex_idx).to(dev))
+        torch.cuda.synchronize()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "legs.npz"), ptr=sims[0].cpu().numpy(),
+                     idx=sims[1].cpu().numpy(), val=sims[2].cpu().numpy(),
+                     ti=top[0].cpu().numpy(), ts=top[1].cpu().numpy(),
+                     ranges=np.asarray(ranges))
+        else:
+            assert sims is None and top is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_knn_build_and_topk_two_processes(gpu, rng, tmp_path):
+    """``_sharded.iknn_build_sharded`` / ``score_topk_sharded`` (what ``bench.py --gpus N`` runs in
+    its sharded legs) with two processes on one GPU: each builds / scores its block with the HIP
+    kernels, the blocks travel point-to-point as DEVICE tensors and are stitched on rank 0 --
+    bit-identical to the single-process build / call."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from lkpy_amd import _device as D
+    from lkpy_amd import synth
+
+    ratings = synth.ml25m_like(seed=7, scale=0.03)
+    k, n = 64, 20
+    B, I = ratings.shape
+    U = (rng.standard_normal((B, k)) * 0.3).astype(np.float32)
+    Q = (rng.standard_normal((I, k)) * 0.3).astype(np.float32)
+    ex_ptr = ratings.indptr.astype(np.int64)
+    ex_idx = ratings.indices.astype(np.int32)
+    dui, diu, _m, _ = D.iknn_prepare(ratings, True, gpu)
+    want = D.iknn_build(dui, diu, 1.0e-6, None)
+    wi, ws = D.score_topk(D.to_device_padded(U, gpu), D.to_device_padded(Q, gpu), k, n,
+                          torch.from_numpy(ex_ptr).to(gpu), torch.from_numpy(ex_idx).to(gpu))
+    w_ptr, w_idx, w_val = (t.cpu().numpy() for t in (want.indptr, want.indices, want.values))
+    wi, ws = wi.cpu().numpy(), ws.cpu().numpy()
+    del want, dui, diu
+    torch.cuda.synchronize()
+    mp.spawn(_worker_legs, args=(2, _free_port(), ratings, U, Q, k, n, ex_ptr, ex_idx,
+                                 str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "legs.npz")
+    assert got["ranges"].shape == (2, 2) and got["ranges"][0, 1] == got["ranges"][1, 0]
+    assert np.array_equal(got["ptr"], w_ptr) and np.array_equal(got["idx"], w_idx)
+    assert np.array_equal(got["val"].view(np.uint32), w_val.view(np.uint32))
+    assert np.array_equal(got["ti"], wi)
+    assert np.array_equal(got["ts"].view(np.uint32), ws.view(np.uint32))
