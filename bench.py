@@ -1168,6 +1168,32 @@ def cfg5_run(args, dev, world, rank, steps, warmup, topk_users=0):
     return out
 
 
+
+def init_ranks(world: int, local_rank: int):
+    """
+    Device + process group of this rank: ``nccl`` (= RCCL) with one GPU per rank -- the contract.
+    ``LK_BENCH_DRYRUN_ONE_GPU=1`` (a rehearsal, never a measurement): every rank uses cuda:0 and
+    the group is ``gloo`` moving device tensors, so that the whole N > 1 flow of this file
+    (sharded engine, collective timing, predicted-vs-measured, sharded legs, watchdog) can be
+    executed on a one-GPU box before an 8-GPU node sees it; the line says ``"dryrun": true``.
+    """
+    import torch
+    import torch.distributed as dist
+
+    dry = os.environ.get("LK_BENCH_DRYRUN_ONE_GPU", "0") == "1"
+    idx = 0 if dry else local_rank
+    torch.cuda.set_device(idx)
+    dev = torch.device("cuda", idx)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if dry:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    return dev, dry
+
+
 def main_cfg5(args):
     "``--config cfg5``: the cfg5 run as a bench line of its own."
     import torch
@@ -1181,12 +1207,10 @@ def main_cfg5(args):
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     _native.require_gpu()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    dev, dry = init_ranks(world, local_rank)
     out = cfg5_run(args, dev, world, rank, args.steps, args.warmup, args.topk_users)
+    if dry and world > 1:
+        out["dryrun"] = True
     if rank == 0:
         emit(out)
     if world > 1:
@@ -1488,7 +1512,8 @@ def compact_line(out: dict) -> dict:
     tail of stdout.  The full objects are in the line printed just before it.
     """
     c = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
-              "higher_is_better", "scaling", "vs_baseline", "dtype", "collectives", "incomplete")
+              "higher_is_better", "scaling", "vs_baseline", "dtype", "collectives", "incomplete",
+              "dryrun")
     c["data"] = _short(out.get("data", ""), 200)
     c["config"] = _pick(out.get("config", {}), "workload", "solver", "parallelism", "data_source")
     if "roofline" in out:
@@ -1510,7 +1535,8 @@ def compact_line(out: dict) -> dict:
                   "build_seconds_to_host_first_call", "build_save_nbrs_100_seconds",
                   "prepare_seconds", "nnz_out", "error")
         d["metric"] = ("item-kNN model build seconds, CSR on device -> similarity CSR on host "
-                       "(BASELINE's definition; hbm_resident = without the download)")
+                       "(BASELINE's definition; hbm_resident = without the download)"
+                       if "build_seconds_hbm_resident" in knn else knn.get("metric"))
         d["roofline"] = _roof(knn.get("roofline"))
         d["cpu_baseline"] = _cpu(knn.get("cpu_baseline"))
         for name in ("batch_score", "recommend"):
@@ -1738,11 +1764,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     _native.require_gpu()  # no CPU fallback: fail loudly without the HIP path
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    dev, dry = init_ranks(world, local_rank)
 
     k, reg, weight = args.k, 0.1, 40.0
     ratings, data_desc, data_source = load_ratings(args.scale)
@@ -1798,6 +1820,8 @@ def main():
         "final_deltas": list(deltas),
         "setup_seconds": round(setup_seconds, 4),
     }
+    if dry and world > 1:
+        out["dryrun"] = True  # ranks shared ONE GPU over gloo: a rehearsal of the flow, not a measurement
     if roof:
         out["roofline"] = roof
     if getattr(eng, "summation_order", None):
