@@ -170,17 +170,16 @@ def test_als_item_half_at_cfg5_shape(gpu, oracle):
     torch.cuda.empty_cache()
     want = np.zeros_like(got)
     oracle.als_half_epoch(sub, want, other_h, oracle.implicit_otor(other_h, reg))
-    exact, cond = oracle.als_referee_f64(sub, other_h, reg)
-    acc = parity.als_half_accounting(got, want, exact, cond)
+    # (no float64 referee here: the raw criterion needs none, and on these rows it doubles the
+    # test's two minutes of host time; bench.py's cfg5 leg runs it)
+    acc = parity.als_half_accounting(got, want, None, None)
     rel = np.linalg.norm(got.astype(np.float64) - want, axis=1) / \
         np.maximum(np.linalg.norm(want.astype(np.float64), axis=1), 1e-300)
     is_long = lens > 4096
     print(f"\ncfg5 item half: {len(rows)} rows checked ({int(is_long.sum())} of more than 4096 "
           f"entries, longest {int(lens.max())}); rows over 1e-4: {acc['rows_over_1e-4']}; worst "
           f"{acc['row_rel_max']:.2e} (long rows {rel[is_long].max():.2e})")
-    assert acc["ok"] and acc["rows_over_1e-4"] == 0, (acc["rows_over_1e-4"], acc["row_rel_max"],
-                                                        acc.get("exceptions"))
-    assert acc["accounted"]
+    assert acc["ok"] and acc["rows_over_1e-4"] == 0, (acc["rows_over_1e-4"], acc["row_rel_max"])
 
 
 def _sample_rows(rng, n_items, n):
