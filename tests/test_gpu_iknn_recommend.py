@@ -189,3 +189,40 @@ def test_nan_similarity_is_the_reference_error(gpu):
         D.iknn_recommend(dsims, _to(ptr, gpu), _to(idx, gpu), None, None, 5, 1, 2,
                          np.array([4], np.int64))
     assert _native is not None
+
+
+def test_history_batch_equals_list_path_at_ml25m_shape(gpu):
+    """``iknn-explicit.toml``'s scorer at the ML-25M shape (``save_nbrs = max_nbrs = 100``), 5 000
+    sampled users: ``recommend_batch`` by USER NUMBER (``HistoryBatch``: histories gathered and
+    mean-centred on the device, hit counts per user from one device pass, two batches of the
+    recommend kernel) against the per-query list path (one ``RecQuery`` per user, host arrays) --
+    the same index and score arrays, bit for bit.  What the array-level bench leg and the
+    ml-latest-small test leave open between them: histories of up to 32 202 entries, more
+    queries than one panel batch holds, the heaviest-first reordering undone."""
+    from lkpy_amd import synth
+    from lkpy_amd.basic import UserTrainingHistoryLookup
+    from lkpy_amd.data import Dataset, RecQuery, Vocabulary
+    from lkpy_amd.knn import ItemKNNScorer
+
+    ratings = synth.ml25m_like()
+    n_u, n_i = ratings.shape
+    ds = Dataset(Vocabulary(np.arange(n_u), "user", reorder=False),
+                 Vocabulary(np.arange(n_i), "item", reorder=False),
+                 np.repeat(np.arange(n_u, dtype=np.int32), np.diff(ratings.indptr)),
+                 ratings.indices, {"rating": ratings.data})
+    scorer = ItemKNNScorer(max_nbrs=100, min_nbrs=1, save_nbrs=100)
+    scorer.train(ds)
+    lookup = UserTrainingHistoryLookup()
+    lookup.train(ds)
+    rng = np.random.default_rng(43)
+    users = rng.choice(n_u, 5000, replace=False)
+    users[:3] = np.argsort(-np.diff(ratings.indptr))[:3]  # the three longest histories
+    gi, gs = scorer.recommend_batch(lookup.batch(users), 100)
+    li, ls = scorer.recommend_batch([lookup(RecQuery.create(int(u))) for u in users], 100)
+    assert gi.shape == (5000, 100) and (gi >= 0).all()
+    assert np.array_equal(gi, li)
+    assert np.array_equal(np.ascontiguousarray(gs).view(np.uint32),
+                          np.ascontiguousarray(ls).view(np.uint32))
+    for r in (0, 1, 2, 77):  # never one of the user's own items
+        own = ratings.indices[ratings.indptr[users[r]]:ratings.indptr[users[r] + 1]]
+        assert not np.isin(gi[r], own).any()
