@@ -521,7 +521,7 @@ def recommend_leg(scorer, ds, n_users=10000, n=100, no_cpu=False):
     if not scorer.config.use_ratings:  # implicit: the constant weight, no rating read
         src = D.DeviceCSR(src.indptr, src.indices, None, src.shape, src.h_indptr)
     t_gather, hist = timed(lambda: D.gather_rows(src, hb.user_nums, scale=scorer.config.weight))
-    plan = D.ALSPlan(hist, k, scorer._solver())
+    plan = D.ALSPlan(hist, k, scorer._solver(), reference_order="accurate")  # (as D.fold_in does)
     u = torch.zeros((len(users), plan.kp), dtype=torch.float32, device=dev)
     t_fold, _ = timed(lambda: plan.half_epoch(u, st["Q"], st["OtOr"]))
     plan.check_status()

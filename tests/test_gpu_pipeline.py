@@ -133,7 +133,8 @@ def test_als_implicit_toml_trains_like_the_reference(gpu, oracle, ml_small, ml_d
     print(f"\nrecommend parity over {len(users)} users: lists bit-identical given the same query "
           f"vector: {len(users)}/{len(users)}; with the CPU fold-in vector: {same_cpu_foldin} "
           f"identical, {near_ties} differ at near-ties only; fold-in rel err max {fold_err:.2e}")
-    assert fold_err < 1e-3  # (measured 3.9e-4: cond 1e3 .. 2e5 on ml-latest-small; round 5 allowed 5e-3)
+    assert fold_err < 3e-4  # (measured 7.3e-5 with fold-in plans in the kernels' own order -- the
+    # reference's fold-in is NumPy, not the Rust chain; 3.9e-4 in the hybrid order; round 5 allowed 5e-3)
 
     # NaN semantics (tests/models/test_als_implicit.py:277-298, _common.py:145-170)
     from lkpy_amd.data import ItemList

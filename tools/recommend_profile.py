@@ -55,7 +55,7 @@ hb = t("lookup.batch (vocabulary, lengths)", lambda: lk.batch(users))
 src = lk._device_matrix()["csr"]
 src = D.DeviceCSR(src.indptr, src.indices, None, src.shape, src.h_indptr)
 hist = t("gather_rows (host prefix + kernel)", lambda: D.gather_rows(src, hb.user_nums, scale=40.0))
-plan = t("ALSPlan(hist)", lambda: D.ALSPlan(hist, 64))
+plan = t("ALSPlan(hist)", lambda: D.ALSPlan(hist, 64, reference_order="accurate"))
 import ctypes  # noqa: E402
 
 from lkpy_amd import _native  # noqa: E402
