@@ -961,7 +961,7 @@ def fold_in_explicit(hist: DeviceCSR, items: torch.Tensor, reg: float, k: int) -
     src/lenskit/als/_explicit.py:121-149): one explicit row solve per history row of ``hist``
     (queries x items CSR, values = bias-normalised ratings).  Returns [n_queries x KP].
     """
-    plan = ALSPlan(hist, k, _native.SOLVER_CHOLESKY)
+    plan = ALSPlan(hist, k, _native.SOLVER_CHOLESKY, reference_order="accurate")  # (as fold_in)
     out = torch.zeros((hist.shape[0], plan.kp), dtype=torch.float32, device=items.device)
     plan.half_epoch_explicit(out, items, reg)
     plan.check_status()
