@@ -39,6 +39,7 @@
 // of algorithmic traffic, L2 / MALL resident for a truncated model) and every hit costs two LDS
 // atomics; the per-window fixed cost (zero, scan, score sweep, copy-out) is what a short history
 // pays.  bench.py reports the call against the HBM roofline on those bytes.
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -275,7 +276,19 @@ __device__ __forceinline__ void walk(unsigned *__restrict__ c, const int64_t *__
 constexpr int RDP = 8;  // batches (of 64 entries) in flight per wave
 constexpr int LQ_CAP = 192;  // per-wave queue of "longer" targets of a window (sweep, phase B)
 
-template <bool FILL, bool EXPL>
+// What a packed walk does with every entry: count it / drop it at its target's cursor / add its
+// weight / add weight x rating to the target's LDS cell (the last two: the accumulating kernel below)
+constexpr int WALK_COUNT = 0, WALK_FILL = 1, WALK_ADD_W = 2, WALK_ADD_WV = 3;
+
+// ds_add_f32 without return: same-address adds of one instruction are applied in ascending lane
+// order, IEEE round-to-nearest, denormals kept (probed on the device before the kernel is used)
+__device__ __forceinline__ void lds_fadd(unsigned *cell, float v)
+{
+    (void)__hip_atomic_fetch_add(reinterpret_cast<float *>(cell), v, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int MODE, bool EXPL>
 __device__ __forceinline__ void walk_packed(
     unsigned *__restrict__ c, unsigned *__restrict__ dsc, const int64_t *__restrict__ s_ptr,
     const int32_t *__restrict__ s_idx, const float *__restrict__ s_val,
@@ -337,26 +350,242 @@ __device__ __forceinline__ void walk_packed(
                 const int64_t e = (int64_t)(((unsigned long long)d_hi[lo] << 32) | d_lo[lo]) +
                                   (int64_t)pc;
                 t_[d] = s_idx[e] - w0;
-                if (FILL) {
-                    s_[d] = s_val[e];
-                    r_[d] = d_rt[lo];
-                }
+                if (MODE != WALK_COUNT) s_[d] = s_val[e];
+                if (MODE == WALK_FILL || MODE == WALK_ADD_WV) r_[d] = d_rt[lo];
             }
 #pragma unroll
             for (int d = 0; d < RDP; ++d) {
                 if (p0 + 64u * d >= total) break;  // (wave-uniform)
                 if (live_[d]) {
-                    if (!FILL) {
+                    if (MODE == WALK_COUNT) {
                         atomicAdd(&c[cidx(t_[d])], 1u);  // ds_add_u32, no return
-                    } else {
+                    } else if (MODE == WALK_FILL) {
                         const unsigned pos = atomicAdd(&c[cidx(t_[d])], 1u);  // lane order
                         if (s_[d] != s_[d]) atomicCAS(status, 0, 1);  // accum.rs:146-151
                         hits[pos] = float2{s_[d], r_[d]};
+                    } else if (MODE == WALK_ADD_W) {
+                        if (s_[d] != s_[d]) atomicCAS(status, 0, 1);  // accum.rs:146-151
+                        lds_fadd(&c[cidx(t_[d])], s_[d]);  // lane order
+                    } else {
+                        lds_fadd(&c[cidx(t_[d])], s_[d] * r_[d]);  // product rounded, then added
                     }
                 }
             }
         }
     }
+}
+
+// The packed walk of the accumulating kernel: the same stream of entries, with the chunk
+// descriptors PIPELINED -- a walk is a chain of dependent loads per 64-row chunk (history rows ->
+// their window offsets and row starts -> the entries), one memory latency each, and that chain is
+// what a walk costs.  Here the history rows of chunk k + 2 and the descriptors of chunk k + 1 are
+// requested before chunk k's entries, so a chunk costs ONE latency after a two-latency prologue;
+// and the first walk of a task RECORDS the descriptors of its first KC chunks in registers
+// (CACHE = 1), which the second and third walk replay (CACHE = 2) without loading anything but
+// entries.
+constexpr int ACC_CAPB = 8192;                  // stream positions the first-position bitmap covers
+static_assert(ACC_CAPB >= RW, "a single row piece (<= RW entries) must fit the bitmap");
+constexpr int ACC_DSC = 192 + ACC_CAPB / 32 + 4;  // words of wave-private table + bitmap
+constexpr int KC = 4;
+struct DescCache {  // (scalars, not arrays: an array indexed by the chunk number goes to scratch)
+    int64_t a0, a1, a2, a3;
+    int n0, n1, n2, n3;
+    float r0, r1, r2, r3;
+};
+struct ChunkDesc {
+    int64_t a;
+    int n;
+    float rate;
+};
+__device__ __forceinline__ ChunkDesc cache_get(const DescCache &dc, int k)
+{
+    // (the candidates pass through an empty asm: left alone, the optimiser folds the selects into
+    // ONE load at a selected address -- and the twelve scalars into a scratch array)
+    int64_t a0 = dc.a0, a1 = dc.a1, a2 = dc.a2, a3 = dc.a3;
+    int n0 = dc.n0, n1 = dc.n1, n2 = dc.n2, n3 = dc.n3;
+    float r0 = dc.r0, r1 = dc.r1, r2 = dc.r2, r3 = dc.r3;
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3));
+    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+    ChunkDesc d;
+    d.a = k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3;
+    d.n = k == 0 ? n0 : k == 1 ? n1 : k == 2 ? n2 : n3;
+    d.rate = k == 0 ? r0 : k == 1 ? r1 : k == 2 ? r2 : r3;
+    return d;
+}
+__device__ __forceinline__ DescCache cache_set(DescCache dc, int k, const ChunkDesc &d)
+{
+    dc.a0 = k == 0 ? d.a : dc.a0;
+    dc.a1 = k == 1 ? d.a : dc.a1;
+    dc.a2 = k == 2 ? d.a : dc.a2;
+    dc.a3 = k == 3 ? d.a : dc.a3;
+    dc.n0 = k == 0 ? d.n : dc.n0;
+    dc.n1 = k == 1 ? d.n : dc.n1;
+    dc.n2 = k == 2 ? d.n : dc.n2;
+    dc.n3 = k == 3 ? d.n : dc.n3;
+    dc.r0 = k == 0 ? d.rate : dc.r0;
+    dc.r1 = k == 1 ? d.rate : dc.r1;
+    dc.r2 = k == 2 ? d.rate : dc.r2;
+    dc.r3 = k == 3 ? d.rate : dc.r3;
+    return dc;
+}
+
+template <int MODE, bool EXPL, int CACHE>
+__device__ __forceinline__ DescCache walk_acc(
+    unsigned *__restrict__ c, unsigned *__restrict__ dsc, const int64_t *__restrict__ s_ptr,
+    const int32_t *__restrict__ s_idx, const float *__restrict__ s_val,
+    const unsigned *__restrict__ woff, int nwin, int win, int64_t n_items,
+    const int32_t *__restrict__ ref_items, const float *__restrict__ ref_rates, int64_t rb,
+    int64_t re, int *__restrict__ status, int lane, DescCache dc)
+{
+    static_assert(MODE != WALK_FILL, "the accumulating kernel keeps no lists");
+    const int w0 = win * RW;
+    // wave-private LDS: [0..127] (piece address - first position) of the rows with entries, by
+    // rank; [128..191] their ratings; then the bitmap of first positions
+    uint2 *d_rel = reinterpret_cast<uint2 *>(dsc);
+    float *d_rt = reinterpret_cast<float *>(dsc + 128);
+    unsigned *d_bm = dsc + 192;
+    // the history row (and rating) of this lane in the chunk at r0; -1: none
+    auto load_row = [&](int64_t r0, int &ri, float &rate) {
+        ri = -1;
+        rate = 0.f;
+        if (r0 + lane < re) {
+            ri = ref_items[r0 + lane];
+            if (EXPL) rate = ref_rates[r0 + lane];
+        }
+    };
+    auto load_desc = [&](int ri, float rate) {
+        ChunkDesc d{0, 0, rate};
+        if (ri >= 0 && ri < n_items) {  // null reference rows are skipped (item_score.rs:38-49)
+            const unsigned *wo = woff + (int64_t)ri * (nwin + 1) + win;
+            const unsigned o0 = wo[0], o1 = wo[1];
+            d.a = s_ptr[ri] + o0;
+            d.n = (int)(o1 - o0);
+        }
+        return d;
+    };
+    ChunkDesc cur{0, 0, 0.f};
+    int ri1 = -1;
+    float rt1 = 0.f;
+    if (CACHE == 2) {
+        cur = cache_get(dc, 0);
+        if (KC < 2 && rb + 64 < re) load_row(rb + 64, ri1, rt1);
+    } else {
+        int ri0;
+        float rt0;
+        load_row(rb, ri0, rt0);
+        if (rb + 64 < re) load_row(rb + 64, ri1, rt1);
+        cur = load_desc(ri0, rt0);
+    }
+    int k = 0;
+    for (int64_t r0 = rb; r0 < re; r0 += 64, ++k) {
+        ChunkDesc nxt{0, 0, 0.f};
+        int ri2 = -1;
+        float rt2 = 0.f;
+        if (r0 + 64 < re) {
+            if (CACHE == 2 && k + 1 < KC)
+                nxt = cache_get(dc, k + 1);
+            else
+                nxt = load_desc(ri1, rt1);
+        }
+        if (r0 + 128 < re && !(CACHE == 2 && k + 2 < KC)) load_row(r0 + 128, ri2, rt2);
+        if (CACHE == 1 && k < KC) dc = cache_set(dc, k, cur);
+        const int n = cur.n;
+        unsigned incl = (unsigned)n;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        // The row of stream position p.  The list kernel's walk finds it by a 6-step binary search
+        // over the prefixes (six dependent LDS reads per 64 entries); here the rows WITH entries are
+        // numbered (rank), a bitmap holds a 1 at every row's first position, and the row of p is
+        // (ones at positions <= p) - 1: one broadcast read of the bitmap's 64 bits at the batch's
+        // start, an and + popcount, and the table read.  The bitmap covers ACC_CAPB positions; a
+        // chunk with more (a full similarity matrix) is walked in runs of whole rows that fit.
+        const unsigned excl = incl - (unsigned)n;
+        unsigned done_pos = 0u;
+        int j0 = 0;
+        while (done_pos < total) {  // (wave-uniform; one turn unless the chunk exceeds the bitmap)
+            const unsigned long long over =
+                __ballot(lane >= j0 && incl - done_pos > (unsigned)ACC_CAPB);
+            const int j1 = over != 0ull ? (int)__builtin_ctzll(over) : 64;
+            if (j1 == j0) {  // a row piece beyond the bitmap: impossible (a piece has <= RW entries,
+                             // columns are unique) unless the matrix is malformed -- refused
+                atomicCAS(status, 0, 2);
+                break;
+            }
+            const unsigned sub_end =
+                j1 == 64 ? total : (unsigned)__builtin_amdgcn_readlane((int)excl, j1);
+            const unsigned sub_total = sub_end - done_pos;
+            const bool in_sub = lane >= j0 && lane < j1 && n > 0;
+            const unsigned long long rows = __ballot(in_sub);
+            const int nrows = (int)__popcll(rows);
+            const unsigned sx = excl - done_pos;  // first position of the lane's row in this run
+            const int64_t rel = cur.a - (int64_t)sx;
+            wave_lds_sync();  // the previous run's readers are done
+            for (unsigned wd = lane; wd < (sub_total >> 5) + 3u; wd += 64u) d_bm[wd] = 0u;
+            wave_lds_sync();
+            if (in_sub) {
+                const int rk = (int)__popcll(rows & ((1ull << lane) - 1ull));
+                d_rel[rk] = uint2{(unsigned)rel, (unsigned)((unsigned long long)rel >> 32)};
+                if (MODE == WALK_ADD_WV) d_rt[rk] = cur.rate;
+                atomicOr(&d_bm[sx >> 5], 1u << (sx & 31u));  // ds_or_b32, no return
+            }
+            wave_lds_sync();
+            unsigned before = 0u;  // ones at positions < the batch's start
+            for (unsigned p0 = 0; p0 < sub_total; p0 += 64u * RDP) {
+                int t_[RDP];
+                float s_[RDP], r_[RDP];
+                bool live_[RDP];
+#pragma unroll
+                for (int d = 0; d < RDP; ++d) {
+                    const unsigned pb = p0 + 64u * d;
+                    const unsigned p = pb + lane;
+                    live_[d] = p < sub_total;
+                    const unsigned pc = live_[d] ? p : sub_total - 1;
+                    // (positions past the end re-read the stream's last entry: every load is
+                    // unconditional)
+                    const unsigned wi = pb < sub_total ? (pb >> 5) : 0u;
+                    const unsigned m0 = d_bm[wi], m1 = d_bm[wi + 1];
+                    const unsigned le0 = lane < 32 ? (0xffffffffu >> (31 - lane)) : 0xffffffffu;
+                    const unsigned le1 = lane < 32 ? 0u : (0xffffffffu >> (63 - lane));
+                    int rk = (int)before + __builtin_popcount(m0 & le0) +
+                             __builtin_popcount(m1 & le1) - 1;
+                    rk = rk < nrows - 1 ? rk : nrows - 1;
+                    rk = pb < sub_total ? rk : nrows - 1;
+                    before += (unsigned)(__builtin_popcount(m0) + __builtin_popcount(m1));
+                    const uint2 rl = d_rel[rk];
+                    const int64_t e =
+                        (int64_t)(((unsigned long long)rl.y << 32) | rl.x) + (int64_t)pc;
+                    t_[d] = s_idx[e] - w0;
+                    if (MODE != WALK_COUNT) s_[d] = s_val[e];
+                    if (MODE == WALK_ADD_WV) r_[d] = d_rt[rk];
+                }
+#pragma unroll
+                for (int d = 0; d < RDP; ++d) {
+                    if (p0 + 64u * d >= sub_total) break;  // (wave-uniform)
+                    if (live_[d]) {
+                        if (MODE == WALK_COUNT) {
+                            atomicAdd(&c[t_[d]], 1u);  // ds_add_u32, no return
+                        } else if (MODE == WALK_ADD_W) {
+                            if (s_[d] != s_[d]) atomicCAS(status, 0, 1);  // accum.rs:146-151
+                            lds_fadd(&c[t_[d]], s_[d]);  // lane order
+                        } else {
+                            lds_fadd(&c[t_[d]], s_[d] * r_[d]);  // product rounded, then added
+                        }
+                    }
+                }
+            }
+            done_pos = sub_end;
+            j0 = j1;
+        }
+        cur = nxt;
+        ri1 = ri2;
+        rt1 = rt2;
+    }
+    return dc;
 }
 
 // Does the LDS hand out the old values of same-address `ds_add_rtn_u32`s of ONE instruction in
@@ -393,6 +622,51 @@ __global__ void lds_atomic_order_probe_kernel(int *__restrict__ ok)
             if (l < lane && al == addr) ++want;
         }
         if (old != want) atomicExch(ok, 0);
+        __syncthreads();
+    }
+}
+
+// The same question for `ds_add_f32` (what iknn_score_acc_kernel relies on): is a cell, after the
+// same-address float adds of several instructions, the SEQUENTIAL f32 sum of the addends in
+// (instruction, lane) order -- round-to-nearest, denormals kept?  Addends of very different
+// magnitudes (and a denormal range), so that any other order or rounding shows in the bits.
+__global__ void lds_fadd_order_probe_kernel(int *__restrict__ ok)
+{
+    __shared__ unsigned cell[64];
+    const int lane = threadIdx.x;
+    for (int pat = 0; pat < 12; ++pat) {
+        cell[lane] = 0u;
+        __syncthreads();
+        float want = 0.f;  // of cell[lane]
+        for (int round = 0; round < 3; ++round) {
+            int addr;
+            switch ((pat + 5 * round) % 12) {
+                case 0: addr = 0; break;
+                case 1: addr = lane & 1; break;
+                case 2: addr = lane % 5; break;
+                case 3: addr = (lane * 7) % 13; break;
+                case 4: addr = lane >> 4; break;
+                case 5: addr = (lane >> 1) & 7; break;
+                case 6: addr = (lane * lane) % 11; break;
+                case 7: addr = lane & 31; break;
+                case 8: addr = 63 - (lane & 7); break;
+                case 9: addr = (lane ^ 21) % 3; break;
+                case 10: addr = lane < 40 ? 3 : lane; break;
+                default: addr = (lane * 37 + 11) % 17; break;
+            }
+            const int ex = pat < 8 ? ((lane * 5 + round * 3 + pat) % 23) - 11   // 2^-11 .. 2^11
+                                   : -140 + ((lane * 3 + round) % 16);           // denormal sums
+            float v = __builtin_ldexpf(1.f + 0.37f * (float)((lane * 11 + pat) % 17), ex);
+            if ((lane + round) % 3 == 0) v = -v;
+            lds_fadd(&cell[addr], v);
+            for (int l = 0; l < 64; ++l) {
+                const int al = __shfl(addr, l, 64);
+                const float vl = __shfl(v, l, 64);
+                if (al == lane) want = want + vl;
+            }
+        }
+        __syncthreads();
+        if (cell[lane] != __builtin_bit_cast(unsigned, want)) atomicExch(ok, 0);
         __syncthreads();
     }
 }
@@ -452,7 +726,7 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
 
         // ---- pass 1: hits per target ----------------------------------------------------
         if constexpr (PACKED)
-            walk_packed<false, EXPL>(c, dsc_all[wave], s_ptr, s_idx, s_val, woff, nwin, win,
+            walk_packed<WALK_COUNT, EXPL>(c, dsc_all[wave], s_ptr, s_idx, s_val, woff, nwin, win,
                                      n_items, ref_items, ref_rates, rb, re, nullptr, status, lane);
         else
             walk<false, EXPL>(c, s_ptr, s_idx, s_val, woff, nwin, win, n_items, ref_items,
@@ -500,7 +774,7 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
 
         // ---- pass 2: the hits, each at its target's cursor (history order by construction) ----
         if constexpr (PACKED)
-            walk_packed<true, EXPL>(c, dsc_all[wave], s_ptr, s_idx, s_val, woff, nwin, win,
+            walk_packed<WALK_FILL, EXPL>(c, dsc_all[wave], s_ptr, s_idx, s_val, woff, nwin, win,
                                     n_items, ref_items, ref_rates, rb, re, lists, status, lane);
         else
             walk<true, EXPL>(c, s_ptr, s_idx, s_val, woff, nwin, win, n_items, ref_items,
@@ -694,6 +968,306 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
 #endif
 }
 
+// ---- round 6: the accumulating kernel ---------------------------------------------------------
+// The lists of the kernel above exist for ONE reason: a target's hits must be summed in history
+// order.  But the LDS applies the same-address `ds_add_f32`s of an instruction in ascending lane
+// order and a wave's instructions in program order (probed, like the cursor order the packed walk
+// relies on), so a walk that ADDS every weight into its target's LDS cell yields the vector's
+// sequential sum bit for bit -- no list, no hit region in HBM, no fence, no sweep that waits on
+// list loads (58 % of the list kernel).  Per (query, window) task:
+//   walk 1  counts the hits per target (as before);
+//   flags   lane l owns targets l, l + 64, ...: two 64-bit masks in registers -- `heavy` (more than
+//           max_nbrs hits: the BinaryHeap case, queued for iknn_heavy_gather_kernel + the replay
+//           kernel, which build such a target's list by themselves) and `scored` (at least
+//           min_nbrs kept hits);
+//   walk 2  cell[t] += weight;  the 64 sums of a lane move to registers;
+//   walk 3  (explicit feedback) cell[t] += weight * rating (product rounded first, accum.rs:128);
+//   sweep   score = ws / tw (+ item mean), NaN where nothing is scored; the window's segment of
+//           the panel row leaves straight from the registers, coalesced.
+// Three walks instead of two, but each is the cheap kind (the count walk: 23 k cycles per task
+// against the fill walk's 34 k and the sweep's 80 k).
+template <bool EXPL>
+__global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))  // (the LDS's limit)
+void iknn_score_acc_kernel(
+    const int64_t *__restrict__ s_ptr, const int32_t *__restrict__ s_idx,
+    const float *__restrict__ s_val, int64_t n_items, int nwin, const unsigned *__restrict__ woff,
+    int64_t q0, int64_t nq, const int64_t *__restrict__ ref_ptr,
+    const int32_t *__restrict__ ref_items, const float *__restrict__ ref_rates,
+    const float *__restrict__ item_bias, int max_nbrs, int min_nbrs, float *__restrict__ panel,
+    int64_t ld, int *__restrict__ task_counter, int *__restrict__ status,
+    OvfEntry *__restrict__ ovf, int ovf_cap, int *__restrict__ ovf_count,
+    unsigned long long *__restrict__ list_cursor)
+{
+    // one cell per target, no padding: the sweeps move FOUR cells per LDS instruction (lane l owns
+    // targets 256 g + 4 l + j) -- with two waves per SIMD a task's time is its instruction count
+    __shared__ uint4 cur4[RWAVES][RW / 4];
+    __shared__ uint2 dsc_all2[RWAVES][ACC_DSC / 2];
+#ifdef LK_REC_PHASES
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint4 *c4 = cur4[wave];
+    unsigned *c = reinterpret_cast<unsigned *>(c4);
+    unsigned *dsc = reinterpret_cast<unsigned *>(dsc_all2[wave]);
+    const int64_t n_tasks = nq * nwin;
+    const float nanf_ = __builtin_nanf("");
+    const unsigned nan_bits = __builtin_bit_cast(unsigned, nanf_);
+    constexpr int NG = RW / 256;  // quads per lane
+    // a target is scored from the vector's sums iff lo_thr <= hits <= max_nbrs (kept = min(hits,
+    // max_nbrs) >= min_nbrs, accum.rs); beyond max_nbrs: the heap's replay
+    const unsigned lo_thr = min_nbrs > 1 ? (unsigned)min_nbrs : 1u;
+    const unsigned span = (unsigned)max_nbrs >= lo_thr ? (unsigned)max_nbrs - lo_thr : 0u;
+    const bool light_possible = (unsigned)max_nbrs >= lo_thr;
+    const bool bias16 = (reinterpret_cast<uintptr_t>(item_bias) & 15u) == 0;
+
+    // (the NEXT task's number is requested while this one runs: a returning global atomic is a
+    // memory round trip at the head of every task otherwise)
+    int next_task = 0;
+    if (lane == 0) next_task = atomicAdd(task_counter, 1);
+    for (;;) {
+        LK_RP_T(p0);
+        const int task = __builtin_amdgcn_readfirstlane(next_task);
+        if (task >= n_tasks) break;
+        if (lane == 0) next_task = atomicAdd(task_counter, 1);
+        const int64_t ql = task / nwin;  // query-major: the windows of a query run side by side
+        const int win = task % nwin;
+        const int64_t q = q0 + ql;
+        const int w0 = win * RW;
+        const int wn = (int)((n_items - w0) < RW ? (n_items - w0) : RW);
+        const int wpad = (int)((ld - w0) < RW ? (ld - w0) : RW);  // (the row's padding: whole quads)
+        const int64_t rb = ref_ptr[q], re = ref_ptr[q + 1];
+        float *prow = panel + ql * ld + w0;
+        if (re == rb) {  // no history: nothing is scored (item.py:238-245)
+            for (int i = lane; i < wn; i += 64) prow[i] = nanf_;
+            continue;
+        }
+        LK_RP_T(p1);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) c4[64 * g + lane] = uint4{0u, 0u, 0u, 0u};
+        LK_RP_T(p2);
+
+        // ---- walk 1: hits per target --------------------------------------------------------
+        const DescCache dc = walk_acc<WALK_COUNT, EXPL, 1>(
+            c, dsc, s_ptr, s_idx, s_val, woff, nwin, win, n_items, ref_items, ref_rates, rb, re,
+            status, lane, DescCache{0, 0, 0, 0, 0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f});
+        wave_lds_sync();
+        LK_RP_T(p3);
+
+        // ---- counts -> the cells' start values: 0 where the vector's sums are the score, NaN
+        // everywhere else (no hit, fewer than min_nbrs, or the heap's case) -- NaN + w stays NaN,
+        // so the sums of such a target come out as the NaN its panel cell must hold anyway ------
+        {
+            uint4 cn[NG];
+            unsigned mx = 0u;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                cn[g] = c4[64 * g + lane];
+                mx = max(max(mx, max(cn[g].x, cn[g].y)), max(cn[g].z, cn[g].w));
+            }
+            if (__ballot(mx != 0u) == 0ull) {  // no hit in this window
+                for (int i = lane; i < wn; i += 64) prow[i] = nanf_;
+                continue;
+            }
+            // Full(heap) targets (rare): the list is built by iknn_heavy_gather_kernel and replayed
+            // by iknn_heap_replay_kernel (the queue holds every such target of the batch: the host
+            // cuts batches by hits / (max_nbrs + 1))
+            if (__ballot(mx > (unsigned)max_nbrs && max_nbrs >= min_nbrs) != 0ull) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const unsigned v[4] = {cn[g].x, cn[g].y, cn[g].z, cn[g].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (v[j] > (unsigned)max_nbrs && max_nbrs >= min_nbrs) {
+                            const int t = 256 * g + 4 * lane + j;
+                            const int slot = atomicAdd(ovf_count, 1);
+                            const unsigned long long at =
+                                atomicAdd(list_cursor, (unsigned long long)v[j]);
+                            if (slot < ovf_cap)
+                                ovf[slot] = OvfEntry{(int)ql, w0 + t, (int)v[j], 0, at};
+                            else
+                                atomicCAS(status, 0, 2);  // cannot happen (host bound)
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                uint4 z;
+                z.x = (light_possible && cn[g].x - lo_thr <= span) ? 0u : nan_bits;
+                z.y = (light_possible && cn[g].y - lo_thr <= span) ? 0u : nan_bits;
+                z.z = (light_possible && cn[g].z - lo_thr <= span) ? 0u : nan_bits;
+                z.w = (light_possible && cn[g].w - lo_thr <= span) ? 0u : nan_bits;
+                c4[64 * g + lane] = z;
+            }
+        }
+        wave_lds_sync();
+        LK_RP_T(p4);
+
+        // ---- walk 2: total weights, in history order by construction ------------------------------
+        (void)walk_acc<WALK_ADD_W, EXPL, 2>(c, dsc, s_ptr, s_idx, s_val, woff, nwin, win, n_items,
+                                            ref_items, ref_rates, rb, re, status, lane, dc);
+        wave_lds_sync();
+        LK_RP_T(p5);
+        float4 tw[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const uint4 x = c4[64 * g + lane];
+            tw[g] = float4{__builtin_bit_cast(float, x.x), __builtin_bit_cast(float, x.y),
+                           __builtin_bit_cast(float, x.z), __builtin_bit_cast(float, x.w)};
+        }
+        if constexpr (EXPL) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) c4[64 * g + lane] = uint4{0u, 0u, 0u, 0u};
+            wave_lds_sync();
+            // ---- walk 3: weighted sums ------------------------------------------------------------
+            (void)walk_acc<WALK_ADD_WV, EXPL, 2>(c, dsc, s_ptr, s_idx, s_val, woff, nwin, win,
+                                                 n_items, ref_items, ref_rates, rb, re, status, lane,
+                                                 dc);
+            wave_lds_sync();
+        }
+        LK_RP_T(p6);
+        // ---- scores: ws / tw (+ item mean), straight from the registers to the panel row; the item
+        // means of the NEXT four quads are requested before this four's stores (a load behind a
+        // store waits for the store) -----------------------------------------------------------------
+        // (two copies of the sweep, each free of branches: FULL = a whole window and 16-byte
+        // aligned means -- every window but the catalogue's last)
+        auto sweep = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            auto load_bias = [&](int g) {
+                float4 b{0.f, 0.f, 0.f, 0.f};
+                if (item_bias) {  // (kernel-uniform)
+                    const int t0 = 256 * g + 4 * lane;
+                    if constexpr (FULL) {
+                        b = *reinterpret_cast<const float4 *>(item_bias + w0 + t0);
+                    } else {  // clamped addresses; what they deliver beyond wn is never stored
+                        const int last = wn - 1;
+                        b.x = item_bias[w0 + (t0 < last ? t0 : last)];
+                        b.y = item_bias[w0 + (t0 + 1 < last ? t0 + 1 : last)];
+                        b.z = item_bias[w0 + (t0 + 2 < last ? t0 + 2 : last)];
+                        b.w = item_bias[w0 + (t0 + 3 < last ? t0 + 3 : last)];
+                    }
+                }
+                return b;
+            };
+            float4 bnext[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bnext[u] = load_bias(u);
+#pragma unroll
+            for (int sg = 0; sg < NG / 4; ++sg) {
+                float4 b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b[u] = bnext[u];
+                if (sg + 1 < NG / 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) bnext[u] = load_bias(4 * (sg + 1) + u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = 4 * sg + u;
+                    float4 sc = tw[g];
+                    if constexpr (EXPL) {
+                        const uint4 x = c4[64 * g + lane];
+                        sc.x = __builtin_bit_cast(float, x.x) / tw[g].x;
+                        sc.y = __builtin_bit_cast(float, x.y) / tw[g].y;
+                        sc.z = __builtin_bit_cast(float, x.z) / tw[g].z;
+                        sc.w = __builtin_bit_cast(float, x.w) / tw[g].w;
+                    }
+                    if (item_bias) {  // item.py:282 (f32 add)
+                        sc.x = sc.x + b[u].x;
+                        sc.y = sc.y + b[u].y;
+                        sc.z = sc.z + b[u].z;
+                        sc.w = sc.w + b[u].w;
+                    }
+                    // (NaN cells: one bit pattern, the one the other kernels write)
+                    sc.x = sc.x != sc.x ? nanf_ : sc.x;
+                    sc.y = sc.y != sc.y ? nanf_ : sc.y;
+                    sc.z = sc.z != sc.z ? nanf_ : sc.z;
+                    sc.w = sc.w != sc.w ? nanf_ : sc.w;
+                    const int t0 = 256 * g + 4 * lane;
+                    if (FULL || t0 < wpad) *reinterpret_cast<float4 *>(prow + t0) = sc;
+                }
+            }
+        };
+        if (bias16 && wn == RW)
+            sweep(std::true_type{});
+        else
+            sweep(std::false_type{});
+        LK_RP_T(p7);
+        LK_RP_ADD(0, p0, p1);
+        LK_RP_ADD(1, p1, p2);
+        LK_RP_ADD(2, p2, p3);
+        LK_RP_ADD(3, p3, p4);
+        LK_RP_ADD(4, p4, p5);
+        LK_RP_ADD(5, p5, p6);
+        LK_RP_ADD(6, p6, p7);
+#ifdef LK_REC_PHASES
+        ph[7] += 1;
+#endif
+    }
+#ifdef LK_REC_PHASES
+    if (lane == 0 && lk_rec_phase_buf)
+        for (int i = 0; i < 8; ++i) atomicAdd(&lk_rec_phase_buf[i], ph[i]);
+#endif
+}
+
+// The hit list of a queued target (more than max_nbrs hits), for the replay kernel: one WAVE per
+// target walks the query's history 64 rows at a time; a lane looks its row's window piece up
+// (`woff`) and searches the target's column in it (rows are sorted by column); the hits of a step
+// are appended in lane order = history order.
+constexpr int GWAVES = 4;
+__global__ __launch_bounds__(GWAVES * 64) void iknn_heavy_gather_kernel(
+    const OvfEntry *__restrict__ ovf, const int *__restrict__ ovf_count, int ovf_cap,
+    const int64_t *__restrict__ s_ptr, const int32_t *__restrict__ s_idx,
+    const float *__restrict__ s_val, int64_t n_items, int nwin, const unsigned *__restrict__ woff,
+    int64_t q0, const int64_t *__restrict__ ref_ptr, const int32_t *__restrict__ ref_items,
+    const float *__restrict__ ref_rates, float2 *__restrict__ hits, int *__restrict__ status)
+{
+    int n = *ovf_count;
+    if (n > ovf_cap) n = ovf_cap;
+    const int lane = lane_id();
+    for (int i = blockIdx.x * GWAVES + (int)(threadIdx.x >> 6); i < n; i += (int)gridDim.x * GWAVES) {
+    const OvfEntry e = ovf[i];
+    const int64_t q = q0 + e.ql;
+    const int64_t rb = ref_ptr[q], re = ref_ptr[q + 1];
+    const int win = e.item / RW;
+    float2 *out = hits + e.list;
+    unsigned base = 0u;
+    for (int64_t r0 = rb; r0 < re; r0 += 64) {
+        bool found = false;
+        float w = 0.f, rate = 0.f;
+        if (r0 + lane < re) {
+            const int ri = ref_items[r0 + lane];
+            if (ri >= 0 && ri < n_items) {
+                const unsigned *wo = woff + (int64_t)ri * (nwin + 1) + win;
+                const int64_t b = s_ptr[ri];
+                int64_t lo = b + wo[0], hi = b + wo[1];
+                const int64_t end = hi;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (s_idx[mid] < e.item)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                if (lo < end && s_idx[lo] == e.item) {
+                    found = true;
+                    w = s_val[lo];
+                    if (ref_rates) rate = ref_rates[r0 + lane];
+                }
+            }
+        }
+        const unsigned long long m = __ballot(found);
+        if (found) {
+            const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (base + rank < (unsigned)e.cnt) out[base + rank] = float2{w, rate};
+        }
+        base += (unsigned)__popcll(m);
+    }
+    if (lane == 0 && base != (unsigned)e.cnt) atomicCAS(status, 0, 2);  // (an internal error)
+    }
+}
+
 // One LANE per queued target: the reference's accumulator replayed on a heap in LDS (slot-major:
 // hw[slot * 64 + lane]), the hit list streamed from the hits buffer.  Writes the panel cell.
 template <bool EXPL>
@@ -705,9 +1279,8 @@ __global__ __launch_bounds__(64) void iknn_heap_replay_kernel(
     extern __shared__ float heap_lds[];  // [2][(max_nbrs + 1)][64]
     int n = *ovf_count;
     if (n > ovf_cap) n = ovf_cap;
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
     const int lane = threadIdx.x;
+    for (int i = blockIdx.x * 64 + lane; i < n; i += (int)gridDim.x * 64) {  // (lanes diverge)
     const OvfEntry e = ovf[i];
     const float2 *l = hits + e.list;
     float *hw = heap_lds + lane, *hv = heap_lds + (size_t)(max_nbrs + 1) * 64 + lane;
@@ -771,6 +1344,7 @@ __global__ __launch_bounds__(64) void iknn_heap_replay_kernel(
     float score = EXPL ? ws / tw : tw;
     if (item_bias) score = score + item_bias[e.item];
     panel[(int64_t)e.ql * ld + e.item] = score;
+    }
 }
 
 // panel[q][own item] = NaN (candidates = all items minus the query's, candidates.py:77-94)
@@ -798,9 +1372,19 @@ static inline int nwindows(int64_t n_items) { return (int)((n_items + RW - 1) / 
 struct Layout {
     size_t off_status, off_woff, off_base, off_cursor, off_heap, off_ovf, off_panel, off_hits,
         off_sort, bytes;
-    int64_t rows, hit_cap;
+    int64_t rows, hit_cap, ovf_cap;
 };
 constexpr int REC_OVF_CAP = 1 << 20;  // queued heap targets per batch (more: HBM-scratch path)
+// the accumulating kernel queues EVERY target with more than max_nbrs hits (it keeps no lists to
+// fall back on): a query has at most min(n_items, hits / (max_nbrs + 1)) of them, the batches
+// are cut so that the sum stays inside the queue, and the queue is never longer than this
+constexpr int64_t REC_OVF_CAP_ACC = (int64_t)1 << 23;
+
+static inline int64_t heavy_bound(int64_t query_hits, int64_t n_items, int32_t max_nbrs)
+{
+    const int64_t b = query_hits / ((int64_t)max_nbrs + 1);
+    return b < n_items ? b : n_items;
+}
 
 static Layout layout(int64_t n_items, int64_t n_queries, int64_t max_query_hits, int32_t max_nbrs,
                      int32_t n)
@@ -842,8 +1426,15 @@ static Layout layout(int64_t n_items, int64_t n_queries, int64_t max_query_hits,
     L.off_heap = off;
     off += align_up((size_t)REC_MAX_WGS * RWAVES * 64 * (size_t)(max_nbrs + 1) * 2 * sizeof(float),
                     256);
+    {
+        const int64_t per = heavy_bound(max_query_hits, n_items, max_nbrs);
+        int64_t need = per * (n_queries < L.rows ? n_queries : L.rows);
+        if (need > REC_OVF_CAP_ACC) need = REC_OVF_CAP_ACC;
+        if (need < per) need = per;  // (a single query always fits)
+        L.ovf_cap = need > REC_OVF_CAP ? need : REC_OVF_CAP;
+    }
     L.off_ovf = off;
-    off += align_up((size_t)REC_OVF_CAP * sizeof(OvfEntry), 256);
+    off += align_up((size_t)L.ovf_cap * sizeof(OvfEntry), 256);
     L.off_panel = off;
     off += align_up((size_t)L.rows * ld_items(n_items) * sizeof(float), 256);
     L.off_hits = off;
@@ -866,8 +1457,9 @@ extern "C" int lk_rec_phase_set(unsigned long long *d_buf)
 #endif
 
 static int g_rec_last_packed = -1;
-// 1 / 0: the last lk_iknn_recommend call of this process took the packed / the piece-wise walk
-// (-1: none yet) -- test hook, like lk_knn_score_last_stats
+// 2 / 1 / 0: the last lk_iknn_recommend call of this process ran the accumulating kernel / the list
+// kernel with the packed walk / with the piece-wise walk (-1: none yet) -- test hook, like
+// lk_knn_score_last_stats
 extern "C" int lk_iknn_recommend_last_packed(void) { return g_rec_last_packed; }
 
 extern "C" size_t lk_iknn_recommend_workspace_bytes(int64_t n_items, int64_t n_queries,
@@ -920,30 +1512,6 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
     const int nwin = nwindows(n_items);
     const int64_t ld = ld_items(n_items);
 
-    // batches: at most L.rows queries and L.hit_cap hits each; a query's hit region starts at the
-    // sum of the hits of the batch's queries before it
-    std::vector<int64_t> base((size_t)n_queries);
-    std::vector<int64_t> cuts{0};
-    {
-        int64_t acc = 0, rows = 0;
-        for (int64_t q = 0; q < n_queries; ++q) {
-            LK_REQUIRE(h_query_hits[q] >= 0, "lk_iknn_recommend: negative hit count");
-            // (+ the rounding of every window's share to a 128-byte granule)
-            const int64_t h = h_query_hits[q] + 16 * (int64_t)nwin;
-            LK_REQUIRE(h <= L.hit_cap,
-                       "lk_iknn_recommend: query %lld has %lld hits, more than max_query_hits",
-                       (long long)q, (long long)h);
-            if (rows == L.rows || acc + h > L.hit_cap) {
-                cuts.push_back(q);
-                acc = 0;
-                rows = 0;
-            }
-            base[(size_t)q] = acc;
-            acc += h;
-            ++rows;
-        }
-        cuts.push_back(n_queries);
-    }
     LK_HIP_CHECK(hipMemsetAsync(status, 0, 256, st));
     // the packed walk needs same-address LDS atomics of one instruction served in lane order:
     // probed once per device (status[3] is free until the first batch); LK_REC_PACKED=0: never
@@ -967,7 +1535,63 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
             packed = good;
         }
     }
-    g_rec_last_packed = packed ? 1 : 0;
+    // the accumulating kernel (round 6) needs the packed walk and, besides, same-address ds_add_f32s
+    // applied in lane order with the VALU's rounding: probed once per device as well; LK_REC_ACC=0:
+    // the list kernel
+    bool acc_kernel = false;
+    if (packed) {
+        static PerDeviceOnce fprobed, fadd_order;
+        const char *e = getenv("LK_REC_ACC");
+        if (!(e && e[0] == '0')) {
+            bool &done = fprobed.flag();
+            bool &good = fadd_order.flag();
+            if (!done) {
+                int one = 1, got = 0;
+                LK_HIP_CHECK(hipMemcpyAsync(status + 3, &one, sizeof(int), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(lds_fadd_order_probe_kernel, dim3(1), dim3(64), 0, st, status + 3);
+                LK_HIP_CHECK(hipMemcpyAsync(&got, status + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+                LK_HIP_CHECK(hipStreamSynchronize(st));
+                good = got == 1;
+                done = true;
+                LK_HIP_CHECK(hipMemsetAsync(status + 3, 0, sizeof(int), st));
+            }
+            acc_kernel = good;
+        }
+    }
+    g_rec_last_packed = acc_kernel ? 2 : (packed ? 1 : 0);
+
+    // batches: at most L.rows queries and L.hit_cap hits each; a query's hit region starts at the
+    // sum of the hits of the batch's queries before it (the list kernel; the accumulating kernel
+    // keeps lists of its queued targets only, anywhere in the region).  Accumulating kernel: the
+    // queue of targets beyond max_nbrs hits holds every such target a batch can have
+    std::vector<int64_t> base((size_t)n_queries);
+    std::vector<int64_t> cuts{0};
+    std::vector<int64_t> heavy_of_batch;
+    {
+        int64_t acc = 0, rows = 0, hv = 0;
+        for (int64_t q = 0; q < n_queries; ++q) {
+            LK_REQUIRE(h_query_hits[q] >= 0, "lk_iknn_recommend: negative hit count");
+            // (+ the rounding of every window's share to a 128-byte granule)
+            const int64_t h = h_query_hits[q] + 16 * (int64_t)nwin;
+            LK_REQUIRE(h <= L.hit_cap,
+                       "lk_iknn_recommend: query %lld has %lld hits, more than max_query_hits",
+                       (long long)q, (long long)h);
+            const int64_t hb = heavy_bound(h_query_hits[q], n_items, max_nbrs);
+            if (rows == L.rows || acc + h > L.hit_cap || (acc_kernel && hv + hb > L.ovf_cap)) {
+                cuts.push_back(q);
+                heavy_of_batch.push_back(hv);
+                acc = 0;
+                rows = 0;
+                hv = 0;
+            }
+            base[(size_t)q] = acc;
+            acc += h;
+            hv += hb;
+            ++rows;
+        }
+        cuts.push_back(n_queries);
+        heavy_of_batch.push_back(hv);
+    }
     LK_HIP_CHECK(hipMemcpyAsync(q_base, base.data(), (size_t)n_queries * sizeof(int64_t),
                                 hipMemcpyHostToDevice, st));
     LK_HIP_CHECK(hipStreamSynchronize(st));  // `base` is host memory that dies with this call
@@ -981,10 +1605,53 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
         const int64_t q0 = cuts[b], nq = cuts[b + 1] - cuts[b];
         if (nq <= 0) continue;
         if (n_items > 0) {
-            LK_HIP_CHECK(hipMemsetAsync(status + 1, 0, 2 * sizeof(int), st));  // tasks, queue
+            // tasks [1], queue length [2], (free [3]), the queued lists' cursor [4..5]
+            LK_HIP_CHECK(hipMemsetAsync(status + 1, 0, 5 * sizeof(int), st));
             const int64_t tasks = nq * nwin;
             int64_t wgs = (tasks + RWAVES - 1) / RWAVES;
             if (wgs > REC_MAX_WGS) wgs = REC_MAX_WGS;
+            if (acc_kernel) {
+                const int64_t hvb = heavy_of_batch[b] < L.ovf_cap ? heavy_of_batch[b] : L.ovf_cap;
+                auto *list_cursor = reinterpret_cast<unsigned long long *>(status + 4);
+#define LK_REC_ACC_LAUNCH(EXPLV)                                                                   \
+    hipLaunchKernelGGL((iknn_score_acc_kernel<EXPLV>), dim3((unsigned)wgs), dim3(RTHREADS), 0, st, \
+                       d_sim_indptr, d_sim_indices, d_sim_values, n_items, nwin, woff, q0, nq,      \
+                       d_ref_ptr, d_ref_items, d_ref_rates, d_item_bias, max_nbrs, min_nbrs, panel, \
+                       ld, status + 1, status, ovf, (int)L.ovf_cap, status + 2, list_cursor)
+                if (d_ref_rates)
+                    LK_REC_ACC_LAUNCH(true);
+                else
+                    LK_REC_ACC_LAUNCH(false);
+#undef LK_REC_ACC_LAUNCH
+                if (hvb > 0) {
+                    LK_REQUIRE(lds_replay, "lk_iknn_recommend: max_nbrs = %d is beyond the replay "
+                               "kernel's LDS heaps (LK_REC_ACC=0 takes the list kernel)", max_nbrs);
+                    if (heap_lds > 64 * 1024) {
+                        LK_HIP_CHECK(hipFuncSetAttribute(
+                            reinterpret_cast<const void *>(&iknn_heap_replay_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds));
+                        LK_HIP_CHECK(hipFuncSetAttribute(
+                            reinterpret_cast<const void *>(&iknn_heap_replay_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds));
+                    }
+                    int64_t gw = (hvb + GWAVES - 1) / GWAVES;
+                    if (gw > 16384) gw = 16384;
+                    hipLaunchKernelGGL(iknn_heavy_gather_kernel, dim3((unsigned)gw), dim3(GWAVES * 64),
+                                       0, st, ovf, status + 2, (int)L.ovf_cap, d_sim_indptr,
+                                       d_sim_indices, d_sim_values, n_items, nwin, woff, q0, d_ref_ptr,
+                                       d_ref_items, d_ref_rates, hits, status);
+                    int64_t gr = (hvb + 63) / 64;
+                    if (gr > 16384) gr = 16384;
+                    if (d_ref_rates)
+                        hipLaunchKernelGGL((iknn_heap_replay_kernel<true>), dim3((unsigned)gr),
+                                           dim3(64), heap_lds, st, ovf, status + 2, (int)L.ovf_cap,
+                                           hits, d_item_bias, max_nbrs, panel, ld);
+                    else
+                        hipLaunchKernelGGL((iknn_heap_replay_kernel<false>), dim3((unsigned)gr),
+                                           dim3(64), heap_lds, st, ovf, status + 2, (int)L.ovf_cap,
+                                           hits, d_item_bias, max_nbrs, panel, ld);
+                }
+            } else {
 #define LK_REC_LAUNCH(EXPLV)                                                                      \
     do {                                                                                          \
     if (packed)                                                                                   \
@@ -1017,6 +1684,7 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
             else
                 LK_REC_LAUNCH(false);
 #undef LK_REC_LAUNCH
+            }
             if (exclude_refs)
                 hipLaunchKernelGGL(mask_refs_kernel, dim3((unsigned)nq), dim3(64), 0, st, d_ref_ptr,
                                    d_ref_items, q0, nq, n_items, panel, ld);
@@ -1029,6 +1697,10 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
     int h = 0;
     LK_HIP_CHECK(hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, st));
     LK_HIP_CHECK(hipStreamSynchronize(st));
+    if (h == 2) {
+        set_error("lk_iknn_recommend: internal error (queue of heap targets / a gathered list)");
+        return LK_E_INVALID;
+    }
     if (h != 0) {
         set_error("similarity is null");  // accum.rs:146-151 -> ValueError
         return LK_E_NAN_SIM;

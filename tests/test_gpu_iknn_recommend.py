@@ -68,24 +68,29 @@ def _check(gi, gs, wi, ws, rows, ptr, idx):
     return ties
 
 
-@pytest.mark.parametrize("walk", ["packed", "pieces", "packed-small-panel"])
+@pytest.mark.parametrize("walk", ["acc", "packed", "pieces", "acc-small-panel"])
 @pytest.mark.parametrize("explicit", [True, False])
 @pytest.mark.parametrize("save_nbrs,max_nbrs,n", [(50, 20, 10), (None, 5, 100), (None, 64, 30)])
 def test_recommend_matches_the_reference_pipeline(gpu, oracle, monkeypatch, walk, explicit,
                                                   save_nbrs, max_nbrs, n):
-    """Both walks of the similarity rows (round 5: the (row x window) pieces PACKED 64 entries to
-    the instruction -- relies on same-address LDS atomics of one instruction being served in lane
-    order, probed on the device -- and the piece-by-piece walk it falls back to): the same bits."""
+    """The three kernels behind ``lk_iknn_recommend`` give the same bits: the ACCUMULATING kernel
+    (round 6, the default: every weight is added to its target's LDS cell by ``ds_add_f32`` --
+    same-address adds of an instruction applied in lane order, probed on the device --, targets
+    beyond ``max_nbrs`` hits gathered and replayed by their own kernels), the list kernel with the
+    (row x window) pieces PACKED 64 entries to the instruction (round 5; ``LK_REC_ACC=0``), and the
+    piece-by-piece walk that one falls back to (``LK_REC_PACKED=0``)."""
     from lkpy_amd import _device as D
     from lkpy_amd import _native
 
     if walk == "pieces":
         monkeypatch.setenv("LK_REC_PACKED", "0")
+    if walk == "packed":
+        monkeypatch.setenv("LK_REC_ACC", "0")
     if walk.endswith("small-panel"):
         # the score panel's byte budget (LK_REC_PANEL_GB; round 6): so small here that the 124
         # queries go through in two batches of 64 rows -- the same lists
         monkeypatch.setenv("LK_REC_PANEL_GB", "0.000001")
-        walk = "packed"
+        walk = "acc"
 
     rng = np.random.default_rng(7)
     n_users, n_items = 600, 9001  # three windows of 4096, the last one partial
@@ -104,8 +109,9 @@ def test_recommend_matches_the_reference_pipeline(gpu, oracle, monkeypatch, walk
                               _to(val, gpu) if explicit else None,
                               _to(means, gpu) if explicit else None, max_nbrs, 2, n, hits)
     gi, gs = gi.cpu().numpy(), gs.cpu().numpy()
-    # the probe of the LDS atomic order must pass on an MI355X: the packed walk is the product path
-    assert _native.load().lk_iknn_recommend_last_packed() == (1 if walk == "packed" else 0)
+    # the probes of the LDS atomic order must pass on an MI355X: the accumulating kernel is the
+    # product path
+    assert _native.load().lk_iknn_recommend_last_packed() == {"acc": 2, "packed": 1, "pieces": 0}[walk]
     wi, ws, rows = oracle.iknn_recommend_batch(sims, ptr, idx, val if explicit else None,
                                                means if explicit else None, max_nbrs, 2, n)
     ties = _check(gi, gs, wi, ws, rows, ptr, idx)
