@@ -50,7 +50,8 @@ namespace lk {
 // selection over a score panel (topk.hip)
 size_t panel_topn_workspace_bytes(int64_t rows, int64_t n_items, int32_t n);
 int panel_topn(const float *panel, int64_t ld_s, int64_t rows, int64_t n_items, int32_t n,
-               void *sort_ws, int32_t *out_idx, float *out_score, hipStream_t st);
+               void *sort_ws, int32_t *out_idx, float *out_score, hipStream_t st,
+               const unsigned *class_max = nullptr, int classes_per_row = 0);
 
 namespace rec {
 
@@ -75,7 +76,11 @@ __device__ __forceinline__ int cidx(int t) { return t + t / TPL; }
 // [5] score sweep, [6] copy-out, [7] tasks
 __device__ unsigned long long *lk_rec_phase_buf;
 #define LK_RP_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#ifdef LK_REC_WALKPH  // (the slots hold walk_acc's inner phases instead: a one-off diagnostic)
+#define LK_RP_ADD(i, a, b) (void)(a)
+#else
 #define LK_RP_ADD(i, a, b) ph[i] += (b) - (a)
+#endif
 #else
 #define LK_RP_T(var)
 #define LK_RP_ADD(i, a, b)
@@ -430,14 +435,40 @@ __device__ __forceinline__ DescCache cache_set(DescCache dc, int k, const ChunkD
     return dc;
 }
 
+// inclusive scan over the 64 lanes in six DPP adds (row_shr 1, 2, 4, 8 inside the rows of 16,
+// row_bcast 15 / 31 across them) -- `__shfl_up` is a ds_bpermute per step: six trips through the
+// LDS queue, the busiest unit of this kernel
+__device__ __forceinline__ unsigned wave_incl_scan_dpp(unsigned x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return (unsigned)v;
+}
+
 template <int MODE, bool EXPL, int CACHE>
 __device__ __forceinline__ DescCache walk_acc(
     unsigned *__restrict__ c, unsigned *__restrict__ dsc, const int64_t *__restrict__ s_ptr,
     const int32_t *__restrict__ s_idx, const float *__restrict__ s_val,
     const unsigned *__restrict__ woff, int nwin, int win, int64_t n_items,
     const int32_t *__restrict__ ref_items, const float *__restrict__ ref_rates, int64_t rb,
-    int64_t re, int *__restrict__ status, int lane, DescCache dc)
+    int64_t re, int *__restrict__ status, int lane, DescCache dc, bool mark_own
+#ifdef LK_REC_WALKPH
+    , unsigned long long *wph
+#endif
+    )
 {
+#ifdef LK_REC_WALKPH
+#define WPH_T(v) unsigned long long v = 0; if (MODE == WALK_ADD_W) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"); v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)"); }
+#define WPH_ADD(i, a, b) if (MODE == WALK_ADD_W) wph[i] += (b) - (a)
+#else
+#define WPH_T(v)
+#define WPH_ADD(i, a, b)
+#endif
     static_assert(MODE != WALK_FILL, "the accumulating kernel keeps no lists");
     const int w0 = win * RW;
     // wave-private LDS: [0..127] (piece address - first position) of the rows with entries, by
@@ -456,6 +487,10 @@ __device__ __forceinline__ DescCache walk_acc(
     };
     auto load_desc = [&](int ri, float rate) {
         ChunkDesc d{0, 0, rate};
+        // (the counting walk also MARKS the query's own items of this window -- bit 31 of the
+        // count cell: never scored, never queued; candidates.py:77-94)
+        if (MODE == WALK_COUNT && mark_own && ri >= w0 && ri < w0 + RW)
+            atomicOr(&c[ri - w0], 0x80000000u);
         if (ri >= 0 && ri < n_items) {  // null reference rows are skipped (item_score.rs:38-49)
             const unsigned *wo = woff + (int64_t)ri * (nwin + 1) + win;
             const unsigned o0 = wo[0], o1 = wo[1];
@@ -464,6 +499,7 @@ __device__ __forceinline__ DescCache walk_acc(
         }
         return d;
     };
+    bool nan_seen = false;
     ChunkDesc cur{0, 0, 0.f};
     int ri1 = -1;
     float rt1 = 0.f;
@@ -479,6 +515,7 @@ __device__ __forceinline__ DescCache walk_acc(
     }
     int k = 0;
     for (int64_t r0 = rb; r0 < re; r0 += 64, ++k) {
+        WPH_T(w0_);
         ChunkDesc nxt{0, 0, 0.f};
         int ri2 = -1;
         float rt2 = 0.f;
@@ -491,12 +528,7 @@ __device__ __forceinline__ DescCache walk_acc(
         if (r0 + 128 < re && !(CACHE == 2 && k + 2 < KC)) load_row(r0 + 128, ri2, rt2);
         if (CACHE == 1 && k < KC) dc = cache_set(dc, k, cur);
         const int n = cur.n;
-        unsigned incl = (unsigned)n;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-        }
+        const unsigned incl = wave_incl_scan_dpp((unsigned)n);
         const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
         // The row of stream position p.  The list kernel's walk finds it by a 6-step binary search
         // over the prefixes (six dependent LDS reads per 64 entries); here the rows WITH entries are
@@ -534,8 +566,11 @@ __device__ __forceinline__ DescCache walk_acc(
                 atomicOr(&d_bm[sx >> 5], 1u << (sx & 31u));  // ds_or_b32, no return
             }
             wave_lds_sync();
+            WPH_T(w1_);
+            WPH_ADD(0, w0_, w1_);
             unsigned before = 0u;  // ones at positions < the batch's start
             for (unsigned p0 = 0; p0 < sub_total; p0 += 64u * RDP) {
+                WPH_T(w2_);
                 int t_[RDP];
                 float s_[RDP], r_[RDP];
                 bool live_[RDP];
@@ -563,20 +598,29 @@ __device__ __forceinline__ DescCache walk_acc(
                     if (MODE != WALK_COUNT) s_[d] = s_val[e];
                     if (MODE == WALK_ADD_WV) r_[d] = d_rt[rk];
                 }
+                WPH_T(w3_);
 #pragma unroll
                 for (int d = 0; d < RDP; ++d) {
                     if (p0 + 64u * d >= sub_total) break;  // (wave-uniform)
+                    // (lanes past the end are masked, not given a dummy cell: the LDS serves atomics
+                    // at about a lane per clock, so an idle lane is time saved)
                     if (live_[d]) {
                         if (MODE == WALK_COUNT) {
                             atomicAdd(&c[t_[d]], 1u);  // ds_add_u32, no return
                         } else if (MODE == WALK_ADD_W) {
-                            if (s_[d] != s_[d]) atomicCAS(status, 0, 1);  // accum.rs:146-151
+                            nan_seen |= s_[d] != s_[d];  // accum.rs:146-151
                             lds_fadd(&c[t_[d]], s_[d]);  // lane order
                         } else {
                             lds_fadd(&c[t_[d]], s_[d] * r_[d]);  // product rounded, then added
                         }
                     }
                 }
+                WPH_T(w4_);
+                WPH_ADD(1, w2_, w3_);
+                WPH_ADD(2, w3_, w4_);
+#ifdef LK_REC_WALKPH
+                if (MODE == WALK_ADD_W) wph[4] += 1;
+#endif
             }
             done_pos = sub_end;
             j0 = j1;
@@ -584,6 +628,12 @@ __device__ __forceinline__ DescCache walk_acc(
         cur = nxt;
         ri1 = ri2;
         rt1 = rt2;
+#ifdef LK_REC_WALKPH
+        if (MODE == WALK_ADD_W) wph[3] += 1;
+#endif
+    }
+    if (MODE == WALK_ADD_W && __ballot(nan_seen) != 0ull) {
+        if (lane == 0) atomicCAS(status, 0, 1);  // "similarity is null" (accum.rs:146-151)
     }
     return dc;
 }
@@ -996,7 +1046,8 @@ void iknn_score_acc_kernel(
     const float *__restrict__ item_bias, int max_nbrs, int min_nbrs, float *__restrict__ panel,
     int64_t ld, int *__restrict__ task_counter, int *__restrict__ status,
     OvfEntry *__restrict__ ovf, int ovf_cap, int *__restrict__ ovf_count,
-    unsigned long long *__restrict__ list_cursor)
+    unsigned long long *__restrict__ list_cursor, int exclude_refs,
+    unsigned *__restrict__ premax)
 {
     // one cell per target, no padding: the sweeps move FOUR cells per LDS instruction (lane l owns
     // targets 256 g + 4 l + j) -- with two waves per SIMD a task's time is its instruction count
@@ -1038,8 +1089,12 @@ void iknn_score_acc_kernel(
         const int wpad = (int)((ld - w0) < RW ? (ld - w0) : RW);  // (the row's padding: whole quads)
         const int64_t rb = ref_ptr[q], re = ref_ptr[q + 1];
         float *prow = panel + ql * ld + w0;
+        // the window's 64 class maxima (lane l: targets 256 g + 4 l + j) for the selection kernel:
+        // order-preserving keys, 0 = nothing valid
+        unsigned *pmax = premax ? premax + ((int64_t)ql * nwin + win) * 64 : nullptr;
         if (re == rb) {  // no history: nothing is scored (item.py:238-245)
             for (int i = lane; i < wn; i += 64) prow[i] = nanf_;
+            if (pmax) pmax[lane] = 0u;
             continue;
         }
         LK_RP_T(p1);
@@ -1050,7 +1105,11 @@ void iknn_score_acc_kernel(
         // ---- walk 1: hits per target --------------------------------------------------------
         const DescCache dc = walk_acc<WALK_COUNT, EXPL, 1>(
             c, dsc, s_ptr, s_idx, s_val, woff, nwin, win, n_items, ref_items, ref_rates, rb, re,
-            status, lane, DescCache{0, 0, 0, 0, 0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f});
+            status, lane, DescCache{0, 0, 0, 0, 0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f}, exclude_refs != 0
+#ifdef LK_REC_WALKPH
+            , ph
+#endif
+            );
         wave_lds_sync();
         LK_RP_T(p3);
 
@@ -1063,10 +1122,16 @@ void iknn_score_acc_kernel(
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 cn[g] = c4[64 * g + lane];
+                // (bit 31: an own item of the query -- as good as no hit)
+                cn[g].x = (int)cn[g].x < 0 ? 0u : cn[g].x;
+                cn[g].y = (int)cn[g].y < 0 ? 0u : cn[g].y;
+                cn[g].z = (int)cn[g].z < 0 ? 0u : cn[g].z;
+                cn[g].w = (int)cn[g].w < 0 ? 0u : cn[g].w;
                 mx = max(max(mx, max(cn[g].x, cn[g].y)), max(cn[g].z, cn[g].w));
             }
             if (__ballot(mx != 0u) == 0ull) {  // no hit in this window
                 for (int i = lane; i < wn; i += 64) prow[i] = nanf_;
+                if (pmax) pmax[lane] = 0u;
                 continue;
             }
             // Full(heap) targets (rare): the list is built by iknn_heavy_gather_kernel and replayed
@@ -1106,7 +1171,11 @@ void iknn_score_acc_kernel(
 
         // ---- walk 2: total weights, in history order by construction ------------------------------
         (void)walk_acc<WALK_ADD_W, EXPL, 2>(c, dsc, s_ptr, s_idx, s_val, woff, nwin, win, n_items,
-                                            ref_items, ref_rates, rb, re, status, lane, dc);
+                                            ref_items, ref_rates, rb, re, status, lane, dc, false
+#ifdef LK_REC_WALKPH
+                                            , ph
+#endif
+                                            );
         wave_lds_sync();
         LK_RP_T(p5);
         float4 tw[NG];
@@ -1123,7 +1192,11 @@ void iknn_score_acc_kernel(
             // ---- walk 3: weighted sums ------------------------------------------------------------
             (void)walk_acc<WALK_ADD_WV, EXPL, 2>(c, dsc, s_ptr, s_idx, s_val, woff, nwin, win,
                                                  n_items, ref_items, ref_rates, rb, re, status, lane,
-                                                 dc);
+                                                 dc, false
+#ifdef LK_REC_WALKPH
+                                                 , ph
+#endif
+                                                 );
             wave_lds_sync();
         }
         LK_RP_T(p6);
@@ -1150,6 +1223,7 @@ void iknn_score_acc_kernel(
                 }
                 return b;
             };
+            float best = nanf_;  // fmaxf(NaN, x) = x: stays NaN while nothing valid was seen
             float4 bnext[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) bnext[u] = load_bias(u);
@@ -1186,8 +1260,11 @@ void iknn_score_acc_kernel(
                     sc.w = sc.w != sc.w ? nanf_ : sc.w;
                     const int t0 = 256 * g + 4 * lane;
                     if (FULL || t0 < wpad) *reinterpret_cast<float4 *>(prow + t0) = sc;
+                    best = __builtin_fmaxf(__builtin_fmaxf(best, sc.x), __builtin_fmaxf(sc.y, sc.z));
+                    best = __builtin_fmaxf(best, sc.w);
                 }
             }
+            if (pmax) pmax[lane] = best == best ? f2key(best) : 0u;
         };
         if (bias16 && wn == RW)
             sweep(std::true_type{});
@@ -1233,36 +1310,72 @@ __global__ __launch_bounds__(GWAVES * 64) void iknn_heavy_gather_kernel(
     const int win = e.item / RW;
     float2 *out = hits + e.list;
     unsigned base = 0u;
-    for (int64_t r0 = rb; r0 < re; r0 += 64) {
-        bool found = false;
-        float w = 0.f, rate = 0.f;
-        if (r0 + lane < re) {
-            const int ri = ref_items[r0 + lane];
-            if (ri >= 0 && ri < n_items) {
-                const unsigned *wo = woff + (int64_t)ri * (nwin + 1) + win;
-                const int64_t b = s_ptr[ri];
-                int64_t lo = b + wo[0], hi = b + wo[1];
-                const int64_t end = hi;
-                while (lo < hi) {
-                    const int64_t mid = (lo + hi) >> 1;
-                    if (s_idx[mid] < e.item)
-                        lo = mid + 1;
+    // four 64-row steps at a time: their chains of dependent loads (history row -> window offsets
+    // and row start -> the search's probes -> the weight) run side by side
+    constexpr int GU = 4;
+    for (int64_t r0 = rb; r0 < re; r0 += 64 * GU) {
+        int ri[GU];
+        int64_t lo[GU], hi[GU], end[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int64_t r = r0 + 64 * u + lane;
+            ri[u] = ref_items[r < re ? r : re - 1];
+            if (!(r < re)) ri[u] = -1;
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const bool ok = ri[u] >= 0 && ri[u] < n_items;
+            const int rr = ok ? ri[u] : 0;
+            const unsigned *wo = woff + (int64_t)rr * (nwin + 1) + win;
+            const int64_t b = s_ptr[rr];
+            lo[u] = b + wo[0];
+            hi[u] = end[u] = b + wo[1];
+            if (!ok) hi[u] = end[u] = lo[u];
+        }
+        // lower bound of the target's column in each piece (rows are sorted by column); the four
+        // searches advance together
+        for (;;) {
+            bool any = false;
+            int64_t mid[GU];
+            int col[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                mid[u] = (lo[u] + hi[u]) >> 1;
+                col[u] = s_idx[lo[u] < hi[u] ? mid[u] : 0];  // (unconditional loads: no branch, one wait)
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                if (lo[u] < hi[u]) {
+                    if (col[u] < e.item)
+                        lo[u] = mid[u] + 1;
                     else
-                        hi = mid;
-                }
-                if (lo < end && s_idx[lo] == e.item) {
-                    found = true;
-                    w = s_val[lo];
-                    if (ref_rates) rate = ref_rates[r0 + lane];
+                        hi[u] = mid[u];
+                    any = any || lo[u] < hi[u];
                 }
             }
+            if (__ballot(any) == 0ull) break;
         }
-        const unsigned long long m = __ballot(found);
-        if (found) {
-            const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-            if (base + rank < (unsigned)e.cnt) out[base + rank] = float2{w, rate};
+        int colf[GU];
+        float w[GU], rate[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int64_t at = lo[u] < end[u] ? lo[u] : 0;
+            colf[u] = s_idx[at];
+            w[u] = s_val[at];
+            if (!(lo[u] < end[u])) colf[u] = -1;
+            const int64_t r = r0 + 64 * u + lane;
+            rate[u] = ref_rates ? ref_rates[r < re ? r : re - 1] : 0.f;
         }
-        base += (unsigned)__popcll(m);
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const bool found = colf[u] == e.item;
+            const unsigned long long m = __ballot(found);
+            if (found) {
+                const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                if (base + rank < (unsigned)e.cnt) out[base + rank] = float2{w[u], rate[u]};
+            }
+            base += (unsigned)__popcll(m);
+        }
     }
     if (lane == 0 && base != (unsigned)e.cnt) atomicCAS(status, 0, 2);  // (an internal error)
     }
@@ -1280,41 +1393,42 @@ __global__ __launch_bounds__(64) void iknn_heap_replay_kernel(
     int n = *ovf_count;
     if (n > ovf_cap) n = ovf_cap;
     const int lane = threadIdx.x;
-    for (int i = blockIdx.x * 64 + lane; i < n; i += (int)gridDim.x * 64) {  // (lanes diverge)
-    const OvfEntry e = ovf[i];
-    const float2 *l = hits + e.list;
-    float *hw = heap_lds + lane, *hv = heap_lds + (size_t)(max_nbrs + 1) * 64 + lane;
-    auto W = [&](int s) -> float & { return hw[s * 64]; };
-    auto V = [&](int s) -> float & { return hv[s * 64]; };
-    auto sift_up = [&](int pos, float ew, float ev) {
-        while (pos > 0) {
-            const int parent = (pos - 1) >> 1;
-            if (ew >= W(parent)) break;
-            W(pos) = W(parent);
-            V(pos) = V(parent);
-            pos = parent;
-        }
-        W(pos) = ew;
-        V(pos) = ev;
-    };
-    // Partial -> Full (accum.rs:76-83): vec.pop() from the back, push each
-    for (int x = 0; x < max_nbrs; ++x) {
-        const float2 h = l[max_nbrs - 1 - x];
-        W(x) = h.x;
-        V(x) = h.y;
-    }
-    for (int kk = 1; kk < max_nbrs; ++kk) sift_up(kk, W(kk), V(kk));
-    float wmin = W(0);
-    for (int x0 = max_nbrs; x0 < e.cnt; x0 += 4) {
-        float2 h[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) h[u] = l[x0 + u < e.cnt ? x0 + u : e.cnt - 1];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (x0 + u < e.cnt && h[u].x > wmin) {  // strictly greater than the minimum
-                // push (sift_up(0, len)), then pop: swap the last element into the root,
-                // sift_down_to_bottom(0), sift_up -- std's BinaryHeap, as in iknn_score.hip
-                sift_up(max_nbrs, h[u].x, h[u].y);
+    // Targets per wave: the lanes of a wave run in lockstep through loops whose trip counts differ
+    // from target to target, and every step waits for its hits to arrive from HBM.  While there
+    // are fewer targets than waves (2 276 in the heaviest cfg3 batch), a wave takes ONE target:
+    // its 64 lanes fetch the next 64 hits together (one coalesced request, the one after it
+    // already in flight) and lane 0 replays them from the registers (`v_readlane`) -- the chain
+    // of a 7 817-hit target waits for 122 requests instead of 1 950.
+    const int waves = (int)gridDim.x;
+    int tpw = (n + waves - 1) / waves;
+    tpw = tpw < 1 ? 1 : (tpw > 64 ? 64 : tpw);
+    const bool solo = tpw == 1;  // (kernel-uniform)
+    for (int i0 = blockIdx.x * tpw; i0 < n; i0 += waves * tpw) {
+        const int i = solo ? i0 : i0 + lane;
+        const bool mine = solo ? lane == 0 : (lane < tpw && i < n);  // this lane replays a target
+        const OvfEntry e = ovf[i < n ? i : n - 1];
+        const float2 *l = hits + e.list;
+        float *hw = heap_lds + lane, *hv = heap_lds + (size_t)(max_nbrs + 1) * 64 + lane;
+        auto W = [&](int s) -> float & { return hw[s * 64]; };
+        auto V = [&](int s) -> float & { return hv[s * 64]; };
+        auto sift_up = [&](int pos, float ew, float ev) {
+            while (pos > 0) {
+                const int parent = (pos - 1) >> 1;
+                if (ew >= W(parent)) break;
+                W(pos) = W(parent);
+                V(pos) = V(parent);
+                pos = parent;
+            }
+            W(pos) = ew;
+            V(pos) = ev;
+        };
+        // one hit offered to the full heap (accum.rs:100-118): strictly greater than the minimum
+        // -> push (sift_up(0, len)), then pop: swap the last element into the root,
+        // sift_down_to_bottom(0), sift_up -- std's BinaryHeap, as in iknn_score.hip
+        float wmin = 0.f;
+        auto offer = [&](float hx, float hy) {
+            if (hx > wmin) {
+                sift_up(max_nbrs, hx, hy);
                 const float ew = W(max_nbrs), ev = V(max_nbrs);
                 const int end = max_nbrs;
                 int pos = 0, child = 1;
@@ -1334,16 +1448,56 @@ __global__ __launch_bounds__(64) void iknn_heap_replay_kernel(
                 sift_up(pos, ew, ev);
                 wmin = W(0);
             }
+        };
+        if (mine) {
+            // Partial -> Full (accum.rs:76-83): vec.pop() from the back, push each
+            for (int x = 0; x < max_nbrs; ++x) {
+                const float2 h = l[max_nbrs - 1 - x];
+                W(x) = h.x;
+                V(x) = h.y;
+            }
+            for (int kk = 1; kk < max_nbrs; ++kk) sift_up(kk, W(kk), V(kk));
+            wmin = W(0);
         }
-    }
-    float tw = 0.f, ws = 0.f;
-    for (int x = 0; x < max_nbrs; ++x) {
-        tw += W(x);
-        if (EXPL) ws += W(x) * V(x);
-    }
-    float score = EXPL ? ws / tw : tw;
-    if (item_bias) score = score + item_bias[e.item];
-    panel[(int64_t)e.ql * ld + e.item] = score;
+        if (solo) {
+            const int cnt = e.cnt;  // (wave-uniform: every lane read the same entry)
+            auto fetch = [&](int x0) {
+                const int x = x0 + lane;
+                return l[x < cnt ? x : cnt - 1];
+            };
+            float2 nxt = fetch(max_nbrs);
+            for (int x0 = max_nbrs; x0 < cnt; x0 += 64) {
+                const float2 cur = nxt;
+                if (x0 + 64 < cnt) nxt = fetch(x0 + 64);
+                const int m = cnt - x0 < 64 ? cnt - x0 : 64;
+                for (int j = 0; j < m; ++j) {
+                    const float hx = __builtin_bit_cast(
+                        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.x), j));
+                    const float hy = __builtin_bit_cast(
+                        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.y), j));
+                    if (mine) offer(hx, hy);
+                }
+            }
+        } else if (mine) {
+            for (int x0 = max_nbrs; x0 < e.cnt; x0 += 4) {
+                float2 h[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) h[u] = l[x0 + u < e.cnt ? x0 + u : e.cnt - 1];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (x0 + u < e.cnt) offer(h[u].x, h[u].y);
+            }
+        }
+        if (mine) {
+            float tw = 0.f, ws = 0.f;
+            for (int x = 0; x < max_nbrs; ++x) {
+                tw += W(x);
+                if (EXPL) ws += W(x) * V(x);
+            }
+            float score = EXPL ? ws / tw : tw;
+            if (item_bias) score = score + item_bias[e.item];
+            panel[(int64_t)e.ql * ld + e.item] = score;
+        }
     }
 }
 
@@ -1371,8 +1525,10 @@ static inline int nwindows(int64_t n_items) { return (int)((n_items + RW - 1) / 
 
 struct Layout {
     size_t off_status, off_woff, off_base, off_cursor, off_heap, off_ovf, off_panel, off_hits,
-        off_sort, bytes;
+        off_sort, off_pmax, bytes, panel_bytes, ovf_bytes, pmax_bytes;
     int64_t rows, hit_cap, ovf_cap;
+    int sets;  // 2: a second score panel and target queue -- batch b + 1 is scored while batch b's
+               // panel is still being replayed into / masked / selected from (accumulating kernel)
 };
 constexpr int REC_OVF_CAP = 1 << 20;  // queued heap targets per batch (more: HBM-scratch path)
 // the accumulating kernel queues EVERY target with more than max_nbrs hits (it keeps no lists to
@@ -1403,9 +1559,12 @@ static Layout layout(int64_t n_items, int64_t n_queries, int64_t max_query_hits,
         const char *e = getenv("LK_REC_PANEL_GB");
         const double gb = e && atof(e) > 0 ? atof(e) : 8.0;
         int64_t fit = (int64_t)(gb * (double)(1ull << 30) / ((double)ld_items(n_items) * 4.0));
+        // (more queries than one budget's rows: two panels of half the budget)
+        if (n_queries > fit || n_queries > panel_rows) fit /= 2;
         if (fit < 64) fit = 64;
         if (L.rows > fit) L.rows = fit;
     }
+    L.sets = n_queries > L.rows ? 2 : 1;
     // a batch holds up to REC_HITS_MIN hits (never less than the heaviest query's; a small call
     // does not pay for more than all of its queries could need)
     // (a query's region = its hits + 16 per window: every window's share is rounded up to a
@@ -1434,13 +1593,20 @@ static Layout layout(int64_t n_items, int64_t n_queries, int64_t max_query_hits,
         L.ovf_cap = need > REC_OVF_CAP ? need : REC_OVF_CAP;
     }
     L.off_ovf = off;
-    off += align_up((size_t)L.ovf_cap * sizeof(OvfEntry), 256);
+    L.ovf_bytes = align_up((size_t)L.ovf_cap * sizeof(OvfEntry), 256);
+    off += L.ovf_bytes * (size_t)L.sets;
     L.off_panel = off;
-    off += align_up((size_t)L.rows * ld_items(n_items) * sizeof(float), 256);
+    L.panel_bytes = align_up((size_t)L.rows * ld_items(n_items) * sizeof(float), 256);
+    off += L.panel_bytes * (size_t)L.sets;
     L.off_hits = off;
     off += align_up((size_t)L.hit_cap * sizeof(float2), 256);
     L.off_sort = off;
     off += align_up(panel_topn_workspace_bytes(L.rows, n_items, n), 256);
+    // class maxima of the panel rows (64 per window) from the accumulating kernel's sweep: the
+    // selection kernel takes its threshold from them instead of a first pass over the row
+    L.off_pmax = off;
+    L.pmax_bytes = align_up((size_t)L.rows * (size_t)nwindows(n_items) * 64 * sizeof(unsigned), 256);
+    off += L.pmax_bytes * (size_t)L.sets;
     L.bytes = off;
     return L;
 }
@@ -1502,9 +1668,7 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
     int64_t *q_base = reinterpret_cast<int64_t *>(ws + L.off_base);
     auto *q_cursor = reinterpret_cast<unsigned long long *>(ws + L.off_cursor);
     float *heap = reinterpret_cast<float *>(ws + L.off_heap);
-    float *panel = reinterpret_cast<float *>(ws + L.off_panel);
     float2 *hits = reinterpret_cast<float2 *>(ws + L.off_hits);
-    OvfEntry *ovf = reinterpret_cast<OvfEntry *>(ws + L.off_ovf);
     // heaps of one replay workgroup in LDS; beyond 64 KiB (max_nbrs > 127) up to the CU's 160
     const size_t heap_lds = (size_t)(max_nbrs + 1) * 64 * 2 * sizeof(float);
     const bool lds_replay = heap_lds <= 150 * 1024;
@@ -1601,28 +1765,85 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
         hipLaunchKernelGGL(row_windows_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0,
                            st, d_sim_indptr, d_sim_indices, n_items, nwin, woff);
     }
+    // Accumulating kernel with more than one batch: batch b's tail (lists of the queued targets,
+    // their replay, the own items struck, the selection) runs on a side stream while the main stream
+    // already scores batch b + 1 into the OTHER panel / queue -- the tail is a few small launches and
+    // one bandwidth-bound pass, the score kernel is latency-bound: they overlap nearly for free.
+    // LK_REC_OVERLAP=0: one stream.
+    struct Tail {
+        hipStream_t side = nullptr;
+        hipEvent_t scored[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+        ~Tail()
+        {
+            for (int i = 0; i < 2; ++i) {
+                if (scored[i]) (void)hipEventDestroy(scored[i]);
+                if (done[i]) (void)hipEventDestroy(done[i]);
+            }
+            if (side) lk::side_stream_release(side);
+        }
+    } tail;
+    bool overlap = acc_kernel && L.sets == 2 && cuts.size() > 2 && n_items > 0;
+    if (const char *e = getenv("LK_REC_OVERLAP"))
+        if (e[0] == '0') overlap = false;
+    if (overlap) {
+        tail.side = lk::side_stream_acquire();
+        for (int i = 0; i < 2; ++i) {
+            LK_HIP_CHECK(hipEventCreateWithFlags(&tail.scored[i], hipEventDisableTiming));
+            LK_HIP_CHECK(hipEventCreateWithFlags(&tail.done[i], hipEventDisableTiming));
+        }
+    }
+    bool done_pending[2] = {false, false};
+    int64_t prev_hits = 0;  // hits of the batch before (its queued lists may still be in use)
     for (size_t b = 0; b + 1 < cuts.size(); ++b) {
         const int64_t q0 = cuts[b], nq = cuts[b + 1] - cuts[b];
         if (nq <= 0) continue;
+        const int set = overlap ? (int)(b & 1) : 0;
+        float *panel_b = reinterpret_cast<float *>(ws + L.off_panel + (size_t)set * L.panel_bytes);
+        OvfEntry *ovf_b = reinterpret_cast<OvfEntry *>(ws + L.off_ovf + (size_t)set * L.ovf_bytes);
+        int *ctr = status + 1 + 8 * set;  // tasks [0], queue length [1], (free), list cursor [3..4]
+        unsigned *pmax_b = reinterpret_cast<unsigned *>(ws + L.off_pmax + (size_t)set * L.pmax_bytes);
+        const bool use_pmax = acc_kernel && n > 0 && n <= 256 && n_items > 0;
+        hipStream_t ts = overlap ? tail.side : st;  // the stream of this batch's tail
         if (n_items > 0) {
-            // tasks [1], queue length [2], (free [3]), the queued lists' cursor [4..5]
-            LK_HIP_CHECK(hipMemsetAsync(status + 1, 0, 5 * sizeof(int), st));
+            if (overlap && done_pending[set]) {  // the set's previous tail has let go of it
+                LK_HIP_CHECK(hipStreamWaitEvent(st, tail.done[set], 0));
+                done_pending[set] = false;
+            }
+            LK_HIP_CHECK(hipMemsetAsync(ctr, 0, 5 * sizeof(int), st));
             const int64_t tasks = nq * nwin;
             int64_t wgs = (tasks + RWAVES - 1) / RWAVES;
             if (wgs > REC_MAX_WGS) wgs = REC_MAX_WGS;
             if (acc_kernel) {
                 const int64_t hvb = heavy_of_batch[b] < L.ovf_cap ? heavy_of_batch[b] : L.ovf_cap;
-                auto *list_cursor = reinterpret_cast<unsigned long long *>(status + 4);
+                auto *list_cursor = reinterpret_cast<unsigned long long *>(ctr + 3);
+                // the queued targets' lists: even batches fill the hit region from the bottom, odd
+                // ones from the top; two consecutive batches that would meet are not overlapped
+                int64_t batch_hits = 0;
+                for (int64_t q = q0; q < q0 + nq; ++q) batch_hits += h_query_hits[q];
+                float2 *hits_b = hits;
+                if (overlap) {
+                    if (set == 1) hits_b = hits + (L.hit_cap - batch_hits);
+                    if (prev_hits + batch_hits > L.hit_cap && done_pending[set ^ 1]) {
+                        LK_HIP_CHECK(hipStreamWaitEvent(st, tail.done[set ^ 1], 0));
+                        done_pending[set ^ 1] = false;
+                    }
+                }
+                prev_hits = batch_hits;
 #define LK_REC_ACC_LAUNCH(EXPLV)                                                                   \
     hipLaunchKernelGGL((iknn_score_acc_kernel<EXPLV>), dim3((unsigned)wgs), dim3(RTHREADS), 0, st, \
                        d_sim_indptr, d_sim_indices, d_sim_values, n_items, nwin, woff, q0, nq,      \
-                       d_ref_ptr, d_ref_items, d_ref_rates, d_item_bias, max_nbrs, min_nbrs, panel, \
-                       ld, status + 1, status, ovf, (int)L.ovf_cap, status + 2, list_cursor)
+                       d_ref_ptr, d_ref_items, d_ref_rates, d_item_bias, max_nbrs, min_nbrs,        \
+                       panel_b, ld, ctr, status, ovf_b, (int)L.ovf_cap, ctr + 1, list_cursor,        \
+                       exclude_refs, use_pmax ? pmax_b : nullptr)
                 if (d_ref_rates)
                     LK_REC_ACC_LAUNCH(true);
                 else
                     LK_REC_ACC_LAUNCH(false);
 #undef LK_REC_ACC_LAUNCH
+                if (overlap) {
+                    LK_HIP_CHECK(hipEventRecord(tail.scored[set], st));
+                    LK_HIP_CHECK(hipStreamWaitEvent(ts, tail.scored[set], 0));
+                }
                 if (hvb > 0) {
                     LK_REQUIRE(lds_replay, "lk_iknn_recommend: max_nbrs = %d is beyond the replay "
                                "kernel's LDS heaps (LK_REC_ACC=0 takes the list kernel)", max_nbrs);
@@ -1637,19 +1858,19 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
                     int64_t gw = (hvb + GWAVES - 1) / GWAVES;
                     if (gw > 16384) gw = 16384;
                     hipLaunchKernelGGL(iknn_heavy_gather_kernel, dim3((unsigned)gw), dim3(GWAVES * 64),
-                                       0, st, ovf, status + 2, (int)L.ovf_cap, d_sim_indptr,
+                                       0, ts, ovf_b, ctr + 1, (int)L.ovf_cap, d_sim_indptr,
                                        d_sim_indices, d_sim_values, n_items, nwin, woff, q0, d_ref_ptr,
-                                       d_ref_items, d_ref_rates, hits, status);
-                    int64_t gr = (hvb + 63) / 64;
-                    if (gr > 16384) gr = 16384;
+                                       d_ref_items, d_ref_rates, hits_b, status);
+                    int64_t gr = hvb;  // (one target per wave while the waves last)
+                    if (gr > 8192) gr = 8192;
                     if (d_ref_rates)
                         hipLaunchKernelGGL((iknn_heap_replay_kernel<true>), dim3((unsigned)gr),
-                                           dim3(64), heap_lds, st, ovf, status + 2, (int)L.ovf_cap,
-                                           hits, d_item_bias, max_nbrs, panel, ld);
+                                           dim3(64), heap_lds, ts, ovf_b, ctr + 1, (int)L.ovf_cap,
+                                           hits_b, d_item_bias, max_nbrs, panel_b, ld);
                     else
                         hipLaunchKernelGGL((iknn_heap_replay_kernel<false>), dim3((unsigned)gr),
-                                           dim3(64), heap_lds, st, ovf, status + 2, (int)L.ovf_cap,
-                                           hits, d_item_bias, max_nbrs, panel, ld);
+                                           dim3(64), heap_lds, ts, ovf_b, ctr + 1, (int)L.ovf_cap,
+                                           hits_b, d_item_bias, max_nbrs, panel_b, ld);
                 }
             } else {
 #define LK_REC_LAUNCH(EXPLV)                                                                      \
@@ -1658,18 +1879,18 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
     hipLaunchKernelGGL((iknn_score_all_kernel<EXPLV, true>), dim3((unsigned)wgs), dim3(RTHREADS),  \
                        0, st, d_sim_indptr, d_sim_indices, d_sim_values, n_items, nwin, woff, q0,  \
                        nq, d_ref_ptr, d_ref_items, d_ref_rates, d_item_bias, max_nbrs, min_nbrs,   \
-                       hits, q_base + q0, q_cursor + q0, panel, ld, heap, status + 1, status,      \
-                       lds_replay ? ovf : nullptr, REC_OVF_CAP, status + 2);                       \
+                       hits, q_base + q0, q_cursor + q0, panel_b, ld, heap, ctr, status,           \
+                       lds_replay ? ovf_b : nullptr, REC_OVF_CAP, ctr + 1);                        \
     else                                                                                          \
     hipLaunchKernelGGL((iknn_score_all_kernel<EXPLV>), dim3((unsigned)wgs), dim3(RTHREADS), 0, st, \
                        d_sim_indptr, d_sim_indices, d_sim_values, n_items, nwin, woff, q0, nq,    \
                        d_ref_ptr, d_ref_items, d_ref_rates, d_item_bias, max_nbrs, min_nbrs, hits, \
-                       q_base + q0, q_cursor + q0, panel, ld, heap, status + 1, status,            \
-                       lds_replay ? ovf : nullptr, REC_OVF_CAP, status + 2);                       \
+                       q_base + q0, q_cursor + q0, panel_b, ld, heap, ctr, status,                 \
+                       lds_replay ? ovf_b : nullptr, REC_OVF_CAP, ctr + 1);                        \
     if (lds_replay)                                                                               \
     hipLaunchKernelGGL((iknn_heap_replay_kernel<EXPLV>), dim3(REC_OVF_CAP / 64), dim3(64),         \
-                       heap_lds, st, ovf, status + 2, REC_OVF_CAP, hits, d_item_bias, max_nbrs,    \
-                       panel, ld);                                                                 \
+                       heap_lds, st, ovf_b, ctr + 1, REC_OVF_CAP, hits, d_item_bias, max_nbrs,     \
+                       panel_b, ld);                                                               \
     } while (0)
             if (lds_replay && heap_lds > 64 * 1024) {
                 LK_HIP_CHECK(hipFuncSetAttribute(
@@ -1685,14 +1906,23 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
                 LK_REC_LAUNCH(false);
 #undef LK_REC_LAUNCH
             }
-            if (exclude_refs)
-                hipLaunchKernelGGL(mask_refs_kernel, dim3((unsigned)nq), dim3(64), 0, st, d_ref_ptr,
-                                   d_ref_items, q0, nq, n_items, panel, ld);
+            // (the accumulating kernel strikes the own items itself: they never reach the queue)
+            if (exclude_refs && !acc_kernel)
+                hipLaunchKernelGGL(mask_refs_kernel, dim3((unsigned)nq), dim3(64), 0, ts, d_ref_ptr,
+                                   d_ref_items, q0, nq, n_items, panel_b, ld);
         }
-        int rc = panel_topn(panel, ld, nq, n_items, n, sort_ws, d_out_idx + q0 * out_cols,
-                            d_out_score ? d_out_score + q0 * out_cols : nullptr, st);
+        int rc = panel_topn(panel_b, ld, nq, n_items, n, sort_ws, d_out_idx + q0 * out_cols,
+                            d_out_score ? d_out_score + q0 * out_cols : nullptr, ts,
+                            use_pmax ? pmax_b : nullptr, use_pmax ? nwin * 64 : 0);
         if (rc != LK_OK) return rc;
+        if (overlap) {
+            LK_HIP_CHECK(hipEventRecord(tail.done[set], ts));
+            done_pending[set] = true;
+        }
     }
+    if (overlap)
+        for (int i = 0; i < 2; ++i)
+            if (done_pending[i]) LK_HIP_CHECK(hipStreamWaitEvent(st, tail.done[i], 0));
     LK_HIP_CHECK(hipGetLastError());
     int h = 0;
     LK_HIP_CHECK(hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, st));

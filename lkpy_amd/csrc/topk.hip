@@ -1808,12 +1808,17 @@ __device__ __forceinline__ unsigned row_topn_radix(const float *__restrict__ row
 // bitonic sort as before.  No per-element LDS atomics: the radix histograms cost ~3 cycles
 // per element per CU.  Rows the bound cannot handle (fewer than n threads saw a valid
 // entry, or more than MAXN entries pass) take the radix path; results are identical.
+// `class_max` (optional; the item-kNN recommend kernel's sweep provides it): per row
+// `classes` order-preserving keys, each the largest valid key of a disjoint class of the row's
+// entries (0: none) -- the first sweep is then not needed.
 template <int MAXN>
 __global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__ scores,
                                                        int64_t ld_s, int64_t row_len, int n,
                                                        int32_t *__restrict__ out_idx,
                                                        float *__restrict__ out_score,
-                                                       int64_t out_ld)
+                                                       int64_t out_ld,
+                                                       const unsigned *__restrict__ class_max,
+                                                       int classes)
 {
     __shared__ unsigned long long cand[MAXN];
     __shared__ unsigned tmax[256];
@@ -1831,16 +1836,21 @@ __global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__
         const bool vec = (reinterpret_cast<uintptr_t>(row) & 15u) == 0;
         const int64_t n4 = vec ? row_len / 4 : 0;
         const f32x4 *row4 = reinterpret_cast<const f32x4 *>(row);
-        for (int64_t i = tid; i < n4; i += 256) {
-            const f32x4 v = row4[i];
-            if (v.x == v.x) best = max(best, f2key(v.x));
-            if (v.y == v.y) best = max(best, f2key(v.y));
-            if (v.z == v.z) best = max(best, f2key(v.z));
-            if (v.w == v.w) best = max(best, f2key(v.w));
-        }
-        for (int64_t i = n4 * 4 + tid; i < row_len; i += 256) {
-            const float x = row[i];
-            if (x == x) best = max(best, f2key(x));
+        if (class_max) {
+            const unsigned *cm = class_max + (int64_t)blockIdx.x * classes;
+            for (int j = tid; j < classes; j += 256) best = max(best, cm[j]);
+        } else {
+            for (int64_t i = tid; i < n4; i += 256) {
+                const f32x4 v = row4[i];
+                if (v.x == v.x) best = max(best, f2key(v.x));
+                if (v.y == v.y) best = max(best, f2key(v.y));
+                if (v.z == v.z) best = max(best, f2key(v.z));
+                if (v.w == v.w) best = max(best, f2key(v.w));
+            }
+            for (int64_t i = n4 * 4 + tid; i < row_len; i += 256) {
+                const float x = row[i];
+                if (x == x) best = max(best, f2key(x));
+            }
         }
         tmax[tid] = best;
         if (tid == 0) f_count = 0;
@@ -2281,7 +2291,8 @@ size_t panel_topn_workspace_bytes(int64_t rows, int64_t n_items, int32_t n)
     return (n < 0 || n > TOPN_MAX) ? topn_sort_workspace_bytes(rows, n_items) : 0;
 }
 int panel_topn(const float *panel, int64_t ld_s, int64_t rows, int64_t n_items, int32_t n,
-               void *sort_ws, int32_t *out_idx, float *out_score, hipStream_t st)
+               void *sort_ws, int32_t *out_idx, float *out_score, hipStream_t st,
+               const unsigned *class_max = nullptr, int classes_per_row = 0)
 {
     if (rows <= 0 || n == 0) return LK_OK;
     if (n < 0 || n > TOPN_MAX) {
@@ -2289,7 +2300,7 @@ int panel_topn(const float *panel, int64_t ld_s, int64_t rows, int64_t n_items, 
         return topn_sort(panel, ld_s, rows, n_items, cols, sort_ws, out_idx, out_score, cols, st);
     }
     hipLaunchKernelGGL(row_topn_kernel<TOPN_MAX>, dim3((unsigned)rows), dim3(256), 0, st, panel,
-                       ld_s, n_items, n, out_idx, out_score, (int64_t)n);
+                       ld_s, n_items, n, out_idx, out_score, (int64_t)n, class_max, classes_per_row);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }
@@ -2340,7 +2351,7 @@ extern "C" int lk_argtopn(const float *d_scores, int64_t n_rows, int64_t row_len
     }
     hipLaunchKernelGGL(lk::row_topn_kernel<lk::TOPN_MAX>, dim3((unsigned)n_rows), dim3(256), 0,
                        lk::as_stream(stream), d_scores, row_len, row_len, n, d_out_idx,
-                       (float *)nullptr, (int64_t)n);
+                       (float *)nullptr, (int64_t)n, (const unsigned *)nullptr, 0);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }
@@ -2391,7 +2402,8 @@ extern "C" int lk_score_topk(const float *d_users, int32_t ld_users, int64_t n_u
         }
         hipLaunchKernelGGL(lk::row_topn_kernel<lk::TOPN_MAX>, dim3((unsigned)rows), dim3(256), 0,
                            st, panel, ld_s, n_items, n, d_out_idx + ub * n,
-                           d_out_score ? d_out_score + ub * n : nullptr, (int64_t)n);
+                           d_out_score ? d_out_score + ub * n : nullptr, (int64_t)n,
+                           (const unsigned *)nullptr, 0);
         return LK_OK;
     };
 
