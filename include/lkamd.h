@@ -466,10 +466,14 @@ int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
  * ---------------------------------------------------------------------- */
 size_t lk_iknn_score_workspace_bytes(int64_t n_items, int64_t n_queries, int32_t max_nbrs);
 void lk_knn_score_last_stats(int64_t *out3);
-/* 1 / 0: the last lk_iknn_recommend call of this process walked the similarity rows PACKED (64
- * entries of several (row x window) pieces per instruction; needs same-address LDS atomics of one
- * instruction served in lane order, probed on the device at first use) or piece by piece; -1: no
- * call yet.  Test hook; LK_REC_PACKED=0 forces the piece-wise walk.  Same scores either way. */
+/* 2 / 1 / 0: the last lk_iknn_recommend call of this process ran the ACCUMULATING kernel (round 6,
+ * the default: weights added to their target's LDS cell by ds_add_f32 -- same-address adds of an
+ * instruction applied in lane order with the VALU's rounding, probed on the device at first use),
+ * the list kernel walking the similarity rows PACKED (64 entries of several (row x window) pieces
+ * per instruction; needs same-address LDS atomics of one instruction served in lane order, probed
+ * as well; LK_REC_ACC=0 forces it), or the list kernel piece by piece (LK_REC_PACKED=0); -1: no
+ * call yet.  Test hook.  Same scores in all three.  LK_REC_OVERLAP=0: the batches' tails (queued
+ * targets, selection) on the caller's stream instead of a side stream. */
 int lk_iknn_recommend_last_packed(void);
 int lk_iknn_score_batch(const int64_t *d_sim_indptr, const int32_t *d_sim_indices,
                         const float *d_sim_values, int64_t n_items, int64_t n_queries,

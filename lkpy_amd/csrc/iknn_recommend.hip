@@ -39,6 +39,14 @@
 // of algorithmic traffic, L2 / MALL resident for a truncated model) and every hit costs two LDS
 // atomics; the per-window fixed cost (zero, scan, score sweep, copy-out) is what a short history
 // pays.  bench.py reports the call against the HBM roofline on those bytes.
+//
+// Round 6: the kernel described above (`iknn_score_all_kernel`, "the list kernel") is the FALLBACK.
+// The product path is `iknn_score_acc_kernel` further down ("the accumulating kernel"): the same
+// tasks and windows, but no lists -- every weight is ADDED to its target's LDS cell by
+// `ds_add_f32`, whose same-address adds the LDS applies in lane order (probed on the device like
+// the cursor order), so the cell is the vector's sequential sum bit for bit; targets beyond
+// max_nbrs hits are queued, their lists built by `iknn_heavy_gather_kernel` and replayed by
+// `iknn_heap_replay_kernel`.  7.0 -> 5.0 ms on the cfg3 batch.
 #include <type_traits>
 #include <vector>
 
@@ -388,6 +396,9 @@ __device__ __forceinline__ void walk_packed(
 // and the first walk of a task RECORDS the descriptors of its first KC chunks in registers
 // (CACHE = 1), which the second and third walk replay (CACHE = 2) without loading anything but
 // entries.
+#ifndef LK_REC_ACC_WAVES
+#define LK_REC_ACC_WAVES 2  // waves per SIMD the LDS lets the accumulating kernel have (RW = 4096)
+#endif
 constexpr int ACC_CAPB = 8192;                  // stream positions the first-position bitmap covers
 static_assert(ACC_CAPB >= RW, "a single row piece (<= RW entries) must fit the bitmap");
 constexpr int ACC_DSC = 192 + ACC_CAPB / 32 + 4;  // words of wave-private table + bitmap
@@ -1037,7 +1048,7 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
 // Three walks instead of two, but each is the cheap kind (the count walk: 23 k cycles per task
 // against the fill walk's 34 k and the sweep's 80 k).
 template <bool EXPL>
-__global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))  // (the LDS's limit)
+__global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(LK_REC_ACC_WAVES, LK_REC_ACC_WAVES)))
 void iknn_score_acc_kernel(
     const int64_t *__restrict__ s_ptr, const int32_t *__restrict__ s_idx,
     const float *__restrict__ s_val, int64_t n_items, int nwin, const unsigned *__restrict__ woff,

@@ -1871,11 +1871,17 @@ __global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__
                         cand[pos] = ((unsigned long long)k << 32) | (0xffffffffu - (unsigned)i);
                 }
             };
+            // (x >= tau_f <=> f2key(x) >= tau for every non-NaN x, and false for NaN: the keys
+            // preserve the order, -0 ranks with +0 on both sides.  Few entries pass, so a wave first
+            // asks whether ANY of its 256 does: one ballot per 16-byte load instead of four offers)
+            const float tau_f = key2f(tau);
             for (int64_t i0 = 0; i0 < n4; i0 += 256) {
                 const int64_t i = i0 + tid;
                 f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
                 const bool in = i < n4;
                 if (in) v = row4[i];
+                const bool hit = in && (v.x >= tau_f || v.y >= tau_f || v.z >= tau_f || v.w >= tau_f);
+                if (__ballot(hit) == 0ull) continue;  // (wave-uniform)
                 const float xs[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
