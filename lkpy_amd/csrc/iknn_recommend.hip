@@ -1056,8 +1056,7 @@ void iknn_score_acc_kernel(
     const int32_t *__restrict__ ref_items, const float *__restrict__ ref_rates,
     const float *__restrict__ item_bias, int max_nbrs, int min_nbrs, float *__restrict__ panel,
     int64_t ld, int *__restrict__ task_counter, int *__restrict__ status,
-    OvfEntry *__restrict__ ovf, int ovf_cap, int *__restrict__ ovf_count,
-    unsigned long long *__restrict__ list_cursor, int exclude_refs,
+    OvfEntry *__restrict__ ovf, int ovf_cap, int *__restrict__ ovf_count, int exclude_refs,
     unsigned *__restrict__ premax)
 {
     // one cell per target, no padding: the sweeps move FOUR cells per LDS instruction (lane l owns
@@ -1145,9 +1144,9 @@ void iknn_score_acc_kernel(
                 if (pmax) pmax[lane] = 0u;
                 continue;
             }
-            // Full(heap) targets (rare): the list is built by iknn_heavy_gather_kernel and replayed
-            // by iknn_heap_replay_kernel (the queue holds every such target of the batch: the host
-            // cuts batches by hits / (max_nbrs + 1))
+            // Full(heap) targets (rare): found again and replayed by iknn_heavy_replay_kernel (the
+            // queue holds every such target of the batch: the host cuts batches by hits /
+            // (max_nbrs + 1))
             if (__ballot(mx > (unsigned)max_nbrs && max_nbrs >= min_nbrs) != 0ull) {
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
@@ -1157,10 +1156,8 @@ void iknn_score_acc_kernel(
                         if (v[j] > (unsigned)max_nbrs && max_nbrs >= min_nbrs) {
                             const int t = 256 * g + 4 * lane + j;
                             const int slot = atomicAdd(ovf_count, 1);
-                            const unsigned long long at =
-                                atomicAdd(list_cursor, (unsigned long long)v[j]);
                             if (slot < ovf_cap)
-                                ovf[slot] = OvfEntry{(int)ql, w0 + t, (int)v[j], 0, at};
+                                ovf[slot] = OvfEntry{(int)ql, w0 + t, (int)v[j], 0, 0ull};
                             else
                                 atomicCAS(status, 0, 2);  // cannot happen (host bound)
                         }
@@ -1299,96 +1296,167 @@ void iknn_score_acc_kernel(
 #endif
 }
 
-// The hit list of a queued target (more than max_nbrs hits), for the replay kernel: one WAVE per
-// target walks the query's history 64 rows at a time; a lane looks its row's window piece up
-// (`woff`) and searches the target's column in it (rows are sorted by column); the hits of a step
-// are appended in lane order = history order.
+// A queued target (more than max_nbrs hits) of the accumulating kernel: its hits are FOUND and
+// REPLAYED by one wave, no list in between.  The wave walks the query's history 256 rows at a time
+// (four 64-row steps whose chains of dependent loads -- history row -> window offsets and row
+// start -> the search's probes -> the weight -- run side by side); a lane looks its row's window
+// piece up (`woff`) and searches the target's column in it (rows are sorted by column); the hits
+// of a step are taken in lane order = history order (`v_readlane` with the ballot's next set bit)
+// and lane 0 feeds them to the reference's accumulator on a heap in the wave's LDS: the first
+// max_nbrs fill the vector, the next one turns it into the heap (accum.rs:76-83: vec.pop() from
+// the back, push each), every later one is offered (accum.rs:100-118).  Writes the panel cell.
 constexpr int GWAVES = 4;
-__global__ __launch_bounds__(GWAVES * 64) void iknn_heavy_gather_kernel(
+template <bool EXPL>
+__global__ __launch_bounds__(GWAVES * 64) void iknn_heavy_replay_kernel(
     const OvfEntry *__restrict__ ovf, const int *__restrict__ ovf_count, int ovf_cap,
     const int64_t *__restrict__ s_ptr, const int32_t *__restrict__ s_idx,
     const float *__restrict__ s_val, int64_t n_items, int nwin, const unsigned *__restrict__ woff,
     int64_t q0, const int64_t *__restrict__ ref_ptr, const int32_t *__restrict__ ref_items,
-    const float *__restrict__ ref_rates, float2 *__restrict__ hits, int *__restrict__ status)
+    const float *__restrict__ ref_rates, const float *__restrict__ item_bias, int max_nbrs,
+    float *__restrict__ panel, int64_t ld, int *__restrict__ status)
 {
+    extern __shared__ float heap_lds[];  // [GWAVES][2][max_nbrs + 1]
     int n = *ovf_count;
     if (n > ovf_cap) n = ovf_cap;
     const int lane = lane_id();
-    for (int i = blockIdx.x * GWAVES + (int)(threadIdx.x >> 6); i < n; i += (int)gridDim.x * GWAVES) {
-    const OvfEntry e = ovf[i];
-    const int64_t q = q0 + e.ql;
-    const int64_t rb = ref_ptr[q], re = ref_ptr[q + 1];
-    const int win = e.item / RW;
-    float2 *out = hits + e.list;
-    unsigned base = 0u;
-    // four 64-row steps at a time: their chains of dependent loads (history row -> window offsets
-    // and row start -> the search's probes -> the weight) run side by side
-    constexpr int GU = 4;
-    for (int64_t r0 = rb; r0 < re; r0 += 64 * GU) {
-        int ri[GU];
-        int64_t lo[GU], hi[GU], end[GU];
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const int64_t r = r0 + 64 * u + lane;
-            ri[u] = ref_items[r < re ? r : re - 1];
-            if (!(r < re)) ri[u] = -1;
-        }
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const bool ok = ri[u] >= 0 && ri[u] < n_items;
-            const int rr = ok ? ri[u] : 0;
-            const unsigned *wo = woff + (int64_t)rr * (nwin + 1) + win;
-            const int64_t b = s_ptr[rr];
-            lo[u] = b + wo[0];
-            hi[u] = end[u] = b + wo[1];
-            if (!ok) hi[u] = end[u] = lo[u];
-        }
-        // lower bound of the target's column in each piece (rows are sorted by column); the four
-        // searches advance together
-        for (;;) {
-            bool any = false;
-            int64_t mid[GU];
-            int col[GU];
+    const int wave = (int)(threadIdx.x >> 6);
+    float *hw = heap_lds + (size_t)wave * 2 * (max_nbrs + 1), *hv = hw + (max_nbrs + 1);
+    for (int i = blockIdx.x * GWAVES + wave; i < n; i += (int)gridDim.x * GWAVES) {
+        const OvfEntry e = ovf[i];
+        const int64_t q = q0 + e.ql;
+        const int64_t rb = ref_ptr[q], re = ref_ptr[q + 1];
+        const int win = e.item / RW;
+        // ---- the accumulator (lane 0 only) ---------------------------------------------------
+        auto sift_up = [&](int pos, float ew, float ev) {
+            while (pos > 0) {
+                const int parent = (pos - 1) >> 1;
+                if (ew >= hw[parent]) break;
+                hw[pos] = hw[parent];
+                hv[pos] = hv[parent];
+                pos = parent;
+            }
+            hw[pos] = ew;
+            hv[pos] = ev;
+        };
+        int fed = 0;
+        float wmin = 0.f;
+        auto feed = [&](float hx, float hy) {
+            if (fed < max_nbrs) {  // Partial(vec); stored back to front: the order the heap is built in
+                hw[max_nbrs - 1 - fed] = hx;
+                hv[max_nbrs - 1 - fed] = hy;
+                if (fed == max_nbrs - 1) {
+                    for (int kk = 1; kk < max_nbrs; ++kk) sift_up(kk, hw[kk], hv[kk]);
+                    wmin = hw[0];
+                }
+            } else if (hx > wmin) {  // strictly greater than the minimum (accum.rs:108)
+                // push (sift_up(0, len)), then pop: swap the last element into the root,
+                // sift_down_to_bottom(0), sift_up -- std's BinaryHeap, as in iknn_score.hip
+                sift_up(max_nbrs, hx, hy);
+                const float ew = hw[max_nbrs], ev = hv[max_nbrs];
+                const int end = max_nbrs;
+                int pos = 0, child = 1;
+                const int limit = end >= 2 ? end - 2 : 0;
+                while (child <= limit && end >= 2) {
+                    if (hw[child] >= hw[child + 1]) child += 1;
+                    hw[pos] = hw[child];
+                    hv[pos] = hv[child];
+                    pos = child;
+                    child = 2 * pos + 1;
+                }
+                if (child == end - 1) {
+                    hw[pos] = hw[child];
+                    hv[pos] = hv[child];
+                    pos = child;
+                }
+                sift_up(pos, ew, ev);
+                wmin = hw[0];
+            }
+            ++fed;
+        };
+        // ---- the walk ------------------------------------------------------------------------
+        unsigned seen = 0u;
+        constexpr int GU = 4;
+        for (int64_t r0 = rb; r0 < re; r0 += 64 * GU) {
+            int ri[GU];
+            int64_t lo[GU], hi[GU], end[GU];
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
-                mid[u] = (lo[u] + hi[u]) >> 1;
-                col[u] = s_idx[lo[u] < hi[u] ? mid[u] : 0];  // (unconditional loads: no branch, one wait)
+                const int64_t r = r0 + 64 * u + lane;
+                ri[u] = ref_items[r < re ? r : re - 1];
+                if (!(r < re)) ri[u] = -1;
             }
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
-                if (lo[u] < hi[u]) {
-                    if (col[u] < e.item)
-                        lo[u] = mid[u] + 1;
-                    else
-                        hi[u] = mid[u];
-                    any = any || lo[u] < hi[u];
+                const bool ok = ri[u] >= 0 && ri[u] < n_items;
+                const int rr = ok ? ri[u] : 0;
+                const unsigned *wo = woff + (int64_t)rr * (nwin + 1) + win;
+                const int64_t b = s_ptr[rr];
+                lo[u] = b + wo[0];
+                hi[u] = end[u] = b + wo[1];
+                if (!ok) hi[u] = end[u] = lo[u];
+            }
+            // lower bound of the target's column in each piece; the four searches advance together
+            for (;;) {
+                bool any = false;
+                int64_t mid[GU];
+                int col[GU];
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    mid[u] = (lo[u] + hi[u]) >> 1;
+                    col[u] = s_idx[lo[u] < hi[u] ? mid[u] : 0];  // (unconditional loads: one wait)
+                }
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    if (lo[u] < hi[u]) {
+                        if (col[u] < e.item)
+                            lo[u] = mid[u] + 1;
+                        else
+                            hi[u] = mid[u];
+                        any = any || lo[u] < hi[u];
+                    }
+                }
+                if (__ballot(any) == 0ull) break;
+            }
+            int colf[GU];
+            float w[GU], rate[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int64_t at = lo[u] < end[u] ? lo[u] : 0;
+                colf[u] = s_idx[at];
+                w[u] = s_val[at];
+                if (!(lo[u] < end[u])) colf[u] = -1;
+                const int64_t r = r0 + 64 * u + lane;
+                rate[u] = ref_rates ? ref_rates[r < re ? r : re - 1] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                unsigned long long m = __ballot(colf[u] == e.item);
+                seen += (unsigned)__popcll(m);
+                while (m != 0ull) {  // (wave-uniform)
+                    const int j = (int)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const float hx = __builtin_bit_cast(
+                        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[u]), j));
+                    const float hy = __builtin_bit_cast(
+                        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rate[u]), j));
+                    if (lane == 0) feed(hx, hy);
                 }
             }
-            if (__ballot(any) == 0ull) break;
         }
-        int colf[GU];
-        float w[GU], rate[GU];
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const int64_t at = lo[u] < end[u] ? lo[u] : 0;
-            colf[u] = s_idx[at];
-            w[u] = s_val[at];
-            if (!(lo[u] < end[u])) colf[u] = -1;
-            const int64_t r = r0 + 64 * u + lane;
-            rate[u] = ref_rates ? ref_rates[r < re ? r : re - 1] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const bool found = colf[u] == e.item;
-            const unsigned long long m = __ballot(found);
-            if (found) {
-                const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                if (base + rank < (unsigned)e.cnt) out[base + rank] = float2{w[u], rate[u]};
+        if (lane == 0) {
+            if (seen != (unsigned)e.cnt || fed <= max_nbrs) {
+                atomicCAS(status, 0, 2);  // (an internal error: the count walk saw other hits)
+            } else {
+                float tw = 0.f, ws = 0.f;
+                for (int x = 0; x < max_nbrs; ++x) {
+                    tw += hw[x];
+                    if (EXPL) ws += hw[x] * hv[x];
+                }
+                float score = EXPL ? ws / tw : tw;
+                if (item_bias) score = score + item_bias[e.item];
+                panel[(int64_t)e.ql * ld + e.item] = score;
             }
-            base += (unsigned)__popcll(m);
         }
-    }
-    if (lane == 0 && base != (unsigned)e.cnt) atomicCAS(status, 0, 2);  // (an internal error)
     }
 }
 
@@ -1736,8 +1804,8 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
     g_rec_last_packed = acc_kernel ? 2 : (packed ? 1 : 0);
 
     // batches: at most L.rows queries and L.hit_cap hits each; a query's hit region starts at the
-    // sum of the hits of the batch's queries before it (the list kernel; the accumulating kernel
-    // keeps lists of its queued targets only, anywhere in the region).  Accumulating kernel: the
+    // sum of the hits of the batch's queries before it (the list kernel only: the accumulating
+    // kernel keeps no lists and leaves the hit region alone).  Accumulating kernel: the
     // queue of targets beyond max_nbrs hits holds every such target a batch can have
     std::vector<int64_t> base((size_t)n_queries);
     std::vector<int64_t> cuts{0};
@@ -1804,14 +1872,13 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
         }
     }
     bool done_pending[2] = {false, false};
-    int64_t prev_hits = 0;  // hits of the batch before (its queued lists may still be in use)
     for (size_t b = 0; b + 1 < cuts.size(); ++b) {
         const int64_t q0 = cuts[b], nq = cuts[b + 1] - cuts[b];
         if (nq <= 0) continue;
         const int set = overlap ? (int)(b & 1) : 0;
         float *panel_b = reinterpret_cast<float *>(ws + L.off_panel + (size_t)set * L.panel_bytes);
         OvfEntry *ovf_b = reinterpret_cast<OvfEntry *>(ws + L.off_ovf + (size_t)set * L.ovf_bytes);
-        int *ctr = status + 1 + 8 * set;  // tasks [0], queue length [1], (free), list cursor [3..4]
+        int *ctr = status + 1 + 8 * set;  // tasks [0], queue length [1]
         unsigned *pmax_b = reinterpret_cast<unsigned *>(ws + L.off_pmax + (size_t)set * L.pmax_bytes);
         const bool use_pmax = acc_kernel && n > 0 && n <= 256 && n_items > 0;
         hipStream_t ts = overlap ? tail.side : st;  // the stream of this batch's tail
@@ -1826,26 +1893,12 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
             if (wgs > REC_MAX_WGS) wgs = REC_MAX_WGS;
             if (acc_kernel) {
                 const int64_t hvb = heavy_of_batch[b] < L.ovf_cap ? heavy_of_batch[b] : L.ovf_cap;
-                auto *list_cursor = reinterpret_cast<unsigned long long *>(ctr + 3);
-                // the queued targets' lists: even batches fill the hit region from the bottom, odd
-                // ones from the top; two consecutive batches that would meet are not overlapped
-                int64_t batch_hits = 0;
-                for (int64_t q = q0; q < q0 + nq; ++q) batch_hits += h_query_hits[q];
-                float2 *hits_b = hits;
-                if (overlap) {
-                    if (set == 1) hits_b = hits + (L.hit_cap - batch_hits);
-                    if (prev_hits + batch_hits > L.hit_cap && done_pending[set ^ 1]) {
-                        LK_HIP_CHECK(hipStreamWaitEvent(st, tail.done[set ^ 1], 0));
-                        done_pending[set ^ 1] = false;
-                    }
-                }
-                prev_hits = batch_hits;
 #define LK_REC_ACC_LAUNCH(EXPLV)                                                                   \
     hipLaunchKernelGGL((iknn_score_acc_kernel<EXPLV>), dim3((unsigned)wgs), dim3(RTHREADS), 0, st, \
                        d_sim_indptr, d_sim_indices, d_sim_values, n_items, nwin, woff, q0, nq,      \
                        d_ref_ptr, d_ref_items, d_ref_rates, d_item_bias, max_nbrs, min_nbrs,        \
-                       panel_b, ld, ctr, status, ovf_b, (int)L.ovf_cap, ctr + 1, list_cursor,        \
-                       exclude_refs, use_pmax ? pmax_b : nullptr)
+                       panel_b, ld, ctr, status, ovf_b, (int)L.ovf_cap, ctr + 1, exclude_refs,       \
+                       use_pmax ? pmax_b : nullptr)
                 if (d_ref_rates)
                     LK_REC_ACC_LAUNCH(true);
                 else
@@ -1856,32 +1909,31 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
                     LK_HIP_CHECK(hipStreamWaitEvent(ts, tail.scored[set], 0));
                 }
                 if (hvb > 0) {
-                    LK_REQUIRE(lds_replay, "lk_iknn_recommend: max_nbrs = %d is beyond the replay "
+                    const size_t hl = (size_t)GWAVES * 2 * (size_t)(max_nbrs + 1) * sizeof(float);
+                    LK_REQUIRE(hl <= 150 * 1024, "lk_iknn_recommend: max_nbrs = %d is beyond the replay "
                                "kernel's LDS heaps (LK_REC_ACC=0 takes the list kernel)", max_nbrs);
-                    if (heap_lds > 64 * 1024) {
+                    if (hl > 64 * 1024) {
                         LK_HIP_CHECK(hipFuncSetAttribute(
-                            reinterpret_cast<const void *>(&iknn_heap_replay_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds));
+                            reinterpret_cast<const void *>(&iknn_heavy_replay_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
                         LK_HIP_CHECK(hipFuncSetAttribute(
-                            reinterpret_cast<const void *>(&iknn_heap_replay_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds));
+                            reinterpret_cast<const void *>(&iknn_heavy_replay_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
                     }
                     int64_t gw = (hvb + GWAVES - 1) / GWAVES;
                     if (gw > 16384) gw = 16384;
-                    hipLaunchKernelGGL(iknn_heavy_gather_kernel, dim3((unsigned)gw), dim3(GWAVES * 64),
-                                       0, ts, ovf_b, ctr + 1, (int)L.ovf_cap, d_sim_indptr,
-                                       d_sim_indices, d_sim_values, n_items, nwin, woff, q0, d_ref_ptr,
-                                       d_ref_items, d_ref_rates, hits_b, status);
-                    int64_t gr = hvb;  // (one target per wave while the waves last)
-                    if (gr > 8192) gr = 8192;
                     if (d_ref_rates)
-                        hipLaunchKernelGGL((iknn_heap_replay_kernel<true>), dim3((unsigned)gr),
-                                           dim3(64), heap_lds, ts, ovf_b, ctr + 1, (int)L.ovf_cap,
-                                           hits_b, d_item_bias, max_nbrs, panel_b, ld);
+                        hipLaunchKernelGGL((iknn_heavy_replay_kernel<true>), dim3((unsigned)gw),
+                                           dim3(GWAVES * 64), hl, ts, ovf_b, ctr + 1, (int)L.ovf_cap,
+                                           d_sim_indptr, d_sim_indices, d_sim_values, n_items, nwin,
+                                           woff, q0, d_ref_ptr, d_ref_items, d_ref_rates, d_item_bias,
+                                           max_nbrs, panel_b, ld, status);
                     else
-                        hipLaunchKernelGGL((iknn_heap_replay_kernel<false>), dim3((unsigned)gr),
-                                           dim3(64), heap_lds, ts, ovf_b, ctr + 1, (int)L.ovf_cap,
-                                           hits_b, d_item_bias, max_nbrs, panel_b, ld);
+                        hipLaunchKernelGGL((iknn_heavy_replay_kernel<false>), dim3((unsigned)gw),
+                                           dim3(GWAVES * 64), hl, ts, ovf_b, ctr + 1, (int)L.ovf_cap,
+                                           d_sim_indptr, d_sim_indices, d_sim_values, n_items, nwin,
+                                           woff, q0, d_ref_ptr, d_ref_items, d_ref_rates, d_item_bias,
+                                           max_nbrs, panel_b, ld, status);
                 }
             } else {
 #define LK_REC_LAUNCH(EXPLV)                                                                      \
