@@ -1431,7 +1431,19 @@ __global__ __launch_bounds__(GWAVES * 64) void iknn_heavy_replay_kernel(
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 unsigned long long m = __ballot(colf[u] == e.item);
-                seen += (unsigned)__popcll(m);
+                // once the heap is full only a weight above its minimum can change it, and the
+                // minimum only rises: the hits that cannot pass are not even handed to lane 0
+                // (~max_nbrs ln(hits / max_nbrs) of a long list's hits do pass)
+                if (seen >= (unsigned)max_nbrs) {
+                    const float wm = __builtin_bit_cast(
+                        float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wmin)));
+                    const unsigned long long pass = __ballot(colf[u] == e.item && w[u] > wm);
+                    if (lane == 0) fed += (int)__popcll(m & ~pass);
+                    seen += (unsigned)__popcll(m);
+                    m = pass;
+                } else {
+                    seen += (unsigned)__popcll(m);
+                }
                 while (m != 0ull) {  // (wave-uniform)
                     const int j = (int)__builtin_ctzll(m);
                     m &= m - 1ull;

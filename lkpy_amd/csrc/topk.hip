@@ -1875,18 +1875,30 @@ __global__ __launch_bounds__(256) void row_topn_kernel(const float *__restrict__
             // preserve the order, -0 ranks with +0 on both sides.  Few entries pass, so a wave first
             // asks whether ANY of its 256 does: one ballot per 16-byte load instead of four offers)
             const float tau_f = key2f(tau);
-            for (int64_t i0 = 0; i0 < n4; i0 += 256) {
-                const int64_t i = i0 + tid;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                const bool in = i < n4;
-                if (in) v = row4[i];
-                const bool hit = in && (v.x >= tau_f || v.y >= tau_f || v.z >= tau_f || v.w >= tau_f);
-                if (__ballot(hit) == 0ull) continue;  // (wave-uniform)
-                const float xs[4] = {v.x, v.y, v.z, v.w};
+            // (four 16-byte loads in flight per thread: with one, a workgroup waits a memory latency
+            // per 4 KB and the sweep runs at 3.4 TB/s)
+            constexpr int TU = 4;
+            for (int64_t i0 = 0; i0 < n4; i0 += 256 * TU) {
+                f32x4 vv[TU];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const unsigned k = f2key(xs[c]);
-                    offer(in && xs[c] == xs[c] && k >= tau, k, i * 4 + c);
+                for (int u = 0; u < TU; ++u) {
+                    const int64_t i = i0 + 256 * u + tid;
+                    vv[u] = row4[i < n4 ? i : n4 - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < TU; ++u) {
+                    const int64_t i = i0 + 256 * u + tid;
+                    const bool in = i < n4;
+                    const f32x4 v = vv[u];
+                    const bool hit =
+                        in && (v.x >= tau_f || v.y >= tau_f || v.z >= tau_f || v.w >= tau_f);
+                    if (__ballot(hit) == 0ull) continue;  // (wave-uniform)
+                    const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned k = f2key(xs[c]);
+                        offer(in && xs[c] == xs[c] && k >= tau, k, i * 4 + c);
+                    }
                 }
             }
             for (int64_t i0 = n4 * 4; i0 < row_len; i0 += 256) {
