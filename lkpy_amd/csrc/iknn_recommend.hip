@@ -1847,10 +1847,12 @@ extern "C" int lk_iknn_recommend(const int64_t *d_sim_indptr, const int32_t *d_s
         cuts.push_back(n_queries);
         heavy_of_batch.push_back(hv);
     }
-    LK_HIP_CHECK(hipMemcpyAsync(q_base, base.data(), (size_t)n_queries * sizeof(int64_t),
-                                hipMemcpyHostToDevice, st));
-    LK_HIP_CHECK(hipStreamSynchronize(st));  // `base` is host memory that dies with this call
-    LK_HIP_CHECK(hipMemsetAsync(q_cursor, 0, (size_t)n_queries * sizeof(unsigned long long), st));
+    if (!acc_kernel) {  // (the hit regions are the list kernel's)
+        LK_HIP_CHECK(hipMemcpyAsync(q_base, base.data(), (size_t)n_queries * sizeof(int64_t),
+                                    hipMemcpyHostToDevice, st));
+        LK_HIP_CHECK(hipStreamSynchronize(st));  // `base` is host memory that dies with this call
+        LK_HIP_CHECK(hipMemsetAsync(q_cursor, 0, (size_t)n_queries * sizeof(unsigned long long), st));
+    }
     if (n_items > 0) {
         const int64_t cells = n_items * (nwin + 1);
         hipLaunchKernelGGL(row_windows_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0,

@@ -267,7 +267,9 @@ class ItemKNNScorer(Component):
                                    hist.values if self.config.explicit else None,
                                    bias if self.config.explicit else None, self.config.max_nbrs,
                                    self.config.min_nbrs, n, hits[order], exclude_history)
-        inv = torch.from_numpy(np.argsort(order, kind="stable")).to(d)
+        inv_h = np.empty_like(order)
+        inv_h[order] = np.arange(len(order))  # (the inverse permutation: O(n), no second sort)
+        inv = torch.from_numpy(inv_h).to(d)
         both = torch.cat([oi.view(torch.float32), osc], dim=1)[inv]
         host = D.to_host(both)
         cols = oi.shape[1]
