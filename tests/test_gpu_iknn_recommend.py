@@ -123,6 +123,62 @@ def test_recommend_matches_the_reference_pipeline(gpu, oracle, monkeypatch, walk
     # _check has established that every list is a genuine top-n of the oracle's score row)
 
 
+@pytest.mark.parametrize("kernel", ["acc", "lists"])
+@pytest.mark.parametrize("case", ["keep-own", "full-ranking", "min-nbrs-3", "wide-heaps", "one-batch"])
+def test_recommend_corners_of_the_accumulating_kernel(gpu, oracle, monkeypatch, kernel, case):
+    """Corners of ``iknn_score_acc_kernel`` and its helpers, each against the oracle and under both
+    kernels: the own items kept (``exclude_refs = False``: nothing is marked in the count cells),
+    the full ranking (``n = -1``: no class maxima, the sort path), ``min_nbrs = 3`` (cells of
+    targets with one or two hits start as NaN), ``max_nbrs`` in the thousands (the replay kernel's
+    heaps beyond 64 KiB of LDS; hardly any target is queued), and a call of ONE batch (no side
+    stream, no second panel)."""
+    from lkpy_amd import _device as D
+    from lkpy_amd import _native
+
+    if kernel == "lists":
+        monkeypatch.setenv("LK_REC_ACC", "0")
+    rng = np.random.default_rng(11)
+    n_users, n_items = 500, 8300
+    csr, sims, means = _model(oracle, rng, n_users, n_items, 30, None)
+    users = np.concatenate([[0, 1, 2], rng.choice(n_users, 40 if case == "one-batch" else 90,
+                                                   replace=False)])
+    ptr, idx, val = _queries(csr, means, users, rng)
+    max_nbrs, min_nbrs, n, exclude = 20, 1, 25, True
+    if case == "keep-own":
+        exclude = False
+    elif case == "full-ranking":
+        n = -1
+    elif case == "min-nbrs-3":
+        max_nbrs, min_nbrs = 6, 3
+    elif case == "wide-heaps":
+        max_nbrs = 2500
+    if case != "one-batch":
+        monkeypatch.setenv("LK_REC_PANEL_ROWS", "64")  # two batches: the side stream, both panels
+    counts = np.diff(sims.indptr).astype(np.int64)
+    per = np.where(idx >= 0, counts[np.maximum(idx, 0)], 0)
+    cs = np.concatenate([[0], np.cumsum(per)])
+    hits = cs[ptr[1:]] - cs[ptr[:-1]]
+    dsims = D.DeviceCSR.from_arrays(sims.indptr.astype(np.int64), sims.indices, sims.data,
+                                    sims.shape, gpu)
+    gi, gs = D.iknn_recommend(dsims, _to(ptr, gpu), _to(idx, gpu), _to(val, gpu), _to(means, gpu),
+                              max_nbrs, min_nbrs, n, hits, exclude)
+    gi, gs = gi.cpu().numpy(), gs.cpu().numpy()
+    assert _native.load().lk_iknn_recommend_last_packed() == (2 if kernel == "acc" else 1)
+    cols = n_items if n < 0 else n
+    wi, ws, rows = oracle.iknn_recommend_batch(sims, ptr, idx, val, means, max_nbrs, min_nbrs, cols,
+                                               exclude_refs=exclude)
+    assert np.array_equal(gs.view(np.uint32), ws.view(np.uint32))  # sorted score rows, bit for bit
+    for q in range(len(gi)):
+        g = gi[q][gi[q] >= 0]
+        assert len(g) == int((wi[q] >= 0).sum()) and len(np.unique(g)) == len(g)
+        assert np.array_equal(rows[q][g].view(np.uint32), gs[q][: len(g)].view(np.uint32))
+        own = idx[ptr[q]:ptr[q + 1]]
+        if exclude:
+            assert not np.isin(g, own[own >= 0]).any()
+    if case == "keep-own":  # the own items do appear (a user's own items score high)
+        assert any(np.isin(gi[q][gi[q] >= 0], idx[ptr[q]:ptr[q + 1]]).any() for q in range(len(gi)))
+
+
 def test_recommend_through_the_scorer_and_batch_runner(gpu, oracle, ml_small):
     """``ItemKNNScorer.recommend_batch`` / ``batch.recommend`` on ml-latest-small: the same lists
     as one ``pipe.run('recommender')`` per user (the scorer's own per-query path), scores bit for
