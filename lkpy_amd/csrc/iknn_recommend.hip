@@ -1606,7 +1606,8 @@ __global__ void mask_refs_kernel(const int64_t *__restrict__ ref_ptr,
     }
 }
 
-constexpr int64_t REC_PANEL_ROWS = 4096;            // queries per batch at most
+constexpr int64_t REC_PANEL_ROWS = 6144;            // queries per batch at most (cfg3, 10 000 queries: 4.43 ms at
+                                                    // 4096, 4.28 ... 4.34 at 5120 ... 8192, 4.45 in one batch)
 constexpr int64_t REC_HITS_MIN = (int64_t)1 << 28;  // hit capacity of a batch (2 GiB) unless a
                                                     // single query needs more
 constexpr int REC_MAX_WGS = 512 * (4096 / RW > 1 ? 4096 / RW : 1);  // persistent grid: what the LDS lets a CU hold
