@@ -1036,17 +1036,22 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
 // relies on), so a walk that ADDS every weight into its target's LDS cell yields the vector's
 // sequential sum bit for bit -- no list, no hit region in HBM, no fence, no sweep that waits on
 // list loads (58 % of the list kernel).  Per (query, window) task:
-//   walk 1  counts the hits per target (as before);
-//   flags   lane l owns targets l, l + 64, ...: two 64-bit masks in registers -- `heavy` (more than
-//           max_nbrs hits: the BinaryHeap case, queued for iknn_heavy_gather_kernel + the replay
-//           kernel, which build such a target's list by themselves) and `scored` (at least
-//           min_nbrs kept hits);
-//   walk 2  cell[t] += weight;  the 64 sums of a lane move to registers;
+//   walk 1  counts the hits per target (`ds_add_u32`) and ORs bit 31 into the cells of the query's
+//           own items (struck here: they are never scored and never queued);
+//   start   lane l owns targets 256 g + 4 l + j (four cells per LDS instruction).  The counts become
+//   values  the cells' START VALUES: 0 where the vector's sums are the score (min_nbrs <= hits <=
+//           max_nbrs), NaN everywhere else -- no hit, too few, own item, or the BinaryHeap case
+//           (hits > max_nbrs: queued for iknn_heavy_replay_kernel, which finds the target's hits
+//           again and replays them).  NaN + w stays NaN, which is what such a panel cell holds;
+//   walk 2  cell[t] += weight;  the 64 sums of a lane move to registers, the cells are zeroed;
 //   walk 3  (explicit feedback) cell[t] += weight * rating (product rounded first, accum.rs:128);
-//   sweep   score = ws / tw (+ item mean), NaN where nothing is scored; the window's segment of
-//           the panel row leaves straight from the registers, coalesced.
-// Three walks instead of two, but each is the cheap kind (the count walk: 23 k cycles per task
-// against the fill walk's 34 k and the sweep's 80 k).
+//   sweep   score = ws / tw (+ item mean); the window's segment of the panel row leaves straight
+//           from the registers, 16 bytes per lane and store, and the lane's largest score goes to
+//           the selection kernel as one of the row's class maxima.
+// Three walks instead of two, each of the cheap kind (walk_acc: rows found by bitmap rank, the
+// descriptors of the first chunks recorded by walk 1 and replayed by the others).  With the LDS
+// holding 16 KiB of cells per wave the kernel runs two waves per SIMD: what a task costs is its
+// instruction count and the LDS's atomic rate (DESIGN.md 4.9 has the counters).
 template <bool EXPL>
 __global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(LK_REC_ACC_WAVES, LK_REC_ACC_WAVES)))
 void iknn_score_acc_kernel(
