@@ -585,6 +585,14 @@ __device__ __forceinline__ DescCache walk_acc(
                 int t_[RDP];
                 float s_[RDP], r_[RDP];
                 bool live_[RDP];
+                // the bitmap words of all RDP batches in ONE read (lane l: word l of the group), handed
+                // out by `v_readlane`: a read per batch was a trip through the LDS queue per batch,
+                // each waited for before the table read could even be addressed
+                unsigned bmw;
+                {
+                    const unsigned wq = (p0 >> 5) + (unsigned)(lane < 2 * RDP ? lane : 0);
+                    bmw = d_bm[wq < (unsigned)(ACC_CAPB / 32 + 3) ? wq : (unsigned)(ACC_CAPB / 32 + 3)];
+                }
 #pragma unroll
                 for (int d = 0; d < RDP; ++d) {
                     const unsigned pb = p0 + 64u * d;
@@ -592,9 +600,10 @@ __device__ __forceinline__ DescCache walk_acc(
                     live_[d] = p < sub_total;
                     const unsigned pc = live_[d] ? p : sub_total - 1;
                     // (positions past the end re-read the stream's last entry: every load is
-                    // unconditional)
-                    const unsigned wi = pb < sub_total ? (pb >> 5) : 0u;
-                    const unsigned m0 = d_bm[wi], m1 = d_bm[wi + 1];
+                    // unconditional; a batch past the end sees whatever the bitmap holds there --
+                    // its rank is overridden below)
+                    const unsigned m0 = (unsigned)__builtin_amdgcn_readlane((int)bmw, 2 * d);
+                    const unsigned m1 = (unsigned)__builtin_amdgcn_readlane((int)bmw, 2 * d + 1);
                     const unsigned le0 = lane < 32 ? (0xffffffffu >> (31 - lane)) : 0xffffffffu;
                     const unsigned le1 = lane < 32 ? 0u : (0xffffffffu >> (63 - lane));
                     int rk = (int)before + __builtin_popcount(m0 & le0) +
