@@ -286,7 +286,10 @@ __device__ __forceinline__ void walk(unsigned *__restrict__ c, const int64_t *__
 // before the packed walk is ever used, and without it the walk above serves (LK_REC_PACKED=0
 // forces that).  Scores stay the reference accumulator's, bit for bit (tests/
 // test_gpu_iknn_recommend.py, the bench's recommend parity).
-constexpr int RDP = 8;  // batches (of 64 entries) in flight per wave
+#ifndef LK_REC_RDP
+#define LK_REC_RDP 8
+#endif
+constexpr int RDP = LK_REC_RDP;  // batches (of 64 entries) in flight per wave
 constexpr int LQ_CAP = 192;  // per-wave queue of "longer" targets of a window (sweep, phase B)
 
 // What a packed walk does with every entry: count it / drop it at its target's cursor / add its
