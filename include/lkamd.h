@@ -425,12 +425,19 @@ int lk_iknn_truncate_fill(const int64_t *d_sim_indptr, const int32_t *d_sim_indi
  *   descending, ties by lower item number, -1 padded; out_score likewise (NaN padded; may be
  *   NULL).  n < 0: every scored candidate, ranked (output [n_queries x n_items]).
  *   The SCORES are the reference accumulator's bit for bit (csrc/iknn_recommend.hip: one wave
- *   per (query, window of 4096 items), hits laid out per item in history order through in-order
- *   LDS cursors -- no barrier per history row as in lk_iknn_score_batch's slot kernel).
+ *   per (query, window of 4096 items); round 6: every weight is added to its item's LDS cell by
+ *   ds_add_f32 in history order -- the LDS applies same-address adds in lane order, probed on the
+ *   device --, items with more than max_nbrs contributors are found again and replayed on the
+ *   reference's heap by a kernel of their own; the list kernel of rounds 4-5 -- hits laid out per
+ *   item through in-order LDS cursors -- is the fallback.  No barrier per history row as in
+ *   lk_iknn_score_batch's slot kernel).
  *   h_query_hits (HOST, [n_queries]): per query, the summed lengths of its reference items'
  *   similarity rows (the caller has the row lengths: `item_counts`); max_query_hits >= their
- *   maximum sizes the workspace.  Queries are processed in batches of <= 4096 and <= 2^28 hits.
- *   Blocking (returns LK_E_NAN_SIM for a NaN similarity).
+ *   maximum sizes the workspace (the list kernel's hit region, the queue of heap items: at most
+ *   hits / (max_nbrs + 1) per query).  Queries are processed in batches of <= 6144
+ *   (LK_REC_PANEL_ROWS), <= 2^28 hits and a full queue at most; a call of several batches keeps
+ *   two score panels (LK_REC_PANEL_GB bounds them) and runs a batch's selection on a side stream
+ *   while the next batch is scored.  Blocking (returns LK_E_NAN_SIM for a NaN similarity).
  * ---------------------------------------------------------------------- */
 size_t lk_iknn_recommend_workspace_bytes(int64_t n_items, int64_t n_queries,
                                          int64_t max_query_hits, int32_t max_nbrs, int32_t n);
