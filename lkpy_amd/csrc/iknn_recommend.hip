@@ -404,7 +404,8 @@ __device__ __forceinline__ void walk_packed(
 #endif
 constexpr int ACC_CAPB = 8192;                  // stream positions the first-position bitmap covers
 static_assert(ACC_CAPB >= RW, "a single row piece (<= RW entries) must fit the bitmap");
-constexpr int ACC_DSC = 192 + ACC_CAPB / 32 + 4;  // words of wave-private table + bitmap
+constexpr int ACC_TAGS = 256;                     // slots of the duplicate detector (see walk_acc)
+constexpr int ACC_DSC = 192 + ACC_CAPB / 32 + 4 + ACC_TAGS;  // words of wave-private table + bitmap + tags
 constexpr int KC = 4;
 struct DescCache {  // (scalars, not arrays: an array indexed by the chunk number goes to scratch)
     int64_t a0, a1, a2, a3;
@@ -490,6 +491,19 @@ __device__ __forceinline__ DescCache walk_acc(
     uint2 *d_rel = reinterpret_cast<uint2 *>(dsc);
     float *d_rt = reinterpret_cast<float *>(dsc + 128);
     unsigned *d_bm = dsc + 192;
+    // `ds_add_f32` costs the LDS ~2.3 cycles per ACTIVE LANE (144 per full instruction; an integer
+    // atomic, a read or a write of 64 random cells: 6 ... 7 -- tools/probes/lds_atomic_rate.hip), so a
+    // float walk adds with it only where it must: where two lanes of the instruction may hit the same
+    // cell.  Every lane posts (batch number, lane) to a slot of a small tag table chosen by its target
+    // (`ds_max_u32`) and reads the slot back: the lane that finds its own stamp is the HIGHEST lane
+    // of its slot -- it adds by read / v_add / write; the others (a lower lane with the same target,
+    // or with a target that shares the slot: ~7 of 64) add atomically FIRST.  For one cell that is
+    // the lower lanes in lane order, then the highest: the instruction's lane order, as before.
+    unsigned *d_tag = dsc + 192 + ACC_CAPB / 32 + 4;
+    unsigned tag_seq = 1u;
+    if (MODE != WALK_COUNT) {
+        for (int i = lane; i < ACC_TAGS; i += 64) d_tag[i] = 0u;
+    }
     // the history row (and rating) of this lane in the chunk at r0; -1: none
     auto load_row = [&](int64_t r0, int &ri, float &rate) {
         ri = -1;
@@ -627,14 +641,27 @@ __device__ __forceinline__ DescCache walk_acc(
                     if (p0 + 64u * d >= sub_total) break;  // (wave-uniform)
                     // (lanes past the end are masked, not given a dummy cell: the LDS serves atomics
                     // at about a lane per clock, so an idle lane is time saved)
-                    if (live_[d]) {
-                        if (MODE == WALK_COUNT) {
-                            atomicAdd(&c[t_[d]], 1u);  // ds_add_u32, no return
-                        } else if (MODE == WALK_ADD_W) {
-                            nan_seen |= s_[d] != s_[d];  // accum.rs:146-151
-                            lds_fadd(&c[t_[d]], s_[d]);  // lane order
+                    if (MODE == WALK_COUNT) {
+                        if (live_[d]) atomicAdd(&c[t_[d]], 1u);  // ds_add_u32, no return
+                    } else {
+                        float val;
+                        if (MODE == WALK_ADD_W) {
+                            val = s_[d];
+                            nan_seen |= live_[d] && val != val;  // accum.rs:146-151
                         } else {
-                            lds_fadd(&c[t_[d]], s_[d] * r_[d]);  // product rounded, then added
+                            val = s_[d] * r_[d];  // product rounded, then added
+                        }
+                        const unsigned stamp = (tag_seq << 6) | (unsigned)lane;
+                        ++tag_seq;
+                        unsigned *slot = &d_tag[(unsigned)t_[d] & (unsigned)(ACC_TAGS - 1)];
+                        if (live_[d]) atomicMax(slot, stamp);  // ds_max_u32, no return
+                        wave_lds_sync();
+                        const bool win = live_[d] && *slot == stamp;
+                        if (live_[d] && !win) lds_fadd(&c[t_[d]], val);  // (the few, lane order)
+                        wave_lds_sync();  // (free; keeps the compiler from moving the read above)
+                        if (win) {
+                            const float old_ = __builtin_bit_cast(float, c[t_[d]]);
+                            c[t_[d]] = __builtin_bit_cast(unsigned, old_ + val);
                         }
                     }
                 }
