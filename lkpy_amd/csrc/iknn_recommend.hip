@@ -404,7 +404,10 @@ __device__ __forceinline__ void walk_packed(
 #endif
 constexpr int ACC_CAPB = 8192;                  // stream positions the first-position bitmap covers
 static_assert(ACC_CAPB >= RW, "a single row piece (<= RW entries) must fit the bitmap");
-constexpr int ACC_TAGS = 256;                     // slots of the duplicate detector (see walk_acc)
+#ifndef LK_REC_ACC_TAGS
+#define LK_REC_ACC_TAGS 256
+#endif
+constexpr int ACC_TAGS = LK_REC_ACC_TAGS;                     // slots of the duplicate detector (see walk_acc)
 constexpr int ACC_DSC = 192 + ACC_CAPB / 32 + 4 + ACC_TAGS;  // words of wave-private table + bitmap + tags
 constexpr int KC = 4;
 struct DescCache {  // (scalars, not arrays: an array indexed by the chunk number goes to scratch)
