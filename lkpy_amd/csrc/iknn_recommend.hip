@@ -1090,6 +1090,9 @@ __global__ __launch_bounds__(RTHREADS) void iknn_score_all_kernel(
 //   sweep   score = ws / tw (+ item mean); the window's segment of the panel row leaves straight
 //           from the registers, 16 bytes per lane and store, and the lane's largest score goes to
 //           the selection kernel as one of the row's class maxima.
+// (How a float walk adds: `ds_add_f32` occupies the LDS for 144 cycles per 64-lane instruction, so
+// only the lanes that may share a cell with another lane of the instruction use it -- the others
+// read, add and write; walk_acc has the tag table that tells them apart, in the same lane order.)
 // Three walks instead of two, each of the cheap kind (walk_acc: rows found by bitmap rank, the
 // descriptors of the first chunks recorded by walk 1 and replayed by the others).  With the LDS
 // holding 16 KiB of cells per wave the kernel runs two waves per SIMD: what a task costs is its
