@@ -613,12 +613,16 @@ __device__ __forceinline__ DescCache walk_acc(
                     const unsigned wq = (p0 >> 5) + (unsigned)(lane < 2 * RDP ? lane : 0);
                     bmw = d_bm[wq < (unsigned)(ACC_CAPB / 32 + 3) ? wq : (unsigned)(ACC_CAPB / 32 + 3)];
                 }
+                // (three passes over the group's batches -- ranks, table reads, entry loads -- so that
+                // the eight table reads leave together and are waited for once)
+                int rk_[RDP];
+                unsigned pc_[RDP];
 #pragma unroll
                 for (int d = 0; d < RDP; ++d) {
                     const unsigned pb = p0 + 64u * d;
                     const unsigned p = pb + lane;
                     live_[d] = p < sub_total;
-                    const unsigned pc = live_[d] ? p : sub_total - 1;
+                    pc_[d] = live_[d] ? p : sub_total - 1;
                     // (positions past the end re-read the stream's last entry: every load is
                     // unconditional; a batch past the end sees whatever the bitmap holds there --
                     // its rank is overridden below)
@@ -629,14 +633,21 @@ __device__ __forceinline__ DescCache walk_acc(
                     int rk = (int)before + __builtin_popcount(m0 & le0) +
                              __builtin_popcount(m1 & le1) - 1;
                     rk = rk < nrows - 1 ? rk : nrows - 1;
-                    rk = pb < sub_total ? rk : nrows - 1;
+                    rk_[d] = pb < sub_total ? rk : nrows - 1;
                     before += (unsigned)(__builtin_popcount(m0) + __builtin_popcount(m1));
-                    const uint2 rl = d_rel[rk];
+                }
+                uint2 rl_[RDP];
+#pragma unroll
+                for (int d = 0; d < RDP; ++d) {
+                    rl_[d] = d_rel[rk_[d]];
+                    if (MODE == WALK_ADD_WV) r_[d] = d_rt[rk_[d]];
+                }
+#pragma unroll
+                for (int d = 0; d < RDP; ++d) {
                     const int64_t e =
-                        (int64_t)(((unsigned long long)rl.y << 32) | rl.x) + (int64_t)pc;
+                        (int64_t)(((unsigned long long)rl_[d].y << 32) | rl_[d].x) + (int64_t)pc_[d];
                     t_[d] = s_idx[e] - w0;
                     if (MODE != WALK_COUNT) s_[d] = s_val[e];
-                    if (MODE == WALK_ADD_WV) r_[d] = d_rt[rk];
                 }
                 WPH_T(w3_);
 #pragma unroll
