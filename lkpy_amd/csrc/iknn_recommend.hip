@@ -700,6 +700,8 @@ __device__ __forceinline__ DescCache walk_acc(
         if (lane == 0) atomicCAS(status, 0, 1);  // "similarity is null" (accum.rs:146-151)
     }
     return dc;
+#undef WPH_T
+#undef WPH_ADD
 }
 
 // Does the LDS hand out the old values of same-address `ds_add_rtn_u32`s of ONE instruction in
